@@ -1,0 +1,161 @@
+/*
+ * sglang_amd.h -- C ABI of the MI355X (gfx950) RadixAttention hot-path library
+ * (libsglang_amd.so).
+ *
+ * This is the drop-in boundary under SGLang's operator surface: every entry
+ * point below is what the reference's Python op wrappers bind for this path
+ * (torch.ops.sgl_kernel.* schemas in
+ * /root/reference/python/sglang/kernels/aot/csrc/common_extension_rocm.cc:25-246
+ * and the Triton launchers they replace).  The reference-side ctypes binding a
+ * maintainer adds is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers
+ *     unless a parameter says "host";
+ *   - bf16 tensors are passed as void* / uint16 storage; strides are in ELEMENTS;
+ *   - the caller owns every buffer, including workspaces -- the library never
+ *     allocates device memory and keeps no mutable device state;
+ *   - every function enqueues on `stream` (a hipStream_t passed as void*; NULL =
+ *     the null stream), never synchronises, and is safe inside hipGraph capture;
+ *   - return 0 on success, negative on error (-1 bad argument, -2 launch
+ *     failure); sgl_amd_last_error() returns a thread-local message.  Nothing
+ *     throws across the ABI.
+ */
+#ifndef SGLANG_AMD_H_
+#define SGLANG_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGL_AMD_ABI_VERSION 1
+
+/* flags for the attention entry points */
+#define SGL_AMD_ATTN_FLAG_NO_DPP 1 /* use ds_bpermute shuffles instead of DPP row ops (debug A/B) */
+
+const char* sgl_amd_last_error(void);
+int sgl_amd_abi_version(void);
+/* "gfx950" -- the only code object in the library. */
+const char* sgl_amd_target_arch(void);
+
+/* ---- RMSNorm (reference: srt/layers/layernorm.py:423,777-826;
+ *      sgl_kernel.rmsnorm / fused_add_rmsnorm, common_extension_rocm.cc) ------ */
+/* out[r,:] = bf16((x[r,:] * rsqrt(mean(x^2)+eps)) * weight), fp32 math. */
+int sgl_amd_rmsnorm(const void* x, const void* weight, void* out, int64_t num_rows, int hidden,
+                    int64_t x_row_stride, int64_t out_row_stride, float eps, void* stream);
+/* in place: residual <- bf16(x + residual); x <- rmsnorm(fp32(x + residual)). */
+int sgl_amd_fused_add_rmsnorm(void* x, void* residual, const void* weight, int64_t num_rows,
+                              int hidden, int64_t x_row_stride, int64_t res_row_stride, float eps,
+                              void* stream);
+
+/* ---- SiLU-and-mul (reference: srt/layers/activation.py:130-150;
+ *      sgl_kernel.silu_and_mul, kernels/aot/csrc/elementwise/activation.cu) --- */
+/* in [rows, 2d] -> out [rows, d].  round_intermediate=1 reproduces the torch-native
+ * bf16 rounding of silu(x) before the multiply; 0 keeps the product in fp32. */
+int sgl_amd_silu_and_mul(const void* in, void* out, int64_t num_rows, int d, int64_t in_row_stride,
+                         int64_t out_row_stride, int round_intermediate, void* stream);
+
+/* ---- Rotary embedding (reference: srt/layers/rotary_embedding/base.py:236-276,
+ *      utils.py:36-63; sgl_kernel.rotary_embedding, common_extension_rocm.cc:236-240) */
+/* In place on q [T,Hq,D] and k [T,Hk,D].  cos_sin_cache [max_pos, rot_dim] = cos||sin,
+ * bf16 (cache_is_f32=0) or fp32 (1).  If k_cache != NULL the rotated K row and the V row
+ * of every token are also scattered to k_cache/v_cache[cache_loc[t]] (fused rope + KV
+ * store, base.py:385-417). */
+int sgl_amd_rotary_embedding(const int64_t* positions, void* q, void* k, const void* cos_sin_cache,
+                             int cache_is_f32, int64_t num_tokens, int num_q_heads, int num_k_heads,
+                             int head_dim, int rot_dim, int64_t q_token_stride,
+                             int64_t k_token_stride, int is_neox, const void* v,
+                             int64_t v_token_stride, void* k_cache, void* v_cache,
+                             const int64_t* cache_loc, int64_t cache_row_stride, void* stream);
+
+/* ---- KV store (reference: srt/mem_cache/memory_pool.py:141-193 store_cache) ---- */
+/* k_cache[loc[t], :] = k[t, :]; v_cache[loc[t], :] = v[t, :]. */
+int sgl_amd_store_kv_cache(const void* k, const void* v, void* k_cache, void* v_cache,
+                           const int64_t* loc, int64_t num_tokens, int k_row_elems,
+                           int v_row_elems, int64_t k_token_stride, int64_t v_token_stride,
+                           int64_t k_cache_row_stride, int64_t v_cache_row_stride, void* stream);
+
+/* ---- Integer metadata (bit-exact) ------------------------------------------- */
+/* kv_indices[kv_indptr[b]+i] = req_to_token[req_pool_indices[b], kv_start_idx[b]+i]
+ * (reference: kernels/ops/attention/utils.py create_flashinfer_kv_indices_triton,
+ *  call site srt/layers/attention/triton_backend.py:447-455). */
+int sgl_amd_create_kv_indices(const int32_t* req_to_token, int64_t req_to_token_stride,
+                              const void* req_pool_indices, int req_pool_indices_is_i64,
+                              const int32_t* kernel_lens, const int32_t* kv_indptr,
+                              const int32_t* kv_start_idx /* may be NULL */, void* kv_indices,
+                              int kv_indices_is_i64, int64_t batch, void* stream);
+/* reference: srt/mem_cache/allocation.py:54-103 write_cache_indices.  prefix_ptrs is a
+ * device array of `batch` device pointers to int64 prefix slot tensors (may be NULL). */
+int sgl_amd_write_req_to_token(int32_t* req_to_token, int64_t req_to_token_stride,
+                               const int64_t* req_pool_indices, const void* prefix_ptrs,
+                               const int64_t* prefix_lens, const int64_t* seq_lens,
+                               const int64_t* extend_lens, const int64_t* out_cache_loc,
+                               int64_t batch, void* stream);
+/* reference: allocation.py:139-148 get_last_loc_torch. */
+int sgl_amd_get_last_loc(const int32_t* req_to_token, int64_t req_to_token_stride,
+                         const int64_t* req_pool_indices, const int64_t* prefix_lens,
+                         int64_t* last_loc, int64_t batch, void* stream);
+/* reference: srt/model_executor/forward_batch_info.py:1790-1804 compute_position_torch. */
+int sgl_amd_compute_position(const void* extend_prefix_lens, const void* extend_seq_lens,
+                             int lens_are_i64, int64_t* positions, void* extend_start_loc,
+                             int64_t batch, void* stream);
+/* reference: forward_batch_info.py:1807 _clamp_position_native. */
+int sgl_amd_clamp_position(const void* seq_lens, int lens_are_i64, int64_t* positions,
+                           int64_t batch, void* stream);
+/* reference: srt/mem_cache/allocator/paged.py:45-102,172-260 (alloc_extend / alloc_decode). */
+int sgl_amd_alloc_extend(const int64_t* prefix_lens, const int64_t* seq_lens,
+                         const int64_t* last_loc, const int64_t* free_pages, int64_t* out_indices,
+                         int64_t batch, int64_t page_size, void* stream);
+int sgl_amd_alloc_decode(const int64_t* seq_lens, const int64_t* last_loc,
+                         const int64_t* free_pages, int64_t* out_indices, int64_t batch,
+                         int64_t page_size, void* stream);
+
+/* ---- Attention (reference: AttentionBackend.forward_extend / forward_decode,
+ *      srt/layers/attention/base_attn_backend.py:260-284; oracle
+ *      torch_native_backend.py:61-398; replaced kernels
+ *      kernels/ops/attention/{extend,decode}_attention.py) ---------------------- */
+/* Decode: one query token per request.  q/out [B,Hq,D] bf16, KV pool [slots,Hkv,D] bf16.
+ * Token t of request b lives in slot req_to_token[req_pool_indices[b], t]  (kv_indptr==NULL)
+ * or req_to_token[kv_indptr[b] + t] (flat kv_indices form).  num_splits>1 needs
+ * ws_acc fp32 [B,Hq,num_splits,D] and ws_ml fp32 [B,Hq,num_splits,2]. */
+int sgl_amd_decode_attention(const void* q, const void* k_cache, const void* v_cache, void* out,
+                             const int32_t* req_to_token, int64_t req_to_token_stride,
+                             const int64_t* req_pool_indices, const int32_t* seq_lens,
+                             const int32_t* kv_indptr, int64_t batch, int num_q_heads,
+                             int num_kv_heads, int head_dim, int64_t q_token_stride,
+                             int64_t out_token_stride, int64_t k_cache_row_stride,
+                             int64_t v_cache_row_stride, float sm_scale, int num_splits,
+                             void* ws_acc, void* ws_ml, int flags, void* stream);
+int sgl_amd_decode_attention_min_chunk(void);
+/* Extend (prefill): request b owns query tokens qo_indptr[b]..qo_indptr[b+1] of q/out
+ * [T,Hq,D]; query i attends kv positions [0, prefix_lens[b]+i] (causal) or
+ * [0, seq_lens[b]) (causal=0) read from the pool through req_to_token.  The new K/V
+ * rows must already be in the pool (sgl_amd_store_kv_cache / fused rope store). */
+int sgl_amd_extend_attention(const void* q, void* out, const void* k_cache, const void* v_cache,
+                             const int32_t* req_to_token, int64_t req_to_token_stride,
+                             const int64_t* req_pool_indices, const int32_t* seq_lens,
+                             const int32_t* prefix_lens, const int32_t* qo_indptr, int64_t batch,
+                             int max_extend_len, int num_q_heads, int num_kv_heads, int head_dim,
+                             int64_t q_token_stride, int64_t out_token_stride,
+                             int64_t k_cache_row_stride, int64_t v_cache_row_stride, float sm_scale,
+                             int causal, void* stream);
+
+/* ---- Sampling (reference: srt/layers/sampler.py:98-260,567-750;
+ *      kernels/ops/sampling/murmur_hash.py:51-121) ------------------------------- */
+/* ids[b] = argmax(logits[b,:]) (first maximum), logits fp32 (is_bf16=0) or bf16. */
+int sgl_amd_argmax(const void* logits, int logits_is_bf16, int64_t* ids, int64_t batch,
+                   int64_t vocab, int64_t row_stride, void* stream);
+/* in place: logits[b,:] = softmax(logits[b,:] / temperatures[b]) (fp32). */
+int sgl_amd_softmax_temperature(float* logits, const float* temperatures, int64_t batch,
+                                int64_t vocab, int64_t row_stride, void* stream);
+
+/* ---- test-only probes (used by tests/ to pin the MFMA lane maps) --------------- */
+int sgl_amd_probe_mfma_16x16x32(const void* a_16x32_bf16, const void* b_32x16_bf16,
+                                void* c_16x16_f32, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGLANG_AMD_H_ */

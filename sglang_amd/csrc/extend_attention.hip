@@ -1,0 +1,382 @@
+// Ragged extend (prefill) attention over the paged token->KV pool, gfx950 MFMA.
+//
+// Replaces (reference, /root/reference/python/sglang):
+//   kernels/ops/attention/extend_attention.py:304 _fwd_kernel, :753 extend_attention_fwd
+// Oracle: srt/layers/attention/torch_native_backend.py:61-174, 279-336 -- the
+// new K/V rows are written to the pool first, then every query token attends
+// causally over req_to_token[req, 0:prefix+i+1].
+//
+// Structure (one workgroup = 4 waves = 128 "rows"):
+//   * a row is a (query token, q head inside the GQA group) pair, so all
+//     H_q/H_kv heads that share a kv head share ONE staged K/V tile (GQA reuse
+//     in LDS instead of L2); each wave owns 32 rows = 2 MFMA M-tiles;
+//   * a KV tile is 64 cached tokens.  Rows of the pool are gathered through
+//     req_to_token with 16-byte loads, D/8 adjacent lanes per row, so every
+//     gathered row is one fully coalesced D*2-byte read;
+//   * K goes to LDS row-major with an XOR swizzle of the 16-byte chunks;
+//     V is transposed on the way in (8x8 bf16 blocks transposed in registers,
+//     written as 16-byte chunks of V^T) with the token order inside a chunk
+//     chosen so the PV operand is a single ds_read_b128;
+//   * both contractions run transposed on v_mfma_f32_16x16x32_bf16:
+//         S^T = K . Q^T      O^T = V^T . P^T
+//     which leaves every lane owning exactly one row per M-tile: running max,
+//     running sum and the rescale factor never cross lanes, and the exp'd
+//     S^T registers ARE the P^T operand of the second MFMA (no LDS round trip);
+//   * fp32 accumulation, exp2 with the softmax scale folded in, bf16 output.
+#include "common.hpp"
+#include "../../include/sglang_amd.h"
+
+using namespace sgl_amd;
+
+namespace {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int kThreads = 256;
+constexpr int kRows = 128;      // rows per workgroup
+constexpr int kKvTile = 64;     // cached tokens per tile
+constexpr float kNegBig = -1.0e30f;
+
+__device__ __forceinline__ bf16x8_t as_frag(const U4& v) { return __builtin_bit_cast(bf16x8_t, v); }
+
+struct ExtendParams {
+  const uint16_t* q;            // [T, Hq, D]
+  uint16_t* out;                // [T, Hq, D]
+  const uint16_t* k_cache;      // [slots, Hkv, D]
+  const uint16_t* v_cache;
+  const int32_t* req_to_token;  // [reqs, max_ctx]
+  const int64_t* req_pool_indices;  // [B]
+  const int32_t* seq_lens;      // [B] prefix + extend
+  const int32_t* prefix_lens;   // [B]
+  const int32_t* qo_indptr;     // [B+1] start of each request's query tokens
+  int64_t q_stride, out_stride, kc_stride, vc_stride, r2t_stride;
+  int num_kv_heads;
+  int group;                    // q heads per kv head
+  int tokens_per_tile;          // kRows / group
+  int causal;
+  float scale_log2;
+};
+
+template <int D>
+struct Smem {
+  U4 k[kKvTile * D / 8];        // [token][chunk ^ swz]
+  U4 vt[D * kKvTile / 8];       // [d][token-chunk ^ swz]
+};
+
+template <int D>
+__global__ __launch_bounds__(kThreads) void extend_attention_kernel(ExtendParams p) {
+  constexpr int CPR = D / 8;            // 16-byte chunks per KV row
+  constexpr int KC = D / 32;            // MFMA k-steps over the head dim
+  constexpr int ND = D / 16;            // 16-wide output tiles over the head dim
+  constexpr int NK_LOADS = kKvTile * CPR / 128;   // K 16-byte loads per K-thread
+  constexpr int V_THREADS = 8 * CPR;    // threads that each transpose one 8x8 block
+
+  __shared__ Smem<D> sm;
+
+  const int tile = blockIdx.x;
+  const int kvh = blockIdx.y;
+  const int b = blockIdx.z;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int l15 = lane & 15;
+  const int g = lane >> 4;
+
+  const int q_begin = p.qo_indptr[b];
+  const int ext_len = p.qo_indptr[b + 1] - q_begin;
+  const int q0 = tile * p.tokens_per_tile;
+  if (q0 >= ext_len) return;
+  int q1 = q0 + p.tokens_per_tile;
+  if (q1 > ext_len) q1 = ext_len;
+  const int kv_len = p.seq_lens[b];
+  const int prefix = p.prefix_lens[b];
+  const int kv_end = p.causal ? (prefix + q1 < kv_len ? prefix + q1 : kv_len) : kv_len;
+  const int n_tiles = (kv_end + kKvTile - 1) / kKvTile;
+  const int32_t* idx_base = p.req_to_token + p.req_pool_indices[b] * p.r2t_stride;
+
+  // ---- this lane's two rows (one per M-tile) ------------------------------
+  int row_tok[2], row_limit[2];
+  bool row_ok[2];
+  int64_t row_off[2];   // element offset of (token, head) inside q / out
+  U4 qfrag[2][KC];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int r = wid * 32 + mt * 16 + l15;
+    const int t = r / p.group;
+    const int hg = r - t * p.group;
+    row_tok[mt] = q0 + t;
+    row_ok[mt] = (t < p.tokens_per_tile) && (q0 + t < q1);
+    row_limit[mt] = row_ok[mt] ? (p.causal ? prefix + q0 + t + 1 : kv_len) : 0;
+    if (row_limit[mt] > kv_len) row_limit[mt] = kv_len;
+    row_off[mt] = static_cast<int64_t>(kvh * p.group + hg) * D;
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      if (row_ok[mt]) {
+        qfrag[mt][kc] = ld16(p.q + static_cast<int64_t>(q_begin + row_tok[mt]) * p.q_stride +
+                             row_off[mt] + kc * 32 + g * 8);
+      } else {
+        qfrag[mt][kc] = U4{0u, 0u, 0u, 0u};
+      }
+    }
+  }
+
+  f32x4_t ot[2][ND];
+  float m_run[2], l_run[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    m_run[mt] = kNegBig;
+    l_run[mt] = 0.f;
+#pragma unroll
+    for (int n = 0; n < ND; ++n) ot[mt][n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+
+  // ---- staging roles -------------------------------------------------------
+  // waves 0-1: V (8x8 transposing blocks), waves 2-3: K (row-major).
+  const bool is_v = tid < 128;
+  const int st = is_v ? tid : tid - 128;
+  const int st_c = st % CPR;                 // 16-byte column of the KV row
+  const int st_r = st / CPR;
+  const bool v_active = is_v && st < V_THREADS;
+  const int v_blk32 = st_r >> 2, v_g = st_r & 3;
+  constexpr int kStage = (NK_LOADS > 8) ? NK_LOADS : 8;
+  U4 stage[kStage];
+
+  auto prefetch = [&](int t) {
+    const int kv0 = t * kKvTile;
+    const int last = kv_end - 1;
+    if (is_v) {
+      if (v_active) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          // token order inside the chunk: i = 4a + r  <->  token 32*blk + 16a + 4g + r
+          int tok = kv0 + 32 * v_blk32 + 16 * (i >> 2) + 4 * v_g + (i & 3);
+          if (tok > last) tok = last;
+          const int64_t slot = idx_base[tok];
+          stage[i] = ld16(p.v_cache + slot * p.vc_stride + static_cast<int64_t>(kvh) * D + st_c * 8);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NK_LOADS; ++i) {
+        int tok = kv0 + st_r + (128 / CPR) * i;
+        if (tok > last) tok = last;
+        const int64_t slot = idx_base[tok];
+        stage[i] = ld16(p.k_cache + slot * p.kc_stride + static_cast<int64_t>(kvh) * D + st_c * 8);
+      }
+    }
+  };
+
+  auto commit = [&]() {
+    if (is_v) {
+      if (v_active) {
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(stage);  // stage[i] dword q -> w[4i+q]
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int d = st_c * 8 + j;
+          U4 o;
+          uint32_t* ow = reinterpret_cast<uint32_t*>(&o);
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd) {
+            const uint32_t a = w[4 * (2 * qd) + (j >> 1)];
+            const uint32_t c = w[4 * (2 * qd + 1) + (j >> 1)];
+            ow[qd] = (j & 1) ? ((a >> 16) | (c & 0xffff0000u)) : ((a & 0xffffu) | (c << 16));
+          }
+          const int chunk = (4 * v_blk32 + v_g) ^ ((d ^ (d >> 3)) & 7);
+          sm.vt[d * 8 + chunk] = o;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NK_LOADS; ++i) {
+        const int row = st_r + (128 / CPR) * i;
+        sm.k[row * CPR + (st_c ^ (row & (CPR - 1)))] = stage[i];
+      }
+    }
+  };
+
+  if (n_tiles > 0) prefetch(0);
+
+  for (int t = 0; t < n_tiles; ++t) {
+    __syncthreads();   // every wave is done reading the previous tile
+    commit();
+    __syncthreads();
+    if (t + 1 < n_tiles) prefetch(t + 1);
+
+    const int kv0 = t * kKvTile;
+
+    // ---- S^T = K . Q^T ---------------------------------------------------
+    f32x4_t st_acc[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) st_acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int row = nt * 16 + l15;
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) {
+        const U4 kf = sm.k[row * CPR + ((kc * 4 + g) ^ (row & (CPR - 1)))];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+          st_acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+              as_frag(kf), as_frag(qfrag[mt][kc]), st_acc[mt][nt], 0, 0, 0);
+      }
+    }
+
+    // ---- online softmax; lane owns row (l15 + 16 mt), tokens 16nt + 4g + r --
+    U4 pfrag[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      float sv[4][4];
+      float mx = kNegBig;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kvpos = kv0 + nt * 16 + g * 4 + r;
+          const float s = (kvpos < row_limit[mt]) ? st_acc[mt][nt][r] * p.scale_log2 : kNegBig;
+          sv[nt][r] = s;
+          mx = fmaxf(mx, s);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run[mt], mx);
+      const float alpha = exp2f(m_run[mt] - m_new);
+      m_run[mt] = m_new;
+      float psum = 0.f;
+      float pv[4][4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = (sv[nt][r] > 0.5f * kNegBig) ? exp2f(sv[nt][r] - m_new) : 0.f;
+          pv[nt][r] = e;
+          psum += e;
+        }
+      l_run[mt] = l_run[mt] * alpha + psum;
+#pragma unroll
+      for (int n = 0; n < ND; ++n) ot[mt][n] *= alpha;
+      // P^T operand for k-step kk: [P(nt=2kk, r=0..3), P(nt=2kk+1, r=0..3)]
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        pfrag[mt][kk].x = pack_bf2(pv[2 * kk][0], pv[2 * kk][1]);
+        pfrag[mt][kk].y = pack_bf2(pv[2 * kk][2], pv[2 * kk][3]);
+        pfrag[mt][kk].z = pack_bf2(pv[2 * kk + 1][0], pv[2 * kk + 1][1]);
+        pfrag[mt][kk].w = pack_bf2(pv[2 * kk + 1][2], pv[2 * kk + 1][3]);
+      }
+    }
+
+    // ---- O^T += V^T . P^T ------------------------------------------------
+#pragma unroll
+    for (int n = 0; n < ND; ++n) {
+      const int d = n * 16 + l15;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const U4 vf = sm.vt[d * 8 + ((kk * 4 + g) ^ ((d ^ (d >> 3)) & 7))];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+          ot[mt][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(vf), as_frag(pfrag[mt][kk]),
+                                                               ot[mt][n], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: lane holds O^T[d = 16n + 4g + r][row] ----------------------
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    float l = l_run[mt];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (!row_ok[mt]) continue;
+    const float inv = (l > 0.f) ? 1.0f / l : 0.f;
+    uint16_t* op = p.out + static_cast<int64_t>(q_begin + row_tok[mt]) * p.out_stride + row_off[mt];
+#pragma unroll
+    for (int n = 0; n < ND; ++n) {
+      uint2 w;
+      w.x = pack_bf2(ot[mt][n][0] * inv, ot[mt][n][1] * inv);
+      w.y = pack_bf2(ot[mt][n][2] * inv, ot[mt][n][3] * inv);
+      *reinterpret_cast<uint2*>(op + n * 16 + g * 4) = w;
+    }
+  }
+}
+
+// Test-only probe: C[16x16] = A[16x32] . B[32x16] with the operand/result lane
+// maps this file assumes (A row = lane&15, k = 8*(lane>>4)+j; C row = 4*(lane>>4)+r,
+// col = lane&15).  tests/ checks it against a plain matmul.
+__global__ void mfma_probe_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ bm,
+                                  float* __restrict__ c) {
+  const int lane = threadIdx.x;
+  const int l15 = lane & 15, g = lane >> 4;
+  U4 af, bf;
+  uint16_t* ap = reinterpret_cast<uint16_t*>(&af);
+  uint16_t* bp = reinterpret_cast<uint16_t*>(&bf);
+  for (int j = 0; j < 8; ++j) {
+    ap[j] = a[l15 * 32 + g * 8 + j];          // A[i = l15][k = 8g + j]
+    bp[j] = bm[(g * 8 + j) * 16 + l15];        // B[k = 8g + j][n = l15]
+  }
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(af), as_frag(bf), acc, 0, 0, 0);
+  for (int r = 0; r < 4; ++r) c[(g * 4 + r) * 16 + l15] = acc[r];
+}
+
+}  // namespace
+
+extern "C" {
+
+int sgl_amd_extend_attention(const void* q, void* out, const void* k_cache, const void* v_cache,
+                             const int32_t* req_to_token, int64_t req_to_token_stride,
+                             const int64_t* req_pool_indices, const int32_t* seq_lens,
+                             const int32_t* prefix_lens, const int32_t* qo_indptr, int64_t batch,
+                             int max_extend_len, int num_q_heads, int num_kv_heads, int head_dim,
+                             int64_t q_token_stride, int64_t out_token_stride,
+                             int64_t k_cache_row_stride, int64_t v_cache_row_stride, float sm_scale,
+                             int causal, void* stream) {
+  SGL_CHECK_ARG(head_dim == 64 || head_dim == 128, "extend_attention: head_dim=%d not supported (64/128)", head_dim);
+  SGL_CHECK_ARG(num_kv_heads > 0 && num_q_heads % num_kv_heads == 0,
+                "extend_attention: num_q_heads=%d not a multiple of num_kv_heads=%d", num_q_heads, num_kv_heads);
+  const int group = num_q_heads / num_kv_heads;
+  SGL_CHECK_ARG(group <= kRows, "extend_attention: GQA group %d too large", group);
+  SGL_CHECK_ARG(q_token_stride % 8 == 0 && out_token_stride % 4 == 0 && k_cache_row_stride % 8 == 0 && v_cache_row_stride % 8 == 0,
+                "extend_attention: strides must keep 16-byte row alignment");
+  SGL_CHECK_ARG(batch <= 65535 && num_kv_heads <= 65535, "extend_attention: grid too large");
+  if (batch == 0 || max_extend_len <= 0) return 0;
+  ExtendParams p;
+  p.q = static_cast<const uint16_t*>(q);
+  p.out = static_cast<uint16_t*>(out);
+  p.k_cache = static_cast<const uint16_t*>(k_cache);
+  p.v_cache = static_cast<const uint16_t*>(v_cache);
+  p.req_to_token = req_to_token;
+  p.req_pool_indices = req_pool_indices;
+  p.seq_lens = seq_lens;
+  p.prefix_lens = prefix_lens;
+  p.qo_indptr = qo_indptr;
+  p.q_stride = q_token_stride;
+  p.out_stride = out_token_stride;
+  p.kc_stride = k_cache_row_stride;
+  p.vc_stride = v_cache_row_stride;
+  p.r2t_stride = req_to_token_stride;
+  p.num_kv_heads = num_kv_heads;
+  p.group = group;
+  p.tokens_per_tile = kRows / group;
+  p.causal = causal;
+  p.scale_log2 = sm_scale * 1.4426950408889634f;
+  const int tiles = (max_extend_len + p.tokens_per_tile - 1) / p.tokens_per_tile;
+  dim3 grid(tiles, num_kv_heads, batch);
+  if (head_dim == 128)
+    hipLaunchKernelGGL(extend_attention_kernel<128>, grid, dim3(kThreads), 0, as_stream(stream), p);
+  else
+    hipLaunchKernelGGL(extend_attention_kernel<64>, grid, dim3(kThreads), 0, as_stream(stream), p);
+  SGL_CHECK_LAUNCH("extend_attention");
+  return 0;
+}
+
+int sgl_amd_probe_mfma_16x16x32(const void* a, const void* b, void* c, void* stream) {
+  hipLaunchKernelGGL(mfma_probe_kernel, dim3(1), dim3(64), 0, as_stream(stream),
+                     static_cast<const uint16_t*>(a), static_cast<const uint16_t*>(b),
+                     static_cast<float*>(c));
+  SGL_CHECK_LAUNCH("probe_mfma_16x16x32");
+  return 0;
+}
+
+}  // extern "C"
