@@ -1,0 +1,212 @@
+"""Floating-point operator oracles (torch CPU), restating the reference's
+`forward_native` / torch-native implementations.  TEST INFRASTRUCTURE ONLY.
+
+All paths are relative to /root/reference/python/sglang.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+
+# ---------------------------------------------------------------- RMSNorm
+def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
+    """kernels/ops/layernorm/__init__.py:75-92 (RMSNormOp.forward_native)."""
+    xf = x.to(torch.float32)
+    variance = xf.pow(2).mean(dim=-1, keepdim=True)
+    xf = xf * torch.rsqrt(variance + eps)
+    return (xf * weight).to(x.dtype)
+
+
+def fused_add_rmsnorm(x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float
+                      ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """srt/layers/layernorm.py:777-826 (RMSNorm.forward_native with residual):
+    x = x.float() + residual.float(); residual = x.to(dtype); norm on fp32 x;
+    (x * weight).to(dtype)."""
+    orig = x.dtype
+    xf = x.to(torch.float32) + residual.to(torch.float32)
+    new_residual = xf.to(orig)
+    variance = xf.pow(2).mean(dim=-1, keepdim=True)
+    xf = xf * torch.rsqrt(variance + eps)
+    return (xf * weight).to(orig), new_residual
+
+
+# ---------------------------------------------------------------- activation
+def silu_and_mul(x: torch.Tensor) -> torch.Tensor:
+    """srt/layers/activation.py:141-143 (SiluAndMul.forward_native)."""
+    d = x.shape[-1] // 2
+    return F.silu(x[..., :d]) * x[..., d:]
+
+
+# ---------------------------------------------------------------- RoPE
+def rope_inv_freq(rotary_dim: int, base: float) -> torch.Tensor:
+    """srt/layers/rotary_embedding/base.py:153-171 (_compute_inv_freq)."""
+    return 1.0 / (base ** (torch.arange(0, rotary_dim, 2, dtype=torch.float) / rotary_dim))
+
+
+def llama3_inv_freq(rotary_dim: int, base: float, scaling_factor: float, low_freq_factor: float,
+                    high_freq_factor: float, orig_max_position: int) -> torch.Tensor:
+    """srt/layers/rotary_embedding/rope_variant.py:560-580 (Llama3RotaryEmbedding)."""
+    inv_freqs = rope_inv_freq(rotary_dim, base)
+    low_freq_wavelen = orig_max_position / low_freq_factor
+    high_freq_wavelen = orig_max_position / high_freq_factor
+    wave_len = 2 * math.pi / inv_freqs
+    if low_freq_factor != high_freq_factor:
+        smooth = (orig_max_position / wave_len - low_freq_factor) / (high_freq_factor - low_freq_factor)
+    else:
+        smooth = 0
+    return torch.where(
+        wave_len < high_freq_wavelen,
+        inv_freqs,
+        torch.where(wave_len > low_freq_wavelen, inv_freqs / scaling_factor,
+                    (1 - smooth) * inv_freqs / scaling_factor + smooth * inv_freqs),
+    )
+
+
+def cos_sin_cache(inv_freq: torch.Tensor, max_position: int) -> torch.Tensor:
+    """base.py:173-182 (_compute_cos_sin_cache): fp32 [max_pos, rot] = cos || sin."""
+    t = torch.arange(max_position, dtype=torch.float)
+    freqs = torch.einsum("i,j -> ij", t, inv_freq)
+    return torch.cat((freqs.cos(), freqs.sin()), dim=-1)
+
+
+def _apply_rotary_emb(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, is_neox_style: bool) -> torch.Tensor:
+    """srt/layers/rotary_embedding/utils.py:36-63: cos/sin are cast to x.dtype first."""
+    cos = cos.unsqueeze(-2).to(x.dtype)
+    sin = sin.unsqueeze(-2).to(x.dtype)
+    if is_neox_style:
+        x1, x2 = torch.chunk(x, 2, dim=-1)
+    else:
+        x1 = x[..., ::2]
+        x2 = x[..., 1::2]
+    o1 = x1 * cos - x2 * sin
+    o2 = x2 * cos + x1 * sin
+    if is_neox_style:
+        return torch.cat((o1, o2), dim=-1)
+    return torch.stack((o1, o2), dim=-1).flatten(-2)
+
+
+def rotary_embedding(positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor, head_size: int,
+                     cache: torch.Tensor, is_neox_style: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+    """base.py:236-276 (RotaryEmbedding.forward_native); rotary_dim = cache.shape[-1]."""
+    rotary_dim = cache.shape[-1]
+    positions = positions.flatten()
+    num_tokens = positions.shape[0]
+    cos_sin = cache.index_select(0, positions)
+    cos, sin = cos_sin.chunk(2, dim=-1)
+
+    def one(t: torch.Tensor) -> torch.Tensor:
+        shape = t.shape
+        t = t.reshape(num_tokens, -1, head_size)
+        rot = _apply_rotary_emb(t[..., :rotary_dim], cos, sin, is_neox_style)
+        return torch.cat((rot, t[..., rotary_dim:]), dim=-1).reshape(shape)
+
+    return one(query), one(key)
+
+
+# ---------------------------------------------------------------- KV store
+def store_kv(k: torch.Tensor, v: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, loc: torch.Tensor) -> None:
+    """srt/mem_cache/memory_pool.py:189-193 (naive path: k_cache[indices] = k)."""
+    k_cache[loc] = k.view(k.shape[0], *k_cache.shape[1:])
+    v_cache[loc] = v.view(v.shape[0], *v_cache.shape[1:])
+
+
+# ---------------------------------------------------------------- attention
+def extend_attention(query: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, req_to_token: torch.Tensor,
+                     req_pool_indices: torch.Tensor, seq_lens: torch.Tensor, extend_prefix_lens: torch.Tensor,
+                     extend_seq_lens: torch.Tensor, scaling: float, causal: bool = True,
+                     compute_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """srt/layers/attention/torch_native_backend.py:61-174 (_run_sdpa_forward_extend).
+
+    query [T, Hq, D]; caches [slots, Hkv, D].  The reference pads Q to the kv
+    length, runs SDPA with is_causal and keeps rows [prefix:].  compute_dtype
+    = torch.float32 evaluates the same graph in fp32 on the bf16-rounded
+    inputs (the fp32-accumulation reference of SURVEY section 8(c))."""
+    out = torch.empty_like(query)
+    q = query.movedim(0, query.dim() - 2)  # [H, T, D]
+    enable_gqa = query.shape[1] != k_cache.shape[1]
+    start_q = 0
+    for i in range(seq_lens.shape[0]):
+        ext = int(extend_seq_lens[i])
+        pre = int(extend_prefix_lens[i])
+        kv = int(seq_lens[i])
+        end_q = start_q + ext
+        per_req_query = q[:, start_q:end_q, :]
+        red = torch.empty((per_req_query.shape[0], kv, per_req_query.shape[2]), dtype=per_req_query.dtype)
+        red.zero_()  # the reference leaves the padded rows uninitialised; they are discarded
+        red[:, pre:, :] = per_req_query
+        toks = req_to_token[int(req_pool_indices[i]), :kv].long()
+        key = k_cache[toks].movedim(0, query.dim() - 2)
+        val = v_cache[toks].movedim(0, query.dim() - 2)
+        if compute_dtype is not None:
+            red, key, val = red.to(compute_dtype), key.to(compute_dtype), val.to(compute_dtype)
+        o = F.scaled_dot_product_attention(red.unsqueeze(0), key.unsqueeze(0), val.unsqueeze(0),
+                                           enable_gqa=enable_gqa, scale=scaling, is_causal=causal)
+        o = o.squeeze(0).movedim(query.dim() - 2, 0)
+        out[start_q:end_q] = o[pre:].to(out.dtype)
+        start_q = end_q
+    return out
+
+
+def decode_attention(query: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, req_to_token: torch.Tensor,
+                     req_pool_indices: torch.Tensor, seq_lens: torch.Tensor, scaling: float,
+                     compute_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """torch_native_backend.py:176-277 (_run_sdpa_forward_decode): one query per request."""
+    out = torch.empty_like(query)
+    q = query.movedim(0, query.dim() - 2)
+    enable_gqa = query.shape[1] != k_cache.shape[1]
+    for i in range(seq_lens.shape[0]):
+        kv = int(seq_lens[i])
+        per_req_query = q[:, i:i + 1, :]
+        toks = req_to_token[int(req_pool_indices[i]), :kv].long()
+        key = k_cache[toks].movedim(0, query.dim() - 2)
+        val = v_cache[toks].movedim(0, query.dim() - 2)
+        if compute_dtype is not None:
+            per_req_query, key, val = per_req_query.to(compute_dtype), key.to(compute_dtype), val.to(compute_dtype)
+        o = F.scaled_dot_product_attention(per_req_query.unsqueeze(0), key.unsqueeze(0), val.unsqueeze(0),
+                                           enable_gqa=enable_gqa, scale=scaling, is_causal=False)
+        out[i:i + 1] = o.squeeze(0).movedim(query.dim() - 2, 0).to(out.dtype)
+    return out
+
+
+# ---------------------------------------------------------------- MoE
+_RENORMALIZE_SUM_EPSILON = 1e-20  # srt/layers/moe/topk.py (module constant)
+
+
+def fused_topk(gating_output: torch.Tensor, topk: int, renormalize: bool) -> Tuple[torch.Tensor, torch.Tensor]:
+    """srt/layers/moe/topk.py:690-736 (fused_topk_torch_native, softmax scoring, no bias)."""
+    w = gating_output.float().softmax(dim=-1)
+    w, ids = torch.topk(w, topk, dim=-1)
+    if renormalize:
+        w = w / (w.sum(dim=-1, keepdim=True, dtype=torch.float32) + _RENORMALIZE_SUM_EPSILON)
+    return w, ids.to(torch.int32)
+
+
+def moe_forward(x: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, topk_weights: torch.Tensor,
+                topk_ids: torch.Tensor) -> torch.Tensor:
+    """srt/layers/moe/fused_moe_native.py:61-164 (moe_forward_native, silu, no bias):
+    per-expert F.linear -> SiluAndMul -> F.linear, combine in topk_weights.dtype."""
+    E = w13.shape[0]
+    cnts = topk_ids.new_zeros((topk_ids.shape[0], E))
+    cnts.scatter_(1, topk_ids.to(torch.int64), 1)
+    tokens_per_expert = cnts.sum(dim=0)
+    idxs = topk_ids.view(-1).argsort()
+    sorted_tokens = x[idxs // topk_ids.shape[1]]
+    outputs = []
+    start = 0
+    for i, n in enumerate(tokens_per_expert.tolist()):
+        if n == 0:
+            continue
+        t = sorted_tokens[start:start + n]
+        gate_up = F.linear(t, w13[i])
+        act = silu_and_mul(gate_up)
+        outputs.append(F.linear(act, w2[i]))
+        start += n
+    outs = torch.cat(outputs, dim=0) if outputs else sorted_tokens.new_empty(0)
+    new_x = torch.empty_like(outs)
+    new_x[idxs] = outs
+    return (new_x.view(*topk_ids.shape, -1).type(topk_weights.dtype)
+            .mul_(topk_weights.unsqueeze(dim=-1)).sum(dim=1).type(new_x.dtype))

@@ -1,0 +1,284 @@
+"""Thin torch-tensor wrappers over the C ABI (pointer + stride plumbing only).
+
+Every function enqueues on torch's current HIP stream, so the kernels compose
+with torch ops and are captured by torch.cuda.graph (hipGraph) like any other
+launch.  No function here computes anything on the host or falls back to torch.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import native
+
+_BF16 = torch.bfloat16
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _need(cond: bool, msg: str) -> None:
+    if not cond:
+        raise ValueError(msg)
+
+
+def _dev(*ts: torch.Tensor) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "sglang_amd kernels need tensors on a HIP device (got a CPU tensor); "
+                "there is no CPU fallback"
+            )
+
+
+# --------------------------------------------------------------------------- norm
+def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """sgl_kernel.rmsnorm(input, weight, eps, out) equivalent."""
+    _dev(x, weight)
+    _need(x.dtype == _BF16 and weight.dtype == _BF16, "rmsnorm: bf16 only")
+    hidden = x.shape[-1]
+    x2 = x.reshape(-1, hidden)
+    _need(x2.stride(-1) == 1, "rmsnorm: last dim must be contiguous")
+    if out is None:
+        out = torch.empty_like(x2)
+    o2 = out.reshape(-1, hidden)
+    native.call("sgl_amd_rmsnorm", x2.data_ptr(), weight.data_ptr(), o2.data_ptr(), x2.shape[0], hidden,
+                x2.stride(0), o2.stride(0), float(eps), _stream())
+    return out.view(x.shape) if out.shape != x.shape else out
+
+
+def fused_add_rmsnorm(x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float) -> None:
+    """sgl_kernel.fused_add_rmsnorm(input, residual, weight, eps): both updated in place."""
+    _dev(x, residual, weight)
+    _need(x.dtype == _BF16 and residual.dtype == _BF16 and weight.dtype == _BF16, "fused_add_rmsnorm: bf16 only")
+    hidden = x.shape[-1]
+    x2 = x.view(-1, hidden)
+    r2 = residual.view(-1, hidden)
+    _need(x2.stride(-1) == 1 and r2.stride(-1) == 1, "fused_add_rmsnorm: last dim must be contiguous")
+    native.call("sgl_amd_fused_add_rmsnorm", x2.data_ptr(), r2.data_ptr(), weight.data_ptr(), x2.shape[0], hidden,
+                x2.stride(0), r2.stride(0), float(eps), _stream())
+
+
+# --------------------------------------------------------------------- activation
+def silu_and_mul(x: torch.Tensor, out: Optional[torch.Tensor] = None, round_intermediate: bool = True) -> torch.Tensor:
+    _dev(x)
+    _need(x.dtype == _BF16, "silu_and_mul: bf16 only")
+    d = x.shape[-1] // 2
+    x2 = x.reshape(-1, 2 * d)
+    _need(x2.stride(-1) == 1, "silu_and_mul: last dim must be contiguous")
+    if out is None:
+        out = torch.empty(x.shape[:-1] + (d,), dtype=x.dtype, device=x.device)
+    o2 = out.view(-1, d)
+    native.call("sgl_amd_silu_and_mul", x2.data_ptr(), o2.data_ptr(), x2.shape[0], d, x2.stride(0), o2.stride(0),
+                1 if round_intermediate else 0, _stream())
+    return out
+
+
+# --------------------------------------------------------------------------- rope
+def rotary_embedding(positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor, head_size: int,
+                     cos_sin_cache: torch.Tensor, is_neox: bool = True,
+                     value: Optional[torch.Tensor] = None, k_cache: Optional[torch.Tensor] = None,
+                     v_cache: Optional[torch.Tensor] = None, cache_loc: Optional[torch.Tensor] = None) -> None:
+    """In-place rope on query/key ([T, H*D] or [T, H, D]); optional fused KV store."""
+    _dev(positions, query, key, cos_sin_cache)
+    _need(query.dtype == _BF16 and key.dtype == _BF16, "rotary_embedding: bf16 only")
+    _need(positions.dtype == torch.int64, "rotary_embedding: positions must be int64")
+    _need(cos_sin_cache.dtype in (_BF16, torch.float32) and cos_sin_cache.is_contiguous(), "rotary_embedding: cache dtype")
+    T = positions.numel()
+    q2 = query.view(T, -1)
+    k2 = key.view(T, -1)
+    _need(q2.stride(-1) == 1 and k2.stride(-1) == 1, "rotary_embedding: last dim must be contiguous")
+    hq = q2.shape[1] // head_size
+    hk = k2.shape[1] // head_size
+    rot = cos_sin_cache.shape[-1]
+    fused = k_cache is not None
+    if fused:
+        _need(value is not None and v_cache is not None and cache_loc is not None, "rotary_embedding: fused store args")
+        _need(cache_loc.dtype == torch.int64, "rotary_embedding: cache_loc must be int64")
+        v2 = value.view(T, -1)
+        kc = k_cache.view(k_cache.shape[0], -1)
+        vc = v_cache.view(v_cache.shape[0], -1)
+        _need(kc.stride(0) == vc.stride(0), "rotary_embedding: k/v cache row strides differ")
+    native.call("sgl_amd_rotary_embedding", positions.data_ptr(), q2.data_ptr(), k2.data_ptr(), cos_sin_cache.data_ptr(),
+                1 if cos_sin_cache.dtype == torch.float32 else 0, T, hq, hk, head_size, rot, q2.stride(0), k2.stride(0),
+                1 if is_neox else 0,
+                v2.data_ptr() if fused else None, v2.stride(0) if fused else 0,
+                kc.data_ptr() if fused else None, vc.data_ptr() if fused else None,
+                cache_loc.data_ptr() if fused else None, kc.stride(0) if fused else 0, _stream())
+
+
+# ----------------------------------------------------------------------- kv store
+def store_kv_cache(k: torch.Tensor, v: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, loc: torch.Tensor) -> None:
+    _dev(k, v, k_cache, v_cache, loc)
+    _need(loc.dtype == torch.int64, "store_kv_cache: loc must be int64")
+    T = loc.numel()
+    k2, v2 = k.view(T, -1), v.view(T, -1)
+    kc, vc = k_cache.view(k_cache.shape[0], -1), v_cache.view(v_cache.shape[0], -1)
+    _need(k2.dtype == kc.dtype == _BF16 and v2.dtype == vc.dtype == _BF16, "store_kv_cache: bf16 only")
+    native.call("sgl_amd_store_kv_cache", k2.data_ptr(), v2.data_ptr(), kc.data_ptr(), vc.data_ptr(), loc.data_ptr(), T,
+                k2.shape[1], v2.shape[1], k2.stride(0), v2.stride(0), kc.stride(0), vc.stride(0), _stream())
+
+
+# ----------------------------------------------------------------------- metadata
+def create_kv_indices(req_to_token: torch.Tensor, req_pool_indices: torch.Tensor, kernel_lens: torch.Tensor,
+                      kv_indptr: torch.Tensor, kv_start_idx: Optional[torch.Tensor], kv_indices: torch.Tensor) -> None:
+    _dev(req_to_token, req_pool_indices, kernel_lens, kv_indptr, kv_indices)
+    _need(req_to_token.dtype == torch.int32 and kernel_lens.dtype == torch.int32 and kv_indptr.dtype == torch.int32,
+          "create_kv_indices: int32 req_to_token / lens / indptr")
+    _need(req_pool_indices.dtype in (torch.int32, torch.int64) and kv_indices.dtype in (torch.int32, torch.int64),
+          "create_kv_indices: index dtypes")
+    native.call("sgl_amd_create_kv_indices", req_to_token.data_ptr(), req_to_token.stride(0), req_pool_indices.data_ptr(),
+                1 if req_pool_indices.dtype == torch.int64 else 0, kernel_lens.data_ptr(), kv_indptr.data_ptr(),
+                _ptr(kv_start_idx), kv_indices.data_ptr(), 1 if kv_indices.dtype == torch.int64 else 0,
+                req_pool_indices.numel(), _stream())
+
+
+def write_req_to_token(req_to_token: torch.Tensor, req_pool_indices: torch.Tensor, prefix_ptrs: Optional[torch.Tensor],
+                       prefix_lens: torch.Tensor, seq_lens: torch.Tensor, extend_lens: torch.Tensor,
+                       out_cache_loc: torch.Tensor) -> None:
+    _dev(req_to_token, req_pool_indices, prefix_lens, seq_lens, extend_lens, out_cache_loc)
+    for t in (req_pool_indices, prefix_lens, seq_lens, extend_lens, out_cache_loc):
+        _need(t.dtype == torch.int64, "write_req_to_token: int64 metadata")
+    native.call("sgl_amd_write_req_to_token", req_to_token.data_ptr(), req_to_token.stride(0), req_pool_indices.data_ptr(),
+                _ptr(prefix_ptrs), prefix_lens.data_ptr(), seq_lens.data_ptr(), extend_lens.data_ptr(),
+                out_cache_loc.data_ptr(), req_pool_indices.numel(), _stream())
+
+
+def get_last_loc(req_to_token: torch.Tensor, req_pool_indices: torch.Tensor, prefix_lens: torch.Tensor) -> torch.Tensor:
+    _dev(req_to_token, req_pool_indices, prefix_lens)
+    _need(req_pool_indices.dtype == torch.int64 and prefix_lens.dtype == torch.int64, "get_last_loc: int64 metadata")
+    out = torch.empty_like(prefix_lens)
+    native.call("sgl_amd_get_last_loc", req_to_token.data_ptr(), req_to_token.stride(0), req_pool_indices.data_ptr(),
+                prefix_lens.data_ptr(), out.data_ptr(), prefix_lens.numel(), _stream())
+    return out
+
+
+def compute_position(extend_prefix_lens: torch.Tensor, extend_seq_lens: torch.Tensor, extend_seq_lens_sum: int
+                     ) -> Tuple[torch.Tensor, torch.Tensor]:
+    _dev(extend_prefix_lens, extend_seq_lens)
+    _need(extend_prefix_lens.dtype == extend_seq_lens.dtype and extend_seq_lens.dtype in (torch.int32, torch.int64),
+          "compute_position: lens dtype")
+    positions = torch.empty(extend_seq_lens_sum, dtype=torch.int64, device=extend_seq_lens.device)
+    start = torch.empty_like(extend_seq_lens)
+    native.call("sgl_amd_compute_position", extend_prefix_lens.data_ptr(), extend_seq_lens.data_ptr(),
+                1 if extend_seq_lens.dtype == torch.int64 else 0, positions.data_ptr(), start.data_ptr(),
+                extend_seq_lens.numel(), _stream())
+    return positions, start
+
+
+def clamp_position(seq_lens: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _dev(seq_lens)
+    if out is None:
+        out = torch.empty(seq_lens.shape, dtype=torch.int64, device=seq_lens.device)
+    native.call("sgl_amd_clamp_position", seq_lens.data_ptr(), 1 if seq_lens.dtype == torch.int64 else 0,
+                out.data_ptr(), seq_lens.numel(), _stream())
+    return out
+
+
+def alloc_extend(prefix_lens: torch.Tensor, seq_lens: torch.Tensor, last_loc: torch.Tensor, free_pages: torch.Tensor,
+                 out_indices: torch.Tensor, page_size: int) -> None:
+    _dev(prefix_lens, seq_lens, last_loc, free_pages, out_indices)
+    for t in (prefix_lens, seq_lens, last_loc, free_pages, out_indices):
+        _need(t.dtype == torch.int64, "alloc_extend: int64 metadata")
+    native.call("sgl_amd_alloc_extend", prefix_lens.data_ptr(), seq_lens.data_ptr(), last_loc.data_ptr(),
+                free_pages.data_ptr(), out_indices.data_ptr(), prefix_lens.numel(), page_size, _stream())
+
+
+def alloc_decode(seq_lens: torch.Tensor, last_loc: torch.Tensor, free_pages: torch.Tensor, out_indices: torch.Tensor,
+                 page_size: int) -> None:
+    _dev(seq_lens, last_loc, free_pages, out_indices)
+    for t in (seq_lens, last_loc, free_pages, out_indices):
+        _need(t.dtype == torch.int64, "alloc_decode: int64 metadata")
+    native.call("sgl_amd_alloc_decode", seq_lens.data_ptr(), last_loc.data_ptr(), free_pages.data_ptr(),
+                out_indices.data_ptr(), seq_lens.numel(), page_size, _stream())
+
+
+# ---------------------------------------------------------------------- attention
+def decode_min_chunk() -> int:
+    return native.lib().sgl_amd_decode_attention_min_chunk()
+
+
+def decode_workspace(batch: int, num_q_heads: int, head_dim: int, num_splits: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
+    acc = torch.empty((batch, num_q_heads, num_splits, head_dim), dtype=torch.float32, device=device)
+    ml = torch.empty((batch, num_q_heads, num_splits, 2), dtype=torch.float32, device=device)
+    return acc, ml
+
+
+def decode_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, out: torch.Tensor,
+                     req_to_token: torch.Tensor, req_pool_indices: Optional[torch.Tensor], seq_lens: torch.Tensor,
+                     sm_scale: float, num_splits: int = 1, ws_acc: Optional[torch.Tensor] = None,
+                     ws_ml: Optional[torch.Tensor] = None, kv_indptr: Optional[torch.Tensor] = None,
+                     flags: int = 0) -> torch.Tensor:
+    """q/out [B, Hq, D]; k_cache/v_cache [slots, Hkv, D]; seq_lens int32 [B]."""
+    _dev(q, k_cache, v_cache, out, req_to_token, seq_lens)
+    B, Hq, D = q.shape
+    Hkv = k_cache.shape[1]
+    _need(q.dtype == _BF16 and k_cache.dtype == _BF16 and v_cache.dtype == _BF16 and out.dtype == _BF16, "decode_attention: bf16 only")
+    _need(seq_lens.dtype == torch.int32 and req_to_token.dtype == torch.int32, "decode_attention: int32 seq_lens / req_to_token")
+    _need(req_pool_indices is None or req_pool_indices.dtype == torch.int64, "decode_attention: int64 req_pool_indices")
+    _need(q.stride(2) == 1 and q.stride(1) == D and out.stride(2) == 1 and out.stride(1) == D, "decode_attention: q/out head layout")
+    _need(k_cache.stride(2) == 1 and k_cache.stride(1) == D and v_cache.stride(1) == D, "decode_attention: cache layout")
+    r2t_stride = req_to_token.stride(0) if req_to_token.dim() == 2 else 0
+    native.call("sgl_amd_decode_attention", q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), out.data_ptr(),
+                req_to_token.data_ptr(), r2t_stride, _ptr(req_pool_indices), seq_lens.data_ptr(), _ptr(kv_indptr),
+                B, Hq, Hkv, D, q.stride(0), out.stride(0), k_cache.stride(0), v_cache.stride(0), float(sm_scale),
+                num_splits, _ptr(ws_acc), _ptr(ws_ml), flags, _stream())
+    return out
+
+
+def extend_attention(q: torch.Tensor, out: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
+                     req_to_token: torch.Tensor, req_pool_indices: torch.Tensor, seq_lens: torch.Tensor,
+                     prefix_lens: torch.Tensor, qo_indptr: torch.Tensor, max_extend_len: int, sm_scale: float,
+                     causal: bool = True) -> torch.Tensor:
+    """q/out [T, Hq, D]; k_cache/v_cache [slots, Hkv, D]; int32 seq_lens/prefix_lens/qo_indptr."""
+    _dev(q, out, k_cache, v_cache, req_to_token, req_pool_indices, seq_lens, prefix_lens, qo_indptr)
+    T, Hq, D = q.shape
+    Hkv = k_cache.shape[1]
+    _need(q.dtype == _BF16 and k_cache.dtype == _BF16 and v_cache.dtype == _BF16 and out.dtype == _BF16, "extend_attention: bf16 only")
+    _need(seq_lens.dtype == torch.int32 and prefix_lens.dtype == torch.int32 and qo_indptr.dtype == torch.int32,
+          "extend_attention: int32 lens")
+    _need(req_pool_indices.dtype == torch.int64 and req_to_token.dtype == torch.int32, "extend_attention: index dtypes")
+    _need(q.stride(2) == 1 and q.stride(1) == D and out.stride(2) == 1 and out.stride(1) == D, "extend_attention: q/out head layout")
+    _need(k_cache.stride(2) == 1 and k_cache.stride(1) == D and v_cache.stride(1) == D, "extend_attention: cache layout")
+    native.call("sgl_amd_extend_attention", q.data_ptr(), out.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
+                req_to_token.data_ptr(), req_to_token.stride(0), req_pool_indices.data_ptr(), seq_lens.data_ptr(),
+                prefix_lens.data_ptr(), qo_indptr.data_ptr(), seq_lens.numel(), int(max_extend_len), Hq, Hkv, D,
+                q.stride(0), out.stride(0), k_cache.stride(0), v_cache.stride(0), float(sm_scale), 1 if causal else 0,
+                _stream())
+    return out
+
+
+# ----------------------------------------------------------------------- sampling
+def argmax(logits: torch.Tensor) -> torch.Tensor:
+    _dev(logits)
+    _need(logits.dim() == 2 and logits.stride(1) == 1, "argmax: [B, V] row-major")
+    _need(logits.dtype in (torch.float32, _BF16), "argmax: fp32 or bf16 logits")
+    ids = torch.empty(logits.shape[0], dtype=torch.int64, device=logits.device)
+    native.call("sgl_amd_argmax", logits.data_ptr(), 1 if logits.dtype == _BF16 else 0, ids.data_ptr(),
+                logits.shape[0], logits.shape[1], logits.stride(0), _stream())
+    return ids
+
+
+def softmax_temperature_(logits: torch.Tensor, temperatures: torch.Tensor) -> torch.Tensor:
+    _dev(logits, temperatures)
+    _need(logits.dtype == torch.float32 and logits.dim() == 2 and logits.stride(1) == 1, "softmax: fp32 [B, V]")
+    t = temperatures.reshape(-1)
+    _need(t.dtype == torch.float32 and t.numel() == logits.shape[0] and t.is_contiguous(), "softmax: temperatures [B] fp32")
+    native.call("sgl_amd_softmax_temperature", logits.data_ptr(), t.data_ptr(), logits.shape[0], logits.shape[1],
+                logits.stride(0), _stream())
+    return logits
+
+
+# -------------------------------------------------------------------------- probe
+def probe_mfma_16x16x32(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    _dev(a, b)
+    _need(a.shape == (16, 32) and b.shape == (32, 16) and a.dtype == _BF16 and b.dtype == _BF16, "probe shapes")
+    c = torch.empty((16, 16), dtype=torch.float32, device=a.device)
+    native.call("sgl_amd_probe_mfma_16x16x32", a.contiguous().data_ptr(), b.contiguous().data_ptr(), c.data_ptr(), _stream())
+    return c

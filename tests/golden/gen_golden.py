@@ -1,0 +1,427 @@
+"""Generate golden fixtures by running the REAL reference code (build container only).
+
+    python tests/golden/gen_golden.py          # needs /root/reference
+
+`import sglang` fails here (orjson, msgspec, zmq, torchvision ... are absent),
+so this script installs an import hook that (a) stubs the missing third-party
+packages, (b) skips every sglang package __init__, and (c) lets a reference
+module that cannot be imported degrade to a permissive stub -- while the modules
+we actually call (`REAL`) must import for real.  The arithmetic we record is
+therefore the reference's own code running on torch CPU.
+
+Outputs (committed): tests/golden/*.pt, tests/golden/*.json.
+Nothing under tests/ reads /root/reference at test time.
+"""
+from __future__ import annotations
+
+import importlib
+import importlib.abc
+import importlib.machinery
+import json
+import random
+import sys
+import types
+from array import array
+from pathlib import Path
+from unittest import mock
+
+import torch
+
+REF = Path("/root/reference/python")
+OUT = Path(__file__).resolve().parent
+
+
+# ----------------------------------------------------------------------------- import hook
+class _AnyMeta(type):
+    def __getattr__(cls, n):
+        if n.startswith("__"):
+            raise AttributeError(n)
+        return _Any
+
+
+class _Any(metaclass=_AnyMeta):
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        if len(a) == 1 and not k and callable(a[0]):
+            return a[0]  # decorator pass-through
+        return _Any()
+
+    def __getattr__(self, n):
+        if n.startswith("__"):
+            raise AttributeError(n)
+        return _Any()
+
+    def __class_getitem__(cls, i):
+        return cls
+
+    def __iter__(self):
+        return iter(())
+
+    def __bool__(self):
+        return False
+
+    def __or__(self, o):
+        return self
+
+    def __ror__(self, o):
+        return self
+
+
+class _Stub(types.ModuleType):
+    def __getattr__(self, name):
+        if name.startswith("__") and name.endswith("__"):
+            raise AttributeError(name)
+        return _Any
+
+
+MISSING = {"orjson", "msgspec", "zmq", "pybase64", "IPython", "uvloop", "setproctitle", "xgrammar",
+           "sgl_kernel", "flashinfer", "aiter", "vllm"}
+REAL = {
+    "sglang.srt.mem_cache.radix_cache",
+    "sglang.srt.mem_cache.base_prefix_cache",
+    "sglang.srt.mem_cache.allocator.paged",
+    "sglang.srt.mem_cache.allocator.token",
+    "sglang.srt.mem_cache.allocation",
+    "sglang.srt.layers.attention.torch_native_backend",
+    "sglang.srt.layers.moe.fused_moe_native",
+    "sglang.srt.layers.moe.topk",
+    "sglang.srt.layers.layernorm",
+    "sglang.srt.layers.rotary_embedding.base",
+    "sglang.srt.layers.rotary_embedding.utils",
+    "sglang.srt.layers.rotary_embedding.rope_variant",
+    "sglang.srt.layers.sampler",
+    "sglang.srt.model_executor.forward_batch_info",
+}
+FAILED = []
+
+
+class _StubLoader(importlib.abc.Loader):
+    def create_module(self, spec):
+        m = _Stub(spec.name)
+        m.__path__ = []
+        return m
+
+    def exec_module(self, m):
+        pass
+
+
+class _PkgLoader(importlib.abc.Loader):
+    def __init__(self, paths):
+        self.paths = paths
+
+    def create_module(self, spec):
+        m = _Stub(spec.name)
+        m.__path__ = self.paths
+        return m
+
+    def exec_module(self, m):
+        pass
+
+
+class _WrapLoader(importlib.abc.Loader):
+    def __init__(self, inner):
+        self.inner = inner
+
+    def create_module(self, spec):
+        return self.inner.create_module(spec)
+
+    def exec_module(self, m):
+        try:
+            self.inner.exec_module(m)
+        except Exception as e:  # degrade to a stub
+            FAILED.append((m.__name__, f"{type(e).__name__}: {str(e)[:100]}"))
+            m.__class__ = _Stub
+            if not hasattr(m, "__path__"):
+                m.__path__ = []
+
+
+class _Finder(importlib.abc.MetaPathFinder):
+    def find_spec(self, name, path, target=None):
+        root = name.split(".")[0]
+        if root in MISSING:
+            return importlib.machinery.ModuleSpec(name, _StubLoader(), is_package=True)
+        if root == "sglang":
+            spec = importlib.machinery.PathFinder.find_spec(name, path)
+            if spec is None:
+                return importlib.machinery.ModuleSpec(name, _StubLoader(), is_package=True)
+            if name in REAL:
+                return spec
+            if spec.submodule_search_locations is not None:
+                return importlib.machinery.ModuleSpec(
+                    name, _PkgLoader(list(spec.submodule_search_locations)), is_package=True)
+            spec.loader = _WrapLoader(spec.loader)
+            return spec
+        return None
+
+
+def install_hook():
+    sys.path.insert(0, str(REF))
+    sys.meta_path.insert(0, _Finder())
+
+
+def ref(mod: str):
+    return importlib.import_module(mod)
+
+
+# ----------------------------------------------------------------------------- generators
+def gen_attention():
+    tnb = ref("sglang.srt.layers.attention.torch_native_backend").TorchNativeAttnBackend
+    g = torch.Generator().manual_seed(1234)
+    cases = {}
+    for name, (Hq, Hkv, D) in {"gqa_d64": (4, 2, 64), "mha_d128": (2, 2, 128), "gqa4_d128": (8, 2, 128)}.items():
+        slots, max_ctx = 96, 40
+        prefix = torch.tensor([0, 5, 17, 8])
+        extend = torch.tensor([9, 7, 3, 1])
+        seq = prefix + extend
+        B = len(seq)
+        perm = torch.randperm(slots - 1, generator=g) + 1
+        req_to_token = torch.zeros((B + 1, max_ctx), dtype=torch.int32)
+        req_pool = torch.tensor([2, 4, 1, 3])
+        off = 0
+        for i in range(B):
+            req_to_token[req_pool[i], : seq[i]] = perm[off: off + seq[i]].to(torch.int32)
+            off += int(seq[i])
+        k_cache = (torch.randn((slots, Hkv, D), generator=g) * 0.5).to(torch.bfloat16)
+        v_cache = (torch.randn((slots, Hkv, D), generator=g) * 0.5).to(torch.bfloat16)
+        T = int(extend.sum())
+        q = (torch.randn((T, Hq, D), generator=g) * 0.5).to(torch.bfloat16)
+        scaling = D ** -0.5
+        o = torch.empty_like(q)
+        tnb._run_sdpa_forward_extend(None, q, o, k_cache, v_cache, req_to_token, req_pool, seq, prefix, extend,
+                                     scaling=scaling, enable_gqa=Hq != Hkv, causal=True)
+        qd = (torch.randn((B, Hq, D), generator=g) * 0.5).to(torch.bfloat16)
+        od = torch.empty_like(qd)
+        tnb._run_sdpa_forward_decode(None, qd, od, k_cache, v_cache, req_to_token, req_pool, seq,
+                                     scaling=scaling, enable_gqa=Hq != Hkv, causal=False)
+        cases[name] = dict(q=q, out_extend=o, q_decode=qd, out_decode=od, k_cache=k_cache, v_cache=v_cache,
+                           req_to_token=req_to_token, req_pool_indices=req_pool, seq_lens=seq,
+                           extend_prefix_lens=prefix, extend_seq_lens=extend, scaling=scaling)
+    torch.save(cases, OUT / "attention_torch_native.pt")
+
+
+def gen_elementwise():
+    ln = ref("sglang.srt.layers.layernorm")
+    rb = ref("sglang.srt.layers.rotary_embedding.base")
+    ru = ref("sglang.srt.layers.rotary_embedding.utils")
+    rv = ref("sglang.srt.layers.rotary_embedding.rope_variant")
+    g = torch.Generator().manual_seed(7)
+    out = {}
+    # RMSNorm.forward_native (layernorm.py:777-826) with a minimal fake self
+    for name, (T, H) in {"t7_h2048": (7, 2048), "t3_h896": (3, 896)}.items():
+        w = (1.0 + 0.1 * torch.randn(H, generator=g)).to(torch.bfloat16)
+        x = torch.randn((T, H), generator=g).to(torch.bfloat16)
+        r = torch.randn((T, H), generator=g).to(torch.bfloat16)
+        fake = types.SimpleNamespace(weight=w, variance_epsilon=1e-5, hidden_size=H, override_orig_dtype=None,
+                                     fp32_residual=False, variance_size_override=None, cast_x_before_out_mul=False)
+        y = ln.RMSNorm.forward_native(fake, x.clone())
+        y2, r2 = ln.RMSNorm.forward_native(fake, x.clone(), r.clone())
+        out[f"rmsnorm_{name}"] = dict(x=x, residual=r, weight=w, eps=1e-5, out=y, out_fused=y2, residual_out=r2)
+    # RotaryEmbedding.forward_native (base.py:236-276) + Llama3 inv_freq (rope_variant.py:560-580)
+    for name, (Hq, Hk, D, neox, llama3) in {"neox_d128_llama3": (4, 2, 128, True, True),
+                                            "neox_d64": (14, 2, 64, True, False),
+                                            "gptj_d64": (2, 2, 64, False, False)}.items():
+        base, max_pos = 500000.0, 512
+        fake = types.SimpleNamespace(rotary_dim=D, base=base, _force_native=False, max_position_embeddings=max_pos,
+                                     scaling_factor=8.0, low_freq_factor=1.0, high_freq_factor=4.0,
+                                     orig_max_position=8192)
+        if llama3:
+            # Llama3RotaryEmbedding._compute_inv_freq calls super()._compute_inv_freq(base)
+            class _L3(rv.Llama3RotaryEmbedding):
+                def __init__(self):  # skip nn.Module / platform init
+                    pass
+            l3 = _L3.__new__(_L3)
+            l3.__dict__.update(fake.__dict__)
+            inv = rv.Llama3RotaryEmbedding._compute_inv_freq(l3, base)
+        else:
+            inv = rb.RotaryEmbedding._compute_inv_freq(fake, base)
+        fake._compute_inv_freq = lambda b, inv=inv: inv
+        cache_f32 = rb.RotaryEmbedding._compute_cos_sin_cache(fake)
+        cache = cache_f32.to(torch.bfloat16)  # HIP path casts the cache to the model dtype (base.py:104-106)
+        T = 6
+        pos = torch.tensor([0, 1, 5, 100, 257, 511])
+        q = torch.randn((T, Hq * D), generator=g).to(torch.bfloat16)
+        k = torch.randn((T, Hk * D), generator=g).to(torch.bfloat16)
+        fwd = types.SimpleNamespace(cos_sin_cache=cache, head_size=D, rotary_dim=D, is_neox_style=neox,
+                                    _apply_rotary_emb_wrapped=ru.apply_rotary_emb)
+        qo, ko = rb.RotaryEmbedding.forward_native(fwd, pos, q.clone(), k.clone())
+        out[f"rope_{name}"] = dict(positions=pos, q=q, k=k, q_out=qo, k_out=ko, cache=cache, cache_f32=cache_f32,
+                                   inv_freq=inv, head_size=D, is_neox=neox, base=base, max_pos=max_pos,
+                                   llama3=llama3)
+    torch.save(out, OUT / "elementwise_native.pt")
+
+
+def gen_moe():
+    topk_mod = ref("sglang.srt.layers.moe.topk")
+    native = ref("sglang.srt.layers.moe.fused_moe_native")
+    g = torch.Generator().manual_seed(11)
+    M, K, N, E, k = 9, 64, 48, 8, 2
+    x = (torch.randn((M, K), generator=g) * 0.5).to(torch.bfloat16)
+    w13 = (torch.randn((E, 2 * N, K), generator=g) * 0.1).to(torch.bfloat16)
+    w2 = (torch.randn((E, K, N), generator=g) * 0.1).to(torch.bfloat16)
+    logits = torch.randn((M, E), generator=g).to(torch.bfloat16)
+    tw, ti = topk_mod.fused_topk_torch_native(x, logits, k, True)
+    layer = types.SimpleNamespace(w13_weight=w13, w2_weight=w2, num_experts=E,
+                                  moe_runner_config=types.SimpleNamespace(apply_router_weight_on_input=False,
+                                                                          activation="silu", gemm1_alpha=None,
+                                                                          gemm1_clamp_limit=None))
+    disp = types.SimpleNamespace(hidden_states=x, topk_output=(tw, ti, logits))
+
+    class _Combine:
+        def __init__(self, hidden_states):
+            self.hidden_states = hidden_states
+    with mock.patch.object(native, "StandardCombineInput", _Combine):
+        y = native.fused_moe_forward_native(layer, disp).hidden_states
+    torch.save(dict(x=x, w13=w13, w2=w2, router_logits=logits, topk=k, topk_weights=tw, topk_ids=ti, out_einsum=y),
+               OUT / "moe_native.pt")
+
+
+def gen_sampler():
+    s = ref("sglang.srt.layers.sampler")
+    g = torch.Generator().manual_seed(5)
+    B, V = 6, 1000
+    logits = torch.randn((B, V), generator=g) * 3
+    probs = torch.softmax(logits, dim=-1)
+    top_ks = torch.tensor([50, 1, 1 << 30, 20, 1 << 30, 5], dtype=torch.int32)
+    top_ps = torch.tensor([0.9, 1.0, 0.5, 1.0, 1.0, 0.3])
+    min_ps = torch.tensor([0.0, 0.0, 0.0, 0.05, 0.02, 0.0])
+    captured = {}
+
+    def fake_multinomial(p, num_samples):
+        captured["kept"] = p.clone()
+        return torch.zeros((p.shape[0], 1), dtype=torch.int64)
+    res = {}
+    for need_min_p in (False, True):
+        with mock.patch.object(torch, "multinomial", fake_multinomial):
+            ids0 = s.top_k_top_p_min_p_sampling_from_probs_torch(probs.clone(), top_ks, top_ps, min_ps, need_min_p,
+                                                                 None, torch.zeros(B, dtype=torch.int64))
+        res[f"kept_sorted_minp{int(need_min_p)}"] = captured["kept"]
+        res[f"rank0_ids_minp{int(need_min_p)}"] = ids0
+    res.update(probs=probs, top_ks=top_ks, top_ps=top_ps, min_ps=min_ps)
+    torch.save(res, OUT / "sampler_torch.pt")
+
+
+def gen_radix():
+    rc = ref("sglang.srt.mem_cache.radix_cache")
+    bpc = ref("sglang.srt.mem_cache.base_prefix_cache")
+    RadixCache, RadixKey = rc.RadixCache, rc.RadixKey
+    traces = {}
+
+    def key(ids):
+        return RadixKey(token_ids=array("q", ids))
+
+    for page_size in (1, 4):
+        rnd = random.Random(100 + page_size)
+        alloc = mock.Mock()
+        alloc.device = "cpu"
+        tree = RadixCache.create_simulated(mock_allocator=alloc, page_size=page_size)
+        ops = []
+        next_slot = 1
+        held = []  # nodes we locked
+        vocab = 6
+        for step in range(220):
+            r = rnd.random()
+            if r < 0.45:
+                n = rnd.randint(1, 14)
+                ids = [rnd.randrange(vocab) for _ in range(n)]
+                vals = list(range(next_slot, next_slot + n))
+                next_slot += n
+                res = tree.insert(bpc.InsertParams(key=key(ids), value=torch.tensor(vals, dtype=torch.int64)))
+                ops.append(dict(op="insert", ids=ids, vals=vals, prefix_len=int(res.prefix_len)))
+            elif r < 0.8:
+                n = rnd.randint(0, 14)
+                ids = [rnd.randrange(vocab) for _ in range(n)]
+                m = tree.match_prefix(bpc.MatchPrefixParams(key=key(ids)))
+                if rnd.random() < 0.3 and m.last_device_node is not tree.root_node:
+                    tree.inc_lock_ref(m.last_device_node)
+                    held.append(m.last_device_node)
+                    locked = True
+                else:
+                    locked = False
+                ops.append(dict(op="match", ids=ids, indices=m.device_indices.tolist(), lock=locked))
+            elif r < 0.9 and held:
+                idx = rnd.randrange(len(held))
+                node = held.pop(idx)
+                tree.dec_lock_ref(node)
+                ops.append(dict(op="unlock", which=idx))
+            else:
+                n = rnd.randint(1, 10)
+                alloc.reset_mock()
+                res = tree.evict(bpc.EvictParams(num_tokens=n))
+                freed = []
+                for c in alloc.free_segment.call_args_list:
+                    freed.append(c.args[0].tolist())
+                ops.append(dict(op="evict", num_tokens=n, num_evicted=int(res.num_tokens_evicted), freed=freed))
+            ops[-1].update(evictable=int(tree.evictable_size()), protected=int(tree.protected_size()),
+                           total=int(tree.total_size()))
+        traces[f"page{page_size}"] = ops
+
+    # the reference's own __main__ scenario (radix_cache.py:849-863)
+    tree = RadixCache.create_simulated()
+    for ids in ([1, 2, 3], [1, 2, 3], [1, 2, 4, 5], [1, 2, 4, 5, 6, 7], [8, 9, 10, 11, 12]):
+        tree.insert(bpc.InsertParams(key=key(ids)))
+    m = tree.match_prefix(bpc.MatchPrefixParams(key=key([1, 2, 3, 13, 14])))
+    traces["main_scenario"] = dict(match=m.device_indices.tolist(), total=int(tree.total_size()))
+    (OUT / "radix_trace.json").write_text(json.dumps(traces))
+
+
+def gen_host_int():
+    paged = ref("sglang.srt.mem_cache.allocator.paged")
+    alloc_mod = ref("sglang.srt.mem_cache.allocation")
+    fbi = ref("sglang.srt.model_executor.forward_batch_info")
+    rnd = random.Random(9)
+    cases = []
+    for page_size in (1, 4, 16):
+        for _ in range(6):
+            bs = rnd.randint(1, 7)
+            prefix = [rnd.randint(0, 40) for _ in range(bs)]
+            ext = [rnd.randint(1, 50) for _ in range(bs)]
+            seq = [p + e for p, e in zip(prefix, ext)]
+            # a consistent last_loc: last slot of the prefix's (possibly partial) page
+            last_loc, used_pages = [], 0
+            for p in prefix:
+                if p == 0:
+                    last_loc.append(-1)
+                else:
+                    page = 1000 + used_pages
+                    used_pages += 1
+                    last_loc.append(page * page_size + (p - 1) % page_size)
+            n_free = sum((s + page_size - 1) // page_size for s in seq) + 3
+            free_pages = rnd.sample(range(1, 900), n_free)
+            out = torch.full((sum(ext),), -7, dtype=torch.int64)
+            paged.alloc_extend_naive(torch.tensor(prefix), torch.tensor(seq), torch.tensor(last_loc),
+                                     torch.tensor(free_pages), out, page_size, "cpu")
+            cases.append(dict(page_size=page_size, prefix=prefix, seq=seq, last_loc=last_loc, free_pages=free_pages,
+                              out=out.tolist()))
+    pos_cases = []
+    for _ in range(5):
+        bs = rnd.randint(1, 6)
+        prefix = torch.tensor([rnd.randint(0, 30) for _ in range(bs)])
+        ext = torch.tensor([rnd.randint(1, 9) for _ in range(bs)])
+        p, s = fbi.compute_position_torch(prefix, ext)
+        pos_cases.append(dict(prefix=prefix.tolist(), extend=ext.tolist(), positions=p.tolist(), start=s.tolist()))
+    r2t = torch.arange(5 * 11, dtype=torch.int32).reshape(5, 11)
+    rp = torch.tensor([3, 0, 4])
+    pl = torch.tensor([0, 4, 11])
+    ll = alloc_mod.get_last_loc_torch(r2t, rp, pl)
+    clamp = fbi._clamp_position_native(torch.tensor([0, 1, 5, 9]))
+    (OUT / "host_int.json").write_text(json.dumps(dict(
+        alloc_extend=cases, compute_position=pos_cases,
+        get_last_loc=dict(req_pool=rp.tolist(), prefix=pl.tolist(), out=ll.tolist()),
+        clamp_position=dict(seq=[0, 1, 5, 9], out=clamp.tolist()))))
+
+
+def main():
+    if not REF.exists():
+        raise SystemExit("/root/reference not present: goldens can only be regenerated in the build container")
+    install_hook()
+    torch.manual_seed(0)
+    for fn in (gen_attention, gen_elementwise, gen_moe, gen_sampler, gen_radix, gen_host_int):
+        fn()
+        print("ok", fn.__name__)
+    print("degraded-to-stub reference modules:", len(FAILED))
+
+
+if __name__ == "__main__":
+    main()
