@@ -1,0 +1,124 @@
+"""Request->token and token->KV pools (device memory laid out for one MI355X).
+
+Mirrors /root/reference/python/sglang/srt/mem_cache/memory_pool.py:
+  ReqToTokenPool      :256-333   int32 [size+1, max_context_len], row 0 = padding row
+  MHATokenToKVPool    :1759-2456 per-layer K/V [size+page_size, H_kv, D], slot 0's page = sink
+
+HBM layout: one contiguous allocation per K and per V, shaped
+[layers, size+page_size, H_kv, D] (NHD rows of H_kv*D*2 bytes); the per-layer
+buffers handed to the attention backend are views of it.  A KV row of one
+token and one kv head is D*2 contiguous bytes -- the unit the attention
+kernels gather with 16-byte lanes.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+
+
+@dataclass
+class KVWriteLoc:
+    """memory_pool.py KVWriteLoc(loc, swa_loc): where this step's K/V rows go."""
+
+    loc: torch.Tensor
+    swa_loc: Optional[torch.Tensor] = None
+
+
+def unwrap_write_loc(loc_info):
+    if isinstance(loc_info, KVWriteLoc):
+        return loc_info.loc, loc_info.swa_loc, None
+    return loc_info, None, None
+
+
+class ReqToTokenPool:
+    """Maps a request slot to the KV slots of its tokens."""
+
+    def __init__(self, size: int, max_context_len: int, device, enable_memory_saver: bool = False):
+        self.size = size
+        self._alloc_size = size + 1   # row 0 absorbs padded (graph) batch entries
+        self.max_context_len = max_context_len
+        self.device = device
+        self.req_to_token = torch.zeros((self._alloc_size, max_context_len), dtype=torch.int32, device=device)
+        self.free_slots: List[int] = list(range(1, self._alloc_size))
+
+    def write(self, indices, values) -> None:
+        self.req_to_token[indices] = values
+
+    def available_size(self) -> int:
+        return len(self.free_slots)
+
+    def alloc(self, reqs) -> Optional[List[int]]:
+        """Assign `req_pool_idx` to every request that has none (memory_pool.py:292-324)."""
+        need = [r for r in reqs if getattr(r, "req_pool_idx", None) is None]
+        if len(need) > len(self.free_slots):
+            return None
+        if need:
+            picked = self.free_slots[-len(need):]
+            del self.free_slots[-len(need):]
+            for r, idx in zip(need, picked):
+                r.req_pool_idx = idx
+        return [r.req_pool_idx for r in reqs]
+
+    def free(self, req) -> None:
+        assert req.req_pool_idx is not None, "request must have req_pool_idx"
+        self.free_slots.append(req.req_pool_idx)
+        req.req_pool_idx = None
+
+    def clear(self) -> None:
+        self.free_slots = list(range(1, self._alloc_size))
+
+
+class MHATokenToKVPool:
+    """Multi-head K/V cache, NHD layout, bf16."""
+
+    def __init__(self, size: int, page_size: int, dtype: torch.dtype, head_num: int, head_dim: int, layer_num: int,
+                 device, enable_memory_saver: bool = False, v_head_dim: Optional[int] = None,
+                 start_layer: Optional[int] = None, end_layer: Optional[int] = None):
+        assert dtype == torch.bfloat16, "the gfx950 KV kernels are bf16"
+        self.size = size
+        self.page_size = page_size
+        self.dtype = dtype
+        self.store_dtype = dtype
+        self.device = device
+        self.head_num = head_num
+        self.head_dim = head_dim
+        self.v_head_dim = v_head_dim if v_head_dim is not None else head_dim
+        self.layer_num = layer_num
+        self.start_layer = start_layer or 0
+        self.end_layer = end_layer if end_layer is not None else layer_num - 1
+        rows = size + page_size
+        # zero-filled so the sink page never holds NaN patterns
+        self._k_all = torch.zeros((layer_num, rows, head_num, head_dim), dtype=dtype, device=device)
+        self._v_all = torch.zeros((layer_num, rows, head_num, self.v_head_dim), dtype=dtype, device=device)
+        self.k_buffer = [self._k_all[i] for i in range(layer_num)]
+        self.v_buffer = [self._v_all[i] for i in range(layer_num)]
+        self.row_dim = head_num * head_dim
+        self.v_row_dim = head_num * self.v_head_dim
+
+    # -- accessors used by attention backends (memory_pool.py:2292-2329) -------
+    def get_key_buffer(self, layer_id: int) -> torch.Tensor:
+        return self.k_buffer[layer_id - self.start_layer]
+
+    def get_value_buffer(self, layer_id: int) -> torch.Tensor:
+        return self.v_buffer[layer_id - self.start_layer]
+
+    def get_kv_buffer(self, layer_id: int):
+        return self.get_key_buffer(layer_id), self.get_value_buffer(layer_id)
+
+    def get_kv_size_bytes(self):
+        return self._k_all.numel() * 2, self._v_all.numel() * 2
+
+    # -- writes (memory_pool.py:2331-2456) ---------------------------------------
+    def set_kv_buffer(self, layer, loc_info, cache_k: torch.Tensor, cache_v: torch.Tensor, k_scale=None,
+                      v_scale=None, layer_id_override: Optional[int] = None) -> None:
+        from .. import kernels
+
+        loc, _, _ = unwrap_write_loc(loc_info)
+        layer_id = layer_id_override if layer_id_override is not None else layer.layer_id
+        if cache_k.dtype != self.dtype:
+            cache_k = cache_k.to(self.dtype)
+            cache_v = cache_v.to(self.dtype)
+        kernels.store_kv_cache(cache_k, cache_v, self.get_key_buffer(layer_id), self.get_value_buffer(layer_id),
+                               loc if loc.dtype == torch.int64 else loc.to(torch.int64))

@@ -1,0 +1,159 @@
+"""Host data model: the product RadixCache / allocators against (a) the trace
+recorded from the real reference RadixCache (tests/golden/radix_trace.json),
+(b) the reference's own unit-test scenarios, (c) the brute-force oracle.  CPU."""
+import json
+import random
+from array import array
+from unittest import mock
+
+import pytest
+import torch
+
+from oracle.host import BruteForcePrefixCache
+from sglang_amd.mem_cache.allocator import TokenToKVPoolAllocator, PagedTokenToKVPoolAllocator
+from sglang_amd.mem_cache.radix_cache import (EvictParams, InsertParams, MatchPrefixParams, RadixCache, RadixKey)
+
+
+def _key(ids):
+    return RadixKey(array("q", ids))
+
+
+@pytest.mark.parametrize("page", [1, 4])
+def test_replay_reference_trace(golden_dir, page):
+    ops = json.loads((golden_dir / "radix_trace.json").read_text())[f"page{page}"]
+    alloc = mock.Mock()
+    alloc.device = "cpu"
+    tree = RadixCache.create_simulated(mock_allocator=alloc, page_size=page)
+    held = []
+    for i, op in enumerate(ops):
+        if op["op"] == "insert":
+            res = tree.insert(InsertParams(key=_key(op["ids"]), value=torch.tensor(op["vals"], dtype=torch.int64)))
+            assert res.prefix_len == op["prefix_len"], (i, op)
+        elif op["op"] == "match":
+            m = tree.match_prefix(MatchPrefixParams(key=_key(op["ids"])))
+            assert m.device_indices.tolist() == op["indices"], (i, op)
+            assert m.device_indices.dtype == torch.int64
+            if op["lock"]:
+                tree.inc_lock_ref(m.last_device_node)
+                held.append(m.last_device_node)
+        elif op["op"] == "unlock":
+            tree.dec_lock_ref(held.pop(op["which"]))
+        else:
+            alloc.reset_mock()
+            res = tree.evict(EvictParams(num_tokens=op["num_tokens"]))
+            assert res.num_tokens_evicted == op["num_evicted"], (i, op)
+            freed = [c.args[0].tolist() for c in alloc.free_segment.call_args_list]
+            assert freed == op["freed"], (i, op)
+        assert tree.evictable_size() == op["evictable"], (i, op)
+        assert tree.protected_size() == op["protected"], (i, op)
+        assert tree.total_size() == op["total"], (i, op)
+
+
+def test_reference_main_scenario(golden_dir):
+    # radix_cache.py:849-863
+    g = json.loads((golden_dir / "radix_trace.json").read_text())["main_scenario"]
+    tree = RadixCache.create_simulated()
+    for ids in ([1, 2, 3], [1, 2, 3], [1, 2, 4, 5], [1, 2, 4, 5, 6, 7], [8, 9, 10, 11, 12]):
+        tree.insert(InsertParams(key=_key(ids)))
+    m = tree.match_prefix(MatchPrefixParams(key=_key([1, 2, 3, 13, 14])))
+    assert m.device_indices.tolist() == g["match"] == [1, 2, 3]
+    assert tree.total_size() == g["total"]
+
+
+def test_radix_key_semantics():
+    # test/registered/unit/mem_cache/test_radix_cache_unit.py:210-258 (match lengths incl. page rounding)
+    a, b = _key([1, 2, 3, 4, 5, 6, 7]), _key([1, 2, 3, 4, 9, 9])
+    assert a.match(b) == 4
+    assert a.match(b, page_size=2) == 4
+    assert a.match(b, page_size=3) == 3
+    assert a.match(_key([]), page_size=1) == 0
+    assert a.match(a) == 7 and a.match(a, page_size=4) == 4
+    assert len(a.page_aligned(4)) == 4 and len(a.page_aligned(8)) == 0
+    assert a[2:5].token_ids.tolist() == [3, 4, 5]
+    assert a.child_key(1) == 1 and a.child_key(3) == (1, 2, 3)
+    assert RadixKey(array("q", [5]), extra_key="lora").child_key(1) == ("lora", 5)
+    with pytest.raises(ValueError):
+        a.match(RadixKey(array("q", [1]), extra_key="x"))
+
+
+def test_extra_key_namespaces_are_disjoint():
+    tree = RadixCache.create_simulated()
+    tree.insert(InsertParams(key=RadixKey(array("q", [1, 2, 3]), extra_key="a"), value=torch.tensor([10, 11, 12])))
+    tree.insert(InsertParams(key=RadixKey(array("q", [1, 2, 3]), extra_key="b"), value=torch.tensor([20, 21, 22])))
+    assert tree.match_prefix(RadixKey(array("q", [1, 2, 3]), extra_key="a")).device_indices.tolist() == [10, 11, 12]
+    assert tree.match_prefix(RadixKey(array("q", [1, 2, 3]), extra_key="b")).device_indices.tolist() == [20, 21, 22]
+    assert tree.match_prefix(_key([1, 2, 3])).device_indices.tolist() == []
+
+
+@pytest.mark.parametrize("page", [1, 2, 16])
+def test_against_bruteforce_oracle(page):
+    rnd = random.Random(page)
+    tree = RadixCache.create_simulated(mock_allocator=mock.Mock(device="cpu"), page_size=page)
+    model = BruteForcePrefixCache(page_size=page)
+    slot = 1
+    for _ in range(400):
+        ids = [rnd.randrange(4) for _ in range(rnd.randint(0, 70))]
+        if rnd.random() < 0.5 and ids:
+            vals = list(range(slot, slot + len(ids)))
+            slot += len(ids)
+            got = tree.insert(InsertParams(key=_key(ids), value=torch.tensor(vals, dtype=torch.int64))).prefix_len
+            assert got == model.insert(ids, vals)
+        else:
+            assert tree.match_prefix(_key(ids)).device_indices.tolist() == model.match(ids)
+
+
+def test_lock_protects_from_eviction_and_disable():
+    alloc = mock.Mock(device="cpu")
+    tree = RadixCache.create_simulated(mock_allocator=alloc)
+    tree.insert(InsertParams(key=_key([1, 2, 3, 4]), value=torch.tensor([1, 2, 3, 4])))
+    tree.insert(InsertParams(key=_key([1, 2, 9]), value=torch.tensor([1, 2, 9])))
+    m = tree.match_prefix(_key([1, 2, 3, 4]))
+    tree.inc_lock_ref(m.last_device_node)
+    assert tree.protected_size() == 4 and tree.evictable_size() == 1
+    assert tree.evict(EvictParams(100)).num_tokens_evicted == 1          # only the [9] leaf can go
+    tree.dec_lock_ref(m.last_device_node)
+    assert tree.evict(EvictParams(100)).num_tokens_evicted == 4
+    assert tree.total_size() == 0
+    off = RadixCache.create_simulated(disable=True)
+    assert off.insert(InsertParams(key=_key([1]))).prefix_len == 0
+    assert off.match_prefix(_key([1])).device_indices.numel() == 0
+
+
+def test_eviction_policies():
+    for policy, first in (("lru", [1]), ("mru", [3]), ("fifo", [1]), ("filo", [3])):
+        alloc = mock.Mock(device="cpu")
+        tree = RadixCache(None, alloc, eviction_policy=policy)
+        for t in (1, 2, 3):
+            tree.insert(InsertParams(key=_key([t]), value=torch.tensor([t])))
+        tree.evict(EvictParams(1))
+        assert alloc.free_segment.call_args_list[0].args[0].tolist() == first, policy
+
+
+def test_token_allocator_matches_reference_semantics():
+    # allocator/token.py:40-76: ascending slots starting at 1, free appends, need_sort merges
+    a = TokenToKVPoolAllocator(16, torch.bfloat16, "cpu")
+    assert a.available_size() == 16
+    x = a.alloc(5)
+    assert x.tolist() == [1, 2, 3, 4, 5]
+    assert a.alloc(12) is None
+    a.free(x[1:3])
+    assert a.available_size() == 13
+    assert a.alloc(11).tolist() == list(range(6, 17))
+    assert a.alloc(2).tolist() == [2, 3]
+    s = TokenToKVPoolAllocator(8, torch.bfloat16, "cpu", need_sort=True)
+    y = s.alloc(8)
+    s.free(y[5:]); s.free(y[:2])
+    assert s.alloc(4).tolist() == [1, 2, 6, 7]
+    a.free_group_begin(); a.free(torch.tensor([9])); a.free(torch.tensor([8])); a.free_group_end()
+    assert sorted(a.free_pages.tolist()) == [8, 9]
+
+
+def test_paged_allocator_free_segments():
+    # base.py:133-149 boundary rule + paged.py:281-313 strided representatives
+    p = PagedTokenToKVPoolAllocator(64, 4, torch.bfloat16, "cpu")
+    idx = p.alloc(16)
+    assert idx.tolist() == list(range(4, 20)) and p.available_size() == 48
+    row = idx                      # one request's kv row: pages 1,2,3,4
+    p.free_segments([(row[2:6], 2), (row[6:16], 6)])   # second segment starts inside page 2
+    assert sorted(p.free_pages.tolist()[:4]) == [1, 2, 3, 4]
+    assert p.available_size() == 64
