@@ -1,0 +1,141 @@
+"""CPU restatement of the reference decoder forward (torch-native everywhere),
+used for end-to-end parity and as bench.py's `cpu_baseline`.  TEST INFRASTRUCTURE ONLY.
+
+Follows /root/reference/python/sglang/srt/models/llama.py:219-223 (rope then
+attention), :341-370 (layer wiring with fused add+norm), :419-470 (model loop),
+qwen2.py (qkv bias / tied head), mixtral.py:108-118 (router -> topk -> experts),
+srt/layers/logits_processor.py:652-700 (last-token logits), with the torch-native
+attention backend's write-then-read KV semantics (torch_native_backend.py:279-398)
+over a private KV pool and the reference's page_size=1 token allocator order.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+
+class OracleLM:
+    def __init__(self, cfg, weights: Dict[str, torch.Tensor], num_slots: int = 4096, max_ctx: int = 2048,
+                 compute_dtype: Optional[torch.dtype] = None):
+        """`weights`: CPU tensors keyed like the product model's state_dict()."""
+        self.cfg = cfg
+        self.w = {k: v.detach().cpu() for k, v in weights.items()}
+        self.compute_dtype = compute_dtype
+        D = cfg.head_dim
+        if cfg.rope_scaling and cfg.rope_scaling.get("rope_type") == "llama3":
+            rs = cfg.rope_scaling
+            inv = ops.llama3_inv_freq(D, cfg.rope_theta, rs["factor"], rs["low_freq_factor"], rs["high_freq_factor"],
+                                      rs["original_max_position_embeddings"])
+        else:
+            inv = ops.rope_inv_freq(D, cfg.rope_theta)
+        self.rope_cache = ops.cos_sin_cache(inv, cfg.max_position_embeddings).to(torch.bfloat16)
+        L = cfg.num_hidden_layers
+        self.k_cache = [torch.zeros((num_slots, cfg.num_key_value_heads, D), dtype=torch.bfloat16) for _ in range(L)]
+        self.v_cache = [torch.zeros((num_slots, cfg.num_key_value_heads, D), dtype=torch.bfloat16) for _ in range(L)]
+        self.req_to_token = torch.zeros((64, max_ctx), dtype=torch.int32)
+        self.next_slot = 1
+
+    # ---- one forward over a ragged batch --------------------------------------------------
+    def forward(self, input_ids: torch.Tensor, positions: torch.Tensor, req_pool: torch.Tensor, seq_lens: torch.Tensor,
+                prefix_lens: torch.Tensor, extend_lens: torch.Tensor, out_loc: torch.Tensor, decode: bool
+                ) -> torch.Tensor:
+        cfg, w = self.cfg, self.w
+        D, Hq, Hkv = cfg.head_dim, cfg.num_attention_heads, cfg.num_key_value_heads
+        h = F.embedding(input_ids, w["embed_tokens"])
+        residual = None
+        for i in range(cfg.num_hidden_layers):
+            p = f"layers.{i}."
+            if residual is None:
+                residual = h
+                h = ops.rmsnorm(h, w[p + "input_layernorm.weight"], cfg.rms_norm_eps)
+            else:
+                h, residual = ops.fused_add_rmsnorm(h, residual, w[p + "input_layernorm.weight"], cfg.rms_norm_eps)
+            qkv = F.linear(h, w[p + "self_attn.qkv_proj.weight"], w.get(p + "self_attn.qkv_proj.bias"))
+            q, k, v = qkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1)
+            q, k = ops.rotary_embedding(positions, q, k, D, self.rope_cache, True)
+            ops.store_kv(k.reshape(-1, Hkv, D), v.reshape(-1, Hkv, D), self.k_cache[i], self.v_cache[i], out_loc)
+            q3 = q.reshape(-1, Hq, D)
+            if decode:
+                o = ops.decode_attention(q3, self.k_cache[i], self.v_cache[i], self.req_to_token, req_pool, seq_lens,
+                                         D ** -0.5, self.compute_dtype)
+            else:
+                o = ops.extend_attention(q3, self.k_cache[i], self.v_cache[i], self.req_to_token, req_pool, seq_lens,
+                                         prefix_lens, extend_lens, D ** -0.5, True, self.compute_dtype)
+            h = F.linear(o.reshape(-1, Hq * D), w[p + "self_attn.o_proj.weight"])
+            h, residual = ops.fused_add_rmsnorm(h, residual, w[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps)
+            if cfg.num_local_experts > 0:
+                logits = F.linear(h, w[p + "mlp.gate.weight"])
+                tw, ti = ops.fused_topk(logits, cfg.num_experts_per_tok, True)
+                h = ops.moe_forward(h, w[p + "mlp.experts.w13_weight"], w[p + "mlp.experts.w2_weight"], tw, ti)
+            else:
+                gu = F.linear(h, w[p + "mlp.gate_up_proj.weight"])
+                h = F.linear(ops.silu_and_mul(gu), w[p + "mlp.down_proj.weight"])
+        h, _ = ops.fused_add_rmsnorm(h, residual, w["norm.weight"], cfg.rms_norm_eps)
+        if not decode:
+            last = torch.cumsum(extend_lens, 0) - 1
+            h = h[last]
+        return F.linear(h, w["lm_head"]).float()
+
+    # ---- greedy generation with prefix reuse expressed the plain way ------------------------
+    def generate(self, prompts: Sequence[Sequence[int]], max_new_tokens: int, return_logits: bool = False,
+                 forced: Optional[Sequence[Sequence[int]]] = None):
+        """Every request gets its own fresh slots (no sharing): the reference result the
+        radix-cached run must reproduce.  `forced[b][i]` (teacher forcing) replaces the
+        oracle's own i-th sampled token as the next input, so logits can be compared
+        step by step against a run whose argmax flipped on a near-tie."""
+        B = len(prompts)
+        req_pool = torch.arange(1, B + 1)
+        lens = torch.tensor([len(p) for p in prompts])
+        T = int(lens.sum())
+        out_loc = torch.arange(self.next_slot, self.next_slot + T)
+        self.next_slot += T
+        off = 0
+        for b in range(B):
+            self.req_to_token[b + 1, : lens[b]] = out_loc[off: off + lens[b]].to(torch.int32)
+            off += int(lens[b])
+        ids = torch.tensor([t for p in prompts for t in p])
+        pos = torch.cat([torch.arange(0, int(n)) for n in lens])
+        zeros = torch.zeros(B, dtype=torch.int64)
+        logits = self.forward(ids, pos, req_pool, lens, zeros, lens, out_loc, decode=False)
+        all_logits = [logits]
+        outs = [[int(t)] for t in logits.argmax(-1)]
+        fed = [[forced[b][0]] if forced is not None else [outs[b][0]] for b in range(B)]
+        seq = lens.clone()
+        for _ in range(max_new_tokens - 1):
+            loc = torch.arange(self.next_slot, self.next_slot + B)
+            self.next_slot += B
+            self.req_to_token[req_pool, seq] = loc.to(torch.int32)
+            seq = seq + 1
+            last = torch.tensor([f[-1] for f in fed])
+            logits = self.forward(last, seq - 1, req_pool, seq, None, None, loc, decode=True)
+            all_logits.append(logits)
+            for b, (o, t) in enumerate(zip(outs, logits.argmax(-1))):
+                o.append(int(t))
+                fed[b].append(forced[b][len(fed[b])] if forced is not None else int(t))
+        return (outs, all_logits) if return_logits else outs
+
+
+def weights_from_product_model(model) -> Dict[str, torch.Tensor]:
+    """Collect the product model's (TP=1) parameters under oracle names."""
+    w = {"embed_tokens": model.embed_tokens.data, "norm.weight": model.norm.weight.data, "lm_head": model.lm_head.data}
+    for i, layer in enumerate(model.layers):
+        p = f"layers.{i}."
+        w[p + "input_layernorm.weight"] = layer.input_layernorm.weight.data
+        w[p + "post_attention_layernorm.weight"] = layer.post_attention_layernorm.weight.data
+        w[p + "self_attn.qkv_proj.weight"] = layer.self_attn.qkv_proj.weight.data
+        if layer.self_attn.qkv_proj.bias is not None:
+            w[p + "self_attn.qkv_proj.bias"] = layer.self_attn.qkv_proj.bias.data
+        w[p + "self_attn.o_proj.weight"] = layer.self_attn.o_proj.weight.data
+        mlp = layer.mlp
+        if hasattr(mlp, "gate_up_proj"):
+            w[p + "mlp.gate_up_proj.weight"] = mlp.gate_up_proj.weight.data
+            w[p + "mlp.down_proj.weight"] = mlp.down_proj.weight.data
+        else:
+            w[p + "mlp.gate.weight"] = mlp.gate.weight.data
+            w[p + "mlp.experts.w13_weight"] = mlp.experts.w13_weight.data
+            w[p + "mlp.experts.w2_weight"] = mlp.experts.w2_weight.data
+    return {k: v.detach().cpu() for k, v in w.items()}

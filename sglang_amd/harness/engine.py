@@ -1,0 +1,283 @@
+"""ModelRunner + a minimal scheduler loop that drives the hot path the way the
+reference scheduler does (call stacks B/C/E):
+
+  prefill : RadixCache.match_prefix -> inc_lock_ref -> alloc_for_extend
+            (req slots, KV slots with eviction, write_req_to_token) ->
+            ForwardBatch.init_new -> model.forward -> Sampler ->
+            RadixCache.cache_unfinished_req
+  decode  : alloc_for_decode -> (hipGraph replay | eager forward) -> Sampler
+  finish  : RadixCache.cache_finished_req -> ReqToTokenPool.free
+
+Reference files: srt/managers/scheduler.py:3225-3711 (batching), schedule_batch.py:2378,
+3060 (prepare_for_extend / prepare_for_decode), mem_cache/allocation.py:281-381,512-560,
+model_executor/model_runner.py:1520-1792.  The real scheduler (zmq, tokenizer,
+policies) is out of scope; this file is the harness that feeds the same data
+structures with the same call order.
+"""
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Optional, Sequence
+
+import torch
+
+from .. import kernels
+from ..distributed import parallel_state as ps
+from ..layers.attention.hip_backend import HipAttnBackend
+from ..layers.sampler import Sampler, SamplingBatchInfo, create_sampler
+from ..mem_cache.allocator import PagedTokenToKVPoolAllocator, TokenToKVPoolAllocator
+from ..mem_cache.memory_pool import MHATokenToKVPool, ReqToTokenPool
+from ..mem_cache.radix_cache import EvictParams, MatchPrefixParams, RadixCache, RadixKey
+from ..model_executor.forward_batch_info import ForwardBatch, ForwardMode
+from ..model_executor.graph_runner import DecodeGraphRunner
+from .models import CONFIGS, CausalLM, ModelConfig
+
+
+@dataclass
+class Req:
+    """The fields of srt/managers/schedule_batch.py Req that the cache / pools touch."""
+
+    rid: int
+    origin_input_ids: List[int]
+    max_new_tokens: int
+    output_ids: List[int] = field(default_factory=list)
+    req_pool_idx: Optional[int] = None
+    prefix_indices: Optional[torch.Tensor] = None
+    last_node: Any = None
+    cache_protected_len: int = 0
+    extra_key: Optional[str] = None
+    cache_salt: Optional[str] = None
+    priority: int = 0
+    # timing (TTFT)
+    t_arrive: float = 0.0
+    t_first_token: float = 0.0
+    cached_tokens: int = 0
+
+    def get_fill_ids(self) -> List[int]:
+        return self.origin_input_ids + self.output_ids
+
+    @property
+    def seqlen(self) -> int:
+        return len(self.origin_input_ids) + len(self.output_ids)
+
+    def finished(self) -> bool:
+        return len(self.output_ids) >= self.max_new_tokens
+
+
+class ModelRunner:
+    def __init__(self, config: ModelConfig, *, max_total_tokens: int, max_running_requests: int,
+                 max_context_len: int, page_size: int = 1, device=None, init_device=None,
+                 use_graph: bool = True, graph_max_bs: Optional[int] = None, disable_radix_cache: bool = False):
+        self.config = config
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.tp_rank = ps.get_tensor_model_parallel_rank()
+        self.tp_size = ps.get_tensor_model_parallel_world_size()
+        self.page_size = page_size
+        self.model = CausalLM(config, self.device, init_device, self.tp_rank, self.tp_size)
+        self.num_attention_heads_per_rank = self.model.num_attention_heads_per_rank
+        self.num_kv_heads_per_rank = self.model.num_kv_heads_per_rank
+        self.head_dim = config.head_dim
+        # pools (model_runner.py:822 alloc_memory_pool)
+        self.req_to_token_pool = ReqToTokenPool(max_running_requests, max_context_len, self.device)
+        size = max_total_tokens // page_size * page_size
+        self.token_to_kv_pool = MHATokenToKVPool(size, page_size, torch.bfloat16, self.num_kv_heads_per_rank,
+                                                 config.head_dim, config.num_hidden_layers, self.device)
+        if page_size == 1:
+            self.token_to_kv_pool_allocator = TokenToKVPoolAllocator(size, torch.bfloat16, self.device,
+                                                                     self.token_to_kv_pool)
+        else:
+            self.token_to_kv_pool_allocator = PagedTokenToKVPoolAllocator(size, page_size, torch.bfloat16,
+                                                                          self.device, self.token_to_kv_pool)
+        self.tree_cache = RadixCache(self.req_to_token_pool, self.token_to_kv_pool_allocator, page_size,
+                                     disable=disable_radix_cache)
+        self.attn_backend = HipAttnBackend(self)                      # model_runner.py:942
+        self.sampler: Sampler = create_sampler("hip")                 # model_runner.py:651
+        self.graph_runner = None
+        if use_graph:
+            self.graph_runner = DecodeGraphRunner(self, graph_max_bs or max_running_requests)  # :1007
+
+    # ------------------------------------------------------------------ forward (model_runner.py:1520-1790)
+    def forward(self, fb: ForwardBatch):
+        if fb.forward_mode.is_decode() and self.graph_runner is not None and self.graph_runner.can_run(fb.batch_size):
+            return self.graph_runner.replay(fb)
+        self.attn_backend.init_forward_metadata(fb)
+        return self.model.forward(fb.input_ids, fb.positions, fb)
+
+    def sample(self, logits_output, fb: ForwardBatch) -> torch.Tensor:
+        info = fb.sampling_info or SamplingBatchInfo.greedy(fb.batch_size, self.device)
+        pos = fb.positions if fb.forward_mode.is_decode() else None
+        if pos is None and info.sampling_seed is not None:
+            pos = (fb.seq_lens - 1).to(torch.int64)
+        return self.sampler(logits_output, info, positions=pos)
+
+
+class Engine:
+    """Runs batches of requests to completion (prefill then decode), like one TP
+    rank's scheduler process.  All ranks run it in lock-step with identical inputs."""
+
+    def __init__(self, runner: ModelRunner):
+        self.r = runner
+        self.device = runner.device
+        self.running: List[Req] = []
+        self.stats: Dict[str, float] = {}
+        self.logits_trace: Optional[List[torch.Tensor]] = None   # tests: set to [] to record every step's logits
+
+    # ---- KV slot allocation with eviction (allocation.py:150-279 alloc_token_slots) ----
+    def _alloc_token_slots(self, n: int) -> torch.Tensor:
+        alloc, tree = self.r.token_to_kv_pool_allocator, self.r.tree_cache
+        if alloc.available_size() < n:
+            tree.evict(EvictParams(num_tokens=n - alloc.available_size()))
+        out = alloc.alloc(n)
+        if out is None:
+            raise RuntimeError(f"out of KV slots: need {n}, available {alloc.available_size()}, "
+                               f"evictable {tree.evictable_size()}")
+        return out
+
+    # ---- prefill (scheduler.py:3225 get_new_batch_prefill + schedule_batch.py:2378) ----
+    def prefill(self, reqs: Sequence[Req], sampling_info: Optional[SamplingBatchInfo] = None) -> torch.Tensor:
+        r, dev, ps_ = self.r, self.device, self.r.page_size
+        tree = r.tree_cache
+        for q in reqs:
+            # match against at most len-1 tokens so at least one token is computed (schedule_policy.py:138)
+            key = RadixKey(q.origin_input_ids[: len(q.origin_input_ids) - 1], q.extra_key, q.cache_salt)
+            m = tree.match_prefix(MatchPrefixParams(key=key))
+            q.prefix_indices, q.last_node = m.device_indices, m.last_device_node
+            q.cached_tokens = int(m.device_indices.numel())
+            q.cache_protected_len = q.cached_tokens
+            tree.inc_lock_ref(q.last_node)
+        if r.req_to_token_pool.alloc(reqs) is None:
+            raise RuntimeError("out of request slots")
+        prefix_lens = [int(q.prefix_indices.numel()) for q in reqs]
+        seq_lens = [len(q.origin_input_ids) for q in reqs]
+        extend_lens = [s - p for s, p in zip(seq_lens, prefix_lens)]
+        T = sum(extend_lens)
+        req_pool_cpu = torch.tensor([q.req_pool_idx for q in reqs], dtype=torch.int64)
+        prefix_cpu = torch.tensor(prefix_lens, dtype=torch.int64)
+        seq_cpu = torch.tensor(seq_lens, dtype=torch.int64)
+        ext_cpu = torch.tensor(extend_lens, dtype=torch.int64)
+        req_pool_dev = req_pool_cpu.to(dev, non_blocking=True)
+        prefix_dev, seq_dev, ext_dev = (t.to(dev, non_blocking=True) for t in (prefix_cpu, seq_cpu, ext_cpu))
+        # alloc_for_extend (allocation.py:281-381)
+        if ps_ == 1:
+            out_cache_loc = self._alloc_token_slots(T)
+        else:
+            alloc = r.token_to_kv_pool_allocator
+            need_pages = sum((s + ps_ - 1) // ps_ - (p + ps_ - 1) // ps_ for s, p in zip(seq_lens, prefix_lens))
+            if len(alloc.free_pages) < need_pages:
+                tree.evict(EvictParams(num_tokens=(need_pages - len(alloc.free_pages)) * ps_))
+            last_loc = torch.cat([(q.prefix_indices[-1:] if q.prefix_indices.numel() > 0
+                                   else torch.full((1,), -1, dtype=torch.int64, device=dev)) for q in reqs])
+            out_cache_loc = alloc.alloc_extend(prefix_dev, prefix_cpu, seq_dev, seq_cpu, last_loc, T, need_pages)
+            if out_cache_loc is None:
+                raise RuntimeError("out of KV pages")
+        # write_cache_indices (allocation.py:54-103) as one gfx950 kernel
+        prefix_ptrs = torch.tensor([q.prefix_indices.data_ptr() if q.prefix_indices.numel() else 0 for q in reqs],
+                                   dtype=torch.int64).to(dev, non_blocking=True)
+        kernels.write_req_to_token(r.req_to_token_pool.req_to_token, req_pool_dev, prefix_ptrs, prefix_dev, seq_dev,
+                                   ext_dev, out_cache_loc)
+        input_ids = torch.tensor([t for q, p in zip(reqs, prefix_lens) for t in q.origin_input_ids[p:]],
+                                 dtype=torch.int64).to(dev, non_blocking=True)
+        fb = ForwardBatch.init_new(forward_mode=ForwardMode.EXTEND, input_ids=input_ids, req_pool_indices=req_pool_dev,
+                                   seq_lens=seq_dev.to(torch.int32), out_cache_loc=out_cache_loc, seq_lens_cpu=seq_cpu,
+                                   req_to_token_pool=r.req_to_token_pool, token_to_kv_pool=r.token_to_kv_pool,
+                                   attn_backend=r.attn_backend, extend_prefix_lens_cpu=prefix_lens,
+                                   extend_seq_lens_cpu=extend_lens, sampling_info=sampling_info)
+        logits = r.forward(fb)
+        if self.logits_trace is not None:
+            self.logits_trace.append(logits.next_token_logits.float().cpu())
+        next_ids = r.sample(logits, fb)
+        ids_cpu = next_ids.tolist()                  # the scheduler's one sync per step
+        now = time.perf_counter()
+        for q, t in zip(reqs, ids_cpu):
+            q.output_ids.append(int(t))
+            q.t_first_token = now
+            # process_batch_result_prefill -> cache_unfinished_req (batch_result_processor.py:240)
+            saved = q.output_ids
+            q.output_ids = []                        # fill_ids = prompt only: the new token has no KV yet
+            tree.cache_unfinished_req(q)
+            q.output_ids = saved
+        self.running.extend(reqs)
+        return next_ids
+
+    # ---- decode (scheduler.py:3566 update_running_batch + schedule_batch.py:3060) ----
+    def decode_step(self, sampling_info: Optional[SamplingBatchInfo] = None) -> torch.Tensor:
+        r, dev, ps_ = self.r, self.device, self.r.page_size
+        reqs = self.running
+        bs = len(reqs)
+        st = self._decode_state
+        if st is None or st["bs"] != bs:
+            st = self._decode_state = self._build_decode_state(reqs)
+        # alloc_for_decode (allocation.py:512-560): one slot per request, written at column seq_len
+        if ps_ == 1:
+            out_cache_loc = self._alloc_token_slots(bs)
+        else:
+            last_loc = r.req_to_token_pool.req_to_token[st["req_pool"], (st["seq_lens"] - 1).long()].to(torch.int64)
+            alloc = r.token_to_kv_pool_allocator
+            if len(alloc.free_pages) < bs:
+                r.tree_cache.evict(EvictParams(num_tokens=bs * ps_))
+            out_cache_loc = alloc.alloc_decode((st["seq_lens"] + 1).to(torch.int64), st["seq_lens_cpu"] + 1, last_loc)
+            if out_cache_loc is None:
+                raise RuntimeError("out of KV pages")
+        r.req_to_token_pool.req_to_token[st["req_pool"], st["seq_lens"].long()] = out_cache_loc.to(torch.int32)
+        st["seq_lens"] += 1
+        st["seq_lens_cpu"] += 1
+        fb = ForwardBatch(forward_mode=ForwardMode.DECODE, batch_size=bs, input_ids=st["last_ids"],
+                          req_pool_indices=st["req_pool"], seq_lens=st["seq_lens"], out_cache_loc=out_cache_loc,
+                          seq_lens_sum=int(st["seq_lens_cpu"].sum()), seq_lens_cpu=st["seq_lens_cpu"],
+                          req_to_token_pool=r.req_to_token_pool, token_to_kv_pool=r.token_to_kv_pool,
+                          attn_backend=r.attn_backend, sampling_info=sampling_info)
+        if r.graph_runner is None or not r.graph_runner.can_run(bs):
+            fb.positions = kernels.clamp_position(fb.seq_lens)
+        logits = r.forward(fb)
+        if self.logits_trace is not None:
+            self.logits_trace.append(logits.next_token_logits.float().cpu())
+        next_ids = r.sample(logits, fb)
+        st["last_ids"] = next_ids.to(torch.int64)
+        st["pending"].append(next_ids)
+        return next_ids
+
+    def _build_decode_state(self, reqs: Sequence[Req]):
+        dev = self.device
+        seq = [q.seqlen - 1 for q in reqs]   # KV rows present: every token except the newest sampled one
+        return dict(bs=len(reqs), req_pool=torch.tensor([q.req_pool_idx for q in reqs], dtype=torch.int64, device=dev),
+                    seq_lens=torch.tensor(seq, dtype=torch.int32, device=dev),
+                    seq_lens_cpu=torch.tensor(seq, dtype=torch.int64),
+                    last_ids=torch.tensor([q.output_ids[-1] for q in reqs], dtype=torch.int64, device=dev),
+                    pending=[])
+
+    _decode_state = None
+
+    def flush_decode_outputs(self) -> None:
+        """Bring the sampled ids of the steps since the last flush to the host (one sync)."""
+        st = self._decode_state
+        if not st or not st["pending"]:
+            return
+        ids = torch.stack(st["pending"]).tolist()
+        st["pending"] = []
+        for step in ids:
+            for q, t in zip(self.running, step):
+                q.output_ids.append(int(t))
+
+    # ---- finish (batch_result_processor.py:863 -> mem_cache/common.py:198 release_kv_cache) ----
+    def finish(self, reqs: Sequence[Req]) -> None:
+        self.flush_decode_outputs()
+        tree, pool = self.r.tree_cache, self.r.req_to_token_pool
+        for q in reqs:
+            # the last sampled token has no KV row: handle seqlen-1 rows
+            tree.cache_finished_req(q, kv_len_to_handle=q.seqlen - 1)
+            pool.free(q)
+        done = set(id(q) for q in reqs)
+        self.running = [q for q in self.running if id(q) not in done]
+        self._decode_state = None
+
+    # ---- convenience: run a set of requests to completion ---------------------------------
+    def generate(self, reqs: Sequence[Req], sampling_info: Optional[SamplingBatchInfo] = None,
+                 sync_every: int = 0) -> None:
+        self.prefill(reqs, sampling_info)
+        steps = max(q.max_new_tokens for q in reqs) - 1
+        for i in range(steps):
+            self.decode_step(sampling_info)
+            if sync_every and (i + 1) % sync_every == 0:
+                self.flush_decode_outputs()
+        self.finish(list(self.running))

@@ -1,0 +1,255 @@
+"""Synthetic-weight decoder models at the BASELINE configs' shapes, wired exactly like
+the reference models: /root/reference/python/sglang/srt/models/llama.py:70-500
+(LlamaMLP :70, LlamaAttention :138-223, LlamaDecoderLayer :283-370, LlamaModel :372,
+LlamaForCausalLM :496), qwen2.py (qkv bias, tied embeddings), mixtral.py:60-118.
+
+Only the operator calls differ: every non-GEMM op goes to the gfx950 kernels
+through the layers in sglang_amd/layers, the GEMMs go to hipBLASLt through
+torch (library GEMMs are allowed for plain projections).  Weights are
+random-init (there are no checkpoints offline): N(0, 0.02^2) bf16, norm weights 1
+-- the `--load-format dummy` equivalent.
+"""
+from __future__ import annotations
+
+import zlib
+from dataclasses import dataclass, field
+from typing import Any, Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ..distributed import parallel_state as ps
+from ..layers.activation import SiluAndMul
+from ..layers.layernorm import RMSNorm
+from ..layers.radix_attention import RadixAttention
+from ..layers.rotary_embedding import FusedSetKVBufferArg, get_rope
+from ..layers.sampler import LogitsProcessorOutput
+
+BF = torch.bfloat16
+
+
+@dataclass
+class ModelConfig:
+    name: str
+    hidden_size: int
+    intermediate_size: int
+    num_hidden_layers: int
+    num_attention_heads: int
+    num_key_value_heads: int
+    head_dim: int
+    vocab_size: int
+    rms_norm_eps: float = 1e-5
+    rope_theta: float = 500000.0
+    rope_scaling: Optional[Dict[str, Any]] = None
+    max_position_embeddings: int = 8192
+    attention_bias: bool = False
+    tie_word_embeddings: bool = False
+    num_local_experts: int = 0
+    num_experts_per_tok: int = 0
+
+
+_LLAMA3_ROPE = dict(rope_type="llama3", factor=8.0, low_freq_factor=1.0, high_freq_factor=4.0,
+                    original_max_position_embeddings=8192)
+
+CONFIGS: Dict[str, ModelConfig] = {
+    # SURVEY.md section 8 size table
+    "llama-3-8b": ModelConfig("llama-3-8b", 4096, 14336, 32, 32, 8, 128, 128256, 1e-5, 500000.0, None, 8192),
+    "llama-3-70b": ModelConfig("llama-3-70b", 8192, 28672, 80, 64, 8, 128, 128256, 1e-5, 500000.0, None, 8192),
+    "qwen2.5-0.5b": ModelConfig("qwen2.5-0.5b", 896, 4864, 24, 14, 2, 64, 151936, 1e-6, 1000000.0, None, 32768,
+                                attention_bias=True, tie_word_embeddings=True),
+    "mixtral-8x7b": ModelConfig("mixtral-8x7b", 4096, 14336, 32, 32, 8, 128, 32000, 1e-5, 1000000.0, None, 32768,
+                                num_local_experts=8, num_experts_per_tok=2),
+    # small shapes for tests / smoke
+    "tiny-llama": ModelConfig("tiny-llama", 256, 512, 2, 8, 2, 64, 1024, 1e-5, 10000.0, None, 2048),
+    "tiny-qwen": ModelConfig("tiny-qwen", 128, 384, 2, 4, 2, 64, 768, 1e-6, 10000.0, None, 2048,
+                             attention_bias=True, tie_word_embeddings=True),
+    "tiny-llama3-rope": ModelConfig("tiny-llama3-rope", 256, 512, 2, 4, 1, 128, 512, 1e-5, 500000.0, _LLAMA3_ROPE, 4096),
+    "tiny-mixtral": ModelConfig("tiny-mixtral", 256, 512, 2, 8, 2, 64, 1024, 1e-5, 10000.0, None, 2048,
+                                num_local_experts=8, num_experts_per_tok=2),
+}
+
+
+def _seed_of(name: str) -> int:
+    return zlib.crc32(name.encode()) & 0x7FFFFFFF
+
+
+def synth_weight(name: str, shape, init_device, std: float = 0.02) -> torch.Tensor:
+    """Deterministic per-tensor init: the same (name, shape, init_device) gives the same bits."""
+    g = torch.Generator(device=init_device)
+    g.manual_seed(_seed_of(name))
+    w = torch.randn(shape, generator=g, device=init_device, dtype=torch.float32)
+    return (w * std).to(BF)
+
+
+class Linear(nn.Module):
+    """y = x W^T (+ b), W [out, in] bf16 -- hipBLASLt via torch."""
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor] = None):
+        super().__init__()
+        self.weight = nn.Parameter(weight, requires_grad=False)
+        self.bias = nn.Parameter(bias, requires_grad=False) if bias is not None else None
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return F.linear(x, self.weight, self.bias)
+
+
+def _shard_rows(w: torch.Tensor, rank: int, world: int) -> torch.Tensor:
+    n = w.shape[0] // world
+    return w[rank * n:(rank + 1) * n].contiguous()
+
+
+def _shard_cols(w: torch.Tensor, rank: int, world: int) -> torch.Tensor:
+    n = w.shape[1] // world
+    return w[:, rank * n:(rank + 1) * n].contiguous()
+
+
+class LlamaMLP(nn.Module):
+    def __init__(self, cfg: ModelConfig, prefix: str, init_device, device, tp_rank: int, tp_size: int):
+        super().__init__()
+        H, I = cfg.hidden_size, cfg.intermediate_size
+        gate = _shard_rows(synth_weight(f"{prefix}.gate_proj", (I, H), init_device), tp_rank, tp_size)
+        up = _shard_rows(synth_weight(f"{prefix}.up_proj", (I, H), init_device), tp_rank, tp_size)
+        down = _shard_cols(synth_weight(f"{prefix}.down_proj", (H, I), init_device), tp_rank, tp_size)
+        self.gate_up_proj = Linear(torch.cat([gate, up], 0).to(device))     # MergedColumnParallelLinear
+        self.down_proj = Linear(down.to(device))                            # RowParallelLinear
+        self.act_fn = SiluAndMul()
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        x = self.down_proj(self.act_fn(self.gate_up_proj(x)))
+        return ps.tensor_model_parallel_all_reduce(x)
+
+
+class LlamaAttention(nn.Module):
+    def __init__(self, cfg: ModelConfig, layer_id: int, prefix: str, init_device, device, tp_rank: int, tp_size: int):
+        super().__init__()
+        H, D = cfg.hidden_size, cfg.head_dim
+        self.total_q, self.total_kv = cfg.num_attention_heads, cfg.num_key_value_heads
+        assert self.total_q % tp_size == 0
+        self.num_heads = self.total_q // tp_size
+        # KV heads are split, or replicated when there are fewer than TP ranks (llama.py:160-171)
+        self.num_kv_heads = max(1, self.total_kv // tp_size)
+        kv_rank = tp_rank * self.total_kv // tp_size if self.total_kv >= tp_size else tp_rank // (tp_size // self.total_kv)
+        self.head_dim = D
+        self.q_size, self.kv_size = self.num_heads * D, self.num_kv_heads * D
+        wq = synth_weight(f"{prefix}.q_proj", (self.total_q * D, H), init_device)
+        wk = synth_weight(f"{prefix}.k_proj", (self.total_kv * D, H), init_device)
+        wv = synth_weight(f"{prefix}.v_proj", (self.total_kv * D, H), init_device)
+        q = wq[tp_rank * self.q_size:(tp_rank + 1) * self.q_size]
+        if self.total_kv >= tp_size:
+            k = wk[tp_rank * self.kv_size:(tp_rank + 1) * self.kv_size]
+            v = wv[tp_rank * self.kv_size:(tp_rank + 1) * self.kv_size]
+        else:
+            k = wk[kv_rank * D:(kv_rank + 1) * D]
+            v = wv[kv_rank * D:(kv_rank + 1) * D]
+        bias = None
+        if cfg.attention_bias:
+            bq = synth_weight(f"{prefix}.q_bias", (self.total_q * D,), init_device)
+            bk = synth_weight(f"{prefix}.k_bias", (self.total_kv * D,), init_device)
+            bv = synth_weight(f"{prefix}.v_bias", (self.total_kv * D,), init_device)
+            if self.total_kv >= tp_size:
+                bks = bk[tp_rank * self.kv_size:(tp_rank + 1) * self.kv_size]
+                bvs = bv[tp_rank * self.kv_size:(tp_rank + 1) * self.kv_size]
+            else:
+                bks, bvs = bk[kv_rank * D:(kv_rank + 1) * D], bv[kv_rank * D:(kv_rank + 1) * D]
+            bias = torch.cat([bq[tp_rank * self.q_size:(tp_rank + 1) * self.q_size], bks, bvs]).to(device)
+        self.qkv_proj = Linear(torch.cat([q, k, v], 0).to(device), bias)    # QKVParallelLinear
+        wo = synth_weight(f"{prefix}.o_proj", (H, self.total_q * D), init_device)
+        self.o_proj = Linear(_shard_cols(wo, tp_rank, tp_size).to(device))  # RowParallelLinear
+        self.rotary_emb = get_rope(D, D, cfg.max_position_embeddings, cfg.rope_theta, True, cfg.rope_scaling, BF, device)
+        self.attn = RadixAttention(self.num_heads, D, D ** -0.5, self.num_kv_heads, layer_id)
+        self.layer_id = layer_id
+
+    def forward(self, positions: torch.Tensor, hidden_states: torch.Tensor, forward_batch) -> torch.Tensor:
+        qkv = self.qkv_proj(hidden_states)
+        q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
+        pool = forward_batch.token_to_kv_pool
+        # rope + KV-row scatter in one kernel (rotary_embedding/base.py:385-417), then attention reads the pool
+        self.rotary_emb(positions, q, k, fused_set_kv_buffer_arg=FusedSetKVBufferArg(
+            value=v, k_buffer=pool.get_key_buffer(self.layer_id), v_buffer=pool.get_value_buffer(self.layer_id),
+            cache_loc=forward_batch.out_cache_loc))
+        attn_output = self.attn(q, k, v, forward_batch, save_kv_cache=False)
+        out = self.o_proj(attn_output)
+        return ps.tensor_model_parallel_all_reduce(out)
+
+
+class LlamaDecoderLayer(nn.Module):
+    def __init__(self, cfg: ModelConfig, layer_id: int, init_device, device, tp_rank: int, tp_size: int):
+        super().__init__()
+        p = f"model.layers.{layer_id}"
+        self.self_attn = LlamaAttention(cfg, layer_id, f"{p}.self_attn", init_device, device, tp_rank, tp_size)
+        if cfg.num_local_experts > 0:
+            from .moe_block import SparseMoeBlock
+
+            self.mlp = SparseMoeBlock(cfg, f"{p}.block_sparse_moe", init_device, device, tp_rank, tp_size)
+        else:
+            self.mlp = LlamaMLP(cfg, f"{p}.mlp", init_device, device, tp_rank, tp_size)
+        self.input_layernorm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps, BF, device)
+        self.post_attention_layernorm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps, BF, device)
+
+    def forward(self, positions, hidden_states, forward_batch, residual) -> Tuple[torch.Tensor, torch.Tensor]:
+        # llama.py:341-370
+        if residual is None:
+            residual = hidden_states
+            hidden_states = self.input_layernorm(hidden_states)
+        else:
+            hidden_states, residual = self.input_layernorm(hidden_states, residual)
+        hidden_states = self.self_attn(positions, hidden_states, forward_batch)
+        hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
+        hidden_states = self.mlp(hidden_states)
+        return hidden_states, residual
+
+
+class CausalLM(nn.Module):
+    """LlamaForCausalLM / Qwen2ForCausalLM / MixtralForCausalLM on one TP rank."""
+
+    def __init__(self, cfg: ModelConfig, device, init_device=None, tp_rank: int = 0, tp_size: int = 1):
+        super().__init__()
+        self.config = cfg
+        self.device = device
+        self.tp_rank, self.tp_size = tp_rank, tp_size
+        init_device = init_device if init_device is not None else device
+        # replicated embedding (the reference shards it over vocab + all-reduce; at
+        # T x hidden the replicated gather is cheaper than a collective on xGMI)
+        self.embed_tokens = nn.Parameter(
+            synth_weight("model.embed_tokens", (cfg.vocab_size, cfg.hidden_size), init_device).to(device),
+            requires_grad=False)
+        self.layers = nn.ModuleList(
+            [LlamaDecoderLayer(cfg, i, init_device, device, tp_rank, tp_size) for i in range(cfg.num_hidden_layers)])
+        self.norm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps, BF, device)
+        if cfg.tie_word_embeddings:
+            head = self.embed_tokens.data
+        else:
+            head = synth_weight("lm_head", (cfg.vocab_size, cfg.hidden_size), init_device).to(device)
+        assert cfg.vocab_size % tp_size == 0
+        n = cfg.vocab_size // tp_size
+        self.lm_head = nn.Parameter(head[tp_rank * n:(tp_rank + 1) * n].contiguous() if tp_size > 1 else head,
+                                    requires_grad=False)                    # vocab-parallel head
+
+    @property
+    def num_attention_heads_per_rank(self) -> int:
+        return self.layers[0].self_attn.num_heads
+
+    @property
+    def num_kv_heads_per_rank(self) -> int:
+        return self.layers[0].self_attn.num_kv_heads
+
+    def forward_hidden(self, input_ids: torch.Tensor, positions: torch.Tensor, forward_batch) -> torch.Tensor:
+        hidden_states = F.embedding(input_ids, self.embed_tokens)
+        residual = None
+        for layer in self.layers:
+            hidden_states, residual = layer(positions, hidden_states, forward_batch, residual)
+        hidden_states, _ = self.norm(hidden_states, residual)
+        return hidden_states
+
+    def compute_logits(self, hidden_states: torch.Tensor, forward_batch) -> LogitsProcessorOutput:
+        """logits_processor.py:652-700: last token of every request, vocab-parallel head + all-gather."""
+        if forward_batch.forward_mode.is_extend():
+            last = torch.cumsum(forward_batch.extend_seq_lens, dim=0, dtype=torch.int64) - 1
+            hidden_states = hidden_states[last]
+        logits = F.linear(hidden_states, self.lm_head)
+        logits = ps.tensor_model_parallel_all_gather(logits, dim=-1)
+        return LogitsProcessorOutput(next_token_logits=logits.float())
+
+    def forward(self, input_ids: torch.Tensor, positions: torch.Tensor, forward_batch) -> LogitsProcessorOutput:
+        return self.compute_logits(self.forward_hidden(input_ids, positions, forward_batch), forward_batch)

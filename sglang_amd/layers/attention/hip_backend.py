@@ -1,0 +1,140 @@
+"""HipAttnBackend: the gfx950 attention backend behind SGLang's AttentionBackend surface.
+
+Takes the place of TritonAttnBackend / TorchNativeAttnBackend
+(/root/reference/python/sglang/srt/layers/attention/triton_backend.py:136-1012,
+torch_native_backend.py:19-398).  Differences that matter on MI355X:
+
+  * no kv_indptr / kv_indices gather per step: the HIP kernels walk
+    req_to_token[req_pool_indices[b], :] directly, so the per-step metadata is
+    just an int32 view of seq_lens (decode) or one tiny qo_indptr (extend);
+    the decode path therefore needs NO out-of-graph refresh besides the
+    ForwardBatch buffers the graph runner already copies -- nothing
+    data-dependent happens on the host inside or around a hipGraph replay;
+  * split-KV count is a static function of (batch bucket, kv heads, context
+    bound), fixed at capture; empty splits exit immediately;
+  * fp32 split workspaces are allocated once (`init_cuda_graph_state`) and
+    owned by the backend, never by the kernels.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from ... import kernels
+from ...mem_cache.memory_pool import KVWriteLoc
+from .base_attn_backend import AttentionBackend
+
+
+@dataclass
+class _Meta:
+    seq_lens_i32: torch.Tensor
+    num_splits: int = 1
+    ws_acc: Optional[torch.Tensor] = None
+    ws_ml: Optional[torch.Tensor] = None
+    qo_indptr: Optional[torch.Tensor] = None
+    prefix_lens_i32: Optional[torch.Tensor] = None
+    max_extend_len: int = 0
+
+
+def choose_num_splits(batch: int, num_kv_heads: int, group: int, max_len: int, target_blocks: int = 512) -> int:
+    """Static split-KV choice: enough workgroups to fill 256 CUs twice, but never
+    chunks shorter than 2 x the kernel's minimum chunk."""
+    head_blocks = max(1, (group + 7) // 8) if group > 4 else 1
+    blocks = max(1, batch * num_kv_heads * head_blocks)
+    want = (target_blocks + blocks - 1) // blocks
+    cap = max(1, max_len // (2 * kernels.decode_min_chunk()))
+    return max(1, min(want, cap, 64))
+
+
+class HipAttnBackend(AttentionBackend):
+    needs_cpu_seq_lens = True
+
+    def __init__(self, model_runner):
+        super().__init__()
+        self.device = model_runner.device
+        self.req_to_token_pool = model_runner.req_to_token_pool
+        self.token_to_kv_pool = model_runner.token_to_kv_pool
+        self.num_q_heads = model_runner.num_attention_heads_per_rank
+        self.num_kv_heads = model_runner.num_kv_heads_per_rank
+        self.head_dim = model_runner.head_dim
+        self.max_context_len = self.req_to_token_pool.max_context_len
+        self.forward_metadata: Optional[_Meta] = None
+        self._graph_ws = {}
+        self.debug_flags = 0
+
+    # ------------------------------------------------------------------ metadata
+    def _workspace(self, batch: int, splits: int):
+        key = (batch, splits)
+        ws = self._graph_ws.get(key)
+        if ws is None:
+            ws = kernels.decode_workspace(batch, self.num_q_heads, self.head_dim, splits, self.device)
+            self._graph_ws[key] = ws
+        return ws
+
+    def init_cuda_graph_state(self, max_bs: int, max_num_tokens: int):
+        """Pre-allocate the split workspaces for the largest bucket (reference :159)."""
+        splits = choose_num_splits(1, self.num_kv_heads, self.num_q_heads // self.num_kv_heads, self.max_context_len)
+        self._workspace(max_bs, max(splits, 1))
+
+    def get_cuda_graph_seq_len_fill_value(self):
+        return 1
+
+    def init_forward_metadata_out_graph(self, forward_batch, in_capture: bool = False):
+        fb = forward_batch
+        seq_i32 = fb.seq_lens if fb.seq_lens.dtype == torch.int32 else fb.seq_lens.to(torch.int32)
+        if fb.forward_mode.is_decode():
+            if in_capture:
+                max_len = self.max_context_len       # the graph must be valid for any later length
+            else:
+                max_len = int(fb.seq_lens_cpu.max()) if fb.seq_lens_cpu is not None else self.max_context_len
+            splits = choose_num_splits(fb.batch_size, self.num_kv_heads, self.num_q_heads // self.num_kv_heads, max_len)
+            ws = self._workspace(fb.batch_size, splits) if splits > 1 else (None, None)
+            self.forward_metadata = _Meta(seq_i32, splits, ws[0], ws[1])
+        elif fb.forward_mode.is_extend():
+            ext = fb.extend_seq_lens_cpu
+            qo = torch.zeros(fb.batch_size + 1, dtype=torch.int32)
+            qo[1:] = torch.cumsum(torch.tensor(ext, dtype=torch.int32), 0)
+            self.forward_metadata = _Meta(seq_i32, qo_indptr=qo.to(self.device, non_blocking=True),
+                                          prefix_lens_i32=fb.extend_prefix_lens.to(torch.int32),
+                                          max_extend_len=max(ext) if ext else 0)
+        else:
+            self.forward_metadata = None
+
+    def init_forward_metadata_in_graph(self, forward_batch):
+        """Nothing to record: the decode kernel reads seq_lens / req_to_token itself."""
+
+    # ------------------------------------------------------------------ forward
+    def _save_kv(self, layer, forward_batch, k, v):
+        self.token_to_kv_pool.set_kv_buffer(layer, KVWriteLoc(forward_batch.out_cache_loc, None), k, v)
+
+    def forward_extend(self, q, k, v, layer, forward_batch, save_kv_cache: bool = True, **kwargs):
+        if save_kv_cache and k is not None and v is not None:
+            self._save_kv(layer, forward_batch, k, v)
+        m = self.forward_metadata
+        q3 = q.view(-1, layer.tp_q_head_num, layer.qk_head_dim)
+        o = torch.empty_like(q3)
+        from ..radix_attention import AttentionType
+
+        causal = not (layer.is_cross_attention or layer.attn_type == AttentionType.ENCODER_ONLY)
+        kernels.extend_attention(q3, o, self.token_to_kv_pool.get_key_buffer(layer.layer_id),
+                                 self.token_to_kv_pool.get_value_buffer(layer.layer_id),
+                                 self.req_to_token_pool.req_to_token, forward_batch.req_pool_indices, m.seq_lens_i32,
+                                 m.prefix_lens_i32, m.qo_indptr, m.max_extend_len, layer.scaling, causal)
+        return o.view(-1, layer.tp_q_head_num * layer.v_head_dim)
+
+    def forward_decode(self, q, k, v, layer, forward_batch, save_kv_cache: bool = True, **kwargs):
+        if save_kv_cache and k is not None and v is not None:
+            self._save_kv(layer, forward_batch, k, v)
+        m = self.forward_metadata
+        q3 = q.reshape(-1, layer.tp_q_head_num, layer.qk_head_dim)
+        o = torch.empty_like(q3)
+        kernels.decode_attention(q3, self.token_to_kv_pool.get_key_buffer(layer.layer_id),
+                                 self.token_to_kv_pool.get_value_buffer(layer.layer_id), o,
+                                 self.req_to_token_pool.req_to_token, forward_batch.req_pool_indices, m.seq_lens_i32,
+                                 layer.scaling, m.num_splits, m.ws_acc, m.ws_ml, flags=self.debug_flags)
+        return o.view(-1, layer.tp_q_head_num * layer.v_head_dim)
+
+    def support_triton(self) -> bool:
+        return False

@@ -1,0 +1,72 @@
+"""Sampler with SGLang's interface (reference:
+/root/reference/python/sglang/srt/layers/sampler.py:71-300, SamplingBatchInfo in
+srt/sampling/sampling_batch_info.py), running the gfx950 sampling kernels."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Any, List, Optional
+
+import torch
+from torch import nn
+
+from .. import kernels
+
+TOP_K_ALL = 1 << 30   # srt/sampling/sampling_params.py:40
+
+
+@dataclass
+class SamplingBatchInfo:
+    temperatures: torch.Tensor            # [B, 1] fp32
+    top_ps: torch.Tensor                  # [B] fp32
+    top_ks: torch.Tensor                  # [B] int32 (TOP_K_ALL = whole vocab)
+    min_ps: torch.Tensor                  # [B] fp32
+    is_all_greedy: bool = True
+    need_top_p_sampling: bool = False
+    need_top_k_sampling: bool = False
+    need_min_p_sampling: bool = False
+    sampling_seed: Optional[torch.Tensor] = None   # [B] int64 -> deterministic gumbel sampling
+
+    @classmethod
+    def greedy(cls, batch: int, device) -> "SamplingBatchInfo":
+        return cls(torch.ones((batch, 1), device=device), torch.ones(batch, device=device),
+                   torch.full((batch,), TOP_K_ALL, dtype=torch.int32, device=device),
+                   torch.zeros(batch, device=device), True)
+
+
+@dataclass
+class LogitsProcessorOutput:
+    next_token_logits: torch.Tensor       # [B, vocab] fp32
+    hidden_states: Optional[torch.Tensor] = None
+
+
+class Sampler(nn.Module):
+    def forward(self, logits_output: LogitsProcessorOutput, sampling_info: SamplingBatchInfo,
+                return_logprob: bool = False, top_logprobs_nums: Optional[List[int]] = None,
+                token_ids_logprobs: Optional[List[List[int]]] = None, positions: Optional[torch.Tensor] = None
+                ) -> torch.Tensor:
+        logits = logits_output.next_token_logits
+        if logits.shape[0] == 0:
+            return torch.empty((0,), dtype=torch.int64, device=logits.device)
+        if return_logprob:
+            raise NotImplementedError("logprob return is outside this path")
+        if sampling_info.is_all_greedy:
+            return kernels.argmax(logits)                                   # sampler.py:133-141
+        probs = kernels.softmax_temperature_(logits, sampling_info.temperatures)   # sampler.py:211-216
+        return kernels.top_k_top_p_min_p_sample(
+            probs, sampling_info.top_ks, sampling_info.top_ps,
+            sampling_info.min_ps if sampling_info.need_min_p_sampling else None,
+            sampling_info.sampling_seed, positions)
+
+
+_SAMPLER_BACKENDS = {"hip": lambda: Sampler()}
+
+
+def register_sampler_backend(name: str, factory) -> None:
+    """sampler.py:531-542."""
+    _SAMPLER_BACKENDS[name] = factory
+
+
+def create_sampler(backend: str = "hip") -> Sampler:
+    if backend not in _SAMPLER_BACKENDS:
+        raise ValueError(f"Unknown sampling backend '{backend}'. Register it via register_sampler_backend().")
+    return _SAMPLER_BACKENDS[backend]()

