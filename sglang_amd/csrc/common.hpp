@@ -25,6 +25,11 @@ void set_last_error(const char* fmt, ...);
     }                                            \
   } while (0)
 
+// hipGetLastError() is per-thread and sticky: another HIP user in the process (torch)
+// may have left a benign error behind.  Every entry point clears it first so that
+// SGL_CHECK_LAUNCH only reports errors of our own launches.
+#define SGL_CLEAR_STALE_ERROR() (void)hipGetLastError()
+
 #define SGL_CHECK_LAUNCH(name)                                              \
   do {                                                                      \
     hipError_t e__ = hipGetLastError();                                     \

@@ -380,7 +380,8 @@ int dispatch_group(const DecodeParams& p, int batch, int group_size, bool use_dp
 
 extern "C" {
 
-int sgl_amd_decode_attention_min_chunk(void) { return 128; }
+int sgl_amd_decode_attention_min_chunk(void) {
+  SGL_CLEAR_STALE_ERROR(); return 128; }
 
 int sgl_amd_decode_attention(const void* q, const void* k_cache, const void* v_cache, void* out,
                              const int32_t* req_to_token, int64_t req_to_token_stride,
@@ -390,6 +391,7 @@ int sgl_amd_decode_attention(const void* q, const void* k_cache, const void* v_c
                              int64_t out_token_stride, int64_t k_cache_row_stride,
                              int64_t v_cache_row_stride, float sm_scale, int num_splits,
                              void* ws_acc, void* ws_ml, int flags, void* stream) {
+  SGL_CLEAR_STALE_ERROR();
   SGL_CHECK_ARG(head_dim == 64 || head_dim == 128 || head_dim == 256,
                 "decode_attention: head_dim=%d not supported (64/128/256)", head_dim);
   SGL_CHECK_ARG(num_kv_heads > 0 && num_q_heads % num_kv_heads == 0,

@@ -210,6 +210,7 @@ extern "C" {
 
 int sgl_amd_rmsnorm(const void* x, const void* weight, void* out, int64_t num_rows, int hidden,
                     int64_t x_row_stride, int64_t out_row_stride, float eps, void* stream) {
+  SGL_CLEAR_STALE_ERROR();
   SGL_CHECK_ARG(hidden > 0 && hidden % 8 == 0, "rmsnorm: hidden=%d must be a positive multiple of 8", hidden);
   SGL_CHECK_ARG(x_row_stride % 8 == 0 && out_row_stride % 8 == 0, "rmsnorm: row strides must be multiples of 8 elements");
   SGL_CHECK_ARG(aligned16(x) && aligned16(weight) && aligned16(out), "rmsnorm: pointers must be 16-byte aligned");
@@ -226,6 +227,7 @@ int sgl_amd_rmsnorm(const void* x, const void* weight, void* out, int64_t num_ro
 int sgl_amd_fused_add_rmsnorm(void* x, void* residual, const void* weight, int64_t num_rows,
                               int hidden, int64_t x_row_stride, int64_t res_row_stride, float eps,
                               void* stream) {
+  SGL_CLEAR_STALE_ERROR();
   SGL_CHECK_ARG(hidden > 0 && hidden % 8 == 0, "fused_add_rmsnorm: hidden=%d must be a positive multiple of 8", hidden);
   SGL_CHECK_ARG(x_row_stride % 8 == 0 && res_row_stride % 8 == 0, "fused_add_rmsnorm: row strides must be multiples of 8 elements");
   SGL_CHECK_ARG(aligned16(x) && aligned16(weight) && aligned16(residual), "fused_add_rmsnorm: pointers must be 16-byte aligned");
@@ -242,6 +244,7 @@ int sgl_amd_fused_add_rmsnorm(void* x, void* residual, const void* weight, int64
 
 int sgl_amd_silu_and_mul(const void* in, void* out, int64_t num_rows, int d, int64_t in_row_stride,
                          int64_t out_row_stride, int round_intermediate, void* stream) {
+  SGL_CLEAR_STALE_ERROR();
   SGL_CHECK_ARG(d > 0 && d % 8 == 0, "silu_and_mul: d=%d must be a positive multiple of 8", d);
   SGL_CHECK_ARG(in_row_stride % 8 == 0 && out_row_stride % 8 == 0, "silu_and_mul: row strides must be multiples of 8 elements");
   SGL_CHECK_ARG(aligned16(in) && aligned16(out), "silu_and_mul: pointers must be 16-byte aligned");
@@ -273,6 +276,7 @@ int sgl_amd_rotary_embedding(const int64_t* positions, void* q, void* k, const v
                              int64_t k_token_stride, int is_neox, const void* v,
                              int64_t v_token_stride, void* k_cache, void* v_cache,
                              const int64_t* cache_loc, int64_t cache_row_stride, void* stream) {
+  SGL_CLEAR_STALE_ERROR();
   SGL_CHECK_ARG(rot_dim > 0 && rot_dim % 2 == 0 && rot_dim <= head_dim, "rotary_embedding: bad rot_dim=%d head_dim=%d", rot_dim, head_dim);
   const bool fused = k_cache != nullptr;
   if (fused) {
@@ -308,6 +312,7 @@ int sgl_amd_store_kv_cache(const void* k, const void* v, void* k_cache, void* v_
                            const int64_t* loc, int64_t num_tokens, int k_row_elems,
                            int v_row_elems, int64_t k_token_stride, int64_t v_token_stride,
                            int64_t k_cache_row_stride, int64_t v_cache_row_stride, void* stream) {
+  SGL_CLEAR_STALE_ERROR();
   SGL_CHECK_ARG(k_row_elems % 8 == 0 && v_row_elems % 8 == 0, "store_kv_cache: row sizes must be multiples of 8 elements (16 B)");
   SGL_CHECK_ARG(k_token_stride % 8 == 0 && v_token_stride % 8 == 0 && k_cache_row_stride % 8 == 0 && v_cache_row_stride % 8 == 0,
                 "store_kv_cache: strides must be multiples of 8 elements");

@@ -332,6 +332,7 @@ int sgl_amd_extend_attention(const void* q, void* out, const void* k_cache, cons
                              int64_t q_token_stride, int64_t out_token_stride,
                              int64_t k_cache_row_stride, int64_t v_cache_row_stride, float sm_scale,
                              int causal, void* stream) {
+  SGL_CLEAR_STALE_ERROR();
   SGL_CHECK_ARG(head_dim == 64 || head_dim == 128, "extend_attention: head_dim=%d not supported (64/128)", head_dim);
   SGL_CHECK_ARG(num_kv_heads > 0 && num_q_heads % num_kv_heads == 0,
                 "extend_attention: num_q_heads=%d not a multiple of num_kv_heads=%d", num_q_heads, num_kv_heads);
@@ -372,6 +373,7 @@ int sgl_amd_extend_attention(const void* q, void* out, const void* k_cache, cons
 }
 
 int sgl_amd_probe_mfma_16x16x32(const void* a, const void* b, void* c, void* stream) {
+  SGL_CLEAR_STALE_ERROR();
   hipLaunchKernelGGL(mfma_probe_kernel, dim3(1), dim3(64), 0, as_stream(stream),
                      static_cast<const uint16_t*>(a), static_cast<const uint16_t*>(b),
                      static_cast<float*>(c));

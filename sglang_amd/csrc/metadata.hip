@@ -174,6 +174,7 @@ int sgl_amd_create_kv_indices(const int32_t* req_to_token, int64_t req_to_token_
                               const int32_t* kernel_lens, const int32_t* kv_indptr,
                               const int32_t* kv_start_idx, void* kv_indices, int kv_indices_is_i64,
                               int64_t batch, void* stream) {
+  SGL_CLEAR_STALE_ERROR();
   SGL_CHECK_ARG(batch <= 0x7fffffffLL, "create_kv_indices: batch too large");
   if (batch == 0) return 0;
   const int64_t* r64 = req_pool_indices_is_i64 ? static_cast<const int64_t*>(req_pool_indices) : nullptr;
@@ -196,6 +197,7 @@ int sgl_amd_write_req_to_token(int32_t* req_to_token, int64_t req_to_token_strid
                                const int64_t* prefix_lens, const int64_t* seq_lens,
                                const int64_t* extend_lens, const int64_t* out_cache_loc,
                                int64_t batch, void* stream) {
+  SGL_CLEAR_STALE_ERROR();
   SGL_CHECK_ARG(batch <= 0x7fffffffLL, "write_req_to_token: batch too large");
   if (batch == 0) return 0;
   hipLaunchKernelGGL(write_req_to_token_kernel, dim3(batch), dim3(256), 0, as_stream(stream),
@@ -209,6 +211,7 @@ int sgl_amd_write_req_to_token(int32_t* req_to_token, int64_t req_to_token_strid
 int sgl_amd_get_last_loc(const int32_t* req_to_token, int64_t req_to_token_stride,
                          const int64_t* req_pool_indices, const int64_t* prefix_lens,
                          int64_t* last_loc, int64_t batch, void* stream) {
+  SGL_CLEAR_STALE_ERROR();
   if (batch == 0) return 0;
   hipLaunchKernelGGL(get_last_loc_kernel, dim3((batch + 255) / 256), dim3(256), 0,
                      as_stream(stream), req_to_token, req_pool_indices, prefix_lens, last_loc,
@@ -220,6 +223,7 @@ int sgl_amd_get_last_loc(const int32_t* req_to_token, int64_t req_to_token_strid
 int sgl_amd_compute_position(const void* extend_prefix_lens, const void* extend_seq_lens,
                              int lens_are_i64, int64_t* positions, void* extend_start_loc,
                              int64_t batch, void* stream) {
+  SGL_CLEAR_STALE_ERROR();
   SGL_CHECK_ARG(batch <= 0x7fffffffLL, "compute_position: batch too large");
   if (batch == 0) return 0;
   if (lens_are_i64)
@@ -238,6 +242,7 @@ int sgl_amd_compute_position(const void* extend_prefix_lens, const void* extend_
 
 int sgl_amd_clamp_position(const void* seq_lens, int lens_are_i64, int64_t* positions,
                            int64_t batch, void* stream) {
+  SGL_CLEAR_STALE_ERROR();
   if (batch == 0) return 0;
   const dim3 grid((batch + 255) / 256);
   if (lens_are_i64)
@@ -253,6 +258,7 @@ int sgl_amd_clamp_position(const void* seq_lens, int lens_are_i64, int64_t* posi
 int sgl_amd_alloc_extend(const int64_t* prefix_lens, const int64_t* seq_lens,
                          const int64_t* last_loc, const int64_t* free_pages, int64_t* out_indices,
                          int64_t batch, int64_t page_size, void* stream) {
+  SGL_CLEAR_STALE_ERROR();
   SGL_CHECK_ARG(page_size >= 1, "alloc_extend: bad page_size");
   SGL_CHECK_ARG(batch <= 0x7fffffffLL, "alloc_extend: batch too large");
   if (batch == 0) return 0;
@@ -265,6 +271,7 @@ int sgl_amd_alloc_extend(const int64_t* prefix_lens, const int64_t* seq_lens,
 int sgl_amd_alloc_decode(const int64_t* seq_lens, const int64_t* last_loc,
                          const int64_t* free_pages, int64_t* out_indices, int64_t batch,
                          int64_t page_size, void* stream) {
+  SGL_CLEAR_STALE_ERROR();
   SGL_CHECK_ARG(page_size >= 1, "alloc_decode: bad page_size");
   SGL_CHECK_ARG(batch <= 0x7fffffffLL, "alloc_decode: batch too large");
   if (batch == 0) return 0;

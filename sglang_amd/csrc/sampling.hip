@@ -94,6 +94,7 @@ extern "C" {
 
 int sgl_amd_argmax(const void* logits, int logits_is_bf16, int64_t* ids, int64_t batch,
                    int64_t vocab, int64_t row_stride, void* stream) {
+  SGL_CLEAR_STALE_ERROR();
   SGL_CHECK_ARG(vocab > 0, "argmax: vocab must be positive");
   SGL_CHECK_ARG(batch <= 0x7fffffffLL, "argmax: batch too large");
   if (batch == 0) return 0;
@@ -109,6 +110,7 @@ int sgl_amd_argmax(const void* logits, int logits_is_bf16, int64_t* ids, int64_t
 
 int sgl_amd_softmax_temperature(float* logits, const float* temperatures, int64_t batch,
                                 int64_t vocab, int64_t row_stride, void* stream) {
+  SGL_CLEAR_STALE_ERROR();
   SGL_CHECK_ARG(vocab > 0, "softmax_temperature: vocab must be positive");
   SGL_CHECK_ARG(batch <= 0x7fffffffLL, "softmax_temperature: batch too large");
   if (batch == 0) return 0;
