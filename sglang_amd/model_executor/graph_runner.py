@@ -64,6 +64,22 @@ class DecodeGraphRunner:
         return self.mr.model.forward(fb.input_ids, fb.positions, fb).next_token_logits
 
     def capture(self) -> None:
+        # A Python GC pass that frees device tensors / graphs of an earlier runner while a capture
+        # is open aborts the process (the reference freezes the GC for the same reason:
+        # runner/decode_cuda_graph_runner.py freeze_gc).
+        import gc
+
+        gc.collect()
+        torch.cuda.synchronize()
+        gc_was_enabled = gc.isenabled()
+        gc.disable()
+        try:
+            self._capture_all()
+        finally:
+            if gc_was_enabled:
+                gc.enable()
+
+    def _capture_all(self) -> None:
         stream = torch.cuda.Stream(device=self.device)
         stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(stream):

@@ -57,6 +57,13 @@ def lib() -> ctypes.CDLL:
     global _lib, _sigs
     if _lib is not None:
         return _lib
+    # ORDER MATTERS: torch bundles its own libamdhip64.so (SONAME libamdhip64.so.7).  It must be
+    # in the process before our library is dlopen'ed so that our NEEDED libamdhip64.so.7 resolves
+    # to the SAME runtime instance torch uses (streams, graphs and device pointers are shared).
+    # Loading us first would pull a second HIP runtime from /opt/rocm and every launch would fail
+    # with hipErrorNoDevice.
+    import torch  # noqa: F401
+
     path = Path(os.environ.get("SGLANG_AMD_LIB", str(LIB_PATH)))
     if not path.exists():
         raise RuntimeError(

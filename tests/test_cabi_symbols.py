@@ -8,7 +8,7 @@ from sglang_amd import build, native
 def test_library_exports_all_declared_symbols():
     path = build.build()
     assert path.exists()
-    cdll = ctypes.CDLL(str(path))
+    cdll = native.lib()     # imports torch first so a single HIP runtime is shared (see native.lib)
     names = native.declared_symbols()
     assert len(names) >= 20
     for n in names:
