@@ -151,6 +151,30 @@ int sgl_amd_argmax(const void* logits, int logits_is_bf16, int64_t* ids, int64_t
 int sgl_amd_softmax_temperature(float* logits, const float* temperatures, int64_t batch,
                                 int64_t vocab, int64_t row_stride, void* stream);
 
+/* Top-k / top-p / min-p sampling with the reference's deterministic gumbel mode
+ * (sampler.py:567-612 top_k_top_p_min_p_sampling_from_probs_torch + :688-729
+ * multinomial_with_seed).  probs fp32 [B,V] (after softmax).  filtered=1: keep the sorted
+ * prefix {rank < top_k, exclusive cumsum <= top_p, [p >= max*min_p]} and return the token whose
+ * SORTED RANK j maximises log(p_j) + gumbel(murmur(seed, position, j)) in fp64.  filtered=0:
+ * sampling_from_probs_torch (:732-750), no filter, column = token id.  seeds are required (for
+ * unseeded sampling the caller draws fresh ones).  Nuclei larger than sgl_amd_sampling_lds_keep()
+ * are ranked in the caller-owned workspaces ws_keys/ws_toks (each B*2*V 4-byte words);
+ * without them such a row returns id -1.  top_ks/top_ps/min_ps/positions/out_n_keep may be NULL. */
+int sgl_amd_top_k_top_p_min_p_sample(const float* probs, int64_t row_stride, int64_t batch,
+                                     int64_t vocab, const int32_t* top_ks, const float* top_ps,
+                                     const float* min_ps, const int64_t* seeds,
+                                     const int64_t* positions, int32_t* out_ids, void* ws_keys,
+                                     void* ws_toks, int32_t* out_n_keep, int filtered, void* stream);
+int sgl_amd_sampling_lds_keep(void);
+/* sgl_kernel.top_k_renorm_prob / top_p_renorm_prob (kernels/aot/python/sgl_kernel/sampling.py:28,79)
+ * and sampler.py:753-762 top_p_normalize_probs_torch: zero everything outside the kept sorted
+ * prefix and renormalise.  Per-row arrays override the scalar values when non-NULL;
+ * top_k_val < 0 disables top-k, top_p_val >= 1 disables top-p. */
+int sgl_amd_top_k_top_p_renorm_probs(const float* probs, float* out, int64_t in_row_stride,
+                                     int64_t out_row_stride, int64_t batch, int64_t vocab,
+                                     const int32_t* top_ks, int top_k_val, const float* top_ps,
+                                     float top_p_val, void* stream);
+
 /* ---- test-only probes (used by tests/ to pin the MFMA lane maps) --------------- */
 int sgl_amd_probe_mfma_16x16x32(const void* a_16x32_bf16, const void* b_32x16_bf16,
                                 void* c_16x16_f32, void* stream);

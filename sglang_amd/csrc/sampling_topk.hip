@@ -1,0 +1,575 @@
+// Top-k / top-p / min-p sampling for gfx950 with the reference's deterministic
+// (murmur-hash gumbel) mode, without sorting the vocabulary.
+//
+// Replaces (reference, /root/reference/python/sglang):
+//   srt/layers/sampler.py:567-612 top_k_top_p_min_p_sampling_from_probs_torch
+//     (sort desc -> cumsum -> zero rank >= top_k -> zero (cumsum - p) > top_p ->
+//      [min_p] -> gumbel argmax over the SORTED ranks),
+//   :688-729 multinomial_with_seed, :732-750 sampling_from_probs_torch,
+//   :753-762 top_p_normalize_probs_torch,
+//   kernels/ops/sampling/murmur_hash.py:51-121 murmur_hash32,
+//   sgl_kernel.top_k_renorm_prob / top_p_renorm_prob (kernels/aot/python/sgl_kernel/sampling.py).
+//
+// One 1024-thread workgroup per row.  The torch path sorts all V probabilities;
+// only the kept prefix of that order matters, so the kernel
+//   1. finds the kept prefix with a 4-level MSB radix select over the fp32 bit
+//      patterns (256-bin count + fixed-point sum histograms in LDS): the result is a
+//      threshold value, the number of strictly larger elements and how many of the
+//      elements equal to the threshold are kept.  Sums are 2^-40 fixed point, so the
+//      result is independent of the order of the atomics (deterministic);
+//   2. compacts the kept (value, token) pairs in token order (two ballot scans per tile);
+//   3. ranks them: descending value, ties by token id.  Up to kLdsKeep pairs are ranked
+//      in LDS by counting; larger nuclei take a stable 4 x 8-bit LSD radix sort in a
+//      caller-owned global workspace;
+//   4. scores rank j with  log(p_j) + gumbel(murmur(seed, position, j))  in fp64 and
+//      takes the arg max (first maximum), exactly the reference's arithmetic.
+// The row (V x 4 B, ~0.5 MB) is read 5-6 times but stays in L2.
+#include "common.hpp"
+#include "../../include/sglang_amd.h"
+
+using namespace sgl_amd;
+
+namespace {
+
+constexpr int kT = 1024;          // threads per row
+constexpr int kNW = kT / 64;      // waves per row
+constexpr int kLdsKeep = 2048;    // nucleus size ranked in LDS
+constexpr double kFix = 1099511627776.0;  // 2^40
+
+// ---- murmur3 (murmur_hash.py:17-99) -------------------------------------------
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+__device__ __forceinline__ uint32_t mm_mix(uint32_t h, uint32_t k) {
+  k *= 0xCC9E2D51u;
+  k = rotl32(k, 15);
+  k *= 0x1B873593u;
+  h ^= k;
+  h = rotl32(h, 13);
+  return h * 5u + 0xE6546B64u;
+}
+__device__ __forceinline__ uint32_t mm_fmix(uint32_t h) {
+  h ^= h >> 16;
+  h *= 0x85EBCA6Bu;
+  h ^= h >> 13;
+  h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return h;
+}
+__device__ __forceinline__ uint32_t murmur_hash32(uint32_t h_seed_pos, uint32_t col) {
+  uint32_t h = mm_mix(h_seed_pos, col);
+  h ^= 16u;
+  return mm_fmix(h);
+}
+__device__ __forceinline__ uint32_t murmur_prefix(uint64_t seed, uint32_t pos) {
+  uint32_t h = 0;
+  h = mm_mix(h, static_cast<uint32_t>(seed & 0xffffffffull));
+  h = mm_mix(h, static_cast<uint32_t>(seed >> 32));
+  return mm_mix(h, pos);
+}
+// sampler.py:716-723: x = hash / (2^32-1); g = -log(clamp(-log(x), 2^-32, DBL_MAX)).
+__device__ __forceinline__ double gumbel_from_hash(uint32_t h) {
+  const double x = static_cast<double>(h) / 4294967295.0;
+  double lx = log(x);                       // h == 0 -> -inf
+  if (lx < -1.7976931348623157e308) lx = -1.7976931348623157e308;
+  if (lx > -2.3283064365386963e-10) lx = -2.3283064365386963e-10;
+  return -log(-lx);
+}
+
+struct Best {
+  double score;
+  int rank;    // sorted rank (tie-break: first)
+  int token;
+};
+__device__ __forceinline__ bool best_better(const Best& a, const Best& b) {
+  // true if b should replace a.  torch.argmax: NaN is maximal, first index wins ties.
+  if (b.rank < 0) return false;
+  if (a.rank < 0) return true;
+  const bool an = a.score != a.score, bn = b.score != b.score;
+  if (an != bn) return bn;
+  if (!an && b.score != a.score) return b.score > a.score;
+  return b.rank < a.rank;
+}
+__device__ __forceinline__ Best block_best(Best v, double* s_score, int* s_rank, int* s_tok) {
+  for (int off = 32; off > 0; off >>= 1) {
+    Best o;
+    o.score = __shfl_xor(v.score, off, 64);
+    o.rank = __shfl_xor(v.rank, off, 64);
+    o.token = __shfl_xor(v.token, off, 64);
+    if (best_better(v, o)) v = o;
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) { s_score[wid] = v.score; s_rank[wid] = v.rank; s_tok[wid] = v.token; }
+  __syncthreads();
+  // every wave merges the kNW partials redundantly with the same butterfly (a serial scalar
+  // loop over LDS here was mis-compiled by hipcc 7.2: the token of partial 1 got dropped)
+  Best r{0.0, -1, 0};
+  if (lane < kNW) { r.score = s_score[lane]; r.rank = s_rank[lane]; r.token = s_tok[lane]; }
+  for (int off = kNW / 2; off > 0; off >>= 1) {
+    Best o;
+    o.score = __shfl_xor(r.score, off, 64);
+    o.rank = __shfl_xor(r.rank, off, 64);
+    o.token = __shfl_xor(r.token, off, 64);
+    if (best_better(r, o)) r = o;
+  }
+  r.score = __shfl(r.score, 0, 64);
+  r.rank = __shfl(r.rank, 0, 64);
+  r.token = __shfl(r.token, 0, 64);
+  return r;
+}
+
+__device__ __forceinline__ uint64_t to_fix(float p) {
+  const double d = static_cast<double>(p) * kFix;
+  return d > 0.0 ? static_cast<uint64_t>(d + 0.5) : 0ull;
+}
+
+struct Select {
+  uint32_t thr_key;   // bit pattern of the smallest kept value
+  int n_eq_keep;      // how many elements == thr are kept (lowest token ids first)
+};
+
+struct RowSmem {
+  uint32_t hist_cnt[256];
+  unsigned long long hist_sum[256];
+  int wave_a[kNW];
+  int wave_b[kNW];
+  double s_score[kNW];
+  int s_rank[kNW];
+  int s_tok[kNW];
+  // select state (written by wave 0, read by all)
+  uint32_t prefix;
+  int c_above;
+  unsigned long long s_above;
+  int found_bin;
+  int n_eq_keep;
+  int done_all;
+  int n_keep;
+  float red[16];
+  uint32_t keys[kLdsKeep];
+  int toks[kLdsKeep];
+  // radix-sort scratch (aliases nothing: only used on the large path)
+  uint32_t digit_cnt[kNW][256];
+  uint32_t digit_base[256];
+};
+
+// probabilities are >= 0: the fp32 bit pattern orders like the value.  -0.0 and NaN
+// are mapped to 0 / +inf bits so the order stays total.
+__device__ __forceinline__ uint32_t key_of(float p) {
+  if (!(p > 0.f)) return (p != p) ? 0x7f800000u : 0u;
+  return __float_as_uint(p);
+}
+
+// ---- 1. radix select ------------------------------------------------------------
+// top_k < 0 or >= V behaves as "all"; top_p >= 1 keeps everything the cumsum allows.
+__device__ Select radix_select(const float* __restrict__ x, int V, int64_t top_k, float top_p,
+                               RowSmem& sm) {
+  const int tid = threadIdx.x;
+  // top_p >= 1 disables the filter: the exclusive cumsum of a softmax row never exceeds 1 in the
+  // reference's fp32 arithmetic, while the exact fixed-point sum can be a few 2^-40 above it.
+  const unsigned long long p_fix =
+      top_p >= 1.0f ? ~0ull >> 1
+                    : static_cast<unsigned long long>(top_p > 0.f ? static_cast<double>(top_p) * kFix : 0.0);
+  if (tid == 0) { sm.prefix = 0; sm.c_above = 0; sm.s_above = 0; sm.done_all = 0; sm.n_eq_keep = 0; }
+  uint32_t mask = 0;
+  for (int level = 0; level < 4; ++level) {
+    const int shift = 24 - 8 * level;
+    if (tid < 256) { sm.hist_cnt[tid] = 0; sm.hist_sum[tid] = 0; }
+    __syncthreads();
+    const uint32_t prefix = sm.prefix;
+    for (int i = tid; i < V; i += kT) {
+      const float p = x[i];
+      const uint32_t key = key_of(p);
+      if ((key & mask) == prefix) {
+        const int b = (key >> shift) & 255;
+        atomicAdd(&sm.hist_cnt[b], 1u);
+        atomicAdd(&sm.hist_sum[b], static_cast<unsigned long long>(to_fix(p)));
+      }
+    }
+    __syncthreads();
+    if (tid < 64) {
+      // lane l owns bins 255-4l .. 252-4l (descending); inclusive scan over lanes.
+      uint32_t c4[4];
+      unsigned long long s4[4];
+      uint32_t lc = 0;
+      unsigned long long ls = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        c4[j] = sm.hist_cnt[255 - 4 * tid - j];
+        s4[j] = sm.hist_sum[255 - 4 * tid - j];
+        lc += c4[j];
+        ls += s4[j];
+      }
+      uint32_t ic = lc;
+      unsigned long long is = ls;
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t oc = __shfl_up(ic, off, 64);
+        const unsigned long long os = __shfl_up(is, off, 64);
+        if (tid >= off) { ic += oc; is += os; }
+      }
+      long long c = static_cast<long long>(sm.c_above) + (ic - lc);
+      unsigned long long s = sm.s_above + (is - ls);
+      int fail = -1;
+      long long c_b = 0;
+      unsigned long long s_b = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (fail < 0) {
+          const bool whole = (c + c4[j] <= top_k) && (s + s4[j] <= p_fix);
+          if (whole || c4[j] == 0) { c += c4[j]; s += s4[j]; }
+          else { fail = 255 - 4 * tid - j; c_b = c; s_b = s; }
+        }
+      }
+      const unsigned long long bal = __ballot(fail >= 0);
+      if (bal == 0ull) {
+        if (tid == 0) sm.done_all = 1;   // everything at this prefix is kept (only possible at level 0)
+      } else {
+        const int first = __ffsll(static_cast<long long>(bal)) - 1;
+        if (tid == first) {
+          sm.found_bin = fail;
+          sm.c_above = static_cast<int>(c_b);
+          sm.s_above = s_b;
+          sm.prefix = prefix | (static_cast<uint32_t>(fail) << shift);
+          if (level == 3) {
+            // single value v, m copies: keep j = 0.. while c_b + j < top_k and s_b + j*v <= p_fix
+            const uint32_t m = sm.hist_cnt[fail];
+            const unsigned long long v = sm.hist_sum[fail] / (m ? m : 1);
+            long long nk = top_k - c_b;
+            if (nk < 0) nk = 0;
+            long long np;
+            if (s_b > p_fix) np = 0;
+            else if (v == 0) np = m;
+            else np = static_cast<long long>((p_fix - s_b) / v) + 1;
+            long long n = m;
+            if (nk < n) n = nk;
+            if (np < n) n = np;
+            sm.n_eq_keep = static_cast<int>(n);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (sm.done_all) break;
+    mask |= 0xffu << shift;
+  }
+  Select r;
+  if (sm.done_all) { r.thr_key = 0; r.n_eq_keep = 0x7fffffff; }
+  else { r.thr_key = sm.prefix; r.n_eq_keep = sm.n_eq_keep; }
+  __syncthreads();
+  return r;
+}
+
+// ---- 2. compaction ---------------------------------------------------------------
+// Kept = key > thr (and key >= min_key)  ||  key == thr with equal-rank < n_eq_keep.
+// Emits pairs through `emit(pos, key, token)`; greater elements first (token order), then
+// the kept ties.  Returns n_keep.  n_gt is computed in a first counting sweep.
+template <typename Emit>
+__device__ int compact_kept(const float* __restrict__ x, int V, Select sel, uint32_t min_key,
+                            RowSmem& sm, Emit emit) {
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  uint32_t thr = sel.thr_key;
+  int n_eq_keep = sel.n_eq_keep;
+  if (min_key > thr) { thr = min_key; n_eq_keep = 0x7fffffff; }   // min_p cut is above the top-k/p cut: keep >= min_key
+  // count strictly-greater elements (the ties go after them)
+  int cnt = 0;
+  for (int i = tid; i < V; i += kT) cnt += key_of(x[i]) > thr;
+  cnt = static_cast<int>(wave_sum(static_cast<float>(cnt)) + 0.5f);
+  __syncthreads();
+  if (lane == 0) sm.wave_a[wid] = cnt;
+  __syncthreads();
+  int n_gt = 0;
+  for (int w = 0; w < kNW; ++w) n_gt += sm.wave_a[w];
+  int base_gt = 0, base_eq = 0;
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (int i0 = 0; i0 < V; i0 += kT) {
+    const int i = i0 + tid;
+    uint32_t key = 0;
+    bool gt = false, eq = false;
+    if (i < V) {
+      key = key_of(x[i]);
+      gt = key > thr;
+      eq = key == thr;
+    }
+    const unsigned long long bg = __ballot(gt), be = __ballot(eq);
+    __syncthreads();
+    if (lane == 0) { sm.wave_a[wid] = __popcll(bg); sm.wave_b[wid] = __popcll(be); }
+    __syncthreads();
+    int og = 0, oe = 0, tg = 0, te = 0;
+    for (int w = 0; w < kNW; ++w) {
+      const int a = sm.wave_a[w], b = sm.wave_b[w];
+      if (w < wid) { og += a; oe += b; }
+      tg += a; te += b;
+    }
+    if (gt) emit(base_gt + og + __popcll(bg & lt_mask), key, i);
+    if (eq) {
+      const int r = base_eq + oe + __popcll(be & lt_mask);
+      if (r < n_eq_keep) emit(n_gt + r, key, i);
+    }
+    base_gt += tg;
+    base_eq += te;
+  }
+  const int kept_eq = base_eq < n_eq_keep ? base_eq : n_eq_keep;
+  __syncthreads();
+  return n_gt + kept_eq;
+}
+
+// ---- 3b. stable LSD radix sort (descending) of n (key, token) pairs in global memory --
+// ping-pongs between (k0,t0) and (k1,t1); after 4 passes the result is back in (k0,t0).
+__device__ void radix_sort_desc(uint32_t* k0, int* t0, uint32_t* k1, int* t1, int n, RowSmem& sm) {
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  uint32_t* ks = k0; int* ts = t0; uint32_t* kd = k1; int* td = t1;
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 8 * pass;
+    if (tid < 256) sm.hist_cnt[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += kT) atomicAdd(&sm.hist_cnt[(ks[i] >> shift) & 255], 1u);
+    __syncthreads();
+    if (tid == 0) {   // descending: digit 255 first
+      uint32_t run = 0;
+      for (int d = 255; d >= 0; --d) { sm.digit_base[d] = run; run += sm.hist_cnt[d]; }
+    }
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += kT) {
+      const int i = i0 + tid;
+      const bool act = i < n;
+      uint32_t key = 0; int tok = 0; int d = 0;
+      if (act) { key = ks[i]; tok = ts[i]; d = (key >> shift) & 255; }
+      for (int z = tid; z < kNW * 256; z += kT) (&sm.digit_cnt[0][0])[z] = 0;
+      // lanes of this wave with the same digit
+      unsigned long long m = __ballot(act);
+#pragma unroll
+      for (int bit = 0; bit < 8; ++bit) {
+        const unsigned long long bb = __ballot((d >> bit) & 1);
+        m &= ((d >> bit) & 1) ? bb : ~bb;
+      }
+      __syncthreads();
+      if (act && (m & lt_mask) == 0ull) sm.digit_cnt[wid][d] = __popcll(m);   // group leader
+      __syncthreads();
+      uint32_t off = 0;
+      if (act) {
+        off = sm.digit_base[d];
+        for (int w = 0; w < wid; ++w) off += sm.digit_cnt[w][d];
+        off += __popcll(m & lt_mask);
+        kd[off] = key;
+        td[off] = tok;
+      }
+      __syncthreads();
+      if (tid < 256) {
+        uint32_t tot = 0;
+        for (int w = 0; w < kNW; ++w) tot += sm.digit_cnt[w][tid];
+        sm.digit_base[tid] += tot;
+      }
+      __syncthreads();
+    }
+    // make this pass's global writes visible to the whole workgroup before the next pass reads them
+    __threadfence_block();
+    __syncthreads();
+    uint32_t* tk = ks; ks = kd; kd = tk;
+    int* tt = ts; ts = td; td = tt;
+  }
+}
+
+struct SampleParams {
+  const float* probs;          // [B, V]
+  int64_t row_stride;
+  int V;
+  const int32_t* top_ks;       // [B] or null (all)
+  const float* top_ps;         // [B] or null (1.0)
+  const float* min_ps;         // [B] or null
+  const int64_t* seeds;        // [B]
+  const int64_t* positions;    // [B] or null (0)
+  int32_t* out_ids;            // [B]
+  uint32_t* ws_keys;           // [B, 2, V] (large nuclei only)
+  int32_t* ws_toks;            // [B, 2, V]
+  int32_t* out_n_keep;         // optional [B] (tests)
+  int filtered;                // 0: sampling_from_probs (no filter, col = token id)
+};
+
+__global__ __launch_bounds__(kT) void sample_kernel(SampleParams p) {
+  __shared__ RowSmem sm;
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const float* x = p.probs + static_cast<int64_t>(row) * p.row_stride;
+  const int V = p.V;
+  const uint64_t seed = static_cast<uint64_t>(p.seeds[row]);
+  const uint32_t pos = p.positions ? static_cast<uint32_t>(p.positions[row] & 0xffffffffll) : 0u;
+  const uint32_t hpre = murmur_prefix(seed, pos);
+  Best best{0.0, -1, 0};
+
+  if (!p.filtered) {
+    // sampler.py:744-747: multinomial_with_seed(torch.log(probs)) -- fp32 log, col = token id
+    for (int i = tid; i < V; i += kT) {
+      const double sc = static_cast<double>(logf(x[i])) + gumbel_from_hash(murmur_hash32(hpre, i));
+      Best c{sc, i, i};
+      if (best_better(best, c)) best = c;
+    }
+    best = block_best(best, sm.s_score, sm.s_rank, sm.s_tok);
+    if (tid == 0) {
+      p.out_ids[row] = best.rank < 0 ? 0 : best.token;
+      if (p.out_n_keep) p.out_n_keep[row] = V;
+    }
+    return;
+  }
+
+  int64_t top_k = p.top_ks ? p.top_ks[row] : V;
+  if (top_k > V) top_k = V;
+  if (top_k < 0) top_k = 0;
+  const float top_p = p.top_ps ? p.top_ps[row] : 1.0f;
+  const Select sel = radix_select(x, V, top_k, top_p, sm);
+
+  uint32_t min_key = 0;
+  if (p.min_ps) {
+    // sampler.py:590-591: threshold = probs_sort[:, 0] * min_p  (fp32), drop p < threshold
+    float mx = 0.f;
+    for (int i = tid; i < V; i += kT) mx = fmaxf(mx, x[i]);
+    mx = block_max(mx, sm.red);
+    min_key = key_of(mx * p.min_ps[row]);
+  }
+
+  // small nuclei are compacted into LDS, larger ones into the global workspace
+  uint32_t* gk0 = p.ws_keys ? p.ws_keys + static_cast<int64_t>(row) * 2 * V : nullptr;
+  int32_t* gt0 = p.ws_toks ? p.ws_toks + static_cast<int64_t>(row) * 2 * V : nullptr;
+  const int n_keep = compact_kept(x, V, sel, min_key, sm, [&](int posn, uint32_t key, int tok) {
+    if (posn < kLdsKeep) { sm.keys[posn] = key; sm.toks[posn] = tok; }
+    if (gk0) { gk0[posn] = key; gt0[posn] = tok; }
+  });
+  if (tid == 0 && p.out_n_keep) p.out_n_keep[row] = n_keep;
+
+  if (n_keep <= kLdsKeep) {
+    __syncthreads();
+    for (int e = tid; e < n_keep; e += kT) {
+      const uint32_t ke = sm.keys[e];
+      int rank = 0;
+      for (int j = 0; j < n_keep; ++j) {
+        const uint32_t kj = sm.keys[j];
+        rank += (kj > ke) || (kj == ke && j < e);
+      }
+      const double sc = log(static_cast<double>(__uint_as_float(ke))) + gumbel_from_hash(murmur_hash32(hpre, rank));
+      Best c{sc, rank, sm.toks[e]};
+      if (best_better(best, c)) best = c;
+    }
+  } else {
+    if (!gk0) {   // no workspace: cannot rank -- report the most probable kept token, flag via n_keep < 0
+      if (tid == 0) { p.out_ids[row] = -1; }
+      return;
+    }
+    __threadfence_block();
+    __syncthreads();
+    radix_sort_desc(gk0, gt0, gk0 + V, gt0 + V, n_keep, sm);
+    for (int j = tid; j < n_keep; j += kT) {
+      const double sc = log(static_cast<double>(__uint_as_float(gk0[j]))) + gumbel_from_hash(murmur_hash32(hpre, j));
+      Best c{sc, j, gt0[j]};
+      if (best_better(best, c)) best = c;
+    }
+  }
+  best = block_best(best, sm.s_score, sm.s_rank, sm.s_tok);
+  if (tid == 0) {
+    int tok = best.token;
+    if (best.rank < 0) {
+      // empty nucleus (top_k == 0): the reference's all -inf row argmax-es to sorted rank 0
+      tok = 0;
+    }
+    p.out_ids[row] = tok;
+  }
+}
+
+// rank-0 token of an empty nucleus must be the arg max of the row; handled by a tiny fix-up
+// kernel so that the common path stays branch-free.
+__global__ __launch_bounds__(kT) void empty_nucleus_fixup_kernel(SampleParams p) {
+  __shared__ RowSmem sm;
+  const int row = blockIdx.x, tid = threadIdx.x;
+  int64_t top_k = p.top_ks ? p.top_ks[row] : p.V;
+  if (top_k > 0) return;
+  const float* x = p.probs + static_cast<int64_t>(row) * p.row_stride;
+  Best best{0.0, -1, 0};
+  for (int i = tid; i < p.V; i += kT) {
+    Best c{static_cast<double>(x[i]), i, i};
+    if (best_better(best, c)) best = c;
+  }
+  best = block_best(best, sm.s_score, sm.s_rank, sm.s_tok);
+  if (tid == 0) p.out_ids[row] = best.token;
+}
+
+// ---- renormalisation (sgl_kernel.top_k_renorm_prob / top_p_renorm_prob,
+//      sampler.py:753-762 top_p_normalize_probs_torch) -----------------------------
+__global__ __launch_bounds__(kT) void renorm_kernel(const float* __restrict__ probs, float* __restrict__ out,
+                                                     int64_t in_stride, int64_t out_stride, int V,
+                                                     const int32_t* __restrict__ top_ks, int top_k_val,
+                                                     const float* __restrict__ top_ps, float top_p_val) {
+  __shared__ RowSmem sm;
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const float* x = probs + static_cast<int64_t>(row) * in_stride;
+  float* y = out + static_cast<int64_t>(row) * out_stride;
+  int64_t top_k = top_ks ? top_ks[row] : top_k_val;
+  if (top_k > V || top_k < 0) top_k = V;
+  const float top_p = top_ps ? top_ps[row] : top_p_val;
+  const Select sel = radix_select(x, V, top_k, top_p, sm);
+  const uint32_t thr = sel.thr_key;
+  // sum of the kept values (fixed thread mapping -> deterministic), ties kept by token order
+  float part = 0.f;
+  int base_eq = 0;
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  // pass A: mark + sum
+  for (int i0 = 0; i0 < V; i0 += kT) {
+    const int i = i0 + tid;
+    const float v = i < V ? x[i] : 0.f;
+    const uint32_t key = i < V ? key_of(v) : 0u;
+    const bool gt = i < V && key > thr, eq = i < V && key == thr;
+    const unsigned long long be = __ballot(eq);
+    __syncthreads();
+    if (lane == 0) sm.wave_b[wid] = __popcll(be);
+    __syncthreads();
+    int oe = 0, te = 0;
+    for (int w = 0; w < kNW; ++w) { const int b = sm.wave_b[w]; if (w < wid) oe += b; te += b; }
+    const bool keep = gt || (eq && (base_eq + oe + __popcll(be & lt_mask)) < sel.n_eq_keep);
+    if (i < V) { y[i] = keep ? v : 0.f; part += keep ? v : 0.f; }
+    base_eq += te;
+  }
+  const float tot = block_sum(part, sm.red);
+  for (int i = tid; i < V; i += kT) y[i] = y[i] / tot;   // each thread re-reads its own writes
+}
+
+}  // namespace
+
+extern "C" {
+
+int sgl_amd_top_k_top_p_min_p_sample(const float* probs, int64_t row_stride, int64_t batch, int64_t vocab,
+                                     const int32_t* top_ks, const float* top_ps, const float* min_ps,
+                                     const int64_t* seeds, const int64_t* positions, int32_t* out_ids,
+                                     void* ws_keys, void* ws_toks, int32_t* out_n_keep, int filtered,
+                                     void* stream) {
+  SGL_CLEAR_STALE_ERROR();
+  SGL_CHECK_ARG(vocab > 0 && vocab <= 0x7fffffffLL, "top_k_top_p_min_p_sample: bad vocab");
+  SGL_CHECK_ARG(batch <= 0x7fffffffLL, "top_k_top_p_min_p_sample: batch too large");
+  SGL_CHECK_ARG(seeds != nullptr, "top_k_top_p_min_p_sample: seeds are required (the caller draws them when sampling is not seeded)");
+  SGL_CHECK_ARG((ws_keys == nullptr) == (ws_toks == nullptr), "top_k_top_p_min_p_sample: pass both workspaces or neither");
+  if (batch == 0) return 0;
+  SampleParams p;
+  p.probs = probs; p.row_stride = row_stride; p.V = static_cast<int>(vocab);
+  p.top_ks = top_ks; p.top_ps = top_ps; p.min_ps = min_ps; p.seeds = seeds; p.positions = positions;
+  p.out_ids = out_ids; p.ws_keys = static_cast<uint32_t*>(ws_keys); p.ws_toks = static_cast<int32_t*>(ws_toks);
+  p.out_n_keep = out_n_keep; p.filtered = filtered;
+  hipLaunchKernelGGL(sample_kernel, dim3(batch), dim3(kT), 0, as_stream(stream), p);
+  SGL_CHECK_LAUNCH("top_k_top_p_min_p_sample");
+  if (filtered && top_ks) {
+    hipLaunchKernelGGL(empty_nucleus_fixup_kernel, dim3(batch), dim3(kT), 0, as_stream(stream), p);
+    SGL_CHECK_LAUNCH("top_k_top_p_min_p_sample(fixup)");
+  }
+  return 0;
+}
+
+int sgl_amd_sampling_lds_keep(void) { return kLdsKeep; }
+
+int sgl_amd_top_k_top_p_renorm_probs(const float* probs, float* out, int64_t in_row_stride,
+                                     int64_t out_row_stride, int64_t batch, int64_t vocab,
+                                     const int32_t* top_ks, int top_k_val, const float* top_ps,
+                                     float top_p_val, void* stream) {
+  SGL_CLEAR_STALE_ERROR();
+  SGL_CHECK_ARG(vocab > 0 && vocab <= 0x7fffffffLL, "renorm_probs: bad vocab");
+  SGL_CHECK_ARG(batch <= 0x7fffffffLL, "renorm_probs: batch too large");
+  if (batch == 0) return 0;
+  hipLaunchKernelGGL(renorm_kernel, dim3(batch), dim3(kT), 0, as_stream(stream), probs, out, in_row_stride,
+                     out_row_stride, static_cast<int>(vocab), top_ks, top_k_val, top_ps, top_p_val);
+  SGL_CHECK_LAUNCH("renorm_probs");
+  return 0;
+}
+
+}  // extern "C"

@@ -275,6 +275,81 @@ def softmax_temperature_(logits: torch.Tensor, temperatures: torch.Tensor) -> to
     return logits
 
 
+
+_SAMPLE_WS = {}
+
+
+def sampling_lds_keep() -> int:
+    return native.lib().sgl_amd_sampling_lds_keep()
+
+
+def _sample_workspace(batch: int, vocab: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Caller-owned ranking workspace for nuclei larger than the LDS capacity (B*2*V words each)."""
+    key = (batch, vocab, str(device))
+    ws = _SAMPLE_WS.get(key)
+    if ws is None:
+        ws = (torch.empty((batch, 2, vocab), dtype=torch.int32, device=device),
+              torch.empty((batch, 2, vocab), dtype=torch.int32, device=device))
+        _SAMPLE_WS[key] = ws
+    return ws
+
+
+def top_k_top_p_min_p_sample(probs: torch.Tensor, top_ks: Optional[torch.Tensor], top_ps: Optional[torch.Tensor],
+                             min_ps: Optional[torch.Tensor], sampling_seed: Optional[torch.Tensor],
+                             positions: Optional[torch.Tensor], filtered: bool = True, use_workspace: bool = True,
+                             return_n_keep: bool = False):
+    """sampler.py:567-612 / :732-750 on the gfx950 sampler.  probs fp32 [B, V] (after softmax).
+    Without sampling_seed fresh per-row seeds are drawn from torch's device generator."""
+    _dev(probs)
+    _need(probs.dtype == torch.float32 and probs.dim() == 2 and probs.stride(1) == 1, "sample: fp32 [B, V] probs")
+    B, V = probs.shape
+    dev = probs.device
+    if sampling_seed is None:
+        sampling_seed = torch.randint(0, 2 ** 62, (B,), dtype=torch.int64, device=dev)
+    seeds = sampling_seed.to(torch.int64) if sampling_seed.dtype != torch.int64 else sampling_seed
+    _need(seeds.numel() == B and seeds.is_contiguous(), "sample: seeds [B]")
+    if positions is not None:
+        positions = positions.to(torch.int64).contiguous()
+        _need(positions.numel() == B, "sample: positions [B]")
+    if top_ks is not None:
+        top_ks = top_ks.to(torch.int32).contiguous()
+    if top_ps is not None:
+        top_ps = top_ps.to(torch.float32).contiguous()
+    if min_ps is not None:
+        min_ps = min_ps.to(torch.float32).contiguous()
+    ids = torch.empty(B, dtype=torch.int32, device=dev)
+    n_keep = torch.empty(B, dtype=torch.int32, device=dev) if return_n_keep else None
+    ws = _sample_workspace(B, V, dev) if (filtered and use_workspace) else (None, None)
+    native.call("sgl_amd_top_k_top_p_min_p_sample", probs.data_ptr(), probs.stride(0), B, V, _ptr(top_ks), _ptr(top_ps),
+                _ptr(min_ps), seeds.data_ptr(), _ptr(positions), ids.data_ptr(), _ptr(ws[0]), _ptr(ws[1]),
+                _ptr(n_keep), 1 if filtered else 0, _stream())
+    return (ids, n_keep) if return_n_keep else ids
+
+
+def _renorm(probs: torch.Tensor, top_k, top_p) -> torch.Tensor:
+    _dev(probs)
+    probs = probs.float()
+    _need(probs.dim() == 2 and probs.stride(1) == 1, "renorm: fp32 [B, V] probs")
+    B, V = probs.shape
+    out = torch.empty_like(probs)
+    k_arr = top_k.to(torch.int32).contiguous() if isinstance(top_k, torch.Tensor) else None
+    p_arr = top_p.to(torch.float32).contiguous() if isinstance(top_p, torch.Tensor) else None
+    native.call("sgl_amd_top_k_top_p_renorm_probs", probs.data_ptr(), out.data_ptr(), probs.stride(0), out.stride(0), B, V,
+                _ptr(k_arr), -1 if (top_k is None or k_arr is not None) else int(top_k),
+                _ptr(p_arr), 2.0 if (top_p is None or p_arr is not None) else float(top_p), _stream())
+    return out
+
+
+def top_k_renorm_prob(probs: torch.Tensor, top_k) -> torch.Tensor:
+    """sgl_kernel.top_k_renorm_prob(probs, top_k) (kernels/aot/python/sgl_kernel/sampling.py:28-72)."""
+    return _renorm(probs, top_k, None)
+
+
+def top_p_renorm_prob(probs: torch.Tensor, top_p) -> torch.Tensor:
+    """sgl_kernel.top_p_renorm_prob(probs, top_p) (sampling.py:79-130); same result as
+    sampler.py:753-762 top_p_normalize_probs_torch."""
+    return _renorm(probs, None, top_p)
+
 # -------------------------------------------------------------------------- probe
 def probe_mfma_16x16x32(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     _dev(a, b)

@@ -25,6 +25,7 @@ class SamplingBatchInfo:
     need_top_k_sampling: bool = False
     need_min_p_sampling: bool = False
     sampling_seed: Optional[torch.Tensor] = None   # [B] int64 -> deterministic gumbel sampling
+    sync_token_ids_across_tp: bool = False
 
     @classmethod
     def greedy(cls, batch: int, device) -> "SamplingBatchInfo":
@@ -51,11 +52,29 @@ class Sampler(nn.Module):
             raise NotImplementedError("logprob return is outside this path")
         if sampling_info.is_all_greedy:
             return kernels.argmax(logits)                                   # sampler.py:133-141
-        probs = kernels.softmax_temperature_(logits, sampling_info.temperatures)   # sampler.py:211-216
-        return kernels.top_k_top_p_min_p_sample(
-            probs, sampling_info.top_ks, sampling_info.top_ps,
-            sampling_info.min_ps if sampling_info.need_min_p_sampling else None,
-            sampling_info.sampling_seed, positions)
+        # sampler.py:148-152, 211-260: div_ temperature, softmax in place, then sample from probs
+        simple_sampling_case = not (sampling_info.need_top_p_sampling or sampling_info.need_top_k_sampling
+                                    or sampling_info.need_min_p_sampling)
+        probs = kernels.softmax_temperature_(logits, sampling_info.temperatures)
+        if simple_sampling_case:
+            ids = kernels.top_k_top_p_min_p_sample(probs, None, None, None, sampling_info.sampling_seed, positions,
+                                                   filtered=False)
+        else:
+            ids = kernels.top_k_top_p_min_p_sample(
+                probs, sampling_info.top_ks, sampling_info.top_ps,
+                sampling_info.min_ps if sampling_info.need_min_p_sampling else None,
+                sampling_info.sampling_seed, positions)
+        return self._sync_token_ids_across_tp(ids, sampling_info)
+
+    def _sync_token_ids_across_tp(self, ids: torch.Tensor, sampling_info: SamplingBatchInfo) -> torch.Tensor:
+        """sampler.py:497-512: MIN all-reduce of the sampled ids when requested (grammar / env)."""
+        from ..distributed import parallel_state as ps
+
+        if getattr(sampling_info, "sync_token_ids_across_tp", False) and ps.get_tensor_model_parallel_world_size() > 1:
+            import torch.distributed as dist
+
+            dist.all_reduce(ids, op=dist.ReduceOp.MIN, group=ps.get_tp_group())
+        return ids
 
 
 _SAMPLER_BACKENDS = {"hip": lambda: Sampler()}
