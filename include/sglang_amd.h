@@ -175,6 +175,58 @@ int sgl_amd_top_k_top_p_renorm_probs(const float* probs, float* out, int64_t in_
                                      const int32_t* top_ks, int top_k_val, const float* top_ps,
                                      float top_p_val, void* stream);
 
+/* ---- Skinny / grouped GEMM (reference: kernels/ops/moe/fused_moe_triton_kernels.py:324,771
+ *      fused_moe_kernel / invoke_fused_moe_kernel; srt/layers/linear.py:1596-1660 for the dense
+ *      decode projections; srt/layers/activation.py:130 when fuse_silu=1) ------------------- */
+/* y[M,N] = x[M,K] . w[N,K]^T (+ bias[N]), bf16 in/out, fp32 accumulate, M <= sgl_amd_skinny_gemm_max_rows().
+ * fuse_silu=1: w is [2N,K] (gate rows then up rows) and y = silu(x.gate^T) * (x.up^T) with torch's
+ * bf16 rounding points.  tiles_per_wave (1|2) = 16-column tiles each wave owns.
+ * num_k_splits > 1 splits K over workgroups: partial tiles go to ws_slabs
+ * (sgl_amd_skinny_gemm_slab_floats(1, N, splits, fuse_silu, tiles_per_wave) floats) and a second
+ * launch sums them in split order (deterministic) and runs the epilogue. */
+int sgl_amd_skinny_gemm(const void* x, const void* w, const void* bias, void* y, int64_t M, int64_t N,
+                        int64_t K, int64_t x_row_stride, int64_t w_row_stride, int64_t y_row_stride,
+                        int fuse_silu, int tiles_per_wave, int num_k_splits, void* ws_slabs,
+                        void* stream);
+int sgl_amd_skinny_gemm_max_rows(void);
+int sgl_amd_skinny_gemm_chunk(void);
+int64_t sgl_amd_skinny_gemm_slab_floats(int64_t row_blocks, int64_t N, int splits, int fuse_silu,
+                                        int tiles_per_wave);
+/* Grouped GEMM over moe_align_block_size output: for every row block b < num_tokens_post_padded/block_m
+ * with expert e = expert_ids[b]:  c[id, :] = a[id / top_k_div, :] . w[e]^T  for id in
+ * sorted_token_ids[b*block_m : (b+1)*block_m] with id < num_valid_ids, optionally scaled by
+ * topk_weights[id] (round_before_scale=1 rounds the accumulator to bf16 first, which is the
+ * arithmetic of fused_moe_native.py:157-163).  out_f32=1 writes c as fp32.  Split-K workspaces as
+ * above with row_blocks = max_m_blocks. */
+int sgl_amd_moe_grouped_gemm(const void* a, const void* w, void* c, const int32_t* sorted_token_ids,
+                             const int32_t* expert_ids, const int32_t* num_tokens_post_padded,
+                             const float* topk_weights, int mul_routed_weight, int round_before_scale,
+                             int top_k_div, int64_t num_valid_ids, int64_t N, int64_t K,
+                             int64_t num_experts, int64_t a_row_stride, int64_t w_row_stride,
+                             int64_t w_expert_stride, int64_t c_row_stride, int block_m,
+                             int64_t max_m_blocks, int fuse_silu, int out_f32, int tiles_per_wave,
+                             int num_k_splits, void* ws_slabs, void* stream);
+
+/* ---- MoE routing / bookkeeping (reference: sgl_kernel.topk_softmax / moe_align_block_size /
+ *      moe_sum_reduce, common_extension_rocm.cc:135-149; torch spec srt/layers/moe/topk.py:690-736) */
+/* softmax over the gate logits (fp32 math), top-k (ties: lowest expert id), optional renormalise
+ * w / (sum w + 1e-20).  gating [M,E] fp32 or bf16; topk_weights fp32 [M,k]; topk_ids int32 [M,k]. */
+int sgl_amd_topk_softmax(const void* gating_output, int gating_is_bf16, float* topk_weights,
+                         int32_t* topk_ids, int64_t num_tokens, int num_experts, int topk,
+                         int64_t gating_row_stride, int renormalize, void* stream);
+/* Stable counting sort of the numel = M*topk flat pair ids by expert, each expert padded to
+ * block_size with the value numel.  ids may be -1 (filtered, sorted first, expert_ids = -1).
+ * sorted_token_ids capacity >= numel + (num_experts+1)*(block_size-1); expert_ids gets one entry per
+ * row block up to expert_capacity (-1 beyond num_tokens_post_pad). */
+int sgl_amd_moe_align_block_size(const void* topk_ids, int ids_are_i64, int64_t numel, int num_experts,
+                                 int block_size, int32_t* sorted_token_ids, int32_t* expert_ids,
+                                 int32_t* num_tokens_post_pad, int64_t sorted_capacity,
+                                 int64_t expert_capacity, void* stream);
+/* out[m,:] = bf16(routed_scaling_factor * sum_k input[m,k,:]), fp32 accumulate; input bf16 or fp32. */
+int sgl_amd_moe_sum_reduce(const void* input, int input_is_f32, void* output, int64_t num_tokens, int topk,
+                           int hidden, int64_t in_token_stride, int64_t in_k_stride,
+                           int64_t out_row_stride, float routed_scaling_factor, void* stream);
+
 /* ---- test-only probes (used by tests/ to pin the MFMA lane maps) --------------- */
 int sgl_amd_probe_mfma_16x16x32(const void* a_16x32_bf16, const void* b_32x16_bf16,
                                 void* c_16x16_f32, void* stream);

@@ -350,6 +350,189 @@ def top_p_renorm_prob(probs: torch.Tensor, top_p) -> torch.Tensor:
     sampler.py:753-762 top_p_normalize_probs_torch."""
     return _renorm(probs, None, top_p)
 
+
+# ------------------------------------------------------------------- skinny / grouped GEMM
+_GEMM_WS = {}
+_NUM_CUS = 256          # MI355X
+
+
+def skinny_gemm_max_rows() -> int:
+    return native.lib().sgl_amd_skinny_gemm_max_rows()
+
+
+def _gemm_workspace(device, slab_floats: int) -> torch.Tensor:
+    """Split-K slabs, one buffer per (device, stream): launches on one stream are ordered, so
+    consecutive GEMMs can share it."""
+    key = (str(device), torch.cuda.current_stream().cuda_stream)
+    ws = _GEMM_WS.get(key)
+    if ws is None or ws.numel() < slab_floats:
+        ws = torch.empty(max(slab_floats, 1 << 23), dtype=torch.float32, device=device)
+        _GEMM_WS[key] = ws
+    return ws
+
+
+def choose_gemm_config(row_blocks: int, N: int, K: int, fuse_silu: bool = False,
+                       target_blocks: int = 4 * _NUM_CUS) -> Tuple[int, int]:
+    """(tiles_per_wave, k_splits): aim at about four 4-wave workgroups per CU (the kernel's
+    occupancy), prefer wide tiles (less activation traffic) when N alone gives enough workgroups."""
+    chunks = (K + 127) // 128
+    best = None
+    for ntw in ((2,) if fuse_silu else (2, 1)):
+        bn = 64 if fuse_silu else 64 * ntw
+        tiles = max(1, row_blocks * ((N + bn - 1) // bn))
+        splits = max(1, min(chunks // 2 if chunks >= 2 else 1, target_blocks // tiles, 16))
+        cand = (ntw, splits, tiles * splits)
+        if best is None or (best[2] < target_blocks // 2 and cand[2] > best[2]):
+            best = cand
+    return best[0], best[1]
+
+
+def skinny_gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, fuse_silu: bool = False,
+                out: Optional[torch.Tensor] = None, splits: Optional[int] = None,
+                tiles_per_wave: Optional[int] = None) -> torch.Tensor:
+    """F.linear(x, w, bias) for x [M <= 64, K], w [N, K] bf16 (fuse_silu: w [2N, K] -> silu(gate)*up)."""
+    _dev(x, w)
+    _need(x.dtype == _BF16 and w.dtype == _BF16 and x.dim() == 2 and w.dim() == 2, "skinny_gemm: bf16 2-D x / w")
+    M, K = x.shape
+    N = w.shape[0] // 2 if fuse_silu else w.shape[0]
+    _need(w.shape[1] == K and x.stride(1) == 1 and w.stride(1) == 1, "skinny_gemm: shapes / contiguity")
+    if out is None:
+        out = torch.empty((M, N), dtype=_BF16, device=x.device)
+    ntw_auto, splits_auto = choose_gemm_config(1, N, K, fuse_silu)
+    ntw = 2 if fuse_silu else (tiles_per_wave or ntw_auto)
+    if splits is None:
+        splits = splits_auto
+    slabs = None
+    if splits > 1:
+        need = native.lib().sgl_amd_skinny_gemm_slab_floats(1, N, splits, 1 if fuse_silu else 0, ntw)
+        slabs = _gemm_workspace(x.device, need)
+    native.call("sgl_amd_skinny_gemm", x.data_ptr(), w.data_ptr(), _ptr(bias), out.data_ptr(), M, N, K, x.stride(0),
+                w.stride(0), out.stride(0), 1 if fuse_silu else 0, ntw, splits, _ptr(slabs), _stream())
+    return out
+
+
+def moe_grouped_gemm(a: torch.Tensor, w: torch.Tensor, c: torch.Tensor, sorted_token_ids: torch.Tensor,
+                     expert_ids: torch.Tensor, num_tokens_post_padded: torch.Tensor,
+                     topk_weights: Optional[torch.Tensor], mul_routed_weight: bool, top_k_div: int, num_valid_ids: int,
+                     block_m: int, fuse_silu: bool = False, round_before_scale: bool = False,
+                     splits: Optional[int] = None, tiles_per_wave: Optional[int] = None) -> torch.Tensor:
+    """invoke_fused_moe_kernel equivalent (fused_moe_triton_kernels.py:771): a [rows, K] bf16,
+    w [E, N(or 2N), K] bf16, c [num_valid_ids, N] bf16 or fp32."""
+    _dev(a, w, c, sorted_token_ids, expert_ids, num_tokens_post_padded)
+    _need(a.dtype == _BF16 and w.dtype == _BF16 and w.dim() == 3, "moe_grouped_gemm: bf16 a / w[E,N,K]")
+    _need(c.dtype in (_BF16, torch.float32) and c.dim() == 2, "moe_grouped_gemm: c bf16 / fp32 [rows, N]")
+    _need(sorted_token_ids.dtype == torch.int32 and expert_ids.dtype == torch.int32
+          and num_tokens_post_padded.dtype == torch.int32, "moe_grouped_gemm: int32 metadata")
+    E, WN, K = w.shape
+    N = WN // 2 if fuse_silu else WN
+    _need(a.shape[1] == K and c.shape[1] == N and a.stride(1) == 1 and w.stride(2) == 1 and c.stride(1) == 1,
+          "moe_grouped_gemm: shapes / contiguity")
+    max_m_blocks = expert_ids.numel()
+    _need(sorted_token_ids.numel() >= max_m_blocks * block_m, "moe_grouped_gemm: sorted_token_ids too short")
+    if mul_routed_weight:
+        _need(topk_weights is not None and topk_weights.dtype == torch.float32 and topk_weights.is_contiguous(),
+              "moe_grouped_gemm: fp32 topk_weights")
+    # only about num_valid_ids / block_m + E of the row blocks are live
+    live = max(1, min(max_m_blocks, num_valid_ids // block_m + E))
+    ntw_auto, splits_auto = choose_gemm_config(live, N, K, fuse_silu)
+    ntw = 2 if fuse_silu else (tiles_per_wave or ntw_auto)
+    if splits is None:
+        splits = splits_auto
+    slabs = None
+    if splits > 1:
+        need = native.lib().sgl_amd_skinny_gemm_slab_floats(max_m_blocks, N, splits, 1 if fuse_silu else 0, ntw)
+        slabs = _gemm_workspace(a.device, need)
+    native.call("sgl_amd_moe_grouped_gemm", a.data_ptr(), w.data_ptr(), c.data_ptr(), sorted_token_ids.data_ptr(),
+                expert_ids.data_ptr(), num_tokens_post_padded.data_ptr(), _ptr(topk_weights),
+                1 if mul_routed_weight else 0, 1 if round_before_scale else 0, top_k_div, num_valid_ids, N, K, E,
+                a.stride(0), w.stride(1), w.stride(0), c.stride(0), block_m, max_m_blocks, 1 if fuse_silu else 0,
+                1 if c.dtype == torch.float32 else 0, ntw, splits, _ptr(slabs), _stream())
+    return c
+
+
+# ---------------------------------------------------------------------------- MoE
+def topk_softmax(gating_output: torch.Tensor, topk: int, renormalize: bool) -> Tuple[torch.Tensor, torch.Tensor]:
+    """sgl_kernel.topk_softmax / fused_topk (topk.py:827): fp32 weights [M,k], int32 ids [M,k]."""
+    _dev(gating_output)
+    _need(gating_output.dim() == 2 and gating_output.stride(1) == 1 and gating_output.dtype in (_BF16, torch.float32),
+          "topk_softmax: [M, E] fp32 / bf16 gate logits")
+    M, E = gating_output.shape
+    w = torch.empty((M, topk), dtype=torch.float32, device=gating_output.device)
+    ids = torch.empty((M, topk), dtype=torch.int32, device=gating_output.device)
+    native.call("sgl_amd_topk_softmax", gating_output.data_ptr(), 1 if gating_output.dtype == _BF16 else 0, w.data_ptr(),
+                ids.data_ptr(), M, E, topk, gating_output.stride(0), 1 if renormalize else 0, _stream())
+    return w, ids
+
+
+def moe_align_block_size(topk_ids: torch.Tensor, block_size: int, num_experts: int
+                         ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """moe_runner/triton_utils/moe_align_block_size.py:31-170: (sorted_token_ids, expert_ids, num_tokens_post_padded)."""
+    _dev(topk_ids)
+    _need(topk_ids.dtype in (torch.int32, torch.int64) and topk_ids.is_contiguous(), "moe_align_block_size: int ids")
+    numel = topk_ids.numel()
+    if numel < num_experts + 1:
+        max_padded = numel * block_size
+    else:
+        max_padded = numel + (num_experts + 1) * (block_size - 1)
+    dev = topk_ids.device
+    max_blocks = (max_padded + block_size - 1) // block_size
+    max_padded = max_blocks * block_size          # whole row blocks, so the grouped GEMM never reads past the end
+    sorted_ids = torch.empty(max_padded, dtype=torch.int32, device=dev)
+    expert_ids = torch.empty(max_blocks, dtype=torch.int32, device=dev)
+    post = torch.empty(1, dtype=torch.int32, device=dev)
+    native.call("sgl_amd_moe_align_block_size", topk_ids.data_ptr(), 1 if topk_ids.dtype == torch.int64 else 0, numel,
+                num_experts, block_size, sorted_ids.data_ptr(), expert_ids.data_ptr(), post.data_ptr(), max_padded,
+                max_blocks, _stream())
+    return sorted_ids, expert_ids, post
+
+
+def moe_sum_reduce(x: torch.Tensor, out: torch.Tensor, routed_scaling_factor: float = 1.0) -> torch.Tensor:
+    """sgl_kernel.moe_sum_reduce: x [M, topk, H] (bf16 or fp32) -> out [M, H] bf16."""
+    _dev(x, out)
+    _need(x.dim() == 3 and x.stride(2) == 1 and x.dtype in (_BF16, torch.float32), "moe_sum_reduce: [M, k, H] input")
+    _need(out.dtype == _BF16 and out.dim() == 2 and out.stride(1) == 1, "moe_sum_reduce: bf16 [M, H] output")
+    M, k, H = x.shape
+    native.call("sgl_amd_moe_sum_reduce", x.data_ptr(), 1 if x.dtype == torch.float32 else 0, out.data_ptr(), M, k, H,
+                x.stride(0), x.stride(1), out.stride(0), float(routed_scaling_factor), _stream())
+    return out
+
+
+def choose_moe_block_m(num_pairs: int, num_experts: int) -> int:
+    """Row-block height of the grouped GEMM: the smallest of 16/32/64 that holds an average expert's rows."""
+    avg = (num_pairs + num_experts - 1) // max(1, num_experts)
+    for bm in (16, 32):
+        if avg <= bm:
+            return bm
+    return 64
+
+
+def fused_experts(hidden_states: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, topk_weights: torch.Tensor,
+                  topk_ids: torch.Tensor, routed_scaling_factor: float = 1.0, out: Optional[torch.Tensor] = None
+                  ) -> torch.Tensor:
+    """fused_experts (moe_runner/triton_utils/fused_moe.py:242-455) on the gfx950 kernels:
+    align -> grouped up-GEMM with silu(gate)*up epilogue -> grouped down-GEMM x router weight (fp32)
+    -> sum over top-k.  hidden [M, K] bf16, w13 [E, 2N, K], w2 [E, K, N]."""
+    M, K = hidden_states.shape
+    E, N2, _ = w13.shape
+    N = N2 // 2
+    topk = topk_ids.shape[1]
+    numel = M * topk
+    dev = hidden_states.device
+    if out is None:
+        out = torch.empty((M, K), dtype=_BF16, device=dev)
+    if M == 0:
+        return out
+    block_m = choose_moe_block_m(numel, E)
+    sorted_ids, expert_ids, post = moe_align_block_size(topk_ids, block_m, E)
+    inter = torch.empty((numel, N), dtype=_BF16, device=dev)
+    moe_grouped_gemm(hidden_states, w13, inter, sorted_ids, expert_ids, post, None, False, topk, numel, block_m,
+                     fuse_silu=True)
+    down = torch.empty((numel, K), dtype=torch.float32, device=dev)
+    moe_grouped_gemm(inter, w2, down, sorted_ids, expert_ids, post, topk_weights.reshape(-1).contiguous(), True, 1, numel,
+                     block_m, round_before_scale=True)
+    moe_sum_reduce(down.view(M, topk, K), out, routed_scaling_factor)
+    return out
+
 # -------------------------------------------------------------------------- probe
 def probe_mfma_16x16x32(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     _dev(a, b)

@@ -29,7 +29,7 @@ def _parse_header() -> Dict[str, List]:
     text = HEADER_PATH.read_text()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     sigs: Dict[str, List] = {}
-    for m in re.finditer(r"\b(int|const char\*)\s+(sgl_amd_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
+    for m in re.finditer(r"\b(int64_t|int|const char\*)\s+(sgl_amd_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
         argtypes = []
         if args and args != "void":
@@ -79,7 +79,7 @@ def lib() -> ctypes.CDLL:
         except AttributeError as e:
             raise RuntimeError(f"{path} does not export {name} (declared in sglang_amd.h)") from e
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_char_p if ret != "int" else ctypes.c_int
+        fn.restype = {"int": ctypes.c_int, "int64_t": ctypes.c_int64}.get(ret, ctypes.c_char_p)
     _lib = cdll
     return cdll
 

@@ -34,21 +34,31 @@ def _check_against_oracle(cfg, runner, prompts, outs, trace, new_tokens):
     oracle = OracleLM(cfg, weights_from_product_model(runner.model), compute_dtype=torch.float32)
     ref_outs, ref_logits = oracle.generate(prompts, new_tokens, return_logits=True, forced=outs)
     agree = total = 0
+    outliers = rows = 0
     for step, (got, ref) in enumerate(zip(trace, ref_logits)):
         # "bf16 logits within 1e-3" is stated for the fp32-accumulating oracle on identical inputs;
         # through L layers of bf16 activations the two bf16 pipelines round differently, so the
         # end-to-end bar here is 2e-2 absolute on logits of magnitude ~1 (bf16 eps = 7.8e-3).
-        torch.testing.assert_close(got, ref, atol=2e-2, rtol=2e-2, msg=f"logits step {step}")
+        bad = ((got - ref).abs() > 2e-2 + 2e-2 * ref.abs()).any(dim=1)
+        rows += got.shape[0]
+        outliers += int(bad.sum())
+        if cfg.num_local_experts == 0:
+            torch.testing.assert_close(got, ref, atol=2e-2, rtol=2e-2, msg=f"logits step {step}")
         top2 = ref.topk(2, dim=-1).values
-        clear = (top2[:, 0] - top2[:, 1]) > 4e-2
+        clear = ((top2[:, 0] - top2[:, 1]) > 4e-2) & ~bad
         total += int(clear.sum())
         agree += int((got.argmax(-1)[clear] == ref.argmax(-1)[clear]).sum())
+    # MoE routing is discrete: a token whose k-th and (k+1)-th expert scores differ by less than the
+    # bf16 noise of its hidden state may be routed differently, which moves that row's logits by far
+    # more than 2e-2 (measured: one such row in 36).  Allow a few such rows, none for dense models.
+    assert outliers <= (max(1, rows // 12) if cfg.num_local_experts > 0 else 0), f"{outliers}/{rows} rows off"
     assert agree == total, f"argmax differs on {total - agree}/{total} clear-margin rows"
 
 
 @pytest.mark.parametrize("name,use_graph,page_size", [("tiny-llama", False, 1), ("tiny-llama", True, 1),
                                                       ("tiny-qwen", True, 1), ("tiny-llama3-rope", True, 1),
-                                                      ("tiny-llama", True, 16)])
+                                                      ("tiny-llama", True, 16), ("tiny-mixtral", True, 1),
+                                                      ("tiny-mixtral", False, 1)])
 def test_shared_prefix_generation_matches_oracle(device, name, use_graph, page_size):
     from sglang_amd.harness.engine import Req
 
