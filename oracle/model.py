@@ -20,9 +20,16 @@ from . import ops
 
 class OracleLM:
     def __init__(self, cfg, weights: Dict[str, torch.Tensor], num_slots: int = 4096, max_ctx: int = 2048,
-                 compute_dtype: Optional[torch.dtype] = None):
-        """`weights`: CPU tensors keyed like the product model's state_dict()."""
+                 compute_dtype: Optional[torch.dtype] = None, tp_size: int = 1, tp_group=None):
+        """`weights`: CPU tensors keyed like the product model's state_dict().  With tp_size > 1 the
+        weights are ONE rank's shard (heads / intermediate / vocab split as in the reference's
+        Column/RowParallelLinear, srt/layers/linear.py) and the row-parallel outputs are summed with
+        torch.distributed.all_reduce over `tp_group` (communication_op.py:18), logits all-gathered
+        (logits_processor.py:676)."""
         self.cfg = cfg
+        self.tp_size, self.tp_group = tp_size, tp_group
+        self.Hq = cfg.num_attention_heads // tp_size
+        self.Hkv = max(1, cfg.num_key_value_heads // tp_size)
         self.w = {k: v.detach().cpu() for k, v in weights.items()}
         self.compute_dtype = compute_dtype
         D = cfg.head_dim
@@ -34,8 +41,8 @@ class OracleLM:
             inv = ops.rope_inv_freq(D, cfg.rope_theta)
         self.rope_cache = ops.cos_sin_cache(inv, cfg.max_position_embeddings).to(torch.bfloat16)
         L = cfg.num_hidden_layers
-        self.k_cache = [torch.zeros((num_slots, cfg.num_key_value_heads, D), dtype=torch.bfloat16) for _ in range(L)]
-        self.v_cache = [torch.zeros((num_slots, cfg.num_key_value_heads, D), dtype=torch.bfloat16) for _ in range(L)]
+        self.k_cache = [torch.zeros((num_slots, self.Hkv, D), dtype=torch.bfloat16) for _ in range(L)]
+        self.v_cache = [torch.zeros((num_slots, self.Hkv, D), dtype=torch.bfloat16) for _ in range(L)]
         self.req_to_token = torch.zeros((64, max_ctx), dtype=torch.int32)
         self.next_slot = 1
 
@@ -44,7 +51,7 @@ class OracleLM:
                 prefix_lens: torch.Tensor, extend_lens: torch.Tensor, out_loc: torch.Tensor, decode: bool
                 ) -> torch.Tensor:
         cfg, w = self.cfg, self.w
-        D, Hq, Hkv = cfg.head_dim, cfg.num_attention_heads, cfg.num_key_value_heads
+        D, Hq, Hkv = cfg.head_dim, self.Hq, self.Hkv
         h = F.embedding(input_ids, w["embed_tokens"])
         residual = None
         for i in range(cfg.num_hidden_layers):
@@ -65,20 +72,35 @@ class OracleLM:
             else:
                 o = ops.extend_attention(q3, self.k_cache[i], self.v_cache[i], self.req_to_token, req_pool, seq_lens,
                                          prefix_lens, extend_lens, D ** -0.5, True, self.compute_dtype)
-            h = F.linear(o.reshape(-1, Hq * D), w[p + "self_attn.o_proj.weight"])
+            h = self._all_reduce(F.linear(o.reshape(-1, Hq * D), w[p + "self_attn.o_proj.weight"]))
             h, residual = ops.fused_add_rmsnorm(h, residual, w[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps)
             if cfg.num_local_experts > 0:
                 logits = F.linear(h, w[p + "mlp.gate.weight"])
                 tw, ti = ops.fused_topk(logits, cfg.num_experts_per_tok, True)
-                h = ops.moe_forward(h, w[p + "mlp.experts.w13_weight"], w[p + "mlp.experts.w2_weight"], tw, ti)
+                h = self._all_reduce(ops.moe_forward(h, w[p + "mlp.experts.w13_weight"], w[p + "mlp.experts.w2_weight"], tw, ti))
             else:
                 gu = F.linear(h, w[p + "mlp.gate_up_proj.weight"])
-                h = F.linear(ops.silu_and_mul(gu), w[p + "mlp.down_proj.weight"])
+                h = self._all_reduce(F.linear(ops.silu_and_mul(gu), w[p + "mlp.down_proj.weight"]))
         h, _ = ops.fused_add_rmsnorm(h, residual, w["norm.weight"], cfg.rms_norm_eps)
         if not decode:
             last = torch.cumsum(extend_lens, 0) - 1
             h = h[last]
-        return F.linear(h, w["lm_head"]).float()
+        logits = F.linear(h, w["lm_head"])
+        if self.tp_size > 1:
+            import torch.distributed as dist
+
+            parts = [torch.empty_like(logits) for _ in range(self.tp_size)]
+            dist.all_gather(parts, logits.contiguous(), group=self.tp_group)
+            logits = torch.cat(parts, dim=-1)
+        return logits.float()
+
+    def _all_reduce(self, x: torch.Tensor) -> torch.Tensor:
+        if self.tp_size > 1:
+            import torch.distributed as dist
+
+            x = x.contiguous()
+            dist.all_reduce(x, group=self.tp_group)
+        return x
 
     # ---- greedy generation with prefix reuse expressed the plain way ------------------------
     def generate(self, prompts: Sequence[Sequence[int]], max_new_tokens: int, return_logits: bool = False,
