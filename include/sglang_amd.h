@@ -119,7 +119,9 @@ int sgl_amd_alloc_decode(const int64_t* seq_lens, const int64_t* last_loc,
 /* Decode: one query token per request.  q/out [B,Hq,D] bf16, KV pool [slots,Hkv,D] bf16.
  * Token t of request b lives in slot req_to_token[req_pool_indices[b], t]  (kv_indptr==NULL)
  * or req_to_token[kv_indptr[b] + t] (flat kv_indices form).  num_splits>1 needs
- * ws_acc fp32 [B,Hq,num_splits,D] and ws_ml fp32 [B,Hq,num_splits,2]. */
+ * ws_acc fp32 [B,Hq,num_splits,D] and ws_ml fp32 [B,Hq,num_splits,2].  batch_order (optional, [B]
+ * permutation, e.g. the cascade plan's) lays requests that share KV rows out on one XCD so the
+ * shared rows are re-read from that XCD's L2. */
 int sgl_amd_decode_attention(const void* q, const void* k_cache, const void* v_cache, void* out,
                              const int32_t* req_to_token, int64_t req_to_token_stride,
                              const int64_t* req_pool_indices, const int32_t* seq_lens,
@@ -127,7 +129,8 @@ int sgl_amd_decode_attention(const void* q, const void* k_cache, const void* v_c
                              int num_kv_heads, int head_dim, int64_t q_token_stride,
                              int64_t out_token_stride, int64_t k_cache_row_stride,
                              int64_t v_cache_row_stride, float sm_scale, int num_splits,
-                             void* ws_acc, void* ws_ml, int flags, void* stream);
+                             void* ws_acc, void* ws_ml, const int32_t* batch_order, int flags,
+                             void* stream);
 int sgl_amd_decode_attention_min_chunk(void);
 /* Extend (prefill): request b owns query tokens qo_indptr[b]..qo_indptr[b+1] of q/out
  * [T,Hq,D]; query i attends kv positions [0, prefix_lens[b]+i] (causal) or
@@ -141,6 +144,49 @@ int sgl_amd_extend_attention(const void* q, void* out, const void* k_cache, cons
                              int64_t q_token_stride, int64_t out_token_stride,
                              int64_t k_cache_row_stride, int64_t v_cache_row_stride, float sm_scale,
                              int causal, void* stream);
+
+/* ---- Shared-prefix (cascade) decode attention ---------------------------------------------------
+ * RadixAttention batches share KV prefixes: requests whose req_to_token rows start with the same slots
+ * read the same pool rows.  sgl_amd_cascade_plan (one launch per decode STEP, device-only, graph-safe)
+ * groups such requests; sgl_amd_cascade_decode_attention (per layer) then reads every group's shared
+ * part ONCE for all members (MFMA, all members' query heads as rows), each request's private suffix
+ * with the paged decode kernel, and LSE-merges the split slots.  Same result as
+ * sgl_amd_decode_attention (reference semantics torch_native_backend.py:176-277) up to fp32 rounding.
+ * plan: int32[sgl_amd_cascade_plan_ints(batch, max_items)]; ws_acc fp32 [B,Hq,slots,D], ws_ml fp32
+ * [B,Hq,slots,2] with slots = shared_slots + suffix_splits, shared_slots >= ceil(max shared len / chunk_tokens). */
+int64_t sgl_amd_cascade_plan_ints(int64_t batch, int64_t max_items);
+int sgl_amd_cascade_plan(const int32_t* req_to_token, int64_t req_to_token_stride,
+                         const int64_t* req_pool_indices, const int32_t* seq_lens, int64_t batch,
+                         int num_q_heads, int num_kv_heads, int min_shared_len, int chunk_tokens,
+                         int32_t* plan, int64_t max_items, void* ws_ml, int shared_slots,
+                         int slots_total, void* stream);
+int sgl_amd_cascade_shared_part(const void* q, const void* k_cache, const void* v_cache,
+                                const int32_t* req_to_token, int64_t req_to_token_stride,
+                                const int32_t* plan, int64_t batch, int64_t max_items, int num_q_heads,
+                                int num_kv_heads, int head_dim, int64_t q_token_stride,
+                                int64_t k_cache_row_stride, int64_t v_cache_row_stride, float sm_scale,
+                                int chunk_tokens, int slots_total, void* ws_acc, void* ws_ml, void* stream);
+int sgl_amd_cascade_suffix_part(const void* q, const void* k_cache, const void* v_cache,
+                                const int32_t* req_to_token, int64_t req_to_token_stride,
+                                const int64_t* req_pool_indices, const int32_t* seq_lens,
+                                const int32_t* plan, int64_t batch, int64_t max_items, int num_q_heads,
+                                int num_kv_heads, int head_dim, int64_t q_token_stride,
+                                int64_t k_cache_row_stride, int64_t v_cache_row_stride, float sm_scale,
+                                int shared_slots, int suffix_splits, void* ws_acc, void* ws_ml, int flags,
+                                void* stream);
+int sgl_amd_cascade_merge(const void* ws_acc, const void* ws_ml, void* out, int64_t batch, int num_q_heads,
+                          int head_dim, int64_t out_token_stride, int slots_total, void* stream);
+/* shared part + suffix part + merge on one stream (the three parts above can also be called
+ * separately, e.g. parts 1 and 2 on two streams). */
+int sgl_amd_cascade_decode_attention(const void* q, const void* k_cache, const void* v_cache, void* out,
+                                     const int32_t* req_to_token, int64_t req_to_token_stride,
+                                     const int64_t* req_pool_indices, const int32_t* seq_lens,
+                                     const int32_t* plan, int64_t batch, int64_t max_items,
+                                     int num_q_heads, int num_kv_heads, int head_dim,
+                                     int64_t q_token_stride, int64_t out_token_stride,
+                                     int64_t k_cache_row_stride, int64_t v_cache_row_stride,
+                                     float sm_scale, int chunk_tokens, int shared_slots,
+                                     int suffix_splits, void* ws_acc, void* ws_ml, int flags, void* stream);
 
 /* ---- Sampling (reference: srt/layers/sampler.py:98-260,567-750;
  *      kernels/ops/sampling/murmur_hash.py:51-121) ------------------------------- */

@@ -36,6 +36,7 @@ class _Meta:
     qo_indptr: Optional[torch.Tensor] = None
     prefix_lens_i32: Optional[torch.Tensor] = None
     max_extend_len: int = 0
+    cascade: Optional["kernels.CascadeWorkspace"] = None   # shared-prefix decode plan + split slots
 
 
 def choose_num_splits(batch: int, num_kv_heads: int, group: int, max_len: int, target_blocks: int = 512) -> int:
@@ -62,7 +63,13 @@ class HipAttnBackend(AttentionBackend):
         self.max_context_len = self.req_to_token_pool.max_context_len
         self.forward_metadata: Optional[_Meta] = None
         self._graph_ws = {}
+        self._cascade_ws = {}
         self.debug_flags = 0
+        # RadixAttention batches share KV prefixes; the cascade decode path reads a shared prefix once
+        # per group (SGLANG_AMD_CASCADE=0 falls back to the plain paged decode kernel)
+        import os
+
+        self.enable_cascade = os.environ.get("SGLANG_AMD_CASCADE", "1") != "0" and self.head_dim in (64, 128)
 
     # ------------------------------------------------------------------ metadata
     def _workspace(self, batch: int, splits: int):
@@ -71,6 +78,13 @@ class HipAttnBackend(AttentionBackend):
         if ws is None:
             ws = kernels.decode_workspace(batch, self.num_q_heads, self.head_dim, splits, self.device)
             self._graph_ws[key] = ws
+        return ws
+
+    def _cascade_workspace(self, batch: int):
+        ws = self._cascade_ws.get(batch)
+        if ws is None:
+            ws = kernels.CascadeWorkspace(batch, self.num_q_heads, self.head_dim, self.max_context_len, 1, self.device)
+            self._cascade_ws[batch] = ws
         return ws
 
     def init_cuda_graph_state(self, max_bs: int, max_num_tokens: int):
@@ -89,6 +103,9 @@ class HipAttnBackend(AttentionBackend):
                 max_len = self.max_context_len       # the graph must be valid for any later length
             else:
                 max_len = int(fb.seq_lens_cpu.max()) if fb.seq_lens_cpu is not None else self.max_context_len
+            if self.enable_cascade and 2 <= fb.batch_size <= 1024:
+                self.forward_metadata = _Meta(seq_i32, cascade=self._cascade_workspace(fb.batch_size))
+                return
             splits = choose_num_splits(fb.batch_size, self.num_kv_heads, self.num_q_heads // self.num_kv_heads, max_len)
             ws = self._workspace(fb.batch_size, splits) if splits > 1 else (None, None)
             self.forward_metadata = _Meta(seq_i32, splits, ws[0], ws[1])
@@ -103,7 +120,12 @@ class HipAttnBackend(AttentionBackend):
             self.forward_metadata = None
 
     def init_forward_metadata_in_graph(self, forward_batch):
-        """Nothing to record: the decode kernel reads seq_lens / req_to_token itself."""
+        """Device-only, static-shape work recorded into the decode graph: the shared-prefix plan of
+        this step (one launch per step, reused by every layer).  The plain decode kernel needs nothing."""
+        m = self.forward_metadata
+        if m is not None and m.cascade is not None and forward_batch.forward_mode.is_decode():
+            kernels.cascade_plan(m.cascade, self.req_to_token_pool.req_to_token, forward_batch.req_pool_indices,
+                                 m.seq_lens_i32, self.num_q_heads, self.num_kv_heads)
 
     # ------------------------------------------------------------------ forward
     def _save_kv(self, layer, forward_batch, k, v):
@@ -130,6 +152,12 @@ class HipAttnBackend(AttentionBackend):
         m = self.forward_metadata
         q3 = q.reshape(-1, layer.tp_q_head_num, layer.qk_head_dim)
         o = torch.empty_like(q3)
+        if m.cascade is not None:
+            kernels.cascade_decode_attention(m.cascade, q3, self.token_to_kv_pool.get_key_buffer(layer.layer_id),
+                                             self.token_to_kv_pool.get_value_buffer(layer.layer_id), o,
+                                             self.req_to_token_pool.req_to_token, forward_batch.req_pool_indices,
+                                             m.seq_lens_i32, layer.scaling, flags=self.debug_flags)
+            return o.view(-1, layer.tp_q_head_num * layer.v_head_dim)
         kernels.decode_attention(q3, self.token_to_kv_pool.get_key_buffer(layer.layer_id),
                                  self.token_to_kv_pool.get_value_buffer(layer.layer_id), o,
                                  self.req_to_token_pool.req_to_token, forward_batch.req_pool_indices, m.seq_lens_i32,

@@ -61,6 +61,7 @@ class DecodeGraphRunner:
 
     def _run(self, fb: ForwardBatch) -> torch.Tensor:
         kernels.clamp_position(fb.seq_lens, out=fb.positions)      # in-graph: positions = seq_lens - 1
+        self.mr.attn_backend.init_forward_metadata_in_graph(fb)    # in-graph: shared-prefix plan of this step
         return self.mr.model.forward(fb.input_ids, fb.positions, fb).next_token_logits
 
     def capture(self) -> None:

@@ -1,0 +1,140 @@
+"""GPU parity tests of the shared-prefix (cascade) decode attention: the device plan is checked against a
+host restatement, and the attention output against the CPU oracle
+(oracle/ops.py decode_attention = torch_native_backend.py:176-277) and the plain paged decode kernel."""
+import pytest
+import torch
+
+from oracle import ops as oo
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def _k():
+    from sglang_amd import kernels
+
+    return kernels
+
+
+def _batch(device, lens, groups, shared, Hq, Hkv, D, seed=0, extra_rows=8):
+    """lens[b] kv length; groups[b] = group id or -1; shared[g] = shared prefix length of group g."""
+    g = torch.Generator().manual_seed(seed)
+    B = len(lens)
+    ctx = max(lens) + extra_rows
+    slots = sum(lens) + 64
+    kc = (torch.randn((slots, Hkv, D), generator=g) * 0.5).to(BF)
+    vc = (torch.randn((slots, Hkv, D), generator=g) * 0.5).to(BF)
+    perm = (torch.randperm(slots - 1, generator=g) + 1).to(torch.int32)
+    r2t = torch.zeros((B + 1, ctx), dtype=torch.int32)
+    off = 0
+    first_of_group = {}
+    for b in range(B):
+        r2t[b + 1, :lens[b]] = perm[off: off + lens[b]]
+        off += lens[b]
+        gi = groups[b]
+        if gi >= 0:
+            if gi in first_of_group:
+                n = min(shared[gi], lens[b] - 1)
+                r2t[b + 1, :n] = r2t[first_of_group[gi] + 1, :n]
+            else:
+                first_of_group[gi] = b
+    q = (torch.randn((B, Hq, D), generator=g) * 0.5).to(BF)
+    pool = torch.arange(1, B + 1)
+    seq = torch.tensor(lens, dtype=torch.int32)
+    return q, kc, vc, r2t, pool, seq
+
+
+def _run(device, q, kc, vc, r2t, pool, seq, Hq, Hkv, D, suffix_splits=1, min_shared=128):
+    K = _k()
+    B = q.shape[0]
+    ws = K.CascadeWorkspace(B, Hq, D, r2t.shape[1], suffix_splits, device)
+    r2t_d, pool_d, seq_d = r2t.to(device), pool.to(device), seq.to(device)
+    K.cascade_plan(ws, r2t_d, pool_d, seq_d, Hq, Hkv, min_shared)
+    out = torch.empty((B, Hq, D), dtype=BF, device=device)
+    K.cascade_decode_attention(ws, q.to(device), kc.to(device), vc.to(device), out, r2t_d, pool_d, seq_d, D ** -0.5)
+    return out.cpu(), K.cascade_plan_summary(ws, B)
+
+
+def _check(out, q, kc, vc, r2t, pool, seq, D):
+    ref = oo.decode_attention(q, kc, vc, r2t, pool, seq.long(), D ** -0.5, compute_dtype=torch.float32)
+    err = (out.float() - ref.float()).abs()
+    assert float(err.max()) <= 2.0 ** -8 * float(ref.float().abs().max()) + 2e-3, float(err.max())
+
+
+def test_plan_groups_the_bench_pattern(device):
+    """4 groups x 16 requests (leaders first, like the engine's running list), 896 shared tokens."""
+    Hq, Hkv, D = 32, 8, 128
+    B, P = 64, 16
+    order = [g * P for g in range(4)] + [g * P + i for g in range(4) for i in range(1, P)]
+    groups = [o // P for o in order]
+    lens = [1030 + (i % 7) for i in range(B)]
+    q, kc, vc, r2t, pool, seq = _batch(device, lens, groups, {g: 896 for g in range(4)}, Hq, Hkv, D)
+    out, plan = _run(device, q, kc, vc, r2t, pool, seq, Hq, Hkv, D)
+    assert plan["n_groups"] == 4 and plan["group_kvlen"] == [896] * 4
+    assert plan["group_qo"] == [0, 16, 32, 48, 64]
+    assert sorted(plan["member_rows"]) == list(range(B))
+    for gi in range(4):
+        rows = plan["member_rows"][16 * gi: 16 * gi + 16]
+        assert rows == sorted(rows) and {groups[r] for r in rows} == {gi}
+    assert plan["req_shared"] == [896] * B
+    assert plan["n_items"] == 4 * 7 and len(set(plan["items"])) == 28
+    _check(out, q, kc, vc, r2t, pool, seq, D)
+
+
+@pytest.mark.parametrize("Hq,Hkv,D", [(32, 8, 128), (8, 1, 128), (14, 2, 64), (16, 4, 128), (4, 4, 64)])
+def test_cascade_matches_oracle_mixed_batch(device, Hq, Hkv, D):
+    """Groups of different sizes / shared lengths, singletons, a too-short share, ragged suffixes,
+    a group whose members share DIFFERENT lengths with the leader (min wins), > 32 members (2 row tiles)."""
+    lens, groups, shared = [], [], {}
+    def add(n, gid, ln):
+        for i in range(n):
+            lens.append(ln + 3 * i)
+            groups.append(gid)
+    add(3, 0, 700); shared[0] = 512
+    add(1, -1, 333)
+    add(40, 1, 300); shared[1] = 200          # rounds down to 192
+    add(2, 2, 150); shared[2] = 70            # below min_shared: no group
+    add(1, -1, 1)                             # a request with a single token
+    add(2, 3, 900); shared[3] = 899
+    q, kc, vc, r2t, pool, seq = _batch(device, lens, groups, shared, Hq, Hkv, D, seed=Hq + D)
+    # make one member of group 0 diverge earlier than the others
+    r2t[3, 300:512] = r2t[4, 600:812]
+    out, plan = _run(device, q, kc, vc, r2t, pool, seq, Hq, Hkv, D, suffix_splits=2)
+    assert plan["n_groups"] == 3
+    assert plan["group_kvlen"] == [256, 192, 896]          # 300 -> 256, 200 -> 192, 899 -> 896
+    tiles_g1 = (40 + (128 // (Hq // Hkv)) - 1) // (128 // (Hq // Hkv))
+    assert plan["n_items"] == 2 * 1 + 2 * tiles_g1 + 7 * 1
+    _check(out, q, kc, vc, r2t, pool, seq, D)
+
+
+def test_cascade_without_sharing_equals_plain_decode(device):
+    K = _k()
+    Hq, Hkv, D = 32, 8, 128
+    lens = [517, 64, 1, 129, 1000, 33, 257]
+    q, kc, vc, r2t, pool, seq = _batch(device, lens, [-1] * len(lens), {}, Hq, Hkv, D, seed=3)
+    out, plan = _run(device, q, kc, vc, r2t, pool, seq, Hq, Hkv, D, suffix_splits=2)
+    assert plan["n_groups"] == 0 and plan["n_items"] == 0 and plan["req_shared"] == [0] * len(lens)
+    _check(out, q, kc, vc, r2t, pool, seq, D)
+    plain = torch.empty_like(q, device=device)
+    K.decode_attention(q.to(device), kc.to(device), vc.to(device), plain, r2t.to(device), pool.to(device), seq.to(device),
+                       D ** -0.5)
+    assert float((plain.cpu().float() - out.float()).abs().max()) <= 2.0 ** -7
+
+
+def test_cascade_plan_replans_every_step(device):
+    """The same workspace is reused across steps with different groupings (stale slots must not leak)."""
+    K = _k()
+    Hq, Hkv, D = 16, 4, 128
+    B = 12
+    ws = None
+    for step, (groups, shared) in enumerate([([0] * 6 + [1] * 6, {0: 640, 1: 384}), ([-1] * 12, {}),
+                                             ([0] * 12, {0: 256})]):
+        lens = [700 + 5 * i for i in range(B)]
+        q, kc, vc, r2t, pool, seq = _batch(device, lens, groups, shared, Hq, Hkv, D, seed=step)
+        if ws is None:
+            ws = K.CascadeWorkspace(B, Hq, D, r2t.shape[1] + 64, 1, device)
+        r2t_d, pool_d, seq_d = r2t.to(device), pool.to(device), seq.to(device)
+        K.cascade_plan(ws, r2t_d, pool_d, seq_d, Hq, Hkv)
+        out = torch.empty((B, Hq, D), dtype=BF, device=device)
+        K.cascade_decode_attention(ws, q.to(device), kc.to(device), vc.to(device), out, r2t_d, pool_d, seq_d, D ** -0.5)
+        _check(out.cpu(), q, kc, vc, r2t, pool, seq, D)
