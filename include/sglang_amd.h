@@ -238,6 +238,25 @@ int sgl_amd_skinny_gemm_max_rows(void);
 int sgl_amd_skinny_gemm_chunk(void);
 int64_t sgl_amd_skinny_gemm_slab_floats(int64_t row_blocks, int64_t N, int splits, int fuse_silu,
                                         int tiles_per_wave);
+/* Weight-streaming GEMM for decode batches (M <= sgl_amd_wstream_gemm_max_rows()): y = x . w^T, bf16,
+ * fp32 accumulate; needs N % 16 == 0 and K % 128 == 0 (other shapes: sgl_amd_skinny_gemm).
+ * Replaces the library matmul of srt/layers/linear.py:1596-1660 (UnquantizedLinearMethod.apply) at decode.
+ * waves_per_group (4..8) x num_k_splits is the host's choice of decomposition: one workgroup is
+ * resident per CU (its LDS ring holds the in-flight chunks), so ceil(N/16/waves) x splits should be a
+ * whole number of 256-workgroup rounds.  num_k_splits > 1 writes fp32 partials
+ * [splits, M, N] to ws_partials (sgl_amd_wstream_gemm_workspace_floats) and a combine kernel sums
+ * them in split order (deterministic) and applies `epilogue`:
+ *   0: y[M,N]   = bf16(acc + bias)                         (bias may be NULL; also valid with 1 split)
+ *   1: y[M,N/2] = silu_and_mul of the [gate | up] columns  (srt/layers/activation.py:141-143 rounding)
+ *   2: h = bf16(acc + bias); residual += h (bf16, in place); y = RMSNorm(residual) * norm_weight
+ *      (srt/layers/layernorm.py:786-820 forward_native with residual). */
+int sgl_amd_wstream_gemm(const void* x, const void* w, const void* bias, void* y, int64_t M, int64_t N,
+                         int64_t K, int64_t x_row_stride, int64_t w_row_stride, int64_t y_row_stride,
+                         int epilogue, void* residual, int64_t residual_row_stride,
+                         const void* norm_weight, float eps, int waves_per_group, int num_k_splits,
+                         void* ws_partials, void* stream);
+int sgl_amd_wstream_gemm_max_rows(void);
+int64_t sgl_amd_wstream_gemm_workspace_floats(int64_t M, int64_t N, int num_k_splits);
 /* Grouped GEMM over moe_align_block_size output: for every row block b < num_tokens_post_padded/block_m
  * with expert e = expert_ids[b]:  c[id, :] = a[id / top_k_div, :] . w[e]^T  for id in
  * sorted_token_ids[b*block_m : (b+1)*block_m] with id < num_valid_ids, optionally scaled by

@@ -1,0 +1,449 @@
+// Weight-streaming GEMM for decode batches on gfx950:  y[M, N] = x[M, K] . W[N, K]^T,  M <= 64.
+//
+// Replaces, for decode-sized M, the library matmul behind the dense projections of the
+// decoder layer (reference, /root/reference/python/sglang):
+//   srt/layers/linear.py:1596-1660   UnquantizedLinearMethod.apply  (qkv / o / gate_up / down / lm_head)
+// and, through the fused epilogues of the split-K combine kernel,
+//   srt/layers/activation.py:141-143 SiluAndMul.forward_native           (after gate_up)
+//   srt/layers/layernorm.py:786-820  RMSNorm.forward_native with residual (after o_proj / down_proj)
+// Oracle: torch F.linear + oracle/ops.py.
+//
+// Every weight byte is used exactly once per decode step, so the kernel is an HBM stream of W
+// with the matrix cores riding along.  Differences from skinny_gemm.hip (which stays for the
+// grouped / ragged-K cases):
+//   * a wave owns ONE 16-row tile of W and a K range; its weight rows go straight from HBM into
+//     the MFMA A-operand registers (non-temporal 16 B loads, 64 contiguous bytes per row per
+//     instruction), kPD K-chunks (kPD KiB per lane group) in flight per wave at all times -- the
+//     activation chunk of the same K range travels in the same register ring, so the in-order
+//     vmcnt never drains the weight prefetch;
+//   * the activation rows are shared by the 4-8 waves of a workgroup through a double-buffered,
+//     XOR-swizzled LDS image (one barrier per 128-wide K chunk);
+//   * the (waves per workgroup, K splits) pair is chosen by the host per shape so that
+//     tiles x splits fills the 256 CUs evenly (N=28672: 7 waves x 2 splits = 14 waves on every CU);
+//   * split-K partials are plain row-major fp32 [split][M][N]; one combine kernel sums them in
+//     split order (deterministic) and applies the epilogue the next operator would have been:
+//     bias, silu(gate)*up, or residual-add + RMSNorm, with the torch-native bf16 rounding points.
+#include "common.hpp"
+#include "../../include/sglang_amd.h"
+
+using namespace sgl_amd;
+
+namespace {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int kKC = 128;              // K elements per chunk (256 B of every weight row)
+constexpr int kKSteps = kKC / 32;     // MFMA k-steps per chunk
+constexpr int kSlotsPerRow = kKC / 8; // 16-byte slots per staged activation row
+
+__device__ __forceinline__ bf16x8_t as_frag(const U4& v) { return __builtin_bit_cast(bf16x8_t, v); }
+
+// streamed-once data: keep it out of the way of the L2-resident activations
+__device__ __forceinline__ U4 ld16_stream(const uint16_t* p) {
+  u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+  return __builtin_bit_cast(U4, v);
+}
+
+struct WsParams {
+  const uint16_t* x;     // [M, K]
+  const uint16_t* w;     // [N, K]
+  const uint16_t* bias;  // optional [N] (only applied when splits == 1)
+  uint16_t* y;           // [M, N] bf16 (splits == 1)
+  float* part;           // [splits, M, N] fp32, or NULL: write y directly
+  int64_t x_stride, w_stride, y_stride;
+  int M, N, K, splits, ntiles;
+};
+
+// ---- LDS-DMA plumbing ------------------------------------------------------------------------
+// The weight and activation chunks go HBM/L2 -> LDS with global_load_lds_dwordx4 (1 KiB per wave
+// instruction, lane i lands at dst + 16 i, no VGPR round trip).  hipcc orders every LDS read it can
+// see behind ALL pending LDS-DMA (s_waitcnt vmcnt(0)), which would collapse the prefetch ring, so
+// the fragment reads are inline-asm ds_read_b128 and the two counters are waited on by hand.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __attribute__((address_space(3))) unsigned char* lds_bytes_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+template <int AUX>
+__device__ __forceinline__ void dma16(const uint16_t* src, lds_ptr_t dst) {
+  __builtin_amdgcn_global_load_lds((glb_ptr_t)(src), dst, 16, 0, AUX);
+}
+
+template <int OFF>
+__device__ __forceinline__ u32x4_t lds_rd(uint32_t addr) {
+  u32x4_t v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+
+// s_waitcnt lgkmcnt(N) that the consumers of (a, b[0..MT)) cannot be scheduled across
+template <int N, int MT>
+__device__ __forceinline__ void wait_lgkm(u32x4_t& a, u32x4_t (&b)[MT]) {
+  if constexpr (MT == 1) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b[0]) : "n"(N));
+  else if constexpr (MT == 2) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b[0]), "+v"(b[1]) : "n"(N));
+  else if constexpr (MT == 3) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]) : "n"(N));
+  else asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N));
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// wait until at most min(k, KMAX) chunks (LPC DMA instructions each) are still outstanding; k is wave-uniform
+template <int LPC, int KMAX>
+__device__ __forceinline__ void wait_chunks(int k) {
+  if constexpr (KMAX == 0) {
+    wait_vm<0>();
+  } else {
+    if (k >= KMAX) wait_vm<KMAX * LPC>();
+    else wait_chunks<LPC, KMAX - 1>(k);
+  }
+}
+
+// ring depth: as many chunk slots as fit the 160 KiB LDS (1 KiB is the dummy landing zone), at most 6
+constexpr int ring_depth(int mt, int nw) {
+  const int slot = nw * 4096 + mt * 4 * 1024;
+  const int d = (160 * 1024 - 1024) / slot;
+  return d > 6 ? 6 : d;
+}
+
+template <int MT, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void wstream_gemm_kernel(WsParams p) {
+  constexpr int PD = ring_depth(MT, NW);
+  constexpr int XPIECES = MT * 4;                       // 1 KiB pieces (4 rows x 256 B) of an activation chunk
+  constexpr int XP = (XPIECES + NW - 1) / NW;           // pieces each wave fetches (surplus -> dummy slot)
+  constexpr int LPC = kKSteps + XP;                     // DMA instructions per wave per chunk
+  constexpr int WCH = NW * 4096;                        // weight bytes per chunk (4 KiB per wave)
+  constexpr int CH = WCH + XPIECES * 1024;              // ring slot: [weights of wave 0..NW) | activations]
+  static_assert(PD >= 3 && PD * CH + 1024 <= 160 * 1024, "LDS ring does not fit");
+  static_assert((PD - 2) * LPC < 64, "vmcnt range");
+  __shared__ __attribute__((aligned(1024))) unsigned char ring[PD * CH + 1024];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g = lane >> 4;
+  const int tile = blockIdx.x * NW + wid;
+  const bool active = tile < p.ntiles;
+  const int split = blockIdx.y;
+  const int nch = p.K / kKC;
+  const int cb = static_cast<int>(static_cast<int64_t>(split) * nch / p.splits);
+  const int ce = static_cast<int>(static_cast<int64_t>(split + 1) * nch / p.splits);
+  const int n = ce - cb;
+
+  // ---- DMA roles.  A 1 KiB piece = 4 rows x 16 slots; the lane at (row q, slot s) of the LDS image
+  // fetches global slot s ^ (row & 15): the XOR swizzle that makes the fragment reads conflict-free
+  // is applied on the global side, each row's 256 B still move as two whole cache lines.
+  const int q4 = lane >> 4, s16 = lane & 15;
+  const uint16_t* wsrc[kKSteps];
+#pragma unroll
+  for (int j = 0; j < kKSteps; ++j) {
+    const int row = 4 * j + q4;
+    wsrc[j] = p.w + (static_cast<int64_t>(active ? tile : p.ntiles - 1) * 16 + row) * p.w_stride +
+              ((s16 ^ row) & 15) * 8 + static_cast<int64_t>(cb) * kKC;
+  }
+  const uint16_t* xsrc[XP];
+  int xoff[XP];                                          // wave-uniform LDS offset inside a ring slot
+#pragma unroll
+  for (int i = 0; i < XP; ++i) {
+    const int piece = wid + NW * i;
+    const bool real = piece < XPIECES;
+    const int row = real ? 4 * piece + q4 : 0;
+    const int srow = row < p.M ? row : p.M - 1;
+    xsrc[i] = p.x + static_cast<int64_t>(srow) * p.x_stride + ((s16 ^ row) & 15) * 8 + static_cast<int64_t>(cb) * kKC;
+    xoff[i] = real ? WCH + piece * 1024 : -1;
+  }
+  lds_bytes_t ring3 = (lds_bytes_t)(ring);
+  auto issue = [&](int c_rel, int slot) {                // chunk cb + c_rel -> ring slot
+    const int koff = c_rel * kKC;
+    const int base = slot * CH;
+#pragma unroll
+    for (int j = 0; j < kKSteps; ++j)
+      dma16<2>(wsrc[j] + koff, (lds_ptr_t)(ring3 + base + wid * 4096 + j * 1024));
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+      const int off = xoff[i] >= 0 ? base + xoff[i] : PD * CH;
+      dma16<0>(xsrc[i] + koff, (lds_ptr_t)(ring3 + off));
+    }
+  };
+
+  // ---- fragment read addresses (bytes, LDS address space) ----
+  const uint32_t ring_addr = (uint32_t)(uintptr_t)(ring3);
+  uint32_t foff[kKSteps];
+#pragma unroll
+  for (int kk = 0; kk < kKSteps; ++kk) foff[kk] = r16 * 256 + (((kk * 4 + g) ^ r16) & 15) * 16;
+
+  f32x4_t acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  auto read_frags = [&](uint32_t slot_addr, int kk, u32x4_t& a, u32x4_t (&b)[MT]) {
+    const uint32_t ad = slot_addr + foff[kk];
+    a = lds_rd<0>(ad + wid * 4096);
+    b[0] = lds_rd<WCH>(ad);
+    if constexpr (MT > 1) b[1] = lds_rd<WCH + 4096>(ad);
+    if constexpr (MT > 2) b[2] = lds_rd<WCH + 8192>(ad);
+    if constexpr (MT > 3) b[3] = lds_rd<WCH + 12288>(ad);
+  };
+  auto compute = [&](int slot) {
+    const uint32_t slot_addr = ring_addr + slot * CH;
+    u32x4_t a[2], b[2][MT];
+    read_frags(slot_addr, 0, a[0], b[0]);
+#pragma unroll
+    for (int kk = 0; kk < kKSteps; ++kk) {
+      const int cur = kk & 1;
+      if (kk + 1 < kKSteps) {
+        read_frags(slot_addr, kk + 1, a[cur ^ 1], b[cur ^ 1]);
+        wait_lgkm<MT + 1, MT>(a[cur], b[cur]);
+      } else {
+        wait_lgkm<0, MT>(a[cur], b[cur]);
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[cur]),
+                                                          __builtin_bit_cast(bf16x8_t, b[cur][mt]), acc[mt], 0, 0, 0);
+    }
+  };
+
+  // ---- pipeline: PD-1 chunks in flight, one barrier per chunk ----
+#pragma unroll
+  for (int u = 0; u < PD - 1; ++u)
+    if (u < n) issue(u, u);
+  int slot = 0, nslot = PD - 1;                          // slot of chunk c, slot of chunk c + PD - 1
+  for (int c = 0; c < n; ++c) {
+    // chunk c has landed once at most the younger in-flight chunks' DMAs are outstanding
+    wait_chunks<LPC, PD - 2>(n - 1 - c);
+    __builtin_amdgcn_s_barrier();                        // everyone's pieces of chunk c are visible,
+                                                         // everyone is done reading chunk c - 1
+    if (c + PD - 1 < n) issue(c + PD - 1, nslot);
+    compute(slot);
+    slot = slot + 1 == PD ? 0 : slot + 1;
+    nslot = nslot + 1 == PD ? 0 : nslot + 1;
+  }
+
+  if (!active) return;
+  // lane holds C[m = 16 mt + r16][n = 16 tile + 4 g + r]
+  const int n0 = tile * 16 + g * 4;
+  if (p.part) {
+    float* base = p.part + static_cast<int64_t>(split) * p.M * p.N;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = mt * 16 + r16;
+      if (m < p.M) *reinterpret_cast<f32x4_t*>(base + static_cast<int64_t>(m) * p.N + n0) = acc[mt];
+    }
+    return;
+  }
+  float b4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) b4[r] = bf2f(p.bias[n0 + r]);
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = mt * 16 + r16;
+    if (m >= p.M) continue;
+    uint2 w2;
+    w2.x = pack_bf2(acc[mt][0] + b4[0], acc[mt][1] + b4[1]);
+    w2.y = pack_bf2(acc[mt][2] + b4[2], acc[mt][3] + b4[3]);
+    *reinterpret_cast<uint2*>(p.y + static_cast<int64_t>(m) * p.y_stride + n0) = w2;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Split-K combine + epilogue.  part [splits, M, N] fp32, summed in split order.
+//   mode 0: y[m, n]  = bf16(sum + bias[n])
+//   mode 1: y[m, j]  = bf16( bf16(silu(bf16(sum[m, j]))) * bf16(sum[m, N/2 + j]) )       j < N/2
+//           (linear -> bf16, activation.py:141-143 silu -> bf16, product -> bf16)
+//   mode 2: h = bf16(sum + bias);  t = h + residual (fp32);  residual <- bf16(t);
+//           y = bf16(t * rsqrt(mean(t^2) + eps) * norm_w)   (layernorm.py:786-820)
+// mode 0/1: grid (column blocks, M); mode 2: one workgroup per row.
+// ---------------------------------------------------------------------------------------------
+struct CombineParams {
+  const float* part;
+  const uint16_t* bias;
+  uint16_t* y;
+  uint16_t* residual;
+  const uint16_t* norm_w;
+  int64_t y_stride, res_stride;
+  int M, N, splits;
+  float eps;
+};
+
+__device__ __forceinline__ f32x4_t sum_splits(const float* p0, int64_t split_stride, int splits) {
+  f32x4_t s = *reinterpret_cast<const f32x4_t*>(p0);
+  for (int sp = 1; sp < splits; ++sp) s += *reinterpret_cast<const f32x4_t*>(p0 + sp * split_stride);
+  return s;
+}
+
+__global__ __launch_bounds__(256) void wstream_combine_kernel(CombineParams p) {
+  const int m = blockIdx.y;
+  const int n0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (n0 >= p.N) return;
+  const int64_t ss = static_cast<int64_t>(p.M) * p.N;
+  f32x4_t s = sum_splits(p.part + static_cast<int64_t>(m) * p.N + n0, ss, p.splits);
+  if (p.bias) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[r] += bf2f(p.bias[n0 + r]);
+  }
+  uint2 w2;
+  w2.x = pack_bf2(s[0], s[1]);
+  w2.y = pack_bf2(s[2], s[3]);
+  *reinterpret_cast<uint2*>(p.y + static_cast<int64_t>(m) * p.y_stride + n0) = w2;
+}
+
+__global__ __launch_bounds__(256) void wstream_combine_silu_kernel(CombineParams p) {
+  const int m = blockIdx.y;
+  const int half = p.N >> 1;
+  const int j0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (j0 >= half) return;
+  const int64_t ss = static_cast<int64_t>(p.M) * p.N;
+  const float* row = p.part + static_cast<int64_t>(m) * p.N;
+  const f32x4_t gt = sum_splits(row + j0, ss, p.splits);
+  const f32x4_t up = sum_splits(row + half + j0, ss, p.splits);
+  float o[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float gb = rbf(gt[r]);
+    const float sl = rbf(gb / (1.0f + expf(-gb)));
+    o[r] = sl * rbf(up[r]);
+  }
+  uint2 w2;
+  w2.x = pack_bf2(o[0], o[1]);
+  w2.y = pack_bf2(o[2], o[3]);
+  *reinterpret_cast<uint2*>(p.y + static_cast<int64_t>(m) * p.y_stride + j0) = w2;
+}
+
+constexpr int kNormThreads = 1024;
+constexpr int kNormMaxVec = 4;   // float4 per thread -> N <= 16384
+
+__global__ __launch_bounds__(kNormThreads) void wstream_combine_norm_kernel(CombineParams p) {
+  __shared__ float scratch[16];
+  const int m = blockIdx.x;
+  const int64_t ss = static_cast<int64_t>(p.M) * p.N;
+  const float* row = p.part + static_cast<int64_t>(m) * p.N;
+  uint16_t* res = p.residual + static_cast<int64_t>(m) * p.res_stride;
+  float t[kNormMaxVec][4];
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < kNormMaxVec; ++i) {
+    const int n0 = (i * kNormThreads + threadIdx.x) * 4;
+    if (n0 < p.N) {
+      f32x4_t s = sum_splits(row + n0, ss, p.splits);
+      const uint2 rv = *reinterpret_cast<const uint2*>(res + n0);
+      const float rr[4] = {bf_lo(rv.x), bf_hi(rv.x), bf_lo(rv.y), bf_hi(rv.y)};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float h = s[r];
+        if (p.bias) h += bf2f(p.bias[n0 + r]);
+        t[i][r] = rbf(h) + rr[r];
+        sq += t[i][r] * t[i][r];
+      }
+      uint2 w2;
+      w2.x = pack_bf2(t[i][0], t[i][1]);
+      w2.y = pack_bf2(t[i][2], t[i][3]);
+      *reinterpret_cast<uint2*>(res + n0) = w2;
+    }
+  }
+  sq = block_sum(sq, scratch);
+  const float rs = 1.0f / sqrtf(sq / static_cast<float>(p.N) + p.eps);
+#pragma unroll
+  for (int i = 0; i < kNormMaxVec; ++i) {
+    const int n0 = (i * kNormThreads + threadIdx.x) * 4;
+    if (n0 < p.N) {
+      const uint2 wv = *reinterpret_cast<const uint2*>(p.norm_w + n0);
+      const float ww[4] = {bf_lo(wv.x), bf_hi(wv.x), bf_lo(wv.y), bf_hi(wv.y)};
+      uint2 w2;
+      w2.x = pack_bf2((t[i][0] * rs) * ww[0], (t[i][1] * rs) * ww[1]);
+      w2.y = pack_bf2((t[i][2] * rs) * ww[2], (t[i][3] * rs) * ww[3]);
+      *reinterpret_cast<uint2*>(p.y + static_cast<int64_t>(m) * p.y_stride + n0) = w2;
+    }
+  }
+}
+
+template <int MT, int NW>
+void launch_main(const WsParams& p, hipStream_t st) {
+  dim3 grid((p.ntiles + NW - 1) / NW, p.splits);
+  hipLaunchKernelGGL((wstream_gemm_kernel<MT, NW>), grid, dim3(64 * NW), 0, st, p);
+}
+
+template <int MT>
+int launch_nw(const WsParams& p, int nw, hipStream_t st) {
+  switch (nw) {
+    case 4: launch_main<MT, 4>(p, st); return 0;
+    case 5: launch_main<MT, 5>(p, st); return 0;
+    case 6: launch_main<MT, 6>(p, st); return 0;
+    case 7: launch_main<MT, 7>(p, st); return 0;
+    case 8: launch_main<MT, 8>(p, st); return 0;
+    default: return -1;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int sgl_amd_wstream_gemm_max_rows(void) { return 64; }
+
+int64_t sgl_amd_wstream_gemm_workspace_floats(int64_t M, int64_t N, int num_k_splits) {
+  return static_cast<int64_t>(num_k_splits) * M * N;   /* needed when num_k_splits > 1 or epilogue != 0 */
+}
+
+int sgl_amd_wstream_gemm(const void* x, const void* w, const void* bias, void* y, int64_t M, int64_t N, int64_t K,
+                         int64_t x_row_stride, int64_t w_row_stride, int64_t y_row_stride, int epilogue,
+                         void* residual, int64_t residual_row_stride, const void* norm_weight, float eps,
+                         int waves_per_group, int num_k_splits, void* ws_partials, void* stream) {
+  SGL_CLEAR_STALE_ERROR();
+  SGL_CHECK_ARG(M >= 0 && M <= 64, "wstream_gemm: M=%lld rows (supported: <= 64)", (long long)M);
+  SGL_CHECK_ARG(N > 0 && N % 16 == 0 && K >= kKC && K % kKC == 0,
+                "wstream_gemm: need N %% 16 == 0 and K %% %d == 0 (got N=%lld K=%lld)", kKC, (long long)N, (long long)K);
+  SGL_CHECK_ARG(x_row_stride % 8 == 0 && w_row_stride % 8 == 0 && y_row_stride % 4 == 0,
+                "wstream_gemm: row strides must keep 16-byte (x, w) / 8-byte (y) alignment");
+  SGL_CHECK_ARG(waves_per_group >= 4 && waves_per_group <= 8,
+                "wstream_gemm: waves_per_group must be 4..8 (got %d)", waves_per_group);
+  SGL_CHECK_ARG(num_k_splits >= 1 && num_k_splits <= K / kKC, "wstream_gemm: bad split count %d", num_k_splits);
+  SGL_CHECK_ARG(epilogue >= 0 && epilogue <= 2, "wstream_gemm: epilogue must be 0 (bias), 1 (silu_and_mul) or 2 (add_rmsnorm)");
+  SGL_CHECK_ARG(epilogue == 0 || ws_partials,
+                "wstream_gemm: the fused epilogues run in the combine kernel (need the partials workspace, even with 1 split)");
+  SGL_CHECK_ARG(num_k_splits == 1 || ws_partials, "wstream_gemm: split-K needs the partials workspace");
+  SGL_CHECK_ARG(epilogue != 1 || N % 8 == 0, "wstream_gemm: silu_and_mul needs N %% 8 == 0");
+  SGL_CHECK_ARG(epilogue != 2 || (residual && norm_weight && N <= kNormThreads * kNormMaxVec * 4 && residual_row_stride % 4 == 0),
+                "wstream_gemm: add_rmsnorm needs residual, norm_weight and N <= %d", kNormThreads * kNormMaxVec * 4);
+  if (M == 0) return 0;
+  hipStream_t st = as_stream(stream);
+  WsParams p{};
+  p.x = static_cast<const uint16_t*>(x);
+  p.w = static_cast<const uint16_t*>(w);
+  const bool combine = num_k_splits > 1 || epilogue != 0;
+  p.bias = combine ? nullptr : static_cast<const uint16_t*>(bias);
+  p.y = static_cast<uint16_t*>(y);
+  p.part = combine ? static_cast<float*>(ws_partials) : nullptr;
+  p.x_stride = x_row_stride; p.w_stride = w_row_stride; p.y_stride = y_row_stride;
+  p.M = static_cast<int>(M); p.N = static_cast<int>(N); p.K = static_cast<int>(K);
+  p.splits = num_k_splits; p.ntiles = static_cast<int>(N / 16);
+  const int mt = static_cast<int>((M + 15) / 16);
+  int rc;
+  switch (mt) {
+    case 1: rc = launch_nw<1>(p, waves_per_group, st); break;
+    case 2: rc = launch_nw<2>(p, waves_per_group, st); break;
+    case 3: rc = launch_nw<3>(p, waves_per_group, st); break;
+    default: rc = launch_nw<4>(p, waves_per_group, st); break;
+  }
+  SGL_CHECK_ARG(rc == 0, "wstream_gemm: unsupported configuration");
+  if (combine) {
+    CombineParams c{};
+    c.part = p.part; c.bias = static_cast<const uint16_t*>(bias); c.y = p.y;
+    c.residual = static_cast<uint16_t*>(residual); c.norm_w = static_cast<const uint16_t*>(norm_weight);
+    c.y_stride = y_row_stride; c.res_stride = residual_row_stride;
+    c.M = p.M; c.N = p.N; c.splits = num_k_splits; c.eps = eps;
+    if (epilogue == 0) {
+      hipLaunchKernelGGL(wstream_combine_kernel, dim3((p.N / 4 + 255) / 256, p.M), dim3(256), 0, st, c);
+    } else if (epilogue == 1) {
+      hipLaunchKernelGGL(wstream_combine_silu_kernel, dim3((p.N / 8 + 255) / 256, p.M), dim3(256), 0, st, c);
+    } else {
+      hipLaunchKernelGGL(wstream_combine_norm_kernel, dim3(p.M), dim3(kNormThreads), 0, st, c);
+    }
+  }
+  SGL_CHECK_LAUNCH("wstream_gemm");
+  return 0;
+}
+
+}  // extern "C"

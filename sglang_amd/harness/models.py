@@ -4,8 +4,10 @@ the reference models: /root/reference/python/sglang/srt/models/llama.py:70-500
 LlamaForCausalLM :496), qwen2.py (qkv bias, tied embeddings), mixtral.py:60-118.
 
 Only the operator calls differ: every non-GEMM op goes to the gfx950 kernels
-through the layers in sglang_amd/layers, the GEMMs go to hipBLASLt through
-torch (library GEMMs are allowed for plain projections).  Weights are
+through the layers in sglang_amd/layers; the projections of decode batches
+(M <= 64) stream their weights through the gfx950 wstream GEMM (with the
+residual-add + RMSNorm fused into its combine kernel at TP=1), prefill-sized
+GEMMs go to hipBLASLt through torch (a plain library GEMM).  Weights are
 random-init (there are no checkpoints offline): N(0, 0.02^2) bf16, norm weights 1
 -- the `--load-format dummy` equivalent.
 """
@@ -19,6 +21,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from .. import kernels
 from ..distributed import parallel_state as ps
 from ..layers.activation import SiluAndMul
 from ..layers.layernorm import RMSNorm
@@ -83,15 +86,29 @@ def synth_weight(name: str, shape, init_device, std: float = 0.02) -> torch.Tens
 
 
 class Linear(nn.Module):
-    """y = x W^T (+ b), W [out, in] bf16 -- hipBLASLt via torch."""
+    """y = x W^T (+ b), W [out, in] bf16.  Decode batches (M <= 64) stream the weights through the
+    gfx950 wstream GEMM; prefill-sized M uses hipBLASLt via torch (a plain library GEMM)."""
 
     def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor] = None):
         super().__init__()
         self.weight = nn.Parameter(weight, requires_grad=False)
         self.bias = nn.Parameter(bias, requires_grad=False) if bias is not None else None
 
+    def streams(self, x: torch.Tensor) -> bool:
+        return (x.is_cuda and x.dim() == 2 and x.stride(1) == 1
+                and kernels.wstream_supported(x.shape[0], self.weight.shape[0], self.weight.shape[1]))
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.streams(x):
+            return kernels.wstream_gemm(x, self.weight.data, self.bias.data if self.bias is not None else None)
         return F.linear(x, self.weight, self.bias)
+
+    def forward_add_rmsnorm(self, x: torch.Tensor, residual: torch.Tensor, norm: RMSNorm) -> torch.Tensor:
+        """norm(self(x), residual) with the residual add + RMSNorm run by the GEMM's split-K combine
+        kernel: `residual` is updated in place, the normed activations are returned."""
+        return kernels.wstream_gemm(x, self.weight.data, self.bias.data if self.bias is not None else None,
+                                    epilogue="add_rmsnorm", residual=residual, norm_weight=norm.weight.data,
+                                    eps=norm.variance_epsilon)
 
 
 def _shard_rows(w: torch.Tensor, rank: int, world: int) -> torch.Tensor:
@@ -118,6 +135,10 @@ class LlamaMLP(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         x = self.down_proj(self.act_fn(self.gate_up_proj(x)))
         return ps.tensor_model_parallel_all_reduce(x)
+
+    def forward_fused_norm(self, x: torch.Tensor, residual: torch.Tensor, next_norm: RMSNorm) -> torch.Tensor:
+        """TP=1 decode: down_proj + residual add + the NEXT norm in one GEMM + combine pair."""
+        return self.down_proj.forward_add_rmsnorm(self.act_fn(self.gate_up_proj(x)), residual, next_norm)
 
 
 class LlamaAttention(nn.Module):
@@ -160,7 +181,10 @@ class LlamaAttention(nn.Module):
         self.attn = RadixAttention(self.num_heads, D, D ** -0.5, self.num_kv_heads, layer_id)
         self.layer_id = layer_id
 
-    def forward(self, positions: torch.Tensor, hidden_states: torch.Tensor, forward_batch) -> torch.Tensor:
+    def forward(self, positions: torch.Tensor, hidden_states: torch.Tensor, forward_batch,
+                fused_norm: Optional[Tuple[torch.Tensor, RMSNorm]] = None) -> torch.Tensor:
+        """fused_norm = (residual, norm): TP=1 decode form, o_proj + residual add + norm in one GEMM +
+        combine pair (returns the normed activations, residual updated in place)."""
         qkv = self.qkv_proj(hidden_states)
         q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
         pool = forward_batch.token_to_kv_pool
@@ -169,6 +193,8 @@ class LlamaAttention(nn.Module):
             value=v, k_buffer=pool.get_key_buffer(self.layer_id), v_buffer=pool.get_value_buffer(self.layer_id),
             cache_loc=forward_batch.out_cache_loc))
         attn_output = self.attn(q, k, v, forward_batch, save_kv_cache=False)
+        if fused_norm is not None:
+            return self.o_proj.forward_add_rmsnorm(attn_output, fused_norm[0], fused_norm[1])
         out = self.o_proj(attn_output)
         return ps.tensor_model_parallel_all_reduce(out)
 
@@ -198,6 +224,19 @@ class LlamaDecoderLayer(nn.Module):
         hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
         hidden_states = self.mlp(hidden_states)
         return hidden_states, residual
+
+    def fusable(self, x: torch.Tensor, tp_size: int) -> bool:
+        """The decode form below needs no collective between a projection and the norm behind it."""
+        return (tp_size == 1 and isinstance(self.mlp, LlamaMLP) and self.self_attn.o_proj.streams(x)
+                and kernels.wstream_supported(x.shape[0], *self.mlp.down_proj.weight.shape) and x.shape[1] <= 16384)
+
+    def forward_decode_fused(self, positions, normed: torch.Tensor, forward_batch, residual: torch.Tensor,
+                             next_norm: RMSNorm) -> torch.Tensor:
+        """Same arithmetic as forward() (llama.py:341-370) for a TP=1 decode batch, with every
+        residual-add + RMSNorm executed by the preceding projection's combine kernel.  `normed` is
+        this layer's input_layernorm output; returns next_norm's output, residual updated in place."""
+        x = self.self_attn(positions, normed, forward_batch, fused_norm=(residual, self.post_attention_layernorm))
+        return self.mlp.forward_fused_norm(x, residual, next_norm)
 
 
 class CausalLM(nn.Module):
@@ -236,6 +275,13 @@ class CausalLM(nn.Module):
 
     def forward_hidden(self, input_ids: torch.Tensor, positions: torch.Tensor, forward_batch) -> torch.Tensor:
         hidden_states = F.embedding(input_ids, self.embed_tokens)
+        if all(layer.fusable(hidden_states, self.tp_size) for layer in self.layers):
+            residual = hidden_states                     # the embedding output becomes the residual stream
+            x = self.layers[0].input_layernorm(hidden_states)
+            for i, layer in enumerate(self.layers):
+                nxt = self.layers[i + 1].input_layernorm if i + 1 < len(self.layers) else self.norm
+                x = layer.forward_decode_fused(positions, x, forward_batch, residual, nxt)
+            return x
         residual = None
         for layer in self.layers:
             hidden_states, residual = layer(positions, hidden_states, forward_batch, residual)
@@ -247,7 +293,10 @@ class CausalLM(nn.Module):
         if forward_batch.forward_mode.is_extend():
             last = torch.cumsum(forward_batch.extend_seq_lens, dim=0, dtype=torch.int64) - 1
             hidden_states = hidden_states[last]
-        logits = F.linear(hidden_states, self.lm_head)
+        if hidden_states.is_cuda and kernels.wstream_supported(hidden_states.shape[0], *self.lm_head.shape):
+            logits = kernels.wstream_gemm(hidden_states, self.lm_head.data)
+        else:
+            logits = F.linear(hidden_states, self.lm_head)
         logits = ps.tensor_model_parallel_all_gather(logits, dim=-1)
         return LogitsProcessorOutput(next_token_logits=logits.float())
 

@@ -6,6 +6,7 @@ launch.  No function here computes anything on the host or falls back to torch.
 """
 from __future__ import annotations
 
+import functools
 from typing import Optional, Tuple
 
 import torch
@@ -516,6 +517,72 @@ def skinny_gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
         slabs = _gemm_workspace(x.device, need)
     native.call("sgl_amd_skinny_gemm", x.data_ptr(), w.data_ptr(), _ptr(bias), out.data_ptr(), M, N, K, x.stride(0),
                 w.stride(0), out.stride(0), 1 if fuse_silu else 0, ntw, splits, _ptr(slabs), _stream())
+    return out
+
+
+# --------------------------------------------------------- weight-streaming decode GEMM
+_WS_EPILOGUES = {"none": 0, "silu_and_mul": 1, "add_rmsnorm": 2}
+
+
+def wstream_gemm_max_rows() -> int:
+    return native.lib().sgl_amd_wstream_gemm_max_rows()
+
+
+def wstream_supported(M: int, N: int, K: int) -> bool:
+    return 0 < M <= 64 and N % 16 == 0 and K % 128 == 0 and K >= 128
+
+
+@functools.lru_cache(maxsize=None)
+def choose_wstream_config(M: int, N: int, K: int, need_combine: bool = False) -> Tuple[int, int]:
+    """(waves_per_group, k_splits) for y[M,N] = x . w[N,K]^T.  One workgroup per CU is resident (its
+    LDS ring holds the in-flight chunks), so the best grids are whole 256-group rounds.  The cost model
+    is fitted to benchmarks/gemm_sweep.py on MI355X: a busy CU streams <= ~24 GB/s, the chip <= ~5.5 TB/s,
+    ~2 us of pipeline fill, and split-K pays the fp32 partial round trip plus the combine launch."""
+    tiles, nch = N // 16, K // 128
+    best = None
+    for nw in (8, 7, 6, 5, 4):
+        groups = (tiles + nw - 1) // nw
+        for s in range(1, max(1, min(nch // 2, 32)) + 1):
+            wgs = groups * s
+            wg_bytes = nw * ((nch + s - 1) // s) * 4096
+            full, rem = divmod(wgs, _NUM_CUS)
+            t = 2.0e-6 + full * _NUM_CUS * wg_bytes / 5.5e12
+            if rem:
+                t += rem * wg_bytes / min(5.5e12, rem * 24e9)
+            if s > 1 or need_combine:
+                t += 2 * s * M * N * 4 / 4e12 + 2.5e-6
+            if best is None or t < best[0]:
+                best = (t, nw, s)
+    return best[1], best[2]
+
+
+def wstream_gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: str = "none",
+                 residual: Optional[torch.Tensor] = None, norm_weight: Optional[torch.Tensor] = None, eps: float = 0.0,
+                 out: Optional[torch.Tensor] = None, waves_per_group: Optional[int] = None,
+                 splits: Optional[int] = None) -> torch.Tensor:
+    """Decode-batch F.linear(x, w, bias) on the weight-streaming kernel, optionally followed (in the
+    split-K combine kernel) by silu_and_mul or by fused_add_rmsnorm(out, residual, norm_weight, eps)."""
+    _dev(x, w)
+    _need(x.dtype == _BF16 and w.dtype == _BF16 and x.dim() == 2 and w.dim() == 2, "wstream_gemm: bf16 2-D x / w")
+    M, K = x.shape
+    N = w.shape[0]
+    _need(w.shape[1] == K and x.stride(1) == 1 and w.stride(1) == 1, "wstream_gemm: shapes / contiguity")
+    ep = _WS_EPILOGUES[epilogue]
+    n_out = N // 2 if ep == 1 else N
+    if out is None:
+        out = torch.empty((M, n_out), dtype=_BF16, device=x.device)
+    _need(out.shape == (M, n_out) and out.stride(1) == 1 and out.dtype == _BF16, "wstream_gemm: out shape")
+    if ep == 2:
+        _need(residual is not None and norm_weight is not None and residual.shape == (M, N) and residual.stride(1) == 1
+              and residual.dtype == _BF16 and norm_weight.dtype == _BF16, "wstream_gemm: add_rmsnorm needs residual [M,N] and norm_weight")
+    if waves_per_group is None or splits is None:
+        nw_auto, s_auto = choose_wstream_config(M, N, K, ep != 0)
+    nw = waves_per_group or nw_auto
+    s = splits or s_auto
+    ws = _gemm_workspace(x.device, native.lib().sgl_amd_wstream_gemm_workspace_floats(M, N, s)) if (s > 1 or ep) else None
+    native.call("sgl_amd_wstream_gemm", x.data_ptr(), w.data_ptr(), _ptr(bias), out.data_ptr(), M, N, K, x.stride(0),
+                w.stride(0), out.stride(0), ep, _ptr(residual), residual.stride(0) if residual is not None else 0,
+                _ptr(norm_weight), float(eps), nw, s, _ptr(ws), _stream())
     return out
 
 

@@ -1,0 +1,120 @@
+"""GPU parity tests of the weight-streaming decode GEMM (wstream_gemm.hip) and its fused combine
+epilogues against an fp64 reference on the same bf16 inputs (F.linear, srt/layers/linear.py:1596-1660)
+and the oracle's silu_and_mul / fused_add_rmsnorm (activation.py:141-143, layernorm.py:786-820)."""
+import pytest
+import torch
+
+from oracle import ops as oo
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def _k():
+    from sglang_amd import kernels
+
+    return kernels
+
+
+def _ref_linear(x, w, bias=None):
+    y = x.double() @ w.double().t()
+    if bias is not None:
+        y = y + bias.double()
+    return y
+
+
+def _check(got, ref64, ulps=1.0):
+    ref = ref64.float()
+    err = (got.float() - ref).abs()
+    tol = ref.abs() * 2.0 ** -8 * ulps + 1e-3
+    assert bool((err <= tol).all()), f"max err {float(err.max())} (ref max {float(ref.abs().max())})"
+
+
+@pytest.mark.parametrize("M", [1, 7, 16, 33, 48, 64])
+@pytest.mark.parametrize("N,K", [(4096, 4096), (6144, 4096), (1024, 14336), (4864, 896), (112, 256), (16, 128)])
+@pytest.mark.parametrize("nw,splits", [(None, None), (4, 1), (5, 2), (6, 1), (7, 2), (8, 3)])
+def test_wstream_gemm_matches_fp64_reference(device, M, N, K, nw, splits):
+    K_ = _k()
+    if splits is not None and splits > K // 128:
+        pytest.skip("more splits than K chunks")
+    g = torch.Generator().manual_seed(M * 131 + N + K)
+    x = (torch.randn((M, K), generator=g) * 0.5).to(BF)
+    w = (torch.randn((N, K), generator=g) * 0.05).to(BF)
+    got = K_.wstream_gemm(x.to(device), w.to(device), waves_per_group=nw, splits=splits).cpu()
+    _check(got, _ref_linear(x, w))
+
+
+def test_wstream_gemm_bias_strides_and_untouched_padding(device):
+    K_ = _k()
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 19, 1152, 896
+    xfull = torch.randn((M, K + 64), generator=g).to(BF).to(device)
+    x = xfull[:, :K]
+    w = (torch.randn((N, K), generator=g) * 0.05).to(BF).to(device)
+    b = torch.randn(N, generator=g).to(BF).to(device)
+    for splits in (1, 3):
+        out_full = torch.zeros((M, N + 8), dtype=BF, device=device)
+        K_.wstream_gemm(x, w, bias=b, out=out_full[:, :N], splits=splits)
+        _check(out_full[:, :N].cpu(), _ref_linear(x.cpu(), w.cpu(), b.cpu()))
+        assert float(out_full[:, N:].abs().max()) == 0.0
+
+
+def test_wstream_gemm_split_k_is_deterministic_and_equals_one_split_order(device):
+    K_ = _k()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn((64, 4096), generator=g).to(BF).to(device)
+    w = (torch.randn((4096, 4096), generator=g) * 0.05).to(BF).to(device)
+    outs = [K_.wstream_gemm(x, w, splits=8, waves_per_group=8).clone() for _ in range(5)]
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    # the decomposition over workgroups must not change the arithmetic: same splits, other group size
+    assert torch.equal(K_.wstream_gemm(x, w, splits=8, waves_per_group=4), outs[0])
+    _check(outs[0].cpu(), _ref_linear(x.cpu(), w.cpu()))
+
+
+@pytest.mark.parametrize("M", [3, 64])
+@pytest.mark.parametrize("splits", [1, 2, 4])
+def test_wstream_silu_epilogue_equals_unfused_ops(device, M, splits):
+    K_ = _k()
+    g = torch.Generator().manual_seed(M)
+    I, K = 1792, 1024
+    x = torch.randn((M, K), generator=g).to(BF).to(device)
+    w = (torch.randn((2 * I, K), generator=g) * 0.05).to(BF).to(device)
+    gate_up = K_.wstream_gemm(x, w, splits=splits)                       # same accumulation order
+    want = oo.silu_and_mul(gate_up.cpu())
+    got = K_.wstream_gemm(x, w, epilogue="silu_and_mul", splits=splits).cpu()
+    d = (got.float() - want.float()).abs()
+    # identical accumulators and rounding points: only expf may differ in the last bf16 ulp
+    assert float((d > 0).float().mean()) < 0.005
+    assert bool((d <= want.float().abs() * 2.0 ** -7 + 1e-6).all())
+
+
+@pytest.mark.parametrize("M", [1, 20, 64])
+@pytest.mark.parametrize("N,K,splits", [(4096, 4096, 8), (4096, 14336, 14), (896, 4864 - 4864 % 128, 1), (256, 512, 2)])
+def test_wstream_add_rmsnorm_epilogue_equals_unfused_ops(device, M, N, K, splits):
+    K_ = _k()
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn((M, K), generator=g).to(BF).to(device)
+    w = (torch.randn((N, K), generator=g) * 0.03).to(BF).to(device)
+    res = torch.randn((M, N), generator=g).to(BF).to(device)
+    nw_ = (torch.rand(N, generator=g) + 0.5).to(BF).to(device)
+    eps = 1e-5
+    h = K_.wstream_gemm(x, w, splits=splits)
+    want_y, want_res = oo.fused_add_rmsnorm(h.cpu(), res.cpu(), nw_.cpu(), eps)
+    res2 = res.clone()
+    got = K_.wstream_gemm(x, w, epilogue="add_rmsnorm", residual=res2, norm_weight=nw_, eps=eps, splits=splits)
+    assert torch.equal(res2.cpu(), want_res), "residual stream must be bit-exact (same bf16 sum)"
+    d = (got.cpu().float() - want_y.float()).abs()
+    # same fp32 inputs; the row reduction order differs from torch's -> at most 1 bf16 ulp
+    assert bool((d <= want_y.float().abs() * 2.0 ** -7 + 1e-6).all())
+    assert float((d > 0).float().mean()) < 0.02
+
+
+def test_wstream_rejects_unsupported_shapes(device):
+    K_ = _k()
+    x = torch.zeros((65, 256), dtype=BF, device=device)
+    w = torch.zeros((64, 256), dtype=BF, device=device)
+    with pytest.raises(RuntimeError):
+        K_.wstream_gemm(x, w)
+    with pytest.raises(RuntimeError):
+        K_.wstream_gemm(x[:4, :200], w[:, :200])
