@@ -146,38 +146,22 @@ int sgl_amd_extend_attention(const void* q, void* out, const void* k_cache, cons
                              int causal, void* stream);
 
 /* ---- Shared-prefix (cascade) decode attention ---------------------------------------------------
- * RadixAttention batches share KV prefixes: requests whose req_to_token rows start with the same slots
- * read the same pool rows.  sgl_amd_cascade_plan (one launch per decode STEP, device-only, graph-safe)
- * groups such requests; sgl_amd_cascade_decode_attention (per layer) then reads every group's shared
- * part ONCE for all members (MFMA, all members' query heads as rows), each request's private suffix
- * with the paged decode kernel, and LSE-merges the split slots.  Same result as
- * sgl_amd_decode_attention (reference semantics torch_native_backend.py:176-277) up to fp32 rounding.
- * plan: int32[sgl_amd_cascade_plan_ints(batch, max_items)]; ws_acc fp32 [B,Hq,slots,D], ws_ml fp32
- * [B,Hq,slots,2] with slots = shared_slots + suffix_splits, shared_slots >= ceil(max shared len / chunk_tokens). */
+ * RadixAttention batches share KV rows: requests whose req_to_token rows start with the same slots
+ * read the same pool rows (reference: the Triton decode path of triton_backend.py:136-1012 re-reads
+ * them once per request).  sgl_amd_cascade_plan (one launch per decode STEP, device-only, graph-safe)
+ * groups such requests; sgl_amd_cascade_decode_attention (per layer, two launches) cuts every group's
+ * shared prefix and every request's private suffix into sgl_amd_cascade_chunk_tokens()-token items,
+ * reads each item's K/V rows once for all its member requests (MFMA), and merges the per-item
+ * partials of a (request, head) in slot order (deterministic).
+ * plan: int32[sgl_amd_cascade_plan_ints(batch, max_items)]; ws_acc fp32 [B,Hq,slots_total,D], ws_ml fp32
+ * [B,Hq,slots_total,2] with slots_total >= ceil(max_context_len / chunk) + 1; head_dim 64 or 128. */
+int sgl_amd_cascade_chunk_tokens(void);
+int sgl_amd_cascade_members_per_item(int num_q_heads, int num_kv_heads);
 int64_t sgl_amd_cascade_plan_ints(int64_t batch, int64_t max_items);
 int sgl_amd_cascade_plan(const int32_t* req_to_token, int64_t req_to_token_stride,
                          const int64_t* req_pool_indices, const int32_t* seq_lens, int64_t batch,
-                         int num_q_heads, int num_kv_heads, int min_shared_len, int chunk_tokens,
-                         int32_t* plan, int64_t max_items, void* ws_ml, int shared_slots,
-                         int slots_total, void* stream);
-int sgl_amd_cascade_shared_part(const void* q, const void* k_cache, const void* v_cache,
-                                const int32_t* req_to_token, int64_t req_to_token_stride,
-                                const int32_t* plan, int64_t batch, int64_t max_items, int num_q_heads,
-                                int num_kv_heads, int head_dim, int64_t q_token_stride,
-                                int64_t k_cache_row_stride, int64_t v_cache_row_stride, float sm_scale,
-                                int chunk_tokens, int slots_total, void* ws_acc, void* ws_ml, void* stream);
-int sgl_amd_cascade_suffix_part(const void* q, const void* k_cache, const void* v_cache,
-                                const int32_t* req_to_token, int64_t req_to_token_stride,
-                                const int64_t* req_pool_indices, const int32_t* seq_lens,
-                                const int32_t* plan, int64_t batch, int64_t max_items, int num_q_heads,
-                                int num_kv_heads, int head_dim, int64_t q_token_stride,
-                                int64_t k_cache_row_stride, int64_t v_cache_row_stride, float sm_scale,
-                                int shared_slots, int suffix_splits, void* ws_acc, void* ws_ml, int flags,
-                                void* stream);
-int sgl_amd_cascade_merge(const void* ws_acc, const void* ws_ml, void* out, int64_t batch, int num_q_heads,
-                          int head_dim, int64_t out_token_stride, int slots_total, void* stream);
-/* shared part + suffix part + merge on one stream (the three parts above can also be called
- * separately, e.g. parts 1 and 2 on two streams). */
+                         int num_q_heads, int num_kv_heads, int min_shared_len, int64_t max_context_len,
+                         int32_t* plan, int64_t max_items, void* stream);
 int sgl_amd_cascade_decode_attention(const void* q, const void* k_cache, const void* v_cache, void* out,
                                      const int32_t* req_to_token, int64_t req_to_token_stride,
                                      const int64_t* req_pool_indices, const int32_t* seq_lens,
@@ -185,8 +169,8 @@ int sgl_amd_cascade_decode_attention(const void* q, const void* k_cache, const v
                                      int num_q_heads, int num_kv_heads, int head_dim,
                                      int64_t q_token_stride, int64_t out_token_stride,
                                      int64_t k_cache_row_stride, int64_t v_cache_row_stride,
-                                     float sm_scale, int chunk_tokens, int shared_slots,
-                                     int suffix_splits, void* ws_acc, void* ws_ml, int flags, void* stream);
+                                     float sm_scale, int64_t max_context_len, int slots_total,
+                                     void* ws_acc, void* ws_ml, void* stream);
 
 /* ---- Sampling (reference: srt/layers/sampler.py:98-260,567-750;
  *      kernels/ops/sampling/murmur_hash.py:51-121) ------------------------------- */

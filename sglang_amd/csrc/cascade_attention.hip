@@ -1,0 +1,536 @@
+// Shared-prefix (cascade) decode attention for gfx950, one launch for the whole step + an LSE merge.
+//
+// Replaces (reference, /root/reference/python/sglang):
+//   srt/layers/attention/triton_backend.py:136-1012 forward_decode -> kernels/ops/attention/
+//   decode_attention.py:1163 decode_attention_fwd, which re-reads a radix-shared prefix once per
+//   request.  Oracle: srt/layers/attention/torch_native_backend.py:176-277 (oracle/ops.py).
+//
+// RadixAttention batches share KV rows: requests whose req_to_token rows start with the same slots
+// attend to the SAME rows of the pool.  The device plan (sgl_amd_cascade_plan) groups them; this
+// kernel then works on "chunk items", each one workgroup:
+//   shared item  = (group, 128-token chunk of the shared prefix, <= 64/G members): the chunk's K/V
+//                  rows are read ONCE and multiplied with the decode queries of all members
+//                  (members x G query heads = up to 64 rows) on the matrix cores;
+//   private item = (request, 128-token chunk of its unshared suffix): the same code with one member.
+// Every item is a single shot -- no KV loop: 128 slot ids -> 128 K rows + 128 V rows gathered in one
+// burst (16 x 16 B loads in flight per lane), S^T = K Q^T and O^T = V^T P^T with MFMA 16x16x32 bf16,
+// softmax state lane-local (transposed products).  That keeps the dependent-load chain at three
+// hops (plan -> slot ids -> rows) whatever the context length; parallelism comes from the number of
+// items.  Each item writes an unnormalised (acc, max, sum) partial into its slot of every member;
+// the merge kernel combines the slots of a (request, head) in slot order.
+#include "common.hpp"
+#include "cascade_plan.hpp"
+#include "../../include/sglang_amd.h"
+
+using namespace sgl_amd;
+
+namespace {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int kThreads = 256;
+constexpr int kChunk = 128;       // kv tokens per item
+constexpr int kRowsPerItem = 64;  // (member, q head) rows per item: 4 waves x one 16-row tile
+constexpr float kNegBig = -1.0e30f;
+
+__device__ __forceinline__ bf16x8_t as_frag(const U4& v) { return __builtin_bit_cast(bf16x8_t, v); }
+
+struct ChunkParams {
+  const uint16_t* q;            // [B, Hq, D]
+  const uint16_t* k_cache;      // [slots, Hkv, D]
+  const uint16_t* v_cache;
+  const int32_t* req_to_token;
+  const int64_t* req_pool_indices;
+  const int32_t* seq_lens;
+  const int32_t* plan;
+  float* ws_acc;                // [B, Hq, slots_total, D]
+  float* ws_ml;                 // [B, Hq, slots_total, 2]
+  int64_t q_stride, kc_stride, vc_stride, r2t_stride;
+  int batch, max_items, num_q_heads, group, members_per_item;
+  int num_kv_heads;
+  int slots_total;
+  float scale_log2;
+};
+
+// One 128-token K image, then (after S^T) the transposed V image, in the SAME 32 KiB (D = 128) buffer:
+// four workgroups fit a CU, so a whole decode step's items are resident at once.
+// One workgroup per (item, kv head) unit; the grid covers the worst-case item count of the batch and the
+// workgroups behind the end of the device-built list leave after one load.  (A persistent loop over the
+// units was measured slower: hipcc hoists the lane-derived LDS addresses out of the loop and spills.)
+template <int D>
+__global__ __launch_bounds__(kThreads, 4) void cascade_chunk_kernel(ChunkParams p) {
+  __shared__ U4 sm[kChunk * D / 8];     // K: [token][16-byte piece ^ swz];  V^T: [d][8-token chunk ^ swz]
+  const int unit = blockIdx.x;
+  constexpr int CPR = D / 8;            // 16-byte pieces per KV row
+  constexpr int KC = D / 32;            // MFMA k-steps over the head dim
+  constexpr int ND = D / 16;            // 16-wide output tiles over the head dim
+  constexpr int NT = kChunk / 16;       // 16-token tiles of the chunk
+  constexpr int NKK = kChunk / 32;      // MFMA k-steps over the tokens
+  constexpr int ROWS_PER_PASS = kThreads / CPR;
+  constexpr int NK_LOADS = kChunk / ROWS_PER_PASS;   // K 16-byte loads per thread (8 at D=128)
+  constexpr int V_THREADS = (kChunk / 8) * CPR;      // one 8x8 transposing block each
+
+  const CascadePlanView pv = cascade_plan_view(p.plan, p.batch, p.max_items);
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int item = unit / p.num_kv_heads;
+  const int kvh = unit - item * p.num_kv_heads;
+  if (item >= p.max_items) return;
+  // ---- one hop to a self-contained record ---------------------------------------------------
+  const int4 ra = *reinterpret_cast<const int4*>(pv.items + 8 * item);       // slot, kv_begin, kv_n, members
+  const int4 rb = *reinterpret_cast<const int4*>(pv.items + 8 * item + 4);   // member_begin | request, private, pool row, group
+  const int n_mem = ra.w;
+  if (n_mem == 0) return;                                                     // end of the list
+  const int slot = ra.x, kv_begin = ra.y, kv_n = ra.z;
+  const int32_t* idx_base = p.req_to_token + static_cast<int64_t>(rb.z) * p.r2t_stride;
+  const int32_t* members = rb.y ? nullptr : pv.member_rows + rb.x;
+  const int single = rb.x;
+  const int last = kv_begin + kv_n - 1;
+  const int n_rows = n_mem * p.group;
+
+  // ---- gather burst: all K / V rows of the chunk --------------------------------------------
+  const int st_c = tid % CPR, st_r = tid / CPR;
+  const int64_t head_off = static_cast<int64_t>(kvh) * D + st_c * 8;
+  const bool v_active = tid < V_THREADS;
+  U4 kst[NK_LOADS], vst[8];
+  {
+    int32_t ks[NK_LOADS];
+#pragma unroll
+    for (int i = 0; i < NK_LOADS; ++i) {
+      int tok = kv_begin + st_r + ROWS_PER_PASS * i;
+      if (tok > last) tok = last;
+      ks[i] = idx_base[tok];
+    }
+    // V block of this thread: k-step kk = st_r >> 2, lane group vg = st_r & 3; token order inside the
+    // block matches the P^T operand built from the S^T accumulators: i = 4a + r <-> 32 kk + 16 a + 4 vg + r
+    int32_t vs[8];
+    const int v_kk = st_r >> 2, v_g = st_r & 3;
+    if (v_active) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        int tok = kv_begin + 32 * v_kk + 16 * (i >> 2) + 4 * v_g + (i & 3);
+        if (tok > last) tok = last;
+        vs[i] = idx_base[tok];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NK_LOADS; ++i) kst[i] = ld16(p.k_cache + static_cast<int64_t>(ks[i]) * p.kc_stride + head_off);
+    if (v_active) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) vst[i] = ld16(p.v_cache + static_cast<int64_t>(vs[i]) * p.vc_stride + head_off);
+    }
+  }
+
+  // ---- this wave's 16 query rows: row = (member, q head of the kv head's group) -----------------
+  const int r = wid * 16 + l15;
+  const bool wave_on = wid * 16 < n_rows;           // wave-uniform
+  const bool row_ok = r < n_rows;
+  const int mem_i = r / p.group, hg = r - mem_i * p.group;
+  int64_t req = 0;
+  U4 qfrag[KC];
+  if (row_ok) {
+    req = members ? members[mem_i] : single;
+    const uint16_t* qp = p.q + req * p.q_stride + static_cast<int64_t>(kvh * p.group + hg) * D + g * 8;
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) qfrag[kc] = ld16(qp + kc * 32);
+  } else {
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) qfrag[kc] = U4{0u, 0u, 0u, 0u};
+  }
+
+  // ---- K image (row-major, XOR-swizzled pieces) ----------------------------------------------
+#pragma unroll
+  for (int i = 0; i < NK_LOADS; ++i) {
+    const int row = st_r + ROWS_PER_PASS * i;
+    sm[row * CPR + (st_c ^ (row & (CPR - 1)))] = kst[i];
+  }
+  __syncthreads();
+
+  // ---- S^T = K . Q^T : lane owns query row l15 of the wave, tokens 16 nt + 4 g + r --------------
+  float mx = kNegBig, psum = 0.f;
+  U4 pfrag[NKK];
+  if (wave_on) {
+    f32x4_t st_acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      st_acc[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      const int row = nt * 16 + l15;
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) {
+        const U4 kf = sm[row * CPR + ((kc * 4 + g) ^ (row & (CPR - 1)))];
+        st_acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(kf), as_frag(qfrag[kc]), st_acc[nt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const float s = (nt * 16 + g * 4 + rr < kv_n) ? st_acc[nt][rr] * p.scale_log2 : kNegBig;
+        st_acc[nt][rr] = s;
+        mx = fmaxf(mx, s);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+      float e[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float s = st_acc[2 * kk + (i >> 2)][i & 3];
+        e[i] = (s > 0.5f * kNegBig) ? exp2f(s - mx) : 0.f;
+        psum += e[i];
+      }
+      pfrag[kk].x = pack_bf2(e[0], e[1]);
+      pfrag[kk].y = pack_bf2(e[2], e[3]);
+      pfrag[kk].z = pack_bf2(e[4], e[5]);
+      pfrag[kk].w = pack_bf2(e[6], e[7]);
+    }
+    psum += __shfl_xor(psum, 16, 64);
+    psum += __shfl_xor(psum, 32, 64);
+  }
+  __syncthreads();        // every wave is done with the K image
+
+  // ---- V^T image: 8x8 blocks transposed through registers -------------------------------------
+  if (v_active) {
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(vst);   // vst[i] dword q -> w[4 i + q]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int d = st_c * 8 + j;
+      U4 o;
+      uint32_t* ow = reinterpret_cast<uint32_t*>(&o);
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const uint32_t a = w[4 * (2 * qd) + (j >> 1)];
+        const uint32_t c = w[4 * (2 * qd + 1) + (j >> 1)];
+        ow[qd] = (j & 1) ? ((a >> 16) | (c & 0xffff0000u)) : ((a & 0xffffu) | (c << 16));
+      }
+      sm[d * 16 + (st_r ^ ((d ^ (d >> 3)) & 15))] = o;
+    }
+  }
+  __syncthreads();
+
+  // ---- O^T = V^T . P^T : lane holds O^T[d = 16 n + 4 g + r][row l15] ----------------------------
+  if (wave_on) {
+  float* ap = nullptr;
+  if (row_ok) {
+    const int64_t sl = (req * p.num_q_heads + kvh * p.group + hg) * p.slots_total + slot;
+    ap = p.ws_acc + sl * D + g * 4;
+    if (g == 0) {
+      p.ws_ml[sl * 2 + 0] = mx;
+      p.ws_ml[sl * 2 + 1] = psum;
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < ND; ++n) {
+    f32x4_t ot = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int d = n * 16 + l15;
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+      const U4 vf = sm[d * 16 + ((kk * 4 + g) ^ ((d ^ (d >> 3)) & 15))];
+      ot = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(vf), as_frag(pfrag[kk]), ot, 0, 0, 0);
+    }
+    if (row_ok) *reinterpret_cast<f32x4_t*>(ap + n * 16) = ot;
+  }
+  }
+}
+
+// ---- cascade plan: group the requests of a decode batch that share a KV prefix ----------------
+// One workgroup, once per decode step.  Requests that share ANY cached prefix share their first slot
+// (page_size-agnostic: identical slot ids <=> the same cached tokens), so the leader of request b is the
+// lowest batch index with the same first slot; the shared length with the leader is the first mismatch
+// of the two req_to_token rows.  A group's shared part is the minimum over its members, rounded down
+// to kv_tile; groups with < 2 members or a short shared part are dropped.  The output is ONE compact
+// list of self-contained chunk items: the shared chunks of every group (x member tiles), then the
+// private chunks of every request.
+constexpr int kPlanThreads = 1024;
+constexpr int kPlanMaxBatch = 1024;
+
+__global__ __launch_bounds__(kPlanThreads) void cascade_plan_kernel(
+    const int32_t* __restrict__ req_to_token, int64_t r2t_stride, const int64_t* __restrict__ req_pool_indices,
+    const int32_t* __restrict__ seq_lens, int batch, int min_shared, int chunk_tokens, int tokens_per_tile,
+    int kv_tile, int max_shared, int32_t* __restrict__ plan, int max_items) {
+  __shared__ int first_slot[kPlanMaxBatch];
+  __shared__ int leader[kPlanMaxBatch];
+  __shared__ int grp_min[kPlanMaxBatch];
+  __shared__ int grp_cnt[kPlanMaxBatch];
+  __shared__ int grp_id[kPlanMaxBatch];
+  __shared__ int scan[kPlanMaxBatch];
+  __shared__ int n_shared_items;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const CascadePlanView pv = cascade_plan_view(plan, batch, max_items);
+  for (int i = tid; i < max_items; i += kPlanThreads) pv.items[8 * i + 3] = 0;   // members == 0: end of list
+  for (int b = tid; b < batch; b += kPlanThreads) {
+    const int len = seq_lens[b];
+    first_slot[b] = len > 1 ? req_to_token[req_pool_indices[b] * r2t_stride] : -1 - b;   // unique when too short
+    grp_min[b] = 0x7fffffff;
+    grp_cnt[b] = 0;
+  }
+  __syncthreads();
+  for (int b = tid; b < batch; b += kPlanThreads) {
+    int l = b;
+    const int fs = first_slot[b];
+    for (int c = 0; c < b; ++c)
+      if (first_slot[c] == fs) { l = c; break; }
+    leader[b] = l;
+  }
+  __syncthreads();
+  // common prefix with the leader: one wave per request, 256 positions per step (4 loads in flight per row)
+  for (int b = wid; b < batch; b += kPlanThreads / 64) {
+    const int l = leader[b];
+    int common = 0;
+    if (l != b) {
+      const int32_t* ra = req_to_token + req_pool_indices[b] * r2t_stride;
+      const int32_t* rb = req_to_token + req_pool_indices[l] * r2t_stride;
+      int lim = seq_lens[b] - 1;                 // the newest token's slot is never shared
+      const int ll = seq_lens[l] - 1;
+      if (ll < lim) lim = ll;
+      common = lim;
+      for (int t0 = 0; t0 < lim; t0 += 256) {
+        int va[4], vb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int t = t0 + 64 * u + lane;
+          const int tc = t < lim ? t : lim - 1;
+          va[u] = ra[tc];
+          vb[u] = rb[tc];
+        }
+        int first = 0x7fffffff;
+#pragma unroll
+        for (int u = 3; u >= 0; --u) {
+          const int t = t0 + 64 * u + lane;
+          const unsigned long long mm = __ballot(t < lim && va[u] != vb[u]);
+          if (mm != 0ull) first = t0 + 64 * u + __ffsll(static_cast<long long>(mm)) - 1;
+        }
+        if (first != 0x7fffffff) { common = first; break; }
+      }
+    }
+    if (lane == 0 && l != b) {
+      atomicMin(&grp_min[l], common);
+      atomicAdd(&grp_cnt[l], 1);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int ng = 0, rows = 0, n_items = 0;
+    pv.group_qo[0] = 0;
+    for (int b = 0; b < batch; ++b) {
+      grp_id[b] = -1;
+      pv.req_shared[b] = 0;
+    }
+    for (int b = 0; b < batch; ++b) {
+      if (leader[b] != b || grp_cnt[b] < 1) continue;
+      int kv = grp_min[b] / kv_tile * kv_tile;
+      if (kv > max_shared) kv = max_shared;
+      if (kv < min_shared) continue;
+      const int members = grp_cnt[b] + 1;
+      const int tiles = (members + tokens_per_tile - 1) / tokens_per_tile;
+      const int chunks = (kv + chunk_tokens - 1) / chunk_tokens;
+      // plan full (leave room for the private chunks of every request): the rest stay ungrouped
+      if (n_items + tiles * chunks > max_items / 2) continue;
+      grp_id[b] = ng;
+      pv.group_pool_row[ng] = static_cast<int32_t>(req_pool_indices[b]);
+      pv.group_kvlen[ng] = kv;
+      for (int c = 0; c < chunks; ++c)
+        for (int t = 0; t < tiles; ++t) {
+          int32_t* it = pv.items + 8 * n_items;
+          const int left = members - t * tokens_per_tile;
+          const int kvn = kv - c * chunk_tokens;
+          it[0] = c;                                         // partial slot
+          it[1] = c * chunk_tokens;                          // first kv token
+          it[2] = kvn < chunk_tokens ? kvn : chunk_tokens;   // kv tokens
+          it[4] = rows + t * tokens_per_tile;                // first entry of member_rows
+          it[5] = 0;                                         // shared item
+          it[6] = static_cast<int32_t>(req_pool_indices[b]);
+          it[7] = ng;
+          it[3] = left < tokens_per_tile ? left : tokens_per_tile;   // members
+          ++n_items;
+        }
+      rows += members;
+      pv.group_qo[ng + 1] = rows;
+      ++ng;
+    }
+    // members in batch order inside each group
+    for (int gi = 0; gi < ng; ++gi) grp_cnt[gi] = pv.group_qo[gi];    // reuse as cursors (indexed by group id)
+    for (int b = 0; b < batch; ++b) {
+      const int gi = grp_id[leader[b]];
+      if (gi < 0) continue;
+      pv.member_rows[grp_cnt[gi]++] = b;
+      pv.req_shared[b] = pv.group_kvlen[gi];
+    }
+    int cur = 0;
+    for (int i = 0; i < rows; ++i) pv.batch_order[cur++] = pv.member_rows[i];
+    for (int b = 0; b < batch; ++b)
+      if (grp_id[leader[b]] < 0) pv.batch_order[cur++] = b;
+    pv.header[1] = ng;
+    pv.header[2] = rows;
+    pv.header[3] = n_items;
+    n_shared_items = n_items;
+  }
+  __syncthreads();
+  // ---- private chunks of every request, appended behind the shared items (block-wide exclusive scan) ----
+  int mine = 0, sh = 0, len = 0;
+  if (tid < batch) {
+    sh = pv.req_shared[tid];
+    len = seq_lens[tid];
+    mine = len > sh ? (len - sh + chunk_tokens - 1) / chunk_tokens : 0;
+  }
+  scan[tid] = mine;
+  __syncthreads();
+  for (int off = 1; off < kPlanThreads; off <<= 1) {
+    const int v = tid >= off ? scan[tid - off] : 0;
+    __syncthreads();
+    scan[tid] += v;
+    __syncthreads();
+  }
+  const int base = n_shared_items + scan[tid] - mine;
+  const int first_slot_p = (sh + chunk_tokens - 1) / chunk_tokens;
+  for (int j = 0; j < mine; ++j) {
+    if (base + j >= max_items) break;                // cannot happen when max_items is sized by the caller
+    int32_t* it = pv.items + 8 * (base + j);
+    const int kvb = sh + j * chunk_tokens;
+    it[0] = first_slot_p + j;
+    it[1] = kvb;
+    it[2] = len - kvb < chunk_tokens ? len - kvb : chunk_tokens;
+    it[4] = tid;                                     // the request itself
+    it[5] = 1;                                       // private item
+    it[6] = static_cast<int32_t>(req_pool_indices[tid]);
+    it[7] = -1;
+    it[3] = 1;
+  }
+  if (tid == kPlanThreads - 1) {
+    const int total = n_shared_items + scan[tid];
+    pv.header[0] = total < max_items ? total : max_items;
+  }
+}
+
+// ---- merge: slots [0, n_slots(b)) of every (request, head), in slot order ----------------------
+// n_slots = shared chunks + private chunks of the request; every one of them was written this step.
+// Block = 256 / (D/4) heads x (D/4) lanes; a thread owns 4 consecutive output elements of one head.
+constexpr int kMergeBlock = 8;   // slots loaded per round (all loads of a round are in flight together)
+
+__global__ __launch_bounds__(256) void cascade_merge2_kernel(const float* __restrict__ ws_acc, const float* __restrict__ ws_ml,
+                                                             const int32_t* __restrict__ plan, const int32_t* __restrict__ seq_lens,
+                                                             uint16_t* __restrict__ out, int64_t out_stride, int batch,
+                                                             int max_items, int num_q_heads, int head_dim, int slots_total) {
+  const int tpd = head_dim >> 2;
+  const int b = blockIdx.x;
+  const int hq = blockIdx.y * (256 / tpd) + threadIdx.x / tpd;
+  const int d = (threadIdx.x % tpd) * 4;
+  if (hq >= num_q_heads) return;
+  const CascadePlanView pv = cascade_plan_view(plan, batch, max_items);
+  const int sh = pv.req_shared[b];
+  const int len = seq_lens[b];
+  int n = (sh + kChunk - 1) / kChunk + (len > sh ? (len - sh + kChunk - 1) / kChunk : 0);
+  if (n > slots_total) n = slots_total;
+  const int64_t base = (static_cast<int64_t>(b) * num_q_heads + hq) * slots_total;
+  const float2* ml = reinterpret_cast<const float2*>(ws_ml) + base;
+  const float* accp = ws_acc + base * head_dim + d;
+  float m_run = kNegBig, l = 0.f;
+  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s0 = 0; s0 < n; s0 += kMergeBlock) {
+    float2 mlv[kMergeBlock];
+    float4 av[kMergeBlock];
+#pragma unroll
+    for (int i = 0; i < kMergeBlock; ++i) {
+      const int s = s0 + i < n ? s0 + i : n - 1;
+      mlv[i] = ml[s];
+      av[i] = *reinterpret_cast<const float4*>(accp + static_cast<int64_t>(s) * head_dim);
+    }
+    float m_new = m_run;
+#pragma unroll
+    for (int i = 0; i < kMergeBlock; ++i)
+      if (s0 + i < n && mlv[i].y > 0.f) m_new = fmaxf(m_new, mlv[i].x);
+    const float alpha = exp2f(m_run - m_new);
+    l *= alpha; o.x *= alpha; o.y *= alpha; o.z *= alpha; o.w *= alpha;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < kMergeBlock; ++i) {
+      if (s0 + i < n && mlv[i].y > 0.f) {
+        const float sc = exp2f(mlv[i].x - m_run);
+        l += mlv[i].y * sc;
+        o.x += av[i].x * sc; o.y += av[i].y * sc; o.z += av[i].z * sc; o.w += av[i].w * sc;
+      }
+    }
+  }
+  const float inv = (l > 0.f) ? 1.0f / l : 0.f;
+  uint2 w;
+  w.x = pack_bf2(o.x * inv, o.y * inv);
+  w.y = pack_bf2(o.z * inv, o.w * inv);
+  *reinterpret_cast<uint2*>(out + static_cast<int64_t>(b) * out_stride + static_cast<int64_t>(hq) * head_dim + d) = w;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sgl_amd_cascade_chunk_tokens(void) { return kChunk; }
+
+int64_t sgl_amd_cascade_plan_ints(int64_t batch, int64_t max_items) { return cascade_plan_ints(batch, max_items); }
+
+int sgl_amd_cascade_plan(const int32_t* req_to_token, int64_t req_to_token_stride, const int64_t* req_pool_indices,
+                         const int32_t* seq_lens, int64_t batch, int num_q_heads, int num_kv_heads,
+                         int min_shared_len, int64_t max_context_len, int32_t* plan, int64_t max_items, void* stream) {
+  SGL_CLEAR_STALE_ERROR();
+  SGL_CHECK_ARG(batch >= 1 && batch <= kPlanMaxBatch, "cascade_plan: batch=%lld (supported: 1..%d)", (long long)batch, kPlanMaxBatch);
+  SGL_CHECK_ARG(num_kv_heads > 0 && num_q_heads % num_kv_heads == 0 && num_q_heads / num_kv_heads <= kRowsPerItem, "cascade_plan: bad head counts");
+  SGL_CHECK_ARG(max_items >= 1 && plan && max_context_len >= 1, "cascade_plan: bad plan arguments");
+  const int members_per_item = kRowsPerItem / (num_q_heads / num_kv_heads);
+  const int chunks = static_cast<int>((max_context_len + kChunk - 1) / kChunk);
+  hipLaunchKernelGGL(cascade_plan_kernel, dim3(1), dim3(kPlanThreads), 0, as_stream(stream), req_to_token,
+                     req_to_token_stride, req_pool_indices, seq_lens, static_cast<int>(batch), min_shared_len,
+                     kChunk, members_per_item, 64, chunks * kChunk, plan, static_cast<int>(max_items));
+  SGL_CHECK_LAUNCH("cascade_plan");
+  return 0;
+}
+
+int sgl_amd_cascade_members_per_item(int num_q_heads, int num_kv_heads) {
+  const int group = num_q_heads / (num_kv_heads > 0 ? num_kv_heads : 1);
+  return group > 0 && group <= kRowsPerItem ? kRowsPerItem / group : 0;
+}
+
+int sgl_amd_cascade_decode_attention(const void* q, const void* k_cache, const void* v_cache, void* out,
+                                     const int32_t* req_to_token, int64_t req_to_token_stride,
+                                     const int64_t* req_pool_indices, const int32_t* seq_lens, const int32_t* plan,
+                                     int64_t batch, int64_t max_items, int num_q_heads, int num_kv_heads, int head_dim,
+                                     int64_t q_token_stride, int64_t out_token_stride, int64_t k_cache_row_stride,
+                                     int64_t v_cache_row_stride, float sm_scale, int64_t max_context_len,
+                                     int slots_total, void* ws_acc, void* ws_ml, void* stream) {
+  SGL_CLEAR_STALE_ERROR();
+  SGL_CHECK_ARG(head_dim == 64 || head_dim == 128, "cascade_decode_attention: head_dim=%d not supported (64/128)", head_dim);
+  SGL_CHECK_ARG(num_kv_heads > 0 && num_q_heads % num_kv_heads == 0 && num_q_heads / num_kv_heads <= kRowsPerItem,
+                "cascade_decode_attention: bad head counts (%d / %d)", num_q_heads, num_kv_heads);
+  SGL_CHECK_ARG(q_token_stride % 8 == 0 && k_cache_row_stride % 8 == 0 && v_cache_row_stride % 8 == 0 && out_token_stride % 4 == 0,
+                "cascade_decode_attention: strides must keep 16-byte (q, k, v) / 8-byte (out) alignment");
+  SGL_CHECK_ARG(batch >= 1 && batch <= 1024 && max_items >= 1 && plan && ws_acc && ws_ml, "cascade_decode_attention: bad batch / workspace");
+  const int chunks = static_cast<int>((max_context_len + kChunk - 1) / kChunk);
+  SGL_CHECK_ARG(slots_total >= chunks + 1, "cascade_decode_attention: slots_total=%d < %d (context chunks + 1)", slots_total, chunks + 1);
+  hipStream_t st = as_stream(stream);
+  ChunkParams p{};
+  p.q = static_cast<const uint16_t*>(q);
+  p.k_cache = static_cast<const uint16_t*>(k_cache);
+  p.v_cache = static_cast<const uint16_t*>(v_cache);
+  p.req_to_token = req_to_token; p.req_pool_indices = req_pool_indices; p.seq_lens = seq_lens; p.plan = plan;
+  p.ws_acc = static_cast<float*>(ws_acc); p.ws_ml = static_cast<float*>(ws_ml);
+  p.q_stride = q_token_stride; p.kc_stride = k_cache_row_stride; p.vc_stride = v_cache_row_stride; p.r2t_stride = req_to_token_stride;
+  p.batch = static_cast<int>(batch); p.max_items = static_cast<int>(max_items); p.num_q_heads = num_q_heads;
+  p.group = num_q_heads / num_kv_heads; p.members_per_item = kRowsPerItem / p.group;
+  p.num_kv_heads = num_kv_heads;
+  p.slots_total = slots_total;
+  p.scale_log2 = sm_scale * 1.4426950408889634f;
+  // worst-case unit count of this batch: every request's private chunks + the shared chunks of batch/2 groups
+  int64_t units = (batch * (chunks + 1) + (batch / 2 + 1) * chunks);
+  if (units > max_items) units = max_items;
+  dim3 grid(static_cast<unsigned>(units * num_kv_heads));
+  if (head_dim == 128) hipLaunchKernelGGL(cascade_chunk_kernel<128>, grid, dim3(kThreads), 0, st, p);
+  else hipLaunchKernelGGL(cascade_chunk_kernel<64>, grid, dim3(kThreads), 0, st, p);
+  const int hpb = 256 / (head_dim / 4);
+  hipLaunchKernelGGL(cascade_merge2_kernel, dim3(static_cast<unsigned>(batch), (num_q_heads + hpb - 1) / hpb), dim3(256), 0, st,
+                     p.ws_acc, p.ws_ml, plan, seq_lens, static_cast<uint16_t*>(out), out_token_stride, p.batch, p.max_items,
+                     num_q_heads, head_dim, slots_total);
+  SGL_CHECK_LAUNCH("cascade_decode_attention");
+  return 0;
+}
+
+}  // extern "C"

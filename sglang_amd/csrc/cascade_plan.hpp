@@ -8,7 +8,8 @@
 //   group_qo[B + 1]      member_rows range of each group
 //   group_pool_row[B]    req_to_token row of the group's leader
 //   group_kvlen[B]       shared kv length of the group (multiple of the kv tile)
-//   items[3 * max_items] (group, kv chunk, row tile)
+//   items[8 * max_items] self-contained records: (group, kv chunk, row tile, members, first member_rows
+//                        index, kv tokens, req_to_token row of the leader, 0); members == 0: unused entry
 //   batch_order[B]       permutation of the batch: grouped requests (group by group) first, then the rest
 #pragma once
 #include <stdint.h>
@@ -27,7 +28,7 @@ struct CascadePlanView {
 };
 
 __host__ __device__ inline int64_t cascade_plan_ints(int64_t batch, int64_t max_items) {
-  return 8 + batch + batch + (batch + 1) + batch + batch + 3 * max_items + batch;
+  return 8 + batch + batch + (batch + 1) + batch + batch + 8 * max_items + batch;
 }
 
 __host__ __device__ inline CascadePlanView cascade_plan_view(const int32_t* plan, int64_t batch, int64_t max_items) {
@@ -39,7 +40,7 @@ __host__ __device__ inline CascadePlanView cascade_plan_view(const int32_t* plan
   v.group_qo = p; p += batch + 1;
   v.group_pool_row = p; p += batch;
   v.group_kvlen = p; p += batch;
-  v.items = p; p += 3 * max_items;
+  v.items = p; p += 8 * max_items;
   v.batch_order = p;
   return v;
 }

@@ -385,166 +385,6 @@ __global__ void decode_stage2_kernel(const float* __restrict__ ws_acc, const flo
 }
 
 
-// ---- cascade plan: group the requests of a decode batch that share a KV prefix ----------------
-// One workgroup.  Requests that share ANY cached prefix share their first slot (page_size-agnostic:
-// identical slot ids <=> the same cached tokens), so the leader of request b is the lowest batch
-// index with the same first slot; the shared length with the leader is the first mismatch of the
-// two req_to_token rows.  A group's shared part is the minimum over its members, rounded down to
-// the kv tile; groups with < 2 members or a short shared part are dropped.
-constexpr int kPlanThreads = 1024;
-constexpr int kPlanMaxBatch = 1024;
-
-__global__ __launch_bounds__(kPlanThreads) void cascade_plan_kernel(
-    const int32_t* __restrict__ req_to_token, int64_t r2t_stride, const int64_t* __restrict__ req_pool_indices,
-    const int32_t* __restrict__ seq_lens, int batch, int min_shared, int chunk_tokens, int tokens_per_tile,
-    int kv_tile, int max_shared, int32_t* __restrict__ plan, int max_items, float* __restrict__ ws_ml, int64_t ml_pairs) {
-  __shared__ int first_slot[kPlanMaxBatch];
-  __shared__ int leader[kPlanMaxBatch];
-  __shared__ int shared_len[kPlanMaxBatch];
-  __shared__ int grp_min[kPlanMaxBatch];
-  __shared__ int grp_cnt[kPlanMaxBatch];
-  __shared__ int grp_id[kPlanMaxBatch];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const CascadePlanView pv = cascade_plan_view(plan, batch, max_items);
-  // every split slot starts the step empty: (max, sum) = (-big, 0)
-  for (int64_t i = tid; i < ml_pairs; i += kPlanThreads) {
-    ws_ml[2 * i] = kNegBig;
-    ws_ml[2 * i + 1] = 0.f;
-  }
-  for (int b = tid; b < batch; b += kPlanThreads) {
-    const int len = seq_lens[b];
-    first_slot[b] = len > 1 ? req_to_token[req_pool_indices[b] * r2t_stride] : -1 - b;   // unique when too short
-    grp_min[b] = 0x7fffffff;
-    grp_cnt[b] = 0;
-  }
-  __syncthreads();
-  for (int b = tid; b < batch; b += kPlanThreads) {
-    int l = b;
-    const int fs = first_slot[b];
-    for (int c = 0; c < b; ++c)
-      if (first_slot[c] == fs) { l = c; break; }
-    leader[b] = l;
-  }
-  __syncthreads();
-  // common prefix with the leader: one wave per request, 64 positions per step
-  for (int b = wid; b < batch; b += kPlanThreads / 64) {
-    const int l = leader[b];
-    int common = 0;
-    if (l != b) {
-      const int32_t* ra = req_to_token + req_pool_indices[b] * r2t_stride;
-      const int32_t* rb = req_to_token + req_pool_indices[l] * r2t_stride;
-      int lim = seq_lens[b] - 1;                 // the newest token's slot is never shared
-      const int ll = seq_lens[l] - 1;
-      if (ll < lim) lim = ll;
-      int t0 = 0;
-      bool done = false;
-      while (t0 < lim && !done) {
-        const int t = t0 + lane;
-        const bool same = t < lim && ra[t] == rb[t];
-        const unsigned long long mm = __ballot(!same);
-        if (mm != 0ull) {
-          common = t0 + __ffsll(static_cast<long long>(mm)) - 1;
-          done = true;
-        } else {
-          t0 += 64;
-          common = t0 < lim ? t0 : lim;
-        }
-      }
-      if (common > lim) common = lim;
-    }
-    if (lane == 0) {
-      shared_len[b] = common;
-      if (l != b) {
-        atomicMin(&grp_min[l], common);
-        atomicAdd(&grp_cnt[l], 1);
-      }
-    }
-  }
-  __syncthreads();
-  if (tid == 0) {
-    int ng = 0, rows = 0, n_items = 0;
-    pv.group_qo[0] = 0;
-    for (int b = 0; b < batch; ++b) {
-      grp_id[b] = -1;
-      pv.req_shared[b] = 0;
-    }
-    for (int b = 0; b < batch; ++b) {
-      if (leader[b] != b || grp_cnt[b] < 1) continue;
-      int kv = grp_min[b] / kv_tile * kv_tile;
-      if (kv > max_shared) kv = max_shared;                      // the shared part owns `shared_slots` split slots
-      if (kv < min_shared) continue;
-      const int members = grp_cnt[b] + 1;
-      const int tiles = (members + tokens_per_tile - 1) / tokens_per_tile;
-      const int chunks = (kv + chunk_tokens - 1) / chunk_tokens;
-      if (n_items + tiles * chunks > max_items) continue;       // plan full: the rest decode the plain way
-      grp_id[b] = ng;
-      pv.group_pool_row[ng] = static_cast<int32_t>(req_pool_indices[b]);
-      pv.group_kvlen[ng] = kv;
-      for (int c = 0; c < chunks; ++c)
-        for (int t = 0; t < tiles; ++t) {
-          pv.items[3 * n_items + 0] = ng;
-          pv.items[3 * n_items + 1] = c;
-          pv.items[3 * n_items + 2] = t;
-          ++n_items;
-        }
-      rows += members;
-      pv.group_qo[ng + 1] = rows;
-      ++ng;
-    }
-    // members in batch order inside each group
-    for (int gi = 0; gi < ng; ++gi) grp_cnt[gi] = pv.group_qo[gi];    // reuse as cursors (indexed by group id)
-    for (int b = 0; b < batch; ++b) {
-      const int gi = grp_id[leader[b]];
-      if (gi < 0) continue;
-      pv.member_rows[grp_cnt[gi]++] = b;
-      pv.req_shared[b] = pv.group_kvlen[gi];
-    }
-    int cur = 0;
-    for (int i = 0; i < rows; ++i) pv.batch_order[cur++] = pv.member_rows[i];
-    for (int b = 0; b < batch; ++b)
-      if (grp_id[leader[b]] < 0) pv.batch_order[cur++] = b;
-    pv.header[0] = n_items;
-    pv.header[1] = ng;
-    pv.header[2] = rows;
-  }
-}
-
-// Merge of all split slots of a (request, head): slots with sum == 0 are empty.
-// Block = 4 heads x (D/4) lanes; each thread owns 4 consecutive output elements of one head.
-__global__ __launch_bounds__(256) void cascade_merge_kernel(const float* __restrict__ ws_acc,
-                                                            const float* __restrict__ ws_ml,
-                                                            uint16_t* __restrict__ out, int64_t out_stride,
-                                                            int num_q_heads, int head_dim, int slots_total) {
-  const int tpd = head_dim >> 2;                      // threads per head
-  const int b = blockIdx.x;
-  const int hq = blockIdx.y * (blockDim.x / tpd) + threadIdx.x / tpd;
-  const int d = (threadIdx.x % tpd) * 4;
-  if (hq >= num_q_heads) return;
-  const int64_t base = (static_cast<int64_t>(b) * num_q_heads + hq) * slots_total;
-  const float2* ml = reinterpret_cast<const float2*>(ws_ml) + base;
-  float m_all = kNegBig;
-  for (int s = 0; s < slots_total; ++s) {
-    const float2 v = ml[s];
-    if (v.y > 0.f) m_all = fmaxf(m_all, v.x);
-  }
-  float l = 0.f;
-  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int s = 0; s < slots_total; ++s) {
-    const float2 v = ml[s];
-    if (v.y > 0.f) {
-      const float sc = exp2f(v.x - m_all);
-      l += v.y * sc;
-      const float4 a = *reinterpret_cast<const float4*>(ws_acc + (base + s) * head_dim + d);
-      o.x += a.x * sc; o.y += a.y * sc; o.z += a.z * sc; o.w += a.w * sc;
-    }
-  }
-  const float inv = (l > 0.f) ? 1.0f / l : 0.f;
-  uint2 w;
-  w.x = pack_bf2(o.x * inv, o.y * inv);
-  w.y = pack_bf2(o.z * inv, o.w * inv);
-  *reinterpret_cast<uint2*>(out + static_cast<int64_t>(b) * out_stride + static_cast<int64_t>(hq) * head_dim + d) = w;
-}
-
 template <int G, int D>
 int launch_stage1(const DecodeParams& p, int batch, int group_size, int head_blocks, bool use_dpp,
                   hipStream_t stream) {
@@ -633,118 +473,6 @@ int sgl_amd_decode_attention(const void* q, const void* k_cache, const void* v_c
     SGL_CHECK_LAUNCH("decode_attention(stage2)");
   }
   return 0;
-}
-
-int64_t sgl_amd_cascade_plan_ints(int64_t batch, int64_t max_items) { return cascade_plan_ints(batch, max_items); }
-
-int sgl_amd_cascade_plan(const int32_t* req_to_token, int64_t req_to_token_stride, const int64_t* req_pool_indices,
-                         const int32_t* seq_lens, int64_t batch, int num_q_heads, int num_kv_heads,
-                         int min_shared_len, int chunk_tokens, int32_t* plan, int64_t max_items, void* ws_ml,
-                         int shared_slots, int slots_total, void* stream) {
-  SGL_CLEAR_STALE_ERROR();
-  SGL_CHECK_ARG(batch >= 1 && batch <= kPlanMaxBatch, "cascade_plan: batch=%lld (supported: 1..%d)", (long long)batch, kPlanMaxBatch);
-  SGL_CHECK_ARG(chunk_tokens >= 64 && chunk_tokens % 64 == 0, "cascade_plan: chunk_tokens must be a multiple of 64");
-  SGL_CHECK_ARG(num_kv_heads > 0 && num_q_heads % num_kv_heads == 0 && num_q_heads / num_kv_heads <= 128, "cascade_plan: bad head counts");
-  SGL_CHECK_ARG(max_items >= 1 && shared_slots >= 1 && slots_total > shared_slots && ws_ml != nullptr, "cascade_plan: bad workspace arguments");
-  const int tokens_per_tile = 128 / (num_q_heads / num_kv_heads);
-  hipLaunchKernelGGL(cascade_plan_kernel, dim3(1), dim3(kPlanThreads), 0, as_stream(stream), req_to_token,
-                     req_to_token_stride, req_pool_indices, seq_lens, static_cast<int>(batch), min_shared_len,
-                     chunk_tokens, tokens_per_tile, 64, shared_slots * chunk_tokens, plan, static_cast<int>(max_items), static_cast<float*>(ws_ml),
-                     batch * num_q_heads * slots_total);
-  SGL_CHECK_LAUNCH("cascade_plan");
-  return 0;
-}
-
-// the shared part is launched from extend_attention.hip
-int sgl_amd_cascade_shared_part(const void* q, const void* k_cache, const void* v_cache, const int32_t* req_to_token,
-                                int64_t req_to_token_stride, const int32_t* plan, int64_t batch, int64_t max_items,
-                                int num_q_heads, int num_kv_heads, int head_dim, int64_t q_token_stride,
-                                int64_t k_cache_row_stride, int64_t v_cache_row_stride, float sm_scale,
-                                int chunk_tokens, int slots_total, void* ws_acc, void* ws_ml, void* stream);
-
-int sgl_amd_cascade_suffix_part(const void* q, const void* k_cache, const void* v_cache,
-                                const int32_t* req_to_token, int64_t req_to_token_stride,
-                                const int64_t* req_pool_indices, const int32_t* seq_lens, const int32_t* plan,
-                                int64_t batch, int64_t max_items, int num_q_heads, int num_kv_heads, int head_dim,
-                                int64_t q_token_stride, int64_t k_cache_row_stride, int64_t v_cache_row_stride,
-                                float sm_scale, int shared_slots, int suffix_splits, void* ws_acc, void* ws_ml,
-                                int flags, void* stream) {
-  SGL_CLEAR_STALE_ERROR();
-  SGL_CHECK_ARG(head_dim == 64 || head_dim == 128, "cascade_suffix_part: head_dim=%d not supported (64/128)", head_dim);
-  SGL_CHECK_ARG(num_kv_heads > 0 && num_q_heads % num_kv_heads == 0, "cascade_suffix_part: bad head counts");
-  SGL_CHECK_ARG(shared_slots >= 1 && suffix_splits >= 1 && ws_acc && ws_ml && plan, "cascade_suffix_part: bad workspace arguments");
-  SGL_CHECK_ARG(q_token_stride % 8 == 0 && k_cache_row_stride % 8 == 0 && v_cache_row_stride % 8 == 0,
-                "cascade_suffix_part: strides must be multiples of 8 elements");
-  SGL_CHECK_ARG(batch <= kPlanMaxBatch, "cascade_suffix_part: batch too large");
-  if (batch == 0) return 0;
-  DecodeParams p;
-  p.q = static_cast<const uint16_t*>(q);
-  p.k_cache = static_cast<const uint16_t*>(k_cache);
-  p.v_cache = static_cast<const uint16_t*>(v_cache);
-  p.req_to_token = req_to_token;
-  p.req_pool_indices = req_pool_indices;
-  p.seq_lens = seq_lens;
-  p.kv_indptr = nullptr;
-  p.out = nullptr;
-  p.ws_acc = static_cast<float*>(ws_acc);
-  p.ws_ml = static_cast<float*>(ws_ml);
-  p.q_stride = q_token_stride;
-  p.out_stride = 0;
-  p.kc_stride = k_cache_row_stride;
-  p.vc_stride = v_cache_row_stride;
-  p.r2t_stride = req_to_token_stride;
-  p.num_q_heads = num_q_heads;
-  p.num_kv_heads = num_kv_heads;
-  p.num_splits = suffix_splits;
-  p.min_chunk = 64;
-  p.scale_log2 = sm_scale * 1.4426950408889634f;
-  p.kv_start = cascade_plan_view(plan, batch, max_items).req_shared;
-  p.batch_order = nullptr;
-  p.slot_offset = shared_slots;
-  p.slots_total = shared_slots + suffix_splits;
-  const int group = num_q_heads / num_kv_heads;
-  const bool use_dpp = (flags & SGL_AMD_ATTN_FLAG_NO_DPP) == 0;
-  hipStream_t st = as_stream(stream);
-  if (head_dim == 64) dispatch_group<64>(p, static_cast<int>(batch), group, use_dpp, st);
-  else dispatch_group<128>(p, static_cast<int>(batch), group, use_dpp, st);
-  SGL_CHECK_LAUNCH("cascade_suffix_part");
-  return 0;
-}
-
-int sgl_amd_cascade_merge(const void* ws_acc, const void* ws_ml, void* out, int64_t batch, int num_q_heads,
-                          int head_dim, int64_t out_token_stride, int slots_total, void* stream) {
-  SGL_CLEAR_STALE_ERROR();
-  SGL_CHECK_ARG(head_dim == 64 || head_dim == 128 || head_dim == 256, "cascade_merge: head_dim=%d not supported", head_dim);
-  SGL_CHECK_ARG(out_token_stride % 4 == 0, "cascade_merge: out stride must be a multiple of 4 elements");
-  if (batch == 0) return 0;
-  const int heads_per_block = 256 / (head_dim / 4);
-  hipLaunchKernelGGL(cascade_merge_kernel, dim3(batch, (num_q_heads + heads_per_block - 1) / heads_per_block), dim3(256), 0,
-                     as_stream(stream), static_cast<const float*>(ws_acc), static_cast<const float*>(ws_ml),
-                     static_cast<uint16_t*>(out), out_token_stride, num_q_heads, head_dim, slots_total);
-  SGL_CHECK_LAUNCH("cascade_merge");
-  return 0;
-}
-
-int sgl_amd_cascade_decode_attention(const void* q, const void* k_cache, const void* v_cache, void* out,
-                                     const int32_t* req_to_token, int64_t req_to_token_stride,
-                                     const int64_t* req_pool_indices, const int32_t* seq_lens, const int32_t* plan,
-                                     int64_t batch, int64_t max_items, int num_q_heads, int num_kv_heads, int head_dim,
-                                     int64_t q_token_stride, int64_t out_token_stride, int64_t k_cache_row_stride,
-                                     int64_t v_cache_row_stride, float sm_scale, int chunk_tokens, int shared_slots,
-                                     int suffix_splits, void* ws_acc, void* ws_ml, int flags, void* stream) {
-  // single-stream composition of the three parts (the backend overlaps 1 and 2 on two streams)
-  if (int rc = sgl_amd_cascade_shared_part(q, k_cache, v_cache, req_to_token, req_to_token_stride, plan, batch, max_items,
-                                           num_q_heads, num_kv_heads, head_dim, q_token_stride, k_cache_row_stride,
-                                           v_cache_row_stride, sm_scale, chunk_tokens, shared_slots + suffix_splits,
-                                           ws_acc, ws_ml, stream))
-    return rc;
-  if (int rc = sgl_amd_cascade_suffix_part(q, k_cache, v_cache, req_to_token, req_to_token_stride, req_pool_indices,
-                                           seq_lens, plan, batch, max_items, num_q_heads, num_kv_heads, head_dim,
-                                           q_token_stride, k_cache_row_stride, v_cache_row_stride, sm_scale,
-                                           shared_slots, suffix_splits, ws_acc, ws_ml, flags, stream))
-    return rc;
-  return sgl_amd_cascade_merge(ws_acc, ws_ml, out, batch, num_q_heads, head_dim, out_token_stride,
-                               shared_slots + suffix_splits, stream);
 }
 
 }  // extern "C"

@@ -24,7 +24,6 @@
 //     S^T registers ARE the P^T operand of the second MFMA (no LDS round trip);
 //   * fp32 accumulation, exp2 with the softmax scale folded in, bf16 output.
 #include "common.hpp"
-#include "cascade_plan.hpp"
 #include "../../include/sglang_amd.h"
 
 using namespace sgl_amd;
@@ -57,15 +56,6 @@ struct ExtendParams {
   int tokens_per_tile;          // kRows / group
   int causal;
   float scale_log2;
-  // ---- shared-prefix (cascade) decode: CASCADE instantiation only ----------------------------
-  const int32_t* plan;          // sgl_amd_cascade_plan output
-  float* ws_acc;                // [B, Hq, slots, D] unnormalised partial outputs
-  float* ws_ml;                 // [B, Hq, slots, 2] (max in log2 units, sum)
-  int num_q_heads;
-  int slots_total;
-  int chunk_tokens;             // kv tokens per work item
-  int max_items;
-  int batch;
 };
 
 template <int D>
@@ -74,32 +64,10 @@ struct Smem {
   U4 vt[D * kKvTile / 8];       // [d][token-chunk ^ swz]
 };
 
-// CASCADE = false: ragged extend attention, bf16 output.
-// CASCADE = true : the shared-prefix part of a decode step.  A work item (group, kv chunk, row tile)
-// comes from the plan; the "request" is a group of decode requests whose first kv_len slots are
-// the same rows of the pool, its "query tokens" are the members' single decode tokens (gathered
-// through member_rows), attention is non-causal over the chunk, and the result is written
-// unnormalised (acc, max, sum) into split slot `chunk` of every member for the LSE merge.
-template <int D, bool CASCADE>
-__device__ __forceinline__ void extend_attention_body(const ExtendParams& p, Smem<D>& sm, int block_x, int block_z);
-
-template <int D, bool CASCADE>
+template <int D>
 __global__ __launch_bounds__(kThreads) void extend_attention_kernel(ExtendParams p) {
   __shared__ Smem<D> sm;
-  if (CASCADE) {
-    // persistent over the plan's work items: the item count is only known on the device
-    const int n_items = p.plan[0];
-    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-      extend_attention_body<D, true>(p, sm, item, 0);
-      __syncthreads();   // the next item re-stages the LDS tiles
-    }
-  } else {
-    extend_attention_body<D, false>(p, sm, blockIdx.x, blockIdx.z);
-  }
-}
-
-template <int D, bool CASCADE>
-__device__ __forceinline__ void extend_attention_body(const ExtendParams& p, Smem<D>& sm, int block_x, int block_z) {
+  const int block_x = blockIdx.x, block_z = blockIdx.z;
   constexpr int CPR = D / 8;            // 16-byte chunks per KV row
   constexpr int KC = D / 32;            // MFMA k-steps over the head dim
   constexpr int ND = D / 16;            // 16-wide output tiles over the head dim
@@ -115,36 +83,17 @@ __device__ __forceinline__ void extend_attention_body(const ExtendParams& p, Sme
   const int l15 = lane & 15;
   const int g = lane >> 4;
 
-  int q_begin, ext_len, kv_len, prefix, kv_begin = 0, chunk = 0;
-  const int32_t* idx_base;
-  const int32_t* member_rows = nullptr;
-  if (CASCADE) {
-    const CascadePlanView pv = cascade_plan_view(p.plan, p.batch, p.max_items);
-    const int item = block_x;
-    const int grp = pv.items[3 * item + 0];
-    chunk = pv.items[3 * item + 1];
-    tile = pv.items[3 * item + 2];
-    q_begin = pv.group_qo[grp];
-    ext_len = pv.group_qo[grp + 1] - q_begin;
-    const int shared = pv.group_kvlen[grp];
-    kv_begin = chunk * p.chunk_tokens;
-    kv_len = kv_begin + p.chunk_tokens < shared ? kv_begin + p.chunk_tokens : shared;
-    prefix = 0;
-    idx_base = p.req_to_token + static_cast<int64_t>(pv.group_pool_row[grp]) * p.r2t_stride;
-    member_rows = pv.member_rows;
-    b = grp;
-  } else {
-    q_begin = p.qo_indptr[b];
-    ext_len = p.qo_indptr[b + 1] - q_begin;
-    kv_len = p.seq_lens[b];
-    prefix = p.prefix_lens[b];
-    idx_base = p.req_to_token + p.req_pool_indices[b] * p.r2t_stride;
-  }
+  const int q_begin = p.qo_indptr[b];
+  const int ext_len = p.qo_indptr[b + 1] - q_begin;
+  const int kv_len = p.seq_lens[b];
+  const int prefix = p.prefix_lens[b];
+  const int kv_begin = 0;
+  const int32_t* idx_base = p.req_to_token + p.req_pool_indices[b] * p.r2t_stride;
   const int q0 = tile * p.tokens_per_tile;
   if (q0 >= ext_len) return;
   int q1 = q0 + p.tokens_per_tile;
   if (q1 > ext_len) q1 = ext_len;
-  const bool causal = !CASCADE && p.causal;
+  const bool causal = p.causal;
   const int kv_end = causal ? (prefix + q1 < kv_len ? prefix + q1 : kv_len) : kv_len;
   const int t_first = kv_begin / kKvTile;
   const int n_tiles = (kv_end + kKvTile - 1) / kKvTile;
@@ -167,7 +116,7 @@ __device__ __forceinline__ void extend_attention_body(const ExtendParams& p, Sme
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc) {
       if (row_ok[mt]) {
-        const int64_t qrow = CASCADE ? member_rows[q_begin + row_tok[mt]] : q_begin + row_tok[mt];
+        const int64_t qrow = q_begin + row_tok[mt];
         qfrag[mt][kc] = ld16(p.q + qrow * p.q_stride + row_off[mt] + kc * 32 + g * 8);
       } else {
         qfrag[mt][kc] = U4{0u, 0u, 0u, 0u};
@@ -343,21 +292,6 @@ __device__ __forceinline__ void extend_attention_body(const ExtendParams& p, Sme
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
     if (!row_ok[mt]) continue;
-    if (CASCADE) {
-      const int64_t req = member_rows[q_begin + row_tok[mt]];
-      const int hq = static_cast<int>(row_off[mt] / D);
-      const int64_t slot = (req * p.num_q_heads + hq) * p.slots_total + chunk;
-      float* ap = p.ws_acc + slot * D;
-#pragma unroll
-      for (int n = 0; n < ND; ++n)
-        *reinterpret_cast<float4*>(ap + n * 16 + g * 4) =
-            make_float4(ot[mt][n][0], ot[mt][n][1], ot[mt][n][2], ot[mt][n][3]);
-      if (g == 0) {
-        p.ws_ml[slot * 2 + 0] = m_run[mt];
-        p.ws_ml[slot * 2 + 1] = l;
-      }
-      continue;
-    }
     const float inv = (l > 0.f) ? 1.0f / l : 0.f;
     uint16_t* op = p.out + static_cast<int64_t>(q_begin + row_tok[mt]) * p.out_stride + row_off[mt];
 #pragma unroll
@@ -434,52 +368,10 @@ int sgl_amd_extend_attention(const void* q, void* out, const void* k_cache, cons
   const int tiles = (max_extend_len + p.tokens_per_tile - 1) / p.tokens_per_tile;
   dim3 grid(tiles, num_kv_heads, batch);
   if (head_dim == 128)
-    hipLaunchKernelGGL((extend_attention_kernel<128, false>), grid, dim3(kThreads), 0, as_stream(stream), p);
+    hipLaunchKernelGGL((extend_attention_kernel<128>), grid, dim3(kThreads), 0, as_stream(stream), p);
   else
-    hipLaunchKernelGGL((extend_attention_kernel<64, false>), grid, dim3(kThreads), 0, as_stream(stream), p);
+    hipLaunchKernelGGL((extend_attention_kernel<64>), grid, dim3(kThreads), 0, as_stream(stream), p);
   SGL_CHECK_LAUNCH("extend_attention");
-  return 0;
-}
-
-int sgl_amd_cascade_shared_part(const void* q, const void* k_cache, const void* v_cache, const int32_t* req_to_token,
-                                int64_t req_to_token_stride, const int32_t* plan, int64_t batch, int64_t max_items,
-                                int num_q_heads, int num_kv_heads, int head_dim, int64_t q_token_stride,
-                                int64_t k_cache_row_stride, int64_t v_cache_row_stride, float sm_scale,
-                                int chunk_tokens, int slots_total, void* ws_acc, void* ws_ml, void* stream) {
-  SGL_CLEAR_STALE_ERROR();
-  const int group = num_q_heads / num_kv_heads;
-  SGL_CHECK_ARG(group <= kRows, "cascade_shared_part: GQA group %d too large", group);
-  ExtendParams p{};
-  p.q = static_cast<const uint16_t*>(q);
-  p.k_cache = static_cast<const uint16_t*>(k_cache);
-  p.v_cache = static_cast<const uint16_t*>(v_cache);
-  p.req_to_token = req_to_token;
-  p.q_stride = q_token_stride;
-  p.kc_stride = k_cache_row_stride;
-  p.vc_stride = v_cache_row_stride;
-  p.r2t_stride = req_to_token_stride;
-  p.num_kv_heads = num_kv_heads;
-  p.group = group;
-  p.tokens_per_tile = kRows / group;
-  p.causal = 0;
-  p.scale_log2 = sm_scale * 1.4426950408889634f;
-  p.plan = plan;
-  p.ws_acc = static_cast<float*>(ws_acc);
-  p.ws_ml = static_cast<float*>(ws_ml);
-  p.num_q_heads = num_q_heads;
-  p.slots_total = slots_total;
-  p.chunk_tokens = chunk_tokens;
-  p.max_items = static_cast<int>(max_items);
-  p.batch = static_cast<int>(batch);
-  // 2 resident workgroups per CU in total; each loops over the plan's items
-  unsigned gx = static_cast<unsigned>((512 + num_kv_heads - 1) / num_kv_heads);
-  if (gx > max_items) gx = static_cast<unsigned>(max_items);
-  dim3 grid(gx, num_kv_heads, 1);
-  if (head_dim == 128)
-    hipLaunchKernelGGL((extend_attention_kernel<128, true>), grid, dim3(kThreads), 0, as_stream(stream), p);
-  else
-    hipLaunchKernelGGL((extend_attention_kernel<64, true>), grid, dim3(kThreads), 0, as_stream(stream), p);
-  SGL_CHECK_LAUNCH("cascade_shared_part");
   return 0;
 }
 

@@ -257,22 +257,21 @@ def extend_attention(q: torch.Tensor, out: torch.Tensor, k_cache: torch.Tensor, 
 
 
 # ------------------------------------------------------------- shared-prefix (cascade) decode
-CASCADE_CHUNK_TOKENS = 128
 CASCADE_MIN_SHARED = 128
 
 
 class CascadeWorkspace:
     """Caller-owned buffers of the cascade decode path for batches up to `max_batch` and contexts up to
-    `max_context_len`: the device plan, and the split-slot partials shared by all layers."""
+    `max_context_len`: the device plan, and the per-item partial slots shared by all layers."""
 
-    def __init__(self, max_batch: int, num_q_heads: int, head_dim: int, max_context_len: int, suffix_splits: int,
-                 device, max_items: int = 2048):
-        self.max_batch, self.max_items = max_batch, max_items
-        self.chunk_tokens = CASCADE_CHUNK_TOKENS
-        self.shared_slots = max(1, (max_context_len + self.chunk_tokens - 1) // self.chunk_tokens)
-        self.suffix_splits = suffix_splits
-        self.slots = self.shared_slots + suffix_splits
-        self.plan = torch.zeros(native.lib().sgl_amd_cascade_plan_ints(max_batch, max_items), dtype=torch.int32, device=device)
+    def __init__(self, max_batch: int, num_q_heads: int, head_dim: int, max_context_len: int, device, max_items: Optional[int] = None):
+        self.max_context_len = max_context_len
+        self.chunk_tokens = native.lib().sgl_amd_cascade_chunk_tokens()
+        chunks = (max_context_len + self.chunk_tokens - 1) // self.chunk_tokens
+        # every request's private chunks + the shared chunks of at most max_batch/2 groups (x member tiles), twice over
+        self.max_batch, self.max_items = max_batch, max_items or 2 * (max_batch * (chunks + 1) + (max_batch // 2 + 1) * chunks)
+        self.slots = (max_context_len + self.chunk_tokens - 1) // self.chunk_tokens + 1
+        self.plan = torch.zeros(native.lib().sgl_amd_cascade_plan_ints(max_batch, self.max_items), dtype=torch.int32, device=device)
         self.ws_acc = torch.empty((max_batch, num_q_heads, self.slots, head_dim), dtype=torch.float32, device=device)
         self.ws_ml = torch.empty((max_batch, num_q_heads, self.slots, 2), dtype=torch.float32, device=device)
 
@@ -287,13 +286,13 @@ def cascade_plan(ws: CascadeWorkspace, req_to_token: torch.Tensor, req_pool_indi
           "cascade_plan: dtypes")
     # NOTE: the plan / slot layout is addressed with the ACTUAL batch size B
     native.call("sgl_amd_cascade_plan", req_to_token.data_ptr(), req_to_token.stride(0), req_pool_indices.data_ptr(),
-                seq_lens.data_ptr(), B, num_q_heads, num_kv_heads, min_shared, ws.chunk_tokens, ws.plan.data_ptr(),
-                ws.max_items, ws.ws_ml.data_ptr(), ws.shared_slots, ws.slots, _stream())
+                seq_lens.data_ptr(), B, num_q_heads, num_kv_heads, min_shared, ws.max_context_len, ws.plan.data_ptr(),
+                ws.max_items, _stream())
 
 
 def cascade_decode_attention(ws: CascadeWorkspace, q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
                              out: torch.Tensor, req_to_token: torch.Tensor, req_pool_indices: torch.Tensor,
-                             seq_lens: torch.Tensor, sm_scale: float, flags: int = 0) -> torch.Tensor:
+                             seq_lens: torch.Tensor, sm_scale: float) -> torch.Tensor:
     """Per layer, after cascade_plan(): q/out [B, Hq, D]."""
     _dev(q, k_cache, v_cache, out)
     B, Hq, D = q.shape
@@ -304,46 +303,14 @@ def cascade_decode_attention(ws: CascadeWorkspace, q: torch.Tensor, k_cache: tor
     native.call("sgl_amd_cascade_decode_attention", q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), out.data_ptr(),
                 req_to_token.data_ptr(), req_to_token.stride(0), req_pool_indices.data_ptr(), seq_lens.data_ptr(),
                 ws.plan.data_ptr(), B, ws.max_items, Hq, Hkv, D, q.stride(0), out.stride(0), k_cache.stride(0),
-                v_cache.stride(0), float(sm_scale), ws.chunk_tokens, ws.shared_slots, ws.suffix_splits,
-                ws.ws_acc.data_ptr(), ws.ws_ml.data_ptr(), flags, _stream())
-    return out
-
-
-
-def cascade_parts(ws: CascadeWorkspace, q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, out: torch.Tensor,
-                  req_to_token: torch.Tensor, req_pool_indices: torch.Tensor, seq_lens: torch.Tensor, sm_scale: float,
-                  side_stream: Optional["torch.cuda.Stream"] = None, flags: int = 0) -> torch.Tensor:
-    """cascade_decode_attention with the two independent parts (shared prefixes / private suffixes)
-    overlapped on two HIP streams; under torch.cuda.graph capture this records a fork/join."""
-    B, Hq, D = q.shape
-    Hkv = k_cache.shape[1]
-    cur = torch.cuda.current_stream()
-    common = (req_to_token.data_ptr(), req_to_token.stride(0))
-    if side_stream is not None:
-        side_stream.wait_stream(cur)
-        with torch.cuda.stream(side_stream):
-            native.call("sgl_amd_cascade_shared_part", q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), *common,
-                        ws.plan.data_ptr(), B, ws.max_items, Hq, Hkv, D, q.stride(0), k_cache.stride(0), v_cache.stride(0),
-                        float(sm_scale), ws.chunk_tokens, ws.slots, ws.ws_acc.data_ptr(), ws.ws_ml.data_ptr(),
-                        side_stream.cuda_stream)
-    else:
-        native.call("sgl_amd_cascade_shared_part", q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), *common,
-                    ws.plan.data_ptr(), B, ws.max_items, Hq, Hkv, D, q.stride(0), k_cache.stride(0), v_cache.stride(0),
-                    float(sm_scale), ws.chunk_tokens, ws.slots, ws.ws_acc.data_ptr(), ws.ws_ml.data_ptr(), _stream())
-    native.call("sgl_amd_cascade_suffix_part", q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), *common,
-                req_pool_indices.data_ptr(), seq_lens.data_ptr(), ws.plan.data_ptr(), B, ws.max_items, Hq, Hkv, D,
-                q.stride(0), k_cache.stride(0), v_cache.stride(0), float(sm_scale), ws.shared_slots, ws.suffix_splits,
-                ws.ws_acc.data_ptr(), ws.ws_ml.data_ptr(), flags, _stream())
-    if side_stream is not None:
-        cur.wait_stream(side_stream)
-    native.call("sgl_amd_cascade_merge", ws.ws_acc.data_ptr(), ws.ws_ml.data_ptr(), out.data_ptr(), B, Hq, D, out.stride(0),
-                ws.slots, _stream())
+                v_cache.stride(0), float(sm_scale), ws.max_context_len, ws.slots, ws.ws_acc.data_ptr(), ws.ws_ml.data_ptr(),
+                _stream())
     return out
 
 
 def cascade_batch_order(ws: CascadeWorkspace, batch: int) -> torch.Tensor:
     """View of the plan's batch permutation (device int32 [B]) for decode_attention(batch_order=...)."""
-    off = 8 + 4 * batch + (batch + 1) + 3 * ws.max_items
+    off = 8 + 4 * batch + (batch + 1) + 8 * ws.max_items
     return ws.plan[off: off + batch]
 
 def cascade_plan_summary(ws: CascadeWorkspace, batch: int) -> dict:
@@ -357,10 +324,13 @@ def cascade_plan_summary(ws: CascadeWorkspace, batch: int) -> dict:
     group_pool = p[o:o + B]; o += B
     group_kvlen = p[o:o + B]; o += B
     ng, nrows = p[1], p[2]
-    order_off = o + 3 * ws.max_items
-    return dict(n_items=p[0], n_groups=ng, req_shared=req_shared, member_rows=member_rows[:nrows],
+    order_off = o + 8 * ws.max_items
+    recs = [p[o + 8 * i:o + 8 * i + 8] for i in range(p[0])]
+    return dict(n_items=p[0], n_shared_items=p[3], n_groups=ng, req_shared=req_shared, member_rows=member_rows[:nrows],
                 group_qo=group_qo[:ng + 1], group_pool_row=group_pool[:ng], group_kvlen=group_kvlen[:ng],
-                items=[tuple(p[o + 3 * i:o + 3 * i + 3]) for i in range(p[0])],
+                # shared items: (group, slot, first member_rows entry, members); private: (request, slot, kv_begin, kv_n)
+                items=[(r[7], r[0], r[4], r[3]) for r in recs if r[5] == 0],
+                private_items=[(r[4], r[0], r[1], r[2]) for r in recs if r[5] == 1],
                 batch_order=p[order_off:order_off + B])
 
 # ----------------------------------------------------------------------- sampling

@@ -83,7 +83,7 @@ class HipAttnBackend(AttentionBackend):
     def _cascade_workspace(self, batch: int):
         ws = self._cascade_ws.get(batch)
         if ws is None:
-            ws = kernels.CascadeWorkspace(batch, self.num_q_heads, self.head_dim, self.max_context_len, 1, self.device)
+            ws = kernels.CascadeWorkspace(batch, self.num_q_heads, self.head_dim, self.max_context_len, self.device)
             self._cascade_ws[batch] = ws
         return ws
 
@@ -156,7 +156,7 @@ class HipAttnBackend(AttentionBackend):
             kernels.cascade_decode_attention(m.cascade, q3, self.token_to_kv_pool.get_key_buffer(layer.layer_id),
                                              self.token_to_kv_pool.get_value_buffer(layer.layer_id), o,
                                              self.req_to_token_pool.req_to_token, forward_batch.req_pool_indices,
-                                             m.seq_lens_i32, layer.scaling, flags=self.debug_flags)
+                                             m.seq_lens_i32, layer.scaling)
             return o.view(-1, layer.tp_q_head_num * layer.v_head_dim)
         kernels.decode_attention(q3, self.token_to_kv_pool.get_key_buffer(layer.layer_id),
                                  self.token_to_kv_pool.get_value_buffer(layer.layer_id), o,

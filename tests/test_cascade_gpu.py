@@ -44,10 +44,10 @@ def _batch(device, lens, groups, shared, Hq, Hkv, D, seed=0, extra_rows=8):
     return q, kc, vc, r2t, pool, seq
 
 
-def _run(device, q, kc, vc, r2t, pool, seq, Hq, Hkv, D, suffix_splits=1, min_shared=128):
+def _run(device, q, kc, vc, r2t, pool, seq, Hq, Hkv, D, min_shared=128):
     K = _k()
     B = q.shape[0]
-    ws = K.CascadeWorkspace(B, Hq, D, r2t.shape[1], suffix_splits, device)
+    ws = K.CascadeWorkspace(B, Hq, D, r2t.shape[1], device)
     r2t_d, pool_d, seq_d = r2t.to(device), pool.to(device), seq.to(device)
     K.cascade_plan(ws, r2t_d, pool_d, seq_d, Hq, Hkv, min_shared)
     out = torch.empty((B, Hq, D), dtype=BF, device=device)
@@ -77,14 +77,17 @@ def test_plan_groups_the_bench_pattern(device):
         rows = plan["member_rows"][16 * gi: 16 * gi + 16]
         assert rows == sorted(rows) and {groups[r] for r in rows} == {gi}
     assert plan["req_shared"] == [896] * B
-    assert plan["n_items"] == 4 * 7 and len(set(plan["items"])) == 28
+    assert plan["n_shared_items"] == 4 * 7 and len(set(plan["items"])) == 28     # 16 members x 4 heads = one 64-row item
+    # private part: tokens [896, len) of every request in 128-token chunks, slots behind the 7 shared ones
+    want = sorted((b, 7 + j, 896 + 128 * j, min(128, lens[b] - 896 - 128 * j)) for b in range(B) for j in range(2))
+    assert sorted(plan["private_items"]) == want and plan["n_items"] == 28 + len(want)
     _check(out, q, kc, vc, r2t, pool, seq, D)
 
 
 @pytest.mark.parametrize("Hq,Hkv,D", [(32, 8, 128), (8, 1, 128), (14, 2, 64), (16, 4, 128), (4, 4, 64)])
 def test_cascade_matches_oracle_mixed_batch(device, Hq, Hkv, D):
     """Groups of different sizes / shared lengths, singletons, a too-short share, ragged suffixes,
-    a group whose members share DIFFERENT lengths with the leader (min wins), > 32 members (2 row tiles)."""
+    a group whose members share DIFFERENT lengths with the leader (min wins), 40 members (several row tiles)."""
     lens, groups, shared = [], [], {}
     def add(n, gid, ln):
         for i in range(n):
@@ -99,11 +102,12 @@ def test_cascade_matches_oracle_mixed_batch(device, Hq, Hkv, D):
     q, kc, vc, r2t, pool, seq = _batch(device, lens, groups, shared, Hq, Hkv, D, seed=Hq + D)
     # make one member of group 0 diverge earlier than the others
     r2t[3, 300:512] = r2t[4, 600:812]
-    out, plan = _run(device, q, kc, vc, r2t, pool, seq, Hq, Hkv, D, suffix_splits=2)
+    out, plan = _run(device, q, kc, vc, r2t, pool, seq, Hq, Hkv, D)
     assert plan["n_groups"] == 3
     assert plan["group_kvlen"] == [256, 192, 896]          # 300 -> 256, 200 -> 192, 899 -> 896
-    tiles_g1 = (40 + (128 // (Hq // Hkv)) - 1) // (128 // (Hq // Hkv))
-    assert plan["n_items"] == 2 * 1 + 2 * tiles_g1 + 7 * 1
+    mpi = 64 // (Hq // Hkv)                     # members per item: 64 (member, head) rows per workgroup
+    tiles = lambda members: (members + mpi - 1) // mpi
+    assert plan["n_shared_items"] == 2 * tiles(3) + 2 * tiles(40) + 7 * tiles(2)
     _check(out, q, kc, vc, r2t, pool, seq, D)
 
 
@@ -112,8 +116,9 @@ def test_cascade_without_sharing_equals_plain_decode(device):
     Hq, Hkv, D = 32, 8, 128
     lens = [517, 64, 1, 129, 1000, 33, 257]
     q, kc, vc, r2t, pool, seq = _batch(device, lens, [-1] * len(lens), {}, Hq, Hkv, D, seed=3)
-    out, plan = _run(device, q, kc, vc, r2t, pool, seq, Hq, Hkv, D, suffix_splits=2)
-    assert plan["n_groups"] == 0 and plan["n_items"] == 0 and plan["req_shared"] == [0] * len(lens)
+    out, plan = _run(device, q, kc, vc, r2t, pool, seq, Hq, Hkv, D)
+    assert plan["n_groups"] == 0 and plan["n_shared_items"] == 0 and plan["req_shared"] == [0] * len(lens)
+    assert plan["n_items"] == sum((ln + 127) // 128 for ln in lens)
     _check(out, q, kc, vc, r2t, pool, seq, D)
     plain = torch.empty_like(q, device=device)
     K.decode_attention(q.to(device), kc.to(device), vc.to(device), plain, r2t.to(device), pool.to(device), seq.to(device),
@@ -132,7 +137,7 @@ def test_cascade_plan_replans_every_step(device):
         lens = [700 + 5 * i for i in range(B)]
         q, kc, vc, r2t, pool, seq = _batch(device, lens, groups, shared, Hq, Hkv, D, seed=step)
         if ws is None:
-            ws = K.CascadeWorkspace(B, Hq, D, r2t.shape[1] + 64, 1, device)
+            ws = K.CascadeWorkspace(B, Hq, D, r2t.shape[1] + 64, device)
         r2t_d, pool_d, seq_d = r2t.to(device), pool.to(device), seq.to(device)
         K.cascade_plan(ws, r2t_d, pool_d, seq_d, Hq, Hkv)
         out = torch.empty((B, Hq, D), dtype=BF, device=device)
