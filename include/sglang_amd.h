@@ -231,7 +231,9 @@ int64_t sgl_amd_skinny_gemm_slab_floats(int64_t row_blocks, int64_t N, int split
  * [splits, M, N] to ws_partials (sgl_amd_wstream_gemm_workspace_floats) and a combine kernel sums
  * them in split order (deterministic) and applies `epilogue`:
  *   0: y[M,N]   = bf16(acc + bias)                         (bias may be NULL; also valid with 1 split)
- *   1: y[M,N/2] = silu_and_mul of the [gate | up] columns  (srt/layers/activation.py:141-143 rounding)
+ *   1: y[M,N/2] = silu_and_mul of the [gate | up] columns  (srt/layers/activation.py:141-143 rounding);
+ *      with num_k_splits == 1 it runs in the GEMM's own epilogue (waves_per_group 2..4, each wave owns a
+ *      gate tile and its up tile; no workspace, no second launch)
  *   2: h = bf16(acc + bias); residual += h (bf16, in place); y = RMSNorm(residual) * norm_weight
  *      (srt/layers/layernorm.py:786-820 forward_native with residual). */
 int sgl_amd_wstream_gemm(const void* x, const void* w, const void* bias, void* y, int64_t M, int64_t N,
@@ -239,6 +241,19 @@ int sgl_amd_wstream_gemm(const void* x, const void* w, const void* bias, void* y
                          int epilogue, void* residual, int64_t residual_row_stride,
                          const void* norm_weight, float eps, int waves_per_group, int num_k_splits,
                          void* ws_partials, void* stream);
+/* qkv_proj + neox rotary embedding + KV-pool store for a decode batch, as one GEMM + combine pair:
+ * q_out[M, Hq*D] = rope(x . w_q^T + b), k_cache[cache_loc[m]] = rope(x . w_k^T + b), v_cache[...] = x . w_v^T + b,
+ * with the rounding points of QKVParallelLinear -> RotaryEmbedding.forward_native -> set_kv_buffer
+ * (srt/layers/linear.py:1596, rotary_embedding/utils.py:49-57, base.py:385-417).  w_qkv is [(Hq+2Hkv)*D, K]
+ * (q rows, k rows, v rows); cos_sin_cache [max_pos, D] = cos | sin halves, bf16 or fp32; ws_partials holds
+ * sgl_amd_wstream_gemm_workspace_floats(M, (Hq+2Hkv)*D, num_k_splits) floats (always needed). */
+int sgl_amd_wstream_qkv_rope(const void* x, const void* w_qkv, const void* bias, void* q_out, int64_t M,
+                             int64_t K, int num_q_heads, int num_kv_heads, int head_dim,
+                             int64_t x_row_stride, int64_t w_row_stride, int64_t q_row_stride,
+                             const int64_t* positions, const void* cos_sin_cache, int cache_is_f32,
+                             int64_t rotary_dim, void* k_cache, void* v_cache, const int64_t* cache_loc,
+                             int64_t cache_row_stride, int waves_per_group, int num_k_splits,
+                             void* ws_partials, void* stream);
 int sgl_amd_wstream_gemm_max_rows(void);
 int64_t sgl_amd_wstream_gemm_workspace_floats(int64_t M, int64_t N, int num_k_splits);
 /* Grouped GEMM over moe_align_block_size output: for every row block b < num_tokens_post_padded/block_m

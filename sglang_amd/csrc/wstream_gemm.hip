@@ -77,14 +77,11 @@ __device__ __forceinline__ u32x4_t lds_rd(uint32_t addr) {
   return v;
 }
 
-// s_waitcnt lgkmcnt(N) that the consumers of (a, b[0..MT)) cannot be scheduled across
-template <int N, int MT>
-__device__ __forceinline__ void wait_lgkm(u32x4_t& a, u32x4_t (&b)[MT]) {
-  if constexpr (MT == 1) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b[0]) : "n"(N));
-  else if constexpr (MT == 2) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b[0]), "+v"(b[1]) : "n"(N));
-  else if constexpr (MT == 3) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]) : "n"(N));
-  else asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N));
-}
+// s_waitcnt lgkmcnt(N), then pin every fragment behind it: volatile asm statements keep their order, and a
+// consumer of `v` depends on the empty asm that "rewrites" it, so it cannot be scheduled above the wait.
+template <int N>
+__device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N)); }
+__device__ __forceinline__ void pin(u32x4_t& v) { asm volatile("" : "+v"(v)); }
 
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -101,19 +98,22 @@ __device__ __forceinline__ void wait_chunks(int k) {
 }
 
 // ring depth: as many chunk slots as fit the 160 KiB LDS (1 KiB is the dummy landing zone), at most 6
-constexpr int ring_depth(int mt, int nw) {
-  const int slot = nw * 4096 + mt * 4 * 1024;
+constexpr int ring_depth(int mt, int nw, int tpw) {
+  const int slot = nw * tpw * 4096 + mt * 4 * 1024;
   const int d = (160 * 1024 - 1024) / slot;
   return d > 6 ? 6 : d;
 }
 
-template <int MT, int NW>
+// TPW = 16-row weight tiles per wave.  TPW == 2 is the silu_and_mul form: the wave owns gate tile t and up
+// tile t + ntiles/2 and writes y[m, 16 t ..] = silu(gate) * up (no partials, no second launch).
+template <int MT, int NW, int TPW>
 __global__ __launch_bounds__(64 * NW, 1) void wstream_gemm_kernel(WsParams p) {
-  constexpr int PD = ring_depth(MT, NW);
+  constexpr int PD = ring_depth(MT, NW, TPW);
   constexpr int XPIECES = MT * 4;                       // 1 KiB pieces (4 rows x 256 B) of an activation chunk
   constexpr int XP = (XPIECES + NW - 1) / NW;           // pieces each wave fetches (surplus -> dummy slot)
-  constexpr int LPC = kKSteps + XP;                     // DMA instructions per wave per chunk
-  constexpr int WCH = NW * 4096;                        // weight bytes per chunk (4 KiB per wave)
+  constexpr int LPC = TPW * kKSteps + XP;               // DMA instructions per wave per chunk
+  constexpr int WWAVE = TPW * 4096;                     // weight bytes per wave per chunk
+  constexpr int WCH = NW * WWAVE;                       // weight bytes per chunk
   constexpr int CH = WCH + XPIECES * 1024;              // ring slot: [weights of wave 0..NW) | activations]
   static_assert(PD >= 3 && PD * CH + 1024 <= 160 * 1024, "LDS ring does not fit");
   static_assert((PD - 2) * LPC < 64, "vmcnt range");
@@ -122,8 +122,9 @@ __global__ __launch_bounds__(64 * NW, 1) void wstream_gemm_kernel(WsParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, g = lane >> 4;
+  const int wtiles = p.ntiles / TPW;                    // tiles a wave index ranges over
   const int tile = blockIdx.x * NW + wid;
-  const bool active = tile < p.ntiles;
+  const bool active = tile < wtiles;
   const int split = blockIdx.y;
   const int nch = p.K / kKC;
   const int cb = static_cast<int>(static_cast<int64_t>(split) * nch / p.splits);
@@ -134,13 +135,15 @@ __global__ __launch_bounds__(64 * NW, 1) void wstream_gemm_kernel(WsParams p) {
   // fetches global slot s ^ (row & 15): the XOR swizzle that makes the fragment reads conflict-free
   // is applied on the global side, each row's 256 B still move as two whole cache lines.
   const int q4 = lane >> 4, s16 = lane & 15;
-  const uint16_t* wsrc[kKSteps];
+  const uint16_t* wsrc[TPW][kKSteps];
 #pragma unroll
-  for (int j = 0; j < kKSteps; ++j) {
-    const int row = 4 * j + q4;
-    wsrc[j] = p.w + (static_cast<int64_t>(active ? tile : p.ntiles - 1) * 16 + row) * p.w_stride +
-              ((s16 ^ row) & 15) * 8 + static_cast<int64_t>(cb) * kKC;
-  }
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int j = 0; j < kKSteps; ++j) {
+      const int row = 4 * j + q4;
+      wsrc[t][j] = p.w + (static_cast<int64_t>((active ? tile : wtiles - 1) + t * wtiles) * 16 + row) * p.w_stride +
+                   ((s16 ^ row) & 15) * 8 + static_cast<int64_t>(cb) * kKC;
+    }
   const uint16_t* xsrc[XP];
   int xoff[XP];                                          // wave-uniform LDS offset inside a ring slot
 #pragma unroll
@@ -157,8 +160,10 @@ __global__ __launch_bounds__(64 * NW, 1) void wstream_gemm_kernel(WsParams p) {
     const int koff = c_rel * kKC;
     const int base = slot * CH;
 #pragma unroll
-    for (int j = 0; j < kKSteps; ++j)
-      dma16<2>(wsrc[j] + koff, (lds_ptr_t)(ring3 + base + wid * 4096 + j * 1024));
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+      for (int j = 0; j < kKSteps; ++j)
+        dma16<2>(wsrc[t][j] + koff, (lds_ptr_t)(ring3 + base + wid * WWAVE + t * 4096 + j * 1024));
 #pragma unroll
     for (int i = 0; i < XP; ++i) {
       const int off = xoff[i] >= 0 ? base + xoff[i] : PD * CH;
@@ -172,13 +177,16 @@ __global__ __launch_bounds__(64 * NW, 1) void wstream_gemm_kernel(WsParams p) {
 #pragma unroll
   for (int kk = 0; kk < kKSteps; ++kk) foff[kk] = r16 * 256 + (((kk * 4 + g) ^ r16) & 15) * 16;
 
-  f32x4_t acc[MT];
+  f32x4_t acc[TPW][MT];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[t][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  auto read_frags = [&](uint32_t slot_addr, int kk, u32x4_t& a, u32x4_t (&b)[MT]) {
+  auto read_frags = [&](uint32_t slot_addr, int kk, u32x4_t (&a)[TPW], u32x4_t (&b)[MT]) {
     const uint32_t ad = slot_addr + foff[kk];
-    a = lds_rd<0>(ad + wid * 4096);
+    a[0] = lds_rd<0>(ad + wid * WWAVE);
+    if constexpr (TPW > 1) a[1] = lds_rd<4096>(ad + wid * WWAVE);
     b[0] = lds_rd<WCH>(ad);
     if constexpr (MT > 1) b[1] = lds_rd<WCH + 4096>(ad);
     if constexpr (MT > 2) b[2] = lds_rd<WCH + 8192>(ad);
@@ -186,21 +194,27 @@ __global__ __launch_bounds__(64 * NW, 1) void wstream_gemm_kernel(WsParams p) {
   };
   auto compute = [&](int slot) {
     const uint32_t slot_addr = ring_addr + slot * CH;
-    u32x4_t a[2], b[2][MT];
+    u32x4_t a[2][TPW], b[2][MT];
     read_frags(slot_addr, 0, a[0], b[0]);
 #pragma unroll
     for (int kk = 0; kk < kKSteps; ++kk) {
       const int cur = kk & 1;
       if (kk + 1 < kKSteps) {
         read_frags(slot_addr, kk + 1, a[cur ^ 1], b[cur ^ 1]);
-        wait_lgkm<MT + 1, MT>(a[cur], b[cur]);
+        wait_lgkm<MT + TPW>();
       } else {
-        wait_lgkm<0, MT>(a[cur], b[cur]);
+        wait_lgkm<0>();
       }
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[cur]),
-                                                          __builtin_bit_cast(bf16x8_t, b[cur][mt]), acc[mt], 0, 0, 0);
+      for (int t = 0; t < TPW; ++t) pin(a[cur][t]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) pin(b[cur][mt]);
+#pragma unroll
+      for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[cur][t]),
+                                                               __builtin_bit_cast(bf16x8_t, b[cur][mt]), acc[t][mt], 0, 0, 0);
     }
   };
 
@@ -223,28 +237,49 @@ __global__ __launch_bounds__(64 * NW, 1) void wstream_gemm_kernel(WsParams p) {
   if (!active) return;
   // lane holds C[m = 16 mt + r16][n = 16 tile + 4 g + r]
   const int n0 = tile * 16 + g * 4;
-  if (p.part) {
-    float* base = p.part + static_cast<int64_t>(split) * p.M * p.N;
+  if constexpr (TPW == 2) {
+    // linear -> bf16, silu -> bf16, product -> bf16 (activation.py:141-143)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int m = mt * 16 + r16;
-      if (m < p.M) *reinterpret_cast<f32x4_t*>(base + static_cast<int64_t>(m) * p.N + n0) = acc[mt];
+      if (m >= p.M) continue;
+      float o[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float gb = rbf(acc[0][mt][r]);
+        const float sl = rbf(gb / (1.0f + expf(-gb)));
+        o[r] = sl * rbf(acc[1][mt][r]);
+      }
+      uint2 w2;
+      w2.x = pack_bf2(o[0], o[1]);
+      w2.y = pack_bf2(o[2], o[3]);
+      *reinterpret_cast<uint2*>(p.y + static_cast<int64_t>(m) * p.y_stride + n0) = w2;
     }
     return;
-  }
-  float b4[4] = {0.f, 0.f, 0.f, 0.f};
-  if (p.bias) {
+  } else {
+    if (p.part) {
+      float* base = p.part + static_cast<int64_t>(split) * p.M * p.N;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) b4[r] = bf2f(p.bias[n0 + r]);
-  }
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m = mt * 16 + r16;
+        if (m < p.M) *reinterpret_cast<f32x4_t*>(base + static_cast<int64_t>(m) * p.N + n0) = acc[0][mt];
+      }
+      return;
+    }
+    float b4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int m = mt * 16 + r16;
-    if (m >= p.M) continue;
-    uint2 w2;
-    w2.x = pack_bf2(acc[mt][0] + b4[0], acc[mt][1] + b4[1]);
-    w2.y = pack_bf2(acc[mt][2] + b4[2], acc[mt][3] + b4[3]);
-    *reinterpret_cast<uint2*>(p.y + static_cast<int64_t>(m) * p.y_stride + n0) = w2;
+      for (int r = 0; r < 4; ++r) b4[r] = bf2f(p.bias[n0 + r]);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = mt * 16 + r16;
+      if (m >= p.M) continue;
+      uint2 w2;
+      w2.x = pack_bf2(acc[0][mt][0] + b4[0], acc[0][mt][1] + b4[1]);
+      w2.y = pack_bf2(acc[0][mt][2] + b4[2], acc[0][mt][3] + b4[3]);
+      *reinterpret_cast<uint2*>(p.y + static_cast<int64_t>(m) * p.y_stride + n0) = w2;
+    }
   }
 }
 
@@ -359,20 +394,102 @@ __global__ __launch_bounds__(kNormThreads) void wstream_combine_norm_kernel(Comb
   }
 }
 
-template <int MT, int NW>
+// ---------------------------------------------------------------------------------------------
+// QKV combine: split-K sum + bias -> bf16 (the qkv_proj output), neox rotary embedding on the q and k
+// heads with the torch-native rounding points (rotary_embedding/utils.py:49-57: cos/sin in bf16,
+// o1 = bf16(bf16(x1 c) - bf16(x2 s)), o2 = bf16(bf16(x2 c) + bf16(x1 s))), q written to q_out, the
+// rotated k row and the v row written straight into the token->KV pool at cache_loc
+// (base.py:385-417 fused_set_kv_buffer).  One workgroup per token.
+// ---------------------------------------------------------------------------------------------
+struct RopeParams {
+  const float* part;            // [splits, M, N]
+  const uint16_t* bias;         // optional [N]
+  uint16_t* q_out;              // [M, Hq * D]
+  uint16_t* k_cache;            // [slots, Hkv * D]
+  uint16_t* v_cache;
+  const int64_t* positions;     // [M]
+  const int64_t* cache_loc;     // [M]
+  const void* cos_sin;          // [max_pos, D]  cos | sin halves, bf16 or fp32
+  int64_t q_stride, cache_row_stride;
+  int M, N, splits, num_q_heads, num_kv_heads, head_dim, cache_f32;
+};
+
+__global__ __launch_bounds__(256) void wstream_combine_rope_kernel(RopeParams p) {
+  const int m = blockIdx.x;
+  const int D = p.head_dim, half = D >> 1;
+  const int64_t ss = static_cast<int64_t>(p.M) * p.N;
+  const float* row = p.part + static_cast<int64_t>(m) * p.N;
+  const int64_t pos = p.positions[m];
+  const int64_t slot = p.cache_loc[m];
+  const int qk_heads = p.num_q_heads + p.num_kv_heads;
+  const int per_head = half >> 2;                       // 4-wide pair chunks per head
+  for (int it = threadIdx.x; it < qk_heads * per_head; it += 256) {
+    const int h = it / per_head, i = (it - h * per_head) * 4;
+    const int n1 = h * D + i, n2 = n1 + half;
+    f32x4_t a = sum_splits(row + n1, ss, p.splits);
+    f32x4_t b = sum_splits(row + n2, ss, p.splits);
+    float c[4], sn[4];
+    if (p.cache_f32) {
+      const float* cs = static_cast<const float*>(p.cos_sin) + pos * D;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { c[r] = rbf(cs[i + r]); sn[r] = rbf(cs[half + i + r]); }
+    } else {
+      const uint16_t* cs = static_cast<const uint16_t*>(p.cos_sin) + pos * D;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { c[r] = bf2f(cs[i + r]); sn[r] = bf2f(cs[half + i + r]); }
+    }
+    float o1[4], o2[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float x1 = a[r], x2 = b[r];
+      if (p.bias) { x1 += bf2f(p.bias[n1 + r]); x2 += bf2f(p.bias[n2 + r]); }
+      x1 = rbf(x1); x2 = rbf(x2);
+      o1[r] = rbf(x1 * c[r]) - rbf(x2 * sn[r]);
+      o2[r] = rbf(x2 * c[r]) + rbf(x1 * sn[r]);
+    }
+    uint16_t* dst = h < p.num_q_heads ? p.q_out + static_cast<int64_t>(m) * p.q_stride + n1
+                                      : p.k_cache + slot * p.cache_row_stride + (h - p.num_q_heads) * D + i;
+    uint2 w1, w2;
+    w1.x = pack_bf2(o1[0], o1[1]); w1.y = pack_bf2(o1[2], o1[3]);
+    w2.x = pack_bf2(o2[0], o2[1]); w2.y = pack_bf2(o2[2], o2[3]);
+    *reinterpret_cast<uint2*>(dst) = w1;
+    *reinterpret_cast<uint2*>(dst + half) = w2;
+  }
+  const int v0 = qk_heads * D, vn = p.num_kv_heads * D;
+  for (int e = threadIdx.x * 4; e < vn; e += 256 * 4) {
+    f32x4_t a = sum_splits(row + v0 + e, ss, p.splits);
+    if (p.bias) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a[r] += bf2f(p.bias[v0 + e + r]);
+    }
+    uint2 w;
+    w.x = pack_bf2(a[0], a[1]); w.y = pack_bf2(a[2], a[3]);
+    *reinterpret_cast<uint2*>(p.v_cache + slot * p.cache_row_stride + e) = w;
+  }
+}
+
+template <int MT, int NW, int TPW>
 void launch_main(const WsParams& p, hipStream_t st) {
-  dim3 grid((p.ntiles + NW - 1) / NW, p.splits);
-  hipLaunchKernelGGL((wstream_gemm_kernel<MT, NW>), grid, dim3(64 * NW), 0, st, p);
+  dim3 grid((p.ntiles / TPW + NW - 1) / NW, p.splits);
+  hipLaunchKernelGGL((wstream_gemm_kernel<MT, NW, TPW>), grid, dim3(64 * NW), 0, st, p);
 }
 
 template <int MT>
-int launch_nw(const WsParams& p, int nw, hipStream_t st) {
+int launch_nw(const WsParams& p, int nw, bool fused_silu, hipStream_t st) {
+  if (fused_silu) {                                   // two tiles per wave: half the waves for the same LDS ring
+    switch (nw) {
+      case 2: launch_main<MT, 2, 2>(p, st); return 0;
+      case 3: launch_main<MT, 3, 2>(p, st); return 0;
+      case 4: launch_main<MT, 4, 2>(p, st); return 0;
+      default: return -1;
+    }
+  }
   switch (nw) {
-    case 4: launch_main<MT, 4>(p, st); return 0;
-    case 5: launch_main<MT, 5>(p, st); return 0;
-    case 6: launch_main<MT, 6>(p, st); return 0;
-    case 7: launch_main<MT, 7>(p, st); return 0;
-    case 8: launch_main<MT, 8>(p, st); return 0;
+    case 4: launch_main<MT, 4, 1>(p, st); return 0;
+    case 5: launch_main<MT, 5, 1>(p, st); return 0;
+    case 6: launch_main<MT, 6, 1>(p, st); return 0;
+    case 7: launch_main<MT, 7, 1>(p, st); return 0;
+    case 8: launch_main<MT, 8, 1>(p, st); return 0;
     default: return -1;
   }
 }
@@ -387,62 +504,98 @@ int64_t sgl_amd_wstream_gemm_workspace_floats(int64_t M, int64_t N, int num_k_sp
   return static_cast<int64_t>(num_k_splits) * M * N;   /* needed when num_k_splits > 1 or epilogue != 0 */
 }
 
+// shared by the two entry points: validates the GEMM part and launches the main kernel
+static int wstream_launch_main(const char* who, const void* x, const void* w, const void* bias, void* y, int64_t M, int64_t N,
+                               int64_t K, int64_t x_row_stride, int64_t w_row_stride, int64_t y_row_stride, bool fused_silu,
+                               bool to_partials, int waves_per_group, int num_k_splits, void* ws_partials, hipStream_t st) {
+  SGL_CHECK_ARG(M >= 1 && M <= 64, "%s: M=%lld rows (supported: 1..64)", who, (long long)M);
+  SGL_CHECK_ARG(N > 0 && N % 16 == 0 && K >= kKC && K % kKC == 0,
+                "%s: need N %% 16 == 0 and K %% %d == 0 (got N=%lld K=%lld)", who, kKC, (long long)N, (long long)K);
+  SGL_CHECK_ARG(x_row_stride % 8 == 0 && w_row_stride % 8 == 0 && y_row_stride % 4 == 0,
+                "%s: row strides must keep 16-byte (x, w) / 8-byte (y) alignment", who);
+  SGL_CHECK_ARG(fused_silu ? (waves_per_group >= 2 && waves_per_group <= 4) : (waves_per_group >= 4 && waves_per_group <= 8),
+                "%s: waves_per_group must be 4..8 (2..4 for the one-pass silu_and_mul form), got %d", who, waves_per_group);
+  SGL_CHECK_ARG(num_k_splits >= 1 && num_k_splits <= K / kKC, "%s: bad split count %d", who, num_k_splits);
+  SGL_CHECK_ARG(!to_partials || ws_partials, "%s: needs the fp32 partials workspace", who);
+  WsParams p{};
+  p.x = static_cast<const uint16_t*>(x);
+  p.w = static_cast<const uint16_t*>(w);
+  p.bias = to_partials ? nullptr : static_cast<const uint16_t*>(bias);
+  p.y = static_cast<uint16_t*>(y);
+  p.part = to_partials ? static_cast<float*>(ws_partials) : nullptr;
+  p.x_stride = x_row_stride; p.w_stride = w_row_stride; p.y_stride = y_row_stride;
+  p.M = static_cast<int>(M); p.N = static_cast<int>(N); p.K = static_cast<int>(K);
+  p.splits = num_k_splits; p.ntiles = static_cast<int>(N / 16);
+  int rc;
+  switch (static_cast<int>((M + 15) / 16)) {
+    case 1: rc = launch_nw<1>(p, waves_per_group, fused_silu, st); break;
+    case 2: rc = launch_nw<2>(p, waves_per_group, fused_silu, st); break;
+    case 3: rc = launch_nw<3>(p, waves_per_group, fused_silu, st); break;
+    default: rc = launch_nw<4>(p, waves_per_group, fused_silu, st); break;
+  }
+  SGL_CHECK_ARG(rc == 0, "%s: unsupported configuration", who);
+  return 0;
+}
+
 int sgl_amd_wstream_gemm(const void* x, const void* w, const void* bias, void* y, int64_t M, int64_t N, int64_t K,
                          int64_t x_row_stride, int64_t w_row_stride, int64_t y_row_stride, int epilogue,
                          void* residual, int64_t residual_row_stride, const void* norm_weight, float eps,
                          int waves_per_group, int num_k_splits, void* ws_partials, void* stream) {
   SGL_CLEAR_STALE_ERROR();
-  SGL_CHECK_ARG(M >= 0 && M <= 64, "wstream_gemm: M=%lld rows (supported: <= 64)", (long long)M);
-  SGL_CHECK_ARG(N > 0 && N % 16 == 0 && K >= kKC && K % kKC == 0,
-                "wstream_gemm: need N %% 16 == 0 and K %% %d == 0 (got N=%lld K=%lld)", kKC, (long long)N, (long long)K);
-  SGL_CHECK_ARG(x_row_stride % 8 == 0 && w_row_stride % 8 == 0 && y_row_stride % 4 == 0,
-                "wstream_gemm: row strides must keep 16-byte (x, w) / 8-byte (y) alignment");
-  SGL_CHECK_ARG(waves_per_group >= 4 && waves_per_group <= 8,
-                "wstream_gemm: waves_per_group must be 4..8 (got %d)", waves_per_group);
-  SGL_CHECK_ARG(num_k_splits >= 1 && num_k_splits <= K / kKC, "wstream_gemm: bad split count %d", num_k_splits);
+  if (M == 0) return 0;
   SGL_CHECK_ARG(epilogue >= 0 && epilogue <= 2, "wstream_gemm: epilogue must be 0 (bias), 1 (silu_and_mul) or 2 (add_rmsnorm)");
-  SGL_CHECK_ARG(epilogue == 0 || ws_partials,
-                "wstream_gemm: the fused epilogues run in the combine kernel (need the partials workspace, even with 1 split)");
-  SGL_CHECK_ARG(num_k_splits == 1 || ws_partials, "wstream_gemm: split-K needs the partials workspace");
+  const bool fused_silu = epilogue == 1 && num_k_splits == 1 && N % 32 == 0 && !bias;   // silu(gate)*up in the GEMM's own epilogue
+  const bool combine = !fused_silu && (num_k_splits > 1 || epilogue != 0);
   SGL_CHECK_ARG(epilogue != 1 || N % 8 == 0, "wstream_gemm: silu_and_mul needs N %% 8 == 0");
   SGL_CHECK_ARG(epilogue != 2 || (residual && norm_weight && N <= kNormThreads * kNormMaxVec * 4 && residual_row_stride % 4 == 0),
                 "wstream_gemm: add_rmsnorm needs residual, norm_weight and N <= %d", kNormThreads * kNormMaxVec * 4);
-  if (M == 0) return 0;
   hipStream_t st = as_stream(stream);
-  WsParams p{};
-  p.x = static_cast<const uint16_t*>(x);
-  p.w = static_cast<const uint16_t*>(w);
-  const bool combine = num_k_splits > 1 || epilogue != 0;
-  p.bias = combine ? nullptr : static_cast<const uint16_t*>(bias);
-  p.y = static_cast<uint16_t*>(y);
-  p.part = combine ? static_cast<float*>(ws_partials) : nullptr;
-  p.x_stride = x_row_stride; p.w_stride = w_row_stride; p.y_stride = y_row_stride;
-  p.M = static_cast<int>(M); p.N = static_cast<int>(N); p.K = static_cast<int>(K);
-  p.splits = num_k_splits; p.ntiles = static_cast<int>(N / 16);
-  const int mt = static_cast<int>((M + 15) / 16);
-  int rc;
-  switch (mt) {
-    case 1: rc = launch_nw<1>(p, waves_per_group, st); break;
-    case 2: rc = launch_nw<2>(p, waves_per_group, st); break;
-    case 3: rc = launch_nw<3>(p, waves_per_group, st); break;
-    default: rc = launch_nw<4>(p, waves_per_group, st); break;
-  }
-  SGL_CHECK_ARG(rc == 0, "wstream_gemm: unsupported configuration");
+  if (int rc = wstream_launch_main("wstream_gemm", x, w, bias, y, M, N, K, x_row_stride, w_row_stride, y_row_stride, fused_silu,
+                                   combine, waves_per_group, num_k_splits, ws_partials, st))
+    return rc;
   if (combine) {
     CombineParams c{};
-    c.part = p.part; c.bias = static_cast<const uint16_t*>(bias); c.y = p.y;
+    c.part = static_cast<const float*>(ws_partials); c.bias = static_cast<const uint16_t*>(bias); c.y = static_cast<uint16_t*>(y);
     c.residual = static_cast<uint16_t*>(residual); c.norm_w = static_cast<const uint16_t*>(norm_weight);
     c.y_stride = y_row_stride; c.res_stride = residual_row_stride;
-    c.M = p.M; c.N = p.N; c.splits = num_k_splits; c.eps = eps;
+    c.M = static_cast<int>(M); c.N = static_cast<int>(N); c.splits = num_k_splits; c.eps = eps;
     if (epilogue == 0) {
-      hipLaunchKernelGGL(wstream_combine_kernel, dim3((p.N / 4 + 255) / 256, p.M), dim3(256), 0, st, c);
+      hipLaunchKernelGGL(wstream_combine_kernel, dim3((c.N / 4 + 255) / 256, c.M), dim3(256), 0, st, c);
     } else if (epilogue == 1) {
-      hipLaunchKernelGGL(wstream_combine_silu_kernel, dim3((p.N / 8 + 255) / 256, p.M), dim3(256), 0, st, c);
+      hipLaunchKernelGGL(wstream_combine_silu_kernel, dim3((c.N / 8 + 255) / 256, c.M), dim3(256), 0, st, c);
     } else {
-      hipLaunchKernelGGL(wstream_combine_norm_kernel, dim3(p.M), dim3(kNormThreads), 0, st, c);
+      hipLaunchKernelGGL(wstream_combine_norm_kernel, dim3(c.M), dim3(kNormThreads), 0, st, c);
     }
   }
   SGL_CHECK_LAUNCH("wstream_gemm");
+  return 0;
+}
+
+int sgl_amd_wstream_qkv_rope(const void* x, const void* w_qkv, const void* bias, void* q_out, int64_t M, int64_t K,
+                             int num_q_heads, int num_kv_heads, int head_dim, int64_t x_row_stride, int64_t w_row_stride,
+                             int64_t q_row_stride, const int64_t* positions, const void* cos_sin_cache, int cache_is_f32,
+                             int64_t rotary_dim, void* k_cache, void* v_cache, const int64_t* cache_loc,
+                             int64_t cache_row_stride, int waves_per_group, int num_k_splits, void* ws_partials, void* stream) {
+  SGL_CLEAR_STALE_ERROR();
+  if (M == 0) return 0;
+  SGL_CHECK_ARG(num_q_heads > 0 && num_kv_heads > 0 && head_dim % 16 == 0 && rotary_dim == head_dim,
+                "wstream_qkv_rope: full-head neox rotary only (head_dim %% 16 == 0, rotary_dim == head_dim)");
+  SGL_CHECK_ARG(positions && cos_sin_cache && k_cache && v_cache && cache_loc && q_out, "wstream_qkv_rope: null argument");
+  SGL_CHECK_ARG(q_row_stride % 4 == 0 && cache_row_stride % 4 == 0, "wstream_qkv_rope: q / cache row strides must be multiples of 4 elements");
+  const int64_t N = static_cast<int64_t>(num_q_heads + 2 * num_kv_heads) * head_dim;
+  hipStream_t st = as_stream(stream);
+  if (int rc = wstream_launch_main("wstream_qkv_rope", x, w_qkv, nullptr, nullptr, M, N, K, x_row_stride, w_row_stride, 4, false,
+                                   true, waves_per_group, num_k_splits, ws_partials, st))
+    return rc;
+  RopeParams r{};
+  r.part = static_cast<const float*>(ws_partials); r.bias = static_cast<const uint16_t*>(bias);
+  r.q_out = static_cast<uint16_t*>(q_out); r.k_cache = static_cast<uint16_t*>(k_cache); r.v_cache = static_cast<uint16_t*>(v_cache);
+  r.positions = positions; r.cache_loc = cache_loc; r.cos_sin = cos_sin_cache;
+  r.q_stride = q_row_stride; r.cache_row_stride = cache_row_stride;
+  r.M = static_cast<int>(M); r.N = static_cast<int>(N); r.splits = num_k_splits;
+  r.num_q_heads = num_q_heads; r.num_kv_heads = num_kv_heads; r.head_dim = head_dim; r.cache_f32 = cache_is_f32;
+  hipLaunchKernelGGL(wstream_combine_rope_kernel, dim3(r.M), dim3(256), 0, st, r);
+  SGL_CHECK_LAUNCH("wstream_qkv_rope");
   return 0;
 }
 

@@ -132,13 +132,19 @@ class LlamaMLP(nn.Module):
         self.down_proj = Linear(down.to(device))                            # RowParallelLinear
         self.act_fn = SiluAndMul()
 
+    def gate_up_act(self, x: torch.Tensor) -> torch.Tensor:
+        """act_fn(gate_up_proj(x)); decode batches get silu(gate) * up from the GEMM's own epilogue."""
+        if self.gate_up_proj.streams(x) and self.gate_up_proj.bias is None:
+            return kernels.wstream_gemm(x, self.gate_up_proj.weight.data, epilogue="silu_and_mul")
+        return self.act_fn(self.gate_up_proj(x))
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        x = self.down_proj(self.act_fn(self.gate_up_proj(x)))
+        x = self.down_proj(self.gate_up_act(x))
         return ps.tensor_model_parallel_all_reduce(x)
 
     def forward_fused_norm(self, x: torch.Tensor, residual: torch.Tensor, next_norm: RMSNorm) -> torch.Tensor:
         """TP=1 decode: down_proj + residual add + the NEXT norm in one GEMM + combine pair."""
-        return self.down_proj.forward_add_rmsnorm(self.act_fn(self.gate_up_proj(x)), residual, next_norm)
+        return self.down_proj.forward_add_rmsnorm(self.gate_up_act(x), residual, next_norm)
 
 
 class LlamaAttention(nn.Module):
@@ -185,9 +191,20 @@ class LlamaAttention(nn.Module):
                 fused_norm: Optional[Tuple[torch.Tensor, RMSNorm]] = None) -> torch.Tensor:
         """fused_norm = (residual, norm): TP=1 decode form, o_proj + residual add + norm in one GEMM +
         combine pair (returns the normed activations, residual updated in place)."""
+        pool = forward_batch.token_to_kv_pool
+        if self.qkv_proj.streams(hidden_states) and self.rotary_emb.is_neox_style:
+            # decode batch: qkv GEMM, rope and the KV-row store in one GEMM + combine pair
+            q = kernels.wstream_qkv_rope(hidden_states, self.qkv_proj.weight.data,
+                                         self.qkv_proj.bias.data if self.qkv_proj.bias is not None else None, positions,
+                                         self.rotary_emb.cos_sin_cache, self.num_heads, self.num_kv_heads, self.head_dim,
+                                         pool.get_key_buffer(self.layer_id), pool.get_value_buffer(self.layer_id),
+                                         forward_batch.out_cache_loc)
+            attn_output = self.attn(q, None, None, forward_batch, save_kv_cache=False)
+            if fused_norm is not None:
+                return self.o_proj.forward_add_rmsnorm(attn_output, fused_norm[0], fused_norm[1])
+            return ps.tensor_model_parallel_all_reduce(self.o_proj(attn_output))
         qkv = self.qkv_proj(hidden_states)
         q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
-        pool = forward_batch.token_to_kv_pool
         # rope + KV-row scatter in one kernel (rotary_embedding/base.py:385-417), then attention reads the pool
         self.rotary_emb(positions, q, k, fused_set_kv_buffer_arg=FusedSetKVBufferArg(
             value=v, k_buffer=pool.get_key_buffer(self.layer_id), v_buffer=pool.get_value_buffer(self.layer_id),

@@ -503,23 +503,25 @@ def wstream_supported(M: int, N: int, K: int) -> bool:
 
 
 @functools.lru_cache(maxsize=None)
-def choose_wstream_config(M: int, N: int, K: int, need_combine: bool = False) -> Tuple[int, int]:
+def choose_wstream_config(M: int, N: int, K: int, need_combine: bool = False, fused_silu: bool = False) -> Tuple[int, int]:
     """(waves_per_group, k_splits) for y[M,N] = x . w[N,K]^T.  One workgroup per CU is resident (its
     LDS ring holds the in-flight chunks), so the best grids are whole 256-group rounds.  The cost model
     is fitted to benchmarks/gemm_sweep.py on MI355X: a busy CU streams <= ~24 GB/s, the chip <= ~5.5 TB/s,
     ~2 us of pipeline fill, and split-K pays the fp32 partial round trip plus the combine launch."""
     tiles, nch = N // 16, K // 128
     best = None
-    for nw in (8, 7, 6, 5, 4):
+    if fused_silu:                    # one pass, each wave owns a gate tile and its up tile: no split-K
+        tiles //= 2
+    for nw in ((4, 3, 2) if fused_silu else (8, 7, 6, 5, 4)):
         groups = (tiles + nw - 1) // nw
-        for s in range(1, max(1, min(nch // 2, 32)) + 1):
+        for s in range(1, 2 if fused_silu else max(1, min(nch // 2, 32)) + 1):
             wgs = groups * s
-            wg_bytes = nw * ((nch + s - 1) // s) * 4096
+            wg_bytes = nw * ((nch + s - 1) // s) * (8192 if fused_silu else 4096)
             full, rem = divmod(wgs, _NUM_CUS)
             t = 2.0e-6 + full * _NUM_CUS * wg_bytes / 5.5e12
             if rem:
                 t += rem * wg_bytes / min(5.5e12, rem * 24e9)
-            if s > 1 or need_combine:
+            if s > 1 or (need_combine and not fused_silu):
                 t += 2 * s * M * N * 4 / 4e12 + 2.5e-6
             if best is None or t < best[0]:
                 best = (t, nw, s)
@@ -546,14 +548,47 @@ def wstream_gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] 
         _need(residual is not None and norm_weight is not None and residual.shape == (M, N) and residual.stride(1) == 1
               and residual.dtype == _BF16 and norm_weight.dtype == _BF16, "wstream_gemm: add_rmsnorm needs residual [M,N] and norm_weight")
     if waves_per_group is None or splits is None:
-        nw_auto, s_auto = choose_wstream_config(M, N, K, ep != 0)
+        # silu_and_mul: one pass with two tiles per wave when the caller does not force a split
+        one_pass = ep == 1 and splits in (None, 1) and N % 32 == 0 and bias is None
+        nw_auto, s_auto = choose_wstream_config(M, N, K, ep != 0, one_pass)
     nw = waves_per_group or nw_auto
     s = splits or s_auto
-    ws = _gemm_workspace(x.device, native.lib().sgl_amd_wstream_gemm_workspace_floats(M, N, s)) if (s > 1 or ep) else None
+    one_pass = ep == 1 and s == 1 and N % 32 == 0 and bias is None
+    ws = _gemm_workspace(x.device, native.lib().sgl_amd_wstream_gemm_workspace_floats(M, N, s)) if ((s > 1 or ep) and not one_pass) else None
     native.call("sgl_amd_wstream_gemm", x.data_ptr(), w.data_ptr(), _ptr(bias), out.data_ptr(), M, N, K, x.stride(0),
                 w.stride(0), out.stride(0), ep, _ptr(residual), residual.stride(0) if residual is not None else 0,
                 _ptr(norm_weight), float(eps), nw, s, _ptr(ws), _stream())
     return out
+
+
+def wstream_qkv_rope(x: torch.Tensor, w_qkv: torch.Tensor, bias: Optional[torch.Tensor], positions: torch.Tensor,
+                     cos_sin_cache: torch.Tensor, num_q_heads: int, num_kv_heads: int, head_dim: int,
+                     k_cache: torch.Tensor, v_cache: torch.Tensor, cache_loc: torch.Tensor,
+                     waves_per_group: Optional[int] = None, splits: Optional[int] = None) -> torch.Tensor:
+    """Decode-batch qkv_proj + neox rotary embedding + KV-pool store (one GEMM + combine pair): returns the
+    rotated q [M, Hq*D]; the rotated k rows and the v rows land in k_cache / v_cache at cache_loc."""
+    _dev(x, w_qkv, positions, cos_sin_cache, k_cache, v_cache, cache_loc)
+    M, K = x.shape
+    N = (num_q_heads + 2 * num_kv_heads) * head_dim
+    _need(x.dtype == _BF16 and w_qkv.dtype == _BF16 and w_qkv.shape == (N, K) and x.stride(1) == 1 and w_qkv.stride(1) == 1,
+          "wstream_qkv_rope: x [M,K] / w_qkv [(Hq+2Hkv)*D, K] bf16")
+    _need(positions.dtype == torch.int64 and cache_loc.dtype == torch.int64 and positions.numel() == M and cache_loc.numel() == M,
+          "wstream_qkv_rope: int64 positions / cache_loc of length M")
+    _need(cos_sin_cache.dtype in (_BF16, torch.float32) and cos_sin_cache.is_contiguous() and cos_sin_cache.shape[-1] == head_dim,
+          "wstream_qkv_rope: cos_sin_cache [max_pos, head_dim]")
+    kc, vc = k_cache.view(k_cache.shape[0], -1), v_cache.view(v_cache.shape[0], -1)
+    _need(kc.dtype == _BF16 and vc.dtype == _BF16 and kc.stride(0) == vc.stride(0) and kc.shape[1] == num_kv_heads * head_dim,
+          "wstream_qkv_rope: bf16 KV pool rows of Hkv*D")
+    if waves_per_group is None or splits is None:
+        nw_auto, s_auto = choose_wstream_config(M, N, K, True)
+    nw, s = waves_per_group or nw_auto, splits or s_auto
+    q_out = torch.empty((M, num_q_heads * head_dim), dtype=_BF16, device=x.device)
+    ws = _gemm_workspace(x.device, native.lib().sgl_amd_wstream_gemm_workspace_floats(M, N, s))
+    native.call("sgl_amd_wstream_qkv_rope", x.data_ptr(), w_qkv.data_ptr(), _ptr(bias), q_out.data_ptr(), M, K, num_q_heads,
+                num_kv_heads, head_dim, x.stride(0), w_qkv.stride(0), q_out.stride(0), positions.data_ptr(),
+                cos_sin_cache.data_ptr(), 1 if cos_sin_cache.dtype == torch.float32 else 0, cos_sin_cache.shape[-1],
+                kc.data_ptr(), vc.data_ptr(), cache_loc.data_ptr(), kc.stride(0), nw, s, ws.data_ptr(), _stream())
+    return q_out
 
 
 def moe_grouped_gemm(a: torch.Tensor, w: torch.Tensor, c: torch.Tensor, sorted_token_ids: torch.Tensor,

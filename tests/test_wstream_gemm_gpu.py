@@ -118,3 +118,51 @@ def test_wstream_rejects_unsupported_shapes(device):
         K_.wstream_gemm(x, w)
     with pytest.raises(RuntimeError):
         K_.wstream_gemm(x[:4, :200], w[:, :200])
+
+
+@pytest.mark.parametrize("M", [1, 20, 64])
+@pytest.mark.parametrize("I,K,nw", [(14336, 4096, None), (1792, 1024, 2), (1792, 1024, 3), (4864, 896, 4), (48, 256, None)])
+def test_wstream_one_pass_silu_equals_unfused_ops(device, M, I, K, nw):
+    """splits == 1: silu(gate) * up comes out of the GEMM's own epilogue (two tiles per wave)."""
+    K_ = _k()
+    g = torch.Generator().manual_seed(M + I)
+    x = torch.randn((M, K), generator=g).to(BF).to(device)
+    w = (torch.randn((2 * I, K), generator=g) * 0.03).to(BF).to(device)
+    gate_up = K_.wstream_gemm(x, w, splits=1, waves_per_group=4)          # same K order: bit-identical accumulators
+    want = oo.silu_and_mul(gate_up.cpu())
+    got = K_.wstream_gemm(x, w, epilogue="silu_and_mul", splits=1, waves_per_group=nw).cpu()
+    d = (got.float() - want.float()).abs()
+    assert float((d > 0).float().mean()) < 0.005
+    assert bool((d <= want.float().abs() * 2.0 ** -7 + 1e-6).all())
+
+
+@pytest.mark.parametrize("M", [1, 17, 64])
+@pytest.mark.parametrize("Hq,Hkv,D,K,bias,f32cache", [(32, 8, 128, 4096, False, False), (14, 2, 64, 896, True, False),
+                                                      (8, 2, 64, 256, False, True), (4, 1, 128, 256, True, False)])
+def test_wstream_qkv_rope_store_equals_unfused_ops(device, M, Hq, Hkv, D, K, bias, f32cache):
+    """qkv GEMM + combine(rope, KV store) == linear -> rotary_embedding (forward_native) -> set_kv_buffer."""
+    K_ = _k()
+    g = torch.Generator().manual_seed(M * 7 + Hq)
+    N = (Hq + 2 * Hkv) * D
+    x = torch.randn((M, K), generator=g).to(BF).to(device)
+    w = (torch.randn((N, K), generator=g) * 0.03).to(BF).to(device)
+    b = torch.randn(N, generator=g).to(BF).to(device) if bias else None
+    max_pos = 512
+    cache = oo.cos_sin_cache(oo.rope_inv_freq(D, 10000.0), max_pos)
+    cache = cache if f32cache else cache.to(BF)
+    positions = torch.randint(0, max_pos, (M,), generator=g)
+    slots = 200
+    loc = torch.randperm(slots - 1, generator=g)[:M] + 1
+    kc = torch.zeros((slots, Hkv, D), dtype=BF, device=device)
+    vc = torch.zeros((slots, Hkv, D), dtype=BF, device=device)
+    splits = 2 if K >= 512 else 1
+    qkv = K_.wstream_gemm(x, w, bias=b, splits=splits).cpu()               # same split count: same accumulators
+    q_ref, k_ref, v_ref = qkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1)
+    q_ref, k_ref = oo.rotary_embedding(positions, q_ref.clone(), k_ref.clone(), D, cache.cpu(), True)
+    q = K_.wstream_qkv_rope(x, w, b, positions.to(device), cache.to(device), Hq, Hkv, D, kc, vc, loc.to(device), splits=splits)
+    assert torch.equal(q.cpu(), q_ref.reshape(M, -1)), "rotated q must be bit-exact"
+    assert torch.equal(kc.cpu()[loc], k_ref.reshape(M, Hkv, D)), "rotated k rows in the pool must be bit-exact"
+    assert torch.equal(vc.cpu()[loc], v_ref.reshape(M, Hkv, D))
+    untouched = torch.ones(slots, dtype=torch.bool)
+    untouched[loc] = False
+    assert float(kc.cpu()[untouched].abs().max()) == 0.0 and float(vc.cpu()[untouched].abs().max()) == 0.0
