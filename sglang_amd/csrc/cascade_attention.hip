@@ -257,7 +257,10 @@ __global__ __launch_bounds__(kPlanThreads) void cascade_plan_kernel(
   __shared__ int grp_cnt[kPlanMaxBatch];
   __shared__ int grp_id[kPlanMaxBatch];
   __shared__ int scan[kPlanMaxBatch];
-  __shared__ int n_shared_items;
+  __shared__ int order[kPlanMaxBatch];
+  __shared__ int g_leader[kPlanMaxBatch / 2], g_kv[kPlanMaxBatch / 2], g_first[kPlanMaxBatch / 2], g_tiles[kPlanMaxBatch / 2],
+      g_rows0[kPlanMaxBatch / 2], g_members[kPlanMaxBatch / 2];
+  __shared__ int n_shared_items, n_groups, n_rows;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const CascadePlanView pv = cascade_plan_view(plan, batch, max_items);
   for (int i = tid; i < max_items; i += kPlanThreads) pv.items[8 * i + 3] = 0;   // members == 0: end of list
@@ -276,7 +279,7 @@ __global__ __launch_bounds__(kPlanThreads) void cascade_plan_kernel(
     leader[b] = l;
   }
   __syncthreads();
-  // common prefix with the leader: one wave per request, 256 positions per step (4 loads in flight per row)
+  // common prefix with the leader: one wave per request, 512 positions per step (8 loads in flight per row)
   for (int b = wid; b < batch; b += kPlanThreads / 64) {
     const int l = leader[b];
     int common = 0;
@@ -287,10 +290,10 @@ __global__ __launch_bounds__(kPlanThreads) void cascade_plan_kernel(
       const int ll = seq_lens[l] - 1;
       if (ll < lim) lim = ll;
       common = lim;
-      for (int t0 = 0; t0 < lim; t0 += 256) {
-        int va[4], vb[4];
+      for (int t0 = 0; t0 < lim; t0 += 512) {
+        int va[8], vb[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
           const int t = t0 + 64 * u + lane;
           const int tc = t < lim ? t : lim - 1;
           va[u] = ra[tc];
@@ -298,7 +301,7 @@ __global__ __launch_bounds__(kPlanThreads) void cascade_plan_kernel(
         }
         int first = 0x7fffffff;
 #pragma unroll
-        for (int u = 3; u >= 0; --u) {
+        for (int u = 7; u >= 0; --u) {
           const int t = t0 + 64 * u + lane;
           const unsigned long long mm = __ballot(t < lim && va[u] != vb[u]);
           if (mm != 0ull) first = t0 + 64 * u + __ffsll(static_cast<long long>(mm)) - 1;
@@ -312,13 +315,10 @@ __global__ __launch_bounds__(kPlanThreads) void cascade_plan_kernel(
     }
   }
   __syncthreads();
+  // ---- grouping decisions: one thread, LDS only (global round trips here would serialise) ----
   if (tid == 0) {
     int ng = 0, rows = 0, n_items = 0;
-    pv.group_qo[0] = 0;
-    for (int b = 0; b < batch; ++b) {
-      grp_id[b] = -1;
-      pv.req_shared[b] = 0;
-    }
+    for (int b = 0; b < batch; ++b) grp_id[b] = -1;
     for (int b = 0; b < batch; ++b) {
       if (leader[b] != b || grp_cnt[b] < 1) continue;
       int kv = grp_min[b] / kv_tile * kv_tile;
@@ -330,49 +330,66 @@ __global__ __launch_bounds__(kPlanThreads) void cascade_plan_kernel(
       // plan full (leave room for the private chunks of every request): the rest stay ungrouped
       if (n_items + tiles * chunks > max_items / 2) continue;
       grp_id[b] = ng;
-      pv.group_pool_row[ng] = static_cast<int32_t>(req_pool_indices[b]);
-      pv.group_kvlen[ng] = kv;
-      for (int c = 0; c < chunks; ++c)
-        for (int t = 0; t < tiles; ++t) {
-          int32_t* it = pv.items + 8 * n_items;
-          const int left = members - t * tokens_per_tile;
-          const int kvn = kv - c * chunk_tokens;
-          it[0] = c;                                         // partial slot
-          it[1] = c * chunk_tokens;                          // first kv token
-          it[2] = kvn < chunk_tokens ? kvn : chunk_tokens;   // kv tokens
-          it[4] = rows + t * tokens_per_tile;                // first entry of member_rows
-          it[5] = 0;                                         // shared item
-          it[6] = static_cast<int32_t>(req_pool_indices[b]);
-          it[7] = ng;
-          it[3] = left < tokens_per_tile ? left : tokens_per_tile;   // members
-          ++n_items;
-        }
+      g_leader[ng] = b; g_kv[ng] = kv; g_first[ng] = n_items; g_tiles[ng] = tiles; g_rows0[ng] = rows; g_members[ng] = members;
+      n_items += tiles * chunks;
       rows += members;
-      pv.group_qo[ng + 1] = rows;
       ++ng;
     }
-    // members in batch order inside each group
-    for (int gi = 0; gi < ng; ++gi) grp_cnt[gi] = pv.group_qo[gi];    // reuse as cursors (indexed by group id)
+    // members in batch order inside each group, then the ungrouped requests
+    for (int gi = 0; gi < ng; ++gi) grp_cnt[gi] = g_rows0[gi];       // reuse as cursors (indexed by group id)
     for (int b = 0; b < batch; ++b) {
       const int gi = grp_id[leader[b]];
-      if (gi < 0) continue;
-      pv.member_rows[grp_cnt[gi]++] = b;
-      pv.req_shared[b] = pv.group_kvlen[gi];
+      if (gi >= 0) order[grp_cnt[gi]++] = b;
     }
-    int cur = 0;
-    for (int i = 0; i < rows; ++i) pv.batch_order[cur++] = pv.member_rows[i];
+    int cur = rows;
     for (int b = 0; b < batch; ++b)
-      if (grp_id[leader[b]] < 0) pv.batch_order[cur++] = b;
-    pv.header[1] = ng;
-    pv.header[2] = rows;
-    pv.header[3] = n_items;
+      if (grp_id[leader[b]] < 0) order[cur++] = b;
+    n_groups = ng;
+    n_rows = rows;
     n_shared_items = n_items;
   }
   __syncthreads();
+  // ---- write-out, all threads ----
+  const int ng = n_groups, rows = n_rows;
+  for (int b = tid; b < batch; b += kPlanThreads) {
+    const int gi = grp_id[leader[b]];
+    pv.req_shared[b] = gi >= 0 ? g_kv[gi] : 0;
+    pv.batch_order[b] = order[b];
+    if (b < rows) pv.member_rows[b] = order[b];
+  }
+  for (int gi = tid; gi < ng; gi += kPlanThreads) {
+    pv.group_pool_row[gi] = static_cast<int32_t>(req_pool_indices[g_leader[gi]]);
+    pv.group_kvlen[gi] = g_kv[gi];
+    pv.group_qo[gi + 1] = g_rows0[gi] + g_members[gi];
+  }
+  for (int i = tid; i < n_shared_items; i += kPlanThreads) {
+    int gi = 0;
+    while (gi + 1 < ng && g_first[gi + 1] <= i) ++gi;
+    const int rel = i - g_first[gi];
+    const int c = rel / g_tiles[gi], t = rel - c * g_tiles[gi];
+    const int left = g_members[gi] - t * tokens_per_tile;
+    const int kvn = g_kv[gi] - c * chunk_tokens;
+    int32_t* it = pv.items + 8 * i;
+    it[0] = c;                                         // partial slot
+    it[1] = c * chunk_tokens;                          // first kv token
+    it[2] = kvn < chunk_tokens ? kvn : chunk_tokens;   // kv tokens
+    it[3] = left < tokens_per_tile ? left : tokens_per_tile;   // members
+    it[4] = g_rows0[gi] + t * tokens_per_tile;         // first entry of member_rows
+    it[5] = 0;                                         // shared item
+    it[6] = static_cast<int32_t>(req_pool_indices[g_leader[gi]]);
+    it[7] = gi;
+  }
+  if (tid == 0) {
+    pv.group_qo[0] = 0;
+    pv.header[1] = ng;
+    pv.header[2] = rows;
+    pv.header[3] = n_shared_items;
+  }
   // ---- private chunks of every request, appended behind the shared items (block-wide exclusive scan) ----
   int mine = 0, sh = 0, len = 0;
   if (tid < batch) {
-    sh = pv.req_shared[tid];
+    const int gi = grp_id[leader[tid]];
+    sh = gi >= 0 ? g_kv[gi] : 0;
     len = seq_lens[tid];
     mine = len > sh ? (len - sh + chunk_tokens - 1) / chunk_tokens : 0;
   }

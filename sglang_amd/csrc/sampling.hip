@@ -38,14 +38,34 @@ __global__ __launch_bounds__(kRowThreads) void argmax_kernel(const void* __restr
   float best = -INFINITY;
   int64_t best_i = INT64_MAX;
   bool best_nan = false;
-  for (int64_t i = threadIdx.x; i < vocab; i += blockDim.x) {
-    const float v = load_logit<BF16>(base, i);
+  auto take = [&](float v, int64_t i) {
     const bool is_nan = v != v;
     // strictly-greater keeps the first index inside a thread (indices ascend)
     if (!best_nan && (is_nan || v > best || best_i == INT64_MAX)) {
       best = v; best_i = i; best_nan = is_nan;
     }
+  };
+  // 16-byte loads (8 bf16 / 4 fp32 per lane) over the aligned body, scalar head and tail
+  constexpr int EPV = BF16 ? 8 : 4;
+  constexpr int ESZ = BF16 ? 2 : 4;
+  const uintptr_t addr = reinterpret_cast<uintptr_t>(base);
+  int64_t head = ((16 - (addr & 15)) & 15) / ESZ;
+  if (head > vocab) head = vocab;
+  const int64_t nvec = (vocab - head) / EPV;
+  for (int64_t i = threadIdx.x; i < head; i += blockDim.x) take(load_logit<BF16>(base, i), i);
+  const U4* vbase = reinterpret_cast<const U4*>(static_cast<const char*>(base) + head * ESZ);
+  for (int64_t j = threadIdx.x; j < nvec; j += blockDim.x) {
+    const U4 v = vbase[j];
+    const int64_t i0 = head + j * EPV;
+    if (BF16) {
+      take(bf_lo(v.x), i0 + 0); take(bf_hi(v.x), i0 + 1); take(bf_lo(v.y), i0 + 2); take(bf_hi(v.y), i0 + 3);
+      take(bf_lo(v.z), i0 + 4); take(bf_hi(v.z), i0 + 5); take(bf_lo(v.w), i0 + 6); take(bf_hi(v.w), i0 + 7);
+    } else {
+      take(__uint_as_float(v.x), i0 + 0); take(__uint_as_float(v.y), i0 + 1);
+      take(__uint_as_float(v.z), i0 + 2); take(__uint_as_float(v.w), i0 + 3);
+    }
   }
+  for (int64_t i = head + nvec * EPV + threadIdx.x; i < vocab; i += blockDim.x) take(load_logit<BF16>(base, i), i);
   auto better = [](float av, int64_t ai, float bv, int64_t bi) {
     // true if (bv, bi) should replace (av, ai)
     if (bi == INT64_MAX) return false;

@@ -399,7 +399,8 @@ __global__ __launch_bounds__(kNormThreads) void wstream_combine_norm_kernel(Comb
 // heads with the torch-native rounding points (rotary_embedding/utils.py:49-57: cos/sin in bf16,
 // o1 = bf16(bf16(x1 c) - bf16(x2 s)), o2 = bf16(bf16(x2 c) + bf16(x1 s))), q written to q_out, the
 // rotated k row and the v row written straight into the token->KV pool at cache_loc
-// (base.py:385-417 fused_set_kv_buffer).  One workgroup per token.
+// (base.py:385-417 fused_set_kv_buffer).  grid (token, item block): one 4-wide item per thread, so the
+// kernel is two dependent loads deep whatever the head count.
 // ---------------------------------------------------------------------------------------------
 struct RopeParams {
   const float* part;            // [splits, M, N]
@@ -423,7 +424,9 @@ __global__ __launch_bounds__(256) void wstream_combine_rope_kernel(RopeParams p)
   const int64_t slot = p.cache_loc[m];
   const int qk_heads = p.num_q_heads + p.num_kv_heads;
   const int per_head = half >> 2;                       // 4-wide pair chunks per head
-  for (int it = threadIdx.x; it < qk_heads * per_head; it += 256) {
+  const int n_rope = qk_heads * per_head;
+  const int it = blockIdx.y * 256 + threadIdx.x;        // rope items first, then the v row
+  if (it < n_rope) {
     const int h = it / per_head, i = (it - h * per_head) * 4;
     const int n1 = h * D + i, n2 = n1 + half;
     f32x4_t a = sum_splits(row + n1, ss, p.splits);
@@ -454,9 +457,11 @@ __global__ __launch_bounds__(256) void wstream_combine_rope_kernel(RopeParams p)
     w2.x = pack_bf2(o2[0], o2[1]); w2.y = pack_bf2(o2[2], o2[3]);
     *reinterpret_cast<uint2*>(dst) = w1;
     *reinterpret_cast<uint2*>(dst + half) = w2;
+    return;
   }
   const int v0 = qk_heads * D, vn = p.num_kv_heads * D;
-  for (int e = threadIdx.x * 4; e < vn; e += 256 * 4) {
+  const int e = (it - n_rope) * 4;
+  if (e < vn) {
     f32x4_t a = sum_splits(row + v0 + e, ss, p.splits);
     if (p.bias) {
 #pragma unroll
@@ -594,7 +599,8 @@ int sgl_amd_wstream_qkv_rope(const void* x, const void* w_qkv, const void* bias,
   r.q_stride = q_row_stride; r.cache_row_stride = cache_row_stride;
   r.M = static_cast<int>(M); r.N = static_cast<int>(N); r.splits = num_k_splits;
   r.num_q_heads = num_q_heads; r.num_kv_heads = num_kv_heads; r.head_dim = head_dim; r.cache_f32 = cache_is_f32;
-  hipLaunchKernelGGL(wstream_combine_rope_kernel, dim3(r.M), dim3(256), 0, st, r);
+  const int items = (num_q_heads + num_kv_heads) * (head_dim / 8) + num_kv_heads * head_dim / 4;
+  hipLaunchKernelGGL(wstream_combine_rope_kernel, dim3(r.M, (items + 255) / 256), dim3(256), 0, st, r);
   SGL_CHECK_LAUNCH("wstream_qkv_rope");
   return 0;
 }

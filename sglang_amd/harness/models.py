@@ -315,7 +315,9 @@ class CausalLM(nn.Module):
         else:
             logits = F.linear(hidden_states, self.lm_head)
         logits = ps.tensor_model_parallel_all_gather(logits, dim=-1)
-        return LogitsProcessorOutput(next_token_logits=logits.float())
+        # kept in the model dtype: the greedy sampler arg-maxes the bf16 logits directly, the sampling path
+        # widens them to fp32 (logits_processor.py returns fp32; bf16 -> fp32 is exact, so nothing changes)
+        return LogitsProcessorOutput(next_token_logits=logits)
 
     def forward(self, input_ids: torch.Tensor, positions: torch.Tensor, forward_batch) -> LogitsProcessorOutput:
         return self.compute_logits(self.forward_hidden(input_ids, positions, forward_batch), forward_batch)

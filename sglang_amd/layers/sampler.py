@@ -36,7 +36,7 @@ class SamplingBatchInfo:
 
 @dataclass
 class LogitsProcessorOutput:
-    next_token_logits: torch.Tensor       # [B, vocab] fp32
+    next_token_logits: torch.Tensor       # [B, vocab] fp32, or the model dtype (widened on use)
     hidden_states: Optional[torch.Tensor] = None
 
 
@@ -55,6 +55,8 @@ class Sampler(nn.Module):
         # sampler.py:148-152, 211-260: div_ temperature, softmax in place, then sample from probs
         simple_sampling_case = not (sampling_info.need_top_p_sampling or sampling_info.need_top_k_sampling
                                     or sampling_info.need_min_p_sampling)
+        if logits.dtype != torch.float32:
+            logits = logits.float()                                         # exact widening of the bf16 logits
         probs = kernels.softmax_temperature_(logits, sampling_info.temperatures)
         if simple_sampling_case:
             ids = kernels.top_k_top_p_min_p_sample(probs, None, None, None, sampling_info.sampling_seed, positions,
