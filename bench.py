@@ -15,8 +15,10 @@ steps so every step does identical work.  value = output tokens / s over the K
 timed steps (max over ranks); at N > 1 the model runs TP=N over RCCL with the
 batch scaled to 64*N requests (weak scaling).
 
-The JSON line also carries `roofline` (the dominant hand-written kernel: paged
-decode attention, HBM bound, measured live with HIP events), `step_roofline`
+The JSON line also carries `roofline` (the dominant hand-written kernel: the
+weight-streaming gate_up GEMM, HBM bound, measured live with HIP events over the
+model's own 32 layers), `attention_roofline` (cascade / plain decode attention
+on the workload's slot pattern), `step_roofline`
 (whole decode step vs 8 TB/s), `prefill_mfma_frac`, p50 TTFT,
 and `cpu_baseline` (the CPU oracle = reference torch-native path, on a bounded
 sample of the same workload, rank 0 / N=1 only).
@@ -49,6 +51,23 @@ def build_prompts(cfg, groups, per_group, prefix, unique, seed=1):
         sys_p = [rnd.randrange(cfg.vocab_size) for _ in range(prefix)]
         prompts.append([sys_p + [rnd.randrange(cfg.vocab_size) for _ in range(unique)] for _ in range(per_group)])
     return prompts
+
+
+def pmc_traffic_bytes(kernel_substr):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc summaries (separate passes for
+    FETCH_SIZE and WRITE_SIZE, KiB per dispatch; MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half of a
+    wide coalesced streaming read, so it is doubled).  None when the summaries are not there."""
+    vals = {}
+    for ctr, fn in (("FETCH_SIZE", "r01_gemm_pmc_fetch.txt"), ("WRITE_SIZE", "r01_gemm_pmc_write.txt")):
+        f = ROOT / "profiles" / fn
+        if not f.exists():
+            return None
+        for line in f.read_text().splitlines():
+            if kernel_substr in line and ctr in line:
+                vals[ctr] = float(line.split("avg")[1].split()[0])
+    if len(vals) != 2:
+        return None
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
 
 
 def p_lin(cfg):
@@ -207,15 +226,54 @@ def main():
                          "frac": prefill_tflops / MFMA_PEAK_TFLOPS},
     }
 
-    # ---- dominant hand-written kernel, measured live with HIP events on torch's stream ----
+    # ---- dominant hand-written kernels, measured live with HIP events on torch's stream ----
     if rank == 0 and not args.no_kernel_roofline:
         from sglang_amd import kernels as K
+
+        def graph_time(fn, launches, reps=5):
+            """Average duration of one launch: `fn` (which enqueues `launches` kernels) captured into a
+            hipGraph, replayed `reps` times between two HIP events on the current stream."""
+            fn()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                fn()
+            g.replay()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / (reps * launches) * 1e-3
+
+        # (1) the kernel with the largest share of the step: the weight-streaming GEMM of gate_up_proj
+        # (fused silu_and_mul epilogue).  One launch per layer over the model's OWN weights, so every
+        # launch streams a different 235 MB from HBM (nothing is left in the 256 MiB infinity cache).
+        mlps = [layer.mlp for layer in runner.model.layers if hasattr(layer.mlp, "gate_up_proj")]
+        if mlps and K.wstream_supported(B, *mlps[0].gate_up_proj.weight.shape):
+            xg = torch.randn((B, cfg.hidden_size), device=dev).to(torch.bfloat16)
+            wN, wK = mlps[0].gate_up_proj.weight.shape
+            t_g = graph_time(lambda: [m.gate_up_act(xg) for m in mlps], len(mlps))
+            alg = wN * wK * 2 + B * wK * 2 + B * (wN // 2) * 2        # weights once + activations in + out
+            nw_s = K.choose_wstream_config(B, wN, wK, True, True)
+            traffic = pmc_traffic_bytes("wstream_gemm_kernel") if (B, wN, wK) == (64, 28672, 4096) else None
+            result["roofline"] = {"bound": "hbm", "achieved": alg / t_g / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                  "frac": alg / t_g / 1e9 / HBM_PEAK_GBPS, "traffic": traffic,
+                                  "traffic_source": "profiles/r01_gemm_pmc_{fetch,write}.txt: 2 x FETCH_SIZE (gfx950 "
+                                                    "counts 64 B per 128 B request) + WRITE_SIZE, KiB per dispatch",
+                                  "kernel": "wstream_gemm_kernel<4,4,2> (gate_up_proj + silu_and_mul)",
+                                  "us_per_launch": t_g * 1e6, "bytes_per_launch": alg,
+                                  "shape": {"M": B, "N": wN, "K": wK, "waves_per_group": nw_s[0], "k_splits": nw_s[1]},
+                                  "share_of_decode_step": len(mlps) * t_g / t_decode_step}
+
+        # (2) decode attention over the workload's own slot pattern (shared prefix rows + private rows)
         from sglang_amd.layers.attention.hip_backend import choose_num_splits
 
         Hq_r, Hkv_r = runner.num_attention_heads_per_rank, runner.num_kv_heads_per_rank
         len_k = in_len + args.out // 2
         r2t = runner.req_to_token_pool.req_to_token
-        # the workload's own slot pattern: shared prefix rows + private rows
         perm = (torch.randperm(runner.token_to_kv_pool.size - 1, device=dev) + 1).to(torch.int32)
         off = 0
         for b in range(B):
@@ -229,25 +287,24 @@ def main():
         o = torch.empty_like(q)
         kc, vc = runner.token_to_kv_pool.get_key_buffer(0), runner.token_to_kv_pool.get_value_buffer(0)
         kc.normal_(); vc.normal_()
+        row_bytes = 2 * Hkv_r * D * 2
+        att = {}
+        if D in (64, 128) and B >= 2:
+            cws = K.CascadeWorkspace(B, Hq_r, D, ctx, dev)
+            K.cascade_plan(cws, r2t, pool_idx, seq, Hq_r, Hkv_r)
+            t_c = graph_time(lambda: K.cascade_decode_attention(cws, q, kc, vc, o, r2t, pool_idx, seq, D ** -0.5), 1, reps=20)
+            uniq = (G * args.prefix + B * (len_k - args.prefix)) * row_bytes
+            att["cascade"] = {"kernel": "cascade_chunk_kernel + cascade_merge2_kernel", "us_per_layer": t_c * 1e6,
+                              "bytes_unique": uniq, "achieved": uniq / t_c / 1e9, "frac": uniq / t_c / 1e9 / HBM_PEAK_GBPS}
         splits = choose_num_splits(B, Hkv_r, Hq_r // Hkv_r, len_k)
         ws = K.decode_workspace(B, Hq_r, D, splits, dev) if splits > 1 else (None, None)
-        fn = lambda: K.decode_attention(q, kc, vc, o, r2t, pool_idx, seq, D ** -0.5, splits, ws[0], ws[1])
-        for _ in range(5):
-            fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        iters = 50
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(iters):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        t_k = e0.elapsed_time(e1) / iters * 1e-3
-        alg = B * len_k * 2 * Hkv_r * D * 2     # len * (2*H_kv*D*2 B) per request and layer
-        result["roofline"] = {"bound": "hbm", "achieved": alg / t_k / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                              "frac": alg / t_k / 1e9 / HBM_PEAK_GBPS, "traffic": None,
-                              "kernel": "decode_stage1_kernel", "us_per_launch": t_k * 1e6, "bytes_per_launch": alg,
-                              "shape": {"B": B, "Hq": Hq_r, "Hkv": Hkv_r, "D": D, "kv_len": len_k, "splits": splits}}
+        t_k = graph_time(lambda: K.decode_attention(q, kc, vc, o, r2t, pool_idx, seq, D ** -0.5, splits, ws[0], ws[1]), 1, reps=20)
+        alg = B * len_k * row_bytes     # len * (2*H_kv*D*2 B) per request and layer, no dedup
+        att["plain"] = {"kernel": "decode_stage1_kernel", "us_per_layer": t_k * 1e6, "bytes_no_dedup": alg,
+                        "achieved": alg / t_k / 1e9, "frac": alg / t_k / 1e9 / HBM_PEAK_GBPS}
+        result["attention_roofline"] = {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                        "shape": {"B": B, "Hq": Hq_r, "Hkv": Hkv_r, "D": D, "kv_len": len_k,
+                                                  "shared_prefix": args.prefix, "groups": G}, **att}
 
     # ---- CPU baseline: the oracle (reference torch-native path) on host cores --------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
