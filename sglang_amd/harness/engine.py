@@ -95,7 +95,16 @@ class ModelRunner:
         self.sampler: Sampler = create_sampler("hip")                 # model_runner.py:651
         self.graph_runner = None
         if use_graph:
-            self.graph_runner = DecodeGraphRunner(self, graph_max_bs or max_running_requests)  # :1007
+            try:
+                self.graph_runner = DecodeGraphRunner(self, graph_max_bs or max_running_requests)  # :1007
+            except RuntimeError as e:
+                # e.g. a collective that cannot be captured on this RCCL build: decode eagerly instead of dying
+                # (model_runner.py falls back the same way when cuda graph capture fails)
+                import warnings
+
+                warnings.warn(f"hipGraph capture failed, decoding eagerly: {e}")
+                torch.cuda.synchronize()
+                self.graph_runner = None
 
     # ------------------------------------------------------------------ forward (model_runner.py:1520-1790)
     def forward(self, fb: ForwardBatch):
