@@ -179,7 +179,7 @@ __global__ __launch_bounds__(kThreads, 4) void cascade_chunk_kernel(ChunkParams 
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const float s = st_acc[2 * kk + (i >> 2)][i & 3];
-        e[i] = (s > 0.5f * kNegBig) ? exp2f(s - mx) : 0.f;
+        e[i] = (s > 0.5f * kNegBig) ? fast_exp2(s - mx) : 0.f;
         psum += e[i];
       }
       pfrag[kk].x = pack_bf2(e[0], e[1]);

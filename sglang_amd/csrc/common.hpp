@@ -50,6 +50,10 @@ __host__ __device__ __forceinline__ float bf2f(uint16_t v) {
 }
 
 __host__ __device__ __forceinline__ uint16_t f2bf(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // gfx950 converts in hardware (v_cvt_pk_bf16_f32, round-to-nearest-even): one instruction instead of ~8
+  return __builtin_bit_cast(uint16_t, static_cast<__bf16>(f));
+#endif
   union { uint32_t u; float f; } c;
   c.f = f;
   uint32_t u = c.u;
@@ -66,8 +70,14 @@ __host__ __device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-  return static_cast<uint32_t>(f2bf(lo)) | (static_cast<uint32_t>(f2bf(hi)) << 16);
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t f = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));   // one v_cvt_pk_bf16_f32
 }
+
+// 2^x for softmax arguments (x <= 0, possibly hugely negative): the bare v_exp_f32, no denormal fix-up.
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // ---- wave64 reductions -----------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

@@ -23,6 +23,7 @@
 //     running sum and the rescale factor never cross lanes, and the exp'd
 //     S^T registers ARE the P^T operand of the second MFMA (no LDS round trip);
 //   * fp32 accumulation, exp2 with the softmax scale folded in, bf16 output.
+#include <cstdlib>
 #include "common.hpp"
 #include "../../include/sglang_amd.h"
 
@@ -145,7 +146,10 @@ __global__ __launch_bounds__(kThreads) void extend_attention_kernel(ExtendParams
   constexpr int kStage = (NK_LOADS > 8) ? NK_LOADS : 8;
   U4 stage[kStage];
 
-  auto prefetch = [&](int t) {
+  // Slot ids run one tile ahead of the rows: a row load that had to wait for its own slot-id load would
+  // park the wave for a full memory round trip in front of every tile's MFMAs.
+  int32_t sidx[kStage];
+  auto prefetch_idx = [&](int t) {
     const int kv0 = t * kKvTile;
     const int last = kv_end - 1;
     if (is_v) {
@@ -155,8 +159,7 @@ __global__ __launch_bounds__(kThreads) void extend_attention_kernel(ExtendParams
           // token order inside the chunk: i = 4a + r  <->  token 32*blk + 16a + 4g + r
           int tok = kv0 + 32 * v_blk32 + 16 * (i >> 2) + 4 * v_g + (i & 3);
           if (tok > last) tok = last;
-          const int64_t slot = idx_base[tok];
-          stage[i] = ld16(p.v_cache + slot * p.vc_stride + static_cast<int64_t>(kvh) * D + st_c * 8);
+          sidx[i] = idx_base[tok];
         }
       }
     } else {
@@ -164,9 +167,21 @@ __global__ __launch_bounds__(kThreads) void extend_attention_kernel(ExtendParams
       for (int i = 0; i < NK_LOADS; ++i) {
         int tok = kv0 + st_r + (128 / CPR) * i;
         if (tok > last) tok = last;
-        const int64_t slot = idx_base[tok];
-        stage[i] = ld16(p.k_cache + slot * p.kc_stride + static_cast<int64_t>(kvh) * D + st_c * 8);
+        sidx[i] = idx_base[tok];
       }
+    }
+  };
+  auto prefetch_rows = [&]() {
+    if (is_v) {
+      if (v_active) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          stage[i] = ld16(p.v_cache + static_cast<int64_t>(sidx[i]) * p.vc_stride + static_cast<int64_t>(kvh) * D + st_c * 8);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NK_LOADS; ++i)
+        stage[i] = ld16(p.k_cache + static_cast<int64_t>(sidx[i]) * p.kc_stride + static_cast<int64_t>(kvh) * D + st_c * 8);
     }
   };
 
@@ -198,13 +213,20 @@ __global__ __launch_bounds__(kThreads) void extend_attention_kernel(ExtendParams
     }
   };
 
-  if (n_tiles > t_first) prefetch(t_first);
+  if (n_tiles > t_first) {
+    prefetch_idx(t_first);
+    prefetch_rows();
+    if (t_first + 1 < n_tiles) prefetch_idx(t_first + 1);
+  }
 
   for (int t = t_first; t < n_tiles; ++t) {
     __syncthreads();   // every wave is done reading the previous tile
     commit();
     __syncthreads();
-    if (t + 1 < n_tiles) prefetch(t + 1);
+    if (t + 1 < n_tiles) {
+      prefetch_rows();                                   // tile t+1, slot ids loaded one iteration ago
+      if (t + 2 < n_tiles) prefetch_idx(t + 2);
+    }
 
     const int kv0 = t * kKvTile;
 
@@ -228,38 +250,63 @@ __global__ __launch_bounds__(kThreads) void extend_attention_kernel(ExtendParams
     }
 
     // ---- online softmax; lane owns row (l15 + 16 mt), tokens 16nt + 4g + r --
+    // The VALU work here, not the MFMAs, sets the pace of this kernel, so: hardware bf16 packing and
+    // v_exp_f32, the scale folded into one fma per score, no masking on tiles that lie inside every row's
+    // causal limit, and no rescale of O when no row of the wave raised its maximum.
     U4 pfrag[2][2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-      float sv[4][4];
-      float mx = kNegBig;
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int kvpos = kv0 + nt * 16 + g * 4 + r;
-          const float s = (kvpos < row_limit[mt]) ? st_acc[mt][nt][r] * p.scale_log2 : kNegBig;
-          sv[nt][r] = s;
-          mx = fmaxf(mx, s);
-        }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run[mt], mx);
-      const float alpha = exp2f(m_run[mt] - m_new);
-      m_run[mt] = m_new;
-      float psum = 0.f;
+      const bool full = __ballot(kv0 + kKvTile > row_limit[mt]) == 0ull;     // wave-uniform
       float pv[4][4];
+      float m_new, psum = 0.f;
+      if (full) {
+        float mx = st_acc[mt][0][0];
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float e = (sv[nt][r] > 0.5f * kNegBig) ? exp2f(sv[nt][r] - m_new) : 0.f;
-          pv[nt][r] = e;
-          psum += e;
-        }
+          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st_acc[mt][nt][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        m_new = fmaxf(m_run[mt], mx * p.scale_log2);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e = fast_exp2(fmaf(st_acc[mt][nt][r], p.scale_log2, -m_new));
+            pv[nt][r] = e;
+            psum += e;
+          }
+      } else {
+        float sv[4][4];
+        float mx = kNegBig;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int kvpos = kv0 + nt * 16 + g * 4 + r;
+            const float s = (kvpos < row_limit[mt]) ? st_acc[mt][nt][r] * p.scale_log2 : kNegBig;
+            sv[nt][r] = s;
+            mx = fmaxf(mx, s);
+          }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        m_new = fmaxf(m_run[mt], mx);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e = (sv[nt][r] > 0.5f * kNegBig) ? fast_exp2(sv[nt][r] - m_new) : 0.f;
+            pv[nt][r] = e;
+            psum += e;
+          }
+      }
+      const float alpha = fast_exp2(m_run[mt] - m_new);
+      m_run[mt] = m_new;
       l_run[mt] = l_run[mt] * alpha + psum;
+      if (__ballot(alpha != 1.0f) != 0ull) {
 #pragma unroll
-      for (int n = 0; n < ND; ++n) ot[mt][n] *= alpha;
+        for (int n = 0; n < ND; ++n) ot[mt][n] *= alpha;
+      }
       // P^T operand for k-step kk: [P(nt=2kk, r=0..3), P(nt=2kk+1, r=0..3)]
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
@@ -364,6 +411,7 @@ int sgl_amd_extend_attention(const void* q, void* out, const void* k_cache, cons
   p.group = group;
   p.tokens_per_tile = kRows / group;
   p.causal = causal;
+
   p.scale_log2 = sm_scale * 1.4426950408889634f;
   const int tiles = (max_extend_len + p.tokens_per_tile - 1) / p.tokens_per_tile;
   dim3 grid(tiles, num_kv_heads, batch);
