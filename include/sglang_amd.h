@@ -225,7 +225,7 @@ int64_t sgl_amd_skinny_gemm_slab_floats(int64_t row_blocks, int64_t N, int split
 /* Weight-streaming GEMM for decode batches (M <= sgl_amd_wstream_gemm_max_rows()): y = x . w^T, bf16,
  * fp32 accumulate; needs N % 16 == 0 and K % 128 == 0 (other shapes: sgl_amd_skinny_gemm).
  * Replaces the library matmul of srt/layers/linear.py:1596-1660 (UnquantizedLinearMethod.apply) at decode.
- * waves_per_group (4..8) x num_k_splits is the host's choice of decomposition: one workgroup is
+ * waves_per_group (4..8; 4..5 beyond 64 rows) x num_k_splits is the host's choice of decomposition: one workgroup is
  * resident per CU (its LDS ring holds the in-flight chunks), so ceil(N/16/waves) x splits should be a
  * whole number of 256-workgroup rounds.  num_k_splits > 1 writes fp32 partials
  * [splits, M, N] to ws_partials (sgl_amd_wstream_gemm_workspace_floats) and a combine kernel sums

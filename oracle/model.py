@@ -20,7 +20,7 @@ from . import ops
 
 class OracleLM:
     def __init__(self, cfg, weights: Dict[str, torch.Tensor], num_slots: int = 4096, max_ctx: int = 2048,
-                 compute_dtype: Optional[torch.dtype] = None, tp_size: int = 1, tp_group=None):
+                 compute_dtype: Optional[torch.dtype] = None, tp_size: int = 1, tp_group=None, max_reqs: int = 63):
         """`weights`: CPU tensors keyed like the product model's state_dict().  With tp_size > 1 the
         weights are ONE rank's shard (heads / intermediate / vocab split as in the reference's
         Column/RowParallelLinear, srt/layers/linear.py) and the row-parallel outputs are summed with
@@ -43,7 +43,7 @@ class OracleLM:
         L = cfg.num_hidden_layers
         self.k_cache = [torch.zeros((num_slots, self.Hkv, D), dtype=torch.bfloat16) for _ in range(L)]
         self.v_cache = [torch.zeros((num_slots, self.Hkv, D), dtype=torch.bfloat16) for _ in range(L)]
-        self.req_to_token = torch.zeros((64, max_ctx), dtype=torch.int32)
+        self.req_to_token = torch.zeros((max_reqs + 1, max_ctx), dtype=torch.int32)
         self.next_slot = 1
 
     # ---- one forward over a ragged batch --------------------------------------------------

@@ -191,18 +191,28 @@ __global__ __launch_bounds__(64 * NW, 1) void wstream_gemm_kernel(WsParams p) {
     if constexpr (MT > 1) b[1] = lds_rd<WCH + 4096>(ad);
     if constexpr (MT > 2) b[2] = lds_rd<WCH + 8192>(ad);
     if constexpr (MT > 3) b[3] = lds_rd<WCH + 12288>(ad);
+    if constexpr (MT > 4) b[4] = lds_rd<WCH + 16384>(ad);
+    if constexpr (MT > 5) b[5] = lds_rd<WCH + 20480>(ad);
+    if constexpr (MT > 6) b[6] = lds_rd<WCH + 24576>(ad);
+    if constexpr (MT > 7) b[7] = lds_rd<WCH + 28672>(ad);
   };
   auto compute = [&](int slot) {
     const uint32_t slot_addr = ring_addr + slot * CH;
+    constexpr bool AHEAD = 2 * (MT + TPW) <= 15;       // lgkmcnt is a 4-bit counter
     u32x4_t a[2][TPW], b[2][MT];
-    read_frags(slot_addr, 0, a[0], b[0]);
+    if constexpr (AHEAD) read_frags(slot_addr, 0, a[0], b[0]);
 #pragma unroll
     for (int kk = 0; kk < kKSteps; ++kk) {
-      const int cur = kk & 1;
-      if (kk + 1 < kKSteps) {
-        read_frags(slot_addr, kk + 1, a[cur ^ 1], b[cur ^ 1]);
-        wait_lgkm<MT + TPW>();
+      const int cur = AHEAD ? (kk & 1) : 0;
+      if constexpr (AHEAD) {
+        if (kk + 1 < kKSteps) {
+          read_frags(slot_addr, kk + 1, a[cur ^ 1], b[cur ^ 1]);
+          wait_lgkm<MT + TPW>();
+        } else {
+          wait_lgkm<0>();
+        }
       } else {
+        read_frags(slot_addr, kk, a[0], b[0]);
         wait_lgkm<0>();
       }
 #pragma unroll
@@ -473,28 +483,34 @@ __global__ __launch_bounds__(256) void wstream_combine_rope_kernel(RopeParams p)
   }
 }
 
+// the activation image of a chunk grows with M: beyond 64 rows only the narrower groups keep a 3-deep ring
 template <int MT, int NW, int TPW>
-void launch_main(const WsParams& p, hipStream_t st) {
-  dim3 grid((p.ntiles / TPW + NW - 1) / NW, p.splits);
-  hipLaunchKernelGGL((wstream_gemm_kernel<MT, NW, TPW>), grid, dim3(64 * NW), 0, st, p);
+int launch_main(const WsParams& p, hipStream_t st) {
+  if constexpr (ring_depth(MT, NW, TPW) >= 3) {
+    dim3 grid((p.ntiles / TPW + NW - 1) / NW, p.splits);
+    hipLaunchKernelGGL((wstream_gemm_kernel<MT, NW, TPW>), grid, dim3(64 * NW), 0, st, p);
+    return 0;
+  } else {
+    return -1;
+  }
 }
 
 template <int MT>
 int launch_nw(const WsParams& p, int nw, bool fused_silu, hipStream_t st) {
   if (fused_silu) {                                   // two tiles per wave: half the waves for the same LDS ring
     switch (nw) {
-      case 2: launch_main<MT, 2, 2>(p, st); return 0;
-      case 3: launch_main<MT, 3, 2>(p, st); return 0;
-      case 4: launch_main<MT, 4, 2>(p, st); return 0;
+      case 2: return launch_main<MT, 2, 2>(p, st);
+      case 3: return launch_main<MT, 3, 2>(p, st);
+      case 4: return launch_main<MT, 4, 2>(p, st);
       default: return -1;
     }
   }
   switch (nw) {
-    case 4: launch_main<MT, 4, 1>(p, st); return 0;
-    case 5: launch_main<MT, 5, 1>(p, st); return 0;
-    case 6: launch_main<MT, 6, 1>(p, st); return 0;
-    case 7: launch_main<MT, 7, 1>(p, st); return 0;
-    case 8: launch_main<MT, 8, 1>(p, st); return 0;
+    case 4: return launch_main<MT, 4, 1>(p, st);
+    case 5: return launch_main<MT, 5, 1>(p, st);
+    case 6: return launch_main<MT, 6, 1>(p, st);
+    case 7: return launch_main<MT, 7, 1>(p, st);
+    case 8: return launch_main<MT, 8, 1>(p, st);
     default: return -1;
   }
 }
@@ -503,7 +519,7 @@ int launch_nw(const WsParams& p, int nw, bool fused_silu, hipStream_t st) {
 
 extern "C" {
 
-int sgl_amd_wstream_gemm_max_rows(void) { return 64; }
+int sgl_amd_wstream_gemm_max_rows(void) { return 128; }
 
 int64_t sgl_amd_wstream_gemm_workspace_floats(int64_t M, int64_t N, int num_k_splits) {
   return static_cast<int64_t>(num_k_splits) * M * N;   /* needed when num_k_splits > 1 or epilogue != 0 */
@@ -513,7 +529,7 @@ int64_t sgl_amd_wstream_gemm_workspace_floats(int64_t M, int64_t N, int num_k_sp
 static int wstream_launch_main(const char* who, const void* x, const void* w, const void* bias, void* y, int64_t M, int64_t N,
                                int64_t K, int64_t x_row_stride, int64_t w_row_stride, int64_t y_row_stride, bool fused_silu,
                                bool to_partials, int waves_per_group, int num_k_splits, void* ws_partials, hipStream_t st) {
-  SGL_CHECK_ARG(M >= 1 && M <= 64, "%s: M=%lld rows (supported: 1..64)", who, (long long)M);
+  SGL_CHECK_ARG(M >= 1 && M <= 128, "%s: M=%lld rows (supported: 1..128)", who, (long long)M);
   SGL_CHECK_ARG(N > 0 && N % 16 == 0 && K >= kKC && K % kKC == 0,
                 "%s: need N %% 16 == 0 and K %% %d == 0 (got N=%lld K=%lld)", who, kKC, (long long)N, (long long)K);
   SGL_CHECK_ARG(x_row_stride % 8 == 0 && w_row_stride % 8 == 0 && y_row_stride % 4 == 0,
@@ -536,7 +552,9 @@ static int wstream_launch_main(const char* who, const void* x, const void* w, co
     case 1: rc = launch_nw<1>(p, waves_per_group, fused_silu, st); break;
     case 2: rc = launch_nw<2>(p, waves_per_group, fused_silu, st); break;
     case 3: rc = launch_nw<3>(p, waves_per_group, fused_silu, st); break;
-    default: rc = launch_nw<4>(p, waves_per_group, fused_silu, st); break;
+    case 4: rc = launch_nw<4>(p, waves_per_group, fused_silu, st); break;
+    case 5: case 6: rc = launch_nw<6>(p, waves_per_group, fused_silu, st); break;
+    default: rc = launch_nw<8>(p, waves_per_group, fused_silu, st); break;
   }
   SGL_CHECK_ARG(rc == 0, "%s: unsupported configuration", who);
   return 0;

@@ -96,7 +96,7 @@ class Linear(nn.Module):
 
     def streams(self, x: torch.Tensor) -> bool:
         return (x.is_cuda and x.dim() == 2 and x.stride(1) == 1
-                and kernels.wstream_supported(x.shape[0], self.weight.shape[0], self.weight.shape[1]))
+                and kernels.wstream_preferred(x.shape[0], self.weight.shape[0], self.weight.shape[1]))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.streams(x):
@@ -245,7 +245,7 @@ class LlamaDecoderLayer(nn.Module):
     def fusable(self, x: torch.Tensor, tp_size: int) -> bool:
         """The decode form below needs no collective between a projection and the norm behind it."""
         return (tp_size == 1 and isinstance(self.mlp, LlamaMLP) and self.self_attn.o_proj.streams(x)
-                and kernels.wstream_supported(x.shape[0], *self.mlp.down_proj.weight.shape) and x.shape[1] <= 16384)
+                and kernels.wstream_preferred(x.shape[0], *self.mlp.down_proj.weight.shape) and x.shape[1] <= 16384)
 
     def forward_decode_fused(self, positions, normed: torch.Tensor, forward_batch, residual: torch.Tensor,
                              next_norm: RMSNorm) -> torch.Tensor:
@@ -310,7 +310,7 @@ class CausalLM(nn.Module):
         if forward_batch.forward_mode.is_extend():
             last = torch.cumsum(forward_batch.extend_seq_lens, dim=0, dtype=torch.int64) - 1
             hidden_states = hidden_states[last]
-        if hidden_states.is_cuda and kernels.wstream_supported(hidden_states.shape[0], *self.lm_head.shape):
+        if hidden_states.is_cuda and kernels.wstream_preferred(hidden_states.shape[0], *self.lm_head.shape):
             logits = kernels.wstream_gemm(hidden_states, self.lm_head.data)
         else:
             logits = F.linear(hidden_states, self.lm_head)

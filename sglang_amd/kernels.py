@@ -499,7 +499,15 @@ def wstream_gemm_max_rows() -> int:
 
 
 def wstream_supported(M: int, N: int, K: int) -> bool:
-    return 0 < M <= 64 and N % 16 == 0 and K % 128 == 0 and K >= 128
+    return 0 < M <= 128 and N % 16 == 0 and K % 128 == 0 and K >= 128
+
+
+@functools.lru_cache(maxsize=None)
+def wstream_preferred(M: int, N: int, K: int) -> bool:
+    """Policy on top of wstream_supported(): up to 64 rows the weight stream always beats the library GEMM
+    on MI355X; at 65..128 rows it still does for the narrow projections (N <= 8192: qkv / o / down), while
+    the wide ones (gate_up, lm_head) are left to hipBLASLt (benchmarks/gemm_sweep.py --M 128)."""
+    return wstream_supported(M, N, K) and (M <= 64 or N <= 8192)
 
 
 @functools.lru_cache(maxsize=None)
@@ -512,7 +520,8 @@ def choose_wstream_config(M: int, N: int, K: int, need_combine: bool = False, fu
     best = None
     if fused_silu:                    # one pass, each wave owns a gate tile and its up tile: no split-K
         tiles //= 2
-    for nw in ((4, 3, 2) if fused_silu else (8, 7, 6, 5, 4)):
+    wide = M > 64                     # a 128-row activation image leaves room for fewer weight waves
+    for nw in (((2,) if wide else (4, 3, 2)) if fused_silu else ((5, 4) if wide else (8, 7, 6, 5, 4))):
         groups = (tiles + nw - 1) // nw
         for s in range(1, 2 if fused_silu else max(1, min(nch // 2, 32)) + 1):
             wgs = groups * s

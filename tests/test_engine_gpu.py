@@ -31,7 +31,8 @@ def _shared_prefix_prompts(cfg, groups=2, per_group=3, shared=70, unique=9, seed
 
 
 def _check_against_oracle(cfg, runner, prompts, outs, trace, new_tokens):
-    oracle = OracleLM(cfg, weights_from_product_model(runner.model), compute_dtype=torch.float32)
+    oracle = OracleLM(cfg, weights_from_product_model(runner.model), compute_dtype=torch.float32,
+                      max_reqs=max(63, len(prompts)), num_slots=max(4096, sum(len(p) + new_tokens for p in prompts) + 64))
     ref_outs, ref_logits = oracle.generate(prompts, new_tokens, return_logits=True, forced=outs)
     agree = total = 0
     outliers = rows = 0
@@ -133,3 +134,27 @@ def test_greedy_sampler_and_graph_padding(device):
         res.append((eng.logits_trace, [q.output_ids for q in reqs]))
     for a, b in zip(res[0][0], res[1][0]):
         torch.testing.assert_close(a, b, atol=2e-2, rtol=2e-2)
+
+
+def test_decode_batch_beyond_64_rows_matches_oracle(device):
+    """80 running requests: the decode projections take the 65..128-row forms of the weight-streaming
+    GEMM (narrow N) or the library GEMM (wide N), with the fused qkv-rope / add-norm combines."""
+    from sglang_amd.harness.engine import Engine, ModelRunner, Req
+    from sglang_amd.harness.models import CONFIGS
+
+    cfg = CONFIGS["tiny-llama"]
+    B = 80
+    runner = ModelRunner(cfg, max_total_tokens=B * 64 + 512, max_running_requests=B, max_context_len=128, device=device,
+                         init_device="cpu", use_graph=True, graph_max_bs=B)
+    eng = Engine(runner)
+    prompts = _shared_prefix_prompts(cfg, groups=4, per_group=B // 4, shared=24, unique=5, seed=11)
+    new_tokens = 3
+    eng.logits_trace = []
+    reqs = [Req(i, p, new_tokens) for i, p in enumerate(prompts)]
+    eng.prefill(reqs)
+    for _ in range(new_tokens - 1):
+        eng.decode_step()
+    done = sorted(eng.running, key=lambda q: q.rid)
+    eng.finish(list(eng.running))
+    outs = [q.output_ids for q in done]
+    _check_against_oracle(cfg, runner, prompts, outs, eng.logits_trace, new_tokens)
