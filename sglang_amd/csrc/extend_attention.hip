@@ -34,8 +34,8 @@ namespace {
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-constexpr int kThreads = 256;
-constexpr int kRows = 128;      // rows per workgroup
+constexpr int kStagers = 256;     // threads that gather K/V tiles (waves 0-1: V, waves 2-3: K)
+constexpr int kRows = 128;      // rows per workgroup with two 16-row M-tiles per wave (64 with one)
 constexpr int kKvTile = 64;     // cached tokens per tile
 constexpr float kNegBig = -1.0e30f;
 
@@ -65,8 +65,14 @@ struct Smem {
   U4 vt[D * kKvTile / 8];       // [d][token-chunk ^ swz]
 };
 
-template <int D>
-__global__ __launch_bounds__(kThreads) void extend_attention_kernel(ExtendParams p) {
+// MTW = 16-row M-tiles per wave: 2 shares every staged K/V tile between 128 rows (fewest gathers per flop) at
+// ~256 VGPRs = one workgroup per CU; 1 halves the rows per workgroup at ~130 VGPRs = three workgroups per CU,
+// whose waves cover each other's barrier, softmax and gather stalls.
+// NWV = waves per workgroup: 8 (x 2 M-tiles = 256 rows) halves the K/V gathers per flop once more and puts two
+// waves on every SIMD (the whole register file: 512 threads x 256 VGPRs) -- the form for long prefixes, where the
+// kernel is bound by the gather traffic rather than by the matrix cores.
+template <int D, int MTW, int NWV>
+__global__ __launch_bounds__(64 * NWV, (MTW == 1 && NWV == 4) ? 3 : (NWV == 8 ? 2 : 1)) void extend_attention_kernel(ExtendParams p) {
   __shared__ Smem<D> sm;
   const int block_x = blockIdx.x, block_z = blockIdx.z;
   constexpr int CPR = D / 8;            // 16-byte chunks per KV row
@@ -100,13 +106,13 @@ __global__ __launch_bounds__(kThreads) void extend_attention_kernel(ExtendParams
   const int n_tiles = (kv_end + kKvTile - 1) / kKvTile;
 
   // ---- this lane's two rows (one per M-tile) ------------------------------
-  int row_tok[2], row_limit[2];
-  bool row_ok[2];
-  int64_t row_off[2];   // element offset of (token, head) inside q / out
-  U4 qfrag[2][KC];
+  int row_tok[MTW], row_limit[MTW];
+  bool row_ok[MTW];
+  int64_t row_off[MTW];   // element offset of (token, head) inside q / out
+  U4 qfrag[MTW][KC];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    const int r = wid * 32 + mt * 16 + l15;
+  for (int mt = 0; mt < MTW; ++mt) {
+    const int r = wid * (16 * MTW) + mt * 16 + l15;
     const int t = r / p.group;
     const int hg = r - t * p.group;
     row_tok[mt] = q0 + t;
@@ -125,10 +131,10 @@ __global__ __launch_bounds__(kThreads) void extend_attention_kernel(ExtendParams
     }
   }
 
-  f32x4_t ot[2][ND];
-  float m_run[2], l_run[2];
+  f32x4_t ot[MTW][ND];
+  float m_run[MTW], l_run[MTW];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int mt = 0; mt < MTW; ++mt) {
     m_run[mt] = kNegBig;
     l_run[mt] = 0.f;
 #pragma unroll
@@ -138,7 +144,8 @@ __global__ __launch_bounds__(kThreads) void extend_attention_kernel(ExtendParams
   // ---- staging roles -------------------------------------------------------
   // waves 0-1: V (8x8 transposing blocks), waves 2-3: K (row-major).
   const bool is_v = tid < 128;
-  const int st = is_v ? tid : tid - 128;
+  const bool is_k = tid >= 128 && tid < kStagers;
+  const int st = is_v ? tid : (tid - 128) & 127;
   const int st_c = st % CPR;                 // 16-byte column of the KV row
   const int st_r = st / CPR;
   const bool v_active = is_v && st < V_THREADS;
@@ -162,7 +169,7 @@ __global__ __launch_bounds__(kThreads) void extend_attention_kernel(ExtendParams
           sidx[i] = idx_base[tok];
         }
       }
-    } else {
+    } else if (is_k) {
 #pragma unroll
       for (int i = 0; i < NK_LOADS; ++i) {
         int tok = kv0 + st_r + (128 / CPR) * i;
@@ -178,7 +185,7 @@ __global__ __launch_bounds__(kThreads) void extend_attention_kernel(ExtendParams
         for (int i = 0; i < 8; ++i)
           stage[i] = ld16(p.v_cache + static_cast<int64_t>(sidx[i]) * p.vc_stride + static_cast<int64_t>(kvh) * D + st_c * 8);
       }
-    } else {
+    } else if (is_k) {
 #pragma unroll
       for (int i = 0; i < NK_LOADS; ++i)
         stage[i] = ld16(p.k_cache + static_cast<int64_t>(sidx[i]) * p.kc_stride + static_cast<int64_t>(kvh) * D + st_c * 8);
@@ -204,7 +211,7 @@ __global__ __launch_bounds__(kThreads) void extend_attention_kernel(ExtendParams
           sm.vt[d * 8 + chunk] = o;
         }
       }
-    } else {
+    } else if (is_k) {
 #pragma unroll
       for (int i = 0; i < NK_LOADS; ++i) {
         const int row = st_r + (128 / CPR) * i;
@@ -231,9 +238,9 @@ __global__ __launch_bounds__(kThreads) void extend_attention_kernel(ExtendParams
     const int kv0 = t * kKvTile;
 
     // ---- S^T = K . Q^T ---------------------------------------------------
-    f32x4_t st_acc[2][4];
+    f32x4_t st_acc[MTW][4];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) st_acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(kThreads) void extend_attention_kernel(ExtendParams
       for (int kc = 0; kc < KC; ++kc) {
         const U4 kf = sm.k[row * CPR + ((kc * 4 + g) ^ (row & (CPR - 1)))];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MTW; ++mt)
           st_acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
               as_frag(kf), as_frag(qfrag[mt][kc]), st_acc[mt][nt], 0, 0, 0);
       }
@@ -253,9 +260,9 @@ __global__ __launch_bounds__(kThreads) void extend_attention_kernel(ExtendParams
     // The VALU work here, not the MFMAs, sets the pace of this kernel, so: hardware bf16 packing and
     // v_exp_f32, the scale folded into one fma per score, no masking on tiles that lie inside every row's
     // causal limit, and no rescale of O when no row of the wave raised its maximum.
-    U4 pfrag[2][2];
+    U4 pfrag[MTW][2];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < MTW; ++mt) {
       const bool full = __ballot(kv0 + kKvTile > row_limit[mt]) == 0ull;     // wave-uniform
       float pv[4][4];
       float m_new, psum = 0.f;
@@ -325,7 +332,7 @@ __global__ __launch_bounds__(kThreads) void extend_attention_kernel(ExtendParams
       for (int kk = 0; kk < 2; ++kk) {
         const U4 vf = sm.vt[d * 8 + ((kk * 4 + g) ^ ((d ^ (d >> 3)) & 7))];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MTW; ++mt)
           ot[mt][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(vf), as_frag(pfrag[mt][kk]),
                                                                ot[mt][n], 0, 0, 0);
       }
@@ -334,7 +341,7 @@ __global__ __launch_bounds__(kThreads) void extend_attention_kernel(ExtendParams
 
   // ---- epilogue: lane holds O^T[d = 16n + 4g + r][row] ----------------------
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int mt = 0; mt < MTW; ++mt) {
     float l = l_run[mt];
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
@@ -409,16 +416,39 @@ int sgl_amd_extend_attention(const void* q, void* out, const void* k_cache, cons
   p.r2t_stride = req_to_token_stride;
   p.num_kv_heads = num_kv_heads;
   p.group = group;
-  p.tokens_per_tile = kRows / group;
+  // Workgroup shape (waves x M-tiles per wave -> rows that share one staged K/V tile):
+  //   8 x 2 = 256 rows, two waves per SIMD and the whole register file: fewest K/V gathers per flop; measured
+  //                    fastest on MI355X for every shape that gives each CU a workgroup (benchmarks/micro.py);
+  //   4 x 1 =  64 rows, 3 workgroups / CU: short extends whose wider grids would leave CUs idle;
+  //   4 x 2 = 128 rows: what is left (GQA groups above 64 on a small grid).
+  const int64_t rows_total = static_cast<int64_t>(max_extend_len) * group;
+  auto wgs = [&](int rows) { return ((rows_total + rows - 1) / rows) * num_kv_heads * batch; };
+  int mtw = 2, nwv = 4;
+  if (group <= 256 && wgs(256) >= 256) { mtw = 2; nwv = 8; }
+  else if (group <= 64) { mtw = 1; nwv = 4; }
+  if (const char* f = getenv("SGL_AMD_EXTEND_SHAPE")) {       // tuning override: "41", "42", "82"
+    const int v = atoi(f);
+    if (v == 41 && group <= 64) { nwv = 4; mtw = 1; }
+    if (v == 42) { nwv = 4; mtw = 2; }
+    if (v == 82) { nwv = 8; mtw = 2; }
+  }
+  p.tokens_per_tile = (nwv * 16 * mtw) / group;
   p.causal = causal;
-
   p.scale_log2 = sm_scale * 1.4426950408889634f;
   const int tiles = (max_extend_len + p.tokens_per_tile - 1) / p.tokens_per_tile;
   dim3 grid(tiles, num_kv_heads, batch);
-  if (head_dim == 128)
-    hipLaunchKernelGGL((extend_attention_kernel<128>), grid, dim3(kThreads), 0, as_stream(stream), p);
-  else
-    hipLaunchKernelGGL((extend_attention_kernel<64>), grid, dim3(kThreads), 0, as_stream(stream), p);
+  hipStream_t st = as_stream(stream);
+#define SGL_LAUNCH_EXT(D_, M_, W_) hipLaunchKernelGGL((extend_attention_kernel<D_, M_, W_>), grid, dim3(64 * W_), 0, st, p)
+  if (head_dim == 128) {
+    if (nwv == 8) SGL_LAUNCH_EXT(128, 2, 8);
+    else if (mtw == 1) SGL_LAUNCH_EXT(128, 1, 4);
+    else SGL_LAUNCH_EXT(128, 2, 4);
+  } else {
+    if (nwv == 8) SGL_LAUNCH_EXT(64, 2, 8);
+    else if (mtw == 1) SGL_LAUNCH_EXT(64, 1, 4);
+    else SGL_LAUNCH_EXT(64, 2, 4);
+  }
+#undef SGL_LAUNCH_EXT
   SGL_CHECK_LAUNCH("extend_attention");
   return 0;
 }

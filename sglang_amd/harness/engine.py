@@ -71,6 +71,10 @@ class ModelRunner:
                  use_graph: bool = True, graph_max_bs: Optional[int] = None, disable_radix_cache: bool = False):
         self.config = config
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if self.device.type == "cuda":
+            from ..tuning import load_gemm_selections
+
+            load_gemm_selections()        # library-GEMM selections for the prefill-sized projections (lookup only)
         self.tp_rank = ps.get_tensor_model_parallel_rank()
         self.tp_size = ps.get_tensor_model_parallel_world_size()
         self.page_size = page_size
