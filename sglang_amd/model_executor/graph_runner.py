@@ -91,7 +91,10 @@ class DecodeGraphRunner:
                     self._run(fb)
                 torch.cuda.current_stream().synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=self.pool, stream=stream):
+                # with collectives in the graph (TP > 1) RCCL's watchdog thread issues event queries while
+                # the capture is open: only THIS thread's calls may invalidate it
+                mode = "thread_local" if getattr(self.mr, "tp_size", 1) > 1 else "global"
+                with torch.cuda.graph(g, pool=self.pool, stream=stream, capture_error_mode=mode):
                     out = self._run(fb)
                 if self.pool is None:
                     self.pool = g.pool()
