@@ -21,7 +21,6 @@
 //   * long sequences are split over gridDim.z; partial (m, l, acc) go to a
 //     caller-owned fp32 workspace and a small second kernel merges them.
 #include "common.hpp"
-#include "cascade_plan.hpp"
 #include "../../include/sglang_amd.h"
 
 using namespace sgl_amd;
@@ -82,11 +81,6 @@ struct DecodeParams {
   int num_splits;
   int min_chunk;              // split chunk granularity (tokens)
   float scale_log2;           // sm_scale * log2(e)
-  // cascade (shared-prefix) mode: this launch covers tokens [kv_start[b], len) of every request
-  // and writes split slot `slot_offset + split` of `slots_total`; empty splits publish (m, l) = (-big, 0)
-  const int32_t* kv_start;    // optional [B]
-  int slot_offset;
-  int slots_total;
   // optional [B] permutation that puts requests sharing a KV prefix next to each other: with it the
   // (request, kv head) workgroups are laid out so that a group's members run on ONE XCD (workgroup
   // i runs on XCD i % 8) and re-read the shared rows from that XCD's L2 instead of HBM
@@ -94,11 +88,10 @@ struct DecodeParams {
 };
 
 __device__ __forceinline__ void split_range(int len, int num_splits, int min_chunk, int split,
-                                            int& c0, int& c1, int start = 0) {
-  const int span = len > start ? len - start : 0;
-  int chunk = (span + num_splits - 1) / num_splits;
+                                            int& c0, int& c1) {
+  int chunk = (len + num_splits - 1) / num_splits;
   chunk = ((chunk + min_chunk - 1) / min_chunk) * min_chunk;
-  c0 = start + split * chunk;
+  c0 = split * chunk;
   c1 = c0 + chunk;
   if (c1 > len) c1 = len;
   if (c0 > len) c0 = len;
@@ -138,23 +131,13 @@ __global__ __launch_bounds__(kThreads) void decode_stage1_kernel(DecodeParams p,
   const int col = lane - sub * LPR;   // 16-byte column inside the row
 
   const int len = p.seq_lens[b];
-  const bool cascade = p.kv_start != nullptr;
   int c0, c1;
-  split_range(len, p.num_splits, p.min_chunk, split, c0, c1, cascade ? p.kv_start[b] : 0);
+  split_range(len, p.num_splits, p.min_chunk, split, c0, c1);
   const int h0 = kvh * group_size + hb * G;                 // first q head of this block
   int g_valid = group_size - hb * G;
   if (g_valid > G) g_valid = G;
 
-  const bool direct = (p.num_splits == 1) && !cascade;
-  if (cascade && c0 >= c1) {
-    if (threadIdx.x < g_valid) {
-      const int64_t base = (static_cast<int64_t>(b) * p.num_q_heads + h0 + threadIdx.x) * p.slots_total +
-                           p.slot_offset + split;
-      p.ws_ml[base * 2 + 0] = kNegBig;
-      p.ws_ml[base * 2 + 1] = 0.f;
-    }
-    return;
-  }
+  const bool direct = p.num_splits == 1;
   if (c0 >= c1) {
     // Empty split: stage 2 skips it (same split_range there).  A zero-length
     // request writes zeros so the output is defined.
@@ -344,8 +327,7 @@ __global__ __launch_bounds__(kThreads) void decode_stage1_kernel(DecodeParams p,
       const float r = (l > 0.f) ? o / l : 0.f;
       p.out[static_cast<int64_t>(b) * p.out_stride + static_cast<int64_t>(hq) * D + d] = f2bf(r);
     } else {
-      const int64_t base = cascade ? (static_cast<int64_t>(b) * p.num_q_heads + hq) * p.slots_total + p.slot_offset + split
-                                   : (static_cast<int64_t>(b) * p.num_q_heads + hq) * p.num_splits + split;
+      const int64_t base = (static_cast<int64_t>(b) * p.num_q_heads + hq) * p.num_splits + split;
       p.ws_acc[base * D + d] = o;
       if (d == 0) {
         p.ws_ml[base * 2 + 0] = m_all;
@@ -458,7 +440,7 @@ int sgl_amd_decode_attention(const void* q, const void* k_cache, const void* v_c
   p.num_splits = num_splits;
   p.min_chunk = sgl_amd_decode_attention_min_chunk();
   p.scale_log2 = sm_scale * 1.4426950408889634f;
-  p.kv_start = nullptr; p.slot_offset = 0; p.slots_total = num_splits; p.batch_order = batch_order;
+  p.batch_order = batch_order;
   const int group = num_q_heads / num_kv_heads;
   const bool use_dpp = (flags & SGL_AMD_ATTN_FLAG_NO_DPP) == 0;
   hipStream_t st = as_stream(stream);

@@ -1,0 +1,65 @@
+"""Host-side decisions that need no GPU: the weight-streaming GEMM's decomposition chooser, the row-count
+policy, the library-GEMM selection file, and that the product never falls back to the CPU."""
+import csv
+
+import pytest
+import torch
+
+from sglang_amd import kernels as K
+from sglang_amd import tuning
+
+
+@pytest.mark.parametrize("M", [1, 16, 64])
+@pytest.mark.parametrize("N,Kd", [(28672, 4096), (4096, 14336), (6144, 4096), (4096, 4096), (128256, 4096),
+                                  (512, 256), (9728, 896), (896, 4864 - 4864 % 128), (16, 128)])
+def test_wstream_config_is_always_launchable(M, N, Kd):
+    """Whatever the cost model prefers, the pair must be one the C entry point accepts."""
+    for need_combine in (False, True):
+        nw, s = K.choose_wstream_config(M, N, Kd, need_combine)
+        assert 4 <= nw <= 8 and 1 <= s <= Kd // 128
+    if N % 32 == 0:
+        nw, s = K.choose_wstream_config(M, N, Kd, True, True)
+        assert 2 <= nw <= 4 and s == 1
+
+
+def test_wstream_config_fills_the_chip_on_the_bench_shapes():
+    """The fitted model reproduces the measured optima (benchmarks/gemm_sweep.py, M = 64): whole 256-group rounds."""
+    assert K.choose_wstream_config(64, 28672, 4096) == (7, 1)          # 1792 tiles = 256 x 7
+    nw, s = K.choose_wstream_config(64, 4096, 14336)                    # 256 tiles: 64 groups x 4 splits
+    assert (256 // nw) * s == 256
+    nw, s = K.choose_wstream_config(64, 4096, 4096)
+    assert (256 // nw) * s == 256
+    assert K.choose_wstream_config(64, 28672, 4096, True, True) == (4, 1)   # one pass, gate + up tile per wave
+
+
+def test_wstream_row_policy():
+    assert K.wstream_supported(64, 4096, 4096) and K.wstream_supported(128, 4096, 4096)
+    assert not K.wstream_supported(129, 4096, 4096) and not K.wstream_supported(0, 4096, 4096)
+    assert not K.wstream_supported(8, 4100, 4096) and not K.wstream_supported(8, 4096, 4000)
+    assert K.wstream_preferred(64, 128256, 4096)
+    assert K.wstream_preferred(128, 4096, 14336) and not K.wstream_preferred(128, 28672, 4096)
+    for M in (65, 128):                                                # beyond 64 rows: narrow groups only
+        nw, s = K.choose_wstream_config(M, 4096, 4096)
+        assert nw in (4, 5)
+        assert K.choose_wstream_config(M, 14336, 4096, True, True)[0] == 2
+
+
+def test_gemm_selection_file_is_wellformed_and_lookup_only_needs_a_gpu():
+    rows = list(csv.reader(open(tuning.RESULTS)))
+    validators = {r[1]: r[2] for r in rows if r[0] == "Validator"}
+    assert validators["GCN_ARCH_NAME"].startswith("gfx950")
+    entries = [r for r in rows if r[0].startswith("GemmTunableOp")]
+    assert len(entries) >= 8 and all(r[0] == "GemmTunableOp_BFloat16_TN" and r[1].startswith("tn_") for r in entries)
+    # the bench's warm-prefill gate_up shape at TP=1 is among them
+    assert any(r[1].startswith("tn_28672_7680_4096_") for r in entries)
+    if not torch.cuda.is_available():
+        assert tuning.load_gemm_selections() is False                  # nothing to select on a CPU-only box
+
+
+def test_kernels_refuse_cpu_tensors():
+    x = torch.zeros((4, 256), dtype=torch.bfloat16)
+    w = torch.zeros((64, 256), dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        K.wstream_gemm(x, w)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        K.rmsnorm(x, torch.ones(256, dtype=torch.bfloat16), 1e-5)
