@@ -254,6 +254,18 @@ int sgl_amd_wstream_qkv_rope(const void* x, const void* w_qkv, const void* bias,
                              int64_t rotary_dim, void* k_cache, void* v_cache, const int64_t* cache_loc,
                              int64_t cache_row_stride, int waves_per_group, int num_k_splits,
                              void* ws_partials, void* stream);
+/* Grouped (mixture-of-experts) form of the weight-streaming GEMM, same contract as sgl_amd_moe_grouped_gemm
+ * (fused_moe_triton_kernels.py:324,771) for shapes with N % 16 == 0 and K % 128 == 0, without split-K: one
+ * workgroup per (row block of moe_align_block_size, group of weight tiles of that block's expert).  fuse_silu=1:
+ * w is [E, 2N, K] and c[id, :N] = silu_and_mul; otherwise c[id, :] = a[id / top_k_div] . w[e]^T, optionally
+ * rounded to bf16 and scaled by topk_weights[id], written bf16 or fp32 (out_f32). */
+int sgl_amd_wstream_moe_gemm(const void* a, const void* w, void* c, const int32_t* sorted_token_ids,
+                             const int32_t* expert_ids, const int32_t* num_tokens_post_padded,
+                             const float* topk_weights, int mul_routed_weight, int round_before_scale,
+                             int top_k_div, int64_t num_valid_ids, int64_t N, int64_t K,
+                             int64_t a_row_stride, int64_t w_row_stride, int64_t w_expert_stride,
+                             int64_t c_row_stride, int block_m, int64_t max_m_blocks, int fuse_silu,
+                             int out_f32, int waves_per_group, void* stream);
 int sgl_amd_wstream_gemm_max_rows(void);
 int64_t sgl_amd_wstream_gemm_workspace_floats(int64_t M, int64_t N, int num_k_splits);
 /* Grouped GEMM over moe_align_block_size output: for every row block b < num_tokens_post_padded/block_m

@@ -54,6 +54,16 @@ struct WsParams {
   float* part;           // [splits, M, N] fp32, or NULL: write y directly
   int64_t x_stride, w_stride, y_stride;
   int M, N, K, splits, ntiles;
+  // grouped (mixture-of-experts) form: blockIdx.y = row block of moe_align_block_size's output, rows gathered /
+  // scattered through sorted_ids, weights of expert expert_ids[block]; M = number of valid (token, k) pair ids
+  const int32_t* sorted_ids;    // [>= blocks * 16 MT]  pair ids, padding >= M
+  const int32_t* expert_ids;    // [blocks], < 0: filtered expert
+  const int32_t* num_post_pad;  // [1]
+  const float* row_scale;       // optional [M] router weights
+  int64_t w_expert_stride;
+  int topk_div;                 // source row of pair id = id / topk_div
+  int out_f32;                  // y is fp32 (the down projection ahead of moe_sum_reduce)
+  int round_before_scale;       // round the accumulator to bf16 before the router weight (fused_moe_native.py:157-163)
 };
 
 // ---- LDS-DMA plumbing ------------------------------------------------------------------------
@@ -106,7 +116,7 @@ constexpr int ring_depth(int mt, int nw, int tpw) {
 
 // TPW = 16-row weight tiles per wave.  TPW == 2 is the silu_and_mul form: the wave owns gate tile t and up
 // tile t + ntiles/2 and writes y[m, 16 t ..] = silu(gate) * up (no partials, no second launch).
-template <int MT, int NW, int TPW>
+template <int MT, int NW, int TPW, bool GROUPED>
 __global__ __launch_bounds__(64 * NW, 1) void wstream_gemm_kernel(WsParams p) {
   constexpr int PD = ring_depth(MT, NW, TPW);
   constexpr int XPIECES = MT * 4;                       // 1 KiB pieces (4 rows x 256 B) of an activation chunk
@@ -125,7 +135,15 @@ __global__ __launch_bounds__(64 * NW, 1) void wstream_gemm_kernel(WsParams p) {
   const int wtiles = p.ntiles / TPW;                    // tiles a wave index ranges over
   const int tile = blockIdx.x * NW + wid;
   const bool active = tile < wtiles;
-  const int split = blockIdx.y;
+  const int split = GROUPED ? 0 : blockIdx.y;
+  const int rb = GROUPED ? blockIdx.y : 0;              // row block (grouped form)
+  const uint16_t* wbase = p.w;
+  if constexpr (GROUPED) {
+    if (rb * (16 * MT) >= p.num_post_pad[0]) return;
+    const int e = p.expert_ids[rb];
+    if (e < 0) return;                                  // filtered expert (EP): its rows stay untouched
+    wbase += static_cast<int64_t>(e) * p.w_expert_stride;
+  }
   const int nch = p.K / kKC;
   const int cb = static_cast<int>(static_cast<int64_t>(split) * nch / p.splits);
   const int ce = static_cast<int>(static_cast<int64_t>(split + 1) * nch / p.splits);
@@ -141,7 +159,7 @@ __global__ __launch_bounds__(64 * NW, 1) void wstream_gemm_kernel(WsParams p) {
 #pragma unroll
     for (int j = 0; j < kKSteps; ++j) {
       const int row = 4 * j + q4;
-      wsrc[t][j] = p.w + (static_cast<int64_t>((active ? tile : wtiles - 1) + t * wtiles) * 16 + row) * p.w_stride +
+      wsrc[t][j] = wbase + (static_cast<int64_t>((active ? tile : wtiles - 1) + t * wtiles) * 16 + row) * p.w_stride +
                    ((s16 ^ row) & 15) * 8 + static_cast<int64_t>(cb) * kKC;
     }
   const uint16_t* xsrc[XP];
@@ -151,7 +169,13 @@ __global__ __launch_bounds__(64 * NW, 1) void wstream_gemm_kernel(WsParams p) {
     const int piece = wid + NW * i;
     const bool real = piece < XPIECES;
     const int row = real ? 4 * piece + q4 : 0;
-    const int srow = row < p.M ? row : p.M - 1;
+    int srow;
+    if constexpr (GROUPED) {
+      const int id = p.sorted_ids[rb * (16 * MT) + row];
+      srow = id < p.M ? id / p.topk_div : 0;            // padding rows read row 0: their columns are discarded
+    } else {
+      srow = row < p.M ? row : p.M - 1;
+    }
     xsrc[i] = p.x + static_cast<int64_t>(srow) * p.x_stride + ((s16 ^ row) & 15) * 8 + static_cast<int64_t>(cb) * kKC;
     xoff[i] = real ? WCH + piece * 1024 : -1;
   }
@@ -247,48 +271,51 @@ __global__ __launch_bounds__(64 * NW, 1) void wstream_gemm_kernel(WsParams p) {
   if (!active) return;
   // lane holds C[m = 16 mt + r16][n = 16 tile + 4 g + r]
   const int n0 = tile * 16 + g * 4;
-  if constexpr (TPW == 2) {
-    // linear -> bf16, silu -> bf16, product -> bf16 (activation.py:141-143)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int m = mt * 16 + r16;
+  for (int mt = 0; mt < MT; ++mt) {
+    int64_t m = mt * 16 + r16;                           // output row
+    float scale = 1.f;
+    if constexpr (GROUPED) {
+      const int id = p.sorted_ids[rb * (16 * MT) + mt * 16 + r16];
+      if (id >= p.M) continue;
+      m = id;
+      if (p.row_scale) scale = p.row_scale[id];
+    } else {
       if (m >= p.M) continue;
-      float o[4];
+    }
+    float o[4];
+    if constexpr (TPW == 2) {
+      // linear -> bf16, silu -> bf16, product -> bf16 (activation.py:141-143)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float gb = rbf(acc[0][mt][r]);
         const float sl = rbf(gb / (1.0f + expf(-gb)));
         o[r] = sl * rbf(acc[1][mt][r]);
       }
+    } else {
+      if (!GROUPED && p.part) {
+        float* base = p.part + static_cast<int64_t>(split) * p.M * p.N;
+        *reinterpret_cast<f32x4_t*>(base + m * p.N + n0) = acc[0][mt];
+        continue;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = acc[0][mt][r];
+      if (!GROUPED && p.bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] += bf2f(p.bias[n0 + r]);
+      }
+    }
+    if (GROUPED && p.row_scale) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = (p.round_before_scale ? rbf(o[r]) : o[r]) * scale;
+    }
+    if (GROUPED && p.out_f32) {
+      *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(p.y) + m * p.y_stride + n0) = f32x4_t{o[0], o[1], o[2], o[3]};
+    } else {
       uint2 w2;
       w2.x = pack_bf2(o[0], o[1]);
       w2.y = pack_bf2(o[2], o[3]);
-      *reinterpret_cast<uint2*>(p.y + static_cast<int64_t>(m) * p.y_stride + n0) = w2;
-    }
-    return;
-  } else {
-    if (p.part) {
-      float* base = p.part + static_cast<int64_t>(split) * p.M * p.N;
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const int m = mt * 16 + r16;
-        if (m < p.M) *reinterpret_cast<f32x4_t*>(base + static_cast<int64_t>(m) * p.N + n0) = acc[0][mt];
-      }
-      return;
-    }
-    float b4[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) b4[r] = bf2f(p.bias[n0 + r]);
-    }
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int m = mt * 16 + r16;
-      if (m >= p.M) continue;
-      uint2 w2;
-      w2.x = pack_bf2(acc[0][mt][0] + b4[0], acc[0][mt][1] + b4[1]);
-      w2.y = pack_bf2(acc[0][mt][2] + b4[2], acc[0][mt][3] + b4[3]);
-      *reinterpret_cast<uint2*>(p.y + static_cast<int64_t>(m) * p.y_stride + n0) = w2;
+      *reinterpret_cast<uint2*>(p.y + m * p.y_stride + n0) = w2;
     }
   }
 }
@@ -485,10 +512,15 @@ __global__ __launch_bounds__(256) void wstream_combine_rope_kernel(RopeParams p)
 
 // the activation image of a chunk grows with M: beyond 64 rows only the narrower groups keep a 3-deep ring
 template <int MT, int NW, int TPW>
-int launch_main(const WsParams& p, hipStream_t st) {
+int launch_main(const WsParams& p, hipStream_t st, int row_blocks = 0) {
   if constexpr (ring_depth(MT, NW, TPW) >= 3) {
-    dim3 grid((p.ntiles / TPW + NW - 1) / NW, p.splits);
-    hipLaunchKernelGGL((wstream_gemm_kernel<MT, NW, TPW>), grid, dim3(64 * NW), 0, st, p);
+    dim3 grid((p.ntiles / TPW + NW - 1) / NW, row_blocks ? row_blocks : p.splits);
+    if (row_blocks) {
+      if constexpr (MT <= 4) hipLaunchKernelGGL((wstream_gemm_kernel<MT, NW, TPW, true>), grid, dim3(64 * NW), 0, st, p);
+      else return -1;
+    } else {
+      hipLaunchKernelGGL((wstream_gemm_kernel<MT, NW, TPW, false>), grid, dim3(64 * NW), 0, st, p);
+    }
     return 0;
   } else {
     return -1;
@@ -496,21 +528,21 @@ int launch_main(const WsParams& p, hipStream_t st) {
 }
 
 template <int MT>
-int launch_nw(const WsParams& p, int nw, bool fused_silu, hipStream_t st) {
+int launch_nw(const WsParams& p, int nw, bool fused_silu, hipStream_t st, int row_blocks = 0) {
   if (fused_silu) {                                   // two tiles per wave: half the waves for the same LDS ring
     switch (nw) {
-      case 2: return launch_main<MT, 2, 2>(p, st);
-      case 3: return launch_main<MT, 3, 2>(p, st);
-      case 4: return launch_main<MT, 4, 2>(p, st);
+      case 2: return launch_main<MT, 2, 2>(p, st, row_blocks);
+      case 3: return launch_main<MT, 3, 2>(p, st, row_blocks);
+      case 4: return launch_main<MT, 4, 2>(p, st, row_blocks);
       default: return -1;
     }
   }
   switch (nw) {
-    case 4: return launch_main<MT, 4, 1>(p, st);
-    case 5: return launch_main<MT, 5, 1>(p, st);
-    case 6: return launch_main<MT, 6, 1>(p, st);
-    case 7: return launch_main<MT, 7, 1>(p, st);
-    case 8: return launch_main<MT, 8, 1>(p, st);
+    case 4: return launch_main<MT, 4, 1>(p, st, row_blocks);
+    case 5: return launch_main<MT, 5, 1>(p, st, row_blocks);
+    case 6: return launch_main<MT, 6, 1>(p, st, row_blocks);
+    case 7: return launch_main<MT, 7, 1>(p, st, row_blocks);
+    case 8: return launch_main<MT, 8, 1>(p, st, row_blocks);
     default: return -1;
   }
 }
@@ -591,6 +623,50 @@ int sgl_amd_wstream_gemm(const void* x, const void* w, const void* bias, void* y
     }
   }
   SGL_CHECK_LAUNCH("wstream_gemm");
+  return 0;
+}
+
+int sgl_amd_wstream_moe_gemm(const void* a, const void* w, void* c, const int32_t* sorted_token_ids,
+                             const int32_t* expert_ids, const int32_t* num_tokens_post_padded,
+                             const float* topk_weights, int mul_routed_weight, int round_before_scale, int top_k_div,
+                             int64_t num_valid_ids, int64_t N, int64_t K, int64_t a_row_stride, int64_t w_row_stride,
+                             int64_t w_expert_stride, int64_t c_row_stride, int block_m, int64_t max_m_blocks,
+                             int fuse_silu, int out_f32, int waves_per_group, void* stream) {
+  SGL_CLEAR_STALE_ERROR();
+  SGL_CHECK_ARG(block_m == 16 || block_m == 32 || block_m == 48 || block_m == 64,
+                "wstream_moe_gemm: block_m=%d (supported: 16/32/48/64, must equal the moe_align block size)", block_m);
+  const int64_t wn = fuse_silu ? 2 * N : N;             // weight rows per expert
+  SGL_CHECK_ARG(N > 0 && wn % (fuse_silu ? 32 : 16) == 0 && K >= kKC && K % kKC == 0,
+                "wstream_moe_gemm: need N %% 16 == 0 and K %% %d == 0 (got N=%lld K=%lld)", kKC, (long long)N, (long long)K);
+  SGL_CHECK_ARG(a_row_stride % 8 == 0 && w_row_stride % 8 == 0 && c_row_stride % 4 == 0,
+                "wstream_moe_gemm: row strides must keep 16-byte (a, w) / 8-byte (c) alignment");
+  SGL_CHECK_ARG(top_k_div >= 1 && max_m_blocks <= 65535, "wstream_moe_gemm: bad top_k_div / too many row blocks");
+  SGL_CHECK_ARG(!mul_routed_weight || topk_weights, "wstream_moe_gemm: mul_routed_weight needs topk_weights");
+  SGL_CHECK_ARG(!(fuse_silu && out_f32), "wstream_moe_gemm: the silu form writes bf16");
+  SGL_CHECK_ARG(fuse_silu ? (waves_per_group >= 2 && waves_per_group <= 4) : (waves_per_group >= 4 && waves_per_group <= 8),
+                "wstream_moe_gemm: waves_per_group must be 4..8 (2..4 for the silu form), got %d", waves_per_group);
+  if (max_m_blocks == 0 || num_valid_ids == 0) return 0;
+  WsParams p{};
+  p.x = static_cast<const uint16_t*>(a);
+  p.w = static_cast<const uint16_t*>(w);
+  p.y = static_cast<uint16_t*>(c);
+  p.x_stride = a_row_stride; p.w_stride = w_row_stride; p.y_stride = c_row_stride; p.w_expert_stride = w_expert_stride;
+  p.M = static_cast<int>(num_valid_ids); p.N = static_cast<int>(wn); p.K = static_cast<int>(K);
+  p.splits = 1; p.ntiles = static_cast<int>(wn / 16);
+  p.sorted_ids = sorted_token_ids; p.expert_ids = expert_ids; p.num_post_pad = num_tokens_post_padded;
+  p.row_scale = mul_routed_weight ? topk_weights : nullptr;
+  p.topk_div = top_k_div; p.out_f32 = out_f32; p.round_before_scale = round_before_scale;
+  hipStream_t st = as_stream(stream);
+  const int blocks = static_cast<int>(max_m_blocks);
+  int rc;
+  switch (block_m / 16) {
+    case 1: rc = launch_nw<1>(p, waves_per_group, fuse_silu != 0, st, blocks); break;
+    case 2: rc = launch_nw<2>(p, waves_per_group, fuse_silu != 0, st, blocks); break;
+    case 3: rc = launch_nw<3>(p, waves_per_group, fuse_silu != 0, st, blocks); break;
+    default: rc = launch_nw<4>(p, waves_per_group, fuse_silu != 0, st, blocks); break;
+  }
+  SGL_CHECK_ARG(rc == 0, "wstream_moe_gemm: unsupported configuration");
+  SGL_CHECK_LAUNCH("wstream_moe_gemm");
   return 0;
 }
 

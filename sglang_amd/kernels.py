@@ -600,6 +600,41 @@ def wstream_qkv_rope(x: torch.Tensor, w_qkv: torch.Tensor, bias: Optional[torch.
     return q_out
 
 
+def moe_wstream_gemm(a: torch.Tensor, w: torch.Tensor, c: torch.Tensor, sorted_token_ids: torch.Tensor,
+                     expert_ids: torch.Tensor, num_tokens_post_padded: torch.Tensor,
+                     topk_weights: Optional[torch.Tensor], mul_routed_weight: bool, top_k_div: int, num_valid_ids: int,
+                     block_m: int, fuse_silu: bool = False, round_before_scale: bool = False,
+                     waves_per_group: Optional[int] = None) -> torch.Tensor:
+    """moe_grouped_gemm on the weight-streaming kernel (no split-K): a [rows, K] bf16, w [E, N(or 2N), K] bf16,
+    c [num_valid_ids, N] bf16 or fp32; needs N % 16 == 0 and K % 128 == 0."""
+    _dev(a, w, c, sorted_token_ids, expert_ids, num_tokens_post_padded)
+    _need(a.dtype == _BF16 and w.dtype == _BF16 and w.dim() == 3, "moe_wstream_gemm: bf16 a / w[E,N,K]")
+    _need(c.dtype in (_BF16, torch.float32) and c.dim() == 2, "moe_wstream_gemm: c bf16 / fp32 [rows, N]")
+    _need(sorted_token_ids.dtype == torch.int32 and expert_ids.dtype == torch.int32
+          and num_tokens_post_padded.dtype == torch.int32, "moe_wstream_gemm: int32 metadata")
+    E, WN, K = w.shape
+    N = WN // 2 if fuse_silu else WN
+    _need(a.shape[1] == K and c.shape[1] == N and a.stride(1) == 1 and w.stride(2) == 1 and c.stride(1) == 1,
+          "moe_wstream_gemm: shapes / contiguity")
+    max_m_blocks = expert_ids.numel()
+    _need(sorted_token_ids.numel() >= max_m_blocks * block_m, "moe_wstream_gemm: sorted_token_ids too short")
+    if mul_routed_weight:
+        _need(topk_weights is not None and topk_weights.dtype == torch.float32 and topk_weights.is_contiguous(),
+              "moe_wstream_gemm: fp32 topk_weights")
+    if waves_per_group is None:
+        # widest group that still gives every CU a workgroup (about num_valid_ids / block_m + E row blocks are live)
+        live = max(1, min(max_m_blocks, num_valid_ids // block_m + E))
+        tiles = (N // 16)
+        cands = (4, 3, 2) if fuse_silu else (8, 7, 6, 5, 4)
+        waves_per_group = next((nw for nw in cands if -(-tiles // nw) * live >= _NUM_CUS), cands[-1])
+    native.call("sgl_amd_wstream_moe_gemm", a.data_ptr(), w.data_ptr(), c.data_ptr(), sorted_token_ids.data_ptr(),
+                expert_ids.data_ptr(), num_tokens_post_padded.data_ptr(), _ptr(topk_weights),
+                1 if mul_routed_weight else 0, 1 if round_before_scale else 0, top_k_div, num_valid_ids, N, K,
+                a.stride(0), w.stride(1), w.stride(0), c.stride(0), block_m, max_m_blocks, 1 if fuse_silu else 0,
+                1 if c.dtype == torch.float32 else 0, waves_per_group, _stream())
+    return c
+
+
 def moe_grouped_gemm(a: torch.Tensor, w: torch.Tensor, c: torch.Tensor, sorted_token_ids: torch.Tensor,
                      expert_ids: torch.Tensor, num_tokens_post_padded: torch.Tensor,
                      topk_weights: Optional[torch.Tensor], mul_routed_weight: bool, top_k_div: int, num_valid_ids: int,
@@ -687,10 +722,12 @@ def moe_sum_reduce(x: torch.Tensor, out: torch.Tensor, routed_scaling_factor: fl
 
 
 def choose_moe_block_m(num_pairs: int, num_experts: int) -> int:
-    """Row-block height of the grouped GEMM: the smallest of 16/32/64 that holds an average expert's rows."""
+    """Row-block height of the grouped GEMM: the smallest of 16/32/48/64 that holds 1.5x an average expert's
+    rows -- an expert whose rows spill into a second block streams its weights twice, padded rows cost nothing
+    (the kernel is bound by the weight stream)."""
     avg = (num_pairs + num_experts - 1) // max(1, num_experts)
-    for bm in (16, 32):
-        if avg <= bm:
+    for bm in (16, 32, 48):
+        if avg + avg // 2 <= bm:
             return bm
     return 64
 
@@ -714,11 +751,13 @@ def fused_experts(hidden_states: torch.Tensor, w13: torch.Tensor, w2: torch.Tens
     block_m = choose_moe_block_m(numel, E)
     sorted_ids, expert_ids, post = moe_align_block_size(topk_ids, block_m, E)
     inter = torch.empty((numel, N), dtype=_BF16, device=dev)
-    moe_grouped_gemm(hidden_states, w13, inter, sorted_ids, expert_ids, post, None, False, topk, numel, block_m,
-                     fuse_silu=True)
+    # the weight-streaming form wherever its tiling fits (N % 16, K % 128); the skinny kernel takes ragged shapes
+    up = moe_wstream_gemm if (N % 16 == 0 and K % 128 == 0) else moe_grouped_gemm
+    dn = moe_wstream_gemm if (K % 16 == 0 and N % 128 == 0) else moe_grouped_gemm
+    up(hidden_states, w13, inter, sorted_ids, expert_ids, post, None, False, topk, numel, block_m, fuse_silu=True)
     down = torch.empty((numel, K), dtype=torch.float32, device=dev)
-    moe_grouped_gemm(inter, w2, down, sorted_ids, expert_ids, post, topk_weights.reshape(-1).contiguous(), True, 1, numel,
-                     block_m, round_before_scale=True)
+    dn(inter, w2, down, sorted_ids, expert_ids, post, topk_weights.reshape(-1).contiguous(), True, 1, numel, block_m,
+       round_before_scale=True)
     moe_sum_reduce(down.view(M, topk, K), out, routed_scaling_factor)
     return out
 

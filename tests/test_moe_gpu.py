@@ -173,3 +173,36 @@ def test_mixtral_block_module(device):
     tw, ti = oo.fused_topk(logits, cfg.num_experts_per_tok, True)
     want = oo.moe_forward(x, blk.experts.w13_weight.data.cpu(), blk.experts.w2_weight.data.cpu(), tw, ti)
     _moe_check(got, want)
+
+
+@pytest.mark.parametrize("M,E,k,N,Kd,bm", [(50, 8, 2, 320, 384, 32), (64, 8, 2, 1792, 1024, 16), (3, 4, 2, 64, 128, 64),
+                                           (130, 8, 2, 256, 256, 48)])
+def test_wstream_moe_gemm_row_gather_scale_and_silu(device, M, E, k, N, Kd, bm):
+    """The weight-streaming grouped form vs a per-pair loop (invoke_fused_moe_kernel semantics,
+    fused_moe_triton_kernels.py:324-770): gather a[id // topk], scatter to c[id], router weight, fp32 / bf16
+    outputs, and the silu_and_mul epilogue against the unfused ops on the same accumulators."""
+    K = _k()
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn((M, Kd), generator=g).to(BF)
+    w = (torch.randn((E, N, Kd), generator=g) * 0.05).to(BF)
+    ids = torch.argsort(torch.rand((M, E), generator=g), dim=1)[:, :k].to(torch.int32)
+    tw = torch.rand((M, k), generator=g)
+    s, e, post = K.moe_align_block_size(ids.to(device), bm, E)
+    want = torch.empty((M * k, N))
+    for i in range(M * k):
+        want[i] = (a[i // k].double() @ w[int(ids.flatten()[i])].double().t()).float()
+    for f32 in (False, True):
+        c = torch.zeros((M * k, N), dtype=torch.float32 if f32 else BF, device=device)
+        K.moe_wstream_gemm(a.to(device), w.to(device), c, s, e, post, tw.reshape(-1).to(device), True, k, M * k, bm,
+                           round_before_scale=f32)
+        ref = (want.to(BF).float() if f32 else want) * tw.flatten()[:, None]
+        d = (c.cpu().float() - ref).abs()
+        assert bool((d <= ref.abs() * 2.0 ** -7 + 1e-3).all()), float(d.max())
+    # silu form: w = [gate rows | up rows] of N/2 columns each
+    c_plain = torch.zeros((M * k, N), dtype=BF, device=device)
+    K.moe_wstream_gemm(a.to(device), w.to(device), c_plain, s, e, post, None, False, k, M * k, bm)
+    c_silu = torch.zeros((M * k, N // 2), dtype=BF, device=device)
+    K.moe_wstream_gemm(a.to(device), w.to(device), c_silu, s, e, post, None, False, k, M * k, bm, fuse_silu=True)
+    ref = oo.silu_and_mul(c_plain.cpu())
+    d = (c_silu.cpu().float() - ref.float()).abs()
+    assert float((d > 0).float().mean()) < 0.005 and bool((d <= ref.float().abs() * 2.0 ** -7 + 1e-6).all())
