@@ -156,7 +156,7 @@ def main():
         sync(); t2 = time.perf_counter()
         for _ in range(args.out - 1):
             eng.decode_step()
-            eng.flush_decode_outputs()        # the scheduler's per-step token hand-off (one sync)
+            eng.flush_decode_outputs(lag=1)   # per-step token hand-off, one step behind the launch (overlap scheduling)
         sync(); t3 = time.perf_counter()
         reqs = list(eng.running)
         hit = sum(q.cached_tokens for q in reqs)

@@ -247,7 +247,13 @@ class Engine:
             self.logits_trace.append(logits.next_token_logits.float().cpu())
         next_ids = r.sample(logits, fb)
         st["last_ids"] = next_ids.to(torch.int64)
-        st["pending"].append(next_ids)
+        # token hand-off to the host: an async copy into pinned memory + an event, so that the scheduler can
+        # launch step N+1 before it looks at step N's tokens (overlap scheduling, scheduler.py:1783)
+        host = st["free_host"].pop() if st["free_host"] else torch.empty(next_ids.shape, dtype=next_ids.dtype, pin_memory=True)
+        host.copy_(next_ids, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        st["pending"].append((host, ev))
         return next_ids
 
     def _build_decode_state(self, reqs: Sequence[Req]):
@@ -257,20 +263,24 @@ class Engine:
                     seq_lens=torch.tensor(seq, dtype=torch.int32, device=dev),
                     seq_lens_cpu=torch.tensor(seq, dtype=torch.int64),
                     last_ids=torch.tensor([q.output_ids[-1] for q in reqs], dtype=torch.int64, device=dev),
-                    pending=[])
+                    pending=[], free_host=[])
 
     _decode_state = None
 
-    def flush_decode_outputs(self) -> None:
-        """Bring the sampled ids of the steps since the last flush to the host (one sync)."""
+    def flush_decode_outputs(self, lag: int = 0) -> None:
+        """Hand the sampled ids of the finished steps to the requests.  `lag` = newest steps left in flight:
+        with lag=1 the host only waits for the step BEFORE the one it has just launched, so the GPU never idles
+        on the host's per-step bookkeeping (the reference's overlap scheduler)."""
         st = self._decode_state
-        if not st or not st["pending"]:
+        if not st or len(st["pending"]) <= lag:
             return
-        ids = torch.stack(st["pending"]).tolist()
-        st["pending"] = []
-        for step in ids:
-            for q, t in zip(self.running, step):
-                q.output_ids.append(int(t))
+        n = len(st["pending"]) - lag
+        ready, st["pending"] = st["pending"][:n], st["pending"][n:]
+        for host, ev in ready:
+            ev.synchronize()
+            for q, t in zip(self.running, host.tolist()):
+                q.output_ids.append(t)
+            st["free_host"].append(host)
 
     # ---- finish (batch_result_processor.py:863 -> mem_cache/common.py:198 release_kv_cache) ----
     def finish(self, reqs: Sequence[Req]) -> None:
