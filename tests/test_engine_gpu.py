@@ -158,3 +158,45 @@ def test_decode_batch_beyond_64_rows_matches_oracle(device):
     eng.finish(list(eng.running))
     outs = [q.output_ids for q in done]
     _check_against_oracle(cfg, runner, prompts, outs, eng.logits_trace, new_tokens)
+
+
+def test_one_llama3_8b_layer_at_the_bench_batch_matches_oracle(device):
+    """The BASELINE.json shapes themselves (hidden 4096, 32 / 8 heads of 128, intermediate 14336, vocab 128256),
+    one decoder layer deep so that the CPU oracle finishes in seconds: 4 groups x 16 requests with a shared prefix
+    long enough for the cascade plan, hipGraph decode with the fused GEMM + combine layer."""
+    import dataclasses
+
+    from sglang_amd.harness.engine import Engine, ModelRunner, Req
+    from sglang_amd.harness.models import CONFIGS
+
+    cfg = dataclasses.replace(CONFIGS["llama-3-8b"], num_hidden_layers=1, name="llama-3-8b-1layer")
+    G, P, shared, unique, new_tokens = 4, 16, 144, 8, 3
+    B = G * P
+    runner = ModelRunner(cfg, max_total_tokens=B * (shared + unique + new_tokens) + 1024, max_running_requests=B,
+                         max_context_len=256, device=device, use_graph=True, graph_max_bs=B)
+    eng = Engine(runner)
+    rnd = random.Random(2)
+    prompts = []
+    for g in range(G):
+        sys_p = [rnd.randrange(cfg.vocab_size) for _ in range(shared)]
+        prompts += [sys_p + [rnd.randrange(cfg.vocab_size) for _ in range(unique)] for _ in range(P)]
+    eng.logits_trace = []
+    reqs = [Req(i, p, new_tokens) for i, p in enumerate(prompts)]
+    leaders = [q for q in reqs if q.rid % P == 0]
+    rest = [q for q in reqs if q.rid % P != 0]
+    eng.prefill(leaders)
+    eng.prefill(rest)
+    assert all(q.cached_tokens == shared for q in rest)
+    for _ in range(new_tokens - 1):
+        eng.decode_step()
+    done = list(eng.running)                                   # leaders first, then the rest
+    eng.finish(list(eng.running))
+    order = [q.rid for q in done]
+    outs = [None] * B
+    for q in done:
+        outs[q.rid] = q.output_ids
+    tr = eng.logits_trace
+    steps = [torch.cat([tr[0], tr[1]])] + tr[2:]
+    inv = [order.index(i) for i in range(B)]
+    trace = [s[inv] for s in steps]
+    _check_against_oracle(cfg, runner, prompts, outs, trace, new_tokens)
