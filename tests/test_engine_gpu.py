@@ -199,4 +199,16 @@ def test_one_llama3_8b_layer_at_the_bench_batch_matches_oracle(device):
     steps = [torch.cat([tr[0], tr[1]])] + tr[2:]
     inv = [order.index(i) for i in range(B)]
     trace = [s[inv] for s in steps]
-    _check_against_oracle(cfg, runner, prompts, outs, trace, new_tokens)
+    # 64 x 128256 logits of magnitude up to ~7 per step: the two bf16 pipelines (bf16 activations into a 4096-term
+    # dot product, bf16 logits out) differ like independent roundings do -- measured max 0.055 / rms 0.004 -- so the
+    # bar is statistical here: rms, a 5-sigma-ish max, and the arg-max wherever the oracle's margin is clear.
+    oracle = OracleLM(cfg, weights_from_product_model(runner.model), compute_dtype=torch.float32, max_reqs=B,
+                      num_slots=B * (shared + unique + new_tokens) + 64)
+    _, ref_logits = oracle.generate(prompts, new_tokens, return_logits=True, forced=outs)
+    for step, (got, ref) in enumerate(zip(trace, ref_logits)):
+        d = (got - ref).abs()
+        assert float(d.pow(2).mean().sqrt()) < 1e-2, f"step {step}: rms {float(d.pow(2).mean().sqrt())}"
+        assert float(d.max()) < 0.12, f"step {step}: max {float(d.max())}"
+        top2 = ref.topk(2, dim=-1).values
+        clear = (top2[:, 0] - top2[:, 1]) > 0.15
+        assert torch.equal(got.argmax(-1)[clear], ref.argmax(-1)[clear]), f"step {step}: arg-max on clear margins"
