@@ -207,48 +207,57 @@ __global__ __launch_bounds__(64 * NW, 1) void wstream_gemm_kernel(WsParams p) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[t][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  auto read_frags = [&](uint32_t slot_addr, int kk, u32x4_t (&a)[TPW], u32x4_t (&b)[MT]) {
+  // fragment reads of one "stage": up to 64 rows the stage is a whole k-step (A tiles + all B tiles); beyond, a
+  // k-step is two stages (A tiles + first half of the B tiles, then the second half) so that the reads of two
+  // consecutive stages stay inside the 4-bit lgkmcnt while one stage is always read ahead of the MFMAs
+  constexpr bool WIDE = MT > 4;
+  constexpr int H = WIDE ? MT / 2 : MT;                // B tiles per stage
+  constexpr int NST = WIDE ? 2 * kKSteps : kKSteps;    // stages per chunk
+  auto read_stage = [&](uint32_t slot_addr, int st, u32x4_t (&a)[TPW], u32x4_t (&b)[H]) {
+    const int kk = WIDE ? st >> 1 : st;
+    const int half = WIDE ? st & 1 : 0;
     const uint32_t ad = slot_addr + foff[kk];
-    a[0] = lds_rd<0>(ad + wid * WWAVE);
-    if constexpr (TPW > 1) a[1] = lds_rd<4096>(ad + wid * WWAVE);
-    b[0] = lds_rd<WCH>(ad);
-    if constexpr (MT > 1) b[1] = lds_rd<WCH + 4096>(ad);
-    if constexpr (MT > 2) b[2] = lds_rd<WCH + 8192>(ad);
-    if constexpr (MT > 3) b[3] = lds_rd<WCH + 12288>(ad);
-    if constexpr (MT > 4) b[4] = lds_rd<WCH + 16384>(ad);
-    if constexpr (MT > 5) b[5] = lds_rd<WCH + 20480>(ad);
-    if constexpr (MT > 6) b[6] = lds_rd<WCH + 24576>(ad);
-    if constexpr (MT > 7) b[7] = lds_rd<WCH + 28672>(ad);
+    if (half == 0) {
+      a[0] = lds_rd<0>(ad + wid * WWAVE);
+      if constexpr (TPW > 1) a[1] = lds_rd<4096>(ad + wid * WWAVE);
+    }
+    const uint32_t bd = ad + half * (H * 4096);
+    b[0] = lds_rd<WCH>(bd);
+    if constexpr (H > 1) b[1] = lds_rd<WCH + 4096>(bd);
+    if constexpr (H > 2) b[2] = lds_rd<WCH + 8192>(bd);
+    if constexpr (H > 3) b[3] = lds_rd<WCH + 12288>(bd);
   };
   auto compute = [&](int slot) {
     const uint32_t slot_addr = ring_addr + slot * CH;
-    constexpr bool AHEAD = 2 * (MT + TPW) <= 15;       // lgkmcnt is a 4-bit counter
-    u32x4_t a[2][TPW], b[2][MT];
-    if constexpr (AHEAD) read_frags(slot_addr, 0, a[0], b[0]);
+    u32x4_t a[2][TPW], b[2][H];                          // a: by k-step parity, b: by stage parity
+    read_stage(slot_addr, 0, a[0], b[0]);
 #pragma unroll
-    for (int kk = 0; kk < kKSteps; ++kk) {
-      const int cur = AHEAD ? (kk & 1) : 0;
-      if constexpr (AHEAD) {
-        if (kk + 1 < kKSteps) {
-          read_frags(slot_addr, kk + 1, a[cur ^ 1], b[cur ^ 1]);
-          wait_lgkm<MT + TPW>();
-        } else {
-          wait_lgkm<0>();
-        }
+    for (int st = 0; st < NST; ++st) {
+      const int kk = WIDE ? st >> 1 : st;
+      const int half = WIDE ? st & 1 : 0;
+      const int ac = kk & 1, bc = st & 1;
+      if (st + 1 < NST) {
+        const int nkk = WIDE ? (st + 1) >> 1 : st + 1;
+        read_stage(slot_addr, st + 1, a[nkk & 1], b[bc ^ 1]);
+        // outstanding reads of stage st+1: its B tiles, plus the A tiles when it opens a k-step
+        if ((WIDE ? ((st + 1) & 1) : 0) == 0) wait_lgkm<H + TPW>();
+        else wait_lgkm<H>();
       } else {
-        read_frags(slot_addr, kk, a[0], b[0]);
         wait_lgkm<0>();
       }
+      if (half == 0) {
 #pragma unroll
-      for (int t = 0; t < TPW; ++t) pin(a[cur][t]);
+        for (int t = 0; t < TPW; ++t) pin(a[ac][t]);
+      }
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) pin(b[cur][mt]);
+      for (int j = 0; j < H; ++j) pin(b[bc][j]);
 #pragma unroll
       for (int t = 0; t < TPW; ++t)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-          acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[cur][t]),
-                                                               __builtin_bit_cast(bf16x8_t, b[cur][mt]), acc[t][mt], 0, 0, 0);
+        for (int j = 0; j < H; ++j)
+          acc[t][half * H + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[ac][t]),
+                                                                       __builtin_bit_cast(bf16x8_t, b[bc][j]),
+                                                                       acc[t][half * H + j], 0, 0, 0);
     }
   };
 
