@@ -495,6 +495,11 @@ int sgl_amd_cascade_plan(const int32_t* req_to_token, int64_t req_to_token_strid
   SGL_CHECK_ARG(max_items >= 1 && plan && max_context_len >= 1, "cascade_plan: bad plan arguments");
   const int members_per_item = kRowsPerItem / (num_q_heads / num_kv_heads);
   const int chunks = static_cast<int>((max_context_len + kChunk - 1) / kChunk);
+  // every request's private chunks must fit behind the shared items (which may use max_items / 2): a list that
+  // silently dropped a chunk would drop its tokens from the attention
+  SGL_CHECK_ARG(max_items >= 2 * batch * (chunks + 1),
+                "cascade_plan: max_items=%lld too small for batch=%lld x %d chunks (need >= %lld)", (long long)max_items,
+                (long long)batch, chunks + 1, (long long)(2 * batch * (chunks + 1)));
   hipLaunchKernelGGL(cascade_plan_kernel, dim3(1), dim3(kPlanThreads), 0, as_stream(stream), req_to_token,
                      req_to_token_stride, req_pool_indices, seq_lens, static_cast<int>(batch), min_shared_len,
                      kChunk, members_per_item, 64, chunks * kChunk, plan, static_cast<int>(max_items));

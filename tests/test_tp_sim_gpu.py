@@ -75,13 +75,13 @@ def _run_rank(rank, grp, name, prompts, new_tokens, device, out, errs):
         grp.bar.abort()
 
 
-@pytest.mark.parametrize("name", ["tiny-llama", "tiny-qwen"])
-def test_tp2_gpu_forward_matches_tp1_oracle(device, name, monkeypatch):
+@pytest.mark.parametrize("name,world", [("tiny-llama", 2), ("tiny-qwen", 2), ("tiny-llama", 4)])
+def test_tp_gpu_forward_matches_tp1_oracle(device, name, world, monkeypatch):
+    """world 4 on tiny-llama (2 KV heads): every KV head is replicated on two ranks (llama.py:160-171)."""
     from sglang_amd.distributed import parallel_state as ps
     from sglang_amd.harness.models import CONFIGS, CausalLM
 
     cfg = CONFIGS[name]
-    world = 2
     grp = _FakeGroup(world)
     monkeypatch.setattr(ps, "get_tensor_model_parallel_world_size", lambda: world)
     monkeypatch.setattr(ps, "get_tensor_model_parallel_rank", grp.rank)
@@ -99,11 +99,13 @@ def test_tp2_gpu_forward_matches_tp1_oracle(device, name, monkeypatch):
     for t in threads:
         t.join(timeout=300)
     assert not errs, errs[0]
-    (tr0, outs0, hits0, _), (tr1, outs1, hits1, _) = out
-    # both ranks took identical scheduling decisions and sampled identical tokens
-    assert outs0 == outs1 and hits0 == hits1 == [0, 0, 40, 40, 40, 40]
-    for a, b in zip(tr0, tr1):
-        assert torch.equal(a, b)
+    tr0, outs0, hits0, _ = out[0]
+    # every rank took identical scheduling decisions and sampled identical tokens
+    assert hits0 == [0, 0, 40, 40, 40, 40]
+    for tr_r, outs_r, hits_r, _ in out[1:]:
+        assert outs_r == outs0 and hits_r == hits0
+        for a, b in zip(tr0, tr_r):
+            assert torch.equal(a, b)
     # against the unsharded oracle (teacher-forced with the tokens the TP run produced)
     full = CausalLM(cfg, torch.device("cpu"), "cpu", tp_rank=0, tp_size=1)
     oracle = OracleLM(cfg, weights_from_product_model(full), compute_dtype=torch.float32)
