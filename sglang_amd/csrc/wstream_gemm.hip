@@ -349,9 +349,21 @@ struct CombineParams {
   float eps;
 };
 
+// Sum of the split partials in split order (deterministic).  The loads of four consecutive splits are issued
+// together (clamped to the last split, so they need no predicate); only the adds are predicated.
 __device__ __forceinline__ f32x4_t sum_splits(const float* p0, int64_t split_stride, int splits) {
   f32x4_t s = *reinterpret_cast<const f32x4_t*>(p0);
-  for (int sp = 1; sp < splits; ++sp) s += *reinterpret_cast<const f32x4_t*>(p0 + sp * split_stride);
+  for (int sp = 1; sp < splits; sp += 4) {
+    f32x4_t v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int q = sp + j < splits ? sp + j : splits - 1;
+      v[j] = *reinterpret_cast<const f32x4_t*>(p0 + q * split_stride);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (sp + j < splits) s += v[j];
+  }
   return s;
 }
 
@@ -403,11 +415,13 @@ __global__ __launch_bounds__(kNormThreads) void wstream_combine_norm_kernel(Comb
   const float* row = p.part + static_cast<int64_t>(m) * p.N;
   uint16_t* res = p.residual + static_cast<int64_t>(m) * p.res_stride;
   float t[kNormMaxVec][4];
+  uint2 wv[kNormMaxVec];                 // norm weights: loaded with the partials, not behind the row reduction
   float sq = 0.f;
 #pragma unroll
   for (int i = 0; i < kNormMaxVec; ++i) {
     const int n0 = (i * kNormThreads + threadIdx.x) * 4;
     if (n0 < p.N) {
+      wv[i] = *reinterpret_cast<const uint2*>(p.norm_w + n0);
       f32x4_t s = sum_splits(row + n0, ss, p.splits);
       const uint2 rv = *reinterpret_cast<const uint2*>(res + n0);
       const float rr[4] = {bf_lo(rv.x), bf_hi(rv.x), bf_lo(rv.y), bf_hi(rv.y)};
@@ -430,8 +444,7 @@ __global__ __launch_bounds__(kNormThreads) void wstream_combine_norm_kernel(Comb
   for (int i = 0; i < kNormMaxVec; ++i) {
     const int n0 = (i * kNormThreads + threadIdx.x) * 4;
     if (n0 < p.N) {
-      const uint2 wv = *reinterpret_cast<const uint2*>(p.norm_w + n0);
-      const float ww[4] = {bf_lo(wv.x), bf_hi(wv.x), bf_lo(wv.y), bf_hi(wv.y)};
+      const float ww[4] = {bf_lo(wv[i].x), bf_hi(wv[i].x), bf_lo(wv[i].y), bf_hi(wv[i].y)};
       uint2 w2;
       w2.x = pack_bf2((t[i][0] * rs) * ww[0], (t[i][1] * rs) * ww[1]);
       w2.y = pack_bf2((t[i][2] * rs) * ww[2], (t[i][3] * rs) * ww[3]);
