@@ -425,7 +425,7 @@ __global__ __launch_bounds__(kPlanThreads) void cascade_plan_kernel(
 // ---- merge: slots [0, n_slots(b)) of every (request, head), in slot order ----------------------
 // n_slots = shared chunks + private chunks of the request; every one of them was written this step.
 // Block = 256 / (D/4) heads x (D/4) lanes; a thread owns 4 consecutive output elements of one head.
-constexpr int kMergeBlock = 8;   // slots loaded per round (all loads of a round are in flight together)
+constexpr int kMergeBlock = 16;  // slots loaded per round (all loads of a round are in flight together)
 
 __global__ __launch_bounds__(256) void cascade_merge2_kernel(const float* __restrict__ ws_acc, const float* __restrict__ ws_ml,
                                                              const int32_t* __restrict__ plan, const int32_t* __restrict__ seq_lens,
