@@ -228,83 +228,87 @@ def main():
 
     # ---- dominant hand-written kernels, measured live with HIP events on torch's stream ----
     if rank == 0 and not args.no_kernel_roofline:
-        from sglang_amd import kernels as K
+        try:
+            from sglang_amd import kernels as K
 
-        def graph_time(fn, launches, reps=5):
-            """Average duration of one launch: `fn` (which enqueues `launches` kernels) captured into a
-            hipGraph, replayed `reps` times between two HIP events on the current stream."""
-            fn()
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            def graph_time(fn, launches, reps=5):
+                """Average duration of one launch: `fn` (which enqueues `launches` kernels) captured into a
+                hipGraph, replayed `reps` times between two HIP events on the current stream."""
                 fn()
-            g.replay()
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(reps):
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    fn()
                 g.replay()
-            e1.record()
-            torch.cuda.synchronize()
-            return e0.elapsed_time(e1) / (reps * launches) * 1e-3
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    g.replay()
+                e1.record()
+                torch.cuda.synchronize()
+                return e0.elapsed_time(e1) / (reps * launches) * 1e-3
 
-        # (1) the kernel with the largest share of the step: the weight-streaming GEMM of gate_up_proj
-        # (fused silu_and_mul epilogue).  One launch per layer over the model's OWN weights, so every
-        # launch streams a different 235 MB from HBM (nothing is left in the 256 MiB infinity cache).
-        mlps = [layer.mlp for layer in runner.model.layers if hasattr(layer.mlp, "gate_up_proj")]
-        if mlps and K.wstream_supported(B, *mlps[0].gate_up_proj.weight.shape):
-            xg = torch.randn((B, cfg.hidden_size), device=dev).to(torch.bfloat16)
-            wN, wK = mlps[0].gate_up_proj.weight.shape
-            t_g = graph_time(lambda: [m.gate_up_act(xg) for m in mlps], len(mlps))
-            alg = wN * wK * 2 + B * wK * 2 + B * (wN // 2) * 2        # weights once + activations in + out
-            nw_s = K.choose_wstream_config(B, wN, wK, True, True)
-            traffic = pmc_traffic_bytes("wstream_gemm_kernel") if (B, wN, wK) == (64, 28672, 4096) else None
-            result["roofline"] = {"bound": "hbm", "achieved": alg / t_g / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                  "frac": alg / t_g / 1e9 / HBM_PEAK_GBPS, "traffic": traffic,
-                                  "traffic_source": "profiles/r01_gemm_pmc_{fetch,write}.txt: 2 x FETCH_SIZE (gfx950 "
-                                                    "counts 64 B per 128 B request) + WRITE_SIZE, KiB per dispatch",
-                                  "kernel": "wstream_gemm_kernel<4,4,2> (gate_up_proj + silu_and_mul)",
-                                  "us_per_launch": t_g * 1e6, "bytes_per_launch": alg,
-                                  "shape": {"M": B, "N": wN, "K": wK, "waves_per_group": nw_s[0], "k_splits": nw_s[1]},
-                                  "share_of_decode_step": len(mlps) * t_g / t_decode_step}
+            # (1) the kernel with the largest share of the step: the weight-streaming GEMM of gate_up_proj
+            # (fused silu_and_mul epilogue).  One launch per layer over the model's OWN weights, so every
+            # launch streams a different 235 MB from HBM (nothing is left in the 256 MiB infinity cache).
+            mlps = [layer.mlp for layer in runner.model.layers if hasattr(layer.mlp, "gate_up_proj")]
+            Mg = min(B, 64)               # the weight-streaming design point (larger per-rank batches: DESIGN.md)
+            if mlps and K.wstream_preferred(Mg, *mlps[0].gate_up_proj.weight.shape):
+                xg = torch.randn((Mg, cfg.hidden_size), device=dev).to(torch.bfloat16)
+                wN, wK = mlps[0].gate_up_proj.weight.shape
+                t_g = graph_time(lambda: [m.gate_up_act(xg) for m in mlps], len(mlps))
+                alg = wN * wK * 2 + Mg * wK * 2 + Mg * (wN // 2) * 2      # weights once + activations in + out
+                nw_s = K.choose_wstream_config(Mg, wN, wK, True, True)
+                traffic = pmc_traffic_bytes("wstream_gemm_kernel") if (Mg, wN, wK) == (64, 28672, 4096) else None
+                result["roofline"] = {"bound": "hbm", "achieved": alg / t_g / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                      "frac": alg / t_g / 1e9 / HBM_PEAK_GBPS, "traffic": traffic,
+                                      "traffic_source": "profiles/r01_gemm_pmc_{fetch,write}.txt: 2 x FETCH_SIZE (gfx950 "
+                                                        "counts 64 B per 128 B request) + WRITE_SIZE, KiB per dispatch",
+                                      "kernel": "wstream_gemm_kernel<4,4,2> (gate_up_proj + silu_and_mul)",
+                                      "us_per_launch": t_g * 1e6, "bytes_per_launch": alg,
+                                      "shape": {"M": Mg, "N": wN, "K": wK, "waves_per_group": nw_s[0], "k_splits": nw_s[1]},
+                                      "share_of_decode_step": len(mlps) * t_g / t_decode_step}
 
-        # (2) decode attention over the workload's own slot pattern (shared prefix rows + private rows)
-        from sglang_amd.layers.attention.hip_backend import choose_num_splits
+            # (2) decode attention over the workload's own slot pattern (shared prefix rows + private rows)
+            from sglang_amd.layers.attention.hip_backend import choose_num_splits
 
-        Hq_r, Hkv_r = runner.num_attention_heads_per_rank, runner.num_kv_heads_per_rank
-        len_k = in_len + args.out // 2
-        r2t = runner.req_to_token_pool.req_to_token
-        perm = (torch.randperm(runner.token_to_kv_pool.size - 1, device=dev) + 1).to(torch.int32)
-        off = 0
-        for b in range(B):
-            r2t[b + 1, :len_k] = perm[off: off + len_k]
-            off += len_k
-            leader = (b // P) * P
-            r2t[b + 1, :args.prefix] = r2t[leader + 1, :args.prefix]
-        pool_idx = torch.arange(1, B + 1, device=dev)
-        seq = torch.full((B,), len_k, dtype=torch.int32, device=dev)
-        q = torch.randn((B, Hq_r, D), device=dev).to(torch.bfloat16)
-        o = torch.empty_like(q)
-        kc, vc = runner.token_to_kv_pool.get_key_buffer(0), runner.token_to_kv_pool.get_value_buffer(0)
-        kc.normal_(); vc.normal_()
-        row_bytes = 2 * Hkv_r * D * 2
-        att = {}
-        if D in (64, 128) and B >= 2:
-            cws = K.CascadeWorkspace(B, Hq_r, D, ctx, dev)
-            K.cascade_plan(cws, r2t, pool_idx, seq, Hq_r, Hkv_r)
-            t_c = graph_time(lambda: K.cascade_decode_attention(cws, q, kc, vc, o, r2t, pool_idx, seq, D ** -0.5), 1, reps=20)
-            uniq = (G * args.prefix + B * (len_k - args.prefix)) * row_bytes
-            att["cascade"] = {"kernel": "cascade_chunk_kernel + cascade_merge2_kernel", "us_per_layer": t_c * 1e6,
-                              "bytes_unique": uniq, "achieved": uniq / t_c / 1e9, "frac": uniq / t_c / 1e9 / HBM_PEAK_GBPS}
-        splits = choose_num_splits(B, Hkv_r, Hq_r // Hkv_r, len_k)
-        ws = K.decode_workspace(B, Hq_r, D, splits, dev) if splits > 1 else (None, None)
-        t_k = graph_time(lambda: K.decode_attention(q, kc, vc, o, r2t, pool_idx, seq, D ** -0.5, splits, ws[0], ws[1]), 1, reps=20)
-        alg = B * len_k * row_bytes     # SURVEY 8(d): len * (2*H_kv*D*2 B) per request and layer, no dedup
-        att["plain"] = {"kernel": "decode_stage1_kernel", "us_per_layer": t_k * 1e6, "bytes_no_dedup": alg,
-                        "achieved": alg / t_k / 1e9, "frac": alg / t_k / 1e9 / HBM_PEAK_GBPS}
-        result["attention_roofline"] = {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                        "shape": {"B": B, "Hq": Hq_r, "Hkv": Hkv_r, "D": D, "kv_len": len_k,
-                                                  "shared_prefix": args.prefix, "groups": G}, **att}
+            Hq_r, Hkv_r = runner.num_attention_heads_per_rank, runner.num_kv_heads_per_rank
+            len_k = in_len + args.out // 2
+            r2t = runner.req_to_token_pool.req_to_token
+            perm = (torch.randperm(runner.token_to_kv_pool.size - 1, device=dev) + 1).to(torch.int32)
+            off = 0
+            for b in range(B):
+                r2t[b + 1, :len_k] = perm[off: off + len_k]
+                off += len_k
+                leader = (b // P) * P
+                r2t[b + 1, :args.prefix] = r2t[leader + 1, :args.prefix]
+            pool_idx = torch.arange(1, B + 1, device=dev)
+            seq = torch.full((B,), len_k, dtype=torch.int32, device=dev)
+            q = torch.randn((B, Hq_r, D), device=dev).to(torch.bfloat16)
+            o = torch.empty_like(q)
+            kc, vc = runner.token_to_kv_pool.get_key_buffer(0), runner.token_to_kv_pool.get_value_buffer(0)
+            kc.normal_(); vc.normal_()
+            row_bytes = 2 * Hkv_r * D * 2
+            att = {}
+            if D in (64, 128) and B >= 2:
+                cws = K.CascadeWorkspace(B, Hq_r, D, ctx, dev)
+                K.cascade_plan(cws, r2t, pool_idx, seq, Hq_r, Hkv_r)
+                t_c = graph_time(lambda: K.cascade_decode_attention(cws, q, kc, vc, o, r2t, pool_idx, seq, D ** -0.5), 1, reps=20)
+                uniq = (G * args.prefix + B * (len_k - args.prefix)) * row_bytes
+                att["cascade"] = {"kernel": "cascade_chunk_kernel + cascade_merge2_kernel", "us_per_layer": t_c * 1e6,
+                                  "bytes_unique": uniq, "achieved": uniq / t_c / 1e9, "frac": uniq / t_c / 1e9 / HBM_PEAK_GBPS}
+            splits = choose_num_splits(B, Hkv_r, Hq_r // Hkv_r, len_k)
+            ws = K.decode_workspace(B, Hq_r, D, splits, dev) if splits > 1 else (None, None)
+            t_k = graph_time(lambda: K.decode_attention(q, kc, vc, o, r2t, pool_idx, seq, D ** -0.5, splits, ws[0], ws[1]), 1, reps=20)
+            alg = B * len_k * row_bytes     # SURVEY 8(d): len * (2*H_kv*D*2 B) per request and layer, no dedup
+            att["plain"] = {"kernel": "decode_stage1_kernel", "us_per_layer": t_k * 1e6, "bytes_no_dedup": alg,
+                            "achieved": alg / t_k / 1e9, "frac": alg / t_k / 1e9 / HBM_PEAK_GBPS}
+            result["attention_roofline"] = {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                            "shape": {"B": B, "Hq": Hq_r, "Hkv": Hkv_r, "D": D, "kv_len": len_k,
+                                                      "shared_prefix": args.prefix, "groups": G}, **att}
+        except Exception as e:      # the measured line must survive a failure of these side measurements
+            result.setdefault("roofline", {"error": f"{type(e).__name__}: {e}"})
 
     # ---- CPU baseline: the oracle (reference torch-native path) on host cores --------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
