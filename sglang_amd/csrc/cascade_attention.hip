@@ -541,8 +541,10 @@ int sgl_amd_cascade_decode_attention(const void* q, const void* k_cache, const v
   p.num_kv_heads = num_kv_heads;
   p.slots_total = slots_total;
   p.scale_log2 = sm_scale * 1.4426950408889634f;
-  // worst-case unit count of this batch: every request's private chunks + the shared chunks of batch/2 groups
-  int64_t units = (batch * (chunks + 1) + (batch / 2 + 1) * chunks);
+  // worst-case item count of this batch: every request's private chunks + the shared chunks of every member tile
+  // (at most batch/2 groups, and sum over groups of ceil(members / members_per_item) <= batch/members_per_item + groups)
+  const int64_t member_tiles = (batch + p.members_per_item - 1) / p.members_per_item + batch / 2 + 1;
+  int64_t units = batch * (chunks + 1) + member_tiles * chunks;
   if (units > max_items) units = max_items;
   dim3 grid(static_cast<unsigned>(units * num_kv_heads));
   if (head_dim == 128) hipLaunchKernelGGL(cascade_chunk_kernel<128>, grid, dim3(kThreads), 0, st, p);

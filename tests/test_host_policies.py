@@ -63,3 +63,15 @@ def test_kernels_refuse_cpu_tensors():
         K.wstream_gemm(x, w)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         K.rmsnorm(x, torch.ones(256, dtype=torch.bfloat16), 1e-5)
+
+
+def test_moe_block_height_holds_one_and_a_half_average_experts():
+    """choose_moe_block_m: an expert whose rows spill into a second row block streams its weights twice."""
+    assert K.choose_moe_block_m(2, 8) == 16            # one token, top-2
+    assert K.choose_moe_block_m(32, 8) == 16           # 4 rows per expert on average
+    assert K.choose_moe_block_m(128, 8) == 32          # the 64-token Mixtral decode batch: 16 on average -> 24 -> 32
+    assert K.choose_moe_block_m(256, 8) == 48
+    assert K.choose_moe_block_m(8192, 8) == 64
+    for pairs in range(1, 600, 7):
+        for experts in (4, 8, 64, 256):
+            assert K.choose_moe_block_m(pairs, experts) in (16, 32, 48, 64)
