@@ -624,6 +624,7 @@ int sgl_amd_wstream_gemm(const void* x, const void* w, const void* bias, void* y
   const bool fused_silu = epilogue == 1 && num_k_splits == 1 && N % 32 == 0 && !bias;   // silu(gate)*up in the GEMM's own epilogue
   const bool combine = !fused_silu && (num_k_splits > 1 || epilogue != 0);
   SGL_CHECK_ARG(epilogue != 1 || N % 8 == 0, "wstream_gemm: silu_and_mul needs N %% 8 == 0");
+  SGL_CHECK_ARG(epilogue != 1 || !bias, "wstream_gemm: the silu_and_mul epilogue takes no bias");
   SGL_CHECK_ARG(epilogue != 2 || (residual && norm_weight && N <= kNormThreads * kNormMaxVec * 4 && residual_row_stride % 4 == 0),
                 "wstream_gemm: add_rmsnorm needs residual, norm_weight and N <= %d", kNormThreads * kNormMaxVec * 4);
   hipStream_t st = as_stream(stream);
