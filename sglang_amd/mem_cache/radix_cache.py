@@ -202,6 +202,7 @@ class RadixCache:
         self.page_size = page_size
         self.disable = disable
         self.disable_finished_insert = disable_finished_insert
+        self.fast_unfinished_path = True      # tests switch it off to compare with the reference's two-pass form
         self.eviction_policy = eviction_policy.lower()
         if self.eviction_policy not in _EVICTION:
             raise ValueError(f"unknown eviction policy {eviction_policy!r}")
@@ -264,7 +265,8 @@ class RadixCache:
             pieces.append(child.value)
             node = child
             key = key[common:]
-        value = torch.cat(pieces) if pieces else self._empty
+        # one piece is returned as it is (node values are never written in place): no copy kernel per request
+        value = (pieces[0] if len(pieces) == 1 else torch.cat(pieces)) if pieces else self._empty
         self.query_tokens += len(params.key if isinstance(params, MatchPrefixParams) else params)
         self.hit_tokens += int(value.numel())
         return MatchResult(value, node, node, node)
@@ -352,8 +354,27 @@ class RadixCache:
         values = kv_indices[: len(key)].to(dtype=torch.int64, copy=True)
         res = self.insert(InsertParams(key=key, value=values, chunked=chunked,
                                        priority=getattr(req, "priority", 0) or 0))
-        self.token_to_kv_pool_allocator.free_segment(kv_indices[req.cache_protected_len:res.prefix_len],
-                                                     start_pos=req.cache_protected_len)
+        if self.fast_unfinished_path and res.prefix_len == req.cache_protected_len and len(key) == len(kv_indices):
+            # Common case (no other request inserted these tokens first): the tree took the request's own slots
+            # for everything behind its locked prefix, so the row of req_to_token is already what the second
+            # match_prefix + rewrite of the reference (radix_cache.py:548-584) would produce.  Same observable
+            # state -- recency refresh of the path, hit counters, lock move -- without its device copies.
+            now = self._tick()
+            node = res.last_device_node
+            while node is not None:
+                node.last_access_time = now
+                node = node.parent
+            self.query_tokens += len(key)
+            self.hit_tokens += len(key)
+            req.cache_protected_len = len(key)
+            self.dec_lock_ref(req.last_node)
+            self.inc_lock_ref(res.last_device_node)
+            req.prefix_indices = values
+            req.last_node = res.last_device_node
+            return
+        if res.prefix_len > req.cache_protected_len:
+            self.token_to_kv_pool_allocator.free_segment(kv_indices[req.cache_protected_len:res.prefix_len],
+                                                         start_pos=req.cache_protected_len)
         m = self.match_prefix(MatchPrefixParams(key=key))
         new_indices, new_last = m.device_indices, m.last_device_node
         assert len(new_indices) == len(key), f"{len(new_indices)=} {len(key)=}"

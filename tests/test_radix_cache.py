@@ -157,3 +157,74 @@ def test_paged_allocator_free_segments():
     p.free_segments([(row[2:6], 2), (row[6:16], 6)])   # second segment starts inside page 2
     assert sorted(p.free_pages.tolist()[:4]) == [1, 2, 3, 4]
     assert p.available_size() == 64
+
+
+def _drive_prefill_like(fast: bool, page: int, seed: int):
+    """Two prefill rounds + finishes over CPU pools, the way harness/engine.py drives the cache."""
+    import random
+
+    from sglang_amd.harness.engine import Req
+    from sglang_amd.mem_cache.allocator import PagedTokenToKVPoolAllocator, TokenToKVPoolAllocator
+    from sglang_amd.mem_cache.memory_pool import ReqToTokenPool
+    from sglang_amd.mem_cache.radix_cache import EvictParams, MatchPrefixParams, RadixCache, RadixKey
+
+    dev = torch.device("cpu")
+    B, ctx, size = 12, 96, 12 * 96
+    r2t = ReqToTokenPool(B, ctx, dev)
+    alloc = (TokenToKVPoolAllocator(size, torch.bfloat16, dev, None) if page == 1
+             else PagedTokenToKVPoolAllocator(size, page, torch.bfloat16, dev, None))
+    tree = RadixCache(r2t, alloc, page)
+    tree.fast_unfinished_path = fast
+    rnd = random.Random(seed)
+    shared = [[rnd.randrange(50) for _ in range(40)] for _ in range(2)]
+    prompts = [shared[i % 2] + [rnd.randrange(50) for _ in range(rnd.randrange(1, 30))] for i in range(8)]
+    prompts += [list(prompts[0]), list(prompts[1][:45])]          # a duplicate prompt and a strict prefix of another
+    reqs = [Req(i, p, 4) for i, p in enumerate(prompts)]
+    log = []
+
+    def prefill(rs):
+        for q in rs:
+            key = RadixKey(q.origin_input_ids[: len(q.origin_input_ids) - 1], q.extra_key, q.cache_salt)
+            m = tree.match_prefix(MatchPrefixParams(key=key))
+            q.prefix_indices, q.last_node = m.device_indices, m.last_device_node
+            q.cached_tokens = int(m.device_indices.numel())
+            q.cache_protected_len = q.cached_tokens
+            tree.inc_lock_ref(q.last_node)
+        assert r2t.alloc(rs) is not None
+        for q in rs:
+            n = len(q.origin_input_ids)
+            if page == 1:
+                loc = alloc.alloc(n - q.cached_tokens)
+            else:
+                # the cached prefix ends on a page boundary, so the new tokens start a fresh page (plain alloc of
+                # whole pages; alloc_extend is a HIP kernel and this test has no GPU)
+                need = (n - q.cached_tokens + page - 1) // page
+                loc = alloc.alloc(need * page)[: n - q.cached_tokens]
+            assert loc is not None
+            r2t.req_to_token[q.req_pool_idx, : q.cached_tokens] = q.prefix_indices.to(torch.int32)
+            r2t.req_to_token[q.req_pool_idx, q.cached_tokens: n] = loc.to(torch.int32)
+        for q in rs:
+            tree.cache_unfinished_req(q)
+            log.append((q.rid, q.cache_protected_len, q.prefix_indices.tolist(),
+                        r2t.req_to_token[q.req_pool_idx, : len(q.origin_input_ids)].tolist()))
+
+    prefill(reqs[:2])
+    prefill(reqs[2:])
+    log.append(("sizes", tree.evictable_size(), tree.protected_size(), tree.total_size(), alloc.available_size()))
+    for q in reqs[:5]:
+        tree.cache_finished_req(q, kv_len_to_handle=len(q.origin_input_ids))
+        r2t.free(q)
+    log.append(("sizes", tree.evictable_size(), tree.protected_size(), tree.total_size(), alloc.available_size()))
+    before = alloc.available_size()
+    tree.evict(EvictParams(num_tokens=60))                          # eviction order depends on the recency stamps
+    log.append(("evicted", alloc.available_size() - before, tree.evictable_size(), sorted(tree.all_values_flatten().tolist())))
+    return log
+
+
+@pytest.mark.parametrize("page", [1, 4])
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_unfinished_req_fast_path_equals_reference_two_pass_form(page, seed):
+    """cache_unfinished_req's shortcut (no second match_prefix / row rewrite when the tree took the request's own
+    slots) leaves exactly the state of the reference's form (radix_cache.py:516-584): rows, locks, sizes, and
+    the eviction order that follows from the recency stamps."""
+    assert _drive_prefill_like(True, page, seed) == _drive_prefill_like(False, page, seed)
