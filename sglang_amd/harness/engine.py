@@ -17,6 +17,7 @@ structures with the same call order.
 from __future__ import annotations
 
 import time
+from array import array
 from dataclasses import dataclass, field
 from typing import Any, Dict, List, Optional, Sequence
 
@@ -54,8 +55,18 @@ class Req:
     t_first_token: float = 0.0
     cached_tokens: int = 0
 
-    def get_fill_ids(self) -> List[int]:
-        return self.origin_input_ids + self.output_ids
+    @property
+    def origin_array(self):
+        """The prompt as a C array of int64, built once: radix keys are slices of it (a memcpy) instead of a
+        fresh list -> array conversion per match / insert."""
+        arr = self.__dict__.get("_origin_array")
+        if arr is None or len(arr) != len(self.origin_input_ids):
+            arr = self.__dict__["_origin_array"] = array("q", self.origin_input_ids)
+        return arr
+
+    def get_fill_ids(self):
+        """schedule_batch.py Req.fill_ids = origin_input_ids + output_ids (here as an int64 array)."""
+        return self.origin_array + array("q", self.output_ids) if self.output_ids else self.origin_array
 
     @property
     def seqlen(self) -> int:
@@ -153,7 +164,7 @@ class Engine:
         tree = r.tree_cache
         for q in reqs:
             # match against at most len-1 tokens so at least one token is computed (schedule_policy.py:138)
-            key = RadixKey(q.origin_input_ids[: len(q.origin_input_ids) - 1], q.extra_key, q.cache_salt)
+            key = RadixKey(q.origin_array[: len(q.origin_input_ids) - 1], q.extra_key, q.cache_salt)
             m = tree.match_prefix(MatchPrefixParams(key=key))
             q.prefix_indices, q.last_node = m.device_indices, m.last_device_node
             q.cached_tokens = int(m.device_indices.numel())

@@ -322,7 +322,8 @@ class RadixCache:
         if self.disable:
             alloc.free_segment(row[req.cache_protected_len:kv_len_to_handle], start_pos=req.cache_protected_len)
             return
-        token_ids = (list(req.origin_input_ids) + list(req.output_ids))[:kv_len_to_handle]
+        fill = req.get_fill_ids() if hasattr(req, "get_fill_ids") else list(req.origin_input_ids) + list(req.output_ids)
+        token_ids = fill[:kv_len_to_handle]
         kv_indices = row[: len(token_ids)]
         key = RadixKey(token_ids, getattr(req, "extra_key", None), getattr(req, "cache_salt", None))
         key = key.page_aligned(self.page_size)

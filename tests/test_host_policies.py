@@ -75,3 +75,22 @@ def test_moe_block_height_holds_one_and_a_half_average_experts():
     for pairs in range(1, 600, 7):
         for experts in (4, 8, 64, 256):
             assert K.choose_moe_block_m(pairs, experts) in (16, 32, 48, 64)
+
+
+def test_req_token_arrays():
+    """Req.origin_array / get_fill_ids (harness/engine.py): int64 arrays that track the lists they mirror."""
+    from array import array
+
+    from sglang_amd.harness.engine import Req
+    from sglang_amd.mem_cache.radix_cache import RadixKey
+
+    q = Req(0, [5, 6, 7, 8], 3)
+    assert isinstance(q.origin_array, array) and q.origin_array.typecode == "q" and list(q.origin_array) == [5, 6, 7, 8]
+    assert q.origin_array is q.origin_array                         # built once
+    assert list(q.get_fill_ids()) == [5, 6, 7, 8]
+    q.output_ids.append(9)
+    assert list(q.get_fill_ids()) == [5, 6, 7, 8, 9] and q.seqlen == 5
+    key = RadixKey(q.origin_array[: len(q.origin_input_ids) - 1], q.extra_key, q.cache_salt)
+    assert len(key) == 3 and key.match(RadixKey([5, 6, 1])) == 2
+    q.origin_input_ids = [1, 2]                                      # a replaced prompt is picked up
+    assert list(q.origin_array) == [1, 2]
