@@ -260,10 +260,14 @@ class Engine:
         st["last_ids"] = next_ids.to(torch.int64)
         # token hand-off to the host: an async copy into pinned memory + an event, so that the scheduler can
         # launch step N+1 before it looks at step N's tokens (overlap scheduling, scheduler.py:1783)
-        host = st["free_host"].pop() if st["free_host"] else torch.empty(next_ids.shape, dtype=next_ids.dtype, pin_memory=True)
+        on_gpu = next_ids.is_cuda                       # (host-logic tests drive this class with CPU tensors)
+        host = st["free_host"].pop() if st["free_host"] else torch.empty(next_ids.shape, dtype=next_ids.dtype,
+                                                                          pin_memory=on_gpu)
         host.copy_(next_ids, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
+        ev = None
+        if on_gpu:
+            ev = torch.cuda.Event()
+            ev.record()
         st["pending"].append((host, ev))
         return next_ids
 
@@ -288,7 +292,8 @@ class Engine:
         n = len(st["pending"]) - lag
         ready, st["pending"] = st["pending"][:n], st["pending"][n:]
         for host, ev in ready:
-            ev.synchronize()
+            if ev is not None:
+                ev.synchronize()
             for q, t in zip(self.running, host.tolist()):
                 q.output_ids.append(t)
             st["free_host"].append(host)

@@ -1,0 +1,170 @@
+"""The engine's host logic on the CPU: radix hits, slot / row bookkeeping, the overlap-scheduled token hand-off and
+the release of everything at the end, driven by a stand-in model runner (a deterministic toy LM) with CPU pools.
+The four integer helper kernels the engine calls are replaced by their oracle restatements (oracle/host.py); the
+GPU suite (tests/test_engine_gpu.py) runs the same class with the real runner."""
+import ctypes
+import random
+
+import pytest
+import torch
+
+from oracle import host as oh
+from sglang_amd import kernels
+from sglang_amd.harness.engine import Engine, Req
+from sglang_amd.layers.sampler import LogitsProcessorOutput
+from sglang_amd.mem_cache.allocator import TokenToKVPoolAllocator
+from sglang_amd.mem_cache.memory_pool import ReqToTokenPool
+from sglang_amd.mem_cache.radix_cache import RadixCache
+
+VOCAB = 97
+
+
+def _toy_next(last_token: int, kv_len: int) -> int:
+    return (last_token * 7 + kv_len * 3 + 1) % VOCAB
+
+
+class _Pool:
+    def __init__(self, size):
+        self.size = size
+
+
+class _ToyRunner:
+    """What Engine reads of harness.engine.ModelRunner, with a next-token rule that depends on the last input
+    token and the number of KV rows the request has (so a wrong seq_len or a stale last token shows up)."""
+
+    def __init__(self, max_reqs, ctx, size, disable_radix=False):
+        self.device = torch.device("cpu")
+        self.page_size = 1
+        self.req_to_token_pool = ReqToTokenPool(max_reqs, ctx, self.device)
+        self.token_to_kv_pool = _Pool(size)
+        self.token_to_kv_pool_allocator = TokenToKVPoolAllocator(size, torch.bfloat16, self.device, None)
+        self.tree_cache = RadixCache(self.req_to_token_pool, self.token_to_kv_pool_allocator, 1, disable=disable_radix)
+        self.attn_backend = None
+        self.graph_runner = None
+        self.seen = []                                   # (mode, kv lengths, slots written) per forward
+
+    def forward(self, fb):
+        if fb.forward_mode.is_extend():
+            last = torch.cumsum(torch.tensor(fb.extend_seq_lens_cpu), 0) - 1
+            last_tok = fb.input_ids[last].tolist()
+        else:
+            last_tok = fb.input_ids.tolist()
+        kv = fb.seq_lens.tolist()
+        self.seen.append((fb.forward_mode.is_extend(), kv, fb.out_cache_loc.tolist(), fb.positions.tolist()))
+        logits = torch.full((len(kv), VOCAB), -1.0)
+        for b, (t, n) in enumerate(zip(last_tok, kv)):
+            logits[b, _toy_next(t, n)] = 1.0
+        return LogitsProcessorOutput(next_token_logits=logits)
+
+    def sample(self, logits_output, fb):
+        return logits_output.next_token_logits.argmax(-1)
+
+
+@pytest.fixture
+def cpu_kernels(monkeypatch):
+    def write_req_to_token(r2t, req_pool, prefix_ptrs, prefix_lens, seq_lens, ext_lens, out_cache_loc):
+        off = 0
+        for b in range(req_pool.numel()):
+            row, pre, seq, ext = int(req_pool[b]), int(prefix_lens[b]), int(seq_lens[b]), int(ext_lens[b])
+            if pre:
+                src = (ctypes.c_int64 * pre).from_address(int(prefix_ptrs[b]))
+                r2t[row, :pre] = torch.tensor(list(src), dtype=torch.int32)
+            r2t[row, pre:seq] = out_cache_loc[off: off + ext].to(torch.int32)
+            off += ext
+
+    def compute_position(prefix_lens, extend_lens, total):
+        pos, start = oh.compute_position(prefix_lens.tolist(), extend_lens.tolist())
+        return torch.from_numpy(pos).to(torch.int64), torch.from_numpy(start).to(extend_lens.dtype)
+
+    def clamp_position(seq_lens, out=None):
+        res = torch.from_numpy(oh.clamp_position(seq_lens.tolist())).to(torch.int64)
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res
+
+    monkeypatch.setattr(kernels, "write_req_to_token", write_req_to_token)
+    monkeypatch.setattr(kernels, "compute_position", compute_position)
+    monkeypatch.setattr(kernels, "clamp_position", clamp_position)
+
+
+def _prompts(groups, per_group, shared, seed=3):
+    rnd = random.Random(seed)
+    out = []
+    for _ in range(groups):
+        sys_p = [rnd.randrange(VOCAB) for _ in range(shared)]
+        out += [sys_p + [rnd.randrange(VOCAB) for _ in range(rnd.randrange(2, 9))] for _ in range(per_group)]
+    return out
+
+
+def _expected(prompt, new_tokens):
+    toks, out = list(prompt), []
+    for _ in range(new_tokens):
+        out.append(_toy_next(toks[-1], len(toks)))
+        toks.append(out[-1])
+    return out
+
+
+@pytest.mark.parametrize("disable_radix", [False, True])
+@pytest.mark.parametrize("lag", [0, 1])
+def test_engine_bookkeeping_with_a_toy_model(cpu_kernels, disable_radix, lag):
+    groups, per_group, shared, new_tokens = 3, 4, 20, 6
+    prompts = _prompts(groups, per_group, shared)
+    B = len(prompts)
+    size = B * 64
+    runner = _ToyRunner(B, 64, size, disable_radix)
+    eng = Engine(runner)
+    reqs = [Req(i, p, new_tokens) for i, p in enumerate(prompts)]
+    leaders = [q for q in reqs if q.rid % per_group == 0]
+    rest = [q for q in reqs if q.rid % per_group]
+    eng.prefill(leaders)
+    eng.prefill(rest)
+    # radix hits: followers reuse their leader's shared prefix (the whole system prompt)
+    assert [q.cached_tokens for q in leaders] == [0] * groups
+    assert [q.cached_tokens for q in rest] == [0 if disable_radix else shared] * len(rest)
+    r2t = runner.req_to_token_pool.req_to_token
+    if not disable_radix:
+        for q in rest:
+            lead = reqs[q.rid - q.rid % per_group]
+            assert torch.equal(r2t[q.req_pool_idx, :shared], r2t[lead.req_pool_idx, :shared])
+    rows = [r2t[q.req_pool_idx, : len(q.origin_input_ids)].tolist() for q in reqs]
+    private = [s for q, row in zip(reqs, rows) for s in (row if q.rid % per_group == 0 or disable_radix else row[shared:])]
+    assert len(set(private)) == len(private) and 0 not in private      # every computed token owns a distinct slot
+    # extend positions start at the cached prefix
+    ext_calls = [c for c in runner.seen if c[0]]
+    assert ext_calls[1][3][:3] == [0 if disable_radix else shared, (0 if disable_radix else shared) + 1,
+                                   (0 if disable_radix else shared) + 2]
+    for _ in range(new_tokens - 1):
+        eng.decode_step()
+        eng.flush_decode_outputs(lag=lag)
+    done = sorted(eng.running, key=lambda q: q.rid)
+    eng.finish(list(eng.running))
+    for q in done:
+        assert q.output_ids == _expected(q.origin_input_ids, new_tokens), q.rid
+    # decode wrote one new slot per request per step, at column kv_len - 1 of its row, positions = kv_len - 1
+    dec_calls = [c for c in runner.seen if not c[0]]
+    assert len(dec_calls) == new_tokens - 1
+    for step, (_, kv, slots, pos) in enumerate(dec_calls):
+        assert len(set(slots)) == B and pos == [n - 1 for n in kv]
+        assert kv == [len(q.origin_input_ids) + step + 1 for q in eng_order(leaders, rest)]
+    # nothing leaked
+    tree, alloc = runner.tree_cache, runner.token_to_kv_pool_allocator
+    assert tree.protected_size() == 0
+    assert alloc.available_size() + tree.evictable_size() == size
+    assert runner.req_to_token_pool.available_size() == runner.req_to_token_pool.size
+
+
+def eng_order(leaders, rest):
+    return list(leaders) + list(rest)
+
+
+def test_results_do_not_depend_on_the_radix_cache(cpu_kernels):
+    prompts = _prompts(2, 5, 16, seed=8)
+    outs = []
+    for disable in (False, True):
+        runner = _ToyRunner(len(prompts), 64, len(prompts) * 64, disable)
+        eng = Engine(runner)
+        reqs = [Req(i, p, 5) for i, p in enumerate(prompts)]
+        eng.generate(reqs, sync_every=2)
+        outs.append([q.output_ids for q in reqs])
+    assert outs[0] == outs[1] == [_expected(p, 5) for p in prompts]
