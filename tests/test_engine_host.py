@@ -12,7 +12,7 @@ from oracle import host as oh
 from sglang_amd import kernels
 from sglang_amd.harness.engine import Engine, Req
 from sglang_amd.layers.sampler import LogitsProcessorOutput
-from sglang_amd.mem_cache.allocator import TokenToKVPoolAllocator
+from sglang_amd.mem_cache.allocator import PagedTokenToKVPoolAllocator, TokenToKVPoolAllocator
 from sglang_amd.mem_cache.memory_pool import ReqToTokenPool
 from sglang_amd.mem_cache.radix_cache import RadixCache
 
@@ -32,13 +32,16 @@ class _ToyRunner:
     """What Engine reads of harness.engine.ModelRunner, with a next-token rule that depends on the last input
     token and the number of KV rows the request has (so a wrong seq_len or a stale last token shows up)."""
 
-    def __init__(self, max_reqs, ctx, size, disable_radix=False):
+    def __init__(self, max_reqs, ctx, size, disable_radix=False, page_size=1):
         self.device = torch.device("cpu")
-        self.page_size = 1
+        self.page_size = page_size
         self.req_to_token_pool = ReqToTokenPool(max_reqs, ctx, self.device)
         self.token_to_kv_pool = _Pool(size)
-        self.token_to_kv_pool_allocator = TokenToKVPoolAllocator(size, torch.bfloat16, self.device, None)
-        self.tree_cache = RadixCache(self.req_to_token_pool, self.token_to_kv_pool_allocator, 1, disable=disable_radix)
+        self.token_to_kv_pool_allocator = (
+            TokenToKVPoolAllocator(size, torch.bfloat16, self.device, None) if page_size == 1
+            else PagedTokenToKVPoolAllocator(size, page_size, torch.bfloat16, self.device, None))
+        self.tree_cache = RadixCache(self.req_to_token_pool, self.token_to_kv_pool_allocator, page_size,
+                                     disable=disable_radix)
         self.attn_backend = None
         self.graph_runner = None
         self.seen = []                                   # (mode, kv lengths, slots written) per forward
@@ -83,6 +86,16 @@ def cpu_kernels(monkeypatch):
             return out
         return res
 
+    def alloc_extend(prefix_lens, seq_lens, last_loc, free_pages, out_indices, page_size):
+        idx, _ = oh.alloc_extend(prefix_lens.tolist(), seq_lens.tolist(), last_loc.tolist(), free_pages.tolist(), page_size)
+        out_indices.copy_(torch.from_numpy(idx))
+
+    def alloc_decode(seq_lens, last_loc, free_pages, out_indices, page_size):
+        idx, _ = oh.alloc_decode(seq_lens.tolist(), last_loc.tolist(), free_pages.tolist(), page_size)
+        out_indices.copy_(torch.from_numpy(idx))
+
+    monkeypatch.setattr(kernels, "alloc_extend", alloc_extend)
+    monkeypatch.setattr(kernels, "alloc_decode", alloc_decode)
     monkeypatch.setattr(kernels, "write_req_to_token", write_req_to_token)
     monkeypatch.setattr(kernels, "compute_position", compute_position)
     monkeypatch.setattr(kernels, "clamp_position", clamp_position)
@@ -168,3 +181,38 @@ def test_results_do_not_depend_on_the_radix_cache(cpu_kernels):
         eng.generate(reqs, sync_every=2)
         outs.append([q.output_ids for q in reqs])
     assert outs[0] == outs[1] == [_expected(p, 5) for p in prompts]
+
+
+@pytest.mark.parametrize("page", [4, 16])
+def test_paged_engine_bookkeeping(cpu_kernels, page):
+    """page_size > 1: radix hits are page aligned, a request's tokens fill whole pages in order
+    (allocator/paged.py:45-102 through the oracle's restatement), decode opens a page every `page` tokens."""
+    groups, per_group, shared, new_tokens = 2, 3, 37, 9
+    prompts = _prompts(groups, per_group, shared, seed=5)
+    B = len(prompts)
+    size = B * 96 // page * page
+    runner = _ToyRunner(B, 96, size, page_size=page)
+    eng = Engine(runner)
+    reqs = [Req(i, p, new_tokens) for i, p in enumerate(prompts)]
+    leaders = [q for q in reqs if q.rid % per_group == 0]
+    rest = [q for q in reqs if q.rid % per_group]
+    eng.prefill(leaders)
+    eng.prefill(rest)
+    assert [q.cached_tokens for q in rest] == [shared // page * page] * len(rest)
+    r2t = runner.req_to_token_pool.req_to_token
+    for q in reqs:
+        row = r2t[q.req_pool_idx, : len(q.origin_input_ids)].tolist()
+        assert all(b == a + 1 for a, b, i in zip(row, row[1:], range(1, len(row))) if i % page)   # pages are contiguous
+    for _ in range(new_tokens - 1):
+        eng.decode_step()
+        eng.flush_decode_outputs(lag=1)
+    done = sorted(eng.running, key=lambda q: q.rid)
+    for q in done:                                                    # rows stay page-contiguous while decoding
+        row = r2t[q.req_pool_idx, : q.seqlen - 1].tolist()
+        assert all(b == a + 1 for a, b, i in zip(row, row[1:], range(1, len(row))) if i % page)
+    eng.finish(list(eng.running))
+    for q in done:
+        assert q.output_ids == _expected(q.origin_input_ids, new_tokens)
+    tree, alloc = runner.tree_cache, runner.token_to_kv_pool_allocator
+    assert tree.protected_size() == 0
+    assert alloc.available_size() + tree.evictable_size() == size
