@@ -216,7 +216,7 @@ def main():
         "config": {"workload": f"{cfg.name} shared-prefix batch: {G} groups x {P} prompts, {args.prefix} shared + "
                                f"{args.unique} unique in, {args.out} out, greedy, page_size {args.page_size}",
                    "model": cfg.name, "global_batch": B, "seq_len": in_len, "parallelism": f"tp{world}",
-                   "decode": "hipGraph" if not args.no_graph else "eager"},
+                   "decode": "hipGraph" if runner.graph_runner is not None else "eager"},
         "ttft_p50_ms": statistics.median(ttfts) * 1e3,
         "phase_ms": {"prefill_cold": cold * 1e3, "prefill_warm": warm * 1e3, "decode": dec * 1e3},
         "decode_tokens_per_s": B / t_decode_step,

@@ -94,3 +94,24 @@ def test_req_token_arrays():
     assert len(key) == 3 and key.match(RadixKey([5, 6, 1])) == 2
     q.origin_input_ids = [1, 2]                                      # a replaced prompt is picked up
     assert list(q.origin_array) == [1, 2]
+
+
+def test_bench_helpers():
+    """bench.py's workload builder and byte / flop bookkeeping (no GPU needed for these)."""
+    import importlib.util
+    from pathlib import Path
+
+    from sglang_amd.harness.models import CONFIGS
+
+    spec = importlib.util.spec_from_file_location("bench_mod", Path(__file__).resolve().parent.parent / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cfg = CONFIGS["llama-3-8b"]
+    assert bench.p_lin(cfg) == 32 * (4096 * 6144 + 4096 * 4096 + 4096 * 28672 + 14336 * 4096)   # SURVEY 8(d): 6.98e9
+    prompts = bench.build_prompts(cfg, 4, 16, 896, 128)
+    assert len(prompts) == 4 and all(len(g) == 16 for g in prompts)
+    assert all(len(p) == 1024 and p[:896] == g[0][:896] for g in prompts for p in g)             # shared system prompt
+    assert prompts[0][0][:896] != prompts[1][0][:896] and prompts[0][0][896:] != prompts[0][1][896:]
+    assert bench.build_prompts(cfg, 4, 16, 896, 128) == prompts                                   # seeded
+    t = bench.pmc_traffic_bytes("wstream_gemm_kernel")                                            # committed PMC passes
+    assert t is None or 0.9 * 237e6 < t < 1.2 * 237e6
