@@ -208,3 +208,73 @@ class BruteForcePrefixCache:
         merged = tuple(have) + slots[len(have):]
         self.seqs.append((tokens, merged))
         return len(have)
+
+
+# ---------------------------------------------------------------- shared-prefix decode plan
+def cascade_plan(req_to_token: np.ndarray, req_pool_indices: Sequence[int], seq_lens: Sequence[int], group: int,
+                 min_shared: int = 128, chunk: int = 128, kv_tile: int = 64, max_context_len: Optional[int] = None,
+                 max_items: Optional[int] = None, rows_per_item: int = 64) -> dict:
+    """Host restatement of the device plan of the shared-prefix decode attention (the product's
+    sglang_amd/csrc/cascade_attention.hip cascade_plan_kernel; the reference has no counterpart -- its decode
+    path, triton_backend.py:136-1012, reads a radix-shared prefix once per request).
+
+    Requests that share ANY cached prefix share their first slot, so the leader of request b is the lowest
+    batch index with the same first slot; the shared length with the leader is the first mismatch of the two
+    req_to_token rows (the newest token is never shared); a group's shared part is the minimum over its members
+    rounded down to kv_tile, groups below min_shared (or single requests) are dropped.  Items: the shared chunks
+    of every group x member tiles of rows_per_item // group members, then the private chunks of every request.
+    Returns req_shared[B], groups (leader, kv, members), shared_items (group, slot, first member, members),
+    private_items (request, slot, kv_begin, kv_n)."""
+    B = len(seq_lens)
+    mpi = rows_per_item // group
+    ctx = max_context_len if max_context_len is not None else int(max(seq_lens))
+    chunks_max = (ctx + chunk - 1) // chunk
+    if max_items is None:
+        max_items = 2 * (B * (chunks_max + 1) + (B // 2 + 1) * chunks_max)
+    rows = [np.asarray(req_to_token[int(r)]) for r in req_pool_indices]
+    first = [int(rows[b][0]) if int(seq_lens[b]) > 1 else -1 - b for b in range(B)]
+    leader = [min(c for c in range(b + 1) if first[c] == first[b]) for b in range(B)]
+    common = [0] * B
+    for b in range(B):
+        l = leader[b]
+        if l == b:
+            continue
+        lim = min(int(seq_lens[b]) - 1, int(seq_lens[l]) - 1)
+        n = 0
+        while n < lim and rows[b][n] == rows[l][n]:
+            n += 1
+        common[b] = n
+    groups, req_shared, grp_of = [], [0] * B, {}
+    n_items = 0
+    for b in range(B):
+        members = [m for m in range(B) if leader[m] == b]
+        if leader[b] != b or len(members) < 2:
+            continue
+        kv = min(common[m] for m in members if m != b) // kv_tile * kv_tile
+        kv = min(kv, chunks_max * chunk)
+        if kv < min_shared:
+            continue
+        tiles = (len(members) + mpi - 1) // mpi
+        n_chunks = (kv + chunk - 1) // chunk
+        if n_items + tiles * n_chunks > max_items // 2:
+            continue
+        grp_of[b] = len(groups)
+        groups.append((b, kv, members))
+        n_items += tiles * n_chunks
+        for m in members:
+            req_shared[m] = kv
+    shared_items, row0 = [], 0
+    for gi, (b, kv, members) in enumerate(groups):
+        tiles = (len(members) + mpi - 1) // mpi
+        for c in range((kv + chunk - 1) // chunk):
+            for t in range(tiles):
+                shared_items.append((gi, c, row0 + t * mpi, min(mpi, len(members) - t * mpi)))
+        row0 += len(members)
+    private_items = []
+    for b in range(B):
+        sh, ln = req_shared[b], int(seq_lens[b])
+        for j in range((ln - sh + chunk - 1) // chunk if ln > sh else 0):
+            private_items.append((b, (sh + chunk - 1) // chunk + j, sh + j * chunk, min(chunk, ln - sh - j * chunk)))
+    member_rows = [m for _, _, members in groups for m in members]
+    return dict(req_shared=req_shared, groups=groups, member_rows=member_rows, shared_items=shared_items,
+                private_items=private_items)
