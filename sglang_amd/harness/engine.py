@@ -54,6 +54,7 @@ class Req:
     t_arrive: float = 0.0
     t_first_token: float = 0.0
     cached_tokens: int = 0
+    fill_len: int = 0            # chunked prefill: tokens of the prompt committed so far (0 = not truncated)
 
     @property
     def origin_array(self):
@@ -66,7 +67,8 @@ class Req:
 
     def get_fill_ids(self):
         """schedule_batch.py Req.fill_ids = origin_input_ids + output_ids (here as an int64 array)."""
-        return self.origin_array + array("q", self.output_ids) if self.output_ids else self.origin_array
+        arr = self.origin_array + array("q", self.output_ids) if self.output_ids else self.origin_array
+        return arr[: self.fill_len] if self.fill_len else arr
 
     @property
     def seqlen(self) -> int:
@@ -223,6 +225,112 @@ class Engine:
             q.output_ids = saved
         self.running.extend(reqs)
         return next_ids
+
+    # ---- chunked prefill (schedule_policy.py:1004-1060 add_chunked_req, :1160-1200 add_one_req) ----
+    def prefill_chunked(self, reqs: Sequence[Req], chunked_prefill_size: int,
+                        sampling_info: Optional[SamplingBatchInfo] = None) -> None:
+        """Prefill with a per-pass token budget: every pass extends whole requests while the budget lasts; the
+        request that does not fit is truncated to what is left (page aligned) and continues FIRST in the next
+        pass (at most one chunked request at a time, like the reference's PrefillAdder).  A truncated request's
+        committed tokens go into the radix tree with cache_unfinished_req(chunked=True); only requests whose
+        prompt completes in a pass are sampled and join the running batch."""
+        assert chunked_prefill_size >= self.r.page_size
+        pending = list(reqs)
+        chunked: Optional[Req] = None
+        while pending or chunked is not None:
+            budget = chunked_prefill_size
+            batch: List[Req] = []
+            ends: List[int] = []
+            if chunked is not None:
+                q = chunked
+                chunked = None
+                left = len(q.origin_input_ids) - len(q.prefix_indices)
+                take = min(left, budget)
+                if take < left:
+                    take = take // self.r.page_size * self.r.page_size
+                    chunked = q
+                batch.append(q)
+                ends.append(len(q.prefix_indices) + take)
+                budget -= take
+            while pending and budget > 0 and chunked is None:
+                q = pending.pop(0)
+                self._match_and_lock(q)
+                left = len(q.origin_input_ids) - len(q.prefix_indices)
+                take = min(left, budget)
+                if take < left:
+                    take = take // self.r.page_size * self.r.page_size
+                    chunked = q
+                    if take == 0:                      # not even a page of budget left: it starts the next pass
+                        break
+                batch.append(q)
+                ends.append(len(q.prefix_indices) + take)
+                budget -= take
+            if batch:
+                self._extend_pass(batch, ends, sampling_info)
+
+    def _match_and_lock(self, q: Req) -> None:
+        key = RadixKey(q.origin_array[: len(q.origin_input_ids) - 1], q.extra_key, q.cache_salt)
+        m = self.r.tree_cache.match_prefix(MatchPrefixParams(key=key))
+        q.prefix_indices, q.last_node = m.device_indices, m.last_device_node
+        q.cached_tokens = int(m.device_indices.numel())
+        q.cache_protected_len = q.cached_tokens
+        self.r.tree_cache.inc_lock_ref(q.last_node)
+
+    def _extend_pass(self, reqs: Sequence[Req], ends: Sequence[int], sampling_info) -> None:
+        """One extend forward over `reqs`, request i committing prompt tokens [len(prefix_indices), ends[i])."""
+        r, dev, ps_ = self.r, self.device, self.r.page_size
+        tree = r.tree_cache
+        fresh = [q for q in reqs if q.req_pool_idx is None]
+        if fresh and r.req_to_token_pool.alloc(fresh) is None:
+            raise RuntimeError("out of request slots")
+        prefix_lens = [int(q.prefix_indices.numel()) for q in reqs]
+        seq_lens = list(ends)
+        extend_lens = [s - p for s, p in zip(seq_lens, prefix_lens)]
+        T = sum(extend_lens)
+        req_pool_cpu = torch.tensor([q.req_pool_idx for q in reqs], dtype=torch.int64)
+        prefix_cpu = torch.tensor(prefix_lens, dtype=torch.int64)
+        seq_cpu = torch.tensor(seq_lens, dtype=torch.int64)
+        ext_cpu = torch.tensor(extend_lens, dtype=torch.int64)
+        req_pool_dev = req_pool_cpu.to(dev, non_blocking=True)
+        prefix_dev, seq_dev, ext_dev = (t.to(dev, non_blocking=True) for t in (prefix_cpu, seq_cpu, ext_cpu))
+        if ps_ == 1:
+            out_cache_loc = self._alloc_token_slots(T)
+        else:
+            alloc = r.token_to_kv_pool_allocator
+            need_pages = sum((s + ps_ - 1) // ps_ - (p + ps_ - 1) // ps_ for s, p in zip(seq_lens, prefix_lens))
+            if len(alloc.free_pages) < need_pages:
+                tree.evict(EvictParams(num_tokens=(need_pages - len(alloc.free_pages)) * ps_))
+            last_loc = torch.cat([(q.prefix_indices[-1:] if q.prefix_indices.numel() > 0
+                                   else torch.full((1,), -1, dtype=torch.int64, device=dev)) for q in reqs])
+            out_cache_loc = alloc.alloc_extend(prefix_dev, prefix_cpu, seq_dev, seq_cpu, last_loc, T, need_pages)
+            if out_cache_loc is None:
+                raise RuntimeError("out of KV pages")
+        prefix_ptrs = torch.tensor([q.prefix_indices.data_ptr() if q.prefix_indices.numel() else 0 for q in reqs],
+                                   dtype=torch.int64).to(dev, non_blocking=True)
+        kernels.write_req_to_token(r.req_to_token_pool.req_to_token, req_pool_dev, prefix_ptrs, prefix_dev, seq_dev,
+                                   ext_dev, out_cache_loc)
+        input_ids = torch.tensor([t for q, p, e in zip(reqs, prefix_lens, seq_lens) for t in q.origin_input_ids[p:e]],
+                                 dtype=torch.int64).to(dev, non_blocking=True)
+        fb = ForwardBatch.init_new(forward_mode=ForwardMode.EXTEND, input_ids=input_ids, req_pool_indices=req_pool_dev,
+                                   seq_lens=seq_dev.to(torch.int32), out_cache_loc=out_cache_loc, seq_lens_cpu=seq_cpu,
+                                   req_to_token_pool=r.req_to_token_pool, token_to_kv_pool=r.token_to_kv_pool,
+                                   attn_backend=r.attn_backend, extend_prefix_lens_cpu=prefix_lens,
+                                   extend_seq_lens_cpu=extend_lens, sampling_info=sampling_info)
+        logits = r.forward(fb)
+        if self.logits_trace is not None:
+            self.logits_trace.append(logits.next_token_logits.float().cpu())
+        ids_cpu = r.sample(logits, fb).tolist()
+        now = time.perf_counter()
+        for q, end, t in zip(reqs, ends, ids_cpu):
+            if end < len(q.origin_input_ids):          # truncated: commit the chunk, no token yet
+                q.fill_len = end
+                tree.cache_unfinished_req(q, chunked=True)
+                continue
+            q.fill_len = 0
+            q.t_first_token = now
+            tree.cache_unfinished_req(q)               # fill_ids = prompt only: the new token has no KV yet
+            q.output_ids.append(int(t))
+            self.running.append(q)
 
     # ---- decode (scheduler.py:3566 update_running_batch + schedule_batch.py:3060) ----
     def decode_step(self, sampling_info: Optional[SamplingBatchInfo] = None) -> torch.Tensor:

@@ -216,3 +216,36 @@ def test_paged_engine_bookkeeping(cpu_kernels, page):
     tree, alloc = runner.tree_cache, runner.token_to_kv_pool_allocator
     assert tree.protected_size() == 0
     assert alloc.available_size() + tree.evictable_size() == size
+
+
+@pytest.mark.parametrize("page", [1, 4])
+@pytest.mark.parametrize("chunk", [16, 24, 64, 1000])
+def test_chunked_prefill_matches_whole_prompt_prefill(cpu_kernels, page, chunk):
+    """prefill_chunked (schedule_policy.py:1004-1060 / 1160-1200): every pass stays inside the token budget, at most
+    one request is truncated per pass and it continues first, and the generated tokens / final cache state are those
+    of the unchunked prefill."""
+    chunk = max(chunk // page * page, page)
+    prompts = _prompts(2, 3, 30, seed=11) + [[(3 * i + 1) % VOCAB for i in range(70)]]      # one long prompt
+    B, new_tokens = len(prompts), 4
+    size = B * 128 // page * page
+    runner = _ToyRunner(B, 128, size, page_size=page)
+    eng = Engine(runner)
+    reqs = [Req(i, p, new_tokens) for i, p in enumerate(prompts)]
+    eng.prefill_chunked(reqs, chunk)
+    ext = [c for c in runner.seen if c[0]]
+    assert all(len(slots) <= chunk for _, _, slots, _ in ext)                   # the budget holds in every pass
+    assert sum(len(slots) for _, _, slots, _ in ext) == sum(len(p) - q.cached_tokens for p, q in zip(prompts, reqs))
+    if chunk < 70:
+        assert len(ext) >= 2                                                    # the long prompt needed several passes
+    assert sorted(q.rid for q in eng.running) == list(range(B))
+    for _ in range(new_tokens - 1):
+        eng.decode_step()
+        eng.flush_decode_outputs(lag=1)
+    done = sorted(eng.running, key=lambda q: q.rid)
+    eng.finish(list(eng.running))
+    for q in done:
+        assert q.output_ids == _expected(q.origin_input_ids, new_tokens), q.rid
+    tree, alloc = runner.tree_cache, runner.token_to_kv_pool_allocator
+    assert tree.protected_size() == 0
+    assert alloc.available_size() + tree.evictable_size() == size
+    assert runner.req_to_token_pool.available_size() == runner.req_to_token_pool.size
