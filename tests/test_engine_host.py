@@ -249,3 +249,26 @@ def test_chunked_prefill_matches_whole_prompt_prefill(cpu_kernels, page, chunk):
     assert tree.protected_size() == 0
     assert alloc.available_size() + tree.evictable_size() == size
     assert runner.req_to_token_pool.available_size() == runner.req_to_token_pool.size
+
+
+def test_waves_of_requests_reuse_the_tree_and_the_slots(cpu_kernels):
+    """Two generations back to back on one engine: the second wave hits what the first one left in the radix
+    tree (prompt + generated tokens of a finished request are cached), under a pool small enough to need eviction."""
+    prompts = _prompts(2, 3, 24, seed=21)
+    B = len(prompts)
+    size = sum(len(p) + 14 for p in prompts) * 4 // 3         # holds one wave, not both: the second one must evict
+    runner = _ToyRunner(B, 96, size)
+    eng = Engine(runner)
+    first = [Req(i, p, 5) for i, p in enumerate(prompts)]
+    eng.generate(first)
+    assert [q.output_ids for q in first] == [_expected(p, 5) for p in prompts]
+    # second wave: each prompt continued by its own generated tokens -> the whole old sequence but the last token
+    # (whose KV row was never written) is a radix hit
+    second_prompts = [p + q.output_ids + [5, 6, 7] for p, q in zip(prompts, first)]
+    second = [Req(100 + i, p, 4) for i, p in enumerate(second_prompts)]
+    eng.generate(second)
+    assert [q.output_ids for q in second] == [_expected(p, 4) for p in second_prompts]
+    hits = [q.cached_tokens for q in second]
+    assert all(h >= len(p) + 5 - 1 - 24 for h, p in zip(hits, prompts)) and max(hits) >= 24
+    tree, alloc = runner.tree_cache, runner.token_to_kv_pool_allocator
+    assert tree.protected_size() == 0 and alloc.available_size() + tree.evictable_size() == size
