@@ -17,7 +17,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB_DIR = PKG / "lib"
 LIB_PATH = LIB_DIR / "libsglang_amd.so"
-INCLUDE = PKG.parent / "include"
+INCLUDE = PKG / "include"          # the packaged header (a link to the repo's include/ in the source tree)
 ARCH = "gfx950"
 
 HIPCC_FLAGS = [
@@ -44,12 +44,14 @@ def sources() -> list[Path]:
 
 
 def _deps_mtime() -> float:
-    hdrs = list(CSRC.glob("*.hpp")) + list(INCLUDE.glob("*.h"))
-    return max([h.stat().st_mtime for h in hdrs] + [0.0])
+    hdrs = list(CSRC.glob("*.hpp")) + list(INCLUDE.glob("*.h")) + list((PKG.parent / "include").glob("*.h"))
+    return max([h.stat().st_mtime for h in hdrs if h.exists()] + [0.0])
 
 
 def _compile_one(src: Path, obj: Path, verbose: bool) -> None:
-    cmd = [_hipcc(), *HIPCC_FLAGS, "-c", str(src), "-o", str(obj)]
+    # the C-ABI header: packaged copy first (installed tree), the repo's include/ as the source-tree fallback
+    incs = [f"-I{d}" for d in (INCLUDE, PKG.parent / "include") if (d / "sglang_amd.h").exists()]
+    cmd = [_hipcc(), *HIPCC_FLAGS, *incs, "-c", str(src), "-o", str(obj)]
     if src.suffix == ".cpp":
         cmd.insert(1, "-x")
         cmd.insert(2, "hip")

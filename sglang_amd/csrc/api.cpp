@@ -2,7 +2,7 @@
 #include <cstdarg>
 #include <cstdio>
 
-#include "../../include/sglang_amd.h"
+#include "sglang_amd.h"
 
 namespace sgl_amd {
 

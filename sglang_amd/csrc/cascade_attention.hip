@@ -20,7 +20,7 @@
 // the merge kernel combines the slots of a (request, head) in slot order.
 #include "common.hpp"
 #include "cascade_plan.hpp"
-#include "../../include/sglang_amd.h"
+#include "sglang_amd.h"
 
 using namespace sgl_amd;
 

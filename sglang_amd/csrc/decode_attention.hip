@@ -21,7 +21,7 @@
 //   * long sequences are split over gridDim.z; partial (m, l, acc) go to a
 //     caller-owned fp32 workspace and a small second kernel merges them.
 #include "common.hpp"
-#include "../../include/sglang_amd.h"
+#include "sglang_amd.h"
 
 using namespace sgl_amd;
 

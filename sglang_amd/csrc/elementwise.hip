@@ -13,7 +13,7 @@
 // bf16 rounding points reproduced so results are bit-comparable with the
 // torch-native path.
 #include "common.hpp"
-#include "../../include/sglang_amd.h"
+#include "sglang_amd.h"
 
 using namespace sgl_amd;
 

@@ -25,7 +25,7 @@
 //   * fp32 accumulation, exp2 with the softmax scale folded in, bf16 output.
 #include <cstdlib>
 #include "common.hpp"
-#include "../../include/sglang_amd.h"
+#include "sglang_amd.h"
 
 using namespace sgl_amd;
 

@@ -14,7 +14,7 @@
 // they exist so a step never needs a device->host sync, and so the decode
 // step can be captured in a hipGraph with static buffers.
 #include "common.hpp"
-#include "../../include/sglang_amd.h"
+#include "sglang_amd.h"
 
 using namespace sgl_amd;
 

@@ -9,7 +9,7 @@
 //     kernels/ops/moe/fused_moe_triton_kernels.py:1165 _moe_sum_reduce_kernel).
 // The grouped GEMM itself lives in skinny_gemm.hip.
 #include "common.hpp"
-#include "../../include/sglang_amd.h"
+#include "sglang_amd.h"
 
 using namespace sgl_amd;
 

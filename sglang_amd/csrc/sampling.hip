@@ -11,7 +11,7 @@
 // One workgroup of 1024 threads per row; a row (vocab x fp32, ~0.5 MB) stays in
 // L2 between the passes, so the passes cost L2 bandwidth, not HBM.
 #include "common.hpp"
-#include "../../include/sglang_amd.h"
+#include "sglang_amd.h"
 
 using namespace sgl_amd;
 

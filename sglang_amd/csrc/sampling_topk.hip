@@ -25,7 +25,7 @@
 //      takes the arg max (first maximum), exactly the reference's arithmetic.
 // The row (V x 4 B, ~0.5 MB) is read 5-6 times but stays in L2.
 #include "common.hpp"
-#include "../../include/sglang_amd.h"
+#include "sglang_amd.h"
 
 using namespace sgl_amd;
 

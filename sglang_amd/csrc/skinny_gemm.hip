@@ -29,7 +29,7 @@
 //     epilogue with the same bf16 rounding points as the unfused torch ops.
 #include <cstdlib>
 #include "common.hpp"
-#include "../../include/sglang_amd.h"
+#include "sglang_amd.h"
 
 using namespace sgl_amd;
 

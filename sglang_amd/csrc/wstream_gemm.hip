@@ -24,7 +24,7 @@
 //     split order (deterministic) and applies the epilogue the next operator would have been:
 //     bias, silu(gate)*up, or residual-add + RMSNorm, with the torch-native bf16 rounding points.
 #include "common.hpp"
-#include "../../include/sglang_amd.h"
+#include "sglang_amd.h"
 
 using namespace sgl_amd;
 

@@ -164,6 +164,7 @@ class Engine:
     def prefill(self, reqs: Sequence[Req], sampling_info: Optional[SamplingBatchInfo] = None) -> torch.Tensor:
         r, dev, ps_ = self.r, self.device, self.r.page_size
         tree = r.tree_cache
+        self._retire_decode_state()
         for q in reqs:
             # match against at most len-1 tokens so at least one token is computed (schedule_policy.py:138)
             key = RadixKey(q.origin_array[: len(q.origin_input_ids) - 1], q.extra_key, q.cache_salt)
@@ -280,6 +281,7 @@ class Engine:
         """One extend forward over `reqs`, request i committing prompt tokens [len(prefix_indices), ends[i])."""
         r, dev, ps_ = self.r, self.device, self.r.page_size
         tree = r.tree_cache
+        self._retire_decode_state()
         fresh = [q for q in reqs if q.req_pool_idx is None]
         if fresh and r.req_to_token_pool.alloc(fresh) is None:
             raise RuntimeError("out of request slots")
@@ -339,6 +341,9 @@ class Engine:
         bs = len(reqs)
         st = self._decode_state
         if st is None or st["bs"] != bs:
+            # hand-offs still in flight belong to the OLD batch composition: deliver them before the state
+            # (and its pending list) is rebuilt, or those tokens never reach output_ids
+            self.flush_decode_outputs()
             st = self._decode_state = self._build_decode_state(reqs)
         # alloc_for_decode (allocation.py:512-560): one slot per request, written at column seq_len
         if ps_ == 1:
@@ -386,9 +391,17 @@ class Engine:
                     seq_lens=torch.tensor(seq, dtype=torch.int32, device=dev),
                     seq_lens_cpu=torch.tensor(seq, dtype=torch.int64),
                     last_ids=torch.tensor([q.output_ids[-1] for q in reqs], dtype=torch.int64, device=dev),
-                    pending=[], free_host=[])
+                    pending=[], free_host=[], reqs=list(reqs))
 
     _decode_state = None
+
+    def _retire_decode_state(self) -> None:
+        """The running batch is about to change (new requests join): deliver every in-flight hand-off to the
+        requests it was sampled for, then drop the per-batch device state so that the next decode step rebuilds
+        it from the requests' own output_ids."""
+        if self._decode_state is not None:
+            self.flush_decode_outputs()
+            self._decode_state = None
 
     def flush_decode_outputs(self, lag: int = 0) -> None:
         """Hand the sampled ids of the finished steps to the requests.  `lag` = newest steps left in flight:
@@ -402,7 +415,7 @@ class Engine:
         for host, ev in ready:
             if ev is not None:
                 ev.synchronize()
-            for q, t in zip(self.running, host.tolist()):
+            for q, t in zip(st["reqs"], host.tolist()):
                 q.output_ids.append(t)
             st["free_host"].append(host)
 

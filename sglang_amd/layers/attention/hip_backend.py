@@ -63,7 +63,8 @@ class HipAttnBackend(AttentionBackend):
         self.max_context_len = self.req_to_token_pool.max_context_len
         self.forward_metadata: Optional[_Meta] = None
         self._graph_ws = {}
-        self._cascade_ws = {}
+        self._cascade_ws = None
+        self._cascade_in_graph = False
         self.debug_flags = 0
         # RadixAttention batches share KV prefixes; the cascade decode path reads a shared prefix once
         # per group (SGLANG_AMD_CASCADE=0 falls back to the plain paged decode kernel)
@@ -81,16 +82,24 @@ class HipAttnBackend(AttentionBackend):
         return ws
 
     def _cascade_workspace(self, batch: int):
-        ws = self._cascade_ws.get(batch)
-        if ws is None:
-            ws = kernels.CascadeWorkspace(batch, self.num_q_heads, self.head_dim, self.max_context_len, self.device)
-            self._cascade_ws[batch] = ws
+        """ONE workspace, sized for the largest batch seen (the graph runner asks for max_bs first): the plan and
+        the slot layout are addressed with the actual batch size of the step, and replays are stream-serialised,
+        so every bucket and every eager batch can share it.  It only ever grows before graphs exist."""
+        ws = self._cascade_ws
+        if ws is None or ws.max_batch < batch:
+            if ws is not None and self._cascade_in_graph:
+                raise RuntimeError(f"cascade workspace holds {ws.max_batch} requests and is referenced by captured "
+                                   f"graphs; a batch of {batch} needs init_cuda_graph_state(max_bs >= {batch})")
+            ws = self._cascade_ws = kernels.CascadeWorkspace(batch, self.num_q_heads, self.head_dim,
+                                                             self.max_context_len, self.device)
         return ws
 
     def init_cuda_graph_state(self, max_bs: int, max_num_tokens: int):
         """Pre-allocate the split workspaces for the largest bucket (reference :159)."""
         splits = choose_num_splits(1, self.num_kv_heads, self.num_q_heads // self.num_kv_heads, self.max_context_len)
         self._workspace(max_bs, max(splits, 1))
+        if self.enable_cascade and max_bs >= 2:
+            self._cascade_workspace(min(max_bs, 1024))
 
     def get_cuda_graph_seq_len_fill_value(self):
         return 1
@@ -105,6 +114,7 @@ class HipAttnBackend(AttentionBackend):
                 max_len = int(fb.seq_lens_cpu.max()) if fb.seq_lens_cpu is not None else self.max_context_len
             if self.enable_cascade and 2 <= fb.batch_size <= 1024:
                 self.forward_metadata = _Meta(seq_i32, cascade=self._cascade_workspace(fb.batch_size))
+                self._cascade_in_graph |= in_capture
                 return
             splits = choose_num_splits(fb.batch_size, self.num_kv_heads, self.num_q_heads // self.num_kv_heads, max_len)
             ws = self._workspace(fb.batch_size, splits) if splits > 1 else (None, None)

@@ -18,7 +18,10 @@ _F32 = ctypes.c_float
 
 PKG = Path(__file__).resolve().parent
 LIB_PATH = PKG / "lib" / "libsglang_amd.so"
-HEADER_PATH = PKG.parent / "include" / "sglang_amd.h"
+# the header ships inside the package (sglang_amd/include/, listed in package-data) so that an installed,
+# non-editable tree can bind and rebuild; in the source tree that entry is a link to the repo's include/
+HEADER_PATH = next((h for h in (PKG / "include" / "sglang_amd.h", PKG.parent / "include" / "sglang_amd.h") if h.exists()),
+                   PKG / "include" / "sglang_amd.h")
 
 _lib = None
 _sigs: Dict[str, List] = {}

@@ -272,3 +272,37 @@ def test_waves_of_requests_reuse_the_tree_and_the_slots(cpu_kernels):
     assert all(h >= len(p) + 5 - 1 - 24 for h, p in zip(hits, prompts)) and max(hits) >= 24
     tree, alloc = runner.tree_cache, runner.token_to_kv_pool_allocator
     assert tree.protected_size() == 0 and alloc.available_size() + tree.evictable_size() == size
+
+
+@pytest.mark.parametrize("lag", [0, 1])
+def test_prefill_between_lagged_decode_steps_keeps_every_token(cpu_kernels, lag):
+    """A new request joins the running batch while hand-offs of the previous steps are still in flight
+    (flush_decode_outputs(lag=1) then prefill): the in-flight tokens must reach their requests before the
+    per-batch decode state is rebuilt, every request ends with exactly max_new_tokens correct tokens, and no
+    KV slot leaks (a stale seq_len would overwrite a req_to_token column)."""
+    prompts = _prompts(2, 3, 12, seed=21)
+    first, late = prompts[:4], prompts[4:]
+    n_first, n_late = 9, 5
+    runner = _ToyRunner(len(prompts), 64, len(prompts) * 64)
+    eng = Engine(runner)
+    a = [Req(i, p, n_first) for i, p in enumerate(first)]
+    b = [Req(10 + i, p, n_late) for i, p in enumerate(late)]
+    eng.prefill(a)
+    for _ in range(3):
+        eng.decode_step()
+        eng.flush_decode_outputs(lag=lag)
+    eng.prefill(b)                                  # joins between two lagged steps
+    for _ in range(n_late - 1):
+        eng.decode_step()
+        eng.flush_decode_outputs(lag=lag)
+    eng.finish(b)                                   # the late ones are done; the first ones go on
+    for _ in range(n_first - 1 - 3 - (n_late - 1)):
+        eng.decode_step()
+        eng.flush_decode_outputs(lag=lag)
+    eng.finish(list(eng.running))
+    for q in a + b:
+        assert q.output_ids == _expected(q.origin_input_ids, q.max_new_tokens), q.rid
+    tree, alloc = runner.tree_cache, runner.token_to_kv_pool_allocator
+    assert tree.protected_size() == 0
+    assert alloc.available_size() + tree.evictable_size() == len(prompts) * 64
+    assert runner.req_to_token_pool.available_size() == runner.req_to_token_pool.size
