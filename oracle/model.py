@@ -1,5 +1,10 @@
-"""CPU restatement of the reference decoder forward (torch-native everywhere),
-used for end-to-end parity and as bench.py's `cpu_baseline`.  TEST INFRASTRUCTURE ONLY.
+"""Restatement of the reference decoder forward (torch-native everywhere), used for
+end-to-end parity and as bench.py's `cpu_baseline`.  TEST INFRASTRUCTURE ONLY.
+
+`device="cpu"` (default) is the reference's CPU torch-native path (BASELINE configs[0]);
+with a HIP device the same plain torch ops run on the GPU -- what the reference's
+`--attention-backend torch_native` executes there -- so that the full-size jobs can be
+teacher-force-compared in seconds (oracle/parity.py).
 
 Follows /root/reference/python/sglang/srt/models/llama.py:219-223 (rope then
 attention), :341-370 (layer wiring with fused add+norm), :419-470 (model loop),
@@ -20,7 +25,8 @@ from . import ops
 
 class OracleLM:
     def __init__(self, cfg, weights: Dict[str, torch.Tensor], num_slots: int = 4096, max_ctx: int = 2048,
-                 compute_dtype: Optional[torch.dtype] = None, tp_size: int = 1, tp_group=None, max_reqs: int = 63):
+                 compute_dtype: Optional[torch.dtype] = None, tp_size: int = 1, tp_group=None, max_reqs: int = 63,
+                 device="cpu", batched_decode: bool = False):
         """`weights`: CPU tensors keyed like the product model's state_dict().  With tp_size > 1 the
         weights are ONE rank's shard (heads / intermediate / vocab split as in the reference's
         Column/RowParallelLinear, srt/layers/linear.py) and the row-parallel outputs are summed with
@@ -30,8 +36,10 @@ class OracleLM:
         self.tp_size, self.tp_group = tp_size, tp_group
         self.Hq = cfg.num_attention_heads // tp_size
         self.Hkv = max(1, cfg.num_key_value_heads // tp_size)
-        self.w = {k: v.detach().cpu() for k, v in weights.items()}
+        self.device = torch.device(device)
+        self.w = {k: v.detach().to(self.device) for k, v in weights.items()}     # no copy when already there
         self.compute_dtype = compute_dtype
+        self.batched_decode = batched_decode
         D = cfg.head_dim
         if cfg.rope_scaling and cfg.rope_scaling.get("rope_type") == "llama3":
             rs = cfg.rope_scaling
@@ -39,11 +47,12 @@ class OracleLM:
                                       rs["original_max_position_embeddings"])
         else:
             inv = ops.rope_inv_freq(D, cfg.rope_theta)
-        self.rope_cache = ops.cos_sin_cache(inv, cfg.max_position_embeddings).to(torch.bfloat16)
+        self.rope_cache = ops.cos_sin_cache(inv, cfg.max_position_embeddings).to(torch.bfloat16).to(self.device)
         L = cfg.num_hidden_layers
-        self.k_cache = [torch.zeros((num_slots, self.Hkv, D), dtype=torch.bfloat16) for _ in range(L)]
-        self.v_cache = [torch.zeros((num_slots, self.Hkv, D), dtype=torch.bfloat16) for _ in range(L)]
-        self.req_to_token = torch.zeros((max_reqs + 1, max_ctx), dtype=torch.int32)
+        dev = self.device
+        self.k_cache = [torch.zeros((num_slots, self.Hkv, D), dtype=torch.bfloat16, device=dev) for _ in range(L)]
+        self.v_cache = [torch.zeros((num_slots, self.Hkv, D), dtype=torch.bfloat16, device=dev) for _ in range(L)]
+        self.req_to_token = torch.zeros((max_reqs + 1, max_ctx), dtype=torch.int32, device=dev)
         self.next_slot = 1
 
     # ---- one forward over a ragged batch --------------------------------------------------
@@ -68,7 +77,7 @@ class OracleLM:
             q3 = q.reshape(-1, Hq, D)
             if decode:
                 o = ops.decode_attention(q3, self.k_cache[i], self.v_cache[i], self.req_to_token, req_pool, seq_lens,
-                                         D ** -0.5, self.compute_dtype)
+                                         D ** -0.5, self.compute_dtype, batched=self.batched_decode)
             else:
                 o = ops.extend_attention(q3, self.k_cache[i], self.v_cache[i], self.req_to_token, req_pool, seq_lens,
                                          prefix_lens, extend_lens, D ** -0.5, True, self.compute_dtype)
@@ -104,45 +113,76 @@ class OracleLM:
 
     # ---- greedy generation with prefix reuse expressed the plain way ------------------------
     def generate(self, prompts: Sequence[Sequence[int]], max_new_tokens: int, return_logits: bool = False,
-                 forced: Optional[Sequence[Sequence[int]]] = None):
+                 forced: Optional[Sequence[Sequence[int]]] = None, logits_hook=None,
+                 share_prefix_groups: Optional[Sequence[Sequence[int]]] = None, shared_len: int = 0):
         """Every request gets its own fresh slots (no sharing): the reference result the
         radix-cached run must reproduce.  `forced[b][i]` (teacher forcing) replaces the
         oracle's own i-th sampled token as the next input, so logits can be compared
-        step by step against a run whose argmax flipped on a near-tie."""
+        step by step against a run whose argmax flipped on a near-tie.  `logits_hook(step, logits)`
+        receives every step's fp32 logits instead of keeping them all (full-size jobs).
+
+        `share_prefix_groups` (lists of prompt indices whose first `shared_len` tokens are equal) runs the
+        prefill the way the radix-cached scheduler does -- each group's first request cold, the others as
+        extends over that request's slots for the shared part -- the phases bench.py times (cpu_baseline)."""
+        dev = self.device
         B = len(prompts)
-        req_pool = torch.arange(1, B + 1)
-        lens = torch.tensor([len(p) for p in prompts])
-        T = int(lens.sum())
-        out_loc = torch.arange(self.next_slot, self.next_slot + T)
-        self.next_slot += T
-        off = 0
-        for b in range(B):
-            self.req_to_token[b + 1, : lens[b]] = out_loc[off: off + lens[b]].to(torch.int32)
-            off += int(lens[b])
-        ids = torch.tensor([t for p in prompts for t in p])
-        pos = torch.cat([torch.arange(0, int(n)) for n in lens])
-        zeros = torch.zeros(B, dtype=torch.int64)
-        logits = self.forward(ids, pos, req_pool, lens, zeros, lens, out_loc, decode=False)
-        all_logits = [logits]
-        outs = [[int(t)] for t in logits.argmax(-1)]
+        req_pool = torch.arange(1, B + 1, device=dev)
+        lens_l = [len(p) for p in prompts]
+        lens = torch.tensor(lens_l, device=dev)
+        logits = torch.empty((B, self.w["lm_head"].shape[0] * self.tp_size), dtype=torch.float32, device=dev)
+        if share_prefix_groups:
+            passes = [[g[0] for g in share_prefix_groups], [b for g in share_prefix_groups for b in g[1:]]]
+            leader_of = {b: g[0] for g in share_prefix_groups for b in g[1:]}
+        else:
+            passes, leader_of = [list(range(B))], {}
+        for members in passes:
+            if not members:
+                continue
+            pre_l = [shared_len if b in leader_of else 0 for b in members]
+            ext_l = [lens_l[b] - p for b, p in zip(members, pre_l)]
+            T = sum(ext_l)
+            out_loc = torch.arange(self.next_slot, self.next_slot + T, device=dev)
+            self.next_slot += T
+            off = 0
+            for b, pre, ext in zip(members, pre_l, ext_l):
+                if pre:
+                    self.req_to_token[b + 1, :pre] = self.req_to_token[leader_of[b] + 1, :pre]
+                self.req_to_token[b + 1, pre: pre + ext] = out_loc[off: off + ext].to(torch.int32)
+                off += ext
+            ids = torch.tensor([t for b, pre in zip(members, pre_l) for t in prompts[b][pre:]], device=dev)
+            pos = torch.cat([torch.arange(pre, pre + ext, device=dev) for pre, ext in zip(pre_l, ext_l)])
+            midx = torch.tensor(members, device=dev)
+            logits[midx] = self.forward(ids, pos, req_pool[midx], lens[midx], torch.tensor(pre_l, device=dev),
+                                        torch.tensor(ext_l, device=dev), out_loc, decode=False)
+        all_logits = []
+        if logits_hook is not None:
+            logits_hook(0, logits)
+        if return_logits:
+            all_logits.append(logits)
+        first = logits.argmax(-1).tolist()
+        outs = [[int(t)] for t in first]
         fed = [[forced[b][0]] if forced is not None else [outs[b][0]] for b in range(B)]
         seq = lens.clone()
-        for _ in range(max_new_tokens - 1):
-            loc = torch.arange(self.next_slot, self.next_slot + B)
+        for step in range(1, max_new_tokens):
+            loc = torch.arange(self.next_slot, self.next_slot + B, device=dev)
             self.next_slot += B
             self.req_to_token[req_pool, seq] = loc.to(torch.int32)
             seq = seq + 1
-            last = torch.tensor([f[-1] for f in fed])
+            last = torch.tensor([f[-1] for f in fed], device=dev)
             logits = self.forward(last, seq - 1, req_pool, seq, None, None, loc, decode=True)
-            all_logits.append(logits)
-            for b, (o, t) in enumerate(zip(outs, logits.argmax(-1))):
+            if logits_hook is not None:
+                logits_hook(step, logits)
+            if return_logits:
+                all_logits.append(logits)
+            for b, (o, t) in enumerate(zip(outs, logits.argmax(-1).tolist())):
                 o.append(int(t))
                 fed[b].append(forced[b][len(fed[b])] if forced is not None else int(t))
         return (outs, all_logits) if return_logits else outs
 
 
-def weights_from_product_model(model) -> Dict[str, torch.Tensor]:
-    """Collect the product model's (TP=1) parameters under oracle names."""
+def weights_from_product_model(model, device="cpu") -> Dict[str, torch.Tensor]:
+    """Collect the product model's (TP=1) parameters under oracle names (on `device`; no copy when the
+    parameters already live there)."""
     w = {"embed_tokens": model.embed_tokens.data, "norm.weight": model.norm.weight.data, "lm_head": model.lm_head.data}
     for i, layer in enumerate(model.layers):
         p = f"layers.{i}."
@@ -160,4 +200,4 @@ def weights_from_product_model(model) -> Dict[str, torch.Tensor]:
             w[p + "mlp.gate.weight"] = mlp.gate.weight.data
             w[p + "mlp.experts.w13_weight"] = mlp.experts.w13_weight.data
             w[p + "mlp.experts.w2_weight"] = mlp.experts.w2_weight.data
-    return {k: v.detach().cpu() for k, v in w.items()}
+    return {k: v.detach().to(device) for k, v in w.items()}

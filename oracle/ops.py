@@ -1,5 +1,10 @@
-"""Floating-point operator oracles (torch CPU), restating the reference's
+"""Floating-point operator oracles (plain torch ops), restating the reference's
 `forward_native` / torch-native implementations.  TEST INFRASTRUCTURE ONLY.
+
+Device-agnostic: on CPU tensors this is the reference's CPU torch-native path; on HIP
+tensors it is what the reference's `torch_native` attention backend + forward_native
+operators execute on a GPU (torch SDPA / F.linear / elementwise ops, no custom kernel),
+which is how the full-size configurations are checked in seconds.
 
 All paths are relative to /root/reference/python/sglang.
 """
@@ -129,16 +134,18 @@ def extend_attention(query: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.
     q = query.movedim(0, query.dim() - 2)  # [H, T, D]
     enable_gqa = query.shape[1] != k_cache.shape[1]
     start_q = 0
+    ext_l, pre_l, kv_l, pool_l = (t.tolist() for t in (extend_seq_lens, extend_prefix_lens, seq_lens, req_pool_indices))
     for i in range(seq_lens.shape[0]):
-        ext = int(extend_seq_lens[i])
-        pre = int(extend_prefix_lens[i])
-        kv = int(seq_lens[i])
+        ext = int(ext_l[i])
+        pre = int(pre_l[i])
+        kv = int(kv_l[i])
         end_q = start_q + ext
         per_req_query = q[:, start_q:end_q, :]
-        red = torch.empty((per_req_query.shape[0], kv, per_req_query.shape[2]), dtype=per_req_query.dtype)
+        red = torch.empty((per_req_query.shape[0], kv, per_req_query.shape[2]), dtype=per_req_query.dtype,
+                          device=query.device)
         red.zero_()  # the reference leaves the padded rows uninitialised; they are discarded
         red[:, pre:, :] = per_req_query
-        toks = req_to_token[int(req_pool_indices[i]), :kv].long()
+        toks = req_to_token[int(pool_l[i]), :kv].long()
         key = k_cache[toks].movedim(0, query.dim() - 2)
         val = v_cache[toks].movedim(0, query.dim() - 2)
         if compute_dtype is not None:
@@ -153,15 +160,28 @@ def extend_attention(query: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.
 
 def decode_attention(query: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, req_to_token: torch.Tensor,
                      req_pool_indices: torch.Tensor, seq_lens: torch.Tensor, scaling: float,
-                     compute_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+                     compute_dtype: Optional[torch.dtype] = None, batched: bool = False) -> torch.Tensor:
     """torch_native_backend.py:176-277 (_run_sdpa_forward_decode): one query per request."""
     out = torch.empty_like(query)
     q = query.movedim(0, query.dim() - 2)
     enable_gqa = query.shape[1] != k_cache.shape[1]
+    kv_l, pool_l = seq_lens.tolist(), req_pool_indices.tolist()
+    if batched and len(set(kv_l)) == 1 and len(kv_l) > 1:
+        # every request has the same KV length: the per-request SDPA calls of the reference loop are issued as one
+        # batched call (identical arithmetic per request; tests/test_oracle_golden.py checks it against the loop)
+        kv = int(kv_l[0])
+        toks = req_to_token[req_pool_indices.long(), :kv].long()          # [B, kv]
+        key = k_cache[toks].transpose(1, 2)                               # [B, Hkv, kv, D]
+        val = v_cache[toks].transpose(1, 2)
+        qb = query.unsqueeze(2)                                           # [B, Hq, 1, D]
+        if compute_dtype is not None:
+            qb, key, val = qb.to(compute_dtype), key.to(compute_dtype), val.to(compute_dtype)
+        o = F.scaled_dot_product_attention(qb, key, val, enable_gqa=enable_gqa, scale=scaling, is_causal=False)
+        return o.squeeze(2).to(out.dtype)
     for i in range(seq_lens.shape[0]):
-        kv = int(seq_lens[i])
+        kv = int(kv_l[i])
         per_req_query = q[:, i:i + 1, :]
-        toks = req_to_token[int(req_pool_indices[i]), :kv].long()
+        toks = req_to_token[int(pool_l[i]), :kv].long()
         key = k_cache[toks].movedim(0, query.dim() - 2)
         val = v_cache[toks].movedim(0, query.dim() - 2)
         if compute_dtype is not None:

@@ -148,6 +148,13 @@ class Engine:
         self.running: List[Req] = []
         self.stats: Dict[str, float] = {}
         self.logits_trace: Optional[List[torch.Tensor]] = None   # tests: set to [] to record every step's logits
+        self.logits_device_trace: Optional[List[torch.Tensor]] = None   # same, kept on the device in the model dtype
+
+    def _record_logits(self, logits) -> None:
+        if self.logits_trace is not None:
+            self.logits_trace.append(logits.next_token_logits.float().cpu())
+        if self.logits_device_trace is not None:
+            self.logits_device_trace.append(logits.next_token_logits.clone())   # the graph's output buffer is reused
 
     # ---- KV slot allocation with eviction (allocation.py:150-279 alloc_token_slots) ----
     def _alloc_token_slots(self, n: int) -> torch.Tensor:
@@ -211,8 +218,7 @@ class Engine:
                                    attn_backend=r.attn_backend, extend_prefix_lens_cpu=prefix_lens,
                                    extend_seq_lens_cpu=extend_lens, sampling_info=sampling_info)
         logits = r.forward(fb)
-        if self.logits_trace is not None:
-            self.logits_trace.append(logits.next_token_logits.float().cpu())
+        self._record_logits(logits)
         next_ids = r.sample(logits, fb)
         ids_cpu = next_ids.tolist()                  # the scheduler's one sync per step
         now = time.perf_counter()
@@ -319,8 +325,7 @@ class Engine:
                                    attn_backend=r.attn_backend, extend_prefix_lens_cpu=prefix_lens,
                                    extend_seq_lens_cpu=extend_lens, sampling_info=sampling_info)
         logits = r.forward(fb)
-        if self.logits_trace is not None:
-            self.logits_trace.append(logits.next_token_logits.float().cpu())
+        self._record_logits(logits)
         ids_cpu = r.sample(logits, fb).tolist()
         now = time.perf_counter()
         for q, end, t in zip(reqs, ends, ids_cpu):
@@ -367,8 +372,7 @@ class Engine:
         if r.graph_runner is None or not r.graph_runner.can_run(bs):
             fb.positions = kernels.clamp_position(fb.seq_lens)
         logits = r.forward(fb)
-        if self.logits_trace is not None:
-            self.logits_trace.append(logits.next_token_logits.float().cpu())
+        self._record_logits(logits)
         next_ids = r.sample(logits, fb)
         st["last_ids"] = next_ids.to(torch.int64)
         # token hand-off to the host: an async copy into pinned memory + an event, so that the scheduler can

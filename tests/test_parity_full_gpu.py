@@ -1,0 +1,144 @@
+"""End-to-end parity at the BASELINE.json configurations themselves, teacher-forced against the oracle running
+its plain torch ops on the GPU (= the reference's torch-native path there; oracle/parity.py):
+
+  * configs[1]: the benchmarked job -- Llama-3-8B, all 32 layers, 4 groups x 16 prompts, 896 shared + 128 unique
+    tokens in, 128 out, radix-cached prefill + hipGraph decode (what bench.py times);
+  * configs[2]: one TP=8 rank of Llama-3-70B (hidden 8192, 8 q heads, 1 kv head, intermediate 3584, vocab shard
+    16032) as a layer stack -- a rank's arithmetic is a TP=1 model of those shapes up to the all-reduce;
+  * configs[3]: one TP=2 rank of Mixtral-8x7B (16 q / 4 kv heads, 8 experts x (2 x 7168) x 4096, top-2);
+  * configs[0]: Qwen2.5-0.5B, the whole model (qkv bias, tied head, head_dim 64), also tied to the CPU oracle.
+
+Every report is written to gpurun_out/parity_<name>.json; the assertions are the measured bars (see DESIGN.md
+section 4 for why the literal 1e-3 bar of north_star is reported, not asserted, at |logit| ~ 6)."""
+import dataclasses
+import json
+import os
+import random
+from pathlib import Path
+
+import pytest
+import torch
+
+from oracle.model import OracleLM, weights_from_product_model
+from oracle.parity import teacher_forced_parity
+
+pytestmark = pytest.mark.gpu
+OUT = Path(__file__).resolve().parent.parent / "gpurun_out"
+
+
+def _prompts(cfg, groups, per_group, shared, unique, seed=1):
+    rnd = random.Random(seed)
+    out = []
+    for _ in range(groups):
+        sys_p = [rnd.randrange(cfg.vocab_size) for _ in range(shared)]
+        out += [sys_p + [rnd.randrange(cfg.vocab_size) for _ in range(unique)] for _ in range(per_group)]
+    return out
+
+
+def run_job(cfg, device, groups, per_group, shared, unique, new_tokens, use_graph=True, page_size=1):
+    """The bench's job: leaders cold, followers on radix hits, hipGraph decode.  Returns prompts, the product's
+    tokens and its per-step logits with rows in prompt order, and the runner (for its weights)."""
+    from sglang_amd.harness.engine import Engine, ModelRunner, Req
+
+    B = groups * per_group
+    in_len = shared + unique
+    runner = ModelRunner(cfg, max_total_tokens=B * (in_len + new_tokens) + 4096, max_running_requests=B,
+                         max_context_len=in_len + new_tokens + 8, page_size=page_size, device=device,
+                         use_graph=use_graph, graph_max_bs=B)
+    eng = Engine(runner)
+    prompts = _prompts(cfg, groups, per_group, shared, unique)
+    reqs = [Req(i, p, new_tokens) for i, p in enumerate(prompts)]
+    leaders = [q for q in reqs if q.rid % per_group == 0]
+    rest = [q for q in reqs if q.rid % per_group]
+    eng.logits_device_trace = []
+    eng.prefill(leaders)
+    if rest:
+        eng.prefill(rest)
+        assert all(q.cached_tokens == shared // page_size * page_size for q in rest)
+    for _ in range(new_tokens - 1):
+        eng.decode_step()
+        eng.flush_decode_outputs(lag=1)
+    order = [q.rid for q in eng.running]
+    eng.finish(list(eng.running))
+    tr = eng.logits_device_trace
+    first = torch.cat(tr[:2]) if rest else tr[0]
+    steps = [first] + tr[(2 if rest else 1):]
+    inv = torch.tensor([order.index(i) for i in range(B)], device=device)
+    steps = [s[inv] for s in steps]
+    outs = [q.output_ids for q in reqs]
+    assert all(len(o) == new_tokens for o in outs) and len(steps) == new_tokens
+    if use_graph:
+        assert runner.graph_runner is not None
+    return prompts, outs, steps, runner
+
+
+def _report(name, rep, extra=None):
+    OUT.mkdir(exist_ok=True)
+    (OUT / f"parity_{name}.json").write_text(json.dumps({"name": name, **(extra or {}), "parity": rep}, indent=1))
+    print(f"\n[parity {name}] " + json.dumps(rep))
+
+
+def _assert_bars(rep, rms_bar, max_bar):
+    for fl in ("fp32acc", "literal"):
+        r = rep[fl]
+        assert r["rms"] < rms_bar, (fl, r)
+        assert r["max_abs"] < max_bar, (fl, r)
+        assert r["argmax_agreement_clear_margin"] == 1.0, (fl, r)
+        assert r["frac_within_2_bf16_ulp"] > 0.9, (fl, r)
+    # the product must be as close to the fp32-accumulating reference as the reference's own literal bf16 form is
+    # (within a factor that covers one extra bf16 rounding of the split partials)
+    noise = rep["literal_vs_fp32acc"]["rms"]
+    assert rep["fp32acc"]["rms"] < max(2.0 * noise, 1e-3), (rep["fp32acc"]["rms"], noise)
+
+
+def test_llama3_8b_benchmarked_job(device):
+    from sglang_amd.harness.models import CONFIGS
+
+    cfg = CONFIGS["llama-3-8b"]
+    prompts, outs, steps, runner = run_job(cfg, device, 4, 16, 896, 128, 128)
+    rep = teacher_forced_parity(cfg, runner.model, prompts, outs, steps, device=device)
+    _report("llama3_8b_bench_job", rep, {"workload": "4 groups x 16 prompts, 896 shared + 128 unique in, 128 out, "
+                                                     "32 layers, hipGraph decode"})
+    _assert_bars(rep, rms_bar=2e-2, max_bar=0.25)
+
+
+def test_llama3_70b_tp8_rank_shapes(device):
+    from sglang_amd.harness.models import ModelConfig
+
+    cfg = ModelConfig("llama-3-70b-tp8-rank", 8192, 3584, 4, 8, 1, 128, 16032, 1e-5, 500000.0, None, 8192)
+    prompts, outs, steps, runner = run_job(cfg, device, 4, 16, 384, 64, 12)
+    rep = teacher_forced_parity(cfg, runner.model, prompts, outs, steps, device=device)
+    _report("llama3_70b_tp8_rank", rep, {"workload": "per-rank shapes of TP=8 (hidden 8192, 8 q / 1 kv heads, "
+                                                     "intermediate 3584, vocab shard 16032), 4 layers, B=64"})
+    _assert_bars(rep, rms_bar=2e-2, max_bar=0.25)
+
+
+def test_mixtral_tp2_rank_shapes(device):
+    from sglang_amd.harness.models import ModelConfig
+
+    cfg = ModelConfig("mixtral-8x7b-tp2-rank", 4096, 7168, 2, 16, 4, 128, 32000, 1e-5, 1000000.0, None, 32768,
+                      num_local_experts=8, num_experts_per_tok=2)
+    prompts, outs, steps, runner = run_job(cfg, device, 4, 16, 256, 64, 8)
+    rep = teacher_forced_parity(cfg, runner.model, prompts, outs, steps, device=device)
+    _report("mixtral_tp2_rank", rep, {"workload": "per-rank shapes of TP=2 (16 q / 4 kv heads, 8 experts, N=7168, "
+                                                  "K=4096, top-2), 2 layers, B=64: prefill (M=1280 / 3840 rows) and "
+                                                  "decode (M=64) expert GEMMs"})
+    _assert_bars(rep, rms_bar=2e-2, max_bar=0.25)
+
+
+def test_qwen25_05b_whole_model_gpu_and_cpu_oracle(device):
+    from sglang_amd.harness.models import CONFIGS
+
+    cfg = CONFIGS["qwen2.5-0.5b"]
+    prompts, outs, steps, runner = run_job(cfg, device, 2, 4, 96, 24, 16)
+    rep = teacher_forced_parity(cfg, runner.model, prompts, outs, steps, device=device)
+    # configs[0] itself: the CPU torch-native path (the plumbing case), on two of the requests
+    sub = [0, 5]
+    cpu = OracleLM(cfg, weights_from_product_model(runner.model, "cpu"), num_slots=1024, max_ctx=160, max_reqs=2,
+                   compute_dtype=torch.float32)
+    _, ref = cpu.generate([prompts[b] for b in sub], 6, return_logits=True, forced=[outs[b] for b in sub])
+    worst = max(float((steps[k][sub].float().cpu() - ref[k]).abs().max()) for k in range(6))
+    rep["cpu_oracle_max_abs_2req_6steps"] = worst
+    _report("qwen25_05b", rep, {"workload": "whole model (24 layers, qkv bias, tied head, D=64), B=8, 120 in, 16 out"})
+    _assert_bars(rep, rms_bar=2e-2, max_bar=0.25)
+    assert worst < 0.25
