@@ -81,7 +81,8 @@ class Req:
 class ModelRunner:
     def __init__(self, config: ModelConfig, *, max_total_tokens: int, max_running_requests: int,
                  max_context_len: int, page_size: int = 1, device=None, init_device=None,
-                 use_graph: bool = True, graph_max_bs: Optional[int] = None, disable_radix_cache: bool = False):
+                 use_graph: bool = True, graph_max_bs: Optional[int] = None, disable_radix_cache: bool = False,
+                 strict_graph: bool = False):
         self.config = config
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         if self.device.type == "cuda":
@@ -115,6 +116,8 @@ class ModelRunner:
             try:
                 self.graph_runner = DecodeGraphRunner(self, graph_max_bs or max_running_requests)  # :1007
             except RuntimeError as e:
+                if strict_graph:             # a benchmark must not silently measure the eager path
+                    raise
                 # e.g. a collective that cannot be captured on this RCCL build: decode eagerly instead of dying
                 # (model_runner.py falls back the same way when cuda graph capture fails)
                 import warnings

@@ -31,6 +31,14 @@ from ..layers.sampler import LogitsProcessorOutput
 
 BF = torch.bfloat16
 
+# True: every operator runs through its own sglang.srt hook (RMSNorm.forward, RotaryEmbedding.forward with the
+# fused KV store, SiluAndMul.forward, AttentionBackend.forward_*, the linear method) -- the path a drop-in under
+# the unchanged reference model classes reaches.  False (default): TP=1 decode batches additionally fold the
+# norms / rope / activation into the projections' combine kernels (needs the model-class patch of INTEGRATION.md).
+import os as _os
+
+OPERATOR_SURFACE_ONLY = _os.environ.get("SGLANG_AMD_OPERATOR_SURFACE", "0") == "1"
+
 
 @dataclass
 class ModelConfig:
@@ -134,7 +142,7 @@ class LlamaMLP(nn.Module):
 
     def gate_up_act(self, x: torch.Tensor) -> torch.Tensor:
         """act_fn(gate_up_proj(x)); decode batches get silu(gate) * up from the GEMM's own epilogue."""
-        if self.gate_up_proj.streams(x) and self.gate_up_proj.bias is None:
+        if not OPERATOR_SURFACE_ONLY and self.gate_up_proj.streams(x) and self.gate_up_proj.bias is None:
             return kernels.wstream_gemm(x, self.gate_up_proj.weight.data, epilogue="silu_and_mul")
         return self.act_fn(self.gate_up_proj(x))
 
@@ -192,7 +200,7 @@ class LlamaAttention(nn.Module):
         """fused_norm = (residual, norm): TP=1 decode form, o_proj + residual add + norm in one GEMM +
         combine pair (returns the normed activations, residual updated in place)."""
         pool = forward_batch.token_to_kv_pool
-        if self.qkv_proj.streams(hidden_states) and self.rotary_emb.is_neox_style:
+        if not OPERATOR_SURFACE_ONLY and self.qkv_proj.streams(hidden_states) and self.rotary_emb.is_neox_style:
             # decode batch: qkv GEMM, rope and the KV-row store in one GEMM + combine pair
             q = kernels.wstream_qkv_rope(hidden_states, self.qkv_proj.weight.data,
                                          self.qkv_proj.bias.data if self.qkv_proj.bias is not None else None, positions,
@@ -244,7 +252,7 @@ class LlamaDecoderLayer(nn.Module):
 
     def fusable(self, x: torch.Tensor, tp_size: int) -> bool:
         """The decode form below needs no collective between a projection and the norm behind it."""
-        return (tp_size == 1 and isinstance(self.mlp, LlamaMLP) and self.self_attn.o_proj.streams(x)
+        return (not OPERATOR_SURFACE_ONLY and tp_size == 1 and isinstance(self.mlp, LlamaMLP) and self.self_attn.o_proj.streams(x)
                 and kernels.wstream_preferred(x.shape[0], *self.mlp.down_proj.weight.shape) and x.shape[1] <= 16384)
 
     def forward_decode_fused(self, positions, normed: torch.Tensor, forward_batch, residual: torch.Tensor,

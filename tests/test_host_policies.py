@@ -113,5 +113,14 @@ def test_bench_helpers():
     assert all(len(p) == 1024 and p[:896] == g[0][:896] for g in prompts for p in g)             # shared system prompt
     assert prompts[0][0][:896] != prompts[1][0][:896] and prompts[0][0][896:] != prompts[0][1][896:]
     assert bench.build_prompts(cfg, 4, 16, 896, 128) == prompts                                   # seeded
-    t = bench.pmc_traffic_bytes("wstream_gemm_kernel")                                            # committed PMC passes
+    # decode weight bytes: SURVEY 8(d) W_act = (P_lin + hidden * vocab) * 2 B = 15.0 GB for the dense 8B model;
+    # Mixtral counts the experts a 64-row batch is expected to hit (all 8 at 128 picks)
+    assert bench.decode_weight_bytes(cfg, 64) == (bench.p_lin(cfg) + 4096 * 128256) * 2
+    mix = CONFIGS["mixtral-8x7b"]
+    per_expert = 3 * 4096 * 14336 * 2
+    assert 7.9 * per_expert * 32 < bench.decode_weight_bytes(mix, 64) - (32 * (4096 * 6144 + 4096 * 4096 + 4096 * 8) + 4096 * 32000) * 2 <= 8 * per_expert * 32
+    # committed PMC summary (profiles/r02_pmc.json) -> bytes per launch of the gate_up weight stream
+    pmc = bench.load_pmc()
+    t = bench.hbm_bytes(bench.pmc_kernel(pmc, "decode", "wstream_gemm_kernel<4, 4, 2"))
     assert t is None or 0.9 * 237e6 < t < 1.2 * 237e6
+    assert bench.hbm_bytes({"FETCH_SIZE": 100.0, "WRITE_SIZE": 10.0}) == 210 * 1024 and bench.hbm_bytes({}) is None
