@@ -99,7 +99,7 @@ class LogitStats:
 
 def teacher_forced_parity(cfg, model, prompts: Sequence[Sequence[int]], outs: Sequence[Sequence[int]],
                           step_logits: Sequence[torch.Tensor], *, device=None, flavours=("fp32acc", "literal"),
-                          max_ctx: Optional[int] = None, clear_margin_ulps: float = 4.0, batched_decode: bool = True
+                          max_ctx: Optional[int] = None, clear_margin_ulps: float = 16.0, batched_decode: bool = True
                           ) -> Dict[str, Dict[str, float]]:
     """`step_logits[k]` = the product's [B, V] logits of output position k, rows in `prompts` order;
     `outs[b]` = the product's tokens.  Returns {flavour: stats, "literal_vs_fp32acc": stats}."""

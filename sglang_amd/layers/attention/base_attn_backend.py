@@ -9,6 +9,7 @@ import torch
 
 class AttentionBackend(ABC):
     needs_cpu_seq_lens: bool = True
+    extend_dummy_seqs_capped_by_req_pool: bool = False
 
     def init_forward_metadata(self, forward_batch):
         """Eager entry point = out-of-graph part + in-graph part (:65-71)."""
@@ -39,6 +40,9 @@ class AttentionBackend(ABC):
         raise NotImplementedError()
 
     def forward_extend(self, q, k, v, layer, forward_batch, save_kv_cache: bool = True, **kwargs):
+        raise NotImplementedError()
+
+    def forward_mixed(self, q, k, v, layer, forward_batch, save_kv_cache: bool = True):
         raise NotImplementedError()
 
     def support_triton(self) -> bool:

@@ -27,6 +27,16 @@ from ...mem_cache.memory_pool import KVWriteLoc
 from .base_attn_backend import AttentionBackend
 
 
+def _kv_write_loc(loc):
+    """The pool's own KVWriteLoc type: the reference pool under sglang (memory_pool.py:1550-1575), ours otherwise."""
+    try:
+        from sglang.srt.mem_cache.memory_pool import KVWriteLoc as Ref
+
+        return Ref(loc, None)
+    except Exception:
+        return KVWriteLoc(loc, None)
+
+
 @dataclass
 class _Meta:
     seq_lens_i32: torch.Tensor
@@ -49,18 +59,50 @@ def choose_num_splits(batch: int, num_kv_heads: int, group: int, max_len: int, t
     return max(1, min(want, cap, 64))
 
 
+def runner_head_dims(model_runner):
+    """(q heads, kv heads, head dim) of this TP rank.  The harness ModelRunner carries them as fields; the
+    reference ModelRunner (model_executor/model_runner.py) carries `model_config` (configs/model_config.py:1106-1196
+    get_num_attention_heads / get_num_kv_heads) and the attention TP size (triton_backend.py:221-227)."""
+    if hasattr(model_runner, "num_attention_heads_per_rank"):
+        return (model_runner.num_attention_heads_per_rank, model_runner.num_kv_heads_per_rank, model_runner.head_dim)
+    mc = model_runner.model_config
+    tp = None
+    try:
+        from sglang.srt.runtime_context import get_parallel      # triton_backend.py:219-227
+
+        tp = get_parallel().attn_tp_size
+    except Exception:
+        pass
+    if tp is None:
+        tp = getattr(model_runner, "attn_tp_size", None) or getattr(model_runner, "tp_size", 1)
+    if hasattr(mc, "get_num_attention_heads"):
+        hq = mc.get_num_attention_heads(tp)
+    else:
+        hq = max(1, mc.num_attention_heads // tp)
+    hkv = mc.get_num_kv_heads(tp) if hasattr(mc, "get_num_kv_heads") else max(1, mc.num_key_value_heads // tp)
+    pool = model_runner.token_to_kv_pool
+    kbuf = pool.get_key_buffer(getattr(pool, "start_layer", 0) or 0)
+    if int(kbuf.shape[-2]) != hkv:
+        raise RuntimeError(f"KV pool holds {int(kbuf.shape[-2])} kv heads per token, the model config says {hkv} per rank")
+    return hq, hkv, int(kbuf.shape[-1])
+
+
 class HipAttnBackend(AttentionBackend):
     needs_cpu_seq_lens = True
+    # qo_indptr / lens are sized per forward, never preallocated at (req pool + 1) (base_attn_backend.py:117-122)
+    extend_dummy_seqs_capped_by_req_pool = False
 
     def __init__(self, model_runner):
+        """Reads what the reference backends read of a ModelRunner (triton_backend.py:145-206,
+        torch_native_backend.py:20-33): `device`, `req_to_token_pool`, `token_to_kv_pool`, and for the head
+        counts `model_config` + the attention TP size -- or the harness runner's per-rank fields."""
         super().__init__()
         self.device = model_runner.device
         self.req_to_token_pool = model_runner.req_to_token_pool
         self.token_to_kv_pool = model_runner.token_to_kv_pool
-        self.num_q_heads = model_runner.num_attention_heads_per_rank
-        self.num_kv_heads = model_runner.num_kv_heads_per_rank
-        self.head_dim = model_runner.head_dim
-        self.max_context_len = self.req_to_token_pool.max_context_len
+        self.num_q_heads, self.num_kv_heads, self.head_dim = runner_head_dims(model_runner)
+        self.max_context_len = int(self.req_to_token_pool.req_to_token.shape[1])
+        self.sliding_window_size = getattr(model_runner, "sliding_window_size", None)
         self.forward_metadata: Optional[_Meta] = None
         self._graph_ws = {}
         self._cascade_ws = None
@@ -134,12 +176,17 @@ class HipAttnBackend(AttentionBackend):
         this step (one launch per step, reused by every layer).  The plain decode kernel needs nothing."""
         m = self.forward_metadata
         if m is not None and m.cascade is not None and forward_batch.forward_mode.is_decode():
-            kernels.cascade_plan(m.cascade, self.req_to_token_pool.req_to_token, forward_batch.req_pool_indices,
+            kernels.cascade_plan(m.cascade, self.req_to_token_pool.req_to_token, self._pool_idx(forward_batch),
                                  m.seq_lens_i32, self.num_q_heads, self.num_kv_heads)
 
     # ------------------------------------------------------------------ forward
     def _save_kv(self, layer, forward_batch, k, v):
-        self.token_to_kv_pool.set_kv_buffer(layer, KVWriteLoc(forward_batch.out_cache_loc, None), k, v)
+        self.token_to_kv_pool.set_kv_buffer(layer, _kv_write_loc(forward_batch.out_cache_loc), k, v)
+
+    @staticmethod
+    def _pool_idx(forward_batch):
+        idx = forward_batch.req_pool_indices
+        return idx if idx.dtype == torch.int64 else idx.to(torch.int64)
 
     def forward_extend(self, q, k, v, layer, forward_batch, save_kv_cache: bool = True, **kwargs):
         if save_kv_cache and k is not None and v is not None:
@@ -152,7 +199,7 @@ class HipAttnBackend(AttentionBackend):
         causal = not (layer.is_cross_attention or layer.attn_type == AttentionType.ENCODER_ONLY)
         kernels.extend_attention(q3, o, self.token_to_kv_pool.get_key_buffer(layer.layer_id),
                                  self.token_to_kv_pool.get_value_buffer(layer.layer_id),
-                                 self.req_to_token_pool.req_to_token, forward_batch.req_pool_indices, m.seq_lens_i32,
+                                 self.req_to_token_pool.req_to_token, self._pool_idx(forward_batch), m.seq_lens_i32,
                                  m.prefix_lens_i32, m.qo_indptr, m.max_extend_len, layer.scaling, causal)
         return o.view(-1, layer.tp_q_head_num * layer.v_head_dim)
 
@@ -165,14 +212,20 @@ class HipAttnBackend(AttentionBackend):
         if m.cascade is not None:
             kernels.cascade_decode_attention(m.cascade, q3, self.token_to_kv_pool.get_key_buffer(layer.layer_id),
                                              self.token_to_kv_pool.get_value_buffer(layer.layer_id), o,
-                                             self.req_to_token_pool.req_to_token, forward_batch.req_pool_indices,
+                                             self.req_to_token_pool.req_to_token, self._pool_idx(forward_batch),
                                              m.seq_lens_i32, layer.scaling)
             return o.view(-1, layer.tp_q_head_num * layer.v_head_dim)
         kernels.decode_attention(q3, self.token_to_kv_pool.get_key_buffer(layer.layer_id),
                                  self.token_to_kv_pool.get_value_buffer(layer.layer_id), o,
-                                 self.req_to_token_pool.req_to_token, forward_batch.req_pool_indices, m.seq_lens_i32,
+                                 self.req_to_token_pool.req_to_token, self._pool_idx(forward_batch), m.seq_lens_i32,
                                  layer.scaling, m.num_splits, m.ws_acc, m.ws_ml, flags=self.debug_flags)
         return o.view(-1, layer.tp_q_head_num * layer.v_head_dim)
+
+    def forward_mixed(self, q, k, v, layer, forward_batch, save_kv_cache: bool = True):
+        """ForwardMode.MIXED (forward_batch_info.py:100-110): chunked-prefill extends and running decodes in ONE
+        batch, the decodes expressed as extends of one token over their cached prefix -- exactly what the extend
+        kernel computes (the reference routes MIXED to forward_extend on every device but the NPU, :216-258)."""
+        return self.forward_extend(q, k, v, layer, forward_batch, save_kv_cache=save_kv_cache)
 
     def support_triton(self) -> bool:
         return False

@@ -1,5 +1,10 @@
 """RMSNorm with SGLang's module signature, running the gfx950 kernels
-(reference: /root/reference/python/sglang/srt/layers/layernorm.py:423-826)."""
+(reference: /root/reference/python/sglang/srt/layers/layernorm.py:423-826).
+
+`RMSNorm.forward` is also what plugin.load() registers as the out-of-tree forward of the reference's RMSNorm
+(BaseFusedOp.register_oot_forward): bound to a reference instance it reads the same attributes (`weight`,
+`variance_epsilon`, and the optional `variance_size_override` / `cast_x_before_out_mul` / `fp32_residual`
+switches) and hands every configuration outside the bf16 hot path to that instance's own `forward_native`."""
 from __future__ import annotations
 
 from typing import Optional, Tuple, Union
@@ -17,11 +22,31 @@ class RMSNorm(nn.Module):
         self.variance_epsilon = eps
         self.hidden_size = hidden_size
 
-    def forward(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None
+    def forward(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None,
+                post_residual_addition: Optional[torch.Tensor] = None, quant_linear: Optional[nn.Module] = None
                 ) -> Union[torch.Tensor, Tuple[torch.Tensor, torch.Tensor]]:
-        """`x` (and `residual`) are updated IN PLACE when a residual is given, like
-        sgl_kernel.fused_add_rmsnorm (layernorm.py:739-751)."""
+        """layernorm.py:474-480 signature.  `x` (and `residual`) are updated IN PLACE when a residual is given, like
+        sgl_kernel.fused_add_rmsnorm (layernorm.py:739-751); `post_residual_addition` is folded into the residual
+        first (layernorm.py:563-564: hidden_states + (residual + post_residual_addition))."""
+        outside = (quant_linear is not None or x.dtype != torch.bfloat16 or self.weight.dtype != torch.bfloat16
+                   or getattr(self, "variance_size_override", None) is not None
+                   or getattr(self, "cast_x_before_out_mul", False) or getattr(self, "fp32_residual", False)
+                   or not x.is_cuda)
+        if outside:
+            native = getattr(self, "forward_native", None)
+            if native is None:
+                raise NotImplementedError("RMSNorm: this configuration (quant_linear / non-bf16 / variance override) is "
+                                          "outside the gfx950 path")
+            return native(x, residual, post_residual_addition, quant_linear)
+        if x.numel() == 0:                                   # layernorm.py:481-486
+            if residual is not None:
+                if post_residual_addition is not None:
+                    residual = residual + post_residual_addition
+                return x, residual
+            return x
         if residual is not None:
+            if post_residual_addition is not None:
+                residual = residual + post_residual_addition
             kernels.fused_add_rmsnorm(x, residual, self.weight.data, self.variance_epsilon)
             return x, residual
         return kernels.rmsnorm(x, self.weight.data, self.variance_epsilon)

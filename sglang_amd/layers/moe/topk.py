@@ -25,15 +25,61 @@ def fused_topk(hidden_states: torch.Tensor, gating_output: torch.Tensor, topk: i
     return kernels.topk_softmax(gating_output, topk, renormalize)
 
 
+class TopKConfig:
+    """topk.py:215-232 (the fields this path reads)."""
+
+    def __init__(self, top_k: int, renormalize: bool = True, use_grouped_topk: bool = False,
+                 custom_routing_function=None, correction_bias=None, scoring_func: str = "softmax",
+                 num_fused_shared_experts: int = 0, routed_scaling_factor=None,
+                 apply_routed_scaling_factor_on_output: bool = False):
+        self.top_k, self.renormalize, self.use_grouped_topk = top_k, renormalize, use_grouped_topk
+        self.custom_routing_function, self.correction_bias, self.scoring_func = custom_routing_function, correction_bias, scoring_func
+        self.num_fused_shared_experts, self.routed_scaling_factor = num_fused_shared_experts, routed_scaling_factor
+        self.apply_routed_scaling_factor_on_output = apply_routed_scaling_factor_on_output
+
+
 class TopK(nn.Module):
-    """topk.py:392 (softmax scoring, no grouping / bias -- the Mixtral configuration)."""
+    """topk.py:392: the router op.  The gfx950 kernel covers the Mixtral configuration (softmax scoring, plain
+    top-k, optional renormalisation); grouped / sigmoid / bias-corrected / custom routers and the non-standard
+    output formats go to the bound reference instance's own `forward_native`."""
 
     def __init__(self, top_k: int, renormalize: bool = True):
         super().__init__()
-        self.top_k = top_k
-        self.renormalize = renormalize
+        self.topk_config = TopKConfig(top_k, renormalize)
+
+    @property
+    def top_k(self) -> int:
+        return self.topk_config.top_k
+
+    @property
+    def renormalize(self) -> bool:
+        return self.topk_config.renormalize
 
     def forward(self, hidden_states: torch.Tensor, router_logits: torch.Tensor, *, num_token_non_padded=None,
-                expert_location_dispatch_info=None) -> StandardTopKOutput:
-        w, ids = fused_topk(hidden_states, router_logits, self.top_k, self.renormalize)
-        return StandardTopKOutput(w, ids, router_logits)
+                expert_location_dispatch_info=None):
+        c = self.topk_config                                         # reference: TopK.topk_config (topk.py:215-232)
+        plain = (not getattr(c, "use_grouped_topk", False) and getattr(c, "custom_routing_function", None) is None
+                 and getattr(c, "correction_bias", None) is None and getattr(c, "scoring_func", "softmax") == "softmax"
+                 and not getattr(c, "num_fused_shared_experts", 0)
+                 and not getattr(c, "apply_routed_scaling_factor_on_output", False)
+                 and getattr(getattr(c, "output_format", None), "name", "STANDARD") == "STANDARD"
+                 and num_token_non_padded is None and expert_location_dispatch_info is None
+                 and router_logits.is_cuda)
+        if not plain:
+            native = getattr(self, "forward_native", None)
+            if native is None:
+                raise NotImplementedError("TopK: only softmax scoring with plain top-k is on the gfx950 path")
+            return native(hidden_states, router_logits, num_token_non_padded=num_token_non_padded,
+                          expert_location_dispatch_info=expert_location_dispatch_info)
+        w, ids = fused_topk(hidden_states, router_logits, c.top_k, c.renormalize)
+        return _standard_output_cls()(w, ids, router_logits)
+
+
+def _standard_output_cls():
+    """Under sglang the reference's own StandardTopKOutput (the dispatcher checks its type: topk.py:238-260)."""
+    try:
+        from sglang.srt.layers.moe.topk import StandardTopKOutput as Ref
+
+        return Ref
+    except Exception:
+        return StandardTopKOutput

@@ -1,17 +1,22 @@
 """SGLang plugin entry point: registers the gfx950 hot path under the unchanged scheduler.
 
 Installed as (pyproject.toml):
-    [project.entry-points."sglang.srt.plugins"]
-    sglang_amd = "sglang_amd.plugin:load"
-`sglang.srt.plugins.load_plugins()` (srt/plugins/__init__.py:103-141) calls `load()` once per
-process, first thing in launch_server.py:8, i.e. before ServerArgs are parsed, so the new CLI
-choices exist in time.  sglang itself cannot be imported in the build container (orjson /
-msgspec / zmq missing), so this module is exercised against the structural stand-ins in
-sglang_amd/layers; every hook below cites the reference line it plugs into.
+    [project.entry-points."sglang.srt.plugins"]    sglang_amd = "sglang_amd.plugin:load"
+    [project.entry-points."sglang.srt.platforms"]  hip_mi355x = "sglang_amd.platform:activate"
+`sglang.srt.plugins.load_plugins()` (srt/plugins/__init__.py:103-141) calls `load()` once per process, first thing
+in launch_server.py:8, i.e. before ServerArgs are parsed, so the new CLI choices exist in time; the platform entry
+point makes `current_platform.is_out_of_tree()` true so that the out-of-tree forwards registered below are the
+ones `BaseFusedOp` dispatches to (kernels/fused_op.py:196-203, 535-544).
+
+sglang itself cannot be imported in the build container (orjson / msgspec / zmq missing).  tests/test_plugin_contract.py
+executes `load()` against a stand-in `sglang` package generated from the reference's own sources
+(tests/golden/gen_contract.py ast-parses the cited files into tests/golden/reference_contract.json: module paths,
+function / method signatures, registry semantics), so every import and every registration call below is checked
+against the reference's names and arities.
 """
 from __future__ import annotations
 
-BACKEND_NAME = "hip_mi355x"
+from .platform import BACKEND_NAME, DISPATCH_KEY
 
 
 def load() -> None:
@@ -34,25 +39,18 @@ def load() -> None:
     # ---- sampler (sampler.py:531-542 register_sampler_backend; created in model_runner.py:651) ---
     from sglang.srt.layers.sampler import register_sampler_backend
 
-    def _sampler_factory():
-        from sglang.srt.layers.sampler import Sampler as RefSampler
-
-        from .layers.sampler import Sampler as HipSampler
-
-        # the factory must return a subclass of the reference Sampler (sampler.py:553-557)
-        cls = type("HipSampler", (RefSampler,), {"forward": HipSampler.forward,
-                                                   "_sync_token_ids_across_tp": HipSampler._sync_token_ids_across_tp})
-        return cls()
-
     register_sampler_backend(BACKEND_NAME, _sampler_factory)
 
-    # ---- fused MoE function (moe_runner/base.py:236-254; runner names are a closed enum, so the
-    #      ("none", "triton") slot is replaced -- SURVEY section 8(b)) --------------------------------
-    from sglang.srt.layers.moe.moe_runner.base import register_fused_func
+    # ---- fused MoE function (moe_runner/base.py:236-254).  Runner names are a closed enum (moe/utils.py:95-113), so
+    #      the ("none", "triton") slot is taken over -- SURVEY section 8(b).  register_fused_func refuses a key that
+    #      is already registered (base.py:124-127) and the reference registers its own at import of
+    #      moe_runner/triton.py, so that module is imported first, its function kept as the fallback for the
+    #      configurations outside this path, and the slot overwritten in the pool itself. -----------------------
+    import sglang.srt.layers.moe.moe_runner.triton  # noqa: F401  (registers the reference's function)
+    from sglang.srt.layers.moe.moe_runner.base import FusedOpPool
 
-    from .layers.moe.fused_moe import fused_experts_none_to_hip
-
-    register_fused_func("none", "triton")(_adapt_fused_func(fused_experts_none_to_hip))
+    reference_fn = FusedOpPool.get_fused_func("none", "triton")
+    FusedOpPool._fused_funcs[("none", "triton")] = _adapt_fused_func(reference_fn)
 
     # ---- fused elementwise ops (kernels/fused_op.py:386-391 register_oot_forward) ----------------
     from sglang.kernels.fused_op import BaseFusedOp
@@ -64,24 +62,55 @@ def load() -> None:
     from .layers import activation, layernorm, rotary_embedding
     from .layers.moe import topk as hip_topk
 
-    key = "hip_mi355x"      # SRTPlatform.get_dispatch_key_name() of the out-of-tree platform
-    BaseFusedOp.register_oot_forward(RMSNorm, layernorm.RMSNorm.forward, key)
-    BaseFusedOp.register_oot_forward(SiluAndMul, activation.SiluAndMul.forward, key)
-    BaseFusedOp.register_oot_forward(RotaryEmbedding, rotary_embedding.RotaryEmbedding.forward, key)
-    BaseFusedOp.register_oot_forward(TopK, hip_topk.TopK.forward, key)
+    BaseFusedOp.register_oot_forward(RMSNorm, layernorm.RMSNorm.forward, DISPATCH_KEY)
+    BaseFusedOp.register_oot_forward(SiluAndMul, activation.SiluAndMul.forward, DISPATCH_KEY)
+    BaseFusedOp.register_oot_forward(RotaryEmbedding, rotary_embedding.RotaryEmbedding.forward, DISPATCH_KEY)
+    BaseFusedOp.register_oot_forward(TopK, hip_topk.TopK.forward, DISPATCH_KEY)
 
 
-def _adapt_fused_func(fn):
-    """Map the reference's TritonMoeQuantInfo (moe_runner/triton.py:60-80) onto MoeQuantInfo."""
+def _sampler_factory():
+    """The factory must return a subclass of the reference Sampler (sampler.py:553-557): the gfx950 forward on
+    top of the reference's own __init__ / _preprocess_logits / output_logprob_processor / _sync_token_ids_across_tp."""
+    from sglang.srt.layers.sampler import Sampler as RefSampler
+
+    from .layers.sampler import Sampler as HipSampler
+
+    cls = type("HipSampler", (RefSampler,), {"forward": HipSampler.forward,
+                                               "_write_logprobs": HipSampler._write_logprobs})
+    return cls()
+
+
+def _adapt_fused_func(reference_fn):
+    """(dispatch_output, quant_info: TritonMoeQuantInfo, runner_config) -> StandardCombineInput
+    (moe_runner/triton.py:180-260).  Unquantised gated-silu experts without biases run on the gfx950 grouped GEMMs;
+    everything else (fp8 / int8 / int4 / mxfp8 weights, biases, interleaved gate-up rows, pre-quantised activations,
+    other activations, no_combine, router weight on input) stays with the reference's function."""
     def wrapper(dispatch_output, quant_info, runner_config):
-        from .layers.moe.fused_moe import MoeQuantInfo, StandardDispatchOutput
+        q = quant_info
+        quantised = any(getattr(q, f, False) for f in ("use_mxfp8", "use_fp8_w8a8", "use_int8_w8a8", "use_int8_w8a16",
+                                                        "use_int4_w4a16", "per_channel_quant", "fuse_swiglu_interleaved"))
+        extras = any(getattr(q, f, None) is not None for f in ("b13", "b2", "w13_scale", "w2_scale", "w13_zp", "w2_zp",
+                                                                "a13_scale", "a2_scale", "block_shape"))
+        c = runner_config
+        unsupported_cfg = (getattr(c, "activation", "silu") != "silu" or not getattr(c, "is_gated", True)
+                           or getattr(c, "no_combine", False) or getattr(c, "apply_router_weight_on_input", False)
+                           or getattr(c, "gate_up_interleaved", False) or getattr(c, "swiglu_limit", None) is not None
+                           or getattr(c, "gemm1_alpha", None) is not None or getattr(c, "gemm1_clamp_limit", None) is not None)
+        x = dispatch_output.hidden_states
+        import torch
+
+        if (quantised or extras or unsupported_cfg or getattr(dispatch_output, "hidden_states_pre_quant", None) is not None
+                or x.dtype != torch.bfloat16 or q.w13_weight.dtype != torch.bfloat16 or not x.is_cuda):
+            if reference_fn is None:
+                raise NotImplementedError("this MoE configuration is outside the gfx950 path")
+            return reference_fn(dispatch_output, quant_info, runner_config)
+        from sglang.srt.layers.moe.token_dispatcher.standard import StandardCombineInput
+
+        from .layers.moe.fused_moe import MoeQuantInfo, StandardDispatchOutput, fused_experts_none_to_hip
         from .layers.moe.topk import StandardTopKOutput
 
         t = dispatch_output.topk_output
-        disp = StandardDispatchOutput(dispatch_output.hidden_states,
-                                      StandardTopKOutput(t.topk_weights, t.topk_ids, t.router_logits))
-        out = fn(disp, MoeQuantInfo(quant_info.w13_weight, quant_info.w2_weight), runner_config)
-        from sglang.srt.layers.moe.token_dispatcher.standard import StandardCombineInput
-
+        disp = StandardDispatchOutput(x, StandardTopKOutput(t.topk_weights, t.topk_ids, t.router_logits))
+        out = fused_experts_none_to_hip(disp, MoeQuantInfo(q.w13_weight, q.w2_weight), runner_config)
         return StandardCombineInput(hidden_states=out.hidden_states)
     return wrapper

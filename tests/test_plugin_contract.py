@@ -1,0 +1,449 @@
+"""The drop-in boundary against the reference's own sources.
+
+tests/golden/reference_contract.json is the ast-extracted contract of the REAL reference (signatures, dataclass
+fields, class constants of every module the plugin touches; tests/golden/gen_contract.py).  This file
+  1. checks that every operator of sglang_amd/layers is call-compatible with the reference operator it stands for
+     (same parameter names in the same order, a default wherever the reference has one);
+  2. builds a stand-in `sglang` package from the contract -- every module path, function and method exists with the
+     reference's exact signature, registries behave as the cited code does -- and EXECUTES plugin.load() and the
+     platform entry point against it, then drives the registered objects the way the reference would:
+     attention factory with a reference-shaped ModelRunner, RMSNorm / TopK forwards bound to reference-shaped op
+     instances, the sampler factory, the fused-MoE slot with quantised / biased inputs.
+No GPU is needed: the HIP library loads on the CPU (symbols only), tensors stay on the CPU so the operators take
+their documented delegation paths.
+"""
+import importlib
+import inspect
+import json
+import sys
+import types
+from pathlib import Path
+
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+CONTRACT = json.loads((ROOT / "tests" / "golden" / "reference_contract.json").read_text())
+MODS = CONTRACT["modules"]
+
+
+def ref(module, name):
+    return MODS[module]["names"][name]
+
+
+def ref_params(module, name, method=None, drop_self=True):
+    rec = ref(module, name)
+    if method is not None:
+        rec = rec["methods"][method]
+    ps = rec["params"]
+    if drop_self and ps and ps[0]["name"] in ("self", "cls"):
+        ps = ps[1:]
+    return ps
+
+
+def assert_call_compatible(ours, ref_ps, what):
+    """Every way the reference can be called must bind on ours: same names, same order for positionals, a default
+    wherever the reference has one; ours may add trailing optional parameters."""
+    sig = inspect.signature(ours)
+    mine = [p for p in sig.parameters.values() if p.name not in ("self", "cls")]
+    names = [p.name for p in mine]
+    pos_ref = [p for p in ref_ps if p["kind"] == "pos"]
+    for i, p in enumerate(pos_ref):
+        assert i < len(mine) and mine[i].name == p["name"], f"{what}: positional #{i} is '{names[i] if i < len(names) else None}', reference has '{p['name']}'"
+        if p["default"]:
+            assert mine[i].default is not inspect.Parameter.empty, f"{what}: '{p['name']}' needs a default"
+    for p in ref_ps:
+        if p["kind"] == "kw":
+            assert p["name"] in sig.parameters, f"{what}: keyword '{p['name']}' missing"
+    for p in mine[len(pos_ref):]:
+        if p.kind in (p.VAR_POSITIONAL, p.VAR_KEYWORD):
+            continue
+        assert p.default is not inspect.Parameter.empty or p.kind == p.KEYWORD_ONLY and p.name in [q["name"] for q in ref_ps], \
+            f"{what}: extra parameter '{p.name}' must be optional"
+
+
+# ------------------------------------------------------------------------------------------ 1. signatures
+def test_operator_signatures_match_the_reference():
+    from sglang_amd.layers import activation, layernorm, rotary_embedding, sampler
+    from sglang_amd.layers.attention.base_attn_backend import AttentionBackend
+    from sglang_amd.layers.attention.hip_backend import HipAttnBackend
+    from sglang_amd.layers.moe import topk
+
+    for fwd in ("forward_cuda", "forward_native"):
+        assert_call_compatible(layernorm.RMSNorm.forward, ref_params("sglang.srt.layers.layernorm", "RMSNorm", fwd), f"RMSNorm vs {fwd}")
+        assert_call_compatible(rotary_embedding.RotaryEmbedding.forward,
+                               ref_params("sglang.srt.layers.rotary_embedding.base", "RotaryEmbedding", fwd), f"RotaryEmbedding vs {fwd}")
+        assert_call_compatible(topk.TopK.forward, ref_params("sglang.srt.layers.moe.topk", "TopK", fwd), f"TopK vs {fwd}")
+    assert_call_compatible(activation.SiluAndMul.forward, ref_params("sglang.srt.layers.activation", "SiluAndMul", "forward_native"), "SiluAndMul")
+    assert_call_compatible(sampler.Sampler.forward, ref_params("sglang.srt.layers.sampler", "Sampler", "forward"), "Sampler.forward")
+    for m in ("init_forward_metadata", "init_forward_metadata_out_graph", "init_forward_metadata_in_graph", "init_cuda_graph_state",
+              "get_cuda_graph_seq_len_fill_value", "forward", "forward_decode", "forward_extend", "forward_mixed", "support_triton"):
+        assert_call_compatible(getattr(HipAttnBackend, m), ref_params("sglang.srt.layers.attention.base_attn_backend", "AttentionBackend", m),
+                               f"HipAttnBackend.{m}")
+    # the class-level switches the graph runner / scheduler read
+    attrs = ref("sglang.srt.layers.attention.base_attn_backend", "AttentionBackend")["attrs"]
+    for a in ("needs_cpu_seq_lens", "extend_dummy_seqs_capped_by_req_pool"):
+        assert a in attrs and hasattr(HipAttnBackend, a), a
+    assert issubclass(HipAttnBackend, AttentionBackend)
+
+
+def test_functional_namespace_matches_sgl_kernel():
+    """kernels.py mirrors of sgl_kernel.{rmsnorm, fused_add_rmsnorm, silu_and_mul, rotary_embedding, topk_softmax, ...}:
+    the reference's positional call forms bind (enable_pdl is CUDA-only and has no counterpart)."""
+    from sglang_amd import kernels
+
+    ns = {}
+    for f in CONTRACT["sgl_kernel"].values():
+        ns.update(f)
+    pairs = {"rmsnorm": ("x", ["input", "weight", "eps", "out"]), "fused_add_rmsnorm": ("x", ["input", "residual", "weight", "eps"]),
+             "silu_and_mul": ("x", ["input", "out"]),
+             "rotary_embedding": ("positions", ["positions", "query", "key", "head_size", "cos_sin_cache", "is_neox"])}
+    for name, (first, ref_order) in pairs.items():
+        got = [p["name"] for p in ns[name]["params"] if p["name"] != "enable_pdl"]
+        assert got == ref_order, (name, got)
+        mine = list(inspect.signature(getattr(kernels, name)).parameters)
+        assert len(mine) >= len(ref_order) and mine[0] == first and mine[1:len(ref_order)] == ref_order[1:], (name, mine)
+    assert ns["top_k_renorm_prob"]["value"] == "top_k_renorm_probs" and ns["top_p_renorm_prob"]["value"] == "top_p_renorm_probs"
+    assert [p["name"] for p in ns["top_k_renorm_probs"]["params"]][:2] == ["probs", "top_k"]
+    assert [p["name"] for p in ns["top_p_renorm_probs"]["params"]][:2] == ["probs", "top_p"]
+    assert list(inspect.signature(kernels.top_k_renorm_prob).parameters) == ["probs", "top_k"]
+    assert list(inspect.signature(kernels.top_p_renorm_prob).parameters) == ["probs", "top_p"]
+
+
+def test_entry_points_are_declared_as_the_reference_discovers_them():
+    import tomli
+
+    ep = tomli.loads((ROOT / "pyproject.toml").read_text())["project"]["entry-points"]
+    assert ref("sglang.srt.plugins", "GENERAL_PLUGINS_GROUP")["value"] in ep
+    assert ref("sglang.srt.plugins", "PLATFORM_PLUGINS_GROUP")["value"] in ep
+    mod, fn = ep["sglang.srt.platforms"]["hip_mi355x"].split(":")
+    assert callable(getattr(importlib.import_module(mod), fn))
+    mod, fn = ep["sglang.srt.plugins"]["sglang_amd"].split(":")
+    assert callable(getattr(importlib.import_module(mod), fn))
+    from sglang_amd import platform
+
+    assert platform.activate() is None or torch.cuda.is_available()      # no gfx950 device -> "hardware not available"
+    # every factory the platform overrides exists on the reference interface with a compatible signature
+    methods = ref("sglang.srt.platforms.interface", "SRTPlatform")["methods"]
+    for m in ("get_dispatch_key_name", "get_default_attention_backend", "support_cuda_graph", "supports_fp8", "get_graph_runner_cls",
+              "get_mha_kv_pool_cls", "get_paged_allocator_cls", "init_backend"):
+        assert m in methods and [p["name"] for p in methods[m]["params"]] == ["self"], m
+    assert "is_out_of_tree" in ref("sglang.srt.platforms.device_mixin", "DeviceMixin")["methods"]
+    assert "OOT" in ref("sglang.srt.platforms.device_mixin", "PlatformEnum")["attrs"]
+
+
+# ------------------------------------------------------------------------------------------ 2. stand-in package
+def _fn_src(name, params, body="raise NotImplementedError('stand-in')", deco=""):
+    parts, seen_kw = [], False
+    for p in params:
+        if p["kind"] == "var":
+            parts.append("*" + p["name"]); seen_kw = True
+        elif p["kind"] == "varkw":
+            parts.append("**" + p["name"])
+        else:
+            if p["kind"] == "kw" and not seen_kw:
+                parts.append("*"); seen_kw = True
+            parts.append(p["name"] + ("=None" if p["default"] else ""))
+    return f"{deco}def {name}({', '.join(parts)}):\n    {body}\n"
+
+
+@pytest.fixture
+def fake_sglang(monkeypatch):
+    """A `sglang` package whose modules, names and signatures are the contract's; behaviour is filled in only where
+    the cited reference code has behaviour the plugin depends on (registries, dispatch rules)."""
+    created = {}
+
+    def module(name):
+        if name in created:
+            return created[name]
+        m = types.ModuleType(name)
+        m.__path__ = []
+        created[name] = m
+        monkeypatch.setitem(sys.modules, name, m)
+        if "." in name:
+            parent, _, child = name.rpartition(".")
+            setattr(module(parent), child, m)
+        return m
+
+    for modname, rec in MODS.items():
+        m = module(modname)
+        for name, r in rec["names"].items():
+            if "." in name:
+                continue
+            if r["kind"] == "constant":
+                setattr(m, name, r["value"])
+            elif r["kind"] == "function":
+                ns = {}
+                exec(_fn_src(name, r["params"]), ns)
+                setattr(m, name, ns[name])
+            elif r["kind"] == "class":
+                body = {}
+                for meth, mr in r["methods"].items():
+                    ns = {}
+                    deco = "".join(f"@{d}\n" for d in mr["decorators"] if d in ("classmethod", "staticmethod"))
+                    exec(_fn_src(meth, mr["params"], deco=deco), ns)
+                    body[meth] = ns[meth]
+                for a, v in r["attrs"].items():
+                    body.setdefault(a, v)
+                body["__contract_fields__"] = [f["name"] for f in r["fields"]]
+                setattr(m, name, type(name, (), body))
+
+    # ---- behaviour, restated from the cited lines -----------------------------------------------------
+    import enum
+
+    dm = created["sglang.srt.platforms.device_mixin"]
+    PlatformEnum = enum.Enum("PlatformEnum", list(ref("sglang.srt.platforms.device_mixin", "PlatformEnum")["attrs"]))
+    dm.PlatformEnum = PlatformEnum
+
+    class DeviceMixin:                                                    # device_mixin.py:101-145
+        _enum = PlatformEnum.UNSPECIFIED
+
+        def is_out_of_tree(self):
+            return self._enum == PlatformEnum.OOT
+
+    dm.DeviceMixin = DeviceMixin
+    created["sglang.srt.platforms.cuda"].CudaDeviceMixin = type("CudaDeviceMixin", (DeviceMixin,), {"_enum": PlatformEnum.CUDA})
+    iface = created["sglang.srt.platforms.interface"]
+    iface.SRTPlatform = type("SRTPlatform", (DeviceMixin,), {k: v for k, v in vars(iface.SRTPlatform).items() if not k.startswith("__")})
+    iface.SRTPlatform.get_dispatch_key_name = lambda self: "native"       # interface.py:133-142
+
+    reg = created["sglang.srt.layers.attention.attention_registry"]
+    reg.ATTENTION_BACKENDS = {}
+
+    def register_attention_backend(name):                                 # attention_registry.py:34-39
+        def deco(fn):
+            reg.ATTENTION_BACKENDS[name] = fn
+            return fn
+        return deco
+
+    reg.register_attention_backend = register_attention_backend
+    sa = created["sglang.srt.server_args"]
+    sa.ATTENTION_BACKEND_CHOICES = ["triton", "torch_native"]
+    sa.add_attention_backend_choices = lambda choices: sa.ATTENTION_BACKEND_CHOICES.extend(choices)   # server_args.py:416-417
+
+    smp = created["sglang.srt.layers.sampler"]
+    smp._SAMPLER_FACTORIES = {}
+
+    class RefSampler(torch.nn.Module):                                    # sampler.py:71-97
+        def __init__(self):
+            super().__init__()
+            self.tp_sync_group = None
+            self.synced = 0
+            self.output_logprob_processor = None
+
+        def _preprocess_logits(self, logits, sampling_info):
+            self.preprocessed = True
+            return logits
+
+        def _sync_token_ids_across_tp(self, batch_next_token_ids, sampling_info):
+            self.synced += 1
+
+        def forward(self, *a, **k):
+            raise AssertionError("the reference forward must have been replaced")
+
+    smp.Sampler = RefSampler
+    smp.register_sampler_backend = lambda backend, factory: smp._SAMPLER_FACTORIES.__setitem__(backend, factory)   # sampler.py:531-542
+
+    base = created["sglang.srt.layers.moe.moe_runner.base"]
+
+    class FusedOpPool:                                                     # base.py:115-143
+        _fused_funcs = {}
+
+        @classmethod
+        def register_fused_func(cls, a2a_backend_name, runner_backend_name, fused_func):
+            key = (a2a_backend_name, runner_backend_name)
+            if key in cls._fused_funcs:
+                raise ValueError(f"Fused function for {a2a_backend_name} to {runner_backend_name} is already registered.")
+            cls._fused_funcs[key] = fused_func
+
+        @classmethod
+        def get_fused_func(cls, dispatch_name, runner_name):
+            return cls._fused_funcs.get((dispatch_name, runner_name))
+
+    base.FusedOpPool = FusedOpPool
+
+    def register_fused_func(a2a_backend_name, runner_backend_name):
+        def decorator(fused_func):
+            FusedOpPool.register_fused_func(a2a_backend_name, runner_backend_name, fused_func)
+            return fused_func
+        return decorator
+
+    base.register_fused_func = register_fused_func
+    tri = created["sglang.srt.layers.moe.moe_runner.triton"]
+    tri.calls = []
+
+    @register_fused_func("none", "triton")                                # triton.py:180 registers at import
+    def fused_experts_none_to_triton(dispatch_output, quant_info, runner_config):
+        tri.calls.append("reference")
+        return "reference-result"
+
+    tri.fused_experts_none_to_triton = fused_experts_none_to_triton
+    std = created["sglang.srt.layers.moe.token_dispatcher.standard"]
+    std.StandardCombineInput = lambda hidden_states: ("combine", hidden_states)
+
+    fo = created["sglang.kernels.fused_op"]
+    current = {"platform": None}
+    plat_pkg = created["sglang.srt.platforms"]
+
+    class BaseFusedOp(torch.nn.Module):                                   # fused_op.py:332-391, 533-562
+        _oot_forward_registry = {}
+
+        @classmethod
+        def register_oot_forward(cls, op_cls, fn, platform_key):
+            cls._oot_forward_registry.setdefault(platform_key, {})[op_cls] = fn
+
+        def _resolve_forward_method(self):
+            p = current["platform"]
+            if p is not None and p.is_out_of_tree():
+                registered = self._oot_forward_registry.get(p.get_dispatch_key_name(), {}).get(type(self))
+                if registered is not None:
+                    return registered.__get__(self)
+            return self.forward_native
+
+        def forward(self, *args, **kwargs):
+            return self._resolve_forward_method()(*args, **kwargs)
+
+    fo.BaseFusedOp = BaseFusedOp
+    ln, act = created["sglang.srt.layers.layernorm"], created["sglang.srt.layers.activation"]
+    rope, tk = created["sglang.srt.layers.rotary_embedding.base"], created["sglang.srt.layers.moe.topk"]
+
+    class RMSNorm(BaseFusedOp):                                            # layernorm.py:423-480
+        def __init__(self, hidden_size, eps=1e-6):
+            super().__init__()
+            self.weight = torch.nn.Parameter(torch.ones(hidden_size, dtype=torch.bfloat16), requires_grad=False)
+            self.variance_epsilon, self.hidden_size = eps, hidden_size
+            self.variance_size_override, self.cast_x_before_out_mul, self.fp32_residual = None, False, False
+
+        def forward_native(self, x, residual=None, post_residual_addition=None, quant_linear=None):
+            self.native_args = (residual is not None, post_residual_addition is not None, quant_linear is not None)
+            return (x, residual) if residual is not None else x
+
+    class TopK(BaseFusedOp):                                               # topk.py:392-520
+        def __init__(self, cfg):
+            super().__init__()
+            self.topk_config = cfg
+
+        def forward_native(self, hidden_states, router_logits, *, num_token_non_padded=None, expert_location_dispatch_info=None):
+            return "native-topk"
+
+    ln.RMSNorm, tk.TopK = RMSNorm, TopK
+    act.SiluAndMul = type("SiluAndMul", (BaseFusedOp,), {"forward_native": lambda self, x: "native-silu"})
+    rope.RotaryEmbedding = type("RotaryEmbedding", (BaseFusedOp,), {"forward_native": lambda self, *a, **k: "native-rope"})
+    tk.StandardTopKOutput = __import__("collections").namedtuple("StandardTopKOutput", ref("sglang.srt.layers.moe.topk", "StandardTopKOutput")["__contract_fields__"]
+                                                                   if False else [f["name"] for f in ref("sglang.srt.layers.moe.topk", "StandardTopKOutput")["fields"]])
+    mp_ = created["sglang.srt.mem_cache.memory_pool"]
+    mp_.KVWriteLoc = __import__("collections").namedtuple("KVWriteLoc", [f["name"] for f in ref("sglang.srt.mem_cache.memory_pool", "KVWriteLoc")["fields"]],
+                                                          defaults=(None, None))
+    created["sglang.srt.model_executor.runner.decode_cuda_graph_runner"].DecodeCudaGraphRunner = type("DecodeCudaGraphRunner", (), {})
+    module("sglang.srt.mem_cache.allocator").PagedTokenToKVPoolAllocator = type("PagedTokenToKVPoolAllocator", (), {})
+    plat_pkg._set = lambda p: current.__setitem__("platform", p)
+    return created
+
+
+def test_plugin_load_runs_against_the_reference_contract(fake_sglang):
+    from sglang_amd import platform, plugin
+    from sglang_amd.layers.attention.hip_backend import HipAttnBackend
+
+    plugin.load()
+    g = fake_sglang
+    # attention backend: registered under the CLI choice, factory takes a reference-shaped runner
+    assert platform.BACKEND_NAME in g["sglang.srt.server_args"].ATTENTION_BACKEND_CHOICES
+    factory = g["sglang.srt.layers.attention.attention_registry"].ATTENTION_BACKENDS[platform.BACKEND_NAME]
+
+    class Pool:                                                           # memory_pool.py MHATokenToKVPool (fields read)
+        start_layer = 0
+
+        def __init__(self):
+            self.k = torch.zeros((64, 2, 64), dtype=torch.bfloat16)
+
+        def get_key_buffer(self, layer_id):
+            return self.k
+
+    class MC:                                                             # configs/model_config.py:1106-1196
+        num_attention_heads, num_key_value_heads, context_len = 16, 4, 96
+
+        def get_num_attention_heads(self, tensor_parallel_size):
+            return max(1, self.num_attention_heads // tensor_parallel_size)
+
+        def get_num_kv_heads(self, tensor_parallel_size, dcp_size=1):
+            return max(1, self.num_key_value_heads // tensor_parallel_size)
+
+    runner = types.SimpleNamespace(device=torch.device("cpu"), model_config=MC(), tp_size=2, sliding_window_size=None,
+                                   token_to_kv_pool=Pool(), server_args=None,
+                                   req_to_token_pool=types.SimpleNamespace(req_to_token=torch.zeros((9, 96), dtype=torch.int32), size=8))
+    be = factory(runner)
+    assert isinstance(be, HipAttnBackend) and (be.num_q_heads, be.num_kv_heads, be.head_dim, be.max_context_len) == (8, 2, 64, 96)
+    assert be.support_triton() is False and be.get_cuda_graph_seq_len_fill_value() == 1
+
+    # sampler: a subclass of the reference Sampler with the gfx950 forward and the reference's own helpers
+    smp = g["sglang.srt.layers.sampler"]
+    s = smp._SAMPLER_FACTORIES[platform.BACKEND_NAME]()
+    assert isinstance(s, smp.Sampler) and type(s).forward is not smp.Sampler.forward
+    assert type(s)._sync_token_ids_across_tp is smp.Sampler._sync_token_ids_across_tp
+    assert s.forward(types.SimpleNamespace(next_token_logits=torch.zeros((0, 8))), None, False, None, None, None).numel() == 0
+
+    # platform: out-of-tree, dispatch key = the key the forwards were registered under
+    cls = platform._build_platform_class()
+    iface = g["sglang.srt.platforms.interface"]
+    assert issubclass(cls, iface.SRTPlatform)
+    p = cls()
+    assert p.is_out_of_tree() and p.get_dispatch_key_name() == platform.DISPATCH_KEY
+    assert p.get_default_attention_backend() == platform.BACKEND_NAME and p.support_cuda_graph()
+    assert p.get_graph_runner_cls().__name__ == "DecodeCudaGraphRunner" and p.get_paged_allocator_cls().__name__ == "PagedTokenToKVPoolAllocator"
+    g["sglang.srt.platforms"]._set(p)
+
+    # fused elementwise ops: BaseFusedOp dispatches to the registered forwards, which accept the reference call forms
+    BaseFusedOp = g["sglang.kernels.fused_op"].BaseFusedOp
+    reg = BaseFusedOp._oot_forward_registry[platform.DISPATCH_KEY]
+    ln = g["sglang.srt.layers.layernorm"]
+    assert set(c.__name__ for c in reg) == {"RMSNorm", "SiluAndMul", "RotaryEmbedding", "TopK"}
+    norm = ln.RMSNorm(32)
+    x, res, pra = (torch.zeros((3, 32), dtype=torch.bfloat16) for _ in range(3))
+    # communicator.py:722 call form: (hidden_states, residual, post_residual_addition); CPU tensors -> the op hands
+    # the call to the instance's forward_native with the same four arguments
+    out = norm(x, res, pra)
+    assert isinstance(out, tuple) and norm.native_args == (True, True, False)
+    norm(x, None, None, quant_linear=torch.nn.Identity())
+    assert norm.native_args == (False, False, True)
+    # TopK: reads topk_config (topk.py:215-232); grouped / biased routers stay with the reference
+    tk = g["sglang.srt.layers.moe.topk"]
+    cfg = types.SimpleNamespace(top_k=2, renormalize=True, use_grouped_topk=True, custom_routing_function=None,
+                                correction_bias=None, scoring_func="softmax", num_fused_shared_experts=0,
+                                apply_routed_scaling_factor_on_output=False, output_format=None)
+    assert tk.TopK(cfg)(torch.zeros(2, 8), torch.zeros(2, 4)) == "native-topk"
+
+    # fused MoE: the ("none", "triton") slot is ours, the reference's function is the fallback for what we do not cover
+    pool = g["sglang.srt.layers.moe.moe_runner.base"].FusedOpPool
+    fn = pool.get_fused_func("none", "triton")
+    tri = g["sglang.srt.layers.moe.moe_runner.triton"]
+    assert fn is not tri.fused_experts_none_to_triton
+    fields = [f["name"] for f in ref("sglang.srt.layers.moe.moe_runner.triton", "TritonMoeQuantInfo")["fields"]]
+    q = types.SimpleNamespace(**{f: None for f in fields})
+    q.w13_weight, q.w2_weight = torch.zeros((2, 8, 4), dtype=torch.bfloat16), torch.zeros((2, 4, 4), dtype=torch.bfloat16)
+    for f in fields:
+        if f.startswith("use_") or f in ("per_channel_quant", "fuse_swiglu_interleaved"):
+            setattr(q, f, False)
+    q.use_fp8_w8a8 = True
+    disp = types.SimpleNamespace(hidden_states=torch.zeros((2, 4), dtype=torch.bfloat16), topk_output=None, hidden_states_pre_quant=None)
+    cfg_r = types.SimpleNamespace(activation="silu", is_gated=True, no_combine=False, apply_router_weight_on_input=False, inplace=False,
+                                  routed_scaling_factor=None)
+    assert fn(disp, q, cfg_r) == "reference-result" and tri.calls == ["reference"]
+    q.use_fp8_w8a8, q.b13 = False, torch.zeros(2, 8)
+    assert fn(disp, q, cfg_r) == "reference-result"                       # expert biases: not silently dropped
+    # loading twice must not trip the pool's duplicate check (plugins are loaded once per process, but be safe)
+    plugin.load()
+
+
+def test_runner_config_and_quant_info_fields_the_moe_hook_reads_exist():
+    cfg_fields = [f["name"] for f in ref("sglang.srt.layers.moe.moe_runner.base", "MoeRunnerConfig")["fields"]]
+    for f in ("activation", "is_gated", "inplace", "no_combine", "routed_scaling_factor", "apply_router_weight_on_input"):
+        assert f in cfg_fields, f
+    q_fields = [f["name"] for f in ref("sglang.srt.layers.moe.moe_runner.triton", "TritonMoeQuantInfo")["fields"]]
+    for f in ("w13_weight", "w2_weight", "b13", "b2", "use_fp8_w8a8", "fuse_swiglu_interleaved", "block_shape"):
+        assert f in q_fields, f
+    tk_fields = [f["name"] for f in ref("sglang.srt.layers.moe.topk", "TopKConfig")["fields"]]
+    for f in ("top_k", "renormalize", "use_grouped_topk", "custom_routing_function", "correction_bias", "scoring_func"):
+        assert f in tk_fields, f
+    assert [f["name"] for f in ref("sglang.srt.layers.moe.topk", "StandardTopKOutput")["fields"]] == ["topk_weights", "topk_ids", "router_logits"]
+    assert [f["name"] for f in ref("sglang.srt.mem_cache.memory_pool", "KVWriteLoc")["fields"]][:2] == ["loc", "swa_loc"]
+    assert [p["name"] for p in ref_params("sglang.srt.mem_cache.memory_pool", "MHATokenToKVPool", "set_kv_buffer")][:4] == ["layer", "loc_info", "cache_k", "cache_v"]
