@@ -71,8 +71,14 @@ struct Smem {
 // NWV = waves per workgroup: 8 (x 2 M-tiles = 256 rows) halves the K/V gathers per flop once more and puts two
 // waves on every SIMD (the whole register file: 512 threads x 256 VGPRs) -- the form for long prefixes, where the
 // kernel is bound by the gather traffic rather than by the matrix cores.
-template <int D, int MTW, int NWV>
+// DEEP (8-wave form only): the two halves of the workgroup stage ALTERNATE K/V tiles -- waves 0-3 the even tiles of
+// the walk, waves 4-7 the odd ones -- so two tiles (64 KiB at D = 128) are in flight per workgroup for the register
+// cost of one per thread, and every gather has two iterations of matrix work to land instead of one.  Measured
+// (rocprofv3 PMC, profiles/r02_pmc.json) the one-deep form spends ~7 us per KV tile against 0.45 us of MFMA issue:
+// it is bound by the bytes a CU keeps in flight, not by the matrix cores.
+template <int D, int MTW, int NWV, bool DEEP>
 __global__ __launch_bounds__(64 * NWV, (MTW == 1 && NWV == 4) ? 3 : (NWV == 8 ? 2 : 1)) void extend_attention_kernel(ExtendParams p) {
+  static_assert(!DEEP || NWV == 8, "the alternating stager halves need 8 waves");
   __shared__ Smem<D> sm;
   const int block_x = blockIdx.x, block_z = blockIdx.z;
   constexpr int CPR = D / 8;            // 16-byte chunks per KV row
@@ -143,9 +149,11 @@ __global__ __launch_bounds__(64 * NWV, (MTW == 1 && NWV == 4) ? 3 : (NWV == 8 ? 
 
   // ---- staging roles -------------------------------------------------------
   // waves 0-1: V (8x8 transposing blocks), waves 2-3: K (row-major).
-  const bool is_v = tid < 128;
-  const bool is_k = tid >= 128 && tid < kStagers;
-  const int st = is_v ? tid : (tid - 128) & 127;
+  const int stid = DEEP ? (tid & 255) : tid;  // role inside the stager half
+  const int half = DEEP ? (tid >> 8) : 0;     // wave-uniform: which tiles of the walk this half stages
+  const bool is_v = stid < 128;
+  const bool is_k = stid >= 128 && stid < kStagers;
+  const int st = is_v ? stid : (stid - 128) & 127;
   const int st_c = st % CPR;                 // 16-byte column of the KV row
   const int st_r = st / CPR;
   const bool v_active = is_v && st < V_THREADS;
@@ -220,19 +228,21 @@ __global__ __launch_bounds__(64 * NWV, (MTW == 1 && NWV == 4) ? 3 : (NWV == 8 ? 
     }
   };
 
-  if (n_tiles > t_first) {
-    prefetch_idx(t_first);
+  constexpr int STEP = DEEP ? 2 : 1;          // tiles between two stagings of the same half
+  if (t_first + half < n_tiles) {
+    prefetch_idx(t_first + half);
     prefetch_rows();
-    if (t_first + 1 < n_tiles) prefetch_idx(t_first + 1);
+    if (t_first + half + STEP < n_tiles) prefetch_idx(t_first + half + STEP);
   }
 
   for (int t = t_first; t < n_tiles; ++t) {
+    const bool mine = !DEEP || ((t - t_first) & 1) == half;      // wave-uniform
     __syncthreads();   // every wave is done reading the previous tile
-    commit();
+    if (mine) commit();
     __syncthreads();
-    if (t + 1 < n_tiles) {
-      prefetch_rows();                                   // tile t+1, slot ids loaded one iteration ago
-      if (t + 2 < n_tiles) prefetch_idx(t + 2);
+    if (mine && t + STEP < n_tiles) {
+      prefetch_rows();                                   // this half's next tile, slot ids loaded one staging ago
+      if (t + 2 * STEP < n_tiles) prefetch_idx(t + 2 * STEP);
     }
 
     const int kv0 = t * kKvTile;
@@ -438,15 +448,19 @@ int sgl_amd_extend_attention(const void* q, void* out, const void* k_cache, cons
   const int tiles = (max_extend_len + p.tokens_per_tile - 1) / p.tokens_per_tile;
   dim3 grid(tiles, num_kv_heads, batch);
   hipStream_t st = as_stream(stream);
-#define SGL_LAUNCH_EXT(D_, M_, W_) hipLaunchKernelGGL((extend_attention_kernel<D_, M_, W_>), grid, dim3(64 * W_), 0, st, p)
+  bool deep = true;
+  if (const char* f = getenv("SGL_AMD_EXTEND_DEEP")) deep = atoi(f) != 0;      // A/B switch (benchmarks/micro.py)
+#define SGL_LAUNCH_EXT(D_, M_, W_, DP_) hipLaunchKernelGGL((extend_attention_kernel<D_, M_, W_, DP_>), grid, dim3(64 * W_), 0, st, p)
   if (head_dim == 128) {
-    if (nwv == 8) SGL_LAUNCH_EXT(128, 2, 8);
-    else if (mtw == 1) SGL_LAUNCH_EXT(128, 1, 4);
-    else SGL_LAUNCH_EXT(128, 2, 4);
+    if (nwv == 8 && deep) SGL_LAUNCH_EXT(128, 2, 8, true);
+    else if (nwv == 8) SGL_LAUNCH_EXT(128, 2, 8, false);
+    else if (mtw == 1) SGL_LAUNCH_EXT(128, 1, 4, false);
+    else SGL_LAUNCH_EXT(128, 2, 4, false);
   } else {
-    if (nwv == 8) SGL_LAUNCH_EXT(64, 2, 8);
-    else if (mtw == 1) SGL_LAUNCH_EXT(64, 1, 4);
-    else SGL_LAUNCH_EXT(64, 2, 4);
+    if (nwv == 8 && deep) SGL_LAUNCH_EXT(64, 2, 8, true);
+    else if (nwv == 8) SGL_LAUNCH_EXT(64, 2, 8, false);
+    else if (mtw == 1) SGL_LAUNCH_EXT(64, 1, 4, false);
+    else SGL_LAUNCH_EXT(64, 2, 4, false);
   }
 #undef SGL_LAUNCH_EXT
   SGL_CHECK_LAUNCH("extend_attention");

@@ -77,10 +77,13 @@ def test_plan_groups_the_bench_pattern(device):
         rows = plan["member_rows"][16 * gi: 16 * gi + 16]
         assert rows == sorted(rows) and {groups[r] for r in rows} == {gi}
     assert plan["req_shared"] == [896] * B
-    assert plan["n_shared_items"] == 4 * 7 and len(set(plan["items"])) == 28     # 16 members x 4 heads = one 64-row item
-    # private part: tokens [896, len) of every request in 128-token chunks, slots behind the 7 shared ones
-    want = sorted((b, 7 + j, 896 + 128 * j, min(128, lens[b] - 896 - 128 * j)) for b in range(B) for j in range(2))
-    assert sorted(plan["private_items"]) == want and plan["n_items"] == 28 + len(want)
+    CH = _k().native.lib().sgl_amd_cascade_chunk_tokens()
+    ns = (896 + CH - 1) // CH
+    assert plan["n_shared_items"] == 4 * ns and len(set(plan["items"])) == 4 * ns     # 16 members x 4 heads = one 64-row item
+    # private part: tokens [896, len) of every request in CH-token items, slots behind the shared ones
+    want = sorted((b, ns + j, 896 + CH * j, min(CH, lens[b] - 896 - CH * j)) for b in range(B)
+                  for j in range((lens[b] - 896 + CH - 1) // CH))
+    assert sorted(plan["private_items"]) == want and plan["n_items"] == 4 * ns + len(want)
     _check(out, q, kc, vc, r2t, pool, seq, D)
 
 
@@ -107,7 +110,9 @@ def test_cascade_matches_oracle_mixed_batch(device, Hq, Hkv, D):
     assert plan["group_kvlen"] == [256, 192, 896]          # 300 -> 256, 200 -> 192, 899 -> 896
     mpi = 64 // (Hq // Hkv)                     # members per item: 64 (member, head) rows per workgroup
     tiles = lambda members: (members + mpi - 1) // mpi
-    assert plan["n_shared_items"] == 2 * tiles(3) + 2 * tiles(40) + 7 * tiles(2)
+    CH = _k().native.lib().sgl_amd_cascade_chunk_tokens()
+    ch = lambda kv: (kv + CH - 1) // CH
+    assert plan["n_shared_items"] == ch(256) * tiles(3) + ch(192) * tiles(40) + ch(896) * tiles(2)
     _check(out, q, kc, vc, r2t, pool, seq, D)
 
 
@@ -118,7 +123,8 @@ def test_cascade_without_sharing_equals_plain_decode(device):
     q, kc, vc, r2t, pool, seq = _batch(device, lens, [-1] * len(lens), {}, Hq, Hkv, D, seed=3)
     out, plan = _run(device, q, kc, vc, r2t, pool, seq, Hq, Hkv, D)
     assert plan["n_groups"] == 0 and plan["n_shared_items"] == 0 and plan["req_shared"] == [0] * len(lens)
-    assert plan["n_items"] == sum((ln + 127) // 128 for ln in lens)
+    CH = K.native.lib().sgl_amd_cascade_chunk_tokens()
+    assert plan["n_items"] == sum((ln + CH - 1) // CH for ln in lens)
     _check(out, q, kc, vc, r2t, pool, seq, D)
     plain = torch.empty_like(q, device=device)
     K.decode_attention(q.to(device), kc.to(device), vc.to(device), plain, r2t.to(device), pool.to(device), seq.to(device),

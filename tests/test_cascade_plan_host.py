@@ -6,6 +6,9 @@ import numpy as np
 import pytest
 
 from oracle import host as oh
+from sglang_amd import native
+
+CH = native.lib().sgl_amd_cascade_chunk_tokens()      # kv tokens per plan item (the library loads without a GPU)
 
 
 def _batch(rnd, B, groups, ctx):
@@ -36,14 +39,14 @@ def test_every_token_is_covered_exactly_once(seed, group):
     B, ctx = rnd.randrange(1, 40), 700
     groups = [rnd.choice([-1, 0, 1, 2, 3]) for _ in range(B)]
     r2t, pool, lens = _batch(rnd, B, groups, ctx)
-    plan = oh.cascade_plan(r2t, pool, lens, group, max_context_len=ctx)
+    plan = oh.cascade_plan(r2t, pool, lens, group, chunk=CH, max_context_len=ctx)
     mpi = 64 // group
     covered = [np.zeros(n, dtype=np.int32) for n in lens]
     slots = [set() for _ in range(B)]
     for gi, slot, first, members in plan["shared_items"]:
         leader, kv, mem = plan["groups"][gi]
         assert 1 <= members <= mpi and kv % 64 == 0 and kv >= 128
-        lo, hi = slot * 128, min(kv, slot * 128 + 128)
+        lo, hi = slot * CH, min(kv, slot * CH + CH)
         for m in plan["member_rows"][first: first + members]:
             assert m in mem
             # the shared rows really are the same pool slots for every member
@@ -51,13 +54,13 @@ def test_every_token_is_covered_exactly_once(seed, group):
             covered[m][lo:hi] += 1
             slots[m].add(slot)
     for b, slot, kv_begin, kv_n in plan["private_items"]:
-        assert 1 <= kv_n <= 128 and kv_begin >= plan["req_shared"][b]
+        assert 1 <= kv_n <= CH and kv_begin >= plan["req_shared"][b]
         covered[b][kv_begin: kv_begin + kv_n] += 1
         assert slot not in slots[b]
         slots[b].add(slot)
     for b in range(B):
         assert (covered[b] == 1).all(), f"request {b}"
-        n = (plan["req_shared"][b] + 127) // 128 + ((lens[b] - plan["req_shared"][b] + 127) // 128 if lens[b] > plan["req_shared"][b] else 0)
+        n = (plan["req_shared"][b] + CH - 1) // CH + ((lens[b] - plan["req_shared"][b] + CH - 1) // CH if lens[b] > plan["req_shared"][b] else 0)
         assert slots[b] == set(range(n))                     # the merge kernel reads slots [0, n)
         assert plan["req_shared"][b] < lens[b]               # the newest token is never in a shared part
 
@@ -78,10 +81,12 @@ def test_bench_pattern_layout():
             r2t[b + 1, :896] = r2t[first_of[grp[b]] + 1, :896]
         else:
             first_of[grp[b]] = b
-    plan = oh.cascade_plan(r2t, list(range(1, B + 1)), lens, 4, max_context_len=1100)
+    plan = oh.cascade_plan(r2t, list(range(1, B + 1)), lens, 4, chunk=CH, max_context_len=1100)
     assert [kv for _, kv, _ in plan["groups"]] == [896] * 4 and plan["req_shared"] == [896] * B
-    assert len(plan["shared_items"]) == 4 * 7 and all(m == 16 for *_, m in plan["shared_items"])
-    want = sorted((b, 7 + j, 896 + 128 * j, min(128, lens[b] - 896 - 128 * j)) for b in range(B) for j in range(2))
+    ns = (896 + CH - 1) // CH                           # shared items per group (one member tile: 16 x 4 rows)
+    assert len(plan["shared_items"]) == 4 * ns and all(m == 16 for *_, m in plan["shared_items"])
+    want = sorted((b, ns + j, 896 + CH * j, min(CH, lens[b] - 896 - CH * j)) for b in range(B)
+                  for j in range((lens[b] - 896 + CH - 1) // CH))
     assert sorted(plan["private_items"]) == want
 
 
@@ -92,6 +97,6 @@ def test_no_sharing_means_private_chunks_only():
     for b, n in enumerate(lens):
         r2t[b + 1, :n] = np.arange(nxt, nxt + n)
         nxt += n
-    plan = oh.cascade_plan(r2t, list(range(1, len(lens) + 1)), lens, 4, max_context_len=1024)
+    plan = oh.cascade_plan(r2t, list(range(1, len(lens) + 1)), lens, 4, chunk=CH, max_context_len=1024)
     assert plan["groups"] == [] and plan["req_shared"] == [0] * len(lens)
-    assert len(plan["private_items"]) == sum((n + 127) // 128 for n in lens)
+    assert len(plan["private_items"]) == sum((n + CH - 1) // CH for n in lens)
