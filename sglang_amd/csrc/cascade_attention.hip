@@ -30,9 +30,7 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int kThreads = 256;
-constexpr int kSub = 128;         // kv tokens per staged LDS image (one pass of the two contractions)
-constexpr int kSubsPerItem = 2;   // an item walks up to this many images with a running softmax
-constexpr int kChunk = kSub * kSubsPerItem;   // kv tokens per item (the plan's chunk size)
+constexpr int kChunk = 128;       // kv tokens per item
 constexpr int kRowsPerItem = 64;  // (member, q head) rows per item: 4 waves x one 16-row tile
 constexpr float kNegBig = -1.0e30f;
 
@@ -55,27 +53,23 @@ struct ChunkParams {
   float scale_log2;
 };
 
-// One workgroup per (item, kv head) unit.  An item is up to kChunk = 256 kv tokens, walked as two 128-token
-// images: the K image, then (after S^T) the transposed V image, share ONE 32 KiB (D = 128) buffer, and while the
-// matrix cores work on image s the rows of image s + 1 are already on their way into the registers image s just
-// vacated (K rows are re-issued right after the K image is written, V rows right after the V^T image is).  The
-// dependent-load chain (plan record -> slot ids -> rows) is therefore paid once per item, not once per 128 tokens,
-// a RadixAttention decode batch needs half the workgroups -- the bench batch (4 groups x 16, ~1090 tokens) is 768
-// units = ONE resident round at three workgroups per CU -- and half the fp32 partials go through the merge.
-// The grid covers the worst-case item count of the batch; the workgroups behind the end of the device-built list
-// leave after one load.
+// One 128-token K image, then (after S^T) the transposed V image, in the SAME 32 KiB (D = 128) buffer:
+// four workgroups fit a CU, so a whole decode step's items are resident at once.
+// One workgroup per (item, kv head) unit; the grid covers the worst-case item count of the batch and the
+// workgroups behind the end of the device-built list leave after one load.  (A persistent loop over the
+// units was measured slower: hipcc hoists the lane-derived LDS addresses out of the loop and spills.)
 template <int D>
-__global__ __launch_bounds__(kThreads, 3) void cascade_chunk_kernel(ChunkParams p) {
-  __shared__ U4 sm[kSub * D / 8];       // K: [token][16-byte piece ^ swz];  V^T: [d][8-token chunk ^ swz]
+__global__ __launch_bounds__(kThreads, 4) void cascade_chunk_kernel(ChunkParams p) {
+  __shared__ U4 sm[kChunk * D / 8];     // K: [token][16-byte piece ^ swz];  V^T: [d][8-token chunk ^ swz]
   const int unit = blockIdx.x;
   constexpr int CPR = D / 8;            // 16-byte pieces per KV row
   constexpr int KC = D / 32;            // MFMA k-steps over the head dim
   constexpr int ND = D / 16;            // 16-wide output tiles over the head dim
-  constexpr int NT = kSub / 16;         // 16-token tiles of an image
-  constexpr int NKK = kSub / 32;        // MFMA k-steps over the tokens
+  constexpr int NT = kChunk / 16;       // 16-token tiles of the chunk
+  constexpr int NKK = kChunk / 32;      // MFMA k-steps over the tokens
   constexpr int ROWS_PER_PASS = kThreads / CPR;
-  constexpr int NK_LOADS = kSub / ROWS_PER_PASS;     // K 16-byte loads per thread (8 at D=128)
-  constexpr int V_THREADS = (kSub / 8) * CPR;        // one 8x8 transposing block each
+  constexpr int NK_LOADS = kChunk / ROWS_PER_PASS;   // K 16-byte loads per thread (8 at D=128)
+  constexpr int V_THREADS = (kChunk / 8) * CPR;      // one 8x8 transposing block each
 
   const CascadePlanView pv = cascade_plan_view(p.plan, p.batch, p.max_items);
 
@@ -95,45 +89,39 @@ __global__ __launch_bounds__(kThreads, 3) void cascade_chunk_kernel(ChunkParams 
   const int single = rb.x;
   const int last = kv_begin + kv_n - 1;
   const int n_rows = n_mem * p.group;
-  const int n_sub = (kv_n + kSub - 1) / kSub;
 
-  // ---- gather roles --------------------------------------------------------------------------
+  // ---- gather burst: all K / V rows of the chunk --------------------------------------------
   const int st_c = tid % CPR, st_r = tid / CPR;
   const int64_t head_off = static_cast<int64_t>(kvh) * D + st_c * 8;
   const bool v_active = tid < V_THREADS;
-  // V block of this thread: k-step kk = st_r >> 2, lane group vg = st_r & 3; token order inside the
-  // block matches the P^T operand built from the S^T accumulators: i = 4a + r <-> 32 kk + 16 a + 4 vg + r
-  const int v_kk = st_r >> 2, v_g = st_r & 3;
   U4 kst[NK_LOADS], vst[8];
-  int32_t ks[NK_LOADS];
-  auto load_k_ids = [&](int sub_begin) {
+  {
+    int32_t ks[NK_LOADS];
 #pragma unroll
     for (int i = 0; i < NK_LOADS; ++i) {
-      int tok = sub_begin + st_r + ROWS_PER_PASS * i;
+      int tok = kv_begin + st_r + ROWS_PER_PASS * i;
       if (tok > last) tok = last;
       ks[i] = idx_base[tok];
     }
-  };
-  auto load_k_rows = [&]() {
-#pragma unroll
-    for (int i = 0; i < NK_LOADS; ++i) kst[i] = ld16(p.k_cache + static_cast<int64_t>(ks[i]) * p.kc_stride + head_off);
-  };
-  auto load_v = [&](int sub_begin) {
+    // V block of this thread: k-step kk = st_r >> 2, lane group vg = st_r & 3; token order inside the
+    // block matches the P^T operand built from the S^T accumulators: i = 4a + r <-> 32 kk + 16 a + 4 vg + r
+    int32_t vs[8];
+    const int v_kk = st_r >> 2, v_g = st_r & 3;
     if (v_active) {
-      int32_t vs[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        int tok = sub_begin + 32 * v_kk + 16 * (i >> 2) + 4 * v_g + (i & 3);
+        int tok = kv_begin + 32 * v_kk + 16 * (i >> 2) + 4 * v_g + (i & 3);
         if (tok > last) tok = last;
         vs[i] = idx_base[tok];
       }
+    }
+#pragma unroll
+    for (int i = 0; i < NK_LOADS; ++i) kst[i] = ld16(p.k_cache + static_cast<int64_t>(ks[i]) * p.kc_stride + head_off);
+    if (v_active) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) vst[i] = ld16(p.v_cache + static_cast<int64_t>(vs[i]) * p.vc_stride + head_off);
     }
-  };
-  load_k_ids(kv_begin);
-  load_k_rows();
-  load_v(kv_begin);
+  }
 
   // ---- this wave's 16 query rows: row = (member, q head of the kv head's group) -----------------
   const int r = wid * 16 + l15;
@@ -152,131 +140,99 @@ __global__ __launch_bounds__(kThreads, 3) void cascade_chunk_kernel(ChunkParams 
     for (int kc = 0; kc < KC; ++kc) qfrag[kc] = U4{0u, 0u, 0u, 0u};
   }
 
-  float m_run = kNegBig, psum = 0.f;                 // psum: this lane's share of the row sum (reduced at the end)
-  f32x4_t oacc[ND];
+  // ---- K image (row-major, XOR-swizzled pieces) ----------------------------------------------
 #pragma unroll
-  for (int n = 0; n < ND; ++n) oacc[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  for (int s = 0; s < n_sub; ++s) {
-    const int sub_n = kv_n - s * kSub < kSub ? kv_n - s * kSub : kSub;
-    const bool more = s + 1 < n_sub;                // workgroup-uniform
-    // The LDS addresses below are lane constants; left alone, hipcc hoists all of them (K reads, V^T reads, both
-    // staging writes: ~80 registers) out of this loop and spills.  An opaque per-iteration zero keeps every address
-    // computation inside the iteration that uses it.
-    int zz;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(zz));
-    const int l15v = l15 + zz, gv = g + zz, st_rv = st_r + zz, st_cv = st_c + zz;
-    // ---- K image (row-major, XOR-swizzled pieces) --------------------------------------------
-#pragma unroll
-    for (int i = 0; i < NK_LOADS; ++i) {
-      const int row = st_rv + ROWS_PER_PASS * i;
-      sm[row * CPR + (st_cv ^ (row & (CPR - 1)))] = kst[i];
-    }
-    __syncthreads();
-    if (more) load_k_ids(kv_begin + (s + 1) * kSub);   // next image's slot ids fly under S^T
-
-    // ---- S^T = K . Q^T : lane owns query row l15 of the wave, tokens 16 nt + 4 g + r ------------
-    U4 pfrag[NKK];
-    if (wave_on) {
-      f32x4_t st_acc[NT];
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        st_acc[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        const int row = nt * 16 + l15v;
-#pragma unroll
-        for (int kc = 0; kc < KC; ++kc) {
-          const U4 kf = sm[row * CPR + ((kc * 4 + gv) ^ (row & (CPR - 1)))];
-          st_acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(kf), as_frag(qfrag[kc]), st_acc[nt], 0, 0, 0);
-        }
-      }
-      float mx = kNegBig;
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const float sv = (nt * 16 + g * 4 + rr < sub_n) ? st_acc[nt][rr] * p.scale_log2 : kNegBig;
-          st_acc[nt][rr] = sv;
-          mx = fmaxf(mx, sv);
-        }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = fast_exp2(m_run - m_new);  // first image: exp2(-1e30) = 0 on zero accumulators
-      m_run = m_new;
-      psum *= alpha;
-      if (s > 0) {
-#pragma unroll
-        for (int n = 0; n < ND; ++n) oacc[n] *= alpha;
-      }
-#pragma unroll
-      for (int kk = 0; kk < NKK; ++kk) {
-        float e[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const float sv = st_acc[2 * kk + (i >> 2)][i & 3];
-          e[i] = (sv > 0.5f * kNegBig) ? fast_exp2(sv - m_new) : 0.f;
-          psum += e[i];
-        }
-        pfrag[kk].x = pack_bf2(e[0], e[1]);
-        pfrag[kk].y = pack_bf2(e[2], e[3]);
-        pfrag[kk].z = pack_bf2(e[4], e[5]);
-        pfrag[kk].w = pack_bf2(e[6], e[7]);
-      }
-    }
-    __syncthreads();        // every wave is done with the K image
-    if (more) load_k_rows();   // next image's K rows fly under the V^T staging and O^T (their registers were freed by the K image)
-
-    // ---- V^T image: 8x8 blocks transposed through registers -----------------------------------
-    if (v_active) {
-      const uint32_t* w = reinterpret_cast<const uint32_t*>(vst);   // vst[i] dword q -> w[4 i + q]
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int d = st_cv * 8 + j;
-        U4 o;
-        uint32_t* ow = reinterpret_cast<uint32_t*>(&o);
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-          const uint32_t a = w[4 * (2 * qd) + (j >> 1)];
-          const uint32_t c = w[4 * (2 * qd + 1) + (j >> 1)];
-          ow[qd] = (j & 1) ? ((a >> 16) | (c & 0xffff0000u)) : ((a & 0xffffu) | (c << 16));
-        }
-        sm[d * 16 + (st_rv ^ ((d ^ (d >> 3)) & 15))] = o;
-      }
-    }
-    __syncthreads();
-
-    // ---- O^T += V^T . P^T : lane holds O^T[d = 16 n + 4 g + r][row l15] --------------------------
-    if (wave_on) {
-#pragma unroll
-      for (int n = 0; n < ND; ++n) {
-        const int d = n * 16 + l15v;
-#pragma unroll
-        for (int kk = 0; kk < NKK; ++kk) {
-          const U4 vf = sm[d * 16 + ((kk * 4 + gv) ^ ((d ^ (d >> 3)) & 15))];
-          oacc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(vf), as_frag(pfrag[kk]), oacc[n], 0, 0, 0);
-        }
-      }
-    }
-    if (more) {
-      load_v(kv_begin + (s + 1) * kSub);            // next image's V rows fly under its K staging and S^T
-      __syncthreads();                              // the V^T image is read before the next K image lands
-    }
+  for (int i = 0; i < NK_LOADS; ++i) {
+    const int row = st_r + ROWS_PER_PASS * i;
+    sm[row * CPR + (st_c ^ (row & (CPR - 1)))] = kst[i];
   }
+  __syncthreads();
 
-  // ---- unnormalised partial of this item into the member's slot -----------------------------------
+  // ---- S^T = K . Q^T : lane owns query row l15 of the wave, tokens 16 nt + 4 g + r --------------
+  float mx = kNegBig, psum = 0.f;
+  U4 pfrag[NKK];
   if (wave_on) {
+    f32x4_t st_acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      st_acc[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      const int row = nt * 16 + l15;
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) {
+        const U4 kf = sm[row * CPR + ((kc * 4 + g) ^ (row & (CPR - 1)))];
+        st_acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(kf), as_frag(qfrag[kc]), st_acc[nt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const float s = (nt * 16 + g * 4 + rr < kv_n) ? st_acc[nt][rr] * p.scale_log2 : kNegBig;
+        st_acc[nt][rr] = s;
+        mx = fmaxf(mx, s);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+      float e[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float s = st_acc[2 * kk + (i >> 2)][i & 3];
+        e[i] = (s > 0.5f * kNegBig) ? fast_exp2(s - mx) : 0.f;
+        psum += e[i];
+      }
+      pfrag[kk].x = pack_bf2(e[0], e[1]);
+      pfrag[kk].y = pack_bf2(e[2], e[3]);
+      pfrag[kk].z = pack_bf2(e[4], e[5]);
+      pfrag[kk].w = pack_bf2(e[6], e[7]);
+    }
     psum += __shfl_xor(psum, 16, 64);
     psum += __shfl_xor(psum, 32, 64);
-    if (row_ok) {
-      const int64_t sl = (req * p.num_q_heads + kvh * p.group + hg) * p.slots_total + slot;
-      float* ap = p.ws_acc + sl * D + g * 4;
-      if (g == 0) {
-        p.ws_ml[sl * 2 + 0] = m_run;
-        p.ws_ml[sl * 2 + 1] = psum;
-      }
+  }
+  __syncthreads();        // every wave is done with the K image
+
+  // ---- V^T image: 8x8 blocks transposed through registers -------------------------------------
+  if (v_active) {
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(vst);   // vst[i] dword q -> w[4 i + q]
 #pragma unroll
-      for (int n = 0; n < ND; ++n) *reinterpret_cast<f32x4_t*>(ap + n * 16) = oacc[n];
+    for (int j = 0; j < 8; ++j) {
+      const int d = st_c * 8 + j;
+      U4 o;
+      uint32_t* ow = reinterpret_cast<uint32_t*>(&o);
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const uint32_t a = w[4 * (2 * qd) + (j >> 1)];
+        const uint32_t c = w[4 * (2 * qd + 1) + (j >> 1)];
+        ow[qd] = (j & 1) ? ((a >> 16) | (c & 0xffff0000u)) : ((a & 0xffffu) | (c << 16));
+      }
+      sm[d * 16 + (st_r ^ ((d ^ (d >> 3)) & 15))] = o;
     }
+  }
+  __syncthreads();
+
+  // ---- O^T = V^T . P^T : lane holds O^T[d = 16 n + 4 g + r][row l15] ----------------------------
+  if (wave_on) {
+  float* ap = nullptr;
+  if (row_ok) {
+    const int64_t sl = (req * p.num_q_heads + kvh * p.group + hg) * p.slots_total + slot;
+    ap = p.ws_acc + sl * D + g * 4;
+    if (g == 0) {
+      p.ws_ml[sl * 2 + 0] = mx;
+      p.ws_ml[sl * 2 + 1] = psum;
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < ND; ++n) {
+    f32x4_t ot = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int d = n * 16 + l15;
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+      const U4 vf = sm[d * 16 + ((kk * 4 + g) ^ ((d ^ (d >> 3)) & 15))];
+      ot = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(vf), as_frag(pfrag[kk]), ot, 0, 0, 0);
+    }
+    if (row_ok) *reinterpret_cast<f32x4_t*>(ap + n * 16) = ot;
+  }
   }
 }
 
@@ -585,10 +541,10 @@ int sgl_amd_cascade_decode_attention(const void* q, const void* k_cache, const v
   p.num_kv_heads = num_kv_heads;
   p.slots_total = slots_total;
   p.scale_log2 = sm_scale * 1.4426950408889634f;
-  // worst-case item count of this batch.  A shared item (group chunk x member tile) stands for the private items
-  // its >= 1 members would otherwise have, so with req_shared_b the shared length of request b
-  //   items <= sum_b ceil((len_b - sh_b) / kChunk) + ceil(sh_b / kChunk) <= batch * (chunks + 1)
-  int64_t units = batch * (chunks + 1);
+  // worst-case item count of this batch: every request's private chunks + the shared chunks of every member tile
+  // (at most batch/2 groups, and sum over groups of ceil(members / members_per_item) <= batch/members_per_item + groups)
+  const int64_t member_tiles = (batch + p.members_per_item - 1) / p.members_per_item + batch / 2 + 1;
+  int64_t units = batch * (chunks + 1) + member_tiles * chunks;
   if (units > max_items) units = max_items;
   dim3 grid(static_cast<unsigned>(units * num_kv_heads));
   if (head_dim == 128) hipLaunchKernelGGL(cascade_chunk_kernel<128>, grid, dim3(kThreads), 0, st, p);
