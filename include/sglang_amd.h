@@ -307,6 +307,34 @@ int sgl_amd_moe_sum_reduce(const void* input, int input_is_f32, void* output, in
 int sgl_amd_probe_mfma_16x16x32(const void* a_16x32_bf16, const void* b_32x16_bf16,
                                 void* c_16x16_f32, void* stream);
 
+/* ---- one-shot all-reduce over xGMI peer mappings (reference:
+ *      kernels/aot/csrc/allreduce/custom_all_reduce_hip.cuh:150-236,347-420,448-590 and
+ *      srt/distributed/device_communicators/custom_all_reduce.py:182-307, under
+ *      GroupCoordinator.all_reduce, srt/distributed/parallel_state.py:648-758) -------------------------------
+ * The ONE place where the library owns device memory: a communicator workspace must be its own (uncached)
+ * allocation to be exportable with hipIpcGetMemHandle, so it is allocated / freed here, once per process, by the
+ * caller's communicator object (sglang_amd/distributed/xgmi_all_reduce.py).  Layout: an 8 KiB signal block
+ * (per-workgroup start / end flags of every rank, the rank's own flag counters) + the data area.
+ * Every rank opens every peer's handle; `peer_workspaces_host` is a HOST array of `world` device pointers
+ * (entry `rank` = the rank's own workspace).  All ranks must issue the same sequence of calls (sizes, num_blocks).
+ * The launch itself has no host state (flag counters live in the workspace): hipGraph-capturable. */
+int64_t sgl_amd_xgmi_workspace_bytes(int64_t max_message_bytes);
+int sgl_amd_xgmi_max_world(void);
+int sgl_amd_xgmi_alloc(int64_t bytes, void** out_ptr);
+int sgl_amd_xgmi_free(void* ptr);
+int sgl_amd_xgmi_ipc_handle_bytes(void);
+int sgl_amd_xgmi_ipc_get_handle(void* ptr, void* out_handle /* host, ipc_handle_bytes */);
+int sgl_amd_xgmi_ipc_open_handle(const void* handle /* host */, void** out_ptr);
+int sgl_amd_xgmi_ipc_close_handle(void* ptr);
+/* 1 when a flag wait of an earlier launch gave up (a peer never arrived); synchronises. */
+int sgl_amd_xgmi_timed_out(const void* workspace);
+/* out[rows, hidden] = sum over ranks of inp (bf16, fp32 accumulation in rank order, one rounding); world 2/4/8.
+ * epilogue 1: residual <- bf16(bf16(sum) + residual); out = RMSNorm(that, norm_weight, eps) -- the operator that
+ * follows a row-parallel projection (layernorm.py:777-826).  num_blocks <= 0: chosen from the message size. */
+int sgl_amd_xgmi_one_shot_all_reduce(const void* inp, void* out, int64_t rows, int hidden, int rank, int world,
+                                     const void* const* peer_workspaces_host, int64_t workspace_bytes, int epilogue,
+                                     void* residual, const void* norm_weight, float eps, int num_blocks, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,293 @@
+// One-shot all-reduce over xGMI peer mappings for decode-sized messages, gfx950.
+//
+// Replaces (reference, /root/reference/python/sglang):
+//   kernels/aot/csrc/allreduce/custom_all_reduce_hip.cuh:347-420 (one-shot kernel), :150-236 (flag barriers),
+//   :448-590 (IPC handle exchange / buffer registration), srt/distributed/device_communicators/
+//   custom_all_reduce.py:182-307 (registration, dispatch, capture), called from
+//   srt/distributed/parallel_state.py:648-758,965-1008 (GroupCoordinator.all_reduce).
+// Oracle: torch.sum over the ranks' inputs in fp32, rounded once (tests/test_xgmi_all_reduce_gpu.py).
+//
+// MI355X has no switch: every GPU has a direct xGMI link to each of its 7 peers, so for a message of a few
+// hundred KiB the cheapest all-reduce is the one where each rank PULLS the other ranks' copies over those links at
+// once and adds them up locally -- one hop, no ring steps, (world-1)/world of the message per link direction:
+//   phase 0  copy my input into my registered (IPC-exported, uncached) buffer
+//   phase 1  flag barrier: tell every peer "my copy is complete", wait for all of theirs
+//   phase 2  every rank reads all copies, adds them in RANK ORDER in fp32 (so all ranks produce identical bits),
+//            rounds once to bf16 and -- optionally -- applies the operator that follows a row-parallel projection in
+//            the decoder layer: residual add + RMSNorm (layernorm.py:777-826), saving a launch and a round trip
+//   phase 3  end barrier: nobody overwrites its buffer for the next call while a peer may still read it
+// The flags are monotonically increasing counters kept in device memory (the kernel increments its own), so a
+// launch has no host-side state: it can be captured into the decode hipGraph and replayed.
+// Flags are written with system-scope release stores straight into the PEER's signal block and polled locally with
+// system-scope acquire loads; the buffers are hipDeviceMallocUncached so neither side can hit a stale L2 line.
+#include <cstddef>
+#include <cstring>
+#include "common.hpp"
+#include "sglang_amd.h"
+
+using namespace sgl_amd;
+
+namespace {
+
+constexpr int kMaxWorld = 8;
+constexpr int kMaxBlocks = 64;
+constexpr int kArThreads = 512;
+constexpr int64_t kDataOffset = 8192;          // data area starts here (signal block padded to 8 KiB)
+
+struct Signal {
+  uint32_t start[kMaxBlocks][kMaxWorld];
+  uint32_t end[kMaxBlocks][kMaxWorld];
+  uint32_t flag[kMaxBlocks];
+  uint32_t timed_out;                        // set when a flag wait gave up (a peer never arrived)
+};
+static_assert(sizeof(Signal) <= kDataOffset, "signal block");
+
+struct Peers {
+  unsigned char* base[kMaxWorld];            // every rank's workspace as mapped into THIS process (own = local pointer)
+};
+
+struct ArParams {
+  Peers peers;
+  const uint16_t* inp;          // [rows, hidden] bf16 (contiguous)
+  uint16_t* out;                // [rows, hidden]
+  uint16_t* residual;           // epilogue 1: [rows, hidden], updated in place
+  const uint16_t* norm_w;       // epilogue 1: [hidden]
+  int64_t numel;                // rows * hidden, multiple of 8
+  int rows, hidden;
+  int rank, world;
+  int epilogue;                 // 0 none, 1 residual add + RMSNorm
+  float eps;
+};
+
+__device__ __forceinline__ void flag_barrier(const ArParams& p, uint32_t (Signal::*arr)[kMaxBlocks][kMaxWorld], uint32_t flag) {
+  // all data stores of this workgroup are ordered before the flags: every thread fences, then one barrier
+  __threadfence_system();
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t < p.world) {
+    Signal* peer = reinterpret_cast<Signal*>(p.peers.base[t]);
+    Signal* self = reinterpret_cast<Signal*>(p.peers.base[p.rank]);
+    __hip_atomic_store(&(peer->*arr)[blockIdx.x][p.rank], flag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // bounded: a peer that never launches (a crashed rank) must not wedge the GPU -- give up after ~seconds,
+    // leave a mark the host can read (sgl_amd_xgmi_timed_out) and let the kernel finish with garbage
+    int spins = 0;
+    while (__hip_atomic_load(&(self->*arr)[blockIdx.x][t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < flag) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > (1 << 22)) {
+        self->timed_out = 1u;
+        break;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// sum of the `world` copies of 8 bf16 at element offset e, in rank order, fp32
+template <int WORLD>
+__device__ __forceinline__ void gather_sum(const ArParams& p, int64_t e, float (&acc)[8]) {
+  U4 v[WORLD];
+#pragma unroll
+  for (int r = 0; r < WORLD; ++r) v[r] = ld16(reinterpret_cast<const uint16_t*>(p.peers.base[r] + kDataOffset) + e);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+  for (int r = 0; r < WORLD; ++r) {
+    const uint32_t w[4] = {v[r].x, v[r].y, v[r].z, v[r].w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[2 * j] += bf_lo(w[j]);
+      acc[2 * j + 1] += bf_hi(w[j]);
+    }
+  }
+}
+
+template <int WORLD>
+__global__ __launch_bounds__(kArThreads) void xgmi_one_shot_all_reduce_kernel(ArParams p) {
+  __shared__ float scratch[16];
+  Signal* self = reinterpret_cast<Signal*>(p.peers.base[p.rank]);
+  const uint32_t flag = self->flag[blockIdx.x] + 1;
+  const int64_t nvec = p.numel / 8;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kArThreads;
+  // phase 0: my copy
+  uint16_t* mine = reinterpret_cast<uint16_t*>(p.peers.base[p.rank] + kDataOffset);
+  if (p.epilogue == 0) {
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kArThreads + threadIdx.x; i < nvec; i += stride)
+      st16(mine + i * 8, ld16(p.inp + i * 8));
+  } else {
+    // row-wise ownership: the rows a workgroup will finish are the rows it publishes
+    for (int r = blockIdx.x; r < p.rows; r += gridDim.x)
+      for (int c = threadIdx.x * 8; c < p.hidden; c += kArThreads * 8)
+        st16(mine + static_cast<int64_t>(r) * p.hidden + c, ld16(p.inp + static_cast<int64_t>(r) * p.hidden + c));
+  }
+  flag_barrier(p, &Signal::start, flag);
+
+  if (p.epilogue == 0) {
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kArThreads + threadIdx.x; i < nvec; i += stride) {
+      float acc[8];
+      gather_sum<WORLD>(p, i * 8, acc);
+      U4 o;
+      o.x = pack_bf2(acc[0], acc[1]); o.y = pack_bf2(acc[2], acc[3]);
+      o.z = pack_bf2(acc[4], acc[5]); o.w = pack_bf2(acc[6], acc[7]);
+      st16(p.out + i * 8, o);
+    }
+  } else {
+    // h = bf16(sum);  t = h + residual (fp32);  residual <- bf16(t);  out = bf16(t * rsqrt(mean(t^2) + eps) * w)
+    constexpr int kMaxVec = 4;                    // hidden <= 512 threads * 8 * 4 = 16384
+    for (int r = blockIdx.x; r < p.rows; r += gridDim.x) {
+      float t[kMaxVec][8];
+      float sq = 0.f;
+#pragma unroll
+      for (int k = 0; k < kMaxVec; ++k) {
+        const int c = (k * kArThreads + threadIdx.x) * 8;
+        if (c < p.hidden) {
+          const int64_t e = static_cast<int64_t>(r) * p.hidden + c;
+          float acc[8];
+          gather_sum<WORLD>(p, e, acc);
+          const U4 rv = ld16(p.residual + e);
+          const uint32_t rw[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            t[k][2 * j] = rbf(acc[2 * j]) + bf_lo(rw[j]);
+            t[k][2 * j + 1] = rbf(acc[2 * j + 1]) + bf_hi(rw[j]);
+          }
+          U4 o;
+          o.x = pack_bf2(t[k][0], t[k][1]); o.y = pack_bf2(t[k][2], t[k][3]);
+          o.z = pack_bf2(t[k][4], t[k][5]); o.w = pack_bf2(t[k][6], t[k][7]);
+          st16(p.residual + e, o);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) sq += t[k][j] * t[k][j];
+        }
+      }
+      sq = block_sum(sq, scratch);
+      const float rs = 1.0f / sqrtf(sq / static_cast<float>(p.hidden) + p.eps);
+#pragma unroll
+      for (int k = 0; k < kMaxVec; ++k) {
+        const int c = (k * kArThreads + threadIdx.x) * 8;
+        if (c < p.hidden) {
+          const U4 wv = ld16(p.norm_w + c);
+          const uint32_t ww[4] = {wv.x, wv.y, wv.z, wv.w};
+          U4 o;
+          o.x = pack_bf2((t[k][0] * rs) * bf_lo(ww[0]), (t[k][1] * rs) * bf_hi(ww[0]));
+          o.y = pack_bf2((t[k][2] * rs) * bf_lo(ww[1]), (t[k][3] * rs) * bf_hi(ww[1]));
+          o.z = pack_bf2((t[k][4] * rs) * bf_lo(ww[2]), (t[k][5] * rs) * bf_hi(ww[2]));
+          o.w = pack_bf2((t[k][6] * rs) * bf_lo(ww[3]), (t[k][7] * rs) * bf_hi(ww[3]));
+          st16(p.out + static_cast<int64_t>(r) * p.hidden + c, o);
+        }
+      }
+    }
+  }
+  flag_barrier(p, &Signal::end, flag);
+  if (threadIdx.x == 0) self->flag[blockIdx.x] = flag;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t sgl_amd_xgmi_workspace_bytes(int64_t max_message_bytes) { return kDataOffset + ((max_message_bytes + 255) / 256) * 256; }
+
+int sgl_amd_xgmi_max_world(void) { return kMaxWorld; }
+
+int sgl_amd_xgmi_alloc(int64_t bytes, void** out_ptr) {
+  SGL_CLEAR_STALE_ERROR();
+  SGL_CHECK_ARG(bytes >= kDataOffset && out_ptr, "xgmi_alloc: need at least %lld bytes", (long long)kDataOffset);
+  void* ptr = nullptr;
+  hipError_t e = hipExtMallocWithFlags(&ptr, static_cast<size_t>(bytes), hipDeviceMallocUncached);
+  SGL_CHECK_ARG(e == hipSuccess, "xgmi_alloc: hipExtMallocWithFlags(%lld, uncached): %s", (long long)bytes, hipGetErrorString(e));
+  e = hipMemset(ptr, 0, static_cast<size_t>(bytes));
+  SGL_CHECK_ARG(e == hipSuccess, "xgmi_alloc: hipMemset: %s", hipGetErrorString(e));
+  e = hipDeviceSynchronize();
+  SGL_CHECK_ARG(e == hipSuccess, "xgmi_alloc: sync: %s", hipGetErrorString(e));
+  *out_ptr = ptr;
+  return 0;
+}
+
+int sgl_amd_xgmi_free(void* ptr) {
+  SGL_CLEAR_STALE_ERROR();
+  if (!ptr) return 0;
+  hipError_t e = hipFree(ptr);
+  SGL_CHECK_ARG(e == hipSuccess, "xgmi_free: %s", hipGetErrorString(e));
+  return 0;
+}
+
+int sgl_amd_xgmi_timed_out(const void* workspace) {
+  SGL_CLEAR_STALE_ERROR();
+  SGL_CHECK_ARG(workspace, "xgmi_timed_out: null workspace");
+  uint32_t v = 0;
+  hipError_t e = hipMemcpy(&v, static_cast<const unsigned char*>(workspace) + offsetof(Signal, timed_out), 4, hipMemcpyDeviceToHost);
+  SGL_CHECK_ARG(e == hipSuccess, "xgmi_timed_out: %s", hipGetErrorString(e));
+  return static_cast<int>(v);
+}
+
+int sgl_amd_xgmi_ipc_handle_bytes(void) { return static_cast<int>(sizeof(hipIpcMemHandle_t)); }
+
+int sgl_amd_xgmi_ipc_get_handle(void* ptr, void* out_handle) {
+  SGL_CLEAR_STALE_ERROR();
+  SGL_CHECK_ARG(ptr && out_handle, "xgmi_ipc_get_handle: null argument");
+  hipIpcMemHandle_t h;
+  hipError_t e = hipIpcGetMemHandle(&h, ptr);
+  SGL_CHECK_ARG(e == hipSuccess, "xgmi_ipc_get_handle: %s (is HSA_ENABLE_IPC_MODE_LEGACY=0 exported?)", hipGetErrorString(e));
+  std::memcpy(out_handle, &h, sizeof(h));
+  return 0;
+}
+
+int sgl_amd_xgmi_ipc_open_handle(const void* handle, void** out_ptr) {
+  SGL_CLEAR_STALE_ERROR();
+  SGL_CHECK_ARG(handle && out_ptr, "xgmi_ipc_open_handle: null argument");
+  hipIpcMemHandle_t h;
+  std::memcpy(&h, handle, sizeof(h));
+  void* ptr = nullptr;
+  hipError_t e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
+  SGL_CHECK_ARG(e == hipSuccess, "xgmi_ipc_open_handle: %s", hipGetErrorString(e));
+  *out_ptr = ptr;
+  return 0;
+}
+
+int sgl_amd_xgmi_ipc_close_handle(void* ptr) {
+  SGL_CLEAR_STALE_ERROR();
+  if (!ptr) return 0;
+  hipError_t e = hipIpcCloseMemHandle(ptr);
+  SGL_CHECK_ARG(e == hipSuccess, "xgmi_ipc_close_handle: %s", hipGetErrorString(e));
+  return 0;
+}
+
+int sgl_amd_xgmi_one_shot_all_reduce(const void* inp, void* out, int64_t rows, int hidden, int rank, int world,
+                                     const void* const* peer_workspaces_host, int64_t workspace_bytes, int epilogue,
+                                     void* residual, const void* norm_weight, float eps, int num_blocks, void* stream) {
+  SGL_CLEAR_STALE_ERROR();
+  SGL_CHECK_ARG(world == 2 || world == 4 || world == 8, "xgmi_one_shot_all_reduce: world=%d (supported: 2, 4, 8)", world);
+  SGL_CHECK_ARG(rank >= 0 && rank < world && peer_workspaces_host, "xgmi_one_shot_all_reduce: bad rank / peers");
+  SGL_CHECK_ARG(rows >= 0 && hidden > 0 && hidden % 8 == 0, "xgmi_one_shot_all_reduce: hidden=%d must be a multiple of 8", hidden);
+  if (rows == 0) return 0;
+  const int64_t numel = rows * hidden;
+  SGL_CHECK_ARG(kDataOffset + numel * 2 <= workspace_bytes, "xgmi_one_shot_all_reduce: message of %lld bytes does not fit the %lld-byte workspace",
+                (long long)(numel * 2), (long long)workspace_bytes);
+  SGL_CHECK_ARG(epilogue == 0 || epilogue == 1, "xgmi_one_shot_all_reduce: epilogue must be 0 (none) or 1 (add_rmsnorm)");
+  SGL_CHECK_ARG(epilogue == 0 || (residual && norm_weight && hidden <= kArThreads * 8 * 4), "xgmi_one_shot_all_reduce: add_rmsnorm needs residual, norm_weight and hidden <= %d", kArThreads * 8 * 4);
+  SGL_CHECK_ARG(inp && out, "xgmi_one_shot_all_reduce: null tensor");
+  ArParams p{};
+  for (int r = 0; r < world; ++r) {
+    SGL_CHECK_ARG(peer_workspaces_host[r], "xgmi_one_shot_all_reduce: peer %d is not mapped", r);
+    p.peers.base[r] = static_cast<unsigned char*>(const_cast<void*>(peer_workspaces_host[r]));
+  }
+  p.inp = static_cast<const uint16_t*>(inp); p.out = static_cast<uint16_t*>(out);
+  p.residual = static_cast<uint16_t*>(residual); p.norm_w = static_cast<const uint16_t*>(norm_weight);
+  p.numel = numel; p.rows = static_cast<int>(rows); p.hidden = hidden; p.rank = rank; p.world = world; p.epilogue = epilogue; p.eps = eps;
+  int blocks = num_blocks;
+  if (blocks <= 0) {
+    // enough workgroups to keep ~7 links busy, never more than the flag table has rows
+    const int64_t want = epilogue ? rows : (numel / 8 + kArThreads * 2 - 1) / (kArThreads * 2);
+    blocks = static_cast<int>(want < 1 ? 1 : (want > 32 ? 32 : want));
+  }
+  SGL_CHECK_ARG(blocks >= 1 && blocks <= kMaxBlocks, "xgmi_one_shot_all_reduce: num_blocks=%d (1..%d)", blocks, kMaxBlocks);
+  hipStream_t st = as_stream(stream);
+  switch (world) {
+    case 2: hipLaunchKernelGGL(xgmi_one_shot_all_reduce_kernel<2>, dim3(blocks), dim3(kArThreads), 0, st, p); break;
+    case 4: hipLaunchKernelGGL(xgmi_one_shot_all_reduce_kernel<4>, dim3(blocks), dim3(kArThreads), 0, st, p); break;
+    default: hipLaunchKernelGGL(xgmi_one_shot_all_reduce_kernel<8>, dim3(blocks), dim3(kArThreads), 0, st, p); break;
+  }
+  SGL_CHECK_LAUNCH("xgmi_one_shot_all_reduce");
+  return 0;
+}
+
+}  // extern "C"

@@ -14,13 +14,18 @@ import torch
 import torch.distributed as dist
 
 _TP_GROUP = None
+_TP_CPU_GROUP = None      # gloo group of the same ranks: control-plane exchanges (IPC handles), like the reference's cpu_group
 _TP_SIZE = 1
 _TP_RANK = 0
+_XGMI = None              # one-shot all-reduce communicator (decode-sized messages), None = RCCL only
 
 
-def init_distributed_environment(backend: Optional[str] = None, tp_size: Optional[int] = None) -> None:
-    """Read RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract)."""
-    global _TP_GROUP, _TP_SIZE, _TP_RANK
+def init_distributed_environment(backend: Optional[str] = None, tp_size: Optional[int] = None,
+                                 device_index: Optional[int] = None, xgmi_all_reduce: Optional[bool] = None) -> None:
+    """Read RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract).  `device_index` overrides LOCAL_RANK
+    (tests put two ranks on one GPU); `xgmi_all_reduce` forces the one-shot communicator on / off (default: on for
+    GPU groups of 2 / 4 / 8 ranks unless SGLANG_AMD_XGMI_AR=0)."""
+    global _TP_GROUP, _TP_SIZE, _TP_RANK, _TP_CPU_GROUP, _XGMI
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if world == 1:
@@ -29,7 +34,7 @@ def init_distributed_environment(backend: Optional[str] = None, tp_size: Optiona
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if torch.cuda.is_available():
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", rank)))
+        torch.cuda.set_device(device_index if device_index is not None else int(os.environ.get("LOCAL_RANK", rank)))
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -39,16 +44,35 @@ def init_distributed_environment(backend: Optional[str] = None, tp_size: Optiona
     for g0 in range(0, world, _TP_SIZE):
         ranks = list(range(g0, g0 + _TP_SIZE))
         grp = dist.new_group(ranks) if _TP_SIZE != world else dist.group.WORLD
+        cpu_grp = dist.new_group(ranks, backend="gloo") if backend != "gloo" else grp
         if rank in ranks:
             _TP_GROUP = grp
+            _TP_CPU_GROUP = cpu_grp
             _TP_RANK = rank - g0
+    if xgmi_all_reduce is None:
+        xgmi_all_reduce = (torch.cuda.is_available() and _TP_SIZE in (2, 4, 8)
+                           and os.environ.get("SGLANG_AMD_XGMI_AR", "1") != "0")
+    if xgmi_all_reduce:
+        from .xgmi_all_reduce import XgmiAllReduce
+
+        _XGMI = XgmiAllReduce(_TP_CPU_GROUP, _TP_RANK, _TP_SIZE, torch.device("cuda", torch.cuda.current_device()))
 
 
 def destroy() -> None:
-    global _TP_GROUP, _TP_SIZE, _TP_RANK
+    global _TP_GROUP, _TP_SIZE, _TP_RANK, _TP_CPU_GROUP, _XGMI
+    if _XGMI is not None:
+        torch.cuda.synchronize()
+        if dist.is_initialized():
+            dist.barrier(group=_TP_CPU_GROUP)        # nobody unmaps a workspace a peer's kernel may still read
+        _XGMI.close()
+        _XGMI = None
     if dist.is_initialized():
         dist.destroy_process_group()
-    _TP_GROUP, _TP_SIZE, _TP_RANK = None, 1, 0
+    _TP_GROUP, _TP_CPU_GROUP, _TP_SIZE, _TP_RANK = None, None, 1, 0
+
+
+def get_xgmi_all_reduce():
+    return _XGMI
 
 
 def get_tensor_model_parallel_world_size() -> int:
@@ -64,12 +88,52 @@ def get_tp_group():
 
 
 def tensor_model_parallel_all_reduce(x: torch.Tensor) -> torch.Tensor:
-    """SUM over the TP ranks (communication_op.py:18).  RCCL enqueues on its own
-    stream behind an event on the current one, i.e. on a side HIP stream."""
+    """SUM over the TP ranks (communication_op.py:18, parallel_state.py:648-758 dispatch): decode-sized bf16
+    messages take the one-shot xGMI kernel (one launch on the current stream, graph-capturable), everything else
+    RCCL (which enqueues on its own stream behind an event on the current one)."""
     if _TP_SIZE == 1:
         return x
+    if _XGMI is not None and _XGMI.should_use(x):
+        return _XGMI.all_reduce(x)
     dist.all_reduce(x, group=_TP_GROUP)
     return x
+
+
+def tensor_model_parallel_all_reduce_add_rmsnorm(x: torch.Tensor, residual: torch.Tensor, norm_weight: torch.Tensor,
+                                                 eps: float) -> torch.Tensor:
+    """RMSNorm(all_reduce(x), residual) -- the pair that follows every row-parallel projection of a decoder layer
+    (llama.py:341-370 through LayerCommunicator).  residual is updated in place, the normed activations returned.
+    With the one-shot communicator this is ONE kernel (sum + residual add + norm in the all-reduce's epilogue)."""
+    from .. import kernels
+
+    if _TP_SIZE > 1 and _XGMI is not None and _XGMI.should_use(x) and residual.is_contiguous():
+        return _XGMI.all_reduce(x, residual=residual, norm_weight=norm_weight, eps=eps)
+    x = tensor_model_parallel_all_reduce(x)
+    kernels.fused_add_rmsnorm(x, residual, norm_weight, eps)
+    return x
+
+
+def row_parallel_linear(x: torch.Tensor, weight: torch.Tensor, min_rows_per_chunk: int = 1024, max_chunks: int = 4
+                        ) -> torch.Tensor:
+    """all_reduce(x @ weight^T) for a prefill-sized row-parallel projection with the collective OVERLAPPED with the
+    matmul: the rows are cut into up to `max_chunks` pieces, piece i's RCCL all-reduce runs on RCCL's own HIP stream
+    (async_op) while piece i+1's GEMM runs on the compute stream; the compute stream waits for the collectives only
+    at the end.  xGMI is point-to-point (7 links per GPU), so a 100 MB all-reduce is link-bound for about as long as
+    the GEMM that produced it takes -- hiding it is worth one extra GEMM launch per piece."""
+    rows = x.shape[0]
+    n = min(max_chunks, rows // max(1, min_rows_per_chunk))
+    if _TP_SIZE == 1 or n <= 1:
+        return tensor_model_parallel_all_reduce(torch.nn.functional.linear(x, weight))
+    out = torch.empty((rows, weight.shape[0]), dtype=x.dtype, device=x.device)
+    step = (rows + n - 1) // n
+    works = []
+    for a in range(0, rows, step):
+        b = min(rows, a + step)
+        torch.matmul(x[a:b], weight.t(), out=out[a:b])
+        works.append(dist.all_reduce(out[a:b], group=_TP_GROUP, async_op=True))
+    for w in works:
+        w.wait()
+    return out
 
 
 def tensor_model_parallel_all_gather(x: torch.Tensor, dim: int = -1) -> torch.Tensor:
@@ -77,6 +141,13 @@ def tensor_model_parallel_all_gather(x: torch.Tensor, dim: int = -1) -> torch.Te
         return x
     if dim < 0:
         dim += x.dim()
+    if x.is_cuda and dist.get_backend(_TP_GROUP) == "gloo":
+        # gloo moves device tensors only for broadcast / all_reduce: stage through the host (two ranks on one GPU in
+        # the single-device tests; a real node runs RCCL)
+        xc = x.cpu()
+        parts = [torch.empty_like(xc) for _ in range(_TP_SIZE)]
+        dist.all_gather(parts, xc.contiguous(), group=_TP_GROUP)
+        return torch.cat(parts, dim=dim).to(x.device)
     parts = [torch.empty_like(x) for _ in range(_TP_SIZE)]
     dist.all_gather(parts, x.contiguous(), group=_TP_GROUP)
     return torch.cat(parts, dim=dim)

@@ -111,6 +111,14 @@ class Linear(nn.Module):
             return kernels.wstream_gemm(x, self.weight.data, self.bias.data if self.bias is not None else None)
         return F.linear(x, self.weight, self.bias)
 
+    def forward_all_reduce(self, x: torch.Tensor) -> torch.Tensor:
+        """RowParallelLinear.forward (linear.py): all_reduce(self(x)); prefill-sized inputs overlap the collective with
+        the matmul piecewise (parallel_state.row_parallel_linear)."""
+        if (ps.get_tensor_model_parallel_world_size() > 1 and self.bias is None and x.dim() == 2 and x.shape[0] >= 2048
+                and not self.streams(x)):
+            return ps.row_parallel_linear(x, self.weight)
+        return ps.tensor_model_parallel_all_reduce(self.forward(x))
+
     def forward_add_rmsnorm(self, x: torch.Tensor, residual: torch.Tensor, norm: RMSNorm) -> torch.Tensor:
         """norm(self(x), residual) with the residual add + RMSNorm run by the GEMM's split-K combine
         kernel: `residual` is updated in place, the normed activations are returned."""
@@ -147,11 +155,14 @@ class LlamaMLP(nn.Module):
         return self.act_fn(self.gate_up_proj(x))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        x = self.down_proj(self.gate_up_act(x))
-        return ps.tensor_model_parallel_all_reduce(x)
+        return self.down_proj.forward_all_reduce(self.gate_up_act(x))
 
-    def forward_fused_norm(self, x: torch.Tensor, residual: torch.Tensor, next_norm: RMSNorm) -> torch.Tensor:
-        """TP=1 decode: down_proj + residual add + the NEXT norm in one GEMM + combine pair."""
+    def forward_fused_norm(self, x: torch.Tensor, residual: torch.Tensor, next_norm: RMSNorm, tp_size: int = 1) -> torch.Tensor:
+        """Decode: down_proj + residual add + the NEXT norm.  TP=1: one GEMM + combine pair; TP>1: the GEMM, then the
+        one-shot xGMI all-reduce with the add + norm in its epilogue."""
+        if tp_size > 1:
+            y = self.down_proj(self.gate_up_act(x))
+            return ps.tensor_model_parallel_all_reduce_add_rmsnorm(y, residual, next_norm.weight.data, next_norm.variance_epsilon)
         return self.down_proj.forward_add_rmsnorm(self.gate_up_act(x), residual, next_norm)
 
 
@@ -209,8 +220,8 @@ class LlamaAttention(nn.Module):
                                          forward_batch.out_cache_loc)
             attn_output = self.attn(q, None, None, forward_batch, save_kv_cache=False)
             if fused_norm is not None:
-                return self.o_proj.forward_add_rmsnorm(attn_output, fused_norm[0], fused_norm[1])
-            return ps.tensor_model_parallel_all_reduce(self.o_proj(attn_output))
+                return self._o_proj_fused_norm(attn_output, fused_norm)
+            return self.o_proj.forward_all_reduce(attn_output)
         qkv = self.qkv_proj(hidden_states)
         q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
         # rope + KV-row scatter in one kernel (rotary_embedding/base.py:385-417), then attention reads the pool
@@ -219,9 +230,15 @@ class LlamaAttention(nn.Module):
             cache_loc=forward_batch.out_cache_loc))
         attn_output = self.attn(q, k, v, forward_batch, save_kv_cache=False)
         if fused_norm is not None:
-            return self.o_proj.forward_add_rmsnorm(attn_output, fused_norm[0], fused_norm[1])
-        out = self.o_proj(attn_output)
-        return ps.tensor_model_parallel_all_reduce(out)
+            return self._o_proj_fused_norm(attn_output, fused_norm)
+        return self.o_proj.forward_all_reduce(attn_output)
+
+    def _o_proj_fused_norm(self, attn_output: torch.Tensor, fused_norm) -> torch.Tensor:
+        residual, norm = fused_norm
+        if ps.get_tensor_model_parallel_world_size() > 1:
+            return ps.tensor_model_parallel_all_reduce_add_rmsnorm(self.o_proj(attn_output), residual, norm.weight.data,
+                                                                   norm.variance_epsilon)
+        return self.o_proj.forward_add_rmsnorm(attn_output, residual, norm)
 
 
 class LlamaDecoderLayer(nn.Module):
@@ -252,8 +269,13 @@ class LlamaDecoderLayer(nn.Module):
 
     def fusable(self, x: torch.Tensor, tp_size: int) -> bool:
         """The decode form below needs no collective between a projection and the norm behind it."""
-        return (not OPERATOR_SURFACE_ONLY and tp_size == 1 and isinstance(self.mlp, LlamaMLP) and self.self_attn.o_proj.streams(x)
-                and kernels.wstream_preferred(x.shape[0], *self.mlp.down_proj.weight.shape) and x.shape[1] <= 16384)
+        if OPERATOR_SURFACE_ONLY or not isinstance(self.mlp, LlamaMLP) or x.shape[1] > 16384:
+            return False
+        if tp_size > 1:     # the add + norm ride in the one-shot all-reduce's epilogue
+            xg = ps.get_xgmi_all_reduce()
+            return xg is not None and x.is_cuda and x.dtype == BF and x.shape[0] * x.shape[1] * 2 <= xg.max_bytes
+        return (self.self_attn.o_proj.streams(x)
+                and kernels.wstream_preferred(x.shape[0], *self.mlp.down_proj.weight.shape))
 
     def forward_decode_fused(self, positions, normed: torch.Tensor, forward_batch, residual: torch.Tensor,
                              next_norm: RMSNorm) -> torch.Tensor:
@@ -261,7 +283,7 @@ class LlamaDecoderLayer(nn.Module):
         residual-add + RMSNorm executed by the preceding projection's combine kernel.  `normed` is
         this layer's input_layernorm output; returns next_norm's output, residual updated in place."""
         x = self.self_attn(positions, normed, forward_batch, fused_norm=(residual, self.post_attention_layernorm))
-        return self.mlp.forward_fused_norm(x, residual, next_norm)
+        return self.mlp.forward_fused_norm(x, residual, next_norm, ps.get_tensor_model_parallel_world_size())
 
 
 class CausalLM(nn.Module):

@@ -40,6 +40,17 @@ def _worker(rank: int, world: int, port: int, name: str, q):
         assert torch.equal(y, torch.full((3, 4), float(sum(range(1, world + 1))), dtype=torch.bfloat16))
         g = ps.tensor_model_parallel_all_gather(torch.full((2, 3), float(rank)), dim=-1)
         assert g.shape == (2, 3 * world) and all(float(g[0, 3 * r]) == r for r in range(world))
+        # row-parallel projection with the collective overlapped piecewise (async all-reduce per row chunk while the
+        # next chunk's matmul runs): same result as matmul + one all-reduce
+        gen = torch.Generator().manual_seed(3)
+        wfull = (torch.randn((24, 64), generator=gen) * 0.1).to(torch.bfloat16)
+        xfull = (torch.randn((300, 64), generator=gen)).to(torch.bfloat16)
+        wk, xk = wfull[:, 32 * rank: 32 * rank + 32].contiguous(), xfull[:, 32 * rank: 32 * rank + 32].contiguous()
+        plain = ps.tensor_model_parallel_all_reduce(torch.nn.functional.linear(xk, wk))
+        piecewise = ps.row_parallel_linear(xk, wk, min_rows_per_chunk=64, max_chunks=4)
+        assert torch.equal(plain, piecewise) and piecewise.shape == (300, 24)
+        # the fused form falls back to all-reduce + the norm kernel's arithmetic when no one-shot communicator exists
+        assert ps.get_xgmi_all_reduce() is None
 
         cfg = CONFIGS[name]
         shard = CausalLM(cfg, torch.device("cpu"), "cpu", tp_rank=rank, tp_size=world)

@@ -1,0 +1,193 @@
+"""The one-shot xGMI all-reduce with TWO PROCESSES SHARING GPU 0: the single-GPU lease still exercises everything
+that is new in the communicator -- workspace export / import over hipIpcMemHandle, the cross-process flag barrier,
+the rank-ordered fp32 sum, the fused residual-add + RMSNorm epilogue, hipGraph capture + replay of the launch,
+and the TP=2 decoder layer that uses it -- only the wire (xGMI instead of local HBM) differs on an 8-GPU node.
+The control plane is a gloo group (RCCL refuses two ranks on one device)."""
+import os
+import socket
+import sys
+import traceback
+from pathlib import Path
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, case, q):
+    try:
+        sys.path.insert(0, str(ROOT))
+        os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1",
+                           "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        import torch.distributed as dist
+
+        from sglang_amd.distributed import parallel_state as ps
+
+        ps.init_distributed_environment(backend="gloo", device_index=0, xgmi_all_reduce=True)
+        out = globals()["_case_" + case](rank, world, ps, dist)
+        torch.cuda.synchronize()
+        xg = ps.get_xgmi_all_reduce()
+        assert not xg.timed_out(), "a flag wait gave up"
+        dist.barrier()
+        ps.destroy()
+        q.put((rank, "ok", out))
+    except Exception:
+        q.put((rank, "error", traceback.format_exc()))
+
+
+def _run(case, world=2, timeout=240):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    try:
+        for _ in range(world):
+            rank, status, payload = q.get(timeout=timeout)
+            assert status == "ok", f"rank {rank}:\n{payload}"
+            res[rank] = payload
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    return res
+
+
+def _inputs(rank, world, rows, hidden, seed):
+    """Every rank can build every rank's input (seeded), so each checks the full sum locally."""
+    xs = []
+    for r in range(world):
+        g = torch.Generator(device="cpu").manual_seed(1000 * seed + r)
+        xs.append((torch.randn((rows, hidden), generator=g) * 0.5).to(torch.bfloat16))
+    return xs
+
+
+def _case_sum(rank, world, ps, dist):
+    dev = torch.device("cuda", 0)
+    xg = ps.get_xgmi_all_reduce()
+    worst = 0.0
+    for i, (rows, hidden) in enumerate([(1, 8), (64, 4096), (64, 8192), (7, 1024), (128, 8192), (3, 4104)]):
+        xs = _inputs(rank, world, rows, hidden, i)
+        want = torch.stack([x.float() for x in xs]).sum(0).to(torch.bfloat16)       # fp32 sum in rank order, one rounding
+        for rep in range(3):                                                         # flags advance call after call
+            got = ps.tensor_model_parallel_all_reduce(xs[rank].to(dev).clone())
+            assert xg.should_use(got) and torch.equal(got.cpu(), want), (rows, hidden, rep)
+    # above the one-shot limit: the group's own collective
+    big = torch.ones((1100, 1024), dtype=torch.bfloat16, device=dev)
+    assert not xg.should_use(big)
+    assert torch.equal(ps.tensor_model_parallel_all_reduce(big).cpu(), torch.full((1100, 1024), float(world)).to(torch.bfloat16))
+    return worst
+
+
+def _case_add_rmsnorm(rank, world, ps, dist):
+    from oracle import ops as oo
+
+    dev = torch.device("cuda", 0)
+    for i, (rows, hidden) in enumerate([(64, 4096), (5, 8192), (64, 896)]):
+        xs = _inputs(rank, world, rows, hidden, 10 + i)
+        g = torch.Generator().manual_seed(77 + i)
+        res0 = (torch.randn((rows, hidden), generator=g)).to(torch.bfloat16)
+        w = (1.0 + 0.1 * torch.randn(hidden, generator=g)).to(torch.bfloat16)
+        summed = torch.stack([x.float() for x in xs]).sum(0).to(torch.bfloat16)
+        want_out, want_res = oo.fused_add_rmsnorm(summed, res0, w, 1e-5)
+        res = res0.to(dev).clone()
+        out = ps.tensor_model_parallel_all_reduce_add_rmsnorm(xs[rank].to(dev), res, w.to(dev), 1e-5)
+        assert torch.equal(res.cpu(), want_res), "residual"
+        err = (out.cpu().float() - want_out.float()).abs()
+        # one bf16 ulp on a few elements (fp32 reduction order of the row's sum of squares)
+        assert float(err.max()) <= 2.0 ** -7 * float(want_out.float().abs().max()) and float((err > 0).float().mean()) < 0.01
+    return 0
+
+
+def _case_graph(rank, world, ps, dist):
+    """The launch has no host state: captured once, replayed with new inputs in the static buffer."""
+    dev = torch.device("cuda", 0)
+    rows, hidden = 64, 4096
+    static_in = torch.zeros((rows, hidden), dtype=torch.bfloat16, device=dev)
+    xg = ps.get_xgmi_all_reduce()
+    out = torch.empty_like(static_in)
+    xg.all_reduce(static_in, out)                      # warm-up outside the capture
+    torch.cuda.synchronize(); dist.barrier()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            xg.all_reduce(static_in, out)
+            xg.all_reduce(out, out)                    # two dependent collectives in one graph
+    torch.cuda.current_stream().wait_stream(s)
+    for i in range(4):
+        xs = _inputs(rank, world, rows, hidden, 20 + i)
+        static_in.copy_(xs[rank])
+        g.replay()
+        torch.cuda.synchronize()
+        once = torch.stack([x.float() for x in xs]).sum(0).to(torch.bfloat16)
+        twice = (once.float() * world).to(torch.bfloat16)
+        assert torch.equal(out.cpu(), twice), i
+    return 0
+
+
+def _case_tp2_engine(rank, world, ps, dist):
+    """A tiny Llama at TP=2 through the engine (radix-cached prefill + eager decode with the fused layer: the
+    add + norm run in the all-reduce's epilogue), each rank checking the gathered logits against the TP=1 oracle."""
+    from oracle.model import OracleLM
+    from sglang_amd.harness.engine import Engine, ModelRunner, Req
+    from sglang_amd.harness.models import CONFIGS, CausalLM
+    from oracle.model import weights_from_product_model
+
+    dev = torch.device("cuda", 0)
+    cfg = CONFIGS["tiny-llama"]
+    runner = ModelRunner(cfg, max_total_tokens=2048, max_running_requests=8, max_context_len=128, device=dev,
+                         init_device="cpu", use_graph=False)
+    assert runner.tp_size == 2 and runner.model.layers[0].fusable(torch.zeros((4, cfg.hidden_size), dtype=torch.bfloat16, device=dev), 2)
+    eng = Engine(runner)
+    eng.logits_trace = []
+    g = torch.Generator().manual_seed(5)
+    shared = torch.randint(0, cfg.vocab_size, (40,), generator=g).tolist()
+    prompts = [shared + torch.randint(0, cfg.vocab_size, (6,), generator=g).tolist() for _ in range(4)]
+    reqs = [Req(i, p, 4) for i, p in enumerate(prompts)]
+    eng.prefill(reqs[:1]); eng.prefill(reqs[1:])
+    for _ in range(3):
+        eng.decode_step()
+    eng.finish(list(eng.running))
+    outs = [q.output_ids for q in reqs]
+    full = CausalLM(cfg, torch.device("cpu"), "cpu")              # the unsharded weights (same seeds)
+    oracle = OracleLM(cfg, weights_from_product_model(full), compute_dtype=torch.float32)
+    _, ref = oracle.generate(prompts, 4, return_logits=True, forced=outs)
+    tr = eng.logits_trace
+    got = [torch.cat(tr[:2])] + tr[2:]
+    for a, b in zip(got, ref):
+        torch.testing.assert_close(a, b, atol=3e-2, rtol=3e-2)
+    return outs
+
+
+def test_one_shot_all_reduce_two_processes_one_gpu(device):
+    _run("sum")
+
+
+def test_all_reduce_with_add_rmsnorm_epilogue(device):
+    _run("add_rmsnorm")
+
+
+def test_all_reduce_records_into_a_hipgraph(device):
+    _run("graph")
+
+
+def test_tp2_engine_with_the_fused_all_reduce_layer(device):
+    res = _run("tp2_engine")
+    assert res[0] == res[1]                    # both ranks sampled the same tokens
