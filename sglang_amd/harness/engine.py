@@ -55,6 +55,12 @@ class Req:
     t_first_token: float = 0.0
     cached_tokens: int = 0
     fill_len: int = 0            # chunked prefill: tokens of the prompt committed so far (0 = not truncated)
+    retracted_output_ids: List[int] = field(default_factory=list)   # outputs folded into the prompt by a retraction
+
+    @property
+    def all_output_ids(self) -> List[int]:
+        """Every token generated for this request, across retractions."""
+        return self.retracted_output_ids + self.output_ids
 
     @property
     def origin_array(self):
@@ -149,15 +155,22 @@ class Engine:
         self.r = runner
         self.device = runner.device
         self.running: List[Req] = []
+        self.waiting: List[Req] = []          # retracted requests waiting to be prefilled again
         self.stats: Dict[str, float] = {}
         self.logits_trace: Optional[List[torch.Tensor]] = None   # tests: set to [] to record every step's logits
         self.logits_device_trace: Optional[List[torch.Tensor]] = None   # same, kept on the device in the model dtype
+        self.logits_by_req: Optional[Dict[int, List[torch.Tensor]]] = None  # tests: {} -> per request, one row per sampled token
 
-    def _record_logits(self, logits) -> None:
+    def _record_logits(self, logits, reqs=None, sampled=None) -> None:
         if self.logits_trace is not None:
             self.logits_trace.append(logits.next_token_logits.float().cpu())
         if self.logits_device_trace is not None:
             self.logits_device_trace.append(logits.next_token_logits.clone())   # the graph's output buffer is reused
+        if self.logits_by_req is not None and reqs is not None:
+            rows = logits.next_token_logits.float().cpu()
+            for i, q in enumerate(reqs):
+                if sampled is None or sampled[i]:            # a truncated chunk samples nothing
+                    self.logits_by_req.setdefault(q.rid, []).append(rows[i])
 
     # ---- KV slot allocation with eviction (allocation.py:150-279 alloc_token_slots) ----
     def _alloc_token_slots(self, n: int) -> torch.Tensor:
@@ -221,7 +234,7 @@ class Engine:
                                    attn_backend=r.attn_backend, extend_prefix_lens_cpu=prefix_lens,
                                    extend_seq_lens_cpu=extend_lens, sampling_info=sampling_info)
         logits = r.forward(fb)
-        self._record_logits(logits)
+        self._record_logits(logits, reqs)
         next_ids = r.sample(logits, fb)
         ids_cpu = next_ids.tolist()                  # the scheduler's one sync per step
         now = time.perf_counter()
@@ -328,7 +341,7 @@ class Engine:
                                    attn_backend=r.attn_backend, extend_prefix_lens_cpu=prefix_lens,
                                    extend_seq_lens_cpu=extend_lens, sampling_info=sampling_info)
         logits = r.forward(fb)
-        self._record_logits(logits)
+        self._record_logits(logits, reqs, [end >= len(q.origin_input_ids) for q, end in zip(reqs, ends)])
         ids_cpu = r.sample(logits, fb).tolist()
         now = time.perf_counter()
         for q, end, t in zip(reqs, ends, ids_cpu):
@@ -345,6 +358,8 @@ class Engine:
     # ---- decode (scheduler.py:3566 update_running_batch + schedule_batch.py:3060) ----
     def decode_step(self, sampling_info: Optional[SamplingBatchInfo] = None) -> torch.Tensor:
         r, dev, ps_ = self.r, self.device, self.r.page_size
+        if not self.check_decode_mem():
+            self.waiting.extend(self.retract_decode())
         reqs = self.running
         bs = len(reqs)
         st = self._decode_state
@@ -375,7 +390,7 @@ class Engine:
         if r.graph_runner is None or not r.graph_runner.can_run(bs):
             fb.positions = kernels.clamp_position(fb.seq_lens)
         logits = r.forward(fb)
-        self._record_logits(logits)
+        self._record_logits(logits, st["reqs"])
         next_ids = r.sample(logits, fb)
         st["last_ids"] = next_ids.to(torch.int64)
         # token hand-off to the host: an async copy into pinned memory + an event, so that the scheduler can
@@ -425,6 +440,107 @@ class Engine:
             for q, t in zip(st["reqs"], host.tolist()):
                 q.output_ids.append(t)
             st["free_host"].append(host)
+
+    # ---- retraction under pool pressure (schedule_batch.py:2825-2925 retract_decode, mem_cache/common.py:198) ----
+    def new_tokens_required_next_decode(self) -> int:
+        """schedule_batch.py:2791-2803: one slot per request, a whole page when its last page is full."""
+        ps_ = self.r.page_size
+        return sum(1 for q in self.running if (q.seqlen - 1) % ps_ == 0) * ps_
+
+    def check_decode_mem(self) -> bool:
+        alloc, tree = self.r.token_to_kv_pool_allocator, self.r.tree_cache
+        return alloc.available_size() + tree.evictable_size() >= self.new_tokens_required_next_decode()
+
+    def retract_decode(self) -> List[Req]:
+        """Not enough KV slots for the next decode step even after evicting the whole tree: give up the requests that
+        are cheapest to redo -- fewest generated tokens first, longer prompts first among equals (the reference's
+        (len(output_ids), -len(origin_input_ids)) order, popped from the end) -- until the rest fits; always keep one.
+        A retracted request's KV is freed without inserting it into the tree ("we need the space instantly"), its
+        generated tokens become part of its prompt, and it waits in `self.waiting` to be prefilled again."""
+        self.flush_decode_outputs()
+        order = sorted(range(len(self.running)), key=lambda i: (len(self.running[i].output_ids),
+                                                                 -len(self.running[i].origin_input_ids)), reverse=True)
+        tree, pool, alloc = self.r.tree_cache, self.r.req_to_token_pool, self.r.token_to_kv_pool_allocator
+        retracted: List[Req] = []
+        first = True
+        while first or not self._fits([self.running[i] for i in order]):
+            if len(order) == 1:
+                break
+            first = False
+            q = self.running[order.pop()]
+            tree.cache_finished_req(q, is_insert=False, kv_len_to_handle=q.seqlen - 1)
+            pool.free(q)
+            q.retracted_output_ids += q.output_ids
+            q.origin_input_ids = list(q.origin_input_ids) + q.output_ids
+            q.max_new_tokens -= len(q.output_ids)
+            q.output_ids = []
+            q.prefix_indices, q.last_node, q.cache_protected_len, q.fill_len = None, None, 0, 0
+            retracted.append(q)
+        keep = sorted(order)
+        self.running = [self.running[i] for i in keep]
+        self._decode_state = None
+        self.stats["retracted"] = self.stats.get("retracted", 0) + len(retracted)
+        return retracted
+
+    def _fits_with(self, q: Req) -> bool:
+        """Room to prefill a waiting request AND run the next decode step of everyone (PrefillAdder's budget check)."""
+        alloc, tree = self.r.token_to_kv_pool_allocator, self.r.tree_cache
+        need = len(q.origin_input_ids) + self.new_tokens_required_next_decode() + len(self.running) + 1
+        return alloc.available_size() + tree.evictable_size() >= need and self.r.req_to_token_pool.available_size() > 0
+
+    def _fits(self, reqs: Sequence[Req]) -> bool:
+        alloc, tree, ps_ = self.r.token_to_kv_pool_allocator, self.r.tree_cache, self.r.page_size
+        need = sum(1 for q in reqs if (q.seqlen - 1) % ps_ == 0) * ps_
+        return alloc.available_size() + tree.evictable_size() >= need
+
+    # ---- mixed batch (schedule_batch.py:2758-2789 mix_with_running, ForwardMode.MIXED) ----
+    def mixed_step(self, new_reqs: Sequence[Req], sampling_info: Optional[SamplingBatchInfo] = None) -> None:
+        """One forward that prefills `new_reqs` AND advances every running request by one token: the running ones join
+        the extend batch as extends of length 1 over their cached prefix (prefix_len = tokens with KV, input = their
+        last sampled token, one new slot each) -- the reference's chunked-prefill "mixed" mode."""
+        assert self.r.page_size == 1, "mixed batches are wired for page_size 1"
+        r, dev = self.r, self.device
+        tree = r.tree_cache
+        self._retire_decode_state()
+        run = list(self.running)
+        for q in new_reqs:
+            self._match_and_lock(q)
+        if r.req_to_token_pool.alloc(list(new_reqs)) is None:
+            raise RuntimeError("out of request slots")
+        reqs = list(new_reqs) + run
+        prefix_lens = [int(q.prefix_indices.numel()) for q in new_reqs] + [q.seqlen - 1 for q in run]
+        seq_lens = [len(q.origin_input_ids) for q in new_reqs] + [q.seqlen for q in run]
+        extend_lens = [s - p for s, p in zip(seq_lens, prefix_lens)]
+        T = sum(extend_lens)
+        out_cache_loc = self._alloc_token_slots(T)
+        req_pool_cpu = torch.tensor([q.req_pool_idx for q in reqs], dtype=torch.int64)
+        prefix_cpu, seq_cpu, ext_cpu = (torch.tensor(v, dtype=torch.int64) for v in (prefix_lens, seq_lens, extend_lens))
+        req_pool_dev = req_pool_cpu.to(dev, non_blocking=True)
+        prefix_dev, seq_dev, ext_dev = (t.to(dev, non_blocking=True) for t in (prefix_cpu, seq_cpu, ext_cpu))
+        # new requests: prefix slots come from the tree; running ones already have their row (prefix pointer 0 = keep)
+        ptrs = [q.prefix_indices.data_ptr() if q.prefix_indices.numel() else 0 for q in new_reqs] + [0] * len(run)
+        kernels.write_req_to_token(r.req_to_token_pool.req_to_token, req_pool_dev,
+                                   torch.tensor(ptrs, dtype=torch.int64).to(dev, non_blocking=True), prefix_dev,
+                                   seq_dev, ext_dev, out_cache_loc)
+        ids = [t for q, p in zip(new_reqs, prefix_lens) for t in q.origin_input_ids[p:]] + [q.output_ids[-1] for q in run]
+        input_ids = torch.tensor(ids, dtype=torch.int64).to(dev, non_blocking=True)
+        fb = ForwardBatch.init_new(forward_mode=ForwardMode.MIXED, input_ids=input_ids, req_pool_indices=req_pool_dev,
+                                   seq_lens=seq_dev.to(torch.int32), out_cache_loc=out_cache_loc, seq_lens_cpu=seq_cpu,
+                                   req_to_token_pool=r.req_to_token_pool, token_to_kv_pool=r.token_to_kv_pool,
+                                   attn_backend=r.attn_backend, extend_prefix_lens_cpu=prefix_lens,
+                                   extend_seq_lens_cpu=extend_lens, sampling_info=sampling_info)
+        logits = r.forward(fb)
+        self._record_logits(logits, reqs)
+        ids_cpu = r.sample(logits, fb).tolist()
+        now = time.perf_counter()
+        for q, t in zip(reqs, ids_cpu):
+            if q in run:
+                q.output_ids.append(int(t))
+                continue
+            q.t_first_token = now
+            tree.cache_unfinished_req(q)               # fill_ids = prompt only: the new token has no KV yet
+            q.output_ids.append(int(t))
+            self.running.append(q)
 
     # ---- finish (batch_result_processor.py:863 -> mem_cache/common.py:198 release_kv_cache) ----
     def finish(self, reqs: Sequence[Req]) -> None:

@@ -212,3 +212,112 @@ def test_one_llama3_8b_layer_at_the_bench_batch_matches_oracle(device):
         top2 = ref.topk(2, dim=-1).values
         clear = (top2[:, 0] - top2[:, 1]) > 0.15
         assert torch.equal(got.argmax(-1)[clear], ref.argmax(-1)[clear]), f"step {step}: arg-max on clear margins"
+
+
+# ---------------------------------------------------------------------------- section 8(f1): scheduler glue on the GPU
+def _oracle_rows(cfg, runner, prompts, outs, new_tokens):
+    oracle = OracleLM(cfg, weights_from_product_model(runner.model), compute_dtype=torch.float32,
+                      max_reqs=max(63, len(prompts)), num_slots=max(4096, sum(len(p) + new_tokens for p in prompts) + 64))
+    _, ref = oracle.generate(prompts, new_tokens, return_logits=True, forced=outs)
+    return ref                                              # ref[k][b] = logits of request b's k-th generated token
+
+
+def _check_rows(eng, reqs, ref, new_tokens):
+    for b, q in enumerate(reqs):
+        rows = eng.logits_by_req[q.rid]
+        assert len(rows) == new_tokens, (q.rid, len(rows))
+        for k, row in enumerate(rows):
+            torch.testing.assert_close(row, ref[k][b], atol=2e-2, rtol=2e-2, msg=f"request {q.rid} token {k}")
+
+
+@pytest.mark.parametrize("page_size,chunk", [(1, 48), (1, 17), (4, 32)])
+def test_chunked_prefill_on_the_gpu_matches_oracle(device, page_size, chunk):
+    """Engine.prefill_chunked (schedule_policy.py:1004-1200): prompts cut at a per-pass token budget, the truncated
+    request continuing first in the next pass over its own committed chunk (an extend with a prefix that is NOT a
+    radix hit of another request), then hipGraph decode."""
+    from sglang_amd.harness.engine import Req
+
+    cfg, runner, eng = _build("tiny-llama", device, True, page_size)
+    prompts = _shared_prefix_prompts(cfg, groups=2, per_group=2, shared=70, unique=9, seed=4) + \
+        [[(13 * j + 5) % cfg.vocab_size for j in range(131)]]
+    new_tokens = 5
+    eng.logits_by_req = {}
+    reqs = [Req(i, p, new_tokens) for i, p in enumerate(prompts)]
+    eng.prefill_chunked(reqs, chunk)
+    assert len(eng.running) == len(reqs)
+    for _ in range(new_tokens - 1):
+        eng.decode_step()
+    eng.finish(list(eng.running))
+    _check_rows(eng, reqs, _oracle_rows(cfg, runner, prompts, [q.output_ids for q in reqs], new_tokens), new_tokens)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_mixed_batch_on_the_gpu_matches_oracle(device, use_graph):
+    """ForwardMode.MIXED (forward_batch_info.py:100-110): new requests are prefilled in the same forward that
+    advances the running ones by a token (1-token extends over their cached rows)."""
+    from sglang_amd.harness.engine import Req
+
+    cfg, runner, eng = _build("tiny-llama", device, use_graph)
+    prompts = _shared_prefix_prompts(cfg, groups=2, per_group=3, shared=50, unique=7, seed=9)
+    new_tokens = 7
+    eng.logits_by_req = {}
+    reqs = [Req(i, p, new_tokens) for i, p in enumerate(prompts)]
+    first, late = [reqs[0], reqs[1], reqs[3]], [reqs[2], reqs[4], reqs[5]]
+    eng.prefill(first)
+    eng.decode_step(); eng.flush_decode_outputs(lag=1)
+    eng.decode_step()
+    eng.mixed_step(late)
+    assert [q.cached_tokens for q in late] == [50, 50, 50]
+    while any(not q.finished() for q in eng.running):
+        done = [q for q in eng.running if q.finished()]
+        if done:
+            eng.finish(done)
+        eng.decode_step(); eng.flush_decode_outputs(lag=1)
+    eng.finish(list(eng.running))
+    assert all(len(q.output_ids) >= new_tokens for q in reqs)
+    outs = [q.output_ids[:new_tokens] for q in reqs]
+    ref = _oracle_rows(cfg, runner, prompts, outs, new_tokens)
+    for b, q in enumerate(reqs):
+        for k in range(new_tokens):
+            torch.testing.assert_close(eng.logits_by_req[q.rid][k], ref[k][b], atol=2e-2, rtol=2e-2, msg=f"request {q.rid} token {k}")
+
+
+def test_retraction_on_the_gpu_matches_oracle(device):
+    """A KV pool that cannot hold the whole batch's generation: requests are retracted (mem_cache/common.py:198,
+    schedule_batch.py:2825), re-prefilled over prompt + the tokens they had generated, and still produce the oracle's
+    logits at every generated position."""
+    from sglang_amd.harness.engine import Engine, ModelRunner, Req
+    from sglang_amd.harness.models import CONFIGS
+
+    cfg = CONFIGS["tiny-llama"]
+    lens = (40, 52, 46, 58)
+    new_tokens = 14
+    runner = ModelRunner(cfg, max_total_tokens=sum(lens) + 4 * 4, max_running_requests=4, max_context_len=128,
+                         device=device, init_device="cpu", use_graph=True, disable_radix_cache=True)
+    eng = Engine(runner)
+    rnd = random.Random(3)
+    prompts = [[rnd.randrange(cfg.vocab_size) for _ in range(n)] for n in lens]
+    eng.logits_by_req = {}
+    reqs = [Req(i, list(p), new_tokens) for i, p in enumerate(prompts)]
+    eng.prefill(reqs)
+    guard = 0
+    while eng.running or eng.waiting:
+        if not eng.running or (eng.waiting and eng._fits_with(eng.waiting[0])):
+            eng.prefill([eng.waiting.pop(0)])
+        done = [q for q in eng.running if q.finished()]
+        if done:
+            eng.finish(done)
+            continue
+        eng.decode_step()
+        eng.flush_decode_outputs()
+        guard += 1
+        assert guard < 300
+    assert eng.stats.get("retracted", 0) >= 1
+    outs = [q.all_output_ids for q in reqs]
+    assert all(len(o) == new_tokens for o in outs)
+    ref = _oracle_rows(cfg, runner, prompts, outs, new_tokens)
+    for b, q in enumerate(reqs):
+        rows = eng.logits_by_req[q.rid]
+        assert len(rows) == new_tokens
+        for k, row in enumerate(rows):
+            torch.testing.assert_close(row, ref[k][b], atol=2e-2, rtol=2e-2, msg=f"request {q.rid} token {k}")

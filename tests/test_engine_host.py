@@ -69,7 +69,7 @@ def cpu_kernels(monkeypatch):
         off = 0
         for b in range(req_pool.numel()):
             row, pre, seq, ext = int(req_pool[b]), int(prefix_lens[b]), int(seq_lens[b]), int(ext_lens[b])
-            if pre:
+            if pre and int(prefix_ptrs[b]):          # a null pointer keeps the row's prefix (mixed batches)
                 src = (ctypes.c_int64 * pre).from_address(int(prefix_ptrs[b]))
                 r2t[row, :pre] = torch.tensor(list(src), dtype=torch.int32)
             r2t[row, pre:seq] = out_cache_loc[off: off + ext].to(torch.int32)
@@ -306,3 +306,62 @@ def test_prefill_between_lagged_decode_steps_keeps_every_token(cpu_kernels, lag)
     assert tree.protected_size() == 0
     assert alloc.available_size() + tree.evictable_size() == len(prompts) * 64
     assert runner.req_to_token_pool.available_size() == runner.req_to_token_pool.size
+
+
+def test_mixed_step_prefills_new_requests_and_advances_the_running_ones(cpu_kernels):
+    """ForwardMode.MIXED: the running requests join the extend batch as 1-token extends over their cached rows."""
+    prompts = _prompts(2, 3, 10, seed=31)
+    runner = _ToyRunner(len(prompts), 64, len(prompts) * 64)
+    eng = Engine(runner)
+    a = [Req(i, prompts[i], 7) for i in (0, 1, 3)]           # two of group 0, one of group 1
+    b = [Req(10 + i, prompts[i], 4) for i in (2, 4, 5)]      # the others: every one finds its group's prefix cached
+    eng.prefill(a)
+    eng.decode_step(); eng.flush_decode_outputs(lag=1)
+    eng.decode_step()                                       # one hand-off still in flight when the mixed batch forms
+    eng.mixed_step(b)
+    mixed = runner.seen[-1]
+    assert mixed[0] and len(mixed[1]) == 6                  # an extend-mode forward over 3 new + 3 running requests
+    assert mixed[1][3:] == [len(q.origin_input_ids) + 3 for q in a]          # kv lengths of the running ones after the step
+    assert [q.cached_tokens for q in b] == [10, 10, 10]     # the group's prefix was cached by the first batch
+    for _ in range(3):
+        eng.decode_step(); eng.flush_decode_outputs(lag=1)
+    eng.finish(list(eng.running))
+    for q in a:
+        assert q.output_ids == _expected(q.origin_input_ids, 7), q.rid
+    for q in b:
+        assert q.output_ids == _expected(q.origin_input_ids, 4), q.rid
+    tree, alloc = runner.tree_cache, runner.token_to_kv_pool_allocator
+    assert tree.protected_size() == 0 and alloc.available_size() + tree.evictable_size() == len(prompts) * 64
+
+
+def test_retraction_under_pool_pressure_keeps_every_token(cpu_kernels):
+    """A KV pool too small for the whole batch's decode: the requests with the fewest generated tokens (longest
+    prompts first among equals) are retracted, their tokens folded into their prompts, re-prefilled later, and every
+    request still ends with exactly its expected tokens."""
+    rnd = random.Random(5)
+    prompts = [[rnd.randrange(VOCAB) for _ in range(n)] for n in (20, 26, 23, 29)]
+    new_tokens = 12
+    size = 20 + 26 + 23 + 29 + 4 * 3              # room for three decode steps of all four, then pressure
+    runner = _ToyRunner(4, 64, size, disable_radix=True)
+    eng = Engine(runner)
+    reqs = [Req(i, p, new_tokens) for i, p in enumerate(prompts)]
+    orig = [list(p) for p in prompts]
+    eng.prefill(reqs)
+    steps = 0
+    while eng.running or eng.waiting:
+        if not eng.running or (eng.waiting and eng._fits_with(eng.waiting[0])):
+            q = eng.waiting.pop(0)
+            eng.prefill([q])
+        done = [q for q in eng.running if q.finished()]
+        if done:
+            eng.finish(done)
+            continue
+        eng.decode_step()
+        eng.flush_decode_outputs()
+        steps += 1
+        assert steps < 200
+    assert eng.stats.get("retracted", 0) >= 1
+    for q, p in zip(reqs, orig):
+        assert q.all_output_ids == _expected(p, new_tokens), q.rid
+    alloc, tree = runner.token_to_kv_pool_allocator, runner.tree_cache
+    assert alloc.available_size() + tree.evictable_size() == size and runner.req_to_token_pool.available_size() == 4
