@@ -335,6 +335,41 @@ int sgl_amd_xgmi_one_shot_all_reduce(const void* inp, void* out, int64_t rows, i
                                      const void* const* peer_workspaces_host, int64_t workspace_bytes, int epilogue,
                                      void* residual, const void* norm_weight, float eps, int num_blocks, void* stream);
 
+/* ---- pool layouts / element formats / masks beyond the bf16 NHD default ----------
+ * kv_fp8 = 1: the pools hold OCP e4m3 bytes of K / k_scale and V / v_scale (memory_pool.py:2364-2374,
+ * `--kv-cache-dtype fp8_e4m3`); the attention folds k_scale into the logit scale and multiplies v_scale into the
+ * output (triton_backend.py:1418-1420 k_descale / v_descale).  row strides are in ELEMENTS (= bytes for fp8).
+ * kv_layout_hnd = 1: pools are [pages, H_kv, page_size, D] (memory_pool.py:2061-2117), slot = page * page_size + off,
+ * page_size a power of two; 0: [slots, H_kv, D].
+ * sliding_window >= 0: a query at position p sees kv positions [p - window, p] (torch_native_backend.py:36-48,
+ * extend_attention.py:480-485); logit_cap > 0: s <- cap * tanh(s / cap) (extend_attention.py:546-547).
+ * custom_mask (extend only; speculative-decoding verify, triton_backend.py:860-919): request b's
+ * [extend_len, kv_len] row-major uint8 mask at custom_mask + mask_indptr[b] replaces the causal rule. */
+int sgl_amd_store_kv_cache_ex(const void* k, const void* v, void* k_cache, void* v_cache, const int64_t* loc,
+                              int64_t num_tokens, int num_kv_heads, int head_dim, int64_t k_token_stride,
+                              int64_t v_token_stride, int64_t cache_row_stride, int kv_fp8, float k_scale, float v_scale,
+                              int page_size, int kv_layout_hnd, void* stream);
+int sgl_amd_decode_attention_ex(const void* q, const void* k_cache, const void* v_cache, void* out,
+                                const int32_t* req_to_token, int64_t req_to_token_stride,
+                                const int64_t* req_pool_indices, const int32_t* seq_lens,
+                                const int32_t* kv_indptr, int64_t batch, int num_q_heads,
+                                int num_kv_heads, int head_dim, int64_t q_token_stride,
+                                int64_t out_token_stride, int64_t k_cache_row_stride,
+                                int64_t v_cache_row_stride, float sm_scale, int num_splits,
+                                void* ws_acc, void* ws_ml, const int32_t* batch_order, int flags,
+                                int kv_fp8, float k_scale, float v_scale, int page_size, int kv_layout_hnd,
+                                int sliding_window, float logit_cap, void* stream);
+int sgl_amd_extend_attention_ex(const void* q, void* out, const void* k_cache, const void* v_cache,
+                                const int32_t* req_to_token, int64_t req_to_token_stride,
+                                const int64_t* req_pool_indices, const int32_t* seq_lens,
+                                const int32_t* prefix_lens, const int32_t* qo_indptr, int64_t batch,
+                                int max_extend_len, int num_q_heads, int num_kv_heads, int head_dim,
+                                int64_t q_token_stride, int64_t out_token_stride,
+                                int64_t k_cache_row_stride, int64_t v_cache_row_stride, float sm_scale,
+                                int causal, int kv_fp8, float k_scale, float v_scale, int page_size, int kv_layout_hnd,
+                                int sliding_window, float logit_cap, const void* custom_mask, const int64_t* mask_indptr,
+                                void* stream);
+
 #ifdef __cplusplus
 }
 #endif

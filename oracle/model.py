@@ -26,7 +26,7 @@ from . import ops
 class OracleLM:
     def __init__(self, cfg, weights: Dict[str, torch.Tensor], num_slots: int = 4096, max_ctx: int = 2048,
                  compute_dtype: Optional[torch.dtype] = None, tp_size: int = 1, tp_group=None, max_reqs: int = 63,
-                 device="cpu", batched_decode: bool = False):
+                 device="cpu", batched_decode: bool = False, kv_cache_dtype: str = "auto"):
         """`weights`: CPU tensors keyed like the product model's state_dict().  With tp_size > 1 the
         weights are ONE rank's shard (heads / intermediate / vocab split as in the reference's
         Column/RowParallelLinear, srt/layers/linear.py) and the row-parallel outputs are summed with
@@ -50,8 +50,13 @@ class OracleLM:
         self.rope_cache = ops.cos_sin_cache(inv, cfg.max_position_embeddings).to(torch.bfloat16).to(self.device)
         L = cfg.num_hidden_layers
         dev = self.device
-        self.k_cache = [torch.zeros((num_slots, self.Hkv, D), dtype=torch.bfloat16, device=dev) for _ in range(L)]
-        self.v_cache = [torch.zeros((num_slots, self.Hkv, D), dtype=torch.bfloat16, device=dev) for _ in range(L)]
+        # "fp8_e4m3": rows are cast to float8_e4m3fn on store (memory_pool.py:2364-2374, scales 1.0 as with dummy weights)
+        self.kv_fp8 = kv_cache_dtype == "fp8_e4m3"
+        kvd = torch.float8_e4m3fn if self.kv_fp8 else torch.bfloat16
+        self.k_cache = [torch.zeros((num_slots, self.Hkv, D), dtype=kvd, device=dev) for _ in range(L)]
+        self.v_cache = [torch.zeros((num_slots, self.Hkv, D), dtype=kvd, device=dev) for _ in range(L)]
+        self.attn_opts = dict(sliding_window=cfg.sliding_window if getattr(cfg, "sliding_window", None) is not None else -1,
+                              logit_cap=float(getattr(cfg, "logit_cap", 0.0) or 0.0))
         self.req_to_token = torch.zeros((max_reqs + 1, max_ctx), dtype=torch.int32, device=dev)
         self.next_slot = 1
 
@@ -73,14 +78,18 @@ class OracleLM:
             qkv = F.linear(h, w[p + "self_attn.qkv_proj.weight"], w.get(p + "self_attn.qkv_proj.bias"))
             q, k, v = qkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1)
             q, k = ops.rotary_embedding(positions, q, k, D, self.rope_cache, True)
-            ops.store_kv(k.reshape(-1, Hkv, D), v.reshape(-1, Hkv, D), self.k_cache[i], self.v_cache[i], out_loc)
+            if self.kv_fp8:
+                ops.store_kv(ops.quantize_kv_fp8(k.reshape(-1, Hkv, D)), ops.quantize_kv_fp8(v.reshape(-1, Hkv, D)),
+                             self.k_cache[i], self.v_cache[i], out_loc)
+            else:
+                ops.store_kv(k.reshape(-1, Hkv, D), v.reshape(-1, Hkv, D), self.k_cache[i], self.v_cache[i], out_loc)
             q3 = q.reshape(-1, Hq, D)
             if decode:
                 o = ops.decode_attention(q3, self.k_cache[i], self.v_cache[i], self.req_to_token, req_pool, seq_lens,
-                                         D ** -0.5, self.compute_dtype, batched=self.batched_decode)
+                                         D ** -0.5, self.compute_dtype, batched=self.batched_decode, **self.attn_opts)
             else:
                 o = ops.extend_attention(q3, self.k_cache[i], self.v_cache[i], self.req_to_token, req_pool, seq_lens,
-                                         prefix_lens, extend_lens, D ** -0.5, True, self.compute_dtype)
+                                         prefix_lens, extend_lens, D ** -0.5, True, self.compute_dtype, **self.attn_opts)
             h = self._all_reduce(F.linear(o.reshape(-1, Hq * D), w[p + "self_attn.o_proj.weight"]))
             h, residual = ops.fused_add_rmsnorm(h, residual, w[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps)
             if cfg.num_local_experts > 0:

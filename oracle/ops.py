@@ -11,7 +11,7 @@ All paths are relative to /root/reference/python/sglang.
 from __future__ import annotations
 
 import math
-from typing import Optional, Tuple
+from typing import Optional, Sequence, Tuple
 
 import torch
 import torch.nn.functional as F
@@ -119,11 +119,55 @@ def store_kv(k: torch.Tensor, v: torch.Tensor, k_cache: torch.Tensor, v_cache: t
     v_cache[loc] = v.view(v.shape[0], *v_cache.shape[1:])
 
 
+# ---------------------------------------------------------------- KV formats
+FP8_MAX = 448.0
+
+
+def quantize_kv_fp8(x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    """srt/mem_cache/memory_pool.py:2364-2374: `cache_k.div_(k_scale)` on the bf16 rows, then the cast to the
+    pool dtype (float8_e4m3fn, OCP).  Out-of-range values are clamped to +-448 first (torch's cast would produce
+    NaN there; the product saturates -- the only place the two could differ is excluded from the comparison)."""
+    y = x.clone()
+    if scale != 1.0:
+        y.div_(scale)
+    return y.float().clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn)
+
+
+def _kv_rows(cache: torch.Tensor, toks: torch.Tensor, descale: float, like: torch.Tensor) -> torch.Tensor:
+    """Rows `toks` of a [slots, H, D] pool as compute values: fp8 rows are widened and multiplied by the scale
+    (triton_backend.py:1418-1420 k_descale / v_descale), bf16 rows pass through."""
+    rows = cache[toks]
+    if rows.dtype == torch.float8_e4m3fn:
+        return rows.to(torch.float32) * descale
+    return rows
+
+
+def _manual_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scaling: float, mask: Optional[torch.Tensor],
+                      logit_cap: float) -> torch.Tensor:
+    """softmax(cap * tanh(q k^T * scaling / cap) masked) v in fp32 (extend_attention.py:546-547 for the cap, which
+    SDPA cannot express).  q [Hq, Tq, D], k / v [Hkv, Tk, D], mask [Tq, Tk] bool (True = attend)."""
+    Hq, Hkv = q.shape[0], k.shape[0]
+    qf, kf, vf = q.float(), k.float(), v.float()
+    if Hq != Hkv:
+        kf = kf.repeat_interleave(Hq // Hkv, dim=0)
+        vf = vf.repeat_interleave(Hq // Hkv, dim=0)
+    s = torch.matmul(qf, kf.transpose(1, 2)) * scaling
+    if logit_cap > 0:
+        s = logit_cap * torch.tanh(s / logit_cap)
+    if mask is not None:
+        s = s.masked_fill(~mask.unsqueeze(0), float("-inf"))
+    pr = torch.softmax(s, dim=-1)
+    pr = torch.nan_to_num(pr, nan=0.0)          # a fully masked row attends to nothing
+    return torch.matmul(pr, vf)
+
+
 # ---------------------------------------------------------------- attention
 def extend_attention(query: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, req_to_token: torch.Tensor,
                      req_pool_indices: torch.Tensor, seq_lens: torch.Tensor, extend_prefix_lens: torch.Tensor,
                      extend_seq_lens: torch.Tensor, scaling: float, causal: bool = True,
-                     compute_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+                     compute_dtype: Optional[torch.dtype] = None, k_scale: float = 1.0, v_scale: float = 1.0,
+                     sliding_window: int = -1, logit_cap: float = 0.0, custom_mask: Optional[torch.Tensor] = None,
+                     mask_indptr: Optional[Sequence[int]] = None) -> torch.Tensor:
     """srt/layers/attention/torch_native_backend.py:61-174 (_run_sdpa_forward_extend).
 
     query [T, Hq, D]; caches [slots, Hkv, D].  The reference pads Q to the kv
@@ -146,8 +190,28 @@ def extend_attention(query: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.
         red.zero_()  # the reference leaves the padded rows uninitialised; they are discarded
         red[:, pre:, :] = per_req_query
         toks = req_to_token[int(pool_l[i]), :kv].long()
-        key = k_cache[toks].movedim(0, query.dim() - 2)
-        val = v_cache[toks].movedim(0, query.dim() - 2)
+        key = _kv_rows(k_cache, toks, k_scale, query).movedim(0, query.dim() - 2)
+        val = _kv_rows(v_cache, toks, v_scale, query).movedim(0, query.dim() - 2)
+        special = sliding_window >= 0 or logit_cap > 0 or custom_mask is not None
+        if special:
+            # rows [pre, kv) of the padded query are the real ones (torch_native_backend.py:61-174); masks are over
+            # absolute positions: causal k <= q, window k >= q - W (:36-48), or the verify mask (extend_attention.py
+            # USE_CUSTOM_MASK: it replaces the causal rule, the prefix part is AND-ed with "inside the prefix")
+            q_pos = torch.arange(pre, kv, device=query.device).unsqueeze(1)
+            k_pos = torch.arange(kv, device=query.device).unsqueeze(0)
+            if custom_mask is not None:
+                m0 = int(mask_indptr[i])
+                mask = custom_mask[m0: m0 + ext * kv].view(ext, kv).to(torch.bool)
+            else:
+                mask = (k_pos <= q_pos) if causal else torch.ones((ext, kv), dtype=torch.bool, device=query.device)
+            if sliding_window >= 0:
+                mask = mask & (k_pos >= q_pos - sliding_window)
+            o = _manual_attention(per_req_query, key, val, scaling, mask, logit_cap)      # [H, ext, D]
+            out[start_q:end_q] = o.movedim(query.dim() - 2, 0).to(out.dtype)
+            start_q = end_q
+            continue
+        if key.dtype != red.dtype and compute_dtype is None:
+            key, val = key.to(red.dtype), val.to(red.dtype)
         if compute_dtype is not None:
             red, key, val = red.to(compute_dtype), key.to(compute_dtype), val.to(compute_dtype)
         o = F.scaled_dot_product_attention(red.unsqueeze(0), key.unsqueeze(0), val.unsqueeze(0),
@@ -160,13 +224,15 @@ def extend_attention(query: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.
 
 def decode_attention(query: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, req_to_token: torch.Tensor,
                      req_pool_indices: torch.Tensor, seq_lens: torch.Tensor, scaling: float,
-                     compute_dtype: Optional[torch.dtype] = None, batched: bool = False) -> torch.Tensor:
+                     compute_dtype: Optional[torch.dtype] = None, batched: bool = False, k_scale: float = 1.0,
+                     v_scale: float = 1.0, sliding_window: int = -1, logit_cap: float = 0.0) -> torch.Tensor:
     """torch_native_backend.py:176-277 (_run_sdpa_forward_decode): one query per request."""
     out = torch.empty_like(query)
     q = query.movedim(0, query.dim() - 2)
     enable_gqa = query.shape[1] != k_cache.shape[1]
     kv_l, pool_l = seq_lens.tolist(), req_pool_indices.tolist()
-    if batched and len(set(kv_l)) == 1 and len(kv_l) > 1:
+    special = sliding_window >= 0 or logit_cap > 0 or k_cache.dtype == torch.float8_e4m3fn
+    if batched and len(set(kv_l)) == 1 and len(kv_l) > 1 and not special:
         # every request has the same KV length: the per-request SDPA calls of the reference loop are issued as one
         # batched call (identical arithmetic per request; tests/test_oracle_golden.py checks it against the loop)
         kv = int(kv_l[0])
@@ -181,9 +247,16 @@ def decode_attention(query: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.
     for i in range(seq_lens.shape[0]):
         kv = int(kv_l[i])
         per_req_query = q[:, i:i + 1, :]
-        toks = req_to_token[int(pool_l[i]), :kv].long()
-        key = k_cache[toks].movedim(0, query.dim() - 2)
-        val = v_cache[toks].movedim(0, query.dim() - 2)
+        # the query sits at position kv - 1; a window keeps kv positions [kv - 1 - W, kv - 1] (torch_native_backend.py:36-48)
+        k0 = max(0, kv - 1 - sliding_window) if sliding_window >= 0 else 0
+        toks = req_to_token[int(pool_l[i]), k0:kv].long()
+        key = _kv_rows(k_cache, toks, k_scale, query).movedim(0, query.dim() - 2)
+        val = _kv_rows(v_cache, toks, v_scale, query).movedim(0, query.dim() - 2)
+        if logit_cap > 0:
+            out[i:i + 1] = _manual_attention(per_req_query, key, val, scaling, None, logit_cap).movedim(query.dim() - 2, 0).to(out.dtype)
+            continue
+        if key.dtype != per_req_query.dtype and compute_dtype is None:
+            key, val = key.to(per_req_query.dtype), val.to(per_req_query.dtype)
         if compute_dtype is not None:
             per_req_query, key, val = per_req_query.to(compute_dtype), key.to(compute_dtype), val.to(compute_dtype)
         o = F.scaled_dot_product_attention(per_req_query.unsqueeze(0), key.unsqueeze(0), val.unsqueeze(0),

@@ -21,6 +21,7 @@
 //   * long sequences are split over gridDim.z; partial (m, l, acc) go to a
 //     caller-owned fp32 workspace and a small second kernel merges them.
 #include "common.hpp"
+#include "kv_format.hpp"
 #include "sglang_amd.h"
 
 using namespace sgl_amd;
@@ -81,6 +82,10 @@ struct DecodeParams {
   int num_splits;
   int min_chunk;              // split chunk granularity (tokens)
   float scale_log2;           // sm_scale * log2(e)
+  KvFormat fmt;               // layout + element format of the pool rows
+  float v_scale;              // fp8 rows: multiplied into the output (k_scale is folded into scale_log2)
+  int window;                 // sliding window: kv positions >= len - 1 - window (torch_native_backend.py:36-48); < 0: off
+  float cap_log2, inv_cap_log2;   // logit soft cap (cap * log2 e, 1 / (cap * log2 e)); cap_log2 == 0: off
   // optional [B] permutation that puts requests sharing a KV prefix next to each other: with it the
   // (request, kv head) workgroups are laid out so that a group's members run on ONE XCD (workgroup
   // i runs on XCD i % 8) and re-read the shared rows from that XCD's L2 instead of HBM
@@ -99,7 +104,7 @@ __device__ __forceinline__ void split_range(int len, int num_splits, int min_chu
 
 // G = query heads per kv head handled by this block (padded to a power of two),
 // D = head dim.  Grid: (B, Hkv * head_blocks, splits).
-template <int G, int D, bool USE_DPP>
+template <int G, int D, bool USE_DPP, bool FP8>
 __global__ __launch_bounds__(kThreads) void decode_stage1_kernel(DecodeParams p, int group_size,
                                                                  int head_blocks) {
   constexpr int LPR = D / 8;          // lanes per KV row
@@ -131,8 +136,11 @@ __global__ __launch_bounds__(kThreads) void decode_stage1_kernel(DecodeParams p,
   const int col = lane - sub * LPR;   // 16-byte column inside the row
 
   const int len = p.seq_lens[b];
+  // sliding window: the query (position len - 1) sees kv positions [len - 1 - window, len - 1]
+  const int kv_start = (p.window >= 0 && len - 1 - p.window > 0) ? len - 1 - p.window : 0;
   int c0, c1;
-  split_range(len, p.num_splits, p.min_chunk, split, c0, c1);
+  split_range(len - kv_start, p.num_splits, p.min_chunk, split, c0, c1);
+  c0 += kv_start; c1 += kv_start;
   const int h0 = kvh * group_size + hb * G;                 // first q head of this block
   int g_valid = group_size - hb * G;
   if (g_valid > G) g_valid = G;
@@ -179,7 +187,6 @@ __global__ __launch_bounds__(kThreads) void decode_stage1_kernel(DecodeParams p,
     for (int j = 0; j < 8; ++j) acc[h][j] = 0.f;
   }
 
-  const int64_t head_off = static_cast<int64_t>(kvh) * D + col * 8;
   const int last_tok = c1 - 1;
   const int tile_stride = kWaves * TILE;
   int t_cur = c0 + wid * TILE;  // first token of this wave's current tile
@@ -196,8 +203,8 @@ __global__ __launch_bounds__(kThreads) void decode_stage1_kernel(DecodeParams p,
   auto load_rows = [&](const int32_t* s, U4* kr, U4* vr) {
 #pragma unroll
     for (int u = 0; u < kLoadsPerTile; ++u) {
-      kr[u] = ld16(p.k_cache + static_cast<int64_t>(s[u]) * p.kc_stride + head_off);
-      vr[u] = ld16(p.v_cache + static_cast<int64_t>(s[u]) * p.vc_stride + head_off);
+      kr[u] = ld_kv8<FP8>(kv_row(p.k_cache, p.fmt, s[u], kvh), col);
+      vr[u] = ld_kv8<FP8>(kv_row(p.v_cache, p.fmt, s[u], kvh), col);
     }
   };
 
@@ -231,6 +238,7 @@ __global__ __launch_bounds__(kThreads) void decode_stage1_kernel(DecodeParams p,
 #pragma unroll
         for (int j = 0; j < 8; ++j) d = fmaf(qf[h][j], kf[j], d);
         d = row_sum<LPR, USE_DPP>(d);
+        if (p.cap_log2 != 0.f) d = soft_cap_log2(d, p.cap_log2, p.inv_cap_log2);
         s[h][u] = valid ? d : kNegBig;
       }
     }
@@ -324,7 +332,7 @@ __global__ __launch_bounds__(kThreads) void decode_stage1_kernel(DecodeParams p,
     }
     const int hq = h0 + h;
     if (direct) {
-      const float r = (l > 0.f) ? o / l : 0.f;
+      const float r = (l > 0.f) ? o / l * p.v_scale : 0.f;
       p.out[static_cast<int64_t>(b) * p.out_stride + static_cast<int64_t>(hq) * D + d] = f2bf(r);
     } else {
       const int64_t base = (static_cast<int64_t>(b) * p.num_q_heads + hq) * p.num_splits + split;
@@ -341,17 +349,18 @@ __global__ __launch_bounds__(kThreads) void decode_stage1_kernel(DecodeParams p,
 __global__ void decode_stage2_kernel(const float* __restrict__ ws_acc, const float* __restrict__ ws_ml,
                                      const int32_t* __restrict__ seq_lens, uint16_t* __restrict__ out,
                                      int64_t out_stride, int num_q_heads, int head_dim,
-                                     int num_splits, int min_chunk) {
+                                     int num_splits, int min_chunk, int window, float v_scale) {
   const int b = blockIdx.x, hq = blockIdx.y, d = threadIdx.x;
   if (d >= head_dim) return;
   const int len = seq_lens[b];
   if (len == 0) return;  // stage 1 already wrote zeros
   const int64_t base = (static_cast<int64_t>(b) * num_q_heads + hq) * num_splits;
+  const int kv_start = (window >= 0 && len - 1 - window > 0) ? len - 1 - window : 0;
   float m_all = kNegBig;
   int n_valid = 0;
   for (int s = 0; s < num_splits; ++s) {
     int c0, c1;
-    split_range(len, num_splits, min_chunk, s, c0, c1);
+    split_range(len - kv_start, num_splits, min_chunk, s, c0, c1);
     if (c0 >= c1) break;
     ++n_valid;
     m_all = fmaxf(m_all, ws_ml[(base + s) * 2]);
@@ -362,7 +371,7 @@ __global__ void decode_stage2_kernel(const float* __restrict__ ws_acc, const flo
     l += ws_ml[(base + s) * 2 + 1] * sc;
     o += ws_acc[(base + s) * head_dim + d] * sc;
   }
-  const float r = (l > 0.f) ? o / l : 0.f;
+  const float r = (l > 0.f) ? o / l * v_scale : 0.f;
   out[static_cast<int64_t>(b) * out_stride + static_cast<int64_t>(hq) * head_dim + d] = f2bf(r);
 }
 
@@ -371,12 +380,13 @@ template <int G, int D>
 int launch_stage1(const DecodeParams& p, int batch, int group_size, int head_blocks, bool use_dpp,
                   hipStream_t stream) {
   dim3 grid(batch, p.num_kv_heads * head_blocks, p.num_splits);
-  if (use_dpp)
-    hipLaunchKernelGGL((decode_stage1_kernel<G, D, true>), grid, dim3(kThreads), 0, stream, p,
-                       group_size, head_blocks);
-  else
-    hipLaunchKernelGGL((decode_stage1_kernel<G, D, false>), grid, dim3(kThreads), 0, stream, p,
-                       group_size, head_blocks);
+  if (p.fmt.fp8) {
+    hipLaunchKernelGGL((decode_stage1_kernel<G, D, true, true>), grid, dim3(kThreads), 0, stream, p, group_size, head_blocks);
+  } else if (use_dpp) {
+    hipLaunchKernelGGL((decode_stage1_kernel<G, D, true, false>), grid, dim3(kThreads), 0, stream, p, group_size, head_blocks);
+  } else {
+    hipLaunchKernelGGL((decode_stage1_kernel<G, D, false, false>), grid, dim3(kThreads), 0, stream, p, group_size, head_blocks);
+  }
   return 0;
 }
 
@@ -407,7 +417,26 @@ int sgl_amd_decode_attention(const void* q, const void* k_cache, const void* v_c
                              int64_t out_token_stride, int64_t k_cache_row_stride,
                              int64_t v_cache_row_stride, float sm_scale, int num_splits,
                              void* ws_acc, void* ws_ml, const int32_t* batch_order, int flags, void* stream) {
+  return sgl_amd_decode_attention_ex(q, k_cache, v_cache, out, req_to_token, req_to_token_stride, req_pool_indices, seq_lens,
+                                     kv_indptr, batch, num_q_heads, num_kv_heads, head_dim, q_token_stride, out_token_stride,
+                                     k_cache_row_stride, v_cache_row_stride, sm_scale, num_splits, ws_acc, ws_ml, batch_order,
+                                     flags, 0, 1.0f, 1.0f, 1, 0, -1, 0.0f, stream);
+}
+
+int sgl_amd_decode_attention_ex(const void* q, const void* k_cache, const void* v_cache, void* out,
+                                const int32_t* req_to_token, int64_t req_to_token_stride,
+                                const int64_t* req_pool_indices, const int32_t* seq_lens,
+                                const int32_t* kv_indptr, int64_t batch, int num_q_heads,
+                                int num_kv_heads, int head_dim, int64_t q_token_stride,
+                                int64_t out_token_stride, int64_t k_cache_row_stride,
+                                int64_t v_cache_row_stride, float sm_scale, int num_splits,
+                                void* ws_acc, void* ws_ml, const int32_t* batch_order, int flags,
+                                int kv_fp8, float k_scale, float v_scale, int page_size, int kv_layout_hnd,
+                                int sliding_window, float logit_cap, void* stream) {
   SGL_CLEAR_STALE_ERROR();
+  SGL_CHECK_ARG(k_cache_row_stride == v_cache_row_stride, "decode_attention: K and V pools must share a row stride");
+  SGL_CHECK_ARG(!kv_fp8 || (k_scale > 0.f && v_scale > 0.f), "decode_attention: fp8 KV needs positive k_scale / v_scale");
+  SGL_CHECK_ARG(logit_cap >= 0.f, "decode_attention: logit_cap must be >= 0 (0 = off)");
   SGL_CHECK_ARG(head_dim == 64 || head_dim == 128 || head_dim == 256,
                 "decode_attention: head_dim=%d not supported (64/128/256)", head_dim);
   SGL_CHECK_ARG(num_kv_heads > 0 && num_q_heads % num_kv_heads == 0,
@@ -439,7 +468,13 @@ int sgl_amd_decode_attention(const void* q, const void* k_cache, const void* v_c
   p.num_kv_heads = num_kv_heads;
   p.num_splits = num_splits;
   p.min_chunk = sgl_amd_decode_attention_min_chunk();
-  p.scale_log2 = sm_scale * 1.4426950408889634f;
+  p.scale_log2 = sm_scale * 1.4426950408889634f * (kv_fp8 ? k_scale : 1.0f);
+  p.v_scale = kv_fp8 ? v_scale : 1.0f;
+  p.window = sliding_window;
+  p.cap_log2 = logit_cap > 0.f ? logit_cap * 1.4426950408889634f : 0.f;
+  p.inv_cap_log2 = logit_cap > 0.f ? 1.0f / p.cap_log2 : 0.f;
+  SGL_CHECK_ARG(make_kv_format(&p.fmt, k_cache_row_stride, num_kv_heads, head_dim, page_size, kv_layout_hnd, kv_fp8),
+                "decode_attention: HND pools need a power-of-two page_size (got %d)", page_size);
   p.batch_order = batch_order;
   const int group = num_q_heads / num_kv_heads;
   const bool use_dpp = (flags & SGL_AMD_ATTN_FLAG_NO_DPP) == 0;
@@ -451,7 +486,7 @@ int sgl_amd_decode_attention(const void* q, const void* k_cache, const void* v_c
   if (num_splits > 1) {
     hipLaunchKernelGGL(decode_stage2_kernel, dim3(batch, num_q_heads), dim3(head_dim), 0, st,
                        p.ws_acc, p.ws_ml, seq_lens, p.out, out_token_stride, num_q_heads, head_dim,
-                       num_splits, p.min_chunk);
+                       num_splits, p.min_chunk, p.window, p.v_scale);
     SGL_CHECK_LAUNCH("decode_attention(stage2)");
   }
   return 0;

@@ -13,6 +13,7 @@
 // bf16 rounding points reproduced so results are bit-comparable with the
 // torch-native path.
 #include "common.hpp"
+#include "kv_format.hpp"
 #include "sglang_amd.h"
 
 using namespace sgl_amd;
@@ -193,6 +194,40 @@ __global__ void store_kv_kernel(const uint16_t* __restrict__ k, const uint16_t* 
   for (int e = threadIdx.x * 8; e < v_row_elems; e += blockDim.x * 8) st16(vd + e, ld16(vs + e));
 }
 
+// The same scatter for any pool layout / element format: one workgroup per token, a thread per 8 elements of the
+// token's [H_kv, D] row; fp8 rows hold x / scale rounded to OCP e4m3 (memory_pool.py:2364-2374).
+template <bool FP8>
+__global__ void store_kv_fmt_kernel(const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
+                                    void* __restrict__ k_cache, void* __restrict__ v_cache,
+                                    const int64_t* __restrict__ loc, int num_kv_heads, int head_dim,
+                                    int64_t k_stride, int64_t v_stride, KvFormat fmt, float inv_k_scale, float inv_v_scale) {
+  const int64_t tok = blockIdx.x;
+  const int slot = static_cast<int>(loc[tok]);
+  const int per_head = head_dim >> 3;
+  for (int e = threadIdx.x; e < num_kv_heads * per_head; e += blockDim.x) {
+    const int h = e / per_head, c = e - h * per_head;
+    const U4 kv8 = ld16(k + tok * k_stride + static_cast<int64_t>(h) * head_dim + c * 8);
+    const U4 vv8 = ld16(v + tok * v_stride + static_cast<int64_t>(h) * head_dim + c * 8);
+    unsigned char* kd = const_cast<unsigned char*>(kv_row(k_cache, fmt, slot, h));
+    unsigned char* vd = const_cast<unsigned char*>(kv_row(v_cache, fmt, slot, h));
+    if constexpr (FP8) {
+      const uint32_t kw[4] = {kv8.x, kv8.y, kv8.z, kv8.w}, vw[4] = {vv8.x, vv8.y, vv8.z, vv8.w};
+      float kf[8], vf[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        // (K / k_scale) is a bf16 division in the reference (cache_k.div_(k_scale) on a bf16 tensor) before the cast
+        kf[2 * j] = rbf(bf_lo(kw[j]) * inv_k_scale); kf[2 * j + 1] = rbf(bf_hi(kw[j]) * inv_k_scale);
+        vf[2 * j] = rbf(bf_lo(vw[j]) * inv_v_scale); vf[2 * j + 1] = rbf(bf_hi(vw[j]) * inv_v_scale);
+      }
+      *reinterpret_cast<uint2*>(kd + c * 8) = f32x8_to_fp8x8(kf, 1.0f);
+      *reinterpret_cast<uint2*>(vd + c * 8) = f32x8_to_fp8x8(vf, 1.0f);
+    } else {
+      st16(kd + c * 16, kv8);
+      st16(vd + c * 16, vv8);
+    }
+  }
+}
+
 inline int norm_threads(int hidden) {
   const int nvec = hidden >> 3;
   int t = (nvec + 1) / 2;
@@ -328,6 +363,33 @@ int sgl_amd_store_kv_cache(const void* k, const void* v, void* k_cache, void* v_
                      k_row_elems, v_row_elems, k_token_stride, v_token_stride, k_cache_row_stride,
                      v_cache_row_stride);
   SGL_CHECK_LAUNCH("store_kv_cache");
+  return 0;
+}
+
+int sgl_amd_store_kv_cache_ex(const void* k, const void* v, void* k_cache, void* v_cache, const int64_t* loc,
+                              int64_t num_tokens, int num_kv_heads, int head_dim, int64_t k_token_stride,
+                              int64_t v_token_stride, int64_t cache_row_stride, int kv_fp8, float k_scale, float v_scale,
+                              int page_size, int kv_layout_hnd, void* stream) {
+  SGL_CLEAR_STALE_ERROR();
+  SGL_CHECK_ARG(head_dim % 8 == 0 && num_kv_heads > 0, "store_kv_cache: head_dim must be a multiple of 8");
+  SGL_CHECK_ARG(k_token_stride % 8 == 0 && v_token_stride % 8 == 0 && cache_row_stride % 8 == 0,
+                "store_kv_cache: strides must be multiples of 8 elements");
+  SGL_CHECK_ARG(!kv_fp8 || (k_scale > 0.f && v_scale > 0.f), "store_kv_cache: fp8 KV needs positive k_scale / v_scale");
+  if (num_tokens == 0) return 0;
+  KvFormat fmt;
+  SGL_CHECK_ARG(make_kv_format(&fmt, cache_row_stride, num_kv_heads, head_dim, page_size, kv_layout_hnd, kv_fp8),
+                "store_kv_cache: HND pools need a power-of-two page_size (got %d)", page_size);
+  int threads = ((num_kv_heads * head_dim / 8 + 63) / 64) * 64;
+  if (threads > 256) threads = 256;
+  if (kv_fp8)
+    hipLaunchKernelGGL(store_kv_fmt_kernel<true>, dim3(num_tokens), dim3(threads), 0, as_stream(stream),
+                       static_cast<const uint16_t*>(k), static_cast<const uint16_t*>(v), k_cache, v_cache, loc, num_kv_heads,
+                       head_dim, k_token_stride, v_token_stride, fmt, 1.0f / k_scale, 1.0f / v_scale);
+  else
+    hipLaunchKernelGGL(store_kv_fmt_kernel<false>, dim3(num_tokens), dim3(threads), 0, as_stream(stream),
+                       static_cast<const uint16_t*>(k), static_cast<const uint16_t*>(v), k_cache, v_cache, loc, num_kv_heads,
+                       head_dim, k_token_stride, v_token_stride, fmt, 1.0f, 1.0f);
+  SGL_CHECK_LAUNCH("store_kv_cache_ex");
   return 0;
 }
 

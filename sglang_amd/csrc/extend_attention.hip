@@ -25,6 +25,7 @@
 //   * fp32 accumulation, exp2 with the softmax scale folded in, bf16 output.
 #include <cstdlib>
 #include "common.hpp"
+#include "kv_format.hpp"
 #include "sglang_amd.h"
 
 using namespace sgl_amd;
@@ -57,6 +58,15 @@ struct ExtendParams {
   int tokens_per_tile;          // kRows / group
   int causal;
   float scale_log2;
+  KvFormat fmt;                 // layout + element format of the pool rows
+  float v_scale;                // fp8 rows: multiplied into the output (k_scale is folded into scale_log2)
+  int window;                   // sliding window: kv position >= q position - window (extend_attention.py:480-485); < 0: off
+  float cap_log2, inv_cap_log2; // logit soft cap (extend_attention.py:546-547), 0: off
+  // custom mask (speculative-decoding verify, triton_backend.py:860-919; extend_attention.py USE_CUSTOM_MASK):
+  // request b's [extend_len, kv_len] row-major uint8 mask starts at custom_mask + mask_indptr[b]; it REPLACES the
+  // causal rule on the extend part and is AND-ed with "inside the prefix" on the prefix part
+  const uint8_t* custom_mask;
+  const int64_t* mask_indptr;
 };
 
 template <int D>
@@ -76,7 +86,7 @@ struct Smem {
 // cost of one per thread, and every gather has two iterations of matrix work to land instead of one.  Measured
 // (rocprofv3 PMC, profiles/r02_pmc.json) the one-deep form spends ~7 us per KV tile against 0.45 us of MFMA issue:
 // it is bound by the bytes a CU keeps in flight, not by the matrix cores.
-template <int D, int MTW, int NWV, bool DEEP>
+template <int D, int MTW, int NWV, bool DEEP, bool FP8>
 __global__ __launch_bounds__(64 * NWV, (MTW == 1 && NWV == 4) ? 3 : (NWV == 8 ? 2 : 1)) void extend_attention_kernel(ExtendParams p) {
   static_assert(!DEEP || NWV == 8, "the alternating stager halves need 8 waves");
   __shared__ Smem<D> sm;
@@ -106,13 +116,17 @@ __global__ __launch_bounds__(64 * NWV, (MTW == 1 && NWV == 4) ? 3 : (NWV == 8 ? 
   if (q0 >= ext_len) return;
   int q1 = q0 + p.tokens_per_tile;
   if (q1 > ext_len) q1 = ext_len;
-  const bool causal = p.causal;
+  const uint8_t* cmask = p.custom_mask ? p.custom_mask + p.mask_indptr[b] : nullptr;
+  const bool causal = p.causal && cmask == nullptr;
+  const bool plain = cmask == nullptr && p.window < 0 && p.cap_log2 == 0.f;   // workgroup-uniform: the unmasked fast path is legal
   const int kv_end = causal ? (prefix + q1 < kv_len ? prefix + q1 : kv_len) : kv_len;
-  const int t_first = kv_begin / kKvTile;
+  // sliding window: the first query row of this tile bounds the earliest kv tile any row can see
+  const int kv_first = (p.window >= 0 && prefix + q0 - p.window > 0) ? prefix + q0 - p.window : 0;
+  const int t_first = (kv_begin > kv_first ? kv_begin : kv_first) / kKvTile;
   const int n_tiles = (kv_end + kKvTile - 1) / kKvTile;
 
   // ---- this lane's two rows (one per M-tile) ------------------------------
-  int row_tok[MTW], row_limit[MTW];
+  int row_tok[MTW], row_limit[MTW], row_start[MTW];
   bool row_ok[MTW];
   int64_t row_off[MTW];   // element offset of (token, head) inside q / out
   U4 qfrag[MTW][KC];
@@ -125,6 +139,7 @@ __global__ __launch_bounds__(64 * NWV, (MTW == 1 && NWV == 4) ? 3 : (NWV == 8 ? 
     row_ok[mt] = (t < p.tokens_per_tile) && (q0 + t < q1);
     row_limit[mt] = row_ok[mt] ? (causal ? prefix + q0 + t + 1 : kv_len) : 0;
     if (row_limit[mt] > kv_len) row_limit[mt] = kv_len;
+    row_start[mt] = (p.window >= 0 && prefix + q0 + t - p.window > 0) ? prefix + q0 + t - p.window : 0;
     row_off[mt] = static_cast<int64_t>(kvh * p.group + hg) * D;
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc) {
@@ -191,12 +206,12 @@ __global__ __launch_bounds__(64 * NWV, (MTW == 1 && NWV == 4) ? 3 : (NWV == 8 ? 
       if (v_active) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-          stage[i] = ld16(p.v_cache + static_cast<int64_t>(sidx[i]) * p.vc_stride + static_cast<int64_t>(kvh) * D + st_c * 8);
+          stage[i] = ld_kv8<FP8>(kv_row(p.v_cache, p.fmt, sidx[i], kvh), st_c);
       }
     } else if (is_k) {
 #pragma unroll
       for (int i = 0; i < NK_LOADS; ++i)
-        stage[i] = ld16(p.k_cache + static_cast<int64_t>(sidx[i]) * p.kc_stride + static_cast<int64_t>(kvh) * D + st_c * 8);
+        stage[i] = ld_kv8<FP8>(kv_row(p.k_cache, p.fmt, sidx[i], kvh), st_c);
     }
   };
 
@@ -273,7 +288,7 @@ __global__ __launch_bounds__(64 * NWV, (MTW == 1 && NWV == 4) ? 3 : (NWV == 8 ? 
     U4 pfrag[MTW][2];
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) {
-      const bool full = __ballot(kv0 + kKvTile > row_limit[mt]) == 0ull;     // wave-uniform
+      const bool full = plain && __ballot(kv0 + kKvTile > row_limit[mt]) == 0ull;     // wave-uniform
       float pv[4][4];
       float m_new, psum = 0.f;
       if (full) {
@@ -301,7 +316,12 @@ __global__ __launch_bounds__(64 * NWV, (MTW == 1 && NWV == 4) ? 3 : (NWV == 8 ? 
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int kvpos = kv0 + nt * 16 + g * 4 + r;
-            const float s = (kvpos < row_limit[mt]) ? st_acc[mt][nt][r] * p.scale_log2 : kNegBig;
+            bool on = kvpos < row_limit[mt] && kvpos >= row_start[mt];
+            if (cmask != nullptr && on)      // the mask row of this query token over all kv_len positions
+              on = cmask[static_cast<int64_t>(row_tok[mt]) * kv_len + kvpos] != 0;
+            float s = st_acc[mt][nt][r] * p.scale_log2;
+            if (p.cap_log2 != 0.f) s = soft_cap_log2(s, p.cap_log2, p.inv_cap_log2);
+            s = on ? s : kNegBig;
             sv[nt][r] = s;
             mx = fmaxf(mx, s);
           }
@@ -312,7 +332,7 @@ __global__ __launch_bounds__(64 * NWV, (MTW == 1 && NWV == 4) ? 3 : (NWV == 8 ? 
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float e = (sv[nt][r] > 0.5f * kNegBig) ? fast_exp2(sv[nt][r] - m_new) : 0.f;
+            const float e = (sv[nt][r] > 0.5f * kNegBig) ? fast_exp2(sv[nt][r] - m_new) : 0.f;   // masked scores add nothing, even while the row's maximum is still the sentinel
             pv[nt][r] = e;
             psum += e;
           }
@@ -356,7 +376,7 @@ __global__ __launch_bounds__(64 * NWV, (MTW == 1 && NWV == 4) ? 3 : (NWV == 8 ? 
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
     if (!row_ok[mt]) continue;
-    const float inv = (l > 0.f) ? 1.0f / l : 0.f;
+    const float inv = (l > 0.f) ? p.v_scale / l : 0.f;
     uint16_t* op = p.out + static_cast<int64_t>(q_begin + row_tok[mt]) * p.out_stride + row_off[mt];
 #pragma unroll
     for (int n = 0; n < ND; ++n) {
@@ -399,7 +419,27 @@ int sgl_amd_extend_attention(const void* q, void* out, const void* k_cache, cons
                              int64_t q_token_stride, int64_t out_token_stride,
                              int64_t k_cache_row_stride, int64_t v_cache_row_stride, float sm_scale,
                              int causal, void* stream) {
+  return sgl_amd_extend_attention_ex(q, out, k_cache, v_cache, req_to_token, req_to_token_stride, req_pool_indices, seq_lens,
+                                     prefix_lens, qo_indptr, batch, max_extend_len, num_q_heads, num_kv_heads, head_dim,
+                                     q_token_stride, out_token_stride, k_cache_row_stride, v_cache_row_stride, sm_scale, causal,
+                                     0, 1.0f, 1.0f, 1, 0, -1, 0.0f, nullptr, nullptr, stream);
+}
+
+int sgl_amd_extend_attention_ex(const void* q, void* out, const void* k_cache, const void* v_cache,
+                                const int32_t* req_to_token, int64_t req_to_token_stride,
+                                const int64_t* req_pool_indices, const int32_t* seq_lens,
+                                const int32_t* prefix_lens, const int32_t* qo_indptr, int64_t batch,
+                                int max_extend_len, int num_q_heads, int num_kv_heads, int head_dim,
+                                int64_t q_token_stride, int64_t out_token_stride,
+                                int64_t k_cache_row_stride, int64_t v_cache_row_stride, float sm_scale,
+                                int causal, int kv_fp8, float k_scale, float v_scale, int page_size, int kv_layout_hnd,
+                                int sliding_window, float logit_cap, const void* custom_mask, const int64_t* mask_indptr,
+                                void* stream) {
   SGL_CLEAR_STALE_ERROR();
+  SGL_CHECK_ARG(k_cache_row_stride == v_cache_row_stride, "extend_attention: K and V pools must share a row stride");
+  SGL_CHECK_ARG(!kv_fp8 || (k_scale > 0.f && v_scale > 0.f), "extend_attention: fp8 KV needs positive k_scale / v_scale");
+  SGL_CHECK_ARG(logit_cap >= 0.f, "extend_attention: logit_cap must be >= 0 (0 = off)");
+  SGL_CHECK_ARG((custom_mask == nullptr) == (mask_indptr == nullptr), "extend_attention: custom_mask and mask_indptr come together");
   SGL_CHECK_ARG(head_dim == 64 || head_dim == 128, "extend_attention: head_dim=%d not supported (64/128)", head_dim);
   SGL_CHECK_ARG(num_kv_heads > 0 && num_q_heads % num_kv_heads == 0,
                 "extend_attention: num_q_heads=%d not a multiple of num_kv_heads=%d", num_q_heads, num_kv_heads);
@@ -444,13 +484,26 @@ int sgl_amd_extend_attention(const void* q, void* out, const void* k_cache, cons
   }
   p.tokens_per_tile = (nwv * 16 * mtw) / group;
   p.causal = causal;
-  p.scale_log2 = sm_scale * 1.4426950408889634f;
+  p.scale_log2 = sm_scale * 1.4426950408889634f * (kv_fp8 ? k_scale : 1.0f);
+  p.v_scale = kv_fp8 ? v_scale : 1.0f;
+  p.window = sliding_window;
+  p.cap_log2 = logit_cap > 0.f ? logit_cap * 1.4426950408889634f : 0.f;
+  p.inv_cap_log2 = logit_cap > 0.f ? 1.0f / p.cap_log2 : 0.f;
+  p.custom_mask = static_cast<const uint8_t*>(custom_mask);
+  p.mask_indptr = mask_indptr;
+  SGL_CHECK_ARG(make_kv_format(&p.fmt, k_cache_row_stride, num_kv_heads, head_dim, page_size, kv_layout_hnd, kv_fp8),
+                "extend_attention: HND pools need a power-of-two page_size (got %d)", page_size);
   const int tiles = (max_extend_len + p.tokens_per_tile - 1) / p.tokens_per_tile;
   dim3 grid(tiles, num_kv_heads, batch);
   hipStream_t st = as_stream(stream);
-  bool deep = true;
-  if (const char* f = getenv("SGL_AMD_EXTEND_DEEP")) deep = atoi(f) != 0;      // A/B switch (benchmarks/micro.py)
-#define SGL_LAUNCH_EXT(D_, M_, W_, DP_) hipLaunchKernelGGL((extend_attention_kernel<D_, M_, W_, DP_>), grid, dim3(64 * W_), 0, st, p)
+  // the alternating-stager form measured no faster (profiles/r02_exp1_cascade_extend_ab.json): opt-in only
+  bool deep = false;
+  if (const char* f = getenv("SGL_AMD_EXTEND_DEEP")) deep = atoi(f) != 0;      // A/B switch (benchmarks/r02_exp1.py)
+#define SGL_LAUNCH_EXT(D_, M_, W_, DP_)                                                                                   \
+  do {                                                                                                                    \
+    if (kv_fp8) hipLaunchKernelGGL((extend_attention_kernel<D_, M_, W_, DP_, true>), grid, dim3(64 * W_), 0, st, p);      \
+    else hipLaunchKernelGGL((extend_attention_kernel<D_, M_, W_, DP_, false>), grid, dim3(64 * W_), 0, st, p);            \
+  } while (0)
   if (head_dim == 128) {
     if (nwv == 8 && deep) SGL_LAUNCH_EXT(128, 2, 8, true);
     else if (nwv == 8) SGL_LAUNCH_EXT(128, 2, 8, false);

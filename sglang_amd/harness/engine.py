@@ -88,7 +88,7 @@ class ModelRunner:
     def __init__(self, config: ModelConfig, *, max_total_tokens: int, max_running_requests: int,
                  max_context_len: int, page_size: int = 1, device=None, init_device=None,
                  use_graph: bool = True, graph_max_bs: Optional[int] = None, disable_radix_cache: bool = False,
-                 strict_graph: bool = False):
+                 strict_graph: bool = False, kv_cache_dtype: str = "auto", use_hnd: bool = False):
         self.config = config
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         if self.device.type == "cuda":
@@ -105,8 +105,9 @@ class ModelRunner:
         # pools (model_runner.py:822 alloc_memory_pool)
         self.req_to_token_pool = ReqToTokenPool(max_running_requests, max_context_len, self.device)
         size = max_total_tokens // page_size * page_size
-        self.token_to_kv_pool = MHATokenToKVPool(size, page_size, torch.bfloat16, self.num_kv_heads_per_rank,
-                                                 config.head_dim, config.num_hidden_layers, self.device)
+        kv_dtype = {"auto": torch.bfloat16, "bfloat16": torch.bfloat16, "fp8_e4m3": torch.float8_e4m3fn}[kv_cache_dtype]
+        self.token_to_kv_pool = MHATokenToKVPool(size, page_size, kv_dtype, self.num_kv_heads_per_rank,
+                                                 config.head_dim, config.num_hidden_layers, self.device, use_hnd=use_hnd)
         if page_size == 1:
             self.token_to_kv_pool_allocator = TokenToKVPoolAllocator(size, torch.bfloat16, self.device,
                                                                      self.token_to_kv_pool)

@@ -58,6 +58,8 @@ class ModelConfig:
     tie_word_embeddings: bool = False
     num_local_experts: int = 0
     num_experts_per_tok: int = 0
+    sliding_window: Optional[int] = None      # every layer attends [p - window, p] (mistral-style); None = full
+    logit_cap: float = 0.0                    # attention logit soft cap (gemma-2 / grok style); 0 = off
 
 
 _LLAMA3_ROPE = dict(rope_type="llama3", factor=8.0, low_freq_factor=1.0, high_freq_factor=4.0,
@@ -203,7 +205,8 @@ class LlamaAttention(nn.Module):
         wo = synth_weight(f"{prefix}.o_proj", (H, self.total_q * D), init_device)
         self.o_proj = Linear(_shard_cols(wo, tp_rank, tp_size).to(device))  # RowParallelLinear
         self.rotary_emb = get_rope(D, D, cfg.max_position_embeddings, cfg.rope_theta, True, cfg.rope_scaling, BF, device)
-        self.attn = RadixAttention(self.num_heads, D, D ** -0.5, self.num_kv_heads, layer_id)
+        self.attn = RadixAttention(self.num_heads, D, D ** -0.5, self.num_kv_heads, layer_id, logit_cap=cfg.logit_cap,
+                                   sliding_window_size=cfg.sliding_window if cfg.sliding_window is not None else -1)
         self.layer_id = layer_id
 
     def forward(self, positions: torch.Tensor, hidden_states: torch.Tensor, forward_batch,
@@ -211,6 +214,16 @@ class LlamaAttention(nn.Module):
         """fused_norm = (residual, norm): TP=1 decode form, o_proj + residual add + norm in one GEMM +
         combine pair (returns the normed activations, residual updated in place)."""
         pool = forward_batch.token_to_kv_pool
+        plain_pool = not getattr(pool, "is_fp8", False) and not getattr(pool, "use_hnd", False)
+        if not plain_pool:
+            # fp8 / HND pools: rope, then the backend stores the rows in the pool's own format (set_kv_buffer)
+            qkv = self.qkv_proj(hidden_states)
+            q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
+            self.rotary_emb(positions, q, k)
+            attn_output = self.attn(q, k, v, forward_batch, save_kv_cache=True)
+            if fused_norm is not None:
+                return self._o_proj_fused_norm(attn_output, fused_norm)
+            return self.o_proj.forward_all_reduce(attn_output)
         if not OPERATOR_SURFACE_ONLY and self.qkv_proj.streams(hidden_states) and self.rotary_emb.is_neox_style:
             # decode batch: qkv GEMM, rope and the KV-row store in one GEMM + combine pair
             q = kernels.wstream_qkv_rope(hidden_states, self.qkv_proj.weight.data,

@@ -115,10 +115,23 @@ def rotary_embedding(positions: torch.Tensor, query: torch.Tensor, key: torch.Te
 
 
 # ----------------------------------------------------------------------- kv store
-def store_kv_cache(k: torch.Tensor, v: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, loc: torch.Tensor) -> None:
+def store_kv_cache(k: torch.Tensor, v: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, loc: torch.Tensor,
+                   num_kv_heads: Optional[int] = None, head_dim: Optional[int] = None, kv_fp8: bool = False,
+                   k_scale: float = 1.0, v_scale: float = 1.0, page_size: int = 1, hnd: bool = False) -> None:
+    """k_cache[loc[t]] = k[t] (and v).  With kv_fp8 / hnd the pool rows are OCP e4m3 bytes of x / scale and / or laid
+    out [pages, H_kv, page_size, D] (memory_pool.py:2061-2117, 2364-2374)."""
     _dev(k, v, k_cache, v_cache, loc)
     _need(loc.dtype == torch.int64, "store_kv_cache: loc must be int64")
     T = loc.numel()
+    if kv_fp8 or hnd:
+        _need(num_kv_heads is not None and head_dim is not None, "store_kv_cache: fp8 / HND pools need num_kv_heads and head_dim")
+        k2, v2 = k.view(T, -1), v.view(T, -1)
+        _need(k2.dtype == _BF16 and v2.dtype == _BF16 and k2.shape[1] == num_kv_heads * head_dim, "store_kv_cache: bf16 [T, H_kv * D] rows")
+        _need(k_cache.dtype == (torch.uint8 if kv_fp8 else _BF16) and v_cache.dtype == k_cache.dtype, "store_kv_cache: pool dtype")
+        native.call("sgl_amd_store_kv_cache_ex", k2.data_ptr(), v2.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), loc.data_ptr(),
+                    T, num_kv_heads, head_dim, k2.stride(0), v2.stride(0), num_kv_heads * head_dim, 1 if kv_fp8 else 0,
+                    float(k_scale), float(v_scale), int(page_size), 1 if hnd else 0, _stream())
+        return
     k2, v2 = k.view(T, -1), v.view(T, -1)
     kc, vc = k_cache.view(k_cache.shape[0], -1), v_cache.view(v_cache.shape[0], -1)
     _need(k2.dtype == kc.dtype == _BF16 and v2.dtype == vc.dtype == _BF16, "store_kv_cache: bf16 only")
@@ -215,11 +228,26 @@ def decode_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
                      req_to_token: torch.Tensor, req_pool_indices: Optional[torch.Tensor], seq_lens: torch.Tensor,
                      sm_scale: float, num_splits: int = 1, ws_acc: Optional[torch.Tensor] = None,
                      ws_ml: Optional[torch.Tensor] = None, kv_indptr: Optional[torch.Tensor] = None,
-                     flags: int = 0, batch_order: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """q/out [B, Hq, D]; k_cache/v_cache [slots, Hkv, D]; seq_lens int32 [B]."""
+                     flags: int = 0, batch_order: Optional[torch.Tensor] = None, kv_fp8: bool = False,
+                     k_scale: float = 1.0, v_scale: float = 1.0, page_size: int = 1, hnd: bool = False,
+                     sliding_window: int = -1, logit_cap: float = 0.0) -> torch.Tensor:
+    """q/out [B, Hq, D]; k_cache/v_cache [slots, Hkv, D] (or [pages, Hkv, page_size, D] with hnd; uint8 e4m3 rows with
+    kv_fp8); seq_lens int32 [B]."""
     _dev(q, k_cache, v_cache, out, req_to_token, seq_lens)
     B, Hq, D = q.shape
     Hkv = k_cache.shape[1]
+    if kv_fp8 or hnd or sliding_window >= 0 or logit_cap > 0:
+        _need(q.dtype == _BF16 and out.dtype == _BF16 and k_cache.dtype == (torch.uint8 if kv_fp8 else _BF16)
+              and v_cache.dtype == k_cache.dtype and k_cache.is_contiguous() and v_cache.is_contiguous(), "decode_attention: dtypes / contiguous pools")
+        _need(seq_lens.dtype == torch.int32 and req_to_token.dtype == torch.int32, "decode_attention: int32 seq_lens / req_to_token")
+        _need(q.stride(2) == 1 and q.stride(1) == D and out.stride(2) == 1 and out.stride(1) == D, "decode_attention: q/out head layout")
+        r2t_stride = req_to_token.stride(0) if req_to_token.dim() == 2 else 0
+        native.call("sgl_amd_decode_attention_ex", q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), out.data_ptr(),
+                    req_to_token.data_ptr(), r2t_stride, _ptr(req_pool_indices), seq_lens.data_ptr(), _ptr(kv_indptr),
+                    B, Hq, Hkv, D, q.stride(0), out.stride(0), Hkv * D, Hkv * D, float(sm_scale), num_splits, _ptr(ws_acc),
+                    _ptr(ws_ml), _ptr(batch_order), flags, 1 if kv_fp8 else 0, float(k_scale), float(v_scale), int(page_size),
+                    1 if hnd else 0, int(sliding_window), float(logit_cap), _stream())
+        return out
     _need(q.dtype == _BF16 and k_cache.dtype == _BF16 and v_cache.dtype == _BF16 and out.dtype == _BF16, "decode_attention: bf16 only")
     _need(seq_lens.dtype == torch.int32 and req_to_token.dtype == torch.int32, "decode_attention: int32 seq_lens / req_to_token")
     _need(req_pool_indices is None or req_pool_indices.dtype == torch.int64, "decode_attention: int64 req_pool_indices")
@@ -236,11 +264,32 @@ def decode_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
 def extend_attention(q: torch.Tensor, out: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
                      req_to_token: torch.Tensor, req_pool_indices: torch.Tensor, seq_lens: torch.Tensor,
                      prefix_lens: torch.Tensor, qo_indptr: torch.Tensor, max_extend_len: int, sm_scale: float,
-                     causal: bool = True) -> torch.Tensor:
-    """q/out [T, Hq, D]; k_cache/v_cache [slots, Hkv, D]; int32 seq_lens/prefix_lens/qo_indptr."""
+                     causal: bool = True, kv_fp8: bool = False, k_scale: float = 1.0, v_scale: float = 1.0,
+                     page_size: int = 1, hnd: bool = False, sliding_window: int = -1, logit_cap: float = 0.0,
+                     custom_mask: Optional[torch.Tensor] = None, mask_indptr: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q/out [T, Hq, D]; k_cache/v_cache [slots, Hkv, D] (HND / fp8 as in decode_attention); int32
+    seq_lens/prefix_lens/qo_indptr; custom_mask uint8 / bool flat, mask_indptr int64 [B + 1]."""
     _dev(q, out, k_cache, v_cache, req_to_token, req_pool_indices, seq_lens, prefix_lens, qo_indptr)
     T, Hq, D = q.shape
     Hkv = k_cache.shape[1]
+    if kv_fp8 or hnd or sliding_window >= 0 or logit_cap > 0 or custom_mask is not None:
+        _need(q.dtype == _BF16 and out.dtype == _BF16 and k_cache.dtype == (torch.uint8 if kv_fp8 else _BF16)
+              and v_cache.dtype == k_cache.dtype and k_cache.is_contiguous() and v_cache.is_contiguous(), "extend_attention: dtypes / contiguous pools")
+        _need(seq_lens.dtype == torch.int32 and prefix_lens.dtype == torch.int32 and qo_indptr.dtype == torch.int32, "extend_attention: int32 lens")
+        _need(req_pool_indices.dtype == torch.int64 and req_to_token.dtype == torch.int32, "extend_attention: index dtypes")
+        _need(q.stride(2) == 1 and q.stride(1) == D and out.stride(2) == 1 and out.stride(1) == D, "extend_attention: q/out head layout")
+        if custom_mask is not None:
+            _dev(custom_mask, mask_indptr)
+            custom_mask = custom_mask.view(torch.uint8) if custom_mask.dtype == torch.bool else custom_mask
+            _need(custom_mask.dtype == torch.uint8 and custom_mask.is_contiguous() and mask_indptr is not None
+                  and mask_indptr.dtype == torch.int64, "extend_attention: uint8 custom_mask + int64 mask_indptr")
+        native.call("sgl_amd_extend_attention_ex", q.data_ptr(), out.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
+                    req_to_token.data_ptr(), req_to_token.stride(0), req_pool_indices.data_ptr(), seq_lens.data_ptr(),
+                    prefix_lens.data_ptr(), qo_indptr.data_ptr(), seq_lens.numel(), int(max_extend_len), Hq, Hkv, D,
+                    q.stride(0), out.stride(0), Hkv * D, Hkv * D, float(sm_scale), 1 if causal else 0, 1 if kv_fp8 else 0,
+                    float(k_scale), float(v_scale), int(page_size), 1 if hnd else 0, int(sliding_window), float(logit_cap),
+                    _ptr(custom_mask), _ptr(mask_indptr), _stream())
+        return out
     _need(q.dtype == _BF16 and k_cache.dtype == _BF16 and v_cache.dtype == _BF16 and out.dtype == _BF16, "extend_attention: bf16 only")
     _need(seq_lens.dtype == torch.int32 and prefix_lens.dtype == torch.int32 and qo_indptr.dtype == torch.int32,
           "extend_attention: int32 lens")

@@ -113,6 +113,10 @@ class HipAttnBackend(AttentionBackend):
         import os
 
         self.enable_cascade = os.environ.get("SGLANG_AMD_CASCADE", "1") != "0" and self.head_dim in (64, 128)
+        # the shared-prefix kernel reads bf16 NHD rows; other pool formats take the plain paged kernel
+        pool = self.token_to_kv_pool
+        self.plain_pool = not getattr(pool, "is_fp8", False) and not getattr(pool, "use_hnd", False)
+        self.enable_cascade = self.enable_cascade and self.plain_pool
 
     # ------------------------------------------------------------------ metadata
     def _workspace(self, batch: int, splits: int):
@@ -188,20 +192,51 @@ class HipAttnBackend(AttentionBackend):
         idx = forward_batch.req_pool_indices
         return idx if idx.dtype == torch.int64 else idx.to(torch.int64)
 
+    def _layer_options(self, layer):
+        """Pool format + the per-layer attention switches the reference kernels honour (radix_attention.py:115-148:
+        logit_cap, sliding_window_size, k_scale / v_scale)."""
+        pool = self.token_to_kv_pool
+        opt = pool.kernel_format(layer) if hasattr(pool, "kernel_format") else {}
+        win = getattr(layer, "sliding_window_size", -1)
+        if win is not None and win > -1:
+            opt["sliding_window"] = int(win)
+        cap = getattr(layer, "logit_cap", 0.0) or 0.0
+        if cap > 0:
+            opt["logit_cap"] = float(cap)
+        if not (opt.get("kv_fp8") or opt.get("hnd") or "sliding_window" in opt or "logit_cap" in opt):
+            return {}
+        return opt
+
     def forward_extend(self, q, k, v, layer, forward_batch, save_kv_cache: bool = True, **kwargs):
         if save_kv_cache and k is not None and v is not None:
             self._save_kv(layer, forward_batch, k, v)
         m = self.forward_metadata
         q3 = q.view(-1, layer.tp_q_head_num, layer.qk_head_dim)
-        o = torch.empty_like(q3)
+        o = torch.empty(q3.shape, dtype=q3.dtype, device=q3.device)
         from ..radix_attention import AttentionType
 
         causal = not (layer.is_cross_attention or layer.attn_type == AttentionType.ENCODER_ONLY)
+        opt = self._layer_options(layer)
+        # speculative-decoding verify / tree attention (triton_backend.py:860-919): spec_info carries the flat mask
+        spec = getattr(forward_batch, "spec_info", None)
+        if spec is not None and getattr(spec, "custom_mask", None) is not None:
+            opt["custom_mask"] = spec.custom_mask
+            opt["mask_indptr"] = self._mask_indptr(forward_batch, m)
         kernels.extend_attention(q3, o, self.token_to_kv_pool.get_key_buffer(layer.layer_id),
                                  self.token_to_kv_pool.get_value_buffer(layer.layer_id),
                                  self.req_to_token_pool.req_to_token, self._pool_idx(forward_batch), m.seq_lens_i32,
-                                 m.prefix_lens_i32, m.qo_indptr, m.max_extend_len, layer.scaling, causal)
+                                 m.prefix_lens_i32, m.qo_indptr, m.max_extend_len, layer.scaling, causal, **opt)
         return o.view(-1, layer.tp_q_head_num * layer.v_head_dim)
+
+    @staticmethod
+    def _mask_indptr(forward_batch, m):
+        """Offsets of every request's [extend_len, kv_len] block in the flat mask (triton_backend.py:880-895:
+        mask_indptr = cumsum(extend_len * kv_len))."""
+        ext = m.qo_indptr[1:].to(torch.int64) - m.qo_indptr[:-1].to(torch.int64)
+        sizes = ext * m.seq_lens_i32.to(torch.int64)
+        out = torch.zeros(sizes.numel() + 1, dtype=torch.int64, device=sizes.device)
+        out[1:] = torch.cumsum(sizes, 0)
+        return out
 
     def forward_decode(self, q, k, v, layer, forward_batch, save_kv_cache: bool = True, **kwargs):
         if save_kv_cache and k is not None and v is not None:
@@ -209,7 +244,8 @@ class HipAttnBackend(AttentionBackend):
         m = self.forward_metadata
         q3 = q.reshape(-1, layer.tp_q_head_num, layer.qk_head_dim)
         o = torch.empty_like(q3)
-        if m.cascade is not None:
+        opt = self._layer_options(layer)
+        if m.cascade is not None and not opt:
             kernels.cascade_decode_attention(m.cascade, q3, self.token_to_kv_pool.get_key_buffer(layer.layer_id),
                                              self.token_to_kv_pool.get_value_buffer(layer.layer_id), o,
                                              self.req_to_token_pool.req_to_token, self._pool_idx(forward_batch),
@@ -218,7 +254,7 @@ class HipAttnBackend(AttentionBackend):
         kernels.decode_attention(q3, self.token_to_kv_pool.get_key_buffer(layer.layer_id),
                                  self.token_to_kv_pool.get_value_buffer(layer.layer_id), o,
                                  self.req_to_token_pool.req_to_token, self._pool_idx(forward_batch), m.seq_lens_i32,
-                                 layer.scaling, m.num_splits, m.ws_acc, m.ws_ml, flags=self.debug_flags)
+                                 layer.scaling, m.num_splits, m.ws_acc, m.ws_ml, flags=self.debug_flags, **opt)
         return o.view(-1, layer.tp_q_head_num * layer.v_head_dim)
 
     def forward_mixed(self, q, k, v, layer, forward_batch, save_kv_cache: bool = True):

@@ -70,32 +70,57 @@ class ReqToTokenPool:
         self.free_slots = list(range(1, self._alloc_size))
 
 
+FP8_E4M3 = torch.float8_e4m3fn
+
+
 class MHATokenToKVPool:
-    """Multi-head K/V cache, NHD layout, bf16."""
+    """Multi-head K/V cache (memory_pool.py:1759-2456): bf16 or OCP e4m3 rows ("fp8_e4m3": K / k_scale and
+    V / v_scale, :2364-2374), NHD [slots, H_kv, D] or -- `use_hnd` with page_size > 1 -- HND
+    [pages, H_kv, page_size, D] (:2061-2117).  fp8 rows are stored as uint8 (`store_dtype`, :1800-1806)."""
 
     def __init__(self, size: int, page_size: int, dtype: torch.dtype, head_num: int, head_dim: int, layer_num: int,
                  device, enable_memory_saver: bool = False, v_head_dim: Optional[int] = None,
-                 start_layer: Optional[int] = None, end_layer: Optional[int] = None):
-        assert dtype == torch.bfloat16, "the gfx950 KV kernels are bf16"
+                 start_layer: Optional[int] = None, end_layer: Optional[int] = None, use_hnd: bool = False):
+        assert dtype in (torch.bfloat16, FP8_E4M3), "the gfx950 KV kernels read bf16 or OCP e4m3 rows"
         self.size = size
         self.page_size = page_size
         self.dtype = dtype
-        self.store_dtype = dtype
+        self.is_fp8 = dtype == FP8_E4M3
+        self.store_dtype = torch.uint8 if self.is_fp8 else dtype
         self.device = device
         self.head_num = head_num
         self.head_dim = head_dim
         self.v_head_dim = v_head_dim if v_head_dim is not None else head_dim
+        assert self.v_head_dim == head_dim, "K and V rows share one layout on this path"
         self.layer_num = layer_num
         self.start_layer = start_layer or 0
         self.end_layer = end_layer if end_layer is not None else layer_num - 1
+        self.use_hnd = bool(use_hnd) and page_size > 1          # at page_size 1 the two layouts coincide
         rows = size + page_size
-        # zero-filled so the sink page never holds NaN patterns
-        self._k_all = torch.zeros((layer_num, rows, head_num, head_dim), dtype=dtype, device=device)
-        self._v_all = torch.zeros((layer_num, rows, head_num, self.v_head_dim), dtype=dtype, device=device)
+        if self.use_hnd:
+            assert page_size & (page_size - 1) == 0, "HND pools need a power-of-two page_size"
+            shape = (layer_num, rows // page_size, head_num, page_size, head_dim)
+        else:
+            shape = (layer_num, rows, head_num, head_dim)
+        # zero-filled so the sink page never holds NaN patterns (0x00 is +0 in e4m3 too)
+        self._k_all = torch.zeros(shape, dtype=self.store_dtype, device=device)
+        self._v_all = torch.zeros(shape, dtype=self.store_dtype, device=device)
         self.k_buffer = [self._k_all[i] for i in range(layer_num)]
         self.v_buffer = [self._v_all[i] for i in range(layer_num)]
         self.row_dim = head_num * head_dim
         self.v_row_dim = head_num * self.v_head_dim
+
+    @property
+    def slot_stride(self) -> int:
+        """Elements between consecutive slots of an NHD pool (H_kv * D); unused by the HND formula."""
+        return self.head_num * self.head_dim
+
+    def kernel_format(self, layer=None):
+        """(kv_fp8, k_scale, v_scale, page_size, hnd) for the attention / store kernels.  Scales are the layer's
+        (RadixAttention.k_scale / v_scale, loaded from the checkpoint) or 1.0 (memory_pool.py:2364-2369)."""
+        ks = float(getattr(layer, "k_scale_float", None) or getattr(layer, "k_scale", None) or 1.0) if self.is_fp8 else 1.0
+        vs = float(getattr(layer, "v_scale_float", None) or getattr(layer, "v_scale", None) or 1.0) if self.is_fp8 else 1.0
+        return dict(kv_fp8=self.is_fp8, k_scale=ks, v_scale=vs, page_size=self.page_size, hnd=self.use_hnd)
 
     # -- accessors used by attention backends (memory_pool.py:2292-2329) -------
     def get_key_buffer(self, layer_id: int) -> torch.Tensor:
@@ -108,7 +133,8 @@ class MHATokenToKVPool:
         return self.get_key_buffer(layer_id), self.get_value_buffer(layer_id)
 
     def get_kv_size_bytes(self):
-        return self._k_all.numel() * 2, self._v_all.numel() * 2
+        es = self._k_all.element_size()
+        return self._k_all.numel() * es, self._v_all.numel() * es
 
     # -- writes (memory_pool.py:2331-2456) ---------------------------------------
     def set_kv_buffer(self, layer, loc_info, cache_k: torch.Tensor, cache_v: torch.Tensor, k_scale=None,
@@ -117,8 +143,17 @@ class MHATokenToKVPool:
 
         loc, _, _ = unwrap_write_loc(loc_info)
         layer_id = layer_id_override if layer_id_override is not None else layer.layer_id
-        if cache_k.dtype != self.dtype:
-            cache_k = cache_k.to(self.dtype)
-            cache_v = cache_v.to(self.dtype)
-        kernels.store_kv_cache(cache_k, cache_v, self.get_key_buffer(layer_id), self.get_value_buffer(layer_id),
-                               loc if loc.dtype == torch.int64 else loc.to(torch.int64))
+        if cache_k.dtype != torch.bfloat16:
+            cache_k = cache_k.to(torch.bfloat16)
+            cache_v = cache_v.to(torch.bfloat16)
+        loc = loc if loc.dtype == torch.int64 else loc.to(torch.int64)
+        if not self.is_fp8 and not self.use_hnd:
+            kernels.store_kv_cache(cache_k, cache_v, self.get_key_buffer(layer_id), self.get_value_buffer(layer_id), loc)
+            return
+        fmt = self.kernel_format(layer)
+        if k_scale is not None:
+            fmt["k_scale"] = float(k_scale)
+        if v_scale is not None:
+            fmt["v_scale"] = float(v_scale)
+        kernels.store_kv_cache(cache_k, cache_v, self.get_key_buffer(layer_id), self.get_value_buffer(layer_id), loc,
+                               num_kv_heads=self.head_num, head_dim=self.head_dim, **fmt)

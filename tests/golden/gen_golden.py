@@ -198,6 +198,15 @@ def gen_attention():
         cases[name] = dict(q=q, out_extend=o, q_decode=qd, out_decode=od, k_cache=k_cache, v_cache=v_cache,
                            req_to_token=req_to_token, req_pool_indices=req_pool, seq_lens=seq,
                            extend_prefix_lens=prefix, extend_seq_lens=extend, scaling=scaling)
+        # sliding-window layers (torch_native_backend.py:36-48,150-156,251-257): the same inputs with a window of 6
+        W = 6
+        ow, odw = torch.empty_like(q), torch.empty_like(qd)
+        backend = types.SimpleNamespace(_make_sliding_window_mask=tnb._make_sliding_window_mask)
+        tnb._run_sdpa_forward_extend(backend, q, ow, k_cache, v_cache, req_to_token, req_pool, seq, prefix, extend,
+                                     scaling=scaling, enable_gqa=Hq != Hkv, causal=True, sliding_window_size=W)
+        tnb._run_sdpa_forward_decode(backend, qd, odw, k_cache, v_cache, req_to_token, req_pool, seq,
+                                     scaling=scaling, enable_gqa=Hq != Hkv, causal=False, sliding_window_size=W)
+        cases[name].update(sliding_window=W, out_extend_window=ow, out_decode_window=odw)
     torch.save(cases, OUT / "attention_torch_native.pt")
 
 

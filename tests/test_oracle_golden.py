@@ -61,6 +61,35 @@ def test_attention_matches_reference(golden_dir):
                                   c["seq_lens"], c["extend_prefix_lens"], c["extend_seq_lens"], c["scaling"],
                                   compute_dtype=torch.float32)
         torch.testing.assert_close(o32.float(), c["out_extend"].float(), atol=2e-2, rtol=2e-2)
+        # sliding-window layers: the restated mask (k <= q and k >= q - W; decode keeps positions [len-1-W, len-1])
+        # against the REAL reference's _make_sliding_window_mask + SDPA (torch_native_backend.py:36-48,150-156,251-257).
+        # The restatement evaluates the masked form in fp32 and rounds once; the reference ran bf16 SDPA with an
+        # attn_mask: equal up to the bf16 rounding of the output.
+        W = c["sliding_window"]
+        ow = oo.extend_attention(c["q"], c["k_cache"], c["v_cache"], c["req_to_token"], c["req_pool_indices"], c["seq_lens"],
+                                 c["extend_prefix_lens"], c["extend_seq_lens"], c["scaling"], sliding_window=W)
+        torch.testing.assert_close(ow.float(), c["out_extend_window"].float(), atol=8e-3, rtol=8e-3)
+        dw = oo.decode_attention(c["q_decode"], c["k_cache"], c["v_cache"], c["req_to_token"], c["req_pool_indices"],
+                                 c["seq_lens"], c["scaling"], sliding_window=W)
+        torch.testing.assert_close(dw.float(), c["out_decode_window"].float(), atol=8e-3, rtol=8e-3)
+        assert not torch.allclose(ow.float(), c["out_extend"].float(), atol=1e-2)      # the window really bites here
+
+
+def test_fp8_kv_quantisation_restatement():
+    """memory_pool.py:2364-2374: rows hold (K / k_scale) cast to float8_e4m3fn; the attention sees them times the scale."""
+    g = torch.Generator().manual_seed(2)
+    x = (torch.randn((64, 2, 64), generator=g) * 3).to(torch.bfloat16)
+    q = oo.quantize_kv_fp8(x, 0.5)
+    assert q.dtype == torch.float8_e4m3fn
+    back = q.float() * 0.5
+    rel = ((back - x.float()).abs() / x.float().abs().clamp_min(0.05)).max()
+    assert float(rel) < 2.0 ** -3                      # 3 significand bits: half an ulp = 2^-4 relative, plus the bf16 divide
+    # literal reference arithmetic: cache_k.div_(k_scale) on the bf16 tensor, then .to(dtype)
+    lit = x.clone(); lit.div_(0.5)
+    assert torch.equal(lit.to(torch.float8_e4m3fn).view(torch.uint8), q.view(torch.uint8))
+    # saturation instead of NaN beyond the e4m3 range
+    big = torch.tensor([1000.0, -1000.0, 448.0], dtype=torch.bfloat16)
+    assert oo.quantize_kv_fp8(big).float().tolist() == [448.0, -448.0, 448.0]
 
 
 def test_norm_rope_match_reference(golden_dir):
