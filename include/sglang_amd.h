@@ -370,6 +370,19 @@ int sgl_amd_extend_attention_ex(const void* q, void* out, const void* k_cache, c
                                 int sliding_window, float logit_cap, const void* custom_mask, const int64_t* mask_indptr,
                                 void* stream);
 
+/* ---- row-tiled grouped GEMM for prefill-sized MoE batches (reference: fused_moe_triton_kernels.py:324,771 with
+ *      BLOCK_SIZE_M >= 64; fused_experts, triton_utils/fused_moe.py:242-455) -------------------------------------
+ * Same contract as sgl_amd_wstream_moe_gemm, with the moe_align block size fixed at sgl_amd_moe_tiled_gemm_block_m()
+ * (128): a 128-row x 128-column MFMA tile per workgroup, both operands staged in LDS, so an expert's weights are
+ * read once per 128 of its rows.  fuse_silu: w is [E, 2N, K] (gate rows, then up rows), c [num_valid_ids, N] bf16 =
+ * silu(gate) * up.  Needs K %% 64 == 0, N %% 4 == 0 (N %% 32 == 0 with fuse_silu). */
+int sgl_amd_moe_tiled_gemm_block_m(void);
+int sgl_amd_moe_tiled_gemm(const void* a, const void* w, void* c, const int32_t* sorted_token_ids, const int32_t* expert_ids,
+                           const int32_t* num_tokens_post_padded, const float* topk_weights, int mul_routed_weight,
+                           int round_before_scale, int top_k_div, int64_t num_valid_ids, int64_t N, int64_t K,
+                           int64_t a_row_stride, int64_t w_row_stride, int64_t w_expert_stride, int64_t c_row_stride,
+                           int64_t max_m_blocks, int fuse_silu, int out_f32, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,243 @@
+// Row-tiled grouped GEMM for prefill-sized MoE batches on gfx950 (MFMA bound form).
+//
+// Replaces (reference, /root/reference/python/sglang):
+//   srt/layers/moe/moe_runner/triton_utils/fused_moe_triton_kernels.py:324 fused_moe_kernel, :771
+//   invoke_fused_moe_kernel with BLOCK_SIZE_M >= 64 (the tuned configs of fused_moe_triton/configs/*.json), called
+//   twice by fused_experts (triton_utils/fused_moe.py:242-455): up projection (+ silu_and_mul) and down projection
+//   (x router weight).  Oracle: srt/layers/moe/fused_moe_native.py:61-164 (oracle/ops.py moe_forward).
+//
+// The weight-streaming form (wstream_gemm.hip) reads an expert's weights once per 16..64-row block: right for decode,
+// where every expert sees a handful of rows, ruinous for prefill, where an expert owns ~1000 rows and would stream its
+// 100+ MB sixteen times.  Here a workgroup owns a 128 (rows of ONE expert) x 128 (output columns) tile and walks K in
+// 64-wide steps with both operands staged in LDS:
+//   * rows are gathered through sorted_token_ids (moe_align_block_size with block 128), weights of expert
+//     expert_ids[block]; both tiles go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave
+//     instruction), two tiles deep, the XOR swizzle applied on the global side so the fragment reads
+//     (ds_read_b128) are conflict-free;
+//   * 4 waves as 2 (rows) x 2 (columns), each 64 x 64 = 4 x 4 MFMA 16x16x32 tiles, computed transposed
+//     (C^T = W x^T) so a lane ends up with 4 consecutive output columns of one token: 8-byte stores;
+//   * up projection: the 128 weight rows of a tile are [32 gate | 32 up] x 2 halves, so every wave holds the gate
+//     and the up value of the same (token, column) in the same lane and applies silu(gate) * up in registers
+//     (torch-native rounding points: activation.py:141-143) -- the [rows, 2N] intermediate never exists;
+//   * down projection: fp32(bf16(acc)) x router weight into the fp32 buffer moe_sum_reduce adds up
+//     (fused_moe_native.py:157-163).
+#include "common.hpp"
+#include "sglang_amd.h"
+
+using namespace sgl_amd;
+
+namespace {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __attribute__((address_space(3))) unsigned char* lds_bytes_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+constexpr int kBM = 128, kBN = 128, kBK = 64;
+constexpr int kTileBytes = kBM * kBK * 2;          // 16 KiB per operand tile
+constexpr int kThreads = 256;
+
+struct TiledParams {
+  const uint16_t* a;            // [rows, K]
+  const uint16_t* w;            // [E, WN, K]   (WN = 2N for the up projection)
+  void* c;                      // [num_valid_ids, N] bf16 or fp32
+  const int32_t* sorted_ids;    // [>= blocks * 128] pair ids, padding >= num_valid
+  const int32_t* expert_ids;    // [blocks]
+  const int32_t* num_post_pad;  // [1]
+  const float* row_scale;       // optional [num_valid_ids]
+  int64_t a_stride, w_row_stride, w_expert_stride, c_stride;
+  int num_valid, N, K, topk_div;
+  int fuse_silu, out_f32, round_before_scale;
+};
+
+__device__ __forceinline__ void dma16(const uint16_t* src, lds_ptr_t dst) {
+  __builtin_amdgcn_global_load_lds((glb_ptr_t)(src), dst, 16, 0, 0);
+}
+template <int OFF>
+__device__ __forceinline__ u32x4_t lds_rd(uint32_t addr) {
+  u32x4_t v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int N>
+__device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N)); }
+__device__ __forceinline__ void pin(u32x4_t& v) { asm volatile("" : "+v"(v)); }
+
+__global__ __launch_bounds__(kThreads, 2) void moe_tiled_gemm_kernel(TiledParams p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * 2 * kTileBytes];   // [buf][A | B]
+  const int rb = blockIdx.y;
+  if (rb * kBM >= p.num_post_pad[0]) return;
+  const int e = p.expert_ids[rb];
+  if (e < 0) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;               // this wave's 64-row / 64-column quadrant
+  const int r16 = lane & 15, g = lane >> 4;
+  const int nt0 = blockIdx.x;                          // output-column tile (64 columns when fused, 128 otherwise)
+  const uint16_t* wbase = p.w + static_cast<int64_t>(e) * p.w_expert_stride;
+
+  // ---- DMA roles: instruction j of a tile covers its rows 8j .. 8j+7; lane i -> (row 8j + i/8, LDS slot i%8) and
+  // fetches global 16-byte piece (slot ^ (row & 7)) of that row.  Wave w issues j = 4w .. 4w+3 of A and of B.
+  const int dr = lane >> 3, ds = lane & 7;
+  const uint16_t* asrc[4];
+  const uint16_t* bsrc[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int row = (wid * 4 + u) * 8 + dr;            // 0..127
+    const int piece = (ds ^ (row & 7)) * 8;
+    const int id = p.sorted_ids[rb * kBM + row];
+    const int srow = id < p.num_valid ? id / p.topk_div : 0;     // padding rows read row 0, their outputs are dropped
+    asrc[u] = p.a + static_cast<int64_t>(srow) * p.a_stride + piece;
+    int wrow;
+    if (p.fuse_silu) {
+      // tile rows: [32 gate | 32 up] for column half 0, then for half 1; output columns nt0 * 64 + half * 32 + c
+      const int half = row >> 6, in = row & 63;
+      const int col = nt0 * 64 + half * 32 + (in & 31);
+      wrow = (in < 32 ? 0 : p.N) + (col < p.N ? col : p.N - 1);
+    } else {
+      const int col = nt0 * kBN + row;
+      wrow = col < p.N ? col : p.N - 1;
+    }
+    bsrc[u] = wbase + static_cast<int64_t>(wrow) * p.w_row_stride + piece;
+  }
+  lds_bytes_t sm3 = (lds_bytes_t)(smem);
+  auto issue = [&](int kt, int buf) {
+    const int koff = kt * kBK;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) dma16(asrc[u] + koff, (lds_ptr_t)(sm3 + buf * 2 * kTileBytes + (wid * 4 + u) * 1024));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) dma16(bsrc[u] + koff, (lds_ptr_t)(sm3 + buf * 2 * kTileBytes + kTileBytes + (wid * 4 + u) * 1024));
+  };
+
+  // ---- fragment addresses: row r of a tile at r * 128 bytes, piece pc in slot pc ^ (r & 7) ----
+  const uint32_t sm_addr = (uint32_t)(uintptr_t)(sm3);
+  uint32_t foff[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) foff[kk] = r16 * 128 + (((kk * 4 + g) ^ (r16 & 7)) & 7) * 16;
+  const uint32_t a_quad = wm * 64 * 128;               // this wave's rows of the A tile
+  const uint32_t b_quad = kTileBytes + wn * 64 * 128;  // and of the B tile
+
+  f32x4_t acc[4][4];                                   // [weight 16-row tile][token 16-row tile]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / kBK;
+  issue(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) {
+      issue(kt + 1, buf ^ 1);                          // every wave finished reading that buffer before the last barrier
+      wait_vm<8>();                                    // tile kt landed (the 8 pieces of tile kt + 1 may still fly)
+    } else {
+      wait_vm<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    const uint32_t base = sm_addr + buf * 2 * kTileBytes;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      u32x4_t wf[4], xf[4];
+      const uint32_t ad = base + foff[kk];
+      wf[0] = lds_rd<0>(ad + b_quad); wf[1] = lds_rd<2048>(ad + b_quad); wf[2] = lds_rd<4096>(ad + b_quad); wf[3] = lds_rd<6144>(ad + b_quad);
+      xf[0] = lds_rd<0>(ad + a_quad); xf[1] = lds_rd<2048>(ad + a_quad); xf[2] = lds_rd<4096>(ad + a_quad); xf[3] = lds_rd<6144>(ad + a_quad);
+      wait_lgkm<0>();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { pin(wf[i]); pin(xf[i]); }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[i]), __builtin_bit_cast(bf16x8_t, xf[j]),
+                                                              acc[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_barrier();                      // all reads of `buf` done before iteration kt + 1 refills it
+  }
+
+  // ---- epilogue: lane holds C^T[n = 16 i + 4 g + r][m = 16 j + r16] ----
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = wm * 64 + j * 16 + r16;
+    const int id = p.sorted_ids[rb * kBM + row];
+    if (id >= p.num_valid) continue;
+    const float scale = p.row_scale ? p.row_scale[id] : 1.f;
+    if (p.fuse_silu) {
+      // weight tiles 0,1 = gate columns [0,32) of this wave's half, tiles 2,3 = the matching up columns
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int col = nt0 * 64 + wn * 32 + i * 16 + g * 4;
+        if (col >= p.N) continue;
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float gb = rbf(acc[i][j][r]);
+          const float sl = rbf(gb / (1.0f + expf(-gb)));
+          o[r] = sl * rbf(acc[i + 2][j][r]);
+        }
+        uint2 w2;
+        w2.x = pack_bf2(o[0], o[1]); w2.y = pack_bf2(o[2], o[3]);
+        *reinterpret_cast<uint2*>(static_cast<uint16_t*>(p.c) + static_cast<int64_t>(id) * p.c_stride + col) = w2;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int col = nt0 * kBN + wn * 64 + i * 16 + g * 4;
+        if (col >= p.N) continue;
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = acc[i][j][r];
+          o[r] = p.row_scale ? (p.round_before_scale ? rbf(v) : v) * scale : v;
+        }
+        if (p.out_f32) {
+          *reinterpret_cast<f32x4_t*>(static_cast<float*>(p.c) + static_cast<int64_t>(id) * p.c_stride + col) = f32x4_t{o[0], o[1], o[2], o[3]};
+        } else {
+          uint2 w2;
+          w2.x = pack_bf2(o[0], o[1]); w2.y = pack_bf2(o[2], o[3]);
+          *reinterpret_cast<uint2*>(static_cast<uint16_t*>(p.c) + static_cast<int64_t>(id) * p.c_stride + col) = w2;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int sgl_amd_moe_tiled_gemm_block_m(void) { return kBM; }
+
+int sgl_amd_moe_tiled_gemm(const void* a, const void* w, void* c, const int32_t* sorted_token_ids, const int32_t* expert_ids,
+                           const int32_t* num_tokens_post_padded, const float* topk_weights, int mul_routed_weight,
+                           int round_before_scale, int top_k_div, int64_t num_valid_ids, int64_t N, int64_t K,
+                           int64_t a_row_stride, int64_t w_row_stride, int64_t w_expert_stride, int64_t c_row_stride,
+                           int64_t max_m_blocks, int fuse_silu, int out_f32, void* stream) {
+  SGL_CLEAR_STALE_ERROR();
+  SGL_CHECK_ARG(N > 0 && N % 4 == 0 && K >= kBK && K % kBK == 0, "moe_tiled_gemm: need N %% 4 == 0 and K %% %d == 0 (got N=%lld K=%lld)",
+                kBK, (long long)N, (long long)K);
+  SGL_CHECK_ARG(!fuse_silu || N % 32 == 0, "moe_tiled_gemm: the silu form needs N %% 32 == 0");
+  SGL_CHECK_ARG(a_row_stride % 8 == 0 && w_row_stride % 8 == 0 && c_row_stride % 4 == 0,
+                "moe_tiled_gemm: row strides must keep 16-byte (a, w) / 8-byte (c) alignment");
+  SGL_CHECK_ARG(top_k_div >= 1 && max_m_blocks <= 65535, "moe_tiled_gemm: bad top_k_div / too many row blocks");
+  SGL_CHECK_ARG(!mul_routed_weight || topk_weights, "moe_tiled_gemm: mul_routed_weight needs topk_weights");
+  SGL_CHECK_ARG(!(fuse_silu && out_f32), "moe_tiled_gemm: the silu form writes bf16");
+  if (max_m_blocks == 0 || num_valid_ids == 0) return 0;
+  TiledParams p{};
+  p.a = static_cast<const uint16_t*>(a); p.w = static_cast<const uint16_t*>(w); p.c = c;
+  p.sorted_ids = sorted_token_ids; p.expert_ids = expert_ids; p.num_post_pad = num_tokens_post_padded;
+  p.row_scale = mul_routed_weight ? topk_weights : nullptr;
+  p.a_stride = a_row_stride; p.w_row_stride = w_row_stride; p.w_expert_stride = w_expert_stride; p.c_stride = c_row_stride;
+  p.num_valid = static_cast<int>(num_valid_ids); p.N = static_cast<int>(N); p.K = static_cast<int>(K); p.topk_div = top_k_div;
+  p.fuse_silu = fuse_silu; p.out_f32 = out_f32; p.round_before_scale = round_before_scale;
+  const int cols_per_tile = fuse_silu ? 64 : kBN;
+  dim3 grid(static_cast<unsigned>((N + cols_per_tile - 1) / cols_per_tile), static_cast<unsigned>(max_m_blocks));
+  hipLaunchKernelGGL(moe_tiled_gemm_kernel, grid, dim3(kThreads), 0, as_stream(stream), p);
+  SGL_CHECK_LAUNCH("moe_tiled_gemm");
+  return 0;
+}
+
+}  // extern "C"

@@ -684,6 +684,41 @@ def moe_wstream_gemm(a: torch.Tensor, w: torch.Tensor, c: torch.Tensor, sorted_t
     return c
 
 
+def moe_tiled_gemm_block_m() -> int:
+    return native.lib().sgl_amd_moe_tiled_gemm_block_m()
+
+
+def moe_tiled_gemm(a: torch.Tensor, w: torch.Tensor, c: torch.Tensor, sorted_token_ids: torch.Tensor,
+                   expert_ids: torch.Tensor, num_tokens_post_padded: torch.Tensor, topk_weights: Optional[torch.Tensor],
+                   mul_routed_weight: bool, top_k_div: int, num_valid_ids: int, block_m: int, fuse_silu: bool = False,
+                   round_before_scale: bool = False) -> torch.Tensor:
+    """moe_grouped_gemm on the row-tiled MFMA kernel (prefill-sized batches): block_m must be
+    moe_tiled_gemm_block_m(); a [rows, K] bf16, w [E, N(or 2N), K] bf16, c [num_valid_ids, N] bf16 or fp32."""
+    _dev(a, w, c, sorted_token_ids, expert_ids, num_tokens_post_padded)
+    _need(block_m == moe_tiled_gemm_block_m(), "moe_tiled_gemm: the align block size must be moe_tiled_gemm_block_m()")
+    _need(a.dtype == _BF16 and w.dtype == _BF16 and w.dim() == 3 and c.dtype in (_BF16, torch.float32) and c.dim() == 2,
+          "moe_tiled_gemm: bf16 a / w[E,N,K], c bf16 / fp32")
+    _need(sorted_token_ids.dtype == torch.int32 and expert_ids.dtype == torch.int32
+          and num_tokens_post_padded.dtype == torch.int32, "moe_tiled_gemm: int32 metadata")
+    E, WN, K = w.shape
+    N = WN // 2 if fuse_silu else WN
+    _need(a.shape[1] == K and c.shape[1] == N and a.stride(1) == 1 and w.stride(2) == 1 and c.stride(1) == 1,
+          "moe_tiled_gemm: shapes / contiguity")
+    max_m_blocks = expert_ids.numel()
+    _need(sorted_token_ids.numel() >= max_m_blocks * block_m, "moe_tiled_gemm: sorted_token_ids too short")
+    if mul_routed_weight:
+        _need(topk_weights is not None and topk_weights.dtype == torch.float32 and topk_weights.is_contiguous(),
+              "moe_tiled_gemm: fp32 topk_weights")
+    native.call("sgl_amd_moe_tiled_gemm", a.data_ptr(), w.data_ptr(), c.data_ptr(), sorted_token_ids.data_ptr(),
+                expert_ids.data_ptr(), num_tokens_post_padded.data_ptr(), _ptr(topk_weights), 1 if mul_routed_weight else 0,
+                1 if round_before_scale else 0, top_k_div, num_valid_ids, N, K, a.stride(0), w.stride(1), w.stride(0),
+                c.stride(0), max_m_blocks, 1 if fuse_silu else 0, 1 if c.dtype == torch.float32 else 0, _stream())
+    return c
+
+
+MOE_TILED_MIN_ROWS_PER_EXPERT = 96     # above this an expert fills most of a 128-row tile: the MFMA-bound form wins
+
+
 def moe_grouped_gemm(a: torch.Tensor, w: torch.Tensor, c: torch.Tensor, sorted_token_ids: torch.Tensor,
                      expert_ids: torch.Tensor, num_tokens_post_padded: torch.Tensor,
                      topk_weights: Optional[torch.Tensor], mul_routed_weight: bool, top_k_div: int, num_valid_ids: int,
@@ -796,6 +831,17 @@ def fused_experts(hidden_states: torch.Tensor, w13: torch.Tensor, w2: torch.Tens
     if out is None:
         out = torch.empty((M, K), dtype=_BF16, device=dev)
     if M == 0:
+        return out
+    if numel // E >= MOE_TILED_MIN_ROWS_PER_EXPERT and K % 64 == 0 and N % 64 == 0:
+        # prefill-sized batch: 128-row MFMA tiles, every expert's weights read once per 128 of its rows
+        block_m = moe_tiled_gemm_block_m()
+        sorted_ids, expert_ids, post = moe_align_block_size(topk_ids, block_m, E)
+        inter = torch.empty((numel, N), dtype=_BF16, device=dev)
+        moe_tiled_gemm(hidden_states, w13, inter, sorted_ids, expert_ids, post, None, False, topk, numel, block_m, fuse_silu=True)
+        down = torch.empty((numel, K), dtype=torch.float32, device=dev)
+        moe_tiled_gemm(inter, w2, down, sorted_ids, expert_ids, post, topk_weights.reshape(-1).contiguous(), True, 1, numel,
+                       block_m, round_before_scale=True)
+        moe_sum_reduce(down.view(M, topk, K), out, routed_scaling_factor)
         return out
     block_m = choose_moe_block_m(numel, E)
     sorted_ids, expert_ids, post = moe_align_block_size(topk_ids, block_m, E)

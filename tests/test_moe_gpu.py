@@ -206,3 +206,42 @@ def test_wstream_moe_gemm_row_gather_scale_and_silu(device, M, E, k, N, Kd, bm):
     ref = oo.silu_and_mul(c_plain.cpu())
     d = (c_silu.cpu().float() - ref.float()).abs()
     assert float((d > 0).float().mean()) < 0.005 and bool((d <= ref.float().abs() * 2.0 ** -7 + 1e-6).all())
+
+
+@pytest.mark.parametrize("M,E,k,N,Kd", [(900, 8, 2, 512, 1024), (2048, 8, 2, 7168, 4096), (1500, 4, 1, 320, 192)])
+def test_fused_experts_prefill_sized_batches_take_the_tiled_form(device, M, E, k, N, Kd):
+    """>= 96 rows per expert: the row-tiled MFMA grouped GEMM (moe_tiled_gemm.hip, 128-row tiles) with the
+    silu_and_mul epilogue and the router-weighted fp32 down projection; (2048, 8, 2, 7168, 4096) is one TP=2 rank of
+    Mixtral-8x7B at a prefill batch.  The reference arithmetic (fused_moe_native.py:61-164) runs on the GPU here."""
+    K = _k()
+    assert M * k // E >= K.MOE_TILED_MIN_ROWS_PER_EXPERT
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn((M, Kd), generator=g).to(BF).to(device)
+    w13 = (torch.randn((E, 2 * N, Kd), generator=g) * 0.03).to(BF).to(device)
+    w2 = (torch.randn((E, Kd, N), generator=g) * 0.03).to(BF).to(device)
+    logits = torch.randn((M, E), generator=g).to(device)
+    tw, ti = oo.fused_topk(logits, k, True)
+    out = K.fused_experts(x, w13, w2, tw, ti)
+    want = oo.moe_forward(x, w13, w2, tw, ti)
+    _moe_check(out.cpu(), want.cpu())
+
+
+def test_tiled_grouped_gemm_row_gather_and_scale(device):
+    """The tiled grouped GEMM alone vs a per-pair loop: gather a[id // topk], scatter to c[id], router weight, ragged
+    expert loads incl. an expert with no rows, N not a multiple of the tile."""
+    K = _k()
+    g = torch.Generator().manual_seed(8)
+    M, E, k, N, Kd = 700, 6, 2, 200, 256
+    bm = K.moe_tiled_gemm_block_m()
+    a = torch.randn((M, Kd), generator=g).to(BF)
+    w = (torch.randn((E, N, Kd), generator=g) * 0.05).to(BF)
+    ids = torch.argsort(torch.rand((M, E - 1), generator=g), dim=1)[:, :k].to(torch.int32)      # expert E-1 gets nothing
+    tw = torch.rand((M, k), generator=g)
+    s, e, post = K.moe_align_block_size(ids.to(device), bm, E)
+    for out_dtype in (BF, torch.float32):
+        c = torch.zeros((M * k, N), dtype=out_dtype, device=device)
+        K.moe_tiled_gemm(a.to(device), w.to(device), c, s, e, post, tw.reshape(-1).to(device), True, k, M * k, bm)
+        want = (torch.einsum("ik,ink->in", a.double()[torch.arange(M * k) // k], w.double()[ids.flatten().long()]).float()
+                * tw.flatten()[:, None])
+        d = (c.cpu().float() - want).abs()
+        assert bool((d <= want.abs() * 2.0 ** -7 + 1e-3).all()), float(d.max())
