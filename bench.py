@@ -422,6 +422,35 @@ def kernel_rooflines(args, cfg, runner, result, B, G, P, in_len, ctx, t_decode_s
                               "shape": {"M": Mg, "N": wN, "K": wK, "waves_per_group": nw_s[0], "k_splits": nw_s[1]},
                               "share_of_decode_step": len(mlps) * t_g / t_decode_step}
 
+    # (1b) mixture-of-experts models: the dominant kernels are the two grouped expert GEMMs of fused_experts at the
+    # decode batch (align -> up + silu -> down x router weight -> sum): bytes = the experts hit x their three matrices
+    moes = [layer.mlp.experts for layer in runner.model.layers if hasattr(layer.mlp, "experts")]
+    if moes:
+        Mg = min(B, 64)
+        xg = torch.randn((Mg, cfg.hidden_size), device=dev).to(torch.bfloat16)
+        tw, ti = K.topk_softmax(torch.randn((Mg, cfg.num_local_experts), device=dev), cfg.num_experts_per_tok, True)
+        hit = int(torch.unique(ti).numel())
+        t_m = graph_time(lambda: [K.fused_experts(xg, m.w13_weight.data, m.w2_weight.data, tw, ti) for m in moes], len(moes))
+        E_, N2, Kd = moes[0].w13_weight.shape
+        alg = hit * (N2 * Kd + Kd * (N2 // 2)) * 2 + Mg * Kd * 2 * 2
+        result["roofline"] = {"bound": "hbm", "achieved": alg / t_m / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                              "frac": alg / t_m / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                              "kernel": "fused_experts at the decode batch: moe_align + wstream grouped up-GEMM (silu_and_mul "
+                                        "epilogue) + grouped down-GEMM (x router weight) + moe_sum_reduce",
+                              "us_per_launch": t_m * 1e6, "bytes_per_launch": alg,
+                              "shape": {"M": Mg, "experts": E_, "experts_hit": hit, "top_k": cfg.num_experts_per_tok,
+                                        "N": N2 // 2, "K": Kd},
+                              "share_of_decode_step": len(moes) * t_m / t_decode_step}
+        # and at a prefill batch: the row-tiled MFMA form
+        Mp = 4096
+        xp = torch.randn((Mp, cfg.hidden_size), device=dev).to(torch.bfloat16)
+        twp, tip = K.topk_softmax(torch.randn((Mp, cfg.num_local_experts), device=dev), cfg.num_experts_per_tok, True)
+        t_p = graph_time(lambda: K.fused_experts(xp, moes[0].w13_weight.data, moes[0].w2_weight.data, twp, tip), 1, reps=3)
+        fl = Mp * cfg.num_experts_per_tok * 3 * (N2 // 2) * Kd * 2
+        result["moe_prefill_mfma"] = {"kernel": "moe_tiled_gemm_kernel (128 x 128 MFMA tiles) x 2 + moe_sum_reduce", "M": Mp,
+                                      "ms": t_p * 1e3, "achieved": fl / t_p / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": fl / t_p / 1e12 / MFMA_PEAK_TFLOPS}
+
     # (2) decode attention over the workload's own slot pattern (shared prefix rows + private rows)
     from sglang_amd.layers.attention.hip_backend import choose_num_splits
 
@@ -484,15 +513,15 @@ def kernel_rooflines(args, cfg, runner, result, B, G, P, in_len, ctx, t_decode_s
                      "shape": {"requests": nreq, "extend": e, "prefix": pre}}
     rec = pmc_kernel(pmc, "prefill_cold", "extend_attention_kernel")
     if rec and rec.get("GRBM_GUI_ACTIVE") and rec.get("SQ_VALU_MFMA_BUSY_CYCLES") is not None:
-        # busy cycles are summed over the chip's 256 CUs x 4 SIMDs (gfx94x MfmaUtil formula, MICROARCH "PMC slots")
-        ext["mfma_util_pmc"] = rec["SQ_VALU_MFMA_BUSY_CYCLES"] / (rec["GRBM_GUI_ACTIVE"] * 256 * 4)
+        # busy SIMD-cycles / (active cycles per XCD x 1024 SIMDs); GRBM_GUI_ACTIVE is summed over the 8 XCDs on gfx950
+        ext["mfma_util_pmc"] = rec["SQ_VALU_MFMA_BUSY_CYCLES"] * 8 / (rec["GRBM_GUI_ACTIVE"] * 1024)
         ext["pmc"] = {k: rec[k] for k in rec if k != "dispatches"}
     result["prefill_mfma"]["extend_attention_kernel"] = ext
     whole = pmc.get("phases", {}).get("prefill_cold", {}) if pmc else {}
     if whole.get("mfma_util") is not None:
         result["prefill_mfma"]["mfma_util"] = whole["mfma_util"]
         result["prefill_mfma"]["mfma_util_source"] = ("profiles/r02_pmc.json: sum of SQ_VALU_MFMA_BUSY_CYCLES over the "
-                                                      "cold prefill's dispatches / (sum of GRBM_GUI_ACTIVE x 256 CUs x 4 SIMDs)")
+                                                      "cold prefill's dispatches / (sum of GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)")
 
 
 def cpu_baseline(args, cfg, runner, prompts):

@@ -66,7 +66,8 @@ def main(out_path, model, batch, decode_steps, dirs):
             if p == "decode":
                 ph["hbm_bytes_per_step"] = ph["hbm_bytes"] / int(decode_steps)
         if tot.get("GRBM_GUI_ACTIVE") and "SQ_VALU_MFMA_BUSY_CYCLES" in tot:
-            ph["mfma_util"] = tot["SQ_VALU_MFMA_BUSY_CYCLES"] / (tot["GRBM_GUI_ACTIVE"] * 256 * 4)
+            # GRBM_GUI_ACTIVE is summed over the 8 XCDs on gfx950: busy SIMD-cycles / (active cycles per XCD x 1024 SIMDs)
+            ph["mfma_util"] = tot["SQ_VALU_MFMA_BUSY_CYCLES"] * 8 / (tot["GRBM_GUI_ACTIVE"] * 1024)
         out["phases"][p] = ph
     json.dump(out, open(out_path, "w"), indent=1)
     for p, ph in out["phases"].items():
