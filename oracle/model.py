@@ -62,11 +62,11 @@ class OracleLM:
 
     # ---- one forward over a ragged batch --------------------------------------------------
     def forward(self, input_ids: torch.Tensor, positions: torch.Tensor, req_pool: torch.Tensor, seq_lens: torch.Tensor,
-                prefix_lens: torch.Tensor, extend_lens: torch.Tensor, out_loc: torch.Tensor, decode: bool
-                ) -> torch.Tensor:
+                prefix_lens: torch.Tensor, extend_lens: torch.Tensor, out_loc: torch.Tensor, decode: bool,
+                input_embeds: Optional[torch.Tensor] = None) -> torch.Tensor:
         cfg, w = self.cfg, self.w
         D, Hq, Hkv = cfg.head_dim, self.Hq, self.Hkv
-        h = F.embedding(input_ids, w["embed_tokens"])
+        h = input_embeds if input_embeds is not None else F.embedding(input_ids, w["embed_tokens"])
         residual = None
         for i in range(cfg.num_hidden_layers):
             p = f"layers.{i}."
@@ -123,7 +123,8 @@ class OracleLM:
     # ---- greedy generation with prefix reuse expressed the plain way ------------------------
     def generate(self, prompts: Sequence[Sequence[int]], max_new_tokens: int, return_logits: bool = False,
                  forced: Optional[Sequence[Sequence[int]]] = None, logits_hook=None,
-                 share_prefix_groups: Optional[Sequence[Sequence[int]]] = None, shared_len: int = 0):
+                 share_prefix_groups: Optional[Sequence[Sequence[int]]] = None, shared_len: int = 0,
+                 prompt_embeds: Optional[Sequence[Optional[torch.Tensor]]] = None):
         """Every request gets its own fresh slots (no sharing): the reference result the
         radix-cached run must reproduce.  `forced[b][i]` (teacher forcing) replaces the
         oracle's own i-th sampled token as the next input, so logits can be compared
@@ -159,10 +160,18 @@ class OracleLM:
                 self.req_to_token[b + 1, pre: pre + ext] = out_loc[off: off + ext].to(torch.int32)
                 off += ext
             ids = torch.tensor([t for b, pre in zip(members, pre_l) for t in prompts[b][pre:]], device=dev)
+            emb = None
+            if prompt_embeds is not None:
+                # image + text prompts: the caller supplies the whole prompt's embeddings (oracle/vision.py
+                # embed_with_images); ids of image positions are pad values outside the vocabulary
+                vocab = self.w["embed_tokens"].shape[0]
+                emb = torch.cat([(prompt_embeds[b][pre:].to(dev) if prompt_embeds[b] is not None
+                                  else F.embedding(torch.tensor(prompts[b][pre:], device=dev).clamp(0, vocab - 1), self.w["embed_tokens"]))
+                                 for b, pre in zip(members, pre_l)]).to(self.w["embed_tokens"].dtype)
             pos = torch.cat([torch.arange(pre, pre + ext, device=dev) for pre, ext in zip(pre_l, ext_l)])
             midx = torch.tensor(members, device=dev)
             logits[midx] = self.forward(ids, pos, req_pool[midx], lens[midx], torch.tensor(pre_l, device=dev),
-                                        torch.tensor(ext_l, device=dev), out_loc, decode=False)
+                                        torch.tensor(ext_l, device=dev), out_loc, decode=False, input_embeds=emb)
         all_logits = []
         if logits_hook is not None:
             logits_hook(0, logits)

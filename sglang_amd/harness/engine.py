@@ -56,6 +56,7 @@ class Req:
     cached_tokens: int = 0
     fill_len: int = 0            # chunked prefill: tokens of the prompt committed so far (0 = not truncated)
     retracted_output_ids: List[int] = field(default_factory=list)   # outputs folded into the prompt by a retraction
+    mm_items: Optional[List[Any]] = None   # images of the request (harness/llava.py MultimodalItem); prompt ids hold their pad values
 
     @property
     def all_output_ids(self) -> List[int]:
@@ -88,7 +89,7 @@ class ModelRunner:
     def __init__(self, config: ModelConfig, *, max_total_tokens: int, max_running_requests: int,
                  max_context_len: int, page_size: int = 1, device=None, init_device=None,
                  use_graph: bool = True, graph_max_bs: Optional[int] = None, disable_radix_cache: bool = False,
-                 strict_graph: bool = False, kv_cache_dtype: str = "auto", use_hnd: bool = False):
+                 strict_graph: bool = False, kv_cache_dtype: str = "auto", use_hnd: bool = False, vision_config=None):
         self.config = config
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         if self.device.type == "cuda":
@@ -99,6 +100,11 @@ class ModelRunner:
         self.tp_size = ps.get_tensor_model_parallel_world_size()
         self.page_size = page_size
         self.model = CausalLM(config, self.device, init_device, self.tp_rank, self.tp_size)
+        self.vision = None
+        if vision_config is not None:            # LLaVA: CLIP tower + projector in front of the language model
+            from .llava import LlavaVision
+
+            self.vision = LlavaVision(vision_config, config.hidden_size, self.device, init_device)
         self.num_attention_heads_per_rank = self.model.num_attention_heads_per_rank
         self.num_kv_heads_per_rank = self.model.num_kv_heads_per_rank
         self.head_dim = config.head_dim
@@ -161,6 +167,16 @@ class Engine:
         self.logits_trace: Optional[List[torch.Tensor]] = None   # tests: set to [] to record every step's logits
         self.logits_device_trace: Optional[List[torch.Tensor]] = None   # same, kept on the device in the model dtype
         self.logits_by_req: Optional[Dict[int, List[torch.Tensor]]] = None  # tests: {} -> per request, one row per sampled token
+
+    def _mm_embeds(self, reqs, input_ids, prefix_lens, extend_lens):
+        """Image + text batches: the extend tokens' embeddings with the image features scattered over the pad-value
+        positions (mm_utils.py:463-503); None for text-only batches."""
+        if self.r.vision is None or not any(getattr(q, "mm_items", None) for q in reqs):
+            return None
+        from .llava import embed_mm_inputs
+
+        return embed_mm_inputs(input_ids, self.r.model.embed_tokens.data, [getattr(q, "mm_items", None) for q in reqs],
+                               prefix_lens, extend_lens, self.r.vision)
 
     def _record_logits(self, logits, reqs=None, sampled=None) -> None:
         if self.logits_trace is not None:
@@ -234,6 +250,7 @@ class Engine:
                                    req_to_token_pool=r.req_to_token_pool, token_to_kv_pool=r.token_to_kv_pool,
                                    attn_backend=r.attn_backend, extend_prefix_lens_cpu=prefix_lens,
                                    extend_seq_lens_cpu=extend_lens, sampling_info=sampling_info)
+        fb.input_embeds = self._mm_embeds(reqs, input_ids, prefix_lens, extend_lens)
         logits = r.forward(fb)
         self._record_logits(logits, reqs)
         next_ids = r.sample(logits, fb)
@@ -341,6 +358,7 @@ class Engine:
                                    req_to_token_pool=r.req_to_token_pool, token_to_kv_pool=r.token_to_kv_pool,
                                    attn_backend=r.attn_backend, extend_prefix_lens_cpu=prefix_lens,
                                    extend_seq_lens_cpu=extend_lens, sampling_info=sampling_info)
+        fb.input_embeds = self._mm_embeds(reqs, input_ids, prefix_lens, extend_lens)
         logits = r.forward(fb)
         self._record_logits(logits, reqs, [end >= len(q.origin_input_ids) for q, end in zip(reqs, ends)])
         ids_cpu = r.sample(logits, fb).tolist()

@@ -334,7 +334,8 @@ class CausalLM(nn.Module):
         return self.layers[0].self_attn.num_kv_heads
 
     def forward_hidden(self, input_ids: torch.Tensor, positions: torch.Tensor, forward_batch) -> torch.Tensor:
-        hidden_states = F.embedding(input_ids, self.embed_tokens)
+        embeds = getattr(forward_batch, "input_embeds", None)
+        hidden_states = embeds if embeds is not None else F.embedding(input_ids, self.embed_tokens)
         if all(layer.fusable(hidden_states, self.tp_size) for layer in self.layers):
             residual = hidden_states                     # the embedding output becomes the residual stream
             x = self.layers[0].input_layernorm(hidden_states)

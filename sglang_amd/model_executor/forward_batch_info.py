@@ -61,6 +61,10 @@ class ForwardBatch:
     encoder_lens: Optional[torch.Tensor] = None
     # sampling
     sampling_info: Any = None
+    # multimodal: embeddings of the extend tokens with the image features already scattered in (mm_utils.py:609
+    # general_mm_embed_routine hands the language model `input_embeds` instead of ids)
+    input_embeds: Optional[torch.Tensor] = None
+    spec_info: Any = None                    # speculative-decoding verify: carries the custom mask (triton_backend.py:860-919)
 
     @classmethod
     def init_new(cls, *, forward_mode: ForwardMode, input_ids: torch.Tensor, req_pool_indices: torch.Tensor,
