@@ -73,6 +73,8 @@ CONFIGS: Dict[str, ModelConfig] = {
                                 attention_bias=True, tie_word_embeddings=True),
     "mixtral-8x7b": ModelConfig("mixtral-8x7b", 4096, 14336, 32, 32, 8, 128, 32000, 1e-5, 1000000.0, None, 32768,
                                 num_local_experts=8, num_experts_per_tok=2),
+    # LLaVA-1.6-7B's language model (vicuna-7B: MHA, rope theta 1e4); the vision tower is harness/llava.py ClipVisionConfig()
+    "llava-1.6-7b": ModelConfig("llava-1.6-7b", 4096, 11008, 32, 32, 32, 128, 32064, 1e-5, 10000.0, None, 4096),
     # small shapes for tests / smoke
     "tiny-llama": ModelConfig("tiny-llama", 256, 512, 2, 8, 2, 64, 1024, 1e-5, 10000.0, None, 2048),
     "tiny-qwen": ModelConfig("tiny-qwen", 128, 384, 2, 4, 2, 64, 768, 1e-6, 10000.0, None, 2048,
