@@ -53,9 +53,51 @@ def init_distributed_environment(backend: Optional[str] = None, tp_size: Optiona
         xgmi_all_reduce = (torch.cuda.is_available() and _TP_SIZE in (2, 4, 8)
                            and os.environ.get("SGLANG_AMD_XGMI_AR", "1") != "0")
     if xgmi_all_reduce:
-        from .xgmi_all_reduce import XgmiAllReduce
+        _XGMI = _start_xgmi()
 
-        _XGMI = XgmiAllReduce(_TP_CPU_GROUP, _TP_RANK, _TP_SIZE, torch.device("cuda", torch.cuda.current_device()))
+
+def _start_xgmi():
+    """Create the one-shot communicator and PROVE it on this node before anything depends on it: every rank reduces a
+    known tensor through the xGMI kernel and through the group's own collective; unless all ranks see identical,
+    correct results (and no flag wait gave up) the communicator is dropped on EVERY rank and RCCL carries all
+    all-reduces -- the reference degrades the same way when its custom all-reduce cannot be set up
+    (custom_all_reduce.py:100-180).  A rank-local failure must not leave the ranks with different algorithms."""
+    import warnings
+
+    from .xgmi_all_reduce import XgmiAllReduce
+
+    dev = torch.device("cuda", torch.cuda.current_device())
+    xg, ok = None, 1
+    try:
+        xg = XgmiAllReduce(_TP_CPU_GROUP, _TP_RANK, _TP_SIZE, dev)
+    except Exception as e:                      # e.g. IPC not permitted between these devices
+        warnings.warn(f"one-shot xGMI all-reduce unavailable ({type(e).__name__}: {e}); using RCCL")
+        ok = 0
+    flag = torch.tensor([ok], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=_TP_CPU_GROUP)
+    if int(flag) == 1:
+        try:
+            g = torch.Generator(device="cpu").manual_seed(1234 + _TP_RANK)
+            x = (torch.randn((64, 4096), generator=g) * 0.5).to(torch.bfloat16).to(dev)
+            mine = xg.all_reduce(x.clone())
+            ref = x.float().clone()
+            dist.all_reduce(ref, group=_TP_GROUP)                       # fp32 sum through the group's collective
+            torch.cuda.synchronize()
+            good = (not xg.timed_out()) and bool(((mine.float() - ref).abs() <= 2.0 ** -7 * ref.abs() + 1e-2).all())
+        except Exception as e:
+            warnings.warn(f"one-shot xGMI all-reduce self-test raised {type(e).__name__}: {e}")
+            good = False
+        flag = torch.tensor([1 if good else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=_TP_CPU_GROUP)
+    if int(flag) == 1:
+        return xg
+    if xg is not None:
+        warnings.warn("one-shot xGMI all-reduce failed its start-up self-test on some rank; using RCCL for every all-reduce")
+        try:
+            xg.close()
+        except Exception:
+            pass
+    return None
 
 
 def destroy() -> None:
