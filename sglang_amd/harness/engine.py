@@ -171,7 +171,7 @@ class Engine:
     def _mm_embeds(self, reqs, input_ids, prefix_lens, extend_lens):
         """Image + text batches: the extend tokens' embeddings with the image features scattered over the pad-value
         positions (mm_utils.py:463-503); None for text-only batches."""
-        if self.r.vision is None or not any(getattr(q, "mm_items", None) for q in reqs):
+        if getattr(self.r, "vision", None) is None or not any(getattr(q, "mm_items", None) for q in reqs):
             return None
         from .llava import embed_mm_inputs
 
