@@ -235,12 +235,18 @@ int64_t sgl_amd_skinny_gemm_slab_floats(int64_t row_blocks, int64_t N, int split
  *      with num_k_splits == 1 it runs in the GEMM's own epilogue (waves_per_group 2..4, each wave owns a
  *      gate tile and its up tile; no workspace, no second launch)
  *   2: h = bf16(acc + bias); residual += h (bf16, in place); y = RMSNorm(residual) * norm_weight
- *      (srt/layers/layernorm.py:786-820 forward_native with residual). */
+ *      (srt/layers/layernorm.py:786-820 forward_native with residual).
+ * Activation layouts: x_chunk_stride / y_chunk_stride = 0 is the reference's row-major [M, K] / [M, N].  A non-zero
+ * value is the "chunk-major" form a chain of these GEMMs may keep BETWEEN its own launches: element (m, n) at
+ * (n / 128) * chunk_stride + m * row_stride + n % 128, e.g. [K/128][M][128] with row_stride 128 and chunk_stride
+ * 128 M, so that the 128-wide K chunk of all rows a workgroup stages per step is one contiguous burst.  The
+ * reduction walks K from a per-workgroup staggered starting chunk (wrapping around): the fp32 summation order is a
+ * fixed function of (shape, waves_per_group, num_k_splits), not of the run. */
 int sgl_amd_wstream_gemm(const void* x, const void* w, const void* bias, void* y, int64_t M, int64_t N,
-                         int64_t K, int64_t x_row_stride, int64_t w_row_stride, int64_t y_row_stride,
-                         int epilogue, void* residual, int64_t residual_row_stride,
-                         const void* norm_weight, float eps, int waves_per_group, int num_k_splits,
-                         void* ws_partials, void* stream);
+                         int64_t K, int64_t x_row_stride, int64_t x_chunk_stride, int64_t w_row_stride,
+                         int64_t y_row_stride, int64_t y_chunk_stride, int epilogue, void* residual,
+                         int64_t residual_row_stride, const void* norm_weight, float eps, int waves_per_group,
+                         int num_k_splits, void* ws_partials, void* stream);
 /* qkv_proj + neox rotary embedding + KV-pool store for a decode batch, as one GEMM + combine pair:
  * q_out[M, Hq*D] = rope(x . w_q^T + b), k_cache[cache_loc[m]] = rope(x . w_k^T + b), v_cache[...] = x . w_v^T + b,
  * with the rounding points of QKVParallelLinear -> RotaryEmbedding.forward_native -> set_kv_buffer
@@ -249,7 +255,7 @@ int sgl_amd_wstream_gemm(const void* x, const void* w, const void* bias, void* y
  * sgl_amd_wstream_gemm_workspace_floats(M, (Hq+2Hkv)*D, num_k_splits) floats (always needed). */
 int sgl_amd_wstream_qkv_rope(const void* x, const void* w_qkv, const void* bias, void* q_out, int64_t M,
                              int64_t K, int num_q_heads, int num_kv_heads, int head_dim,
-                             int64_t x_row_stride, int64_t w_row_stride, int64_t q_row_stride,
+                             int64_t x_row_stride, int64_t x_chunk_stride, int64_t w_row_stride, int64_t q_row_stride,
                              const int64_t* positions, const void* cos_sin_cache, int cache_is_f32,
                              int64_t rotary_dim, void* k_cache, void* v_cache, const int64_t* cache_loc,
                              int64_t cache_row_stride, int waves_per_group, int num_k_splits,

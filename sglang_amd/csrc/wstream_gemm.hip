@@ -46,6 +46,13 @@ __device__ __forceinline__ U4 ld16_stream(const uint16_t* p) {
   return __builtin_bit_cast(U4, v);
 }
 
+// Activations come row-major [M, K] or "chunk-major" [K/128][M][128] (every 128-wide K chunk of all rows contiguous:
+// the 16 KiB a workgroup stages per step is then one burst over all L2 channels instead of 64 pieces 2K bytes
+// apart).  Both are (row stride, chunk stride) pairs; element (m, n) lives at (n / 128) * cstride + m * stride + n % 128.
+__device__ __forceinline__ int64_t blocked_off(int64_t m, int n, int64_t stride, int64_t cstride) {
+  return static_cast<int64_t>(n >> 7) * cstride + m * stride + (n & 127);
+}
+
 struct WsParams {
   const uint16_t* x;     // [M, K]
   const uint16_t* w;     // [N, K]
@@ -53,6 +60,8 @@ struct WsParams {
   uint16_t* y;           // [M, N] bf16 (splits == 1)
   float* part;           // [splits, M, N] fp32, or NULL: write y directly
   int64_t x_stride, w_stride, y_stride;
+  int64_t x_cstride;     // elements between consecutive 128-wide K chunks of an x row (128 for a row-major x)
+  int64_t y_cstride;     // the same for the 128-wide column blocks of y (bf16 outputs)
   int M, N, K, splits, ntiles;
   // grouped (mixture-of-experts) form: blockIdx.y = row block of moe_align_block_size's output, rows gathered /
   // scattered through sorted_ids, weights of expert expert_ids[block]; M = number of valid (token, k) pair ids
@@ -75,6 +84,19 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef __attribute__((address_space(3))) unsigned char* lds_bytes_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
+#ifdef WS_TRACE
+// timeline probe (benchmarks/r02_exp5_ws_trace.py): per workgroup, 100 MHz chip-wide clock at entry, first chunk
+// landed, last chunk multiplied, epilogue stored
+__device__ uint64_t* g_ws_trace = nullptr;
+#define WS_STAMP(i)                                                                                   \
+  do {                                                                                                \
+    if (g_ws_trace && threadIdx.x == 0)                                                               \
+      g_ws_trace[(static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x) * 4 + (i)] = wall_clock64(); \
+  } while (0)
+#else
+#define WS_STAMP(i)
+#endif
+
 template <int AUX>
 __device__ __forceinline__ void dma16(const uint16_t* src, lds_ptr_t dst) {
   __builtin_amdgcn_global_load_lds((glb_ptr_t)(src), dst, 16, 0, AUX);
@@ -96,17 +118,6 @@ __device__ __forceinline__ void pin(u32x4_t& v) { asm volatile("" : "+v"(v)); }
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// wait until at most min(k, KMAX) chunks (LPC DMA instructions each) are still outstanding; k is wave-uniform
-template <int LPC, int KMAX>
-__device__ __forceinline__ void wait_chunks(int k) {
-  if constexpr (KMAX == 0) {
-    wait_vm<0>();
-  } else {
-    if (k >= KMAX) wait_vm<KMAX * LPC>();
-    else wait_chunks<LPC, KMAX - 1>(k);
-  }
-}
-
 // ring depth: as many chunk slots as fit the 160 KiB LDS (1 KiB is the dummy landing zone), at most 6
 constexpr int ring_depth(int mt, int nw, int tpw) {
   const int slot = nw * tpw * 4096 + mt * 4 * 1024;
@@ -121,15 +132,16 @@ __global__ __launch_bounds__(64 * NW, 1) void wstream_gemm_kernel(WsParams p) {
   constexpr int PD = ring_depth(MT, NW, TPW);
   constexpr int XPIECES = MT * 4;                       // 1 KiB pieces (4 rows x 256 B) of an activation chunk
   constexpr int XP = (XPIECES + NW - 1) / NW;           // pieces each wave fetches (surplus -> dummy slot)
-  constexpr int LPC = TPW * kKSteps + XP;               // DMA instructions per wave per chunk
+  constexpr int WPC = TPW * kKSteps;                    // weight DMA instructions per wave per chunk
   constexpr int WWAVE = TPW * 4096;                     // weight bytes per wave per chunk
   constexpr int WCH = NW * WWAVE;                       // weight bytes per chunk
   constexpr int CH = WCH + XPIECES * 1024;              // ring slot: [weights of wave 0..NW) | activations]
   static_assert(PD >= 3 && PD * CH + 1024 <= 160 * 1024, "LDS ring does not fit");
-  static_assert((PD - 2) * LPC < 64, "vmcnt range");
+  static_assert((PD - 1) * WPC + (PD - 2) * XP < 64, "vmcnt range");
   __shared__ __attribute__((aligned(1024))) unsigned char ring[PD * CH + 1024];
 
   const int tid = threadIdx.x, lane = tid & 63;
+  WS_STAMP(0);
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, g = lane >> 4;
   const int wtiles = p.ntiles / TPW;                    // tiles a wave index ranges over
@@ -176,22 +188,49 @@ __global__ __launch_bounds__(64 * NW, 1) void wstream_gemm_kernel(WsParams p) {
     } else {
       srow = row < p.M ? row : p.M - 1;
     }
-    xsrc[i] = p.x + static_cast<int64_t>(srow) * p.x_stride + ((s16 ^ row) & 15) * 8 + static_cast<int64_t>(cb) * kKC;
+    xsrc[i] = p.x + static_cast<int64_t>(srow) * p.x_stride + ((s16 ^ row) & 15) * 8 + static_cast<int64_t>(cb) * p.x_cstride;
     xoff[i] = real ? WCH + piece * 1024 : -1;
   }
   lds_bytes_t ring3 = (lds_bytes_t)(ring);
-  auto issue = [&](int c_rel, int slot) {                // chunk cb + c_rel -> ring slot
-    const int koff = c_rel * kKC;
-    const int base = slot * CH;
+  // Chunk c lives in ring slot c % PD.  A wave's weight tiles of a slot are private to it: the wave copies them to
+  // registers (TPW * 4 fragments) at the top of compute() and refills the slot with chunk c + PD at once, so all PD
+  // slots' worth of weights stay in flight; the activation image is shared, so chunk c + PD - 1's goes into slot
+  // c - 1 after the barrier that retires it.  Behind the end of the K range a dummy DMA (L2-resident source, the
+  // 1 KiB landing zone) is issued instead, which keeps the in-order vmcnt arithmetic the same in every iteration.
+  const uint16_t* dummy_src = p.x + s16 * 8;
+  lds_ptr_t dummy_dst = (lds_ptr_t)(ring3 + PD * CH);
+  // Without split-K the workgroups walk the K range from staggered starting chunks (wrapping around): launched
+  // together they would otherwise all pull the same 256-byte column of their rows at the same moment, which the row
+  // stride (a multiple of 8 KiB) maps onto a few memory channels (gate_up 46.5 -> 38.6 us).  Split-K launches already
+  // start at `splits` different columns and measured 0.3-1 us slower staggered.
+  const int rot = p.splits == 1 && n > 1 ? static_cast<int>((static_cast<int64_t>(blockIdx.x) * n) / gridDim.x) : 0;
+  auto issue_w = [&](int c_rel, int slot) {
+    if (c_rel < n) {
+      const int cr = c_rel + rot < n ? c_rel + rot : c_rel + rot - n;
+      const int koff = cr * kKC;
+      const int base = slot * CH + wid * WWAVE;
 #pragma unroll
-    for (int t = 0; t < TPW; ++t)
+      for (int t = 0; t < TPW; ++t)
 #pragma unroll
-      for (int j = 0; j < kKSteps; ++j)
-        dma16<2>(wsrc[t][j] + koff, (lds_ptr_t)(ring3 + base + wid * WWAVE + t * 4096 + j * 1024));
+        for (int j = 0; j < kKSteps; ++j) dma16<2>(wsrc[t][j] + koff, (lds_ptr_t)(ring3 + base + t * 4096 + j * 1024));
+    } else {
 #pragma unroll
-    for (int i = 0; i < XP; ++i) {
-      const int off = xoff[i] >= 0 ? base + xoff[i] : PD * CH;
-      dma16<0>(xsrc[i] + koff, (lds_ptr_t)(ring3 + off));
+      for (int i = 0; i < WPC; ++i) dma16<0>(dummy_src, dummy_dst);
+    }
+  };
+  auto issue_x = [&](int c_rel, int slot) {
+    if (c_rel < n) {
+      const int cr = c_rel + rot < n ? c_rel + rot : c_rel + rot - n;
+      const int64_t koff = cr * p.x_cstride;
+      const int base = slot * CH;
+#pragma unroll
+      for (int i = 0; i < XP; ++i) {
+        const int off = xoff[i] >= 0 ? base + xoff[i] : PD * CH;
+        dma16<0>(xsrc[i] + koff, (lds_ptr_t)(ring3 + off));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < XP; ++i) dma16<0>(dummy_src, dummy_dst);
     }
   };
 
@@ -207,47 +246,46 @@ __global__ __launch_bounds__(64 * NW, 1) void wstream_gemm_kernel(WsParams p) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[t][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  // fragment reads of one "stage": up to 64 rows the stage is a whole k-step (A tiles + all B tiles); beyond, a
-  // k-step is two stages (A tiles + first half of the B tiles, then the second half) so that the reads of two
-  // consecutive stages stay inside the 4-bit lgkmcnt while one stage is always read ahead of the MFMAs
+  // activation fragments of one "stage": up to 64 rows the stage is a whole k-step (all B tiles); beyond, a k-step is
+  // two stages (first half of the B tiles, then the second half) so that the reads of two consecutive stages stay
+  // inside the 4-bit lgkmcnt while one stage is always read ahead of the MFMAs
   constexpr bool WIDE = MT > 4;
   constexpr int H = WIDE ? MT / 2 : MT;                // B tiles per stage
   constexpr int NST = WIDE ? 2 * kKSteps : kKSteps;    // stages per chunk
-  auto read_stage = [&](uint32_t slot_addr, int st, u32x4_t (&a)[TPW], u32x4_t (&b)[H]) {
+  auto read_stage = [&](uint32_t slot_addr, int st, u32x4_t (&b)[H]) {
     const int kk = WIDE ? st >> 1 : st;
     const int half = WIDE ? st & 1 : 0;
-    const uint32_t ad = slot_addr + foff[kk];
-    if (half == 0) {
-      a[0] = lds_rd<0>(ad + wid * WWAVE);
-      if constexpr (TPW > 1) a[1] = lds_rd<4096>(ad + wid * WWAVE);
-    }
-    const uint32_t bd = ad + half * (H * 4096);
+    const uint32_t bd = slot_addr + foff[kk] + half * (H * 4096);
     b[0] = lds_rd<WCH>(bd);
     if constexpr (H > 1) b[1] = lds_rd<WCH + 4096>(bd);
     if constexpr (H > 2) b[2] = lds_rd<WCH + 8192>(bd);
     if constexpr (H > 3) b[3] = lds_rd<WCH + 12288>(bd);
   };
-  auto compute = [&](int slot) {
+  auto compute = [&](int slot, int c) {
     const uint32_t slot_addr = ring_addr + slot * CH;
-    u32x4_t a[2][TPW], b[2][H];                          // a: by k-step parity, b: by stage parity
-    read_stage(slot_addr, 0, a[0], b[0]);
+    u32x4_t a[kKSteps][TPW], b[2][H];                    // a: the wave's weight tiles of the chunk; b: by stage parity
+#pragma unroll
+    for (int kk = 0; kk < kKSteps; ++kk) {
+      a[kk][0] = lds_rd<0>(slot_addr + foff[kk] + wid * WWAVE);
+      if constexpr (TPW > 1) a[kk][1] = lds_rd<4096>(slot_addr + foff[kk] + wid * WWAVE);
+    }
+    read_stage(slot_addr, 0, b[0]);
+    wait_lgkm<H>();                                      // LDS returns in order: the weight fragments are in
+#pragma unroll
+    for (int kk = 0; kk < kKSteps; ++kk)
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) pin(a[kk][t]);
+    issue_w(c + PD, slot);                               // the tiles just copied out are free: refill them now
 #pragma unroll
     for (int st = 0; st < NST; ++st) {
       const int kk = WIDE ? st >> 1 : st;
       const int half = WIDE ? st & 1 : 0;
-      const int ac = kk & 1, bc = st & 1;
+      const int bc = st & 1;
       if (st + 1 < NST) {
-        const int nkk = WIDE ? (st + 1) >> 1 : st + 1;
-        read_stage(slot_addr, st + 1, a[nkk & 1], b[bc ^ 1]);
-        // outstanding reads of stage st+1: its B tiles, plus the A tiles when it opens a k-step
-        if ((WIDE ? ((st + 1) & 1) : 0) == 0) wait_lgkm<H + TPW>();
-        else wait_lgkm<H>();
+        read_stage(slot_addr, st + 1, b[bc ^ 1]);
+        wait_lgkm<H>();
       } else {
         wait_lgkm<0>();
-      }
-      if (half == 0) {
-#pragma unroll
-        for (int t = 0; t < TPW; ++t) pin(a[ac][t]);
       }
 #pragma unroll
       for (int j = 0; j < H; ++j) pin(b[bc][j]);
@@ -255,28 +293,39 @@ __global__ __launch_bounds__(64 * NW, 1) void wstream_gemm_kernel(WsParams p) {
       for (int t = 0; t < TPW; ++t)
 #pragma unroll
         for (int j = 0; j < H; ++j)
-          acc[t][half * H + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[ac][t]),
+          acc[t][half * H + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[kk][t]),
                                                                        __builtin_bit_cast(bf16x8_t, b[bc][j]),
                                                                        acc[t][half * H + j], 0, 0, 0);
     }
   };
 
-  // ---- pipeline: PD-1 chunks in flight, one barrier per chunk ----
+  // ---- pipeline: weights PD chunks ahead, activations PD - 1, one barrier per chunk ----
 #pragma unroll
-  for (int u = 0; u < PD - 1; ++u)
-    if (u < n) issue(u, u);
-  int slot = 0, nslot = PD - 1;                          // slot of chunk c, slot of chunk c + PD - 1
+  for (int u = 0; u < PD - 1; ++u) {
+    issue_w(u, u);
+    issue_x(u, u);
+  }
+  issue_w(PD - 1, PD - 1);
+  int slot = 0, nslot = PD - 1;                          // slot of chunk c, slot of chunk c - 1 (= c + PD - 1)
   for (int c = 0; c < n; ++c) {
-    // chunk c has landed once at most the younger in-flight chunks' DMAs are outstanding
-    wait_chunks<LPC, PD - 2>(n - 1 - c);
+    // chunk c has landed once only the DMAs issued after its activations are outstanding:
+    // weights of c+1 .. c+PD-1 and activations of c+1 .. c+PD-2
+    wait_vm<(PD - 1) * WPC + (PD - 2) * XP>();
     __builtin_amdgcn_s_barrier();                        // everyone's pieces of chunk c are visible,
-                                                         // everyone is done reading chunk c - 1
-    if (c + PD - 1 < n) issue(c + PD - 1, nslot);
-    compute(slot);
+                                                         // everyone is done reading the activations of chunk c - 1
+    issue_x(c + PD - 1, nslot);
+#ifdef WS_TRACE
+    if (c == 0) WS_STAMP(1);
+#endif
+    compute(slot, c);
     slot = slot + 1 == PD ? 0 : slot + 1;
     nslot = nslot + 1 == PD ? 0 : nslot + 1;
   }
 
+  WS_STAMP(2);
+#ifdef WS_TRACE
+  struct StampAtExit { __device__ ~StampAtExit() { __builtin_amdgcn_s_waitcnt(0); WS_STAMP(3); } } stamp_at_exit;
+#endif
   if (!active) return;
   // lane holds C[m = 16 mt + r16][n = 16 tile + 4 g + r]
   const int n0 = tile * 16 + g * 4;
@@ -324,7 +373,7 @@ __global__ __launch_bounds__(64 * NW, 1) void wstream_gemm_kernel(WsParams p) {
       uint2 w2;
       w2.x = pack_bf2(o[0], o[1]);
       w2.y = pack_bf2(o[2], o[3]);
-      *reinterpret_cast<uint2*>(p.y + m * p.y_stride + n0) = w2;
+      *reinterpret_cast<uint2*>(p.y + blocked_off(m, n0, p.y_stride, p.y_cstride)) = w2;
     }
   }
 }
@@ -344,7 +393,7 @@ struct CombineParams {
   uint16_t* y;
   uint16_t* residual;
   const uint16_t* norm_w;
-  int64_t y_stride, res_stride;
+  int64_t y_stride, y_cstride, res_stride;
   int M, N, splits;
   float eps;
 };
@@ -380,7 +429,7 @@ __global__ __launch_bounds__(256) void wstream_combine_kernel(CombineParams p) {
   uint2 w2;
   w2.x = pack_bf2(s[0], s[1]);
   w2.y = pack_bf2(s[2], s[3]);
-  *reinterpret_cast<uint2*>(p.y + static_cast<int64_t>(m) * p.y_stride + n0) = w2;
+  *reinterpret_cast<uint2*>(p.y + blocked_off(m, n0, p.y_stride, p.y_cstride)) = w2;
 }
 
 __global__ __launch_bounds__(256) void wstream_combine_silu_kernel(CombineParams p) {
@@ -402,7 +451,7 @@ __global__ __launch_bounds__(256) void wstream_combine_silu_kernel(CombineParams
   uint2 w2;
   w2.x = pack_bf2(o[0], o[1]);
   w2.y = pack_bf2(o[2], o[3]);
-  *reinterpret_cast<uint2*>(p.y + static_cast<int64_t>(m) * p.y_stride + j0) = w2;
+  *reinterpret_cast<uint2*>(p.y + blocked_off(m, j0, p.y_stride, p.y_cstride)) = w2;
 }
 
 constexpr int kNormThreads = 1024;
@@ -448,7 +497,7 @@ __global__ __launch_bounds__(kNormThreads) void wstream_combine_norm_kernel(Comb
       uint2 w2;
       w2.x = pack_bf2((t[i][0] * rs) * ww[0], (t[i][1] * rs) * ww[1]);
       w2.y = pack_bf2((t[i][2] * rs) * ww[2], (t[i][3] * rs) * ww[3]);
-      *reinterpret_cast<uint2*>(p.y + static_cast<int64_t>(m) * p.y_stride + n0) = w2;
+      *reinterpret_cast<uint2*>(p.y + blocked_off(m, n0, p.y_stride, p.y_cstride)) = w2;
     }
   }
 }
@@ -573,6 +622,13 @@ int launch_nw(const WsParams& p, int nw, bool fused_silu, hipStream_t st, int ro
 
 extern "C" {
 
+#ifdef WS_TRACE
+int sgl_amd_debug_ws_trace(void* buf) {
+  uint64_t* p = static_cast<uint64_t*>(buf);
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_ws_trace), &p, sizeof(p)) == hipSuccess ? 0 : 1;
+}
+#endif
+
 int sgl_amd_wstream_gemm_max_rows(void) { return 128; }
 
 int64_t sgl_amd_wstream_gemm_workspace_floats(int64_t M, int64_t N, int num_k_splits) {
@@ -581,7 +637,8 @@ int64_t sgl_amd_wstream_gemm_workspace_floats(int64_t M, int64_t N, int num_k_sp
 
 // shared by the two entry points: validates the GEMM part and launches the main kernel
 static int wstream_launch_main(const char* who, const void* x, const void* w, const void* bias, void* y, int64_t M, int64_t N,
-                               int64_t K, int64_t x_row_stride, int64_t w_row_stride, int64_t y_row_stride, bool fused_silu,
+                               int64_t K, int64_t x_row_stride, int64_t x_chunk_stride, int64_t w_row_stride,
+                               int64_t y_row_stride, int64_t y_chunk_stride, bool fused_silu,
                                bool to_partials, int waves_per_group, int num_k_splits, void* ws_partials, hipStream_t st) {
   SGL_CHECK_ARG(M >= 1 && M <= 128, "%s: M=%lld rows (supported: 1..128)", who, (long long)M);
   SGL_CHECK_ARG(N > 0 && N % 16 == 0 && K >= kKC && K % kKC == 0,
@@ -599,6 +656,10 @@ static int wstream_launch_main(const char* who, const void* x, const void* w, co
   p.y = static_cast<uint16_t*>(y);
   p.part = to_partials ? static_cast<float*>(ws_partials) : nullptr;
   p.x_stride = x_row_stride; p.w_stride = w_row_stride; p.y_stride = y_row_stride;
+  SGL_CHECK_ARG(x_chunk_stride % 8 == 0 && y_chunk_stride % 4 == 0 && x_chunk_stride >= 0 && y_chunk_stride >= 0,
+                "%s: chunk strides must keep 16-byte (x) / 8-byte (y) alignment", who);
+  p.x_cstride = x_chunk_stride ? x_chunk_stride : kKC;
+  p.y_cstride = y_chunk_stride ? y_chunk_stride : 128;
   p.M = static_cast<int>(M); p.N = static_cast<int>(N); p.K = static_cast<int>(K);
   p.splits = num_k_splits; p.ntiles = static_cast<int>(N / 16);
   int rc;
@@ -615,9 +676,10 @@ static int wstream_launch_main(const char* who, const void* x, const void* w, co
 }
 
 int sgl_amd_wstream_gemm(const void* x, const void* w, const void* bias, void* y, int64_t M, int64_t N, int64_t K,
-                         int64_t x_row_stride, int64_t w_row_stride, int64_t y_row_stride, int epilogue,
-                         void* residual, int64_t residual_row_stride, const void* norm_weight, float eps,
-                         int waves_per_group, int num_k_splits, void* ws_partials, void* stream) {
+                         int64_t x_row_stride, int64_t x_chunk_stride, int64_t w_row_stride, int64_t y_row_stride,
+                         int64_t y_chunk_stride, int epilogue, void* residual, int64_t residual_row_stride,
+                         const void* norm_weight, float eps, int waves_per_group, int num_k_splits, void* ws_partials,
+                         void* stream) {
   SGL_CLEAR_STALE_ERROR();
   if (M == 0) return 0;
   SGL_CHECK_ARG(epilogue >= 0 && epilogue <= 2, "wstream_gemm: epilogue must be 0 (bias), 1 (silu_and_mul) or 2 (add_rmsnorm)");
@@ -628,14 +690,16 @@ int sgl_amd_wstream_gemm(const void* x, const void* w, const void* bias, void* y
   SGL_CHECK_ARG(epilogue != 2 || (residual && norm_weight && N <= kNormThreads * kNormMaxVec * 4 && residual_row_stride % 4 == 0),
                 "wstream_gemm: add_rmsnorm needs residual, norm_weight and N <= %d", kNormThreads * kNormMaxVec * 4);
   hipStream_t st = as_stream(stream);
-  if (int rc = wstream_launch_main("wstream_gemm", x, w, bias, y, M, N, K, x_row_stride, w_row_stride, y_row_stride, fused_silu,
-                                   combine, waves_per_group, num_k_splits, ws_partials, st))
+  SGL_CHECK_ARG(y_chunk_stride == 0 || (epilogue == 1 ? N % 256 == 0 : N % 128 == 0),
+                "wstream_gemm: a chunk-major y needs whole 128-column blocks");
+  if (int rc = wstream_launch_main("wstream_gemm", x, w, bias, y, M, N, K, x_row_stride, x_chunk_stride, w_row_stride, y_row_stride,
+                                   y_chunk_stride, fused_silu, combine, waves_per_group, num_k_splits, ws_partials, st))
     return rc;
   if (combine) {
     CombineParams c{};
     c.part = static_cast<const float*>(ws_partials); c.bias = static_cast<const uint16_t*>(bias); c.y = static_cast<uint16_t*>(y);
     c.residual = static_cast<uint16_t*>(residual); c.norm_w = static_cast<const uint16_t*>(norm_weight);
-    c.y_stride = y_row_stride; c.res_stride = residual_row_stride;
+    c.y_stride = y_row_stride; c.y_cstride = y_chunk_stride ? y_chunk_stride : 128; c.res_stride = residual_row_stride;
     c.M = static_cast<int>(M); c.N = static_cast<int>(N); c.splits = num_k_splits; c.eps = eps;
     if (epilogue == 0) {
       hipLaunchKernelGGL(wstream_combine_kernel, dim3((c.N / 4 + 255) / 256, c.M), dim3(256), 0, st, c);
@@ -674,6 +738,7 @@ int sgl_amd_wstream_moe_gemm(const void* a, const void* w, void* c, const int32_
   p.w = static_cast<const uint16_t*>(w);
   p.y = static_cast<uint16_t*>(c);
   p.x_stride = a_row_stride; p.w_stride = w_row_stride; p.y_stride = c_row_stride; p.w_expert_stride = w_expert_stride;
+  p.x_cstride = kKC; p.y_cstride = 128;
   p.M = static_cast<int>(num_valid_ids); p.N = static_cast<int>(wn); p.K = static_cast<int>(K);
   p.splits = 1; p.ntiles = static_cast<int>(wn / 16);
   p.sorted_ids = sorted_token_ids; p.expert_ids = expert_ids; p.num_post_pad = num_tokens_post_padded;
@@ -694,8 +759,8 @@ int sgl_amd_wstream_moe_gemm(const void* a, const void* w, void* c, const int32_
 }
 
 int sgl_amd_wstream_qkv_rope(const void* x, const void* w_qkv, const void* bias, void* q_out, int64_t M, int64_t K,
-                             int num_q_heads, int num_kv_heads, int head_dim, int64_t x_row_stride, int64_t w_row_stride,
-                             int64_t q_row_stride, const int64_t* positions, const void* cos_sin_cache, int cache_is_f32,
+                             int num_q_heads, int num_kv_heads, int head_dim, int64_t x_row_stride, int64_t x_chunk_stride,
+                             int64_t w_row_stride, int64_t q_row_stride, const int64_t* positions, const void* cos_sin_cache, int cache_is_f32,
                              int64_t rotary_dim, void* k_cache, void* v_cache, const int64_t* cache_loc,
                              int64_t cache_row_stride, int waves_per_group, int num_k_splits, void* ws_partials, void* stream) {
   SGL_CLEAR_STALE_ERROR();
@@ -706,8 +771,8 @@ int sgl_amd_wstream_qkv_rope(const void* x, const void* w_qkv, const void* bias,
   SGL_CHECK_ARG(q_row_stride % 4 == 0 && cache_row_stride % 4 == 0, "wstream_qkv_rope: q / cache row strides must be multiples of 4 elements");
   const int64_t N = static_cast<int64_t>(num_q_heads + 2 * num_kv_heads) * head_dim;
   hipStream_t st = as_stream(stream);
-  if (int rc = wstream_launch_main("wstream_qkv_rope", x, w_qkv, nullptr, nullptr, M, N, K, x_row_stride, w_row_stride, 4, false,
-                                   true, waves_per_group, num_k_splits, ws_partials, st))
+  if (int rc = wstream_launch_main("wstream_qkv_rope", x, w_qkv, nullptr, nullptr, M, N, K, x_row_stride, x_chunk_stride, w_row_stride,
+                                   4, 0, false, true, waves_per_group, num_k_splits, ws_partials, st))
     return rc;
   RopeParams r{};
   r.part = static_cast<const float*>(ws_partials); r.bias = static_cast<const uint16_t*>(bias);

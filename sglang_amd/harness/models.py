@@ -107,13 +107,15 @@ class Linear(nn.Module):
         self.bias = nn.Parameter(bias, requires_grad=False) if bias is not None else None
 
     def streams(self, x: torch.Tensor) -> bool:
-        return (x.is_cuda and x.dim() == 2 and x.stride(1) == 1
-                and kernels.wstream_preferred(x.shape[0], self.weight.shape[0], self.weight.shape[1]))
+        """x: row-major [M, K], or the chunk-major [K/128, M, 128] form the decode GEMMs hand to each other."""
+        rows = x.shape[1] if x.dim() == 3 else x.shape[0]
+        return (x.is_cuda and x.dim() in (2, 3) and x.stride(-1) == 1
+                and kernels.wstream_preferred(rows, self.weight.shape[0], self.weight.shape[1]))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.streams(x):
             return kernels.wstream_gemm(x, self.weight.data, self.bias.data if self.bias is not None else None)
-        return F.linear(x, self.weight, self.bias)
+        return F.linear(kernels.unblock(x), self.weight, self.bias)
 
     def forward_all_reduce(self, x: torch.Tensor) -> torch.Tensor:
         """RowParallelLinear.forward (linear.py): all_reduce(self(x)); prefill-sized inputs overlap the collective with
@@ -125,10 +127,11 @@ class Linear(nn.Module):
 
     def forward_add_rmsnorm(self, x: torch.Tensor, residual: torch.Tensor, norm: RMSNorm) -> torch.Tensor:
         """norm(self(x), residual) with the residual add + RMSNorm run by the GEMM's split-K combine
-        kernel: `residual` is updated in place, the normed activations are returned."""
+        kernel: `residual` is updated in place, the normed activations are returned -- chunk-major when the
+        width allows, since only the next projection's GEMM reads them."""
         return kernels.wstream_gemm(x, self.weight.data, self.bias.data if self.bias is not None else None,
                                     epilogue="add_rmsnorm", residual=residual, norm_weight=norm.weight.data,
-                                    eps=norm.variance_epsilon)
+                                    eps=norm.variance_epsilon, out_blocked=self.weight.shape[0] % 128 == 0)
 
 
 def _shard_rows(w: torch.Tensor, rank: int, world: int) -> torch.Tensor:
@@ -152,10 +155,12 @@ class LlamaMLP(nn.Module):
         self.down_proj = Linear(down.to(device))                            # RowParallelLinear
         self.act_fn = SiluAndMul()
 
-    def gate_up_act(self, x: torch.Tensor) -> torch.Tensor:
-        """act_fn(gate_up_proj(x)); decode batches get silu(gate) * up from the GEMM's own epilogue."""
+    def gate_up_act(self, x: torch.Tensor, out_blocked: bool = False) -> torch.Tensor:
+        """act_fn(gate_up_proj(x)); decode batches get silu(gate) * up from the GEMM's own epilogue (chunk-major on
+        request: the fused decode layer hands it to down_proj's GEMM only)."""
         if not OPERATOR_SURFACE_ONLY and self.gate_up_proj.streams(x) and self.gate_up_proj.bias is None:
-            return kernels.wstream_gemm(x, self.gate_up_proj.weight.data, epilogue="silu_and_mul")
+            return kernels.wstream_gemm(x, self.gate_up_proj.weight.data, epilogue="silu_and_mul",
+                                        out_blocked=out_blocked and self.gate_up_proj.weight.shape[0] % 256 == 0)
         return self.act_fn(self.gate_up_proj(x))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -165,9 +170,9 @@ class LlamaMLP(nn.Module):
         """Decode: down_proj + residual add + the NEXT norm.  TP=1: one GEMM + combine pair; TP>1: the GEMM, then the
         one-shot xGMI all-reduce with the add + norm in its epilogue."""
         if tp_size > 1:
-            y = self.down_proj(self.gate_up_act(x))
+            y = self.down_proj(self.gate_up_act(x, out_blocked=True))
             return ps.tensor_model_parallel_all_reduce_add_rmsnorm(y, residual, next_norm.weight.data, next_norm.variance_epsilon)
-        return self.down_proj.forward_add_rmsnorm(self.gate_up_act(x), residual, next_norm)
+        return self.down_proj.forward_add_rmsnorm(self.gate_up_act(x, out_blocked=True), residual, next_norm)
 
 
 class LlamaAttention(nn.Module):
@@ -355,8 +360,11 @@ class CausalLM(nn.Module):
         """logits_processor.py:652-700: last token of every request, vocab-parallel head + all-gather."""
         if forward_batch.forward_mode.is_extend():
             last = torch.cumsum(forward_batch.extend_seq_lens, dim=0, dtype=torch.int64) - 1
-            hidden_states = hidden_states[last]
-        if hidden_states.is_cuda and kernels.wstream_preferred(hidden_states.shape[0], *self.lm_head.shape):
+            hidden_states = kernels.unblock(hidden_states)[last]
+        rows = hidden_states.shape[1] if hidden_states.dim() == 3 else hidden_states.shape[0]
+        if hidden_states.dim() == 3 and not kernels.wstream_preferred(rows, *self.lm_head.shape):
+            hidden_states = kernels.unblock(hidden_states)
+        if hidden_states.is_cuda and kernels.wstream_preferred(rows, *self.lm_head.shape):
             logits = kernels.wstream_gemm(hidden_states, self.lm_head.data)
         else:
             logits = F.linear(hidden_states, self.lm_head)

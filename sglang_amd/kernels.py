@@ -586,22 +586,46 @@ def choose_wstream_config(M: int, N: int, K: int, need_combine: bool = False, fu
     return best[1], best[2]
 
 
+def _x_layout(x: torch.Tensor, who: str) -> Tuple[int, int, int, int]:
+    """(M, K, row stride, chunk stride) of a decode activation: row-major [M, K] (chunk stride 0) or the
+    chunk-major [K/128, M, 128] form the wstream GEMMs hand to each other (blocked_activation())."""
+    if x.dim() == 3:
+        _need(x.shape[2] == 128 and x.stride(2) == 1, f"{who}: a chunk-major activation is [K/128, M, 128]")
+        return x.shape[1], x.shape[0] * 128, x.stride(1), x.stride(0)
+    _need(x.dim() == 2 and x.stride(1) == 1, f"{who}: activations are [M, K] rows or [K/128, M, 128] chunks")
+    return x.shape[0], x.shape[1], x.stride(0), 0
+
+
+def blocked_activation(M: int, N: int, device) -> torch.Tensor:
+    """An empty chunk-major activation [N/128, M, 128] (element (m, n) at [n // 128, m, n % 128])."""
+    _need(N % 128 == 0, "blocked_activation: N must be a multiple of 128")
+    return torch.empty((N // 128, M, 128), dtype=_BF16, device=device)
+
+
+def unblock(x: torch.Tensor) -> torch.Tensor:
+    """Row-major [M, N] copy of a chunk-major activation (a no-op for a row-major one)."""
+    return x.permute(1, 0, 2).reshape(x.shape[1], -1) if x.dim() == 3 else x
+
+
 def wstream_gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: str = "none",
                  residual: Optional[torch.Tensor] = None, norm_weight: Optional[torch.Tensor] = None, eps: float = 0.0,
                  out: Optional[torch.Tensor] = None, waves_per_group: Optional[int] = None,
-                 splits: Optional[int] = None) -> torch.Tensor:
+                 splits: Optional[int] = None, out_blocked: bool = False) -> torch.Tensor:
     """Decode-batch F.linear(x, w, bias) on the weight-streaming kernel, optionally followed (in the
-    split-K combine kernel) by silu_and_mul or by fused_add_rmsnorm(out, residual, norm_weight, eps)."""
+    split-K combine kernel) by silu_and_mul or by fused_add_rmsnorm(out, residual, norm_weight, eps).
+    x may be chunk-major (see _x_layout); out_blocked=True returns the result chunk-major."""
     _dev(x, w)
-    _need(x.dtype == _BF16 and w.dtype == _BF16 and x.dim() == 2 and w.dim() == 2, "wstream_gemm: bf16 2-D x / w")
-    M, K = x.shape
+    _need(x.dtype == _BF16 and w.dtype == _BF16 and w.dim() == 2, "wstream_gemm: bf16 x / 2-D bf16 w")
+    M, K, x_rs, x_cs = _x_layout(x, "wstream_gemm")
     N = w.shape[0]
-    _need(w.shape[1] == K and x.stride(1) == 1 and w.stride(1) == 1, "wstream_gemm: shapes / contiguity")
+    _need(w.shape[1] == K and w.stride(1) == 1, "wstream_gemm: shapes / contiguity")
     ep = _WS_EPILOGUES[epilogue]
     n_out = N // 2 if ep == 1 else N
     if out is None:
-        out = torch.empty((M, n_out), dtype=_BF16, device=x.device)
-    _need(out.shape == (M, n_out) and out.stride(1) == 1 and out.dtype == _BF16, "wstream_gemm: out shape")
+        out = blocked_activation(M, n_out, x.device) if out_blocked else torch.empty((M, n_out), dtype=_BF16, device=x.device)
+    _need(out.dtype == _BF16, "wstream_gemm: bf16 out")
+    oM, oN, y_rs, y_cs = _x_layout(out, "wstream_gemm (out)")
+    _need((oM, oN) == (M, n_out), "wstream_gemm: out shape")
     if ep == 2:
         _need(residual is not None and norm_weight is not None and residual.shape == (M, N) and residual.stride(1) == 1
               and residual.dtype == _BF16 and norm_weight.dtype == _BF16, "wstream_gemm: add_rmsnorm needs residual [M,N] and norm_weight")
@@ -613,8 +637,8 @@ def wstream_gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] 
     s = splits or s_auto
     one_pass = ep == 1 and s == 1 and N % 32 == 0 and bias is None
     ws = _gemm_workspace(x.device, native.lib().sgl_amd_wstream_gemm_workspace_floats(M, N, s)) if ((s > 1 or ep) and not one_pass) else None
-    native.call("sgl_amd_wstream_gemm", x.data_ptr(), w.data_ptr(), _ptr(bias), out.data_ptr(), M, N, K, x.stride(0),
-                w.stride(0), out.stride(0), ep, _ptr(residual), residual.stride(0) if residual is not None else 0,
+    native.call("sgl_amd_wstream_gemm", x.data_ptr(), w.data_ptr(), _ptr(bias), out.data_ptr(), M, N, K, x_rs, x_cs,
+                w.stride(0), y_rs, y_cs, ep, _ptr(residual), residual.stride(0) if residual is not None else 0,
                 _ptr(norm_weight), float(eps), nw, s, _ptr(ws), _stream())
     return out
 
@@ -626,9 +650,9 @@ def wstream_qkv_rope(x: torch.Tensor, w_qkv: torch.Tensor, bias: Optional[torch.
     """Decode-batch qkv_proj + neox rotary embedding + KV-pool store (one GEMM + combine pair): returns the
     rotated q [M, Hq*D]; the rotated k rows and the v rows land in k_cache / v_cache at cache_loc."""
     _dev(x, w_qkv, positions, cos_sin_cache, k_cache, v_cache, cache_loc)
-    M, K = x.shape
+    M, K, x_rs, x_cs = _x_layout(x, "wstream_qkv_rope")
     N = (num_q_heads + 2 * num_kv_heads) * head_dim
-    _need(x.dtype == _BF16 and w_qkv.dtype == _BF16 and w_qkv.shape == (N, K) and x.stride(1) == 1 and w_qkv.stride(1) == 1,
+    _need(x.dtype == _BF16 and w_qkv.dtype == _BF16 and w_qkv.shape == (N, K) and w_qkv.stride(1) == 1,
           "wstream_qkv_rope: x [M,K] / w_qkv [(Hq+2Hkv)*D, K] bf16")
     _need(positions.dtype == torch.int64 and cache_loc.dtype == torch.int64 and positions.numel() == M and cache_loc.numel() == M,
           "wstream_qkv_rope: int64 positions / cache_loc of length M")
@@ -643,7 +667,7 @@ def wstream_qkv_rope(x: torch.Tensor, w_qkv: torch.Tensor, bias: Optional[torch.
     q_out = torch.empty((M, num_q_heads * head_dim), dtype=_BF16, device=x.device)
     ws = _gemm_workspace(x.device, native.lib().sgl_amd_wstream_gemm_workspace_floats(M, N, s))
     native.call("sgl_amd_wstream_qkv_rope", x.data_ptr(), w_qkv.data_ptr(), _ptr(bias), q_out.data_ptr(), M, K, num_q_heads,
-                num_kv_heads, head_dim, x.stride(0), w_qkv.stride(0), q_out.stride(0), positions.data_ptr(),
+                num_kv_heads, head_dim, x_rs, x_cs, w_qkv.stride(0), q_out.stride(0), positions.data_ptr(),
                 cos_sin_cache.data_ptr(), 1 if cos_sin_cache.dtype == torch.float32 else 0, cos_sin_cache.shape[-1],
                 kc.data_ptr(), vc.data_ptr(), cache_loc.data_ptr(), kc.stride(0), nw, s, ws.data_ptr(), _stream())
     return q_out

@@ -69,8 +69,12 @@ def test_wstream_gemm_split_k_is_deterministic_and_equals_one_split_order(device
     outs = [K_.wstream_gemm(x, w, splits=8, waves_per_group=8).clone() for _ in range(5)]
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
-    # the decomposition over workgroups must not change the arithmetic: same splits, other group size
-    assert torch.equal(K_.wstream_gemm(x, w, splits=8, waves_per_group=4), outs[0])
+    # another group size walks the K range from other staggered starting chunks: same products, another fp32
+    # summation order, so only the last bf16 ulp of a few outputs may move
+    alt = K_.wstream_gemm(x, w, splits=8, waves_per_group=4)
+    d = (alt.float() - outs[0].float()).abs()
+    assert float((d > 0).float().mean()) < 0.02
+    assert bool((d <= outs[0].float().abs() * 2.0 ** -7 + 1e-3).all())
     _check(outs[0].cpu(), _ref_linear(x.cpu(), w.cpu()))
 
 
@@ -82,13 +86,15 @@ def test_wstream_silu_epilogue_equals_unfused_ops(device, M, splits):
     I, K = 1792, 1024
     x = torch.randn((M, K), generator=g).to(BF).to(device)
     w = (torch.randn((2 * I, K), generator=g) * 0.05).to(BF).to(device)
-    gate_up = K_.wstream_gemm(x, w, splits=splits)                       # same accumulation order
+    gate_up = K_.wstream_gemm(x, w, splits=splits)
     want = oo.silu_and_mul(gate_up.cpu())
     got = K_.wstream_gemm(x, w, epilogue="silu_and_mul", splits=splits).cpu()
     d = (got.float() - want.float()).abs()
-    # identical accumulators and rounding points: only expf may differ in the last bf16 ulp
-    assert float((d > 0).float().mean()) < 0.005
-    assert bool((d <= want.float().abs() * 2.0 ** -7 + 1e-6).all())
+    # same products and rounding points; the one-pass form walks K from other starting chunks (fp32 summation
+    # order) and expf may differ in the last place: a few gate / up values cross a bf16 rounding boundary (one ulp of a
+    # gate around -5 moves silu(gate) by 2.5 %)
+    assert float((d > 0).float().mean()) < 0.02
+    assert bool((d <= want.float().abs() * 2.0 ** -4 + 1e-3).all())
 
 
 @pytest.mark.parametrize("M", [1, 20, 64, 128])
@@ -132,12 +138,15 @@ def test_wstream_one_pass_silu_equals_unfused_ops(device, M, I, K, nw):
     w = (torch.randn((2 * I, K), generator=g) * 0.03).to(BF).to(device)
     if M > 64 and nw is not None and nw > 2:
         pytest.skip("beyond 64 rows the one-pass form runs 2-wave groups")
-    gate_up = K_.wstream_gemm(x, w, splits=1, waves_per_group=4)          # same K order: bit-identical accumulators
+    gate_up = K_.wstream_gemm(x, w, splits=1, waves_per_group=4)
     want = oo.silu_and_mul(gate_up.cpu())
     got = K_.wstream_gemm(x, w, epilogue="silu_and_mul", splits=1, waves_per_group=nw).cpu()
     d = (got.float() - want.float()).abs()
-    assert float((d > 0).float().mean()) < 0.005
-    assert bool((d <= want.float().abs() * 2.0 ** -7 + 1e-6).all())
+    # same products and rounding points; the K walk starts at other staggered chunks (fp32 summation order), so a gate
+    # or up value sitting on a bf16 rounding boundary may land on the other side.  One ulp of a gate around -5 moves
+    # silu(gate) by 2.5 % (d ln silu / dg ~ 0.8 there, ulp 2^-5), hence the relative bound of 2^-4.
+    assert float((d > 0).float().mean()) < 0.03
+    assert bool((d <= want.float().abs() * 2.0 ** -4 + 1e-3).all())
 
 
 @pytest.mark.parametrize("M", [1, 17, 64, 128])
@@ -170,3 +179,54 @@ def test_wstream_qkv_rope_store_equals_unfused_ops(device, M, Hq, Hkv, D, K, bia
     untouched = torch.ones(slots, dtype=torch.bool)
     untouched[loc] = False
     assert float(kc.cpu()[untouched].abs().max()) == 0.0 and float(vc.cpu()[untouched].abs().max()) == 0.0
+
+
+def _blocked(x):
+    """[M, K] -> chunk-major [K/128, M, 128]."""
+    M, K = x.shape
+    return x.view(M, K // 128, 128).permute(1, 0, 2).contiguous()
+
+
+@pytest.mark.parametrize("M", [1, 20, 64, 100])
+@pytest.mark.parametrize("N,K,splits", [(4096, 4096, None), (1024, 14336, 4), (256, 512, 1)])
+def test_wstream_chunk_major_activations_change_no_bit(device, M, N, K, splits):
+    """The chunk-major [K/128, M, 128] layout is an addressing choice: blocked in / blocked out give the very
+    bits of the row-major call with the same decomposition."""
+    K_ = _k()
+    g = torch.Generator().manual_seed(M + N + K)
+    x = (torch.randn((M, K), generator=g) * 0.5).to(BF).to(device)
+    w = (torch.randn((N, K), generator=g) * 0.05).to(BF).to(device)
+    nw, s = K_.choose_wstream_config(M, N, K)
+    s = splits or s
+    want = K_.wstream_gemm(x, w, waves_per_group=nw, splits=s)
+    got_in = K_.wstream_gemm(_blocked(x), w, waves_per_group=nw, splits=s)
+    got_out = K_.wstream_gemm(x, w, waves_per_group=nw, splits=s, out_blocked=True)
+    assert got_out.shape == (N // 128, M, 128)
+    assert torch.equal(got_in, want)
+    assert torch.equal(K_.unblock(got_out), want)
+    # a blocked activation with padding between its chunks (a view of a larger buffer)
+    big = torch.zeros((K // 128, M + 3, 128), dtype=BF, device=device)
+    big[:, :M] = _blocked(x)
+    assert torch.equal(K_.wstream_gemm(big[:, :M], w, waves_per_group=nw, splits=s), want)
+
+
+@pytest.mark.parametrize("M", [3, 64])
+def test_wstream_chunk_major_epilogues(device, M):
+    K_ = _k()
+    g = torch.Generator().manual_seed(M)
+    I, K, H = 1792, 1024, 1024
+    x = torch.randn((M, K), generator=g).to(BF).to(device)
+    w13 = (torch.randn((2 * I, K), generator=g) * 0.05).to(BF).to(device)
+    for splits in (1, 2):
+        want = K_.wstream_gemm(x, w13, epilogue="silu_and_mul", splits=splits)
+        got = K_.wstream_gemm(_blocked(x), w13, epilogue="silu_and_mul", splits=splits, out_blocked=True)
+        assert torch.equal(K_.unblock(got), want)
+    w2 = (torch.randn((H, I), generator=g) * 0.05).to(BF).to(device)
+    act = K_.wstream_gemm(x, w13, epilogue="silu_and_mul")
+    nrm = torch.randn(H, generator=g).to(BF).to(device)
+    res0 = torch.randn((M, H), generator=g).to(BF).to(device)
+    r1, r2 = res0.clone(), res0.clone()
+    want = K_.wstream_gemm(act, w2, epilogue="add_rmsnorm", residual=r1, norm_weight=nrm, eps=1e-5, splits=2)
+    got = K_.wstream_gemm(_blocked(act), w2, epilogue="add_rmsnorm", residual=r2, norm_weight=nrm, eps=1e-5, splits=2,
+                          out_blocked=True)
+    assert torch.equal(K_.unblock(got), want) and torch.equal(r1, r2)
