@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--json", default=None)
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--M", type=int, default=64)
+    ap.add_argument("--blocked", action="store_true", help="chunk-major [K/128, M, 128] activations")
     args = ap.parse_args()
     shapes = [("gate_up", 28672, 4096), ("down", 4096, 14336), ("qkv", 6144, 4096), ("o", 4096, 4096),
               ("lm_head", 128256, 4096)]
@@ -52,6 +53,8 @@ def main():
         copies = max(2, int(600e6 // (N * Kd * 2)) + 1)
         ws = [(torch.randn((N, Kd), device=DEV) * 0.02).to(BF) for _ in range(copies)]
         x = torch.randn((M, Kd), device=DEV).to(BF)
+        if args.blocked:
+            x = x.view(M, Kd // 128, 128).permute(1, 0, 2).contiguous()
         wbytes = N * Kd * 2
         it = [0]
 
@@ -59,7 +62,7 @@ def main():
             it[0] = (it[0] + 1) % copies
             return ws[it[0]]
 
-        t = timeit(lambda: F.linear(x, nxt()))
+        t = timeit(lambda: F.linear(K.unblock(x), nxt()))
         rows.append(dict(shape=name, N=N, K=Kd, M=M, impl="hipblaslt", us=t * 1e6, GBps=wbytes / t / 1e9))
         print(json.dumps(rows[-1]), flush=True)
         nch = Kd // 128

@@ -18,6 +18,8 @@
 // hops (plan -> slot ids -> rows) whatever the context length; parallelism comes from the number of
 // items.  Each item writes an unnormalised (acc, max, sum) partial into its slot of every member;
 // the merge kernel combines the slots of a (request, head) in slot order.
+#include <type_traits>
+
 #include "common.hpp"
 #include "cascade_plan.hpp"
 #include "sglang_amd.h"
@@ -36,6 +38,18 @@ constexpr float kNegBig = -1.0e30f;
 
 __device__ __forceinline__ bf16x8_t as_frag(const U4& v) { return __builtin_bit_cast(bf16x8_t, v); }
 
+#ifdef CASC_TRACE
+// timeline probe (benchmarks/r02_exp8_casc_trace.py): per workgroup, the chip-wide 100 MHz clock at entry, record read,
+// K image staged, scores done, V image staged, partials stored
+__device__ uint64_t* g_casc_trace = nullptr;
+#define CASC_STAMP(i)                                                                                     \
+  do {                                                                                                    \
+    if (g_casc_trace && threadIdx.x == 0) g_casc_trace[static_cast<int64_t>(blockIdx.x) * 8 + (i)] = wall_clock64(); \
+  } while (0)
+#else
+#define CASC_STAMP(i)
+#endif
+
 struct ChunkParams {
   const uint16_t* q;            // [B, Hq, D]
   const uint16_t* k_cache;      // [slots, Hkv, D]
@@ -53,23 +67,32 @@ struct ChunkParams {
   float scale_log2;
 };
 
-// One 128-token K image, then (after S^T) the transposed V image, in the SAME 32 KiB (D = 128) buffer:
-// four workgroups fit a CU, so a whole decode step's items are resident at once.
+// The K rows, then (after S^T) the transposed V rows, pass through ONE 16 KiB LDS image; at D = 128 it is filled twice
+// per operand: K by token halves (64 tokens x 128 dims: each score tile is complete inside its half), V^T by head-dim
+// halves (64 dims x 128 tokens: each output tile is complete inside its half).  With <= 96 VGPRs that makes five
+// workgroups per CU resident -- 1280 on the chip: the bench batch's 1248 units run as one round
+// (at four per CU the last 224 started when the first finished, 7 us of a 20 us kernel, benchmarks/r02_exp8).
 // One workgroup per (item, kv head) unit; the grid covers the worst-case item count of the batch and the
 // workgroups behind the end of the device-built list leave after one load.  (A persistent loop over the
 // units was measured slower: hipcc hoists the lane-derived LDS addresses out of the loop and spills.)
 template <int D>
-__global__ __launch_bounds__(kThreads, 4) void cascade_chunk_kernel(ChunkParams p) {
-  __shared__ U4 sm[kChunk * D / 8];     // K: [token][16-byte piece ^ swz];  V^T: [d][8-token chunk ^ swz]
+__global__ __launch_bounds__(kThreads, 5) void cascade_chunk_kernel(ChunkParams p) {
+  constexpr int NP = D > 64 ? D / 64 : 1;   // parts the 16 KiB image is filled in: K by tokens, V^T by head dims
+  constexpr int RP = kChunk / NP;           // K rows (tokens) per part
+  constexpr int DH = D / NP;                // V^T rows (head dims) per part
+  constexpr int CPR = D / 8;                // 16-byte pieces per KV row
+  __shared__ U4 sm[RP * CPR];           // K: [token of the part][piece ^ swz];  V^T: [d of the part][8-token chunk ^ swz]
   const int unit = blockIdx.x;
-  constexpr int CPR = D / 8;            // 16-byte pieces per KV row
   constexpr int KC = D / 32;            // MFMA k-steps over the head dim
-  constexpr int ND = D / 16;            // 16-wide output tiles over the head dim
+  constexpr int NDH = D / 16 / NP;      // 16-wide output tiles of one V^T part
   constexpr int NT = kChunk / 16;       // 16-token tiles of the chunk
+  constexpr int NTP = NT / NP;          // ... of one K part
   constexpr int NKK = kChunk / 32;      // MFMA k-steps over the tokens
   constexpr int ROWS_PER_PASS = kThreads / CPR;
   constexpr int NK_LOADS = kChunk / ROWS_PER_PASS;   // K 16-byte loads per thread (8 at D=128)
+  constexpr int LPP = NK_LOADS / NP;                 // ... per part
   constexpr int V_THREADS = (kChunk / 8) * CPR;      // one 8x8 transposing block each
+  static_assert(RP % ROWS_PER_PASS == 0 && NT % NP == 0, "part boundaries");
 
   const CascadePlanView pv = cascade_plan_view(p.plan, p.batch, p.max_items);
 
@@ -78,29 +101,44 @@ __global__ __launch_bounds__(kThreads, 4) void cascade_chunk_kernel(ChunkParams 
   const int item = unit / p.num_kv_heads;
   const int kvh = unit - item * p.num_kv_heads;
   if (item >= p.max_items) return;
+  CASC_STAMP(0);
   // ---- one hop to a self-contained record ---------------------------------------------------
+  // (the record is the same for every lane: readfirstlane moves it to scalar registers, the kernel lives at 96 VGPRs)
   const int4 ra = *reinterpret_cast<const int4*>(pv.items + 8 * item);       // slot, kv_begin, kv_n, members
   const int4 rb = *reinterpret_cast<const int4*>(pv.items + 8 * item + 4);   // member_begin | request, private, pool row, group
-  const int n_mem = ra.w;
+  const int n_mem = __builtin_amdgcn_readfirstlane(ra.w);
   if (n_mem == 0) return;                                                     // end of the list
-  const int slot = ra.x, kv_begin = ra.y, kv_n = ra.z;
-  const int32_t* idx_base = p.req_to_token + static_cast<int64_t>(rb.z) * p.r2t_stride;
-  const int32_t* members = rb.y ? nullptr : pv.member_rows + rb.x;
-  const int single = rb.x;
+  CASC_STAMP(1);
+  const int slot = __builtin_amdgcn_readfirstlane(ra.x), kv_begin = __builtin_amdgcn_readfirstlane(ra.y),
+            kv_n = __builtin_amdgcn_readfirstlane(ra.z);
+  const int rec_x = __builtin_amdgcn_readfirstlane(rb.x), rec_private = __builtin_amdgcn_readfirstlane(rb.y),
+            rec_pool = __builtin_amdgcn_readfirstlane(rb.z);
+  const int32_t* idx_base = p.req_to_token + static_cast<int64_t>(rec_pool) * p.r2t_stride;
+  const int32_t* members = rec_private ? nullptr : pv.member_rows + rec_x;
   const int last = kv_begin + kv_n - 1;
   const int n_rows = n_mem * p.group;
 
+  // ---- this wave's 16 query rows: row = (member, q head of the kv head's group).  The member lookup goes first: the
+  // q loads depend on it and would otherwise wait, in order, behind the whole K / V burst ----------------------
+  const int r = wid * 16 + l15;
+  const bool wave_on = wid * 16 < n_rows;           // wave-uniform
+  const bool row_valid = r < n_rows;
+  const int mem_i = r / p.group, hg = r - mem_i * p.group;
+  int req = rec_x;
+  if (row_valid && members) req = members[mem_i];
+
   // ---- gather burst: all K / V rows of the chunk --------------------------------------------
   const int st_c = tid % CPR, st_r = tid / CPR;
-  const int64_t head_off = static_cast<int64_t>(kvh) * D + st_c * 8;
+  const int head_off = kvh * D + st_c * 8;
   const bool v_active = tid < V_THREADS;
-  U4 kst[NK_LOADS], vst[8];
+  U4 kst[NK_LOADS], vst[8], qfrag[KC];
+  int sl = 0;                                          // this row's partial slot (rows x slots_total fits 31 bits)
   {
     int32_t ks[NK_LOADS];
 #pragma unroll
     for (int i = 0; i < NK_LOADS; ++i) {
       int tok = kv_begin + st_r + ROWS_PER_PASS * i;
-      if (tok > last) tok = last;
+      if (tok > last) tok = last;      // (skipping the rows behind a short chunk's end instead measured no faster)
       ks[i] = idx_base[tok];
     }
     // V block of this thread: k-step kk = st_r >> 2, lane group vg = st_r & 3; token order inside the
@@ -115,6 +153,18 @@ __global__ __launch_bounds__(kThreads, 4) void cascade_chunk_kernel(ChunkParams 
         vs[i] = idx_base[tok];
       }
     }
+    // q goes out between the slot-id loads and the rows that depend on them: it waits for `req` only
+    if (wave_on) {
+      if (row_valid) {
+        const uint16_t* qp = p.q + static_cast<int64_t>(req) * p.q_stride + (kvh * p.group + hg) * D + g * 8;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) qfrag[kc] = ld16(qp + kc * 32);
+        sl = (req * p.num_q_heads + kvh * p.group + hg) * p.slots_total + slot;
+      } else {
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) qfrag[kc] = U4{0u, 0u, 0u, 0u};
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NK_LOADS; ++i) kst[i] = ld16(p.k_cache + static_cast<int64_t>(ks[i]) * p.kc_stride + head_off);
     if (v_active) {
@@ -123,117 +173,134 @@ __global__ __launch_bounds__(kThreads, 4) void cascade_chunk_kernel(ChunkParams 
     }
   }
 
-  // ---- this wave's 16 query rows: row = (member, q head of the kv head's group) -----------------
-  const int r = wid * 16 + l15;
-  const bool wave_on = wid * 16 < n_rows;           // wave-uniform
-  const bool row_ok = r < n_rows;
-  const int mem_i = r / p.group, hg = r - mem_i * p.group;
-  int64_t req = 0;
-  U4 qfrag[KC];
-  if (row_ok) {
-    req = members ? members[mem_i] : single;
-    const uint16_t* qp = p.q + req * p.q_stride + static_cast<int64_t>(kvh * p.group + hg) * D + g * 8;
-#pragma unroll
-    for (int kc = 0; kc < KC; ++kc) qfrag[kc] = ld16(qp + kc * 32);
-  } else {
-#pragma unroll
-    for (int kc = 0; kc < KC; ++kc) qfrag[kc] = U4{0u, 0u, 0u, 0u};
-  }
-
-  // ---- K image (row-major, XOR-swizzled pieces) ----------------------------------------------
-#pragma unroll
-  for (int i = 0; i < NK_LOADS; ++i) {
-    const int row = st_r + ROWS_PER_PASS * i;
-    sm[row * CPR + (st_c ^ (row & (CPR - 1)))] = kst[i];
-  }
-  __syncthreads();
-
-  // ---- S^T = K . Q^T : lane owns query row l15 of the wave, tokens 16 nt + 4 g + r --------------
-  float mx = kNegBig, psum = 0.f;
-  U4 pfrag[NKK];
-  if (wave_on) {
+  // Waves without query rows (three of four in a private item) only stage: they take their own copy of the code
+  // below with the matrix work compiled out -- same barriers, no accumulator registers kept alive for them.
+  auto body = [&](auto on_tag) {
+    constexpr bool ON = decltype(on_tag)::value;
+    const bool row_ok = ON && row_valid;
+    // ---- S^T = K . Q^T, one token part at a time: lane owns query row l15 of the wave, tokens 16 nt + 4 g + r.
+    // piece ^ swz(row) keeps the 16 rows of a fragment read on distinct banks (rows of 256 B: row & 15; 128 B:
+    // (row >> 1) & 7)
     f32x4_t st_acc[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      st_acc[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      const int row = nt * 16 + l15;
+    for (int h = 0; h < NP; ++h) {
 #pragma unroll
-      for (int kc = 0; kc < KC; ++kc) {
-        const U4 kf = sm[row * CPR + ((kc * 4 + g) ^ (row & (CPR - 1)))];
-        st_acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(kf), as_frag(qfrag[kc]), st_acc[nt], 0, 0, 0);
+      for (int i = 0; i < LPP; ++i) {
+        const int row = st_r + ROWS_PER_PASS * i;                     // row inside the part
+        sm[row * CPR + (st_c ^ ((row * CPR / 16) & (CPR - 1)))] = kst[h * LPP + i];
       }
+      __syncthreads();
+#ifdef CASC_TRACE
+      if (h == 0) CASC_STAMP(2);
+#endif
+      if constexpr (ON) {
+#pragma unroll
+        for (int n2 = 0; n2 < NTP; ++n2) {
+          const int row = n2 * 16 + l15;
+          f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kc = 0; kc < KC; ++kc) {
+            const U4 kf = sm[row * CPR + ((kc * 4 + g) ^ ((row * CPR / 16) & (CPR - 1)))];
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(kf), as_frag(qfrag[kc]), acc, 0, 0, 0);
+          }
+          st_acc[h * NTP + n2] = acc;
+          __builtin_amdgcn_sched_barrier(0);   // no fragment reads of the next tile hoisted up here: 96 VGPRs, no spill
+        }
+      }
+      __syncthreads();      // every wave is done with this part of the K image
     }
+    float mx = kNegBig, psum = 0.f;
+    U4 pfrag[NKK];
+    if constexpr (ON) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+      for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const float s = (nt * 16 + g * 4 + rr < kv_n) ? st_acc[nt][rr] * p.scale_log2 : kNegBig;
-        st_acc[nt][rr] = s;
-        mx = fmaxf(mx, s);
+        for (int rr = 0; rr < 4; ++rr) {
+          const float sv = (nt * 16 + g * 4 + rr < kv_n) ? st_acc[nt][rr] * p.scale_log2 : kNegBig;
+          st_acc[nt][rr] = sv;
+          mx = fmaxf(mx, sv);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk) {
+        float e[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float sv = st_acc[2 * kk + (i >> 2)][i & 3];
+          e[i] = (sv > 0.5f * kNegBig) ? fast_exp2(sv - mx) : 0.f;
+          psum += e[i];
+        }
+        pfrag[kk].x = pack_bf2(e[0], e[1]);
+        pfrag[kk].y = pack_bf2(e[2], e[3]);
+        pfrag[kk].z = pack_bf2(e[4], e[5]);
+        pfrag[kk].w = pack_bf2(e[6], e[7]);
       }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-#pragma unroll
-    for (int kk = 0; kk < NKK; ++kk) {
-      float e[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float s = st_acc[2 * kk + (i >> 2)][i & 3];
-        e[i] = (s > 0.5f * kNegBig) ? fast_exp2(s - mx) : 0.f;
-        psum += e[i];
-      }
-      pfrag[kk].x = pack_bf2(e[0], e[1]);
-      pfrag[kk].y = pack_bf2(e[2], e[3]);
-      pfrag[kk].z = pack_bf2(e[4], e[5]);
-      pfrag[kk].w = pack_bf2(e[6], e[7]);
+      psum += __shfl_xor(psum, 16, 64);
+      psum += __shfl_xor(psum, 32, 64);
     }
-    psum += __shfl_xor(psum, 16, 64);
-    psum += __shfl_xor(psum, 32, 64);
-  }
-  __syncthreads();        // every wave is done with the K image
+    CASC_STAMP(3);
 
-  // ---- V^T image: 8x8 blocks transposed through registers -------------------------------------
-  if (v_active) {
-    const uint32_t* w = reinterpret_cast<const uint32_t*>(vst);   // vst[i] dword q -> w[4 i + q]
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int d = st_c * 8 + j;
-      U4 o;
-      uint32_t* ow = reinterpret_cast<uint32_t*>(&o);
-#pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        const uint32_t a = w[4 * (2 * qd) + (j >> 1)];
-        const uint32_t c = w[4 * (2 * qd + 1) + (j >> 1)];
-        ow[qd] = (j & 1) ? ((a >> 16) | (c & 0xffff0000u)) : ((a & 0xffffu) | (c << 16));
+    // ---- O^T = V^T . P^T per head-dim part: the V^T image is built from 8x8 blocks transposed through registers;
+    // lane holds O^T[d = 16 n + 4 g + r][row l15] -------------------------------------------------------------
+    float* ap = nullptr;
+    if constexpr (ON) {
+      if (row_ok) {
+        int sl32 = sl;
+        asm volatile("" : "+v"(sl32));     // widened here, not carried as a register pair through the kernel
+        const int64_t sl64 = sl32;
+        ap = p.ws_acc + sl64 * D + g * 4;
+        if (g == 0) {
+          p.ws_ml[sl64 * 2 + 0] = mx;
+          p.ws_ml[sl64 * 2 + 1] = psum;
+        }
       }
-      sm[d * 16 + (st_r ^ ((d ^ (d >> 3)) & 15))] = o;
     }
-  }
-  __syncthreads();
-
-  // ---- O^T = V^T . P^T : lane holds O^T[d = 16 n + 4 g + r][row l15] ----------------------------
-  if (wave_on) {
-  float* ap = nullptr;
-  if (row_ok) {
-    const int64_t sl = (req * p.num_q_heads + kvh * p.group + hg) * p.slots_total + slot;
-    ap = p.ws_acc + sl * D + g * 4;
-    if (g == 0) {
-      p.ws_ml[sl * 2 + 0] = mx;
-      p.ws_ml[sl * 2 + 1] = psum;
-    }
-  }
 #pragma unroll
-  for (int n = 0; n < ND; ++n) {
-    f32x4_t ot = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    const int d = n * 16 + l15;
+    for (int h = 0; h < NP; ++h) {
+      if (v_active && st_c * 8 / DH == h) {
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(vst);   // vst[i] dword q -> w[4 i + q]
 #pragma unroll
-    for (int kk = 0; kk < NKK; ++kk) {
-      const U4 vf = sm[d * 16 + ((kk * 4 + g) ^ ((d ^ (d >> 3)) & 15))];
-      ot = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(vf), as_frag(pfrag[kk]), ot, 0, 0, 0);
+        for (int j = 0; j < 8; ++j) {
+          const int d = st_c * 8 + j;
+          U4 o;
+          uint32_t* ow = reinterpret_cast<uint32_t*>(&o);
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd) {
+            const uint32_t a = w[4 * (2 * qd) + (j >> 1)];
+            const uint32_t c = w[4 * (2 * qd + 1) + (j >> 1)];
+            ow[qd] = (j & 1) ? ((a >> 16) | (c & 0xffff0000u)) : ((a & 0xffffu) | (c << 16));
+          }
+          sm[(d - h * DH) * 16 + (st_r ^ ((d ^ (d >> 3)) & 15))] = o;
+        }
+      }
+      __syncthreads();
+#ifdef CASC_TRACE
+      if (h == 0) CASC_STAMP(4);
+#endif
+      if constexpr (ON) {
+#pragma unroll
+        for (int n2 = 0; n2 < NDH; ++n2) {
+          const int n = h * NDH + n2;
+          f32x4_t ot = f32x4_t{0.f, 0.f, 0.f, 0.f};
+          const int d = n * 16 + l15;
+#pragma unroll
+          for (int kk = 0; kk < NKK; ++kk) {
+            const U4 vf = sm[(d - h * DH) * 16 + ((kk * 4 + g) ^ ((d ^ (d >> 3)) & 15))];
+            ot = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(vf), as_frag(pfrag[kk]), ot, 0, 0, 0);
+          }
+          if (row_ok) *reinterpret_cast<f32x4_t*>(ap + n * 16) = ot;
+        }
+      }
+      if (h + 1 < NP) __syncthreads();
     }
-    if (row_ok) *reinterpret_cast<f32x4_t*>(ap + n * 16) = ot;
-  }
-  }
+  };
+  if (wave_on) body(std::true_type{});
+  else body(std::false_type{});
+#ifdef CASC_TRACE
+  __builtin_amdgcn_s_waitcnt(0);
+  CASC_STAMP(5);
+#endif
 }
 
 // ---- cascade plan: group the requests of a decode batch that share a KV prefix ----------------
@@ -481,6 +548,13 @@ __global__ __launch_bounds__(256) void cascade_merge2_kernel(const float* __rest
 }  // namespace
 
 extern "C" {
+
+#ifdef CASC_TRACE
+int sgl_amd_debug_casc_trace(void* buf) {
+  uint64_t* p = static_cast<uint64_t*>(buf);
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_casc_trace), &p, sizeof(p)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 int sgl_amd_cascade_chunk_tokens(void) { return kChunk; }
 

@@ -1,0 +1,44 @@
+"""Build-time guard: the kernels whose residency is tuned to a register budget must not spill (hipcc's allocator is
+one refactor away from scratch traffic in the middle of a load burst).  Cross-compiles for gfx950; no GPU needed."""
+import re
+import shutil
+import subprocess
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def _resource_usage(src: str, tmp_path):
+    out = tmp_path / "k.s"
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{ROOT / 'include'}", "--cuda-device-only", "-S",
+           str(ROOT / "sglang_amd" / "csrc" / src), "-o", str(out)]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-2000:]
+    usage = {}
+    name = None
+    for line in out.read_text().splitlines():
+        m = re.match(r"\s+\.name:\s+(\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.match(r"\s+\.(vgpr_count|vgpr_spill_count|sgpr_spill_count|group_segment_fixed_size):\s+(\d+)", line)
+        if m:
+            usage.setdefault("pending", {})[m.group(1)] = int(m.group(2))
+        if name and "pending" in usage and line.strip().startswith(".wavefront_size"):
+            usage[name] = usage.pop("pending")
+            name = None
+    usage.pop("pending", None)
+    return usage
+
+
+@pytest.mark.skipif(not Path(HIPCC).exists(), reason="hipcc not installed")
+def test_cascade_chunk_kernel_fits_five_workgroups_per_cu(tmp_path):
+    usage = _resource_usage("cascade_attention.hip", tmp_path)
+    chunk = {k: v for k, v in usage.items() if "cascade_chunk_kernel" in k}
+    assert len(chunk) == 2, sorted(usage)
+    for name, u in chunk.items():
+        assert u["vgpr_spill_count"] == 0 and u["sgpr_spill_count"] == 0, (name, u)
+        assert u["vgpr_count"] <= 96, (name, u)                 # 512 / 5 waves per SIMD, 8-register granules
+        assert u["group_segment_fixed_size"] <= 16384, (name, u)  # five 16 KiB images of the 160 KiB (LDS granule 1280 B)
