@@ -74,13 +74,19 @@ def main():
                 for s in (1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16):
                     if s <= nch // 2:
                         cands.add((nw, s))
-        for nw, s in sorted(cands):
+            for nw in (2, 3, 4):                      # two tiles per wave
+                for s in (1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16):
+                    if s <= nch // 2 and N % 32 == 0:
+                        cands.add((nw, s, 2))
+        for cand in sorted(cands):
+            nw, s = cand[:2]
+            tpw = cand[2] if len(cand) > 2 else 1
             try:
-                t = timeit(lambda: K.wstream_gemm(x, nxt(), waves_per_group=nw, splits=s))
+                t = timeit(lambda: K.wstream_gemm(x, nxt(), waves_per_group=nw, splits=s, tiles_per_wave=tpw))
             except RuntimeError as e:
                 print("skip", nw, s, e)
                 continue
-            rows.append(dict(shape=name, N=N, K=Kd, M=M, impl="wstream", nw=nw, splits=s, auto=(nw, s) == auto,
+            rows.append(dict(shape=name, N=N, K=Kd, M=M, impl="wstream", nw=nw, splits=s, tpw=tpw, auto=(nw, s) == auto and tpw == 1,
                              us=t * 1e6, GBps=wbytes / t / 1e9))
             print(json.dumps(rows[-1]), flush=True)
         del ws
@@ -93,7 +99,7 @@ def main():
         rs = [r for r in rows if r["shape"] == name]
         lib = [r for r in rs if r["impl"] == "hipblaslt"][0]
         best = min((r for r in rs if r["impl"] == "wstream"), key=lambda r: r["us"])
-        print(f"{name:8s} hipblaslt {lib['us']:7.1f} us {lib['GBps']:6.0f} GB/s | best wstream nw={best['nw']} s={best['splits']} "
+        print(f"{name:8s} hipblaslt {lib['us']:7.1f} us {lib['GBps']:6.0f} GB/s | best wstream nw={best['nw']} tpw={best['tpw']} s={best['splits']} "
               f"{best['us']:7.1f} us {best['GBps']:6.0f} GB/s")
 
 

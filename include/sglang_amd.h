@@ -225,9 +225,10 @@ int64_t sgl_amd_skinny_gemm_slab_floats(int64_t row_blocks, int64_t N, int split
 /* Weight-streaming GEMM for decode batches (M <= sgl_amd_wstream_gemm_max_rows()): y = x . w^T, bf16,
  * fp32 accumulate; needs N % 16 == 0 and K % 128 == 0 (other shapes: sgl_amd_skinny_gemm).
  * Replaces the library matmul of srt/layers/linear.py:1596-1660 (UnquantizedLinearMethod.apply) at decode.
- * waves_per_group (4..8; 4..5 beyond 64 rows) x num_k_splits is the host's choice of decomposition: one workgroup is
- * resident per CU (its LDS ring holds the in-flight chunks), so ceil(N/16/waves) x splits should be a
- * whole number of 256-workgroup rounds.  num_k_splits > 1 writes fp32 partials
+ * waves_per_group (4..8; 4..5 beyond 64 rows) x tiles_per_wave x num_k_splits is the host's choice of decomposition:
+ * one workgroup is resident per CU (its LDS ring holds the in-flight chunks), so ceil(N/16/tiles/waves) x splits
+ * should be a whole number of 256-workgroup rounds.  tiles_per_wave = 2 (N % 32 == 0, waves_per_group 2..4): a wave
+ * owns output tiles t and t + N/32, which halves the activation traffic per weight byte.  num_k_splits > 1 writes fp32 partials
  * [splits, M, N] to ws_partials (sgl_amd_wstream_gemm_workspace_floats) and a combine kernel sums
  * them in split order (deterministic) and applies `epilogue`:
  *   0: y[M,N]   = bf16(acc + bias)                         (bias may be NULL; also valid with 1 split)
@@ -246,7 +247,7 @@ int sgl_amd_wstream_gemm(const void* x, const void* w, const void* bias, void* y
                          int64_t K, int64_t x_row_stride, int64_t x_chunk_stride, int64_t w_row_stride,
                          int64_t y_row_stride, int64_t y_chunk_stride, int epilogue, void* residual,
                          int64_t residual_row_stride, const void* norm_weight, float eps, int waves_per_group,
-                         int num_k_splits, void* ws_partials, void* stream);
+                         int tiles_per_wave, int num_k_splits, void* ws_partials, void* stream);
 /* qkv_proj + neox rotary embedding + KV-pool store for a decode batch, as one GEMM + combine pair:
  * q_out[M, Hq*D] = rope(x . w_q^T + b), k_cache[cache_loc[m]] = rope(x . w_k^T + b), v_cache[...] = x . w_v^T + b,
  * with the rounding points of QKVParallelLinear -> RotaryEmbedding.forward_native -> set_kv_buffer
@@ -258,8 +259,8 @@ int sgl_amd_wstream_qkv_rope(const void* x, const void* w_qkv, const void* bias,
                              int64_t x_row_stride, int64_t x_chunk_stride, int64_t w_row_stride, int64_t q_row_stride,
                              const int64_t* positions, const void* cos_sin_cache, int cache_is_f32,
                              int64_t rotary_dim, void* k_cache, void* v_cache, const int64_t* cache_loc,
-                             int64_t cache_row_stride, int waves_per_group, int num_k_splits,
-                             void* ws_partials, void* stream);
+                             int64_t cache_row_stride, int waves_per_group, int tiles_per_wave,
+                             int num_k_splits, void* ws_partials, void* stream);
 /* Grouped (mixture-of-experts) form of the weight-streaming GEMM, same contract as sgl_amd_moe_grouped_gemm
  * (fused_moe_triton_kernels.py:324,771) for shapes with N % 16 == 0 and K % 128 == 0, without split-K: one
  * workgroup per (row block of moe_align_block_size, group of weight tiles of that block's expert).  fuse_silu=1:

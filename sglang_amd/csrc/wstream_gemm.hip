@@ -73,6 +73,7 @@ struct WsParams {
   int topk_div;                 // source row of pair id = id / topk_div
   int out_f32;                  // y is fp32 (the down projection ahead of moe_sum_reduce)
   int round_before_scale;       // round the accumulator to bf16 before the router weight (fused_moe_native.py:157-163)
+  int pair_silu;                // two-tile waves: y[:, 16 t ..] = silu(tile t) * tile (t + ntiles/2) instead of two outputs
 };
 
 // ---- LDS-DMA plumbing ------------------------------------------------------------------------
@@ -125,8 +126,9 @@ constexpr int ring_depth(int mt, int nw, int tpw) {
   return d > 6 ? 6 : d;
 }
 
-// TPW = 16-row weight tiles per wave.  TPW == 2 is the silu_and_mul form: the wave owns gate tile t and up
-// tile t + ntiles/2 and writes y[m, 16 t ..] = silu(gate) * up (no partials, no second launch).
+// TPW = 16-row weight tiles per wave.  TPW == 2: the wave owns tiles t and t + ntiles/2 (half the activation reads
+// per weight byte); with pair_silu they are a gate tile and its up tile and the wave writes
+// y[m, 16 t ..] = silu(gate) * up (no partials, no second launch).
 template <int MT, int NW, int TPW, bool GROUPED>
 __global__ __launch_bounds__(64 * NW, 1) void wstream_gemm_kernel(WsParams p) {
   constexpr int PD = ring_depth(MT, NW, TPW);
@@ -341,39 +343,49 @@ __global__ __launch_bounds__(64 * NW, 1) void wstream_gemm_kernel(WsParams p) {
     } else {
       if (m >= p.M) continue;
     }
-    float o[4];
-    if constexpr (TPW == 2) {
+    // one 4-wide piece of an output row: partial, or bias / router weight and the store
+    auto put = [&](float (&o)[4], int nn, bool plain) {
+      if (plain && !GROUPED && p.bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] += bf2f(p.bias[nn + r]);
+      }
+      if (GROUPED && p.row_scale) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (p.round_before_scale ? rbf(o[r]) : o[r]) * scale;
+      }
+      if (GROUPED && p.out_f32) {
+        *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(p.y) + m * p.y_stride + nn) = f32x4_t{o[0], o[1], o[2], o[3]};
+      } else {
+        uint2 w2;
+        w2.x = pack_bf2(o[0], o[1]);
+        w2.y = pack_bf2(o[2], o[3]);
+        *reinterpret_cast<uint2*>(p.y + blocked_off(m, nn, p.y_stride, p.y_cstride)) = w2;
+      }
+    };
+    if (TPW == 2 && p.pair_silu) {
       // linear -> bf16, silu -> bf16, product -> bf16 (activation.py:141-143)
+      float o[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float gb = rbf(acc[0][mt][r]);
         const float sl = rbf(gb / (1.0f + expf(-gb)));
-        o[r] = sl * rbf(acc[1][mt][r]);
+        o[r] = sl * rbf(acc[TPW - 1][mt][r]);
       }
-    } else {
+      put(o, n0, false);
+      continue;
+    }
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {                      // plain form: tile t of the wave is output tile `tile + t * wtiles`
+      const int nn = n0 + t * wtiles * 16;
       if (!GROUPED && p.part) {
         float* base = p.part + static_cast<int64_t>(split) * p.M * p.N;
-        *reinterpret_cast<f32x4_t*>(base + m * p.N + n0) = acc[0][mt];
+        *reinterpret_cast<f32x4_t*>(base + m * p.N + nn) = acc[t][mt];
         continue;
       }
+      float o[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] = acc[0][mt][r];
-      if (!GROUPED && p.bias) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] += bf2f(p.bias[n0 + r]);
-      }
-    }
-    if (GROUPED && p.row_scale) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] = (p.round_before_scale ? rbf(o[r]) : o[r]) * scale;
-    }
-    if (GROUPED && p.out_f32) {
-      *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(p.y) + m * p.y_stride + n0) = f32x4_t{o[0], o[1], o[2], o[3]};
-    } else {
-      uint2 w2;
-      w2.x = pack_bf2(o[0], o[1]);
-      w2.y = pack_bf2(o[2], o[3]);
-      *reinterpret_cast<uint2*>(p.y + blocked_off(m, n0, p.y_stride, p.y_cstride)) = w2;
+      for (int r = 0; r < 4; ++r) o[r] = acc[t][mt][r];
+      put(o, nn, true);
     }
   }
 }
@@ -599,8 +611,8 @@ int launch_main(const WsParams& p, hipStream_t st, int row_blocks = 0) {
 }
 
 template <int MT>
-int launch_nw(const WsParams& p, int nw, bool fused_silu, hipStream_t st, int row_blocks = 0) {
-  if (fused_silu) {                                   // two tiles per wave: half the waves for the same LDS ring
+int launch_nw(const WsParams& p, int nw, bool two_tiles, hipStream_t st, int row_blocks = 0) {
+  if (two_tiles) {                                    // two tiles per wave: half the waves for the same LDS ring
     switch (nw) {
       case 2: return launch_main<MT, 2, 2>(p, st, row_blocks);
       case 3: return launch_main<MT, 3, 2>(p, st, row_blocks);
@@ -638,15 +650,18 @@ int64_t sgl_amd_wstream_gemm_workspace_floats(int64_t M, int64_t N, int num_k_sp
 // shared by the two entry points: validates the GEMM part and launches the main kernel
 static int wstream_launch_main(const char* who, const void* x, const void* w, const void* bias, void* y, int64_t M, int64_t N,
                                int64_t K, int64_t x_row_stride, int64_t x_chunk_stride, int64_t w_row_stride,
-                               int64_t y_row_stride, int64_t y_chunk_stride, bool fused_silu,
+                               int64_t y_row_stride, int64_t y_chunk_stride, bool fused_silu, int tiles_per_wave,
                                bool to_partials, int waves_per_group, int num_k_splits, void* ws_partials, hipStream_t st) {
   SGL_CHECK_ARG(M >= 1 && M <= 128, "%s: M=%lld rows (supported: 1..128)", who, (long long)M);
   SGL_CHECK_ARG(N > 0 && N % 16 == 0 && K >= kKC && K % kKC == 0,
                 "%s: need N %% 16 == 0 and K %% %d == 0 (got N=%lld K=%lld)", who, kKC, (long long)N, (long long)K);
   SGL_CHECK_ARG(x_row_stride % 8 == 0 && w_row_stride % 8 == 0 && y_row_stride % 4 == 0,
                 "%s: row strides must keep 16-byte (x, w) / 8-byte (y) alignment", who);
-  SGL_CHECK_ARG(fused_silu ? (waves_per_group >= 2 && waves_per_group <= 4) : (waves_per_group >= 4 && waves_per_group <= 8),
-                "%s: waves_per_group must be 4..8 (2..4 for the one-pass silu_and_mul form), got %d", who, waves_per_group);
+  const bool two_tiles = fused_silu || tiles_per_wave == 2;
+  SGL_CHECK_ARG(tiles_per_wave == 1 || tiles_per_wave == 2, "%s: tiles_per_wave must be 1 or 2", who);
+  SGL_CHECK_ARG(!two_tiles || N % 32 == 0, "%s: two tiles per wave need N %% 32 == 0", who);
+  SGL_CHECK_ARG(two_tiles ? (waves_per_group >= 2 && waves_per_group <= 4) : (waves_per_group >= 4 && waves_per_group <= 8),
+                "%s: waves_per_group must be 4..8 (2..4 with two tiles per wave), got %d", who, waves_per_group);
   SGL_CHECK_ARG(num_k_splits >= 1 && num_k_splits <= K / kKC, "%s: bad split count %d", who, num_k_splits);
   SGL_CHECK_ARG(!to_partials || ws_partials, "%s: needs the fp32 partials workspace", who);
   WsParams p{};
@@ -662,14 +677,15 @@ static int wstream_launch_main(const char* who, const void* x, const void* w, co
   p.y_cstride = y_chunk_stride ? y_chunk_stride : 128;
   p.M = static_cast<int>(M); p.N = static_cast<int>(N); p.K = static_cast<int>(K);
   p.splits = num_k_splits; p.ntiles = static_cast<int>(N / 16);
+  p.pair_silu = fused_silu ? 1 : 0;
   int rc;
   switch (static_cast<int>((M + 15) / 16)) {
-    case 1: rc = launch_nw<1>(p, waves_per_group, fused_silu, st); break;
-    case 2: rc = launch_nw<2>(p, waves_per_group, fused_silu, st); break;
-    case 3: rc = launch_nw<3>(p, waves_per_group, fused_silu, st); break;
-    case 4: rc = launch_nw<4>(p, waves_per_group, fused_silu, st); break;
-    case 5: case 6: rc = launch_nw<6>(p, waves_per_group, fused_silu, st); break;
-    default: rc = launch_nw<8>(p, waves_per_group, fused_silu, st); break;
+    case 1: rc = launch_nw<1>(p, waves_per_group, two_tiles, st); break;
+    case 2: rc = launch_nw<2>(p, waves_per_group, two_tiles, st); break;
+    case 3: rc = launch_nw<3>(p, waves_per_group, two_tiles, st); break;
+    case 4: rc = launch_nw<4>(p, waves_per_group, two_tiles, st); break;
+    case 5: case 6: rc = launch_nw<6>(p, waves_per_group, two_tiles, st); break;
+    default: rc = launch_nw<8>(p, waves_per_group, two_tiles, st); break;
   }
   SGL_CHECK_ARG(rc == 0, "%s: unsupported configuration", who);
   return 0;
@@ -678,8 +694,8 @@ static int wstream_launch_main(const char* who, const void* x, const void* w, co
 int sgl_amd_wstream_gemm(const void* x, const void* w, const void* bias, void* y, int64_t M, int64_t N, int64_t K,
                          int64_t x_row_stride, int64_t x_chunk_stride, int64_t w_row_stride, int64_t y_row_stride,
                          int64_t y_chunk_stride, int epilogue, void* residual, int64_t residual_row_stride,
-                         const void* norm_weight, float eps, int waves_per_group, int num_k_splits, void* ws_partials,
-                         void* stream) {
+                         const void* norm_weight, float eps, int waves_per_group, int tiles_per_wave, int num_k_splits,
+                         void* ws_partials, void* stream) {
   SGL_CLEAR_STALE_ERROR();
   if (M == 0) return 0;
   SGL_CHECK_ARG(epilogue >= 0 && epilogue <= 2, "wstream_gemm: epilogue must be 0 (bias), 1 (silu_and_mul) or 2 (add_rmsnorm)");
@@ -693,7 +709,7 @@ int sgl_amd_wstream_gemm(const void* x, const void* w, const void* bias, void* y
   SGL_CHECK_ARG(y_chunk_stride == 0 || (epilogue == 1 ? N % 256 == 0 : N % 128 == 0),
                 "wstream_gemm: a chunk-major y needs whole 128-column blocks");
   if (int rc = wstream_launch_main("wstream_gemm", x, w, bias, y, M, N, K, x_row_stride, x_chunk_stride, w_row_stride, y_row_stride,
-                                   y_chunk_stride, fused_silu, combine, waves_per_group, num_k_splits, ws_partials, st))
+                                   y_chunk_stride, fused_silu, tiles_per_wave, combine, waves_per_group, num_k_splits, ws_partials, st))
     return rc;
   if (combine) {
     CombineParams c{};
@@ -744,6 +760,7 @@ int sgl_amd_wstream_moe_gemm(const void* a, const void* w, void* c, const int32_
   p.sorted_ids = sorted_token_ids; p.expert_ids = expert_ids; p.num_post_pad = num_tokens_post_padded;
   p.row_scale = mul_routed_weight ? topk_weights : nullptr;
   p.topk_div = top_k_div; p.out_f32 = out_f32; p.round_before_scale = round_before_scale;
+  p.pair_silu = fuse_silu ? 1 : 0;
   hipStream_t st = as_stream(stream);
   const int blocks = static_cast<int>(max_m_blocks);
   int rc;
@@ -762,7 +779,8 @@ int sgl_amd_wstream_qkv_rope(const void* x, const void* w_qkv, const void* bias,
                              int num_q_heads, int num_kv_heads, int head_dim, int64_t x_row_stride, int64_t x_chunk_stride,
                              int64_t w_row_stride, int64_t q_row_stride, const int64_t* positions, const void* cos_sin_cache, int cache_is_f32,
                              int64_t rotary_dim, void* k_cache, void* v_cache, const int64_t* cache_loc,
-                             int64_t cache_row_stride, int waves_per_group, int num_k_splits, void* ws_partials, void* stream) {
+                             int64_t cache_row_stride, int waves_per_group, int tiles_per_wave, int num_k_splits,
+                             void* ws_partials, void* stream) {
   SGL_CLEAR_STALE_ERROR();
   if (M == 0) return 0;
   SGL_CHECK_ARG(num_q_heads > 0 && num_kv_heads > 0 && head_dim % 16 == 0 && rotary_dim == head_dim,
@@ -772,7 +790,7 @@ int sgl_amd_wstream_qkv_rope(const void* x, const void* w_qkv, const void* bias,
   const int64_t N = static_cast<int64_t>(num_q_heads + 2 * num_kv_heads) * head_dim;
   hipStream_t st = as_stream(stream);
   if (int rc = wstream_launch_main("wstream_qkv_rope", x, w_qkv, nullptr, nullptr, M, N, K, x_row_stride, x_chunk_stride, w_row_stride,
-                                   4, 0, false, true, waves_per_group, num_k_splits, ws_partials, st))
+                                   4, 0, false, tiles_per_wave, true, waves_per_group, num_k_splits, ws_partials, st))
     return rc;
   RopeParams r{};
   r.part = static_cast<const float*>(ws_partials); r.bias = static_cast<const uint16_t*>(bias);

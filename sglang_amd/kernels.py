@@ -607,10 +607,39 @@ def unblock(x: torch.Tensor) -> torch.Tensor:
     return x.permute(1, 0, 2).reshape(x.shape[1], -1) if x.dim() == 3 else x
 
 
+@functools.lru_cache(maxsize=None)
+def choose_wstream_decomposition(M: int, N: int, K: int, need_combine: bool = False, fused_silu: bool = False) -> Tuple[int, int, int]:
+    """(waves_per_group, tiles_per_wave, k_splits).  On top of choose_wstream_config(): a launch without split-K
+    whose rows fit 64 may give every wave two output tiles (t and t + N/32) -- half the activation traffic per weight
+    byte: lm_head 200 -> 174 us, the unfused gate_up 39.6 -> 39.1 (benchmarks/gemm_sweep.py --blocked).  With split-K
+    the two-tile forms measured no faster (down 27.8 vs 27.5 us), so those keep one tile per wave."""
+    nw, s = choose_wstream_config(M, N, K, need_combine, fused_silu)
+    if fused_silu:
+        return nw, 2, s
+    if s != 1 or M > 64 or N % 32 != 0:
+        return nw, 1, s
+    nch = K // 128
+
+    def rounds_time(groups: int, wg_bytes: int, chip: float, per_cu: float) -> float:
+        full, rem = divmod(groups, _NUM_CUS)
+        t = 2.0e-6 + full * _NUM_CUS * wg_bytes / chip
+        if rem:
+            t += rem * wg_bytes / min(chip, rem * per_cu)
+        return t
+
+    one = rounds_time((N // 16 + nw - 1) // nw, nw * nch * 4096, 5.3e12, 24e9)
+    best = (one, nw, 1)
+    for nw2 in (4, 3, 2):
+        two = rounds_time((N // 32 + nw2 - 1) // nw2, nw2 * nch * 8192, 6.0e12, 26e9)
+        if two < best[0] * 0.98:
+            best = (two, nw2, 2)
+    return best[1], best[2], 1
+
+
 def wstream_gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: str = "none",
                  residual: Optional[torch.Tensor] = None, norm_weight: Optional[torch.Tensor] = None, eps: float = 0.0,
                  out: Optional[torch.Tensor] = None, waves_per_group: Optional[int] = None,
-                 splits: Optional[int] = None, out_blocked: bool = False) -> torch.Tensor:
+                 splits: Optional[int] = None, out_blocked: bool = False, tiles_per_wave: Optional[int] = None) -> torch.Tensor:
     """Decode-batch F.linear(x, w, bias) on the weight-streaming kernel, optionally followed (in the
     split-K combine kernel) by silu_and_mul or by fused_add_rmsnorm(out, residual, norm_weight, eps).
     x may be chunk-major (see _x_layout); out_blocked=True returns the result chunk-major."""
@@ -629,24 +658,30 @@ def wstream_gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] 
     if ep == 2:
         _need(residual is not None and norm_weight is not None and residual.shape == (M, N) and residual.stride(1) == 1
               and residual.dtype == _BF16 and norm_weight.dtype == _BF16, "wstream_gemm: add_rmsnorm needs residual [M,N] and norm_weight")
+    tpw_auto = 1
     if waves_per_group is None or splits is None:
         # silu_and_mul: one pass with two tiles per wave when the caller does not force a split
         one_pass = ep == 1 and splits in (None, 1) and N % 32 == 0 and bias is None
-        nw_auto, s_auto = choose_wstream_config(M, N, K, ep != 0, one_pass)
+        if waves_per_group is None and splits is None and tiles_per_wave is None:
+            nw_auto, tpw_auto, s_auto = choose_wstream_decomposition(M, N, K, ep != 0, one_pass)
+        else:
+            nw_auto, s_auto = choose_wstream_config(M, N, K, ep != 0, one_pass)
     nw = waves_per_group or nw_auto
     s = splits or s_auto
     one_pass = ep == 1 and s == 1 and N % 32 == 0 and bias is None
+    tpw = 2 if one_pass else (tiles_per_wave or tpw_auto)
     ws = _gemm_workspace(x.device, native.lib().sgl_amd_wstream_gemm_workspace_floats(M, N, s)) if ((s > 1 or ep) and not one_pass) else None
     native.call("sgl_amd_wstream_gemm", x.data_ptr(), w.data_ptr(), _ptr(bias), out.data_ptr(), M, N, K, x_rs, x_cs,
                 w.stride(0), y_rs, y_cs, ep, _ptr(residual), residual.stride(0) if residual is not None else 0,
-                _ptr(norm_weight), float(eps), nw, s, _ptr(ws), _stream())
+                _ptr(norm_weight), float(eps), nw, tpw, s, _ptr(ws), _stream())
     return out
 
 
 def wstream_qkv_rope(x: torch.Tensor, w_qkv: torch.Tensor, bias: Optional[torch.Tensor], positions: torch.Tensor,
                      cos_sin_cache: torch.Tensor, num_q_heads: int, num_kv_heads: int, head_dim: int,
                      k_cache: torch.Tensor, v_cache: torch.Tensor, cache_loc: torch.Tensor,
-                     waves_per_group: Optional[int] = None, splits: Optional[int] = None) -> torch.Tensor:
+                     waves_per_group: Optional[int] = None, splits: Optional[int] = None,
+                     tiles_per_wave: Optional[int] = None) -> torch.Tensor:
     """Decode-batch qkv_proj + neox rotary embedding + KV-pool store (one GEMM + combine pair): returns the
     rotated q [M, Hq*D]; the rotated k rows and the v rows land in k_cache / v_cache at cache_loc."""
     _dev(x, w_qkv, positions, cos_sin_cache, k_cache, v_cache, cache_loc)
@@ -669,7 +704,7 @@ def wstream_qkv_rope(x: torch.Tensor, w_qkv: torch.Tensor, bias: Optional[torch.
     native.call("sgl_amd_wstream_qkv_rope", x.data_ptr(), w_qkv.data_ptr(), _ptr(bias), q_out.data_ptr(), M, K, num_q_heads,
                 num_kv_heads, head_dim, x_rs, x_cs, w_qkv.stride(0), q_out.stride(0), positions.data_ptr(),
                 cos_sin_cache.data_ptr(), 1 if cos_sin_cache.dtype == torch.float32 else 0, cos_sin_cache.shape[-1],
-                kc.data_ptr(), vc.data_ptr(), cache_loc.data_ptr(), kc.stride(0), nw, s, ws.data_ptr(), _stream())
+                kc.data_ptr(), vc.data_ptr(), cache_loc.data_ptr(), kc.stride(0), nw, tiles_per_wave or 1, s, ws.data_ptr(), _stream())
     return q_out
 
 

@@ -32,6 +32,26 @@ def test_wstream_config_fills_the_chip_on_the_bench_shapes():
     assert K.choose_wstream_config(64, 28672, 4096, True, True) == (4, 1)   # one pass, gate + up tile per wave
 
 
+@pytest.mark.parametrize("M", [1, 16, 64, 100])
+@pytest.mark.parametrize("N,Kd", [(28672, 4096), (4096, 14336), (6144, 4096), (128256, 4096), (151936, 896), (112, 256), (16, 128)])
+def test_wstream_decomposition_two_tile_waves_only_where_they_pay(M, N, Kd):
+    """Two output tiles per wave: launches without split-K, at most 64 rows, N % 32 == 0 -- and a group size the
+    two-tile kernels exist for; everything else keeps choose_wstream_config()'s pair."""
+    nw, tpw, s = K.choose_wstream_decomposition(M, N, Kd)
+    assert tpw in (1, 2)
+    if tpw == 2:
+        assert s == 1 and M <= 64 and N % 32 == 0 and 2 <= nw <= 4
+    else:
+        assert (nw, s) == K.choose_wstream_config(M, N, Kd)
+    assert K.choose_wstream_decomposition(M, N, Kd, True)[2] == K.choose_wstream_config(M, N, Kd, True)[1]
+
+
+def test_wstream_decomposition_on_the_bench_shapes():
+    assert K.choose_wstream_decomposition(64, 128256, 4096) == (4, 2, 1)      # lm_head: 200 -> 174 us
+    assert K.choose_wstream_decomposition(64, 4096, 14336)[1] == 1            # split-K shapes: one tile per wave
+    assert K.choose_wstream_decomposition(64, 28672, 4096, True, True) == (4, 2, 1)
+
+
 def test_wstream_row_policy():
     assert K.wstream_supported(64, 4096, 4096) and K.wstream_supported(128, 4096, 4096)
     assert not K.wstream_supported(129, 4096, 4096) and not K.wstream_supported(0, 4096, 4096)
