@@ -131,6 +131,8 @@ __global__ __launch_bounds__(kThreads, 5) void cascade_chunk_kernel(ChunkParams 
   const int st_c = tid % CPR, st_r = tid / CPR;
   const int head_off = kvh * D + st_c * 8;
   const bool v_active = tid < V_THREADS;
+  // slot ids are non-negative and the row strides fit 32 bits (checked by the host): one v_mad_u64_u32 per row address
+  const uint32_t kc_stride32 = static_cast<uint32_t>(p.kc_stride), vc_stride32 = static_cast<uint32_t>(p.vc_stride);
   U4 kst[NK_LOADS], vst[8], qfrag[KC];
   int sl = 0;                                          // this row's partial slot (rows x slots_total fits 31 bits)
   {
@@ -166,10 +168,10 @@ __global__ __launch_bounds__(kThreads, 5) void cascade_chunk_kernel(ChunkParams 
       }
     }
 #pragma unroll
-    for (int i = 0; i < NK_LOADS; ++i) kst[i] = ld16(p.k_cache + static_cast<int64_t>(ks[i]) * p.kc_stride + head_off);
+    for (int i = 0; i < NK_LOADS; ++i) kst[i] = ld16(p.k_cache + static_cast<uint64_t>(static_cast<uint32_t>(ks[i])) * kc_stride32 + head_off);
     if (v_active) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) vst[i] = ld16(p.v_cache + static_cast<int64_t>(vs[i]) * p.vc_stride + head_off);
+      for (int i = 0; i < 8; ++i) vst[i] = ld16(p.v_cache + static_cast<uint64_t>(static_cast<uint32_t>(vs[i])) * vc_stride32 + head_off);
     }
   }
 
@@ -599,6 +601,8 @@ int sgl_amd_cascade_decode_attention(const void* q, const void* k_cache, const v
                 "cascade_decode_attention: bad head counts (%d / %d)", num_q_heads, num_kv_heads);
   SGL_CHECK_ARG(q_token_stride % 8 == 0 && k_cache_row_stride % 8 == 0 && v_cache_row_stride % 8 == 0 && out_token_stride % 4 == 0,
                 "cascade_decode_attention: strides must keep 16-byte (q, k, v) / 8-byte (out) alignment");
+  SGL_CHECK_ARG(k_cache_row_stride > 0 && v_cache_row_stride > 0 && k_cache_row_stride < (int64_t{1} << 31) && v_cache_row_stride < (int64_t{1} << 31),
+                "cascade_decode_attention: KV row strides must be positive and below 2^31 elements");
   SGL_CHECK_ARG(batch >= 1 && batch <= 1024 && max_items >= 1 && plan && ws_acc && ws_ml, "cascade_decode_attention: bad batch / workspace");
   const int chunks = static_cast<int>((max_context_len + kChunk - 1) / kChunk);
   SGL_CHECK_ARG(slots_total >= chunks + 1, "cascade_decode_attention: slots_total=%d < %d (context chunks + 1)", slots_total, chunks + 1);

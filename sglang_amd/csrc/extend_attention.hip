@@ -67,6 +67,7 @@ struct ExtendParams {
   // causal rule on the extend part and is AND-ed with "inside the prefix" on the prefix part
   const uint8_t* custom_mask;
   const int64_t* mask_indptr;
+  int num_tiles, batch;         // the double-buffered kernel's 1-D grid: query tiles per request, requests
 };
 
 template <int D>
@@ -81,14 +82,11 @@ struct Smem {
 // NWV = waves per workgroup: 8 (x 2 M-tiles = 256 rows) halves the K/V gathers per flop once more and puts two
 // waves on every SIMD (the whole register file: 512 threads x 256 VGPRs) -- the form for long prefixes, where the
 // kernel is bound by the gather traffic rather than by the matrix cores.
-// DEEP (8-wave form only): the two halves of the workgroup stage ALTERNATE K/V tiles -- waves 0-3 the even tiles of
-// the walk, waves 4-7 the odd ones -- so two tiles (64 KiB at D = 128) are in flight per workgroup for the register
-// cost of one per thread, and every gather has two iterations of matrix work to land instead of one.  Measured
-// (rocprofv3 PMC, profiles/r02_pmc.json) the one-deep form spends ~7 us per KV tile against 0.45 us of MFMA issue:
-// it is bound by the bytes a CU keeps in flight, not by the matrix cores.
-template <int D, int MTW, int NWV, bool DEEP, bool FP8>
+// (The bf16 8-wave case has its own kernel below, extend_attention_dbuf_kernel; this one serves fp8 pools and the
+// 4-wave shapes.)
+template <int D, int MTW, int NWV, bool FP8>
 __global__ __launch_bounds__(64 * NWV, (MTW == 1 && NWV == 4) ? 3 : (NWV == 8 ? 2 : 1)) void extend_attention_kernel(ExtendParams p) {
-  static_assert(!DEEP || NWV == 8, "the alternating stager halves need 8 waves");
+  constexpr bool DEEP = false;
   __shared__ Smem<D> sm;
   const int block_x = blockIdx.x, block_z = blockIdx.z;
   constexpr int CPR = D / 8;            // 16-byte chunks per KV row
@@ -388,6 +386,413 @@ __global__ __launch_bounds__(64 * NWV, (MTW == 1 && NWV == 4) ? 3 : (NWV == 8 ? 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The bf16 8-wave form (256 rows per workgroup, two M-tiles per wave): the shape every prefill of the bench runs.
+// Same products, lane maps and softmax as above; what differs is how the K/V tiles travel:
+//   * two LDS images per operand and ONE barrier per tile: all 512 threads ask for the rows of tile t + 1 (four 16-byte
+//     loads each) before they multiply tile t, and write them to the other image once tile t is done -- the gather has
+//     the whole tile's matrix work to land, and no wave waits for a commit between two barriers;
+//   * V stays row-major: per 16 head dims a [64 tokens][16] sub-image (rows of 32 B, sub-images 2080 B apart so that the
+//     16 pieces of a row land on 16 distinct bank slots); the V^T operand of O^T = V^T . P^T comes out of
+//     ds_read_b64_tr_b16 (lane i of a 16-lane group, element j <- row j, column i of the 4 x 16 block the group points
+//     at), two reads per operand: tokens 32 kk + 4 g + j and 32 kk + 16 + 4 g + j -- the token order of the P^T
+//     fragments built from the S^T accumulators.  No transposition through the VALU;
+//   * the running maximum is only raised when some row of the wave outgrows it by more than 2^8 (the rescale of the 64
+//     output accumulators is the largest VALU item of a tile); P stays below 2^8 in between, l and O carry the same factor.
+constexpr float kDeferMax = 8.0f;   // log2 units
+
+#ifdef EXT_TRACE
+// phase probe (benchmarks/r02_exp9_ext_trace.py): per wave, shader clocks spent in [row loads issued, S^T, softmax,
+// PV, commit, barrier] summed over the tiles of the walk, and the tile count
+__device__ uint64_t* g_ext_trace = nullptr;
+#define EXT_T(i)                                   \
+  do {                                             \
+    const uint64_t now_ = __builtin_readcyclecounter(); \
+    tacc[i] += now_ - tprev;                       \
+    tprev = now_;                                  \
+  } while (0)
+#else
+#define EXT_T(i)
+#endif
+
+template <int D>
+struct SmemDbuf {
+  static constexpr int kVSub = 64 * 32 + 32;                   // bytes of one 16-dim V sub-image + bank skew
+  U4 k[2][kKvTile * D / 8];                                    // [token][chunk ^ swz]
+  U4 v[2][(D / 16) * kVSub / 16];
+  U4 q[8 * 2 * (D / 32) * 64];                                 // [wave][M-tile][k-step][lane]: every lane's own Q^T fragments
+};
+
+typedef short v4s16_t __attribute__((ext_vector_type(4)));
+
+template <int D>
+__global__ __launch_bounds__(512, 2) void extend_attention_dbuf_kernel(ExtendParams p) {
+  __shared__ SmemDbuf<D> sm;
+  constexpr int MTW = 2;
+  constexpr int CPR = D / 8;            // 16-byte chunks per KV row
+  constexpr int KC = D / 32;            // MFMA k-steps over the head dim
+  constexpr int ND = D / 16;            // 16-wide output tiles over the head dim
+  constexpr int ROWS_PER_PASS = 512 / CPR;
+  constexpr int LOADS = kKvTile / ROWS_PER_PASS;     // 16-byte loads per thread per operand per tile (2 at D = 128)
+  constexpr int VSUB16 = SmemDbuf<D>::kVSub / 16;    // sub-image stride in 16-byte units
+
+  // 1-D grid -> (query tile, kv head, request).  Two things ride on the order: (1) under a causal mask the last query
+  // tile of a request walks the most KV tiles, so ALL pairs' heaviest tiles are handed out first and the light ones
+  // fill the tail of the launch (4 x 1024 tokens: 115 -> 76 us; pair after pair measured 100); (2) workgroup L runs
+  // on XCD L % 8 and every query tile of a (request, kv head) pair reads the same K/V rows, so a pair always lands on
+  // the same XCD: what one of its tiles pulled from HBM the others find in that XCD's L2.
+  int tile, kvh, b;
+  {
+    const int L = blockIdx.x;
+    const int pairs = p.batch * p.num_kv_heads;
+    int pair, rank;
+    if (pairs % 8 == 0) {
+      const int per_xcd = pairs / 8;
+      const int j = L >> 3;
+      pair = (j % per_xcd) * 8 + (L & 7);
+      rank = j / per_xcd;
+    } else {
+      pair = L % pairs;
+      rank = L / pairs;
+    }
+    tile = p.num_tiles - 1 - rank;
+    kvh = pair % p.num_kv_heads;
+    b = pair / p.num_kv_heads;
+  }
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int l15 = lane & 15;
+  const int g = lane >> 4;
+
+  const int q_begin = p.qo_indptr[b];
+  const int ext_len = p.qo_indptr[b + 1] - q_begin;
+  const int kv_len = p.seq_lens[b];
+  const int prefix = p.prefix_lens[b];
+  const int32_t* idx_base = p.req_to_token + p.req_pool_indices[b] * p.r2t_stride;
+  const int q0 = tile * p.tokens_per_tile;
+  if (q0 >= ext_len) return;
+  int q1 = q0 + p.tokens_per_tile;
+  if (q1 > ext_len) q1 = ext_len;
+  const bool causal = p.causal != 0;                // (sliding window / soft cap / custom mask: the general kernel)
+  const int kv_end = causal ? (prefix + q1 < kv_len ? prefix + q1 : kv_len) : kv_len;
+  const int t_first = 0;
+  const int n_tiles = (kv_end + kKvTile - 1) / kKvTile;
+
+  // ---- this lane's two rows (one per M-tile) ------------------------------
+  int row_tok[MTW], row_limit[MTW];
+  bool row_ok[MTW];
+  int row_off[MTW];       // element offset of the row's head inside a q / out token
+  // the Q^T fragments live in LDS, lane-private ([wave][mt][kc][lane], linear = conflict-free): 32 VGPRs the output
+  // accumulators need more (two waves per SIMD: 256 registers each)
+  U4* qimg = sm.q + wid * (MTW * KC * 64) + lane;
+#pragma unroll
+  for (int mt = 0; mt < MTW; ++mt) {
+    const int r = wid * (16 * MTW) + mt * 16 + l15;
+    const int t = r / p.group;
+    const int hg = r - t * p.group;
+    row_tok[mt] = q0 + t;
+    row_ok[mt] = (t < p.tokens_per_tile) && (q0 + t < q1);
+    row_limit[mt] = row_ok[mt] ? (causal ? prefix + q0 + t + 1 : kv_len) : 0;
+    if (row_limit[mt] > kv_len) row_limit[mt] = kv_len;
+    row_off[mt] = (kvh * p.group + hg) * D;
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      U4 qf = U4{0u, 0u, 0u, 0u};
+      if (row_ok[mt]) {
+        const int64_t qrow = q_begin + row_tok[mt];
+        qf = ld16(p.q + qrow * p.q_stride + row_off[mt] + kc * 32 + g * 8);
+      }
+      qimg[(mt * KC + kc) * 64] = qf;
+    }
+  }
+
+  f32x4_t ot[MTW][ND];
+  float m_run[MTW], l_run[MTW];
+#pragma unroll
+  for (int mt = 0; mt < MTW; ++mt) {
+    m_run[mt] = kNegBig;
+    l_run[mt] = 0.f;
+#pragma unroll
+    for (int n = 0; n < ND; ++n) ot[mt][n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+
+  // ---- staging: thread = (row st_r + ROWS_PER_PASS i, 16-byte chunk st_c) of a K tile and of a V tile ----
+  const int st_c = tid % CPR, st_r = tid / CPR;
+  int32_t idx_k[LOADS], idx_v[LOADS];       // slot ids of the K tile / V tile this thread fetches next
+  U4 kst[LOADS], vst[LOADS];
+  auto load_idx = [&](int t, int32_t (&dst)[LOADS]) {
+    const int last = kv_end - 1;
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+      int tok = t * kKvTile + st_r + ROWS_PER_PASS * i;
+      if (tok > last) tok = last;
+      dst[i] = idx_base[tok];
+    }
+  };
+  auto load_k = [&]() {
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) kst[i] = ld_kv8<false>(kv_row(p.k_cache, p.fmt, idx_k[i], kvh), st_c);
+  };
+  auto load_v = [&]() {
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) vst[i] = ld_kv8<false>(kv_row(p.v_cache, p.fmt, idx_v[i], kvh), st_c);
+  };
+  auto commit_k = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+      const int row = st_r + ROWS_PER_PASS * i;
+      sm.k[buf][row * CPR + (st_c ^ ((row * CPR / 16) & (CPR - 1)))] = kst[i];
+    }
+  };
+  auto commit_v = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+      const int row = st_r + ROWS_PER_PASS * i;
+      sm.v[buf][(st_c >> 1) * VSUB16 + row * 2 + (st_c & 1)] = vst[i];
+    }
+  };
+  // V^T fragment reads: byte offset of this lane inside a sub-image, token rows 4 g + (l15 >> 2), 8-byte piece l15 & 3
+  const int v_lane = (4 * g + (l15 >> 2)) * 32 + (l15 & 3) * 8;
+
+  // ---- the two halves of the workgroup run half a tile apart ---------------------------------------------------
+  // Waves w and w + 4 share a SIMD.  Time is cut into slots, one barrier each; in slot s a wave is either in its
+  // matrix block  [ O^T += V^T P^T of tile u - 1,  S^T = K Q^T of tile u ]  or in its vector block  [ softmax of
+  // tile u, staging ]: waves 0-3 multiply in the even slots (u = s / 2), waves 4-7 in the odd ones, so on every SIMD
+  // one wave feeds the matrix core while the other one runs the exp / max / pack work on the VALU (in lock-step both
+  // queue for the same unit: 7100 clocks per tile, 2780 of them softmax, benchmarks/r02_exp9_ext_trace.py).
+  // Staging rides at the end of the matrix blocks: the waves multiplying in slots 2 v and 2 v + 1 write their
+  // share of K tile v + 1 (its image was last read in slot 2 v - 1, is first read in slot 2 v + 2) and of V tile v
+  // (last read 2 v - 1, first read 2 v + 2), then ask for K tile v + 2 and V tile v + 1: a tile-time in flight.
+  const int grp = __builtin_amdgcn_readfirstlane(wid >> 2);
+  const int t0 = t_first;
+  if (t0 < n_tiles) {
+    load_idx(t0, idx_k);
+    load_idx(t0, idx_v);
+    load_k();
+    if (t0 + 1 < n_tiles) load_idx(t0 + 1, idx_k);
+    commit_k(0);
+    load_v();                                        // V tile t0, written in slot 2 t0 / 2 t0 + 1
+    if (t0 + 1 < n_tiles) {
+      load_idx(t0 + 1, idx_v);
+      load_k();                                      // K tile t0 + 1, same
+    }
+    if (t0 + 2 < n_tiles) load_idx(t0 + 2, idx_k);
+  }
+  __syncthreads();
+
+  f32x4_t st_acc[MTW][4];
+  U4 pfrag[MTW][2];
+#ifdef EXT_TRACE
+  uint64_t tacc[6] = {0, 0, 0, 0, 0, 0};
+  uint64_t tprev = __builtin_readcyclecounter();
+  const uint64_t tstart = tprev;
+#endif
+  // matrix block of tile u: O^T += V^T P^T of tile u - 1, then S^T of tile u
+  auto matrix_block = [&](int u) {
+    EXT_T(5);
+    if (u - 1 >= t0 && u - 1 < n_tiles) {
+      // ---- O^T += V^T . P^T (tile u - 1) ----------------------------------
+      const unsigned char* vbase = reinterpret_cast<const unsigned char*>(sm.v[(u - 1 - t0) & 1]) + v_lane;
+#pragma unroll
+      for (int n = 0; n < ND; ++n) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          typedef __attribute__((address_space(3))) v4s16_t* lds_v4_t;
+          const v4s16_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (lds_v4_t)(vbase + n * SmemDbuf<D>::kVSub + kk * 1024));
+          const v4s16_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (lds_v4_t)(vbase + n * SmemDbuf<D>::kVSub + kk * 1024 + 512));
+          U4 vf;
+          vf.x = __builtin_bit_cast(uint2, lo).x; vf.y = __builtin_bit_cast(uint2, lo).y;
+          vf.z = __builtin_bit_cast(uint2, hi).x; vf.w = __builtin_bit_cast(uint2, hi).y;
+#pragma unroll
+          for (int mt = 0; mt < MTW; ++mt)
+            ot[mt][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(vf), as_frag(pfrag[mt][kk]),
+                                                                 ot[mt][n], 0, 0, 0);
+        }
+      }
+    }
+    EXT_T(3);
+    if (u < n_tiles) {
+      // ---- S^T = K . Q^T (tile u) -----------------------------------------
+      const U4* kimg = sm.k[(u - t0) & 1];
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) st_acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int row = nt * 16 + l15;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+          const U4 kf = kimg[row * CPR + ((kc * 4 + g) ^ ((row * CPR / 16) & (CPR - 1)))];
+#pragma unroll
+          for (int mt = 0; mt < MTW; ++mt)
+            st_acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                as_frag(kf), as_frag(qimg[(mt * KC + kc) * 64]), st_acc[mt][nt], 0, 0, 0);
+        }
+      }
+    }
+    EXT_T(1);
+    // ---- staging of this slot pair (v = u): K tile v + 1 and V tile v go to LDS, K tile v + 2 and V tile v + 1 are
+    // asked for.  Behind the MFMAs: the writes wait for rows requested a tile ago while the matrix core drains.
+    const int v = u;
+    if (v < n_tiles) commit_v((v - t0) & 1);
+    if (v + 1 < n_tiles) commit_k((v + 1 - t0) & 1);
+    EXT_T(4);
+    EXT_T(0);
+  };
+  // vector block: softmax of tile u (the scores the wave holds)
+  auto vector_block = [&](int u) {
+    EXT_T(5);
+    if (u >= t0 && u < n_tiles) {
+      const int kv0 = u * kKvTile;
+      // ---- online softmax; lane owns row (l15 + 16 mt), tokens 16 nt + 4 g + r.  Both M-tiles go through each step
+      // together (two independent chains in flight), the row maximum crosses the four 16-lane rows of the wave with
+      // v_permlane16_swap / v_permlane32_swap (no LDS round trip), the scale rides in the exp's fma.
+      const bool full = __ballot(kv0 + kKvTile > row_limit[0] || kv0 + kKvTile > row_limit[1]) == 0ull;   // wave-uniform
+      float mx[MTW];
+      if (full) {
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+          float m = st_acc[mt][0][0];
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m = fmaxf(m, st_acc[mt][nt][r]);
+          mx[mt] = m * p.scale_log2;
+        }
+      } else {
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+          float m = kNegBig;
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int kvpos = kv0 + nt * 16 + g * 4 + r;
+              // a masked score becomes the sentinel BEFORE the scale: exp2(fma(sentinel, scale, -m)) = 0
+              const float sc = kvpos < row_limit[mt] ? st_acc[mt][nt][r] : kNegBig;
+              st_acc[mt][nt][r] = sc;
+              m = fmaxf(m, sc);
+            }
+          mx[mt] = m > 0.5f * kNegBig ? m * p.scale_log2 : kNegBig;
+        }
+      }
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt) {
+        const unsigned mu = __builtin_bit_cast(unsigned, mx[mt]);
+        const auto s16 = __builtin_amdgcn_permlane16_swap(mu, mu, false, false);
+        const float m16 = fmaxf(__builtin_bit_cast(float, s16[0]), __builtin_bit_cast(float, s16[1]));
+        const unsigned m16u = __builtin_bit_cast(unsigned, m16);
+        const auto s32 = __builtin_amdgcn_permlane32_swap(m16u, m16u, false, false);
+        mx[mt] = fmaxf(__builtin_bit_cast(float, s32[0]), __builtin_bit_cast(float, s32[1]));
+      }
+      if (__ballot(mx[0] > m_run[0] + kDeferMax || mx[1] > m_run[1] + kDeferMax) != 0ull) {
+        // some row outgrew its maximum: raise them all
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+          const float m_new = fmaxf(m_run[mt], mx[mt]);
+          const float alpha = fast_exp2(m_run[mt] - m_new);
+          m_run[mt] = m_new;
+          l_run[mt] *= alpha;
+#pragma unroll
+          for (int n = 0; n < ND; ++n) ot[mt][n] *= alpha;
+        }
+      }
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt) {
+        float psum = 0.f;
+        float pv[4][4];
+        // rows that have seen no key yet keep the sentinel as maximum: their (all masked) scores must give 0, not 1
+        const float neg_m = m_run[mt] > 0.5f * kNegBig ? -m_run[mt] : 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e = fast_exp2(fmaf(st_acc[mt][nt][r], p.scale_log2, neg_m));
+            pv[nt][r] = e;
+            psum += e;
+          }
+        l_run[mt] += psum;
+        // P^T operand for k-step kk: [P(nt=2kk, r=0..3), P(nt=2kk+1, r=0..3)]
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          pfrag[mt][kk].x = pack_bf2(pv[2 * kk][0], pv[2 * kk][1]);
+          pfrag[mt][kk].y = pack_bf2(pv[2 * kk][2], pv[2 * kk][3]);
+          pfrag[mt][kk].z = pack_bf2(pv[2 * kk + 1][0], pv[2 * kk + 1][1]);
+          pfrag[mt][kk].w = pack_bf2(pv[2 * kk + 1][2], pv[2 * kk + 1][3]);
+        }
+      }
+    }
+    EXT_T(2);
+    // ---- requests for the next commit (matrix block u + 1 writes K tile u + 2 and V tile u + 1): the registers are
+    // free since this wave's matrix block u wrote their previous contents to LDS
+    const int v = u;
+    // (each id array is loaded straight into its own registers: handing idx_k over to idx_v by a copy made hipcc wait
+    // for EVERY load in flight at the end of this block -- 900-1400 clocks per tile)
+    if (v + 1 < n_tiles) {
+      load_v();                                     // V tile v + 1 (idx_v holds its slot ids)
+      if (v + 2 < n_tiles) load_idx(v + 2, idx_v);
+    }
+    if (v + 2 < n_tiles) {
+      load_k();                                     // K tile v + 2
+      if (v + 3 < n_tiles) load_idx(v + 3, idx_k);
+    }
+    EXT_T(0);
+  };
+  // two straight-line loops instead of one loop with a role switch per slot (which hipcc spilled around)
+  if (grp == 0) {
+    for (int u = t0; u <= n_tiles; ++u) {
+      matrix_block(u);
+      __syncthreads();
+      EXT_T(5);
+      vector_block(u);
+      __syncthreads();
+      EXT_T(5);
+    }
+  } else {
+    __syncthreads();                                  // the half-tile offset: an empty first slot
+    for (int u = t0; u < n_tiles; ++u) {
+      matrix_block(u);
+      __syncthreads();
+      EXT_T(5);
+      vector_block(u);
+      __syncthreads();
+      EXT_T(5);
+    }
+    matrix_block(n_tiles);
+    __syncthreads();
+  }
+#ifdef EXT_TRACE
+  if (g_ext_trace && lane == 0) {
+    uint64_t* o = g_ext_trace + static_cast<int64_t>(blockIdx.x) * 64 + wid * 8;
+    for (int i = 0; i < 6; ++i) o[i] = tacc[i];
+    o[6] = n_tiles - t_first;
+    o[7] = tstart;
+  }
+#endif
+
+  // ---- epilogue: lane holds O^T[d = 16n + 4g + r][row] ----------------------
+#pragma unroll
+  for (int mt = 0; mt < MTW; ++mt) {
+    float l = l_run[mt];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (!row_ok[mt]) continue;
+    const float inv = (l > 0.f) ? 1.0f / l : 0.f;
+    uint16_t* op = p.out + static_cast<int64_t>(q_begin + row_tok[mt]) * p.out_stride + row_off[mt];
+#pragma unroll
+    for (int n = 0; n < ND; ++n) {
+      uint2 w;
+      w.x = pack_bf2(ot[mt][n][0] * inv, ot[mt][n][1] * inv);
+      w.y = pack_bf2(ot[mt][n][2] * inv, ot[mt][n][3] * inv);
+      *reinterpret_cast<uint2*>(op + n * 16 + g * 4) = w;
+    }
+  }
+}
+
 // Test-only probe: C[16x16] = A[16x32] . B[32x16] with the operand/result lane
 // maps this file assumes (A row = lane&15, k = 8*(lane>>4)+j; C row = 4*(lane>>4)+r,
 // col = lane&15).  tests/ checks it against a plain matmul.
@@ -492,33 +897,46 @@ int sgl_amd_extend_attention_ex(const void* q, void* out, const void* k_cache, c
   p.custom_mask = static_cast<const uint8_t*>(custom_mask);
   p.mask_indptr = mask_indptr;
   SGL_CHECK_ARG(make_kv_format(&p.fmt, k_cache_row_stride, num_kv_heads, head_dim, page_size, kv_layout_hnd, kv_fp8),
-                "extend_attention: HND pools need a power-of-two page_size (got %d)", page_size);
+                "extend_attention: HND pools need a power-of-two page_size (got %d); row / page strides must stay below 4 GiB", page_size);
   const int tiles = (max_extend_len + p.tokens_per_tile - 1) / p.tokens_per_tile;
   dim3 grid(tiles, num_kv_heads, batch);
   hipStream_t st = as_stream(stream);
-  // the alternating-stager form measured no faster (profiles/r02_exp1_cascade_extend_ab.json): opt-in only
-  bool deep = false;
-  if (const char* f = getenv("SGL_AMD_EXTEND_DEEP")) deep = atoi(f) != 0;      // A/B switch (benchmarks/r02_exp1.py)
-#define SGL_LAUNCH_EXT(D_, M_, W_, DP_)                                                                                   \
+  // bf16 pools, 8-wave shape: the double-buffered kernel (SGL_AMD_EXTEND_DBUF=0 keeps the single-image one: A/B switch)
+  bool dbuf = !kv_fp8 && nwv == 8 && sliding_window < 0 && logit_cap == 0.f && custom_mask == nullptr;
+  if (const char* f = getenv("SGL_AMD_EXTEND_DBUF")) dbuf = dbuf && atoi(f) != 0;
+  if (dbuf) {
+    p.num_tiles = tiles; p.batch = static_cast<int>(batch);
+    const dim3 grid1(static_cast<unsigned>(tiles) * num_kv_heads * static_cast<unsigned>(batch));
+    if (head_dim == 128) hipLaunchKernelGGL((extend_attention_dbuf_kernel<128>), grid1, dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((extend_attention_dbuf_kernel<64>), grid1, dim3(512), 0, st, p);
+    SGL_CHECK_LAUNCH("extend_attention");
+    return 0;
+  }
+#define SGL_LAUNCH_EXT(D_, M_, W_)                                                                                        \
   do {                                                                                                                    \
-    if (kv_fp8) hipLaunchKernelGGL((extend_attention_kernel<D_, M_, W_, DP_, true>), grid, dim3(64 * W_), 0, st, p);      \
-    else hipLaunchKernelGGL((extend_attention_kernel<D_, M_, W_, DP_, false>), grid, dim3(64 * W_), 0, st, p);            \
+    if (kv_fp8) hipLaunchKernelGGL((extend_attention_kernel<D_, M_, W_, true>), grid, dim3(64 * W_), 0, st, p);           \
+    else hipLaunchKernelGGL((extend_attention_kernel<D_, M_, W_, false>), grid, dim3(64 * W_), 0, st, p);                 \
   } while (0)
   if (head_dim == 128) {
-    if (nwv == 8 && deep) SGL_LAUNCH_EXT(128, 2, 8, true);
-    else if (nwv == 8) SGL_LAUNCH_EXT(128, 2, 8, false);
-    else if (mtw == 1) SGL_LAUNCH_EXT(128, 1, 4, false);
-    else SGL_LAUNCH_EXT(128, 2, 4, false);
+    if (nwv == 8) SGL_LAUNCH_EXT(128, 2, 8);
+    else if (mtw == 1) SGL_LAUNCH_EXT(128, 1, 4);
+    else SGL_LAUNCH_EXT(128, 2, 4);
   } else {
-    if (nwv == 8 && deep) SGL_LAUNCH_EXT(64, 2, 8, true);
-    else if (nwv == 8) SGL_LAUNCH_EXT(64, 2, 8, false);
-    else if (mtw == 1) SGL_LAUNCH_EXT(64, 1, 4, false);
-    else SGL_LAUNCH_EXT(64, 2, 4, false);
+    if (nwv == 8) SGL_LAUNCH_EXT(64, 2, 8);
+    else if (mtw == 1) SGL_LAUNCH_EXT(64, 1, 4);
+    else SGL_LAUNCH_EXT(64, 2, 4);
   }
 #undef SGL_LAUNCH_EXT
   SGL_CHECK_LAUNCH("extend_attention");
   return 0;
 }
+
+#ifdef EXT_TRACE
+int sgl_amd_debug_ext_trace(void* buf) {
+  uint64_t* p = static_cast<uint64_t*>(buf);
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_ext_trace), &p, sizeof(p)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 int sgl_amd_probe_mfma_16x16x32(const void* a, const void* b, void* c, void* stream) {
   SGL_CLEAR_STALE_ERROR();
