@@ -530,13 +530,24 @@ __global__ __launch_bounds__(512, 2) void extend_attention_dbuf_kernel(ExtendPar
       dst[i] = idx_base[tok];
     }
   };
+  // token-major pools (the default): row = base + slot * row bytes, one v_mad_u64_u32 per gathered row; the paged
+  // head-major layout goes through the general formula
+  const bool nhd = p.fmt.page_mask == 0 && p.fmt.page_shift == 0;                  // workgroup-uniform
+  const unsigned char* k_rows = reinterpret_cast<const unsigned char*>(p.k_cache) + static_cast<uint64_t>(kvh) * p.fmt.head_stride + st_c * 16;
+  const unsigned char* v_rows = reinterpret_cast<const unsigned char*>(p.v_cache) + static_cast<uint64_t>(kvh) * p.fmt.head_stride + st_c * 16;
   auto load_k = [&]() {
 #pragma unroll
-    for (int i = 0; i < LOADS; ++i) kst[i] = ld_kv8<false>(kv_row(p.k_cache, p.fmt, idx_k[i], kvh), st_c);
+    for (int i = 0; i < LOADS; ++i) {
+      if (nhd) kst[i] = ld16(k_rows + static_cast<uint64_t>(static_cast<uint32_t>(idx_k[i])) * p.fmt.page_stride);
+      else kst[i] = ld_kv8<false>(kv_row(p.k_cache, p.fmt, idx_k[i], kvh), st_c);
+    }
   };
   auto load_v = [&]() {
 #pragma unroll
-    for (int i = 0; i < LOADS; ++i) vst[i] = ld_kv8<false>(kv_row(p.v_cache, p.fmt, idx_v[i], kvh), st_c);
+    for (int i = 0; i < LOADS; ++i) {
+      if (nhd) vst[i] = ld16(v_rows + static_cast<uint64_t>(static_cast<uint32_t>(idx_v[i])) * p.fmt.page_stride);
+      else vst[i] = ld_kv8<false>(kv_row(p.v_cache, p.fmt, idx_v[i], kvh), st_c);
+    }
   };
   auto commit_k = [&](int buf) {
 #pragma unroll
