@@ -76,13 +76,12 @@ def load_pmc():
 
 
 def pmc_kernel(pmc, phase, substr):
-    """Per-dispatch averages of the first kernel of `phase` whose name contains `substr`."""
+    """Per-dispatch averages of the kernel of `phase` whose name contains `substr` (the most dispatched one when
+    several launch sizes of it ran: records are keyed by name + grid size)."""
     if not pmc:
         return None
-    for name, rec in pmc.get("phases", {}).get(phase, {}).get("kernels", {}).items():
-        if substr in name:
-            return rec
-    return None
+    hits = [rec for name, rec in pmc.get("phases", {}).get(phase, {}).get("kernels", {}).items() if substr in name]
+    return max(hits, key=lambda r: r.get("dispatches", 0)) if hits else None
 
 
 def hbm_bytes(rec):
@@ -511,7 +510,7 @@ def kernel_rooflines(args, cfg, runner, result, B, G, P, in_len, ctx, t_decode_s
         fl = nreq * 4 * Hq_r * D * (e * pre + e * (e + 1) / 2)
         ext[name] = {"us": t_x * 1e6, "tflops": fl / t_x / 1e12, "frac": fl / t_x / 1e12 / MFMA_PEAK_TFLOPS,
                      "shape": {"requests": nreq, "extend": e, "prefix": pre}}
-    rec = pmc_kernel(pmc, "prefill_cold", "extend_attention_kernel")
+    rec = pmc_kernel(pmc, "prefill_cold", "extend_attention")
     if rec and rec.get("GRBM_GUI_ACTIVE") and rec.get("SQ_VALU_MFMA_BUSY_CYCLES") is not None:
         # busy SIMD-cycles / (active cycles per XCD x 1024 SIMDs); GRBM_GUI_ACTIVE is summed over the 8 XCDs on gfx950
         ext["mfma_util_pmc"] = rec["SQ_VALU_MFMA_BUSY_CYCLES"] * 8 / (rec["GRBM_GUI_ACTIVE"] * 1024)

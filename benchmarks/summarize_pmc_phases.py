@@ -42,7 +42,10 @@ def main(out_path, model, batch, decode_steps, dirs):
                 p = phase_of[int(r["Dispatch_Id"])]
                 if p is None:
                     continue
-                a = phases[p]["kernels"][short(r["Kernel_Name"])][r["Counter_Name"]]
+                # one template instance can serve several operators (gate_up and lm_head both run the two-tile GEMM):
+                # key by launch size too so that per-dispatch averages stay per operator
+                key = short(r["Kernel_Name"]) + " grid=" + str(r.get("Grid_Size", "?"))
+                a = phases[p]["kernels"][key][r["Counter_Name"]]
                 a[0] += 1
                 a[1] += float(r["Counter_Value"])
                 phases[p]["totals"][r["Counter_Name"]] += float(r["Counter_Value"])
