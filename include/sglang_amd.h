@@ -171,6 +171,19 @@ int sgl_amd_cascade_decode_attention(const void* q, const void* k_cache, const v
                                      int64_t k_cache_row_stride, int64_t v_cache_row_stride,
                                      float sm_scale, int64_t max_context_len, int slots_total,
                                      void* ws_acc, void* ws_ml, void* stream);
+/* The same over any pool format of srt/mem_cache/memory_pool.py (as sgl_amd_decode_attention_ex): kv_fp8 rows are OCP
+ * e4m3 bytes of K / k_scale, V / v_scale (:2364-2374; k_cache_row_stride then counts bytes = elements of a row);
+ * kv_layout_hnd pools are [pages, H_kv, page_size, D] (:2061-2117), page_size a power of two. */
+int sgl_amd_cascade_decode_attention_ex(const void* q, const void* k_cache, const void* v_cache, void* out,
+                                        const int32_t* req_to_token, int64_t req_to_token_stride,
+                                        const int64_t* req_pool_indices, const int32_t* seq_lens,
+                                        const int32_t* plan, int64_t batch, int64_t max_items,
+                                        int num_q_heads, int num_kv_heads, int head_dim,
+                                        int64_t q_token_stride, int64_t out_token_stride,
+                                        int64_t k_cache_row_stride, int64_t v_cache_row_stride,
+                                        float sm_scale, int64_t max_context_len, int slots_total,
+                                        void* ws_acc, void* ws_ml, int kv_fp8, float k_scale, float v_scale,
+                                        int page_size, int kv_layout_hnd, void* stream);
 
 /* ---- Sampling (reference: srt/layers/sampler.py:98-260,567-750;
  *      kernels/ops/sampling/murmur_hash.py:51-121) ------------------------------- */

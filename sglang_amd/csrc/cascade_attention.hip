@@ -22,6 +22,7 @@
 
 #include "common.hpp"
 #include "cascade_plan.hpp"
+#include "kv_format.hpp"
 #include "sglang_amd.h"
 
 using namespace sgl_amd;
@@ -61,6 +62,7 @@ struct ChunkParams {
   float* ws_acc;                // [B, Hq, slots_total, D]
   float* ws_ml;                 // [B, Hq, slots_total, 2]
   int64_t q_stride, kc_stride, vc_stride, r2t_stride;
+  KvFormat fmt;                 // pool layout (token-major or paged head-major) + element format (bf16 / e4m3 rows)
   int batch, max_items, num_q_heads, group, members_per_item;
   int num_kv_heads;
   int slots_total;
@@ -75,7 +77,7 @@ struct ChunkParams {
 // One workgroup per (item, kv head) unit; the grid covers the worst-case item count of the batch and the
 // workgroups behind the end of the device-built list leave after one load.  (A persistent loop over the
 // units was measured slower: hipcc hoists the lane-derived LDS addresses out of the loop and spills.)
-template <int D>
+template <int D, bool FP8, bool HND>
 __global__ __launch_bounds__(kThreads, 5) void cascade_chunk_kernel(ChunkParams p) {
   constexpr int NP = D > 64 ? D / 64 : 1;   // parts the 16 KiB image is filled in: K by tokens, V^T by head dims
   constexpr int RP = kChunk / NP;           // K rows (tokens) per part
@@ -129,10 +131,14 @@ __global__ __launch_bounds__(kThreads, 5) void cascade_chunk_kernel(ChunkParams 
 
   // ---- gather burst: all K / V rows of the chunk --------------------------------------------
   const int st_c = tid % CPR, st_r = tid / CPR;
-  const int head_off = kvh * D + st_c * 8;
   const bool v_active = tid < V_THREADS;
-  // slot ids are non-negative and the row strides fit 32 bits (checked by the host): one v_mad_u64_u32 per row address
-  const uint32_t kc_stride32 = static_cast<uint32_t>(p.kc_stride), vc_stride32 = static_cast<uint32_t>(p.vc_stride);
+  // token-major pools (HND = false): row = base + slot * row bytes (slot ids are non-negative, the stride fits 32 bits:
+  // one v_mad_u64_u32 per gathered row); the paged head-major layout takes the general formula.  fp8 rows are 8 bytes
+  // per lane, widened to bf16 in registers on arrival (exact), so the images and the matrix work are the same.
+  const uint32_t row_bytes = p.fmt.page_stride;
+  const int lane_off = st_c * (FP8 ? 8 : 16);
+  const unsigned char* k_rows = reinterpret_cast<const unsigned char*>(p.k_cache) + static_cast<uint32_t>(kvh) * p.fmt.head_stride;
+  const unsigned char* v_rows = reinterpret_cast<const unsigned char*>(p.v_cache) + static_cast<uint32_t>(kvh) * p.fmt.head_stride;
   U4 kst[NK_LOADS], vst[8], qfrag[KC];
   int sl = 0;                                          // this row's partial slot (rows x slots_total fits 31 bits)
   {
@@ -167,11 +173,22 @@ __global__ __launch_bounds__(kThreads, 5) void cascade_chunk_kernel(ChunkParams 
         for (int kc = 0; kc < KC; ++kc) qfrag[kc] = U4{0u, 0u, 0u, 0u};
       }
     }
+    if constexpr (!HND) {
 #pragma unroll
-    for (int i = 0; i < NK_LOADS; ++i) kst[i] = ld16(p.k_cache + static_cast<uint64_t>(static_cast<uint32_t>(ks[i])) * kc_stride32 + head_off);
-    if (v_active) {
+      for (int i = 0; i < NK_LOADS; ++i)
+        kst[i] = ld_kv8<FP8>(k_rows + static_cast<uint64_t>(static_cast<uint32_t>(ks[i])) * row_bytes + lane_off, 0);
+      if (v_active) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) vst[i] = ld16(p.v_cache + static_cast<uint64_t>(static_cast<uint32_t>(vs[i])) * vc_stride32 + head_off);
+        for (int i = 0; i < 8; ++i)
+          vst[i] = ld_kv8<FP8>(v_rows + static_cast<uint64_t>(static_cast<uint32_t>(vs[i])) * row_bytes + lane_off, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NK_LOADS; ++i) kst[i] = ld_kv8<FP8>(kv_row(p.k_cache, p.fmt, ks[i], kvh), st_c);
+      if (v_active) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) vst[i] = ld_kv8<FP8>(kv_row(p.v_cache, p.fmt, vs[i], kvh), st_c);
+      }
     }
   }
 
@@ -499,7 +516,8 @@ constexpr int kMergeBlock = 16;  // slots loaded per round (all loads of a round
 __global__ __launch_bounds__(256) void cascade_merge2_kernel(const float* __restrict__ ws_acc, const float* __restrict__ ws_ml,
                                                              const int32_t* __restrict__ plan, const int32_t* __restrict__ seq_lens,
                                                              uint16_t* __restrict__ out, int64_t out_stride, int batch,
-                                                             int max_items, int num_q_heads, int head_dim, int slots_total) {
+                                                             int max_items, int num_q_heads, int head_dim, int slots_total,
+                                                             float out_scale) {
   const int tpd = head_dim >> 2;
   const int b = blockIdx.x;
   const int hq = blockIdx.y * (256 / tpd) + threadIdx.x / tpd;
@@ -540,7 +558,7 @@ __global__ __launch_bounds__(256) void cascade_merge2_kernel(const float* __rest
       }
     }
   }
-  const float inv = (l > 0.f) ? 1.0f / l : 0.f;
+  const float inv = (l > 0.f) ? out_scale / l : 0.f;       // out_scale: v_scale of an fp8 pool, else 1
   uint2 w;
   w.x = pack_bf2(o.x * inv, o.y * inv);
   w.y = pack_bf2(o.z * inv, o.w * inv);
@@ -595,14 +613,29 @@ int sgl_amd_cascade_decode_attention(const void* q, const void* k_cache, const v
                                      int64_t q_token_stride, int64_t out_token_stride, int64_t k_cache_row_stride,
                                      int64_t v_cache_row_stride, float sm_scale, int64_t max_context_len,
                                      int slots_total, void* ws_acc, void* ws_ml, void* stream) {
+  return sgl_amd_cascade_decode_attention_ex(q, k_cache, v_cache, out, req_to_token, req_to_token_stride, req_pool_indices,
+                                             seq_lens, plan, batch, max_items, num_q_heads, num_kv_heads, head_dim,
+                                             q_token_stride, out_token_stride, k_cache_row_stride, v_cache_row_stride, sm_scale,
+                                             max_context_len, slots_total, ws_acc, ws_ml, 0, 1.0f, 1.0f, 1, 0, stream);
+}
+
+int sgl_amd_cascade_decode_attention_ex(const void* q, const void* k_cache, const void* v_cache, void* out,
+                                        const int32_t* req_to_token, int64_t req_to_token_stride,
+                                        const int64_t* req_pool_indices, const int32_t* seq_lens, const int32_t* plan,
+                                        int64_t batch, int64_t max_items, int num_q_heads, int num_kv_heads, int head_dim,
+                                        int64_t q_token_stride, int64_t out_token_stride, int64_t k_cache_row_stride,
+                                        int64_t v_cache_row_stride, float sm_scale, int64_t max_context_len,
+                                        int slots_total, void* ws_acc, void* ws_ml, int kv_fp8, float k_scale, float v_scale,
+                                        int page_size, int kv_layout_hnd, void* stream) {
   SGL_CLEAR_STALE_ERROR();
   SGL_CHECK_ARG(head_dim == 64 || head_dim == 128, "cascade_decode_attention: head_dim=%d not supported (64/128)", head_dim);
   SGL_CHECK_ARG(num_kv_heads > 0 && num_q_heads % num_kv_heads == 0 && num_q_heads / num_kv_heads <= kRowsPerItem,
                 "cascade_decode_attention: bad head counts (%d / %d)", num_q_heads, num_kv_heads);
   SGL_CHECK_ARG(q_token_stride % 8 == 0 && k_cache_row_stride % 8 == 0 && v_cache_row_stride % 8 == 0 && out_token_stride % 4 == 0,
                 "cascade_decode_attention: strides must keep 16-byte (q, k, v) / 8-byte (out) alignment");
-  SGL_CHECK_ARG(k_cache_row_stride > 0 && v_cache_row_stride > 0 && k_cache_row_stride < (int64_t{1} << 31) && v_cache_row_stride < (int64_t{1} << 31),
-                "cascade_decode_attention: KV row strides must be positive and below 2^31 elements");
+  SGL_CHECK_ARG(k_cache_row_stride > 0 && k_cache_row_stride == v_cache_row_stride,
+                "cascade_decode_attention: K and V pools must share a positive row stride");
+  SGL_CHECK_ARG(!kv_fp8 || (k_scale > 0.f && v_scale > 0.f), "cascade_decode_attention: fp8 KV needs positive k_scale / v_scale");
   SGL_CHECK_ARG(batch >= 1 && batch <= 1024 && max_items >= 1 && plan && ws_acc && ws_ml, "cascade_decode_attention: bad batch / workspace");
   const int chunks = static_cast<int>((max_context_len + kChunk - 1) / kChunk);
   SGL_CHECK_ARG(slots_total >= chunks + 1, "cascade_decode_attention: slots_total=%d < %d (context chunks + 1)", slots_total, chunks + 1);
@@ -618,19 +651,29 @@ int sgl_amd_cascade_decode_attention(const void* q, const void* k_cache, const v
   p.group = num_q_heads / num_kv_heads; p.members_per_item = kRowsPerItem / p.group;
   p.num_kv_heads = num_kv_heads;
   p.slots_total = slots_total;
-  p.scale_log2 = sm_scale * 1.4426950408889634f;
+  p.scale_log2 = sm_scale * 1.4426950408889634f * (kv_fp8 ? k_scale : 1.0f);
+  SGL_CHECK_ARG(make_kv_format(&p.fmt, k_cache_row_stride, num_kv_heads, head_dim, page_size, kv_layout_hnd, kv_fp8),
+                "cascade_decode_attention: HND pools need a power-of-two page_size (got %d); row / page strides below 4 GiB", page_size);
   // worst-case item count of this batch: every request's private chunks + the shared chunks of every member tile
   // (at most batch/2 groups, and sum over groups of ceil(members / members_per_item) <= batch/members_per_item + groups)
   const int64_t member_tiles = (batch + p.members_per_item - 1) / p.members_per_item + batch / 2 + 1;
   int64_t units = batch * (chunks + 1) + member_tiles * chunks;
   if (units > max_items) units = max_items;
   dim3 grid(static_cast<unsigned>(units * num_kv_heads));
-  if (head_dim == 128) hipLaunchKernelGGL(cascade_chunk_kernel<128>, grid, dim3(kThreads), 0, st, p);
-  else hipLaunchKernelGGL(cascade_chunk_kernel<64>, grid, dim3(kThreads), 0, st, p);
+#define SGL_LAUNCH_CASC(D_)                                                                                  \
+  do {                                                                                                       \
+    if (kv_fp8 && kv_layout_hnd) hipLaunchKernelGGL((cascade_chunk_kernel<D_, true, true>), grid, dim3(kThreads), 0, st, p);   \
+    else if (kv_fp8) hipLaunchKernelGGL((cascade_chunk_kernel<D_, true, false>), grid, dim3(kThreads), 0, st, p);             \
+    else if (kv_layout_hnd) hipLaunchKernelGGL((cascade_chunk_kernel<D_, false, true>), grid, dim3(kThreads), 0, st, p);      \
+    else hipLaunchKernelGGL((cascade_chunk_kernel<D_, false, false>), grid, dim3(kThreads), 0, st, p);                        \
+  } while (0)
+  if (head_dim == 128) SGL_LAUNCH_CASC(128);
+  else SGL_LAUNCH_CASC(64);
+#undef SGL_LAUNCH_CASC
   const int hpb = 256 / (head_dim / 4);
   hipLaunchKernelGGL(cascade_merge2_kernel, dim3(static_cast<unsigned>(batch), (num_q_heads + hpb - 1) / hpb), dim3(256), 0, st,
                      p.ws_acc, p.ws_ml, plan, seq_lens, static_cast<uint16_t*>(out), out_token_stride, p.batch, p.max_items,
-                     num_q_heads, head_dim, slots_total);
+                     num_q_heads, head_dim, slots_total, kv_fp8 ? v_scale : 1.0f);
   SGL_CHECK_LAUNCH("cascade_decode_attention");
   return 0;
 }

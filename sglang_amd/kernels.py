@@ -341,19 +341,28 @@ def cascade_plan(ws: CascadeWorkspace, req_to_token: torch.Tensor, req_pool_indi
 
 def cascade_decode_attention(ws: CascadeWorkspace, q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
                              out: torch.Tensor, req_to_token: torch.Tensor, req_pool_indices: torch.Tensor,
-                             seq_lens: torch.Tensor, sm_scale: float) -> torch.Tensor:
-    """Per layer, after cascade_plan(): q/out [B, Hq, D]."""
+                             seq_lens: torch.Tensor, sm_scale: float, kv_fp8: bool = False, k_scale: float = 1.0,
+                             v_scale: float = 1.0, page_size: int = 1, hnd: bool = False) -> torch.Tensor:
+    """Per layer, after cascade_plan(): q/out [B, Hq, D]; pools as in decode_attention (bf16 or uint8 e4m3 rows,
+    [slots, Hkv, D] or [pages, Hkv, page_size, D] with hnd)."""
     _dev(q, k_cache, v_cache, out)
     B, Hq, D = q.shape
     Hkv = k_cache.shape[1]
-    _need(q.dtype == _BF16 and k_cache.dtype == _BF16 and v_cache.dtype == _BF16 and out.dtype == _BF16, "cascade: bf16 only")
+    _need(q.dtype == _BF16 and out.dtype == _BF16 and k_cache.dtype == (torch.uint8 if kv_fp8 else _BF16)
+          and v_cache.dtype == k_cache.dtype, "cascade: bf16 q / out, bf16 or uint8 (e4m3) pools")
     _need(q.stride(2) == 1 and q.stride(1) == D and out.stride(2) == 1 and out.stride(1) == D, "cascade: q/out head layout")
-    _need(k_cache.stride(2) == 1 and k_cache.stride(1) == D and v_cache.stride(1) == D, "cascade: cache layout")
-    native.call("sgl_amd_cascade_decode_attention", q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), out.data_ptr(),
+    if kv_fp8 or hnd:
+        _need(k_cache.is_contiguous() and v_cache.is_contiguous(), "cascade: contiguous pools")
+        row = Hkv * D
+    else:
+        _need(k_cache.stride(2) == 1 and k_cache.stride(1) == D and v_cache.stride(1) == D
+              and k_cache.stride(0) == v_cache.stride(0), "cascade: cache layout")
+        row = k_cache.stride(0)
+    native.call("sgl_amd_cascade_decode_attention_ex", q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), out.data_ptr(),
                 req_to_token.data_ptr(), req_to_token.stride(0), req_pool_indices.data_ptr(), seq_lens.data_ptr(),
-                ws.plan.data_ptr(), B, ws.max_items, Hq, Hkv, D, q.stride(0), out.stride(0), k_cache.stride(0),
-                v_cache.stride(0), float(sm_scale), ws.max_context_len, ws.slots, ws.ws_acc.data_ptr(), ws.ws_ml.data_ptr(),
-                _stream())
+                ws.plan.data_ptr(), B, ws.max_items, Hq, Hkv, D, q.stride(0), out.stride(0), row, row,
+                float(sm_scale), ws.max_context_len, ws.slots, ws.ws_acc.data_ptr(), ws.ws_ml.data_ptr(),
+                1 if kv_fp8 else 0, float(k_scale), float(v_scale), int(page_size), 1 if hnd else 0, _stream())
     return out
 
 

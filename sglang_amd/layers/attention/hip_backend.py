@@ -113,10 +113,10 @@ class HipAttnBackend(AttentionBackend):
         import os
 
         self.enable_cascade = os.environ.get("SGLANG_AMD_CASCADE", "1") != "0" and self.head_dim in (64, 128)
-        # the shared-prefix kernel reads bf16 NHD rows; other pool formats take the plain paged kernel
+        # the shared-prefix kernel reads every pool format (bf16 / fp8 rows, token-major / paged head-major); layers
+        # with a sliding window or a logit cap take the plain paged kernel (forward_decode)
         pool = self.token_to_kv_pool
         self.plain_pool = not getattr(pool, "is_fp8", False) and not getattr(pool, "use_hnd", False)
-        self.enable_cascade = self.enable_cascade and self.plain_pool
 
     # ------------------------------------------------------------------ metadata
     def _workspace(self, batch: int, splits: int):
@@ -245,11 +245,11 @@ class HipAttnBackend(AttentionBackend):
         q3 = q.reshape(-1, layer.tp_q_head_num, layer.qk_head_dim)
         o = torch.empty_like(q3)
         opt = self._layer_options(layer)
-        if m.cascade is not None and not opt:
+        if m.cascade is not None and "sliding_window" not in opt and "logit_cap" not in opt:
             kernels.cascade_decode_attention(m.cascade, q3, self.token_to_kv_pool.get_key_buffer(layer.layer_id),
                                              self.token_to_kv_pool.get_value_buffer(layer.layer_id), o,
                                              self.req_to_token_pool.req_to_token, self._pool_idx(forward_batch),
-                                             m.seq_lens_i32, layer.scaling)
+                                             m.seq_lens_i32, layer.scaling, **opt)      # opt: the pool format, if any
             return o.view(-1, layer.tp_q_head_num * layer.v_head_dim)
         kernels.decode_attention(q3, self.token_to_kv_pool.get_key_buffer(layer.layer_id),
                                  self.token_to_kv_pool.get_value_buffer(layer.layer_id), o,

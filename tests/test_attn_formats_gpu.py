@@ -98,6 +98,42 @@ def test_decode_attention_formats(device, case, Hq, Hkv, D):
         assert float(err.max()) <= 2.0 ** -7 * float(ref.float().abs().max()) + 2e-3, (splits, float(err.max()))
 
 
+@pytest.mark.parametrize("case", [dict(fp8=True), dict(hnd=True, page=4), dict(hnd=True, page=16, fp8=True)],
+                         ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
+@pytest.mark.parametrize("Hq,Hkv,D", [(8, 2, 128), (4, 4, 64)])
+def test_cascade_decode_attention_formats(device, case, Hq, Hkv, D):
+    """The shared-prefix kernel over fp8 / paged head-major pools: two groups sharing 256 / 128 cached tokens plus a
+    loner, against the oracle's per-request attention on the same (quantised) rows."""
+    K = _k()
+    fp8, hnd, page = case.get("fp8", False), case.get("hnd", False), case.get("page", 1)
+    ks, vs = (0.5, 1.5) if fp8 else (1.0, 1.0)
+    slots, ctx = 4096, 640
+    k, v = _pool(slots, Hkv, D, page, hnd, fp8, 11)
+    kc, vc = _store(device, k, v, page, hnd, fp8, ks, vs)
+    lens = [300, 333, 290, 513, 200, 170, 77]
+    groups = [(0, 1, 2, 3), (4, 5)]                      # members of a group share their first `shared` slots
+    shared = {0: 256, 1: 128}
+    r2t, pool = _batch(lens, slots, ctx, 13)
+    for gi, members in enumerate(groups):
+        for m in members[1:]:
+            r2t[m + 1, :shared[gi]] = r2t[members[0] + 1, :shared[gi]]
+    B = len(lens)
+    q = (torch.randn((B, Hq, D), generator=torch.Generator().manual_seed(2)) * 0.5).to(BF)
+    seq = torch.tensor(lens, dtype=torch.int32)
+    out = torch.empty((B, Hq, D), dtype=BF, device=device)
+    ws = K.CascadeWorkspace(B, Hq, D, ctx, device)
+    K.cascade_plan(ws, r2t.to(device), pool.to(device), seq.to(device), Hq, Hkv)
+    summ = K.cascade_plan_summary(ws, B)
+    assert summ["n_groups"] == 2, summ
+    K.cascade_decode_attention(ws, q.to(device), kc, vc, out, r2t.to(device), pool.to(device), seq.to(device), D ** -0.5,
+                               kv_fp8=fp8, k_scale=ks, v_scale=vs, page_size=page, hnd=hnd)
+    kref = oo.quantize_kv_fp8(k, ks) if fp8 else k
+    vref = oo.quantize_kv_fp8(v, vs) if fp8 else v
+    ref = oo.decode_attention(q, kref, vref, r2t, pool, seq.long(), D ** -0.5, compute_dtype=torch.float32, k_scale=ks, v_scale=vs)
+    err = (out.cpu().float() - ref.float()).abs()
+    assert float(err.max()) <= 2.0 ** -7 * float(ref.float().abs().max()) + 2e-3, float(err.max())
+
+
 @pytest.mark.parametrize("case", CASES + [dict(mask=True), dict(mask=True, fp8=True)], ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
 def test_extend_attention_formats(device, case):
     K = _k()
