@@ -93,6 +93,12 @@ int sgl_amd_write_req_to_token(int32_t* req_to_token, int64_t req_to_token_strid
                                const int64_t* prefix_lens, const int64_t* seq_lens,
                                const int64_t* extend_lens, const int64_t* out_cache_loc,
                                int64_t batch, void* stream);
+/* One decode step's per-request bookkeeping at page_size 1 (reference: schedule_batch.py prepare_for_decode,
+ * allocation.py:512-560 alloc_for_decode, :73-82 write_req_to_token_pool): req_to_token[req_pool_indices[b],
+ * seq_lens[b]] = new_slots[b]; out_cache_loc[b] = new_slots[b]; seq_lens[b] += 1 (int32, in place). */
+int sgl_amd_decode_advance(int32_t* req_to_token, int64_t req_to_token_stride, const int64_t* req_pool_indices,
+                           int32_t* seq_lens, const int64_t* new_slots, int64_t* out_cache_loc, int64_t batch,
+                           void* stream);
 /* reference: allocation.py:139-148 get_last_loc_torch. */
 int sgl_amd_get_last_loc(const int32_t* req_to_token, int64_t req_to_token_stride,
                          const int64_t* req_pool_indices, const int64_t* prefix_lens,

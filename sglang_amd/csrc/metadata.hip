@@ -78,6 +78,22 @@ __global__ void write_req_to_token_kernel(int32_t* __restrict__ req_to_token,
     row[pre + i] = static_cast<int32_t>(out_cache_loc[start + i]);
 }
 
+// One decode step's bookkeeping for page_size 1 (schedule_batch.py prepare_for_decode + allocation.py:512-560
+// alloc_for_decode): request b takes slot new_slots[b], which is written to its req_to_token row at column seq_lens[b]
+// and to out_cache_loc[b]; seq_lens[b] += 1.  Five eager tensor ops (two casts, an index_put, an add, a copy) in one
+// launch: the decode loop spends ~4.5 us per eager launch between two graph replays.
+__global__ void decode_advance_kernel(int32_t* __restrict__ req_to_token, int64_t r2t_stride,
+                                      const int64_t* __restrict__ req_pool_indices, int32_t* __restrict__ seq_lens,
+                                      const int64_t* __restrict__ new_slots, int64_t* __restrict__ out_cache_loc, int64_t n) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  const int32_t len = seq_lens[i];
+  const int64_t slot = new_slots[i];
+  req_to_token[req_pool_indices[i] * r2t_stride + len] = static_cast<int32_t>(slot);
+  out_cache_loc[i] = slot;
+  seq_lens[i] = len + 1;
+}
+
 __global__ void get_last_loc_kernel(const int32_t* __restrict__ req_to_token,
                                     const int64_t* __restrict__ req_pool_indices,
                                     const int64_t* __restrict__ prefix_lens,
@@ -189,6 +205,18 @@ int sgl_amd_create_kv_indices(const int32_t* req_to_token, int64_t req_to_token_
                        req_to_token, r64, r32, kernel_lens, kv_indptr, kv_start_idx,
                        static_cast<int32_t*>(kv_indices), req_to_token_stride);
   SGL_CHECK_LAUNCH("create_kv_indices");
+  return 0;
+}
+
+int sgl_amd_decode_advance(int32_t* req_to_token, int64_t req_to_token_stride, const int64_t* req_pool_indices,
+                           int32_t* seq_lens, const int64_t* new_slots, int64_t* out_cache_loc, int64_t batch,
+                           void* stream) {
+  SGL_CLEAR_STALE_ERROR();
+  SGL_CHECK_ARG(req_to_token && req_pool_indices && seq_lens && new_slots && out_cache_loc, "decode_advance: null argument");
+  if (batch <= 0) return 0;
+  hipLaunchKernelGGL(decode_advance_kernel, dim3(static_cast<unsigned>((batch + 255) / 256)), dim3(256), 0, as_stream(stream),
+                     req_to_token, req_to_token_stride, req_pool_indices, seq_lens, new_slots, out_cache_loc, batch);
+  SGL_CHECK_LAUNCH("decode_advance");
   return 0;
 }
 

@@ -388,7 +388,12 @@ class Engine:
             self.flush_decode_outputs()
             st = self._decode_state = self._build_decode_state(reqs)
         # alloc_for_decode (allocation.py:512-560): one slot per request, written at column seq_len
-        if ps_ == 1:
+        fused = st.get("fused", False)
+        if ps_ == 1 and fused:
+            out_cache_loc = st["out_cache_loc"]
+            kernels.decode_advance(r.req_to_token_pool.req_to_token, st["req_pool"], st["seq_lens"],
+                                   self._alloc_token_slots(bs), out_cache_loc)
+        elif ps_ == 1:
             out_cache_loc = self._alloc_token_slots(bs)
         else:
             last_loc = r.req_to_token_pool.req_to_token[st["req_pool"], (st["seq_lens"] - 1).long()].to(torch.int64)
@@ -398,8 +403,9 @@ class Engine:
             out_cache_loc = alloc.alloc_decode((st["seq_lens"] + 1).to(torch.int64), st["seq_lens_cpu"] + 1, last_loc)
             if out_cache_loc is None:
                 raise RuntimeError("out of KV pages")
-        r.req_to_token_pool.req_to_token[st["req_pool"], st["seq_lens"].long()] = out_cache_loc.to(torch.int32)
-        st["seq_lens"] += 1
+        if not fused:
+            r.req_to_token_pool.req_to_token[st["req_pool"], st["seq_lens"].long()] = out_cache_loc.to(torch.int32)
+            st["seq_lens"] += 1
         st["seq_lens_cpu"] += 1
         fb = ForwardBatch(forward_mode=ForwardMode.DECODE, batch_size=bs, input_ids=st["last_ids"],
                           req_pool_indices=st["req_pool"], seq_lens=st["seq_lens"], out_cache_loc=out_cache_loc,
@@ -411,7 +417,10 @@ class Engine:
         logits = r.forward(fb)
         self._record_logits(logits, st["reqs"])
         next_ids = r.sample(logits, fb)
-        st["last_ids"] = next_ids.to(torch.int64)
+        if fused:
+            st["last_ids"].copy_(next_ids)              # straight into the graph's input buffer
+        else:
+            st["last_ids"] = next_ids.to(torch.int64)
         # token hand-off to the host: an async copy into pinned memory + an event, so that the scheduler can
         # launch step N+1 before it looks at step N's tokens (overlap scheduling, scheduler.py:1783)
         on_gpu = next_ids.is_cuda                       # (host-logic tests drive this class with CPU tensors)
@@ -427,12 +436,30 @@ class Engine:
 
     def _build_decode_state(self, reqs: Sequence[Req]):
         dev = self.device
+        bs = len(reqs)
         seq = [q.seqlen - 1 for q in reqs]   # KV rows present: every token except the newest sampled one
-        return dict(bs=len(reqs), req_pool=torch.tensor([q.req_pool_idx for q in reqs], dtype=torch.int64, device=dev),
-                    seq_lens=torch.tensor(seq, dtype=torch.int32, device=dev),
-                    seq_lens_cpu=torch.tensor(seq, dtype=torch.int64),
-                    last_ids=torch.tensor([q.output_ids[-1] for q in reqs], dtype=torch.int64, device=dev),
-                    pending=[], free_host=[], reqs=list(reqs))
+        st = dict(bs=bs, req_pool=torch.tensor([q.req_pool_idx for q in reqs], dtype=torch.int64, device=dev),
+                  seq_lens=torch.tensor(seq, dtype=torch.int32, device=dev),
+                  seq_lens_cpu=torch.tensor(seq, dtype=torch.int64),
+                  last_ids=torch.tensor([q.output_ids[-1] for q in reqs], dtype=torch.int64, device=dev),
+                  pending=[], free_host=[], reqs=list(reqs), fused=False)
+        # On the GPU the per-batch device state LIVES in the decode graph's static input buffers (the replay then has
+        # nothing to copy) and one launch does the step's slot bookkeeping (kernels.decode_advance): the loop between
+        # two replays was a dozen eager launches of ~4.5 us each.
+        gr = getattr(self.r, "graph_runner", None)
+        import os
+
+        if torch.device(dev).type == "cuda" and self.r.page_size == 1 and os.environ.get("SGLANG_AMD_DECODE_FUSED_PREP", "1") != "0":
+            if gr is not None and gr.can_run(bs):
+                for key, buf in (("req_pool", gr.req_pool_indices), ("seq_lens", gr.seq_lens), ("last_ids", gr.input_ids)):
+                    view = buf[:bs]
+                    view.copy_(st[key])
+                    st[key] = view
+                st["out_cache_loc"] = gr.out_cache_loc[:bs]
+            else:
+                st["out_cache_loc"] = torch.zeros(bs, dtype=torch.int64, device=dev)
+            st["fused"] = True
+        return st
 
     _decode_state = None
 

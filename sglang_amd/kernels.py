@@ -164,6 +164,21 @@ def write_req_to_token(req_to_token: torch.Tensor, req_pool_indices: torch.Tenso
                 out_cache_loc.data_ptr(), req_pool_indices.numel(), _stream())
 
 
+def decode_advance(req_to_token: torch.Tensor, req_pool_indices: torch.Tensor, seq_lens: torch.Tensor,
+                   new_slots: torch.Tensor, out_cache_loc: torch.Tensor) -> None:
+    """One decode step's bookkeeping (page_size 1): req_to_token[pool[b], seq_lens[b]] = new_slots[b],
+    out_cache_loc[b] = new_slots[b], seq_lens[b] += 1 -- one launch instead of five eager tensor ops."""
+    _dev(req_to_token, req_pool_indices, seq_lens, new_slots, out_cache_loc)
+    n = seq_lens.numel()
+    _need(req_to_token.dtype == torch.int32 and req_to_token.dim() == 2 and req_to_token.stride(1) == 1, "decode_advance: int32 req_to_token")
+    _need(req_pool_indices.dtype == torch.int64 and new_slots.dtype == torch.int64 and out_cache_loc.dtype == torch.int64
+          and seq_lens.dtype == torch.int32, "decode_advance: int64 pool rows / slots, int32 seq_lens")
+    _need(req_pool_indices.numel() == n and new_slots.numel() == n and out_cache_loc.numel() == n
+          and all(t.is_contiguous() for t in (req_pool_indices, seq_lens, new_slots, out_cache_loc)), "decode_advance: shapes")
+    native.call("sgl_amd_decode_advance", req_to_token.data_ptr(), req_to_token.stride(0), req_pool_indices.data_ptr(),
+                seq_lens.data_ptr(), new_slots.data_ptr(), out_cache_loc.data_ptr(), n, _stream())
+
+
 def get_last_loc(req_to_token: torch.Tensor, req_pool_indices: torch.Tensor, prefix_lens: torch.Tensor) -> torch.Tensor:
     _dev(req_to_token, req_pool_indices, prefix_lens)
     _need(req_pool_indices.dtype == torch.int64 and prefix_lens.dtype == torch.int64, "get_last_loc: int64 metadata")

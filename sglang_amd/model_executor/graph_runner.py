@@ -114,9 +114,10 @@ class DecodeGraphRunner:
             self.req_pool_indices[raw:bs].zero_()
             self.seq_lens[raw:bs].fill_(self.fill)
             self.out_cache_loc[raw:bs].zero_()
-        self.input_ids[:raw].copy_(fb.input_ids, non_blocking=True)
-        self.req_pool_indices[:raw].copy_(fb.req_pool_indices, non_blocking=True)
-        self.seq_lens[:raw].copy_(fb.seq_lens, non_blocking=True)
-        self.out_cache_loc[:raw].copy_(fb.out_cache_loc, non_blocking=True)
+        # a caller that keeps its batch state IN these buffers (harness/engine.py) has nothing to copy
+        for buf, src in ((self.input_ids, fb.input_ids), (self.req_pool_indices, fb.req_pool_indices),
+                         (self.seq_lens, fb.seq_lens), (self.out_cache_loc, fb.out_cache_loc)):
+            if src.data_ptr() != buf.data_ptr():
+                buf[:raw].copy_(src, non_blocking=True)
         self.graphs[bs].replay()
         return LogitsProcessorOutput(next_token_logits=self.outputs[bs][:raw])
