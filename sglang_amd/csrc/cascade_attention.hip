@@ -347,12 +347,17 @@ __global__ __launch_bounds__(kPlanThreads) void cascade_plan_kernel(
   __shared__ int g_leader[kPlanMaxBatch / 2], g_kv[kPlanMaxBatch / 2], g_first[kPlanMaxBatch / 2], g_tiles[kPlanMaxBatch / 2],
       g_rows0[kPlanMaxBatch / 2], g_members[kPlanMaxBatch / 2];
   __shared__ int n_shared_items, n_groups, n_rows;
+  __shared__ int pool_row[kPlanMaxBatch], len_s[kPlanMaxBatch];   // read once: every later phase would pay the hop again
+  __shared__ int wave_tot[kPlanThreads / 64];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const CascadePlanView pv = cascade_plan_view(plan, batch, max_items);
   for (int i = tid; i < max_items; i += kPlanThreads) pv.items[8 * i + 3] = 0;   // members == 0: end of list
   for (int b = tid; b < batch; b += kPlanThreads) {
     const int len = seq_lens[b];
-    first_slot[b] = len > 1 ? req_to_token[req_pool_indices[b] * r2t_stride] : -1 - b;   // unique when too short
+    const int row = static_cast<int>(req_pool_indices[b]);
+    pool_row[b] = row;
+    len_s[b] = len;
+    first_slot[b] = len > 1 ? req_to_token[static_cast<int64_t>(row) * r2t_stride] : -1 - b;   // unique when too short
     grp_min[b] = 0x7fffffff;
     grp_cnt[b] = 0;
   }
@@ -365,21 +370,23 @@ __global__ __launch_bounds__(kPlanThreads) void cascade_plan_kernel(
     leader[b] = l;
   }
   __syncthreads();
-  // common prefix with the leader: one wave per request, 512 positions per step (8 loads in flight per row)
+  // common prefix with the leader: one wave per request, 2048 positions per round (32 loads in flight per row): a wave
+  // walks its batch / 16 requests one after the other, so every round is a full memory round trip of the plan
+  constexpr int kCmpLoads = 32;
   for (int b = wid; b < batch; b += kPlanThreads / 64) {
     const int l = leader[b];
     int common = 0;
     if (l != b) {
-      const int32_t* ra = req_to_token + req_pool_indices[b] * r2t_stride;
-      const int32_t* rb = req_to_token + req_pool_indices[l] * r2t_stride;
-      int lim = seq_lens[b] - 1;                 // the newest token's slot is never shared
-      const int ll = seq_lens[l] - 1;
+      const int32_t* ra = req_to_token + static_cast<int64_t>(pool_row[b]) * r2t_stride;
+      const int32_t* rb = req_to_token + static_cast<int64_t>(pool_row[l]) * r2t_stride;
+      int lim = len_s[b] - 1;                    // the newest token's slot is never shared
+      const int ll = len_s[l] - 1;
       if (ll < lim) lim = ll;
       common = lim;
-      for (int t0 = 0; t0 < lim; t0 += 512) {
-        int va[8], vb[8];
+      for (int t0 = 0; t0 < lim; t0 += 64 * kCmpLoads) {
+        int va[kCmpLoads], vb[kCmpLoads];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < kCmpLoads; ++u) {
           const int t = t0 + 64 * u + lane;
           const int tc = t < lim ? t : lim - 1;
           va[u] = ra[tc];
@@ -387,7 +394,7 @@ __global__ __launch_bounds__(kPlanThreads) void cascade_plan_kernel(
         }
         int first = 0x7fffffff;
 #pragma unroll
-        for (int u = 7; u >= 0; --u) {
+        for (int u = kCmpLoads - 1; u >= 0; --u) {
           const int t = t0 + 64 * u + lane;
           const unsigned long long mm = __ballot(t < lim && va[u] != vb[u]);
           if (mm != 0ull) first = t0 + 64 * u + __ffsll(static_cast<long long>(mm)) - 1;
@@ -401,38 +408,73 @@ __global__ __launch_bounds__(kPlanThreads) void cascade_plan_kernel(
     }
   }
   __syncthreads();
-  // ---- grouping decisions: one thread, LDS only (global round trips here would serialise) ----
-  if (tid == 0) {
-    int ng = 0, rows = 0, n_items = 0;
-    for (int b = 0; b < batch; ++b) grp_id[b] = -1;
-    for (int b = 0; b < batch; ++b) {
-      if (leader[b] != b || grp_cnt[b] < 1) continue;
+  // ---- grouping decisions.  (One thread walking the batch through LDS took ~0.3 us per request -- every step of it a
+  // dependent LDS round trip: 25 us of a 39 us kernel at 64 requests.)  Three parallel passes instead:
+  // (1) every request works out whether it LEADS a candidate group and what the group would cost;
+  for (int b = tid; b < batch; b += kPlanThreads) {
+    grp_id[b] = -1;
+    int cost = 0;
+    if (leader[b] == b && grp_cnt[b] >= 1) {
       int kv = grp_min[b] / kv_tile * kv_tile;
       if (kv > max_shared) kv = max_shared;
-      if (kv < min_shared) continue;
-      const int members = grp_cnt[b] + 1;
-      const int tiles = (members + tokens_per_tile - 1) / tokens_per_tile;
-      const int chunks = (kv + chunk_tokens - 1) / chunk_tokens;
-      // plan full (leave room for the private chunks of every request): the rest stay ungrouped
-      if (n_items + tiles * chunks > max_items / 2) continue;
-      grp_id[b] = ng;
-      g_leader[ng] = b; g_kv[ng] = kv; g_first[ng] = n_items; g_tiles[ng] = tiles; g_rows0[ng] = rows; g_members[ng] = members;
-      n_items += tiles * chunks;
-      rows += members;
-      ++ng;
+      if (kv >= min_shared) {
+        const int members = grp_cnt[b] + 1;
+        const int tiles = (members + tokens_per_tile - 1) / tokens_per_tile;
+        const int chunks = (kv + chunk_tokens - 1) / chunk_tokens;
+        cost = tiles * chunks;
+        scan[b] = kv;                                  // parked for pass (2): kv, tiles (members = grp_cnt + 1)
+        order[b] = tiles;
+      }
     }
-    // members in batch order inside each group, then the ungrouped requests
-    for (int gi = 0; gi < ng; ++gi) grp_cnt[gi] = g_rows0[gi];       // reuse as cursors (indexed by group id)
-    for (int b = 0; b < batch; ++b) {
+    first_slot[b] = cost;                              // first_slot is dead after the leader search: reused as "cost"
+  }
+  __syncthreads();
+  // (2) wave 0 accepts the candidates in batch order -- the running item count decides (plan full: the rest stay
+  // ungrouped), so this is sequential, but over wave-uniform scalars read with readlane, not over LDS;
+  if (wid == 0) {
+    int ng = 0, rows = 0, n_items = 0;
+    for (int base = 0; base < batch; base += 64) {
+      const int bb = base + lane;
+      const int cost = bb < batch ? first_slot[bb] : 0;
+      const int members = bb < batch ? grp_cnt[bb] + 1 : 0;
+      unsigned long long todo = __ballot(cost > 0);
+      int my_gid = -1, my_first = 0, my_rows0 = 0;
+      while (todo != 0ull) {
+        const int j = __ffsll(static_cast<long long>(todo)) - 1;
+        todo &= todo - 1;
+        const int cj = __builtin_amdgcn_readlane(cost, j);
+        const int mj = __builtin_amdgcn_readlane(members, j);
+        // plan full (leave room for the private chunks of every request): the rest stay ungrouped
+        if (n_items + cj > max_items / 2) continue;
+        if (lane == j) { my_gid = ng; my_first = n_items; my_rows0 = rows; }
+        n_items += cj;
+        rows += mj;
+        ++ng;
+      }
+      if (my_gid >= 0) {
+        grp_id[bb] = my_gid;
+        g_leader[my_gid] = bb; g_kv[my_gid] = scan[bb]; g_first[my_gid] = my_first; g_tiles[my_gid] = order[bb];
+        g_rows0[my_gid] = my_rows0; g_members[my_gid] = members;
+      }
+    }
+    if (lane == 0) { n_groups = ng; n_rows = rows; n_shared_items = n_items; }
+  }
+  __syncthreads();
+  // (3) members in batch order inside each group, then the ungrouped requests: a request's place is the number of
+  // earlier requests of its kind.
+  {
+    const int rows_total = n_rows;
+    int my_pos[ (kPlanMaxBatch + kPlanThreads - 1) / kPlanThreads ];
+    int k = 0;
+    for (int b = tid; b < batch; b += kPlanThreads, ++k) {
       const int gi = grp_id[leader[b]];
-      if (gi >= 0) order[grp_cnt[gi]++] = b;
+      int rank = 0;
+      for (int c = 0; c < b; ++c) rank += (grp_id[leader[c]] == gi) ? 1 : 0;   // gi < 0: all ungrouped count together
+      my_pos[k] = gi >= 0 ? g_rows0[gi] + rank : rows_total + rank;
     }
-    int cur = rows;
-    for (int b = 0; b < batch; ++b)
-      if (grp_id[leader[b]] < 0) order[cur++] = b;
-    n_groups = ng;
-    n_rows = rows;
-    n_shared_items = n_items;
+    __syncthreads();                                   // `order` was scratch of pass (1)/(2) until here
+    k = 0;
+    for (int b = tid; b < batch; b += kPlanThreads, ++k) order[my_pos[k]] = b;
   }
   __syncthreads();
   // ---- write-out, all threads ----
@@ -444,7 +486,7 @@ __global__ __launch_bounds__(kPlanThreads) void cascade_plan_kernel(
     if (b < rows) pv.member_rows[b] = order[b];
   }
   for (int gi = tid; gi < ng; gi += kPlanThreads) {
-    pv.group_pool_row[gi] = static_cast<int32_t>(req_pool_indices[g_leader[gi]]);
+    pv.group_pool_row[gi] = pool_row[g_leader[gi]];
     pv.group_kvlen[gi] = g_kv[gi];
     pv.group_qo[gi + 1] = g_rows0[gi] + g_members[gi];
   }
@@ -462,7 +504,7 @@ __global__ __launch_bounds__(kPlanThreads) void cascade_plan_kernel(
     it[3] = left < tokens_per_tile ? left : tokens_per_tile;   // members
     it[4] = g_rows0[gi] + t * tokens_per_tile;         // first entry of member_rows
     it[5] = 0;                                         // shared item
-    it[6] = static_cast<int32_t>(req_pool_indices[g_leader[gi]]);
+    it[6] = pool_row[g_leader[gi]];
     it[7] = gi;
   }
   if (tid == 0) {
@@ -476,17 +518,23 @@ __global__ __launch_bounds__(kPlanThreads) void cascade_plan_kernel(
   if (tid < batch) {
     const int gi = grp_id[leader[tid]];
     sh = gi >= 0 ? g_kv[gi] : 0;
-    len = seq_lens[tid];
+    len = len_s[tid];
     mine = len > sh ? (len - sh + chunk_tokens - 1) / chunk_tokens : 0;
   }
-  scan[tid] = mine;
-  __syncthreads();
-  for (int off = 1; off < kPlanThreads; off <<= 1) {
-    const int v = tid >= off ? scan[tid - off] : 0;
-    __syncthreads();
-    scan[tid] += v;
-    __syncthreads();
+  // inclusive scan: inside the wave by shuffles, across the 16 waves through LDS (three barriers, not twenty)
+  int incl = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += v;
   }
+  if (lane == 63) wave_tot[wid] = incl;
+  __syncthreads();
+  int wave_base = 0;
+  for (int w = 0; w < wid; ++w) wave_base += wave_tot[w];
+  incl += wave_base;
+  scan[tid] = incl;
+  __syncthreads();
   const int base = n_shared_items + scan[tid] - mine;
   const int first_slot_p = (sh + chunk_tokens - 1) / chunk_tokens;
   for (int j = 0; j < mine; ++j) {
@@ -498,7 +546,7 @@ __global__ __launch_bounds__(kPlanThreads) void cascade_plan_kernel(
     it[2] = len - kvb < chunk_tokens ? len - kvb : chunk_tokens;
     it[4] = tid;                                     // the request itself
     it[5] = 1;                                       // private item
-    it[6] = static_cast<int32_t>(req_pool_indices[tid]);
+    it[6] = pool_row[tid];
     it[7] = -1;
     it[3] = 1;
   }

@@ -147,7 +147,14 @@ class ModelRunner:
         return self.model.forward(fb.input_ids, fb.positions, fb)
 
     def sample(self, logits_output, fb: ForwardBatch) -> torch.Tensor:
-        info = fb.sampling_info or SamplingBatchInfo.greedy(fb.batch_size, self.device)
+        info = fb.sampling_info
+        if info is None:
+            # the default (all-greedy) batch info is four constant tensors: built once per batch size, not once per
+            # decode step (four fill launches = 18 us of every 4.3 ms step)
+            cache = self.__dict__.setdefault("_greedy_info", {})
+            info = cache.get(fb.batch_size)
+            if info is None:
+                info = cache[fb.batch_size] = SamplingBatchInfo.greedy(fb.batch_size, self.device)
         pos = fb.positions if fb.forward_mode.is_decode() else None
         if pos is None and info.sampling_seed is not None:
             pos = (fb.seq_lens - 1).to(torch.int64)
