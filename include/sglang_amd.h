@@ -196,6 +196,13 @@ int sgl_amd_cascade_decode_attention_ex(const void* q, const void* k_cache, cons
 /* ids[b] = argmax(logits[b,:]) (first maximum), logits fp32 (is_bf16=0) or bf16. */
 int sgl_amd_argmax(const void* logits, int logits_is_bf16, int64_t* ids, int64_t batch,
                    int64_t vocab, int64_t row_stride, void* stream);
+/* The same ids with every row cut into num_splits column ranges (one workgroup each; a decode batch on one workgroup
+ * per row leaves most CUs idle): range winners meet in a per-row 64-bit key by atomicMax, the last arriver writes the id.
+ * workspace: sgl_amd_argmax_split_workspace_bytes(batch) bytes, ZERO before the first call, private to one stream at a
+ * time (the kernel re-arms it); rows 16-byte aligned; vocab < 2^32. */
+int64_t sgl_amd_argmax_split_workspace_bytes(int64_t batch);
+int sgl_amd_argmax_split(const void* logits, int logits_is_bf16, int64_t* ids, int64_t batch, int64_t vocab,
+                         int64_t row_stride, int num_splits, void* workspace, void* stream);
 /* in place: logits[b,:] = softmax(logits[b,:] / temperatures[b]) (fp32). */
 int sgl_amd_softmax_temperature(float* logits, const float* temperatures, int64_t batch,
                                 int64_t vocab, int64_t row_stride, void* stream);

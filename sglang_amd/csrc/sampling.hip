@@ -91,6 +91,90 @@ __global__ __launch_bounds__(kRowThreads) void argmax_kernel(const void* __restr
   }
 }
 
+// The same arg-max with every row cut into `splits` column ranges, one workgroup each (a decode batch of 64 rows on
+// one-workgroup-per-row keeps 64 of 256 CUs busy: 21 us for 16 MB).  A workgroup folds its range's winner into the
+// row's 64-bit key  (order-preserving value bits << 32) | (2^32 - 1 - index)  with one atomicMax -- the larger key is
+// the larger value, on ties the smaller index, NaN above everything, -0 == +0 -- and takes a ticket; the last arriver
+// reads the key back, writes the id and re-arms key and ticket (the workspace is zero once, never again by the host).
+__device__ __forceinline__ unsigned long long argmax_key(float v, uint32_t idx) {
+  uint32_t u = __float_as_uint(v + 0.0f);                 // -0 -> +0
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  if (v != v) u = 0xffffffffu;
+  return (static_cast<unsigned long long>(u) << 32) | (0xffffffffu - idx);
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(kRowThreads) void argmax_split_kernel(const void* __restrict__ logits, int64_t* __restrict__ ids,
+                                                                    int64_t vocab, int64_t row_stride, int splits,
+                                                                    unsigned long long* __restrict__ keys,
+                                                                    unsigned int* __restrict__ tickets) {
+  __shared__ unsigned long long s_key[16];
+  const int64_t row = blockIdx.y;
+  constexpr int EPV = BF16 ? 8 : 4;
+  // ranges in whole 16-byte vectors (the host checked the row alignment); the last range takes the scalar tail
+  const int64_t nvec = vocab / EPV;
+  const int64_t per = (nvec + splits - 1) / splits;
+  const int64_t v0 = blockIdx.x * per, v1 = (v0 + per < nvec) ? v0 + per : nvec;
+  const char* base = static_cast<const char*>(logits) + row * row_stride * (BF16 ? 2 : 4);
+  const U4* vbase = reinterpret_cast<const U4*>(base);
+  unsigned long long best = 0ull;
+  auto take = [&](float v, int64_t i) {
+    const unsigned long long k = argmax_key(v, static_cast<uint32_t>(i));
+    best = k > best ? k : best;
+  };
+  // Fast path per 16-byte vector: its maximum and its sum (a NaN -- or inf - inf -- poisons the sum); only a vector
+  // that beats the thread's running maximum, or may hold a NaN, is looked at element by element with the full key
+  // (~2 VALU ops per element instead of ~12: at 12 the kernel was VALU-bound, 18.7 us for 16 MB).
+  float run_max = -INFINITY;
+  bool any = false;
+  auto take_vec = [&](const U4& v, int64_t i0) {
+    float e[8];
+    if (BF16) {
+      e[0] = bf_lo(v.x); e[1] = bf_hi(v.x); e[2] = bf_lo(v.y); e[3] = bf_hi(v.y);
+      e[4] = bf_lo(v.z); e[5] = bf_hi(v.z); e[6] = bf_lo(v.w); e[7] = bf_hi(v.w);
+    } else {
+      e[0] = __uint_as_float(v.x); e[1] = __uint_as_float(v.y); e[2] = __uint_as_float(v.z); e[3] = __uint_as_float(v.w);
+    }
+    float m = e[0], sum = e[0];
+#pragma unroll
+    for (int q = 1; q < EPV; ++q) { m = fmaxf(m, e[q]); sum += e[q]; }
+    if (m > run_max || sum != sum || !any) {
+#pragma unroll
+      for (int q = 0; q < EPV; ++q) take(e[q], i0 + q);
+      run_max = fmaxf(run_max, m);
+      any = true;
+    }
+  };
+  int64_t j = v0 + threadIdx.x;
+  for (; j + kRowThreads < v1; j += 2 * kRowThreads) {     // two loads in flight
+    const U4 a = vbase[j], b2 = vbase[j + kRowThreads];
+    take_vec(a, j * EPV);
+    take_vec(b2, (j + kRowThreads) * EPV);
+  }
+  if (j < v1) take_vec(vbase[j], j * EPV);
+  if (blockIdx.x == splits - 1)
+    for (int64_t i = nvec * EPV + threadIdx.x; i < vocab; i += kRowThreads) take(load_logit<BF16>(base, i), i);
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long o = __shfl_xor(best, off, 64);
+    best = o > best ? o : best;
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) s_key[wid] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kRowThreads / 64; ++w) best = s_key[w] > best ? s_key[w] : best;
+    atomicMax(&keys[row], best);
+    __threadfence();
+    if (atomicAdd(&tickets[row], 1u) == static_cast<unsigned>(splits - 1)) {
+      __threadfence();
+      const unsigned long long k = atomicMax(&keys[row], 0ull);
+      ids[row] = k ? static_cast<int64_t>(0xffffffffu - static_cast<uint32_t>(k & 0xffffffffu)) : 0;
+      atomicExch(&keys[row], 0ull);
+      atomicExch(&tickets[row], 0u);
+    }
+  }
+}
+
 // logits <- softmax(logits / T), fp32, in place (sampler.py:211-216).
 __global__ __launch_bounds__(kRowThreads) void softmax_temperature_kernel(
     float* __restrict__ logits, const float* __restrict__ temperatures, int64_t vocab,
@@ -125,6 +209,29 @@ int sgl_amd_argmax(const void* logits, int logits_is_bf16, int64_t* ids, int64_t
     hipLaunchKernelGGL(argmax_kernel<false>, dim3(batch), dim3(kRowThreads), 0, as_stream(stream),
                        logits, ids, vocab, row_stride);
   SGL_CHECK_LAUNCH("argmax");
+  return 0;
+}
+
+int64_t sgl_amd_argmax_split_workspace_bytes(int64_t batch) { return batch * 16; }
+
+int sgl_amd_argmax_split(const void* logits, int logits_is_bf16, int64_t* ids, int64_t batch, int64_t vocab,
+                         int64_t row_stride, int num_splits, void* workspace, void* stream) {
+  SGL_CLEAR_STALE_ERROR();
+  SGL_CHECK_ARG(vocab > 0 && vocab < (int64_t{1} << 32), "argmax_split: vocab must be in [1, 2^32)");
+  SGL_CHECK_ARG(batch <= 65535 && num_splits >= 1 && num_splits <= 64, "argmax_split: batch <= 65535, 1..64 splits");
+  SGL_CHECK_ARG(workspace && (reinterpret_cast<uintptr_t>(logits) & 15) == 0 && (row_stride * (logits_is_bf16 ? 2 : 4)) % 16 == 0,
+                "argmax_split: needs the workspace and 16-byte aligned rows");
+  if (batch == 0) return 0;
+  unsigned long long* keys = static_cast<unsigned long long*>(workspace);
+  unsigned int* tickets = reinterpret_cast<unsigned int*>(keys + batch);
+  const dim3 grid(num_splits, static_cast<unsigned>(batch));
+  if (logits_is_bf16)
+    hipLaunchKernelGGL(argmax_split_kernel<true>, grid, dim3(kRowThreads), 0, as_stream(stream), logits, ids, vocab, row_stride,
+                       num_splits, keys, tickets);
+  else
+    hipLaunchKernelGGL(argmax_split_kernel<false>, grid, dim3(kRowThreads), 0, as_stream(stream), logits, ids, vocab, row_stride,
+                       num_splits, keys, tickets);
+  SGL_CHECK_LAUNCH("argmax_split");
   return 0;
 }
 

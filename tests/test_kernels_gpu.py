@@ -332,3 +332,30 @@ def test_argmax_and_softmax(device):
         p = _k().softmax_temperature_(logits.clone().to(device), temps.to(device)).cpu()
         ref = torch.softmax(logits / temps.view(-1, 1), dim=-1)
         torch.testing.assert_close(p, ref, atol=1e-6, rtol=1e-4)
+
+
+@pytest.mark.parametrize("B,V", [(64, 128256), (3, 151936), (17, 32003), (200, 50257)])
+def test_argmax_split_rows_semantics(device, B, V):
+    """The column-range form (decode-sized batches of wide rows): first maximum on ties across ranges, NaN maximal,
+    -0 == +0, all -inf rows, and the workspace re-arms itself (three calls through the same one)."""
+    torch.manual_seed(B + V)
+    logits = torch.randn((B, V)) * 2
+    logits[0, 5] = logits[0, V - 3] = 40.0             # tie in the first and the last range: first index wins
+    if B > 1:
+        logits[1, V // 2 + 1] = float("nan")           # NaN beats everything
+        logits[1, 7] = 1e30
+    if B > 2:
+        logits[2].fill_(-0.0)
+        logits[2, V // 3] = 0.0                        # +0 after -0: equal, the first index (0) wins
+    for dt in (torch.float32, BF):
+        x = logits.to(dt)
+        if dt == torch.float32 and (x.stride(0) * 4) % 16 != 0:
+            continue                                   # unaligned rows take the one-workgroup-per-row kernel anyway
+        want = torch.argmax(x.float(), -1)
+        if B > 1:
+            want[1] = V // 2 + 1
+        for _ in range(3):
+            got = _k().argmax(x.to(device)).cpu()
+            assert torch.equal(got, want), (dt, (got != want).nonzero().flatten().tolist()[:5])
+    ninf = torch.full((4, 65536), float("-inf"), dtype=BF)
+    assert _k().argmax(ninf.to(device)).cpu().tolist() == [0, 0, 0, 0]
