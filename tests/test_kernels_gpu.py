@@ -235,6 +235,28 @@ def _run_extend(c, device, causal=True):
     return out.cpu()
 
 
+def test_decode_advance_equals_the_eager_ops(device):
+    """One launch = the decode step's five eager tensor ops (allocation.py:512-560 alloc_for_decode +
+    write_req_to_token_pool at column seq_len, then seq_lens += 1), for a few steps in a row."""
+    bs, ctx = 37, 96
+    g = torch.Generator().manual_seed(3)
+    pool = torch.randperm(64, generator=g)[:bs].to(torch.int64) + 1
+    seq0 = torch.randint(1, 80, (bs,), generator=g, dtype=torch.int32)
+    r2t_a = torch.randint(0, 1000, (70, ctx), generator=g, dtype=torch.int32)
+    r2t_b = r2t_a.clone().to(device)
+    seq_a, seq_b = seq0.clone(), seq0.clone().to(device)
+    out_b = torch.zeros(bs, dtype=torch.int64, device=device)
+    for step in range(4):
+        slots = (torch.randperm(5000, generator=g)[:bs] + 10 + 10000 * step).to(torch.int64)
+        # the eager form (harness/engine.py, CPU path)
+        r2t_a[pool, seq_a.long()] = slots.to(torch.int32)
+        seq_a += 1
+        _k().decode_advance(r2t_b, pool.to(device), seq_b, slots.to(device), out_b)
+        assert torch.equal(out_b.cpu(), slots)
+        assert torch.equal(seq_b.cpu(), seq_a)
+        assert torch.equal(r2t_b.cpu(), r2t_a)
+
+
 def test_attention_golden(device, golden_dir):
     """Fixtures recorded from the real TorchNativeAttnBackend (bf16 SDPA)."""
     cases = _load(golden_dir, "attention_torch_native.pt")
