@@ -399,7 +399,10 @@ __global__ __launch_bounds__(64 * NWV, (MTW == 1 && NWV == 4) ? 3 : (NWV == 8 ? 
 //     fragments built from the S^T accumulators.  No transposition through the VALU;
 //   * the running maximum is only raised when some row of the wave outgrows it by more than 2^8 (the rescale of the 64
 //     output accumulators is the largest VALU item of a tile); P stays below 2^8 in between, l and O carry the same factor.
-constexpr float kDeferMax = 8.0f;   // log2 units
+#ifndef EXT_DEFER_MAX
+#define EXT_DEFER_MAX 8.0f
+#endif
+constexpr float kDeferMax = EXT_DEFER_MAX;   // log2 units
 
 #ifdef EXT_TRACE
 // phase probe (benchmarks/r02_exp9_ext_trace.py): per wave, shader clocks spent in [row loads issued, S^T, softmax,
@@ -414,6 +417,22 @@ __device__ uint64_t* g_ext_trace = nullptr;
 #else
 #define EXT_T(i)
 #endif
+
+// Maximum over the four 16-lane rows of a wave (the lanes l, l + 16, l + 32, l + 48 hold one query row's scores of
+// different tokens): v_permlane16_swap exchanges the odd rows of its first operand with the even rows of its second,
+// v_permlane32_swap the upper half of the first with the lower half of the second; on two copies of x each leaves
+// (own, partner) in the two registers.  Inline asm on purpose: with the builtin on two copies of ONE value hipcc kept
+// only the first result (max(r0, r0)), which turned the reduction into "everybody takes row 0's maximum" -- harmless
+// until a row's largest score sits in another lane row and exceeds the others by 2^128 (tests/test_kernels_gpu.py,
+// every_workgroup_shape).  The s_nops cover the VALU-write -> permlane-read hazard the assembler does not pad.
+__device__ __forceinline__ float row_groups_max(float x) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  a = fmaxf(a, b);
+  b = a;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return fmaxf(a, b);
+}
 
 template <int D>
 struct SmemDbuf {
@@ -692,14 +711,7 @@ __global__ __launch_bounds__(512, 2) void extend_attention_dbuf_kernel(ExtendPar
         }
       }
 #pragma unroll
-      for (int mt = 0; mt < MTW; ++mt) {
-        const unsigned mu = __builtin_bit_cast(unsigned, mx[mt]);
-        const auto s16 = __builtin_amdgcn_permlane16_swap(mu, mu, false, false);
-        const float m16 = fmaxf(__builtin_bit_cast(float, s16[0]), __builtin_bit_cast(float, s16[1]));
-        const unsigned m16u = __builtin_bit_cast(unsigned, m16);
-        const auto s32 = __builtin_amdgcn_permlane32_swap(m16u, m16u, false, false);
-        mx[mt] = fmaxf(__builtin_bit_cast(float, s32[0]), __builtin_bit_cast(float, s32[1]));
-      }
+      for (int mt = 0; mt < MTW; ++mt) mx[mt] = row_groups_max(mx[mt]);
       if (__ballot(mx[0] > m_run[0] + kDeferMax || mx[1] > m_run[1] + kDeferMax) != 0ull) {
         // some row outgrew its maximum: raise them all
 #pragma unroll

@@ -329,6 +329,29 @@ def test_extend_attention_noncausal(device):
     torch.testing.assert_close(o.float(), ref.float(), atol=4e-3, rtol=1e-2)
 
 
+@pytest.mark.parametrize("shape", ["82", "42", "41"])
+@pytest.mark.parametrize("Hq,Hkv,D,causal", [(32, 8, 128, True), (8, 1, 128, True), (14, 2, 64, True), (16, 4, 128, False),
+                                             (4, 4, 64, False)])
+def test_extend_attention_every_workgroup_shape(device, monkeypatch, shape, Hq, Hkv, D, causal):
+    """The launcher picks the workgroup shape from the grid size, so small test batches rarely reach the 8-wave
+    double-buffered ping-pong kernel the bench's prefills run on: SGL_AMD_EXTEND_SHAPE forces each shape in turn
+    (82 = 8 waves x 2 M-tiles, the dbuf kernel; 42 / 41 = the 4-wave forms) on a ragged batch with cached prefixes,
+    one-token and tile-straddling extends, and a late dominating key (the deferred-rescale path)."""
+    if shape == "41" and Hq // Hkv > 64:
+        pytest.skip("the 64-row shape holds groups up to 64")
+    monkeypatch.setenv("SGL_AMD_EXTEND_SHAPE", shape)
+    prefix = [0, 896, 5, 0, 63, 64, 200, 1000] if causal else [0, 0, 0, 0]
+    extend = [130, 128, 1, 333, 65, 64, 7, 70] if causal else [50, 64, 129, 300]
+    c = _random_case(len(prefix), Hq, Hkv, D, prefix, extend, seed=Hq + D + int(shape), spike=True)
+    # the spike of _random_case follows the DECODE query of the last request: give the extend queries one too
+    c["q"][-3] = (c["k_cache"][c["req_to_token"][c["req_pool_indices"][-1], 3].long(), 0] * 30).to(BF)
+    ref = oo.extend_attention(c["q"], c["k_cache"], c["v_cache"], c["req_to_token"], c["req_pool_indices"],
+                              c["seq_lens"], c["extend_prefix_lens"], c["extend_seq_lens"], c["scaling"],
+                              causal=causal, compute_dtype=torch.float32)
+    o = _run_extend(c, device, causal=causal)
+    torch.testing.assert_close(o.float(), ref.float(), atol=4e-3, rtol=1e-2)
+
+
 def test_decode_equals_extend_of_one_token(device):
     """Size-independent property: decoding token n == extending by one token over prefix n-1."""
     lens = [700, 1024, 33]
