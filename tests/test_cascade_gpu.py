@@ -149,3 +149,31 @@ def test_cascade_plan_replans_every_step(device):
         out = torch.empty((B, Hq, D), dtype=BF, device=device)
         K.cascade_decode_attention(ws, q.to(device), kc.to(device), vc.to(device), out, r2t_d, pool_d, seq_d, D ** -0.5)
         _check(out.cpu(), q, kc, vc, r2t, pool, seq, D)
+
+
+@pytest.mark.parametrize("where", ["shared", "private"])
+def test_cascade_and_plain_decode_survive_a_dominating_key(device, where):
+    """Scores 250 log2-units apart inside one request (a query aligned with one huge key): every partial maximum has to
+    reach every lane and every merge, or exp2 overflows (the extend kernel's lane-row reduction once did not:
+    test_kernels_gpu.py every_workgroup_shape).  The key sits in the shared prefix or in a private suffix, at a position
+    that is not a multiple of 4 or 16."""
+    Hq, Hkv, D = 32, 8, 128
+    lens, groups = [700, 705, 650, 333], [0, 0, 0, -1]
+    q, kc, vc, r2t, pool, seq = _batch(device, lens, groups, {0: 512}, Hq, Hkv, D, seed=5)
+    b, pos = 1, (301 if where == "shared" else 641)
+    slot = int(r2t[int(pool[b]), pos])
+    base = (torch.randn(D, generator=torch.Generator().manual_seed(9)) * 0.6).to(BF)
+    kc[slot] = (base * 8).to(BF)                  # all kv heads of that token
+    q[b] = (base * 7).to(BF)                      # all q heads of request b: score ~ 56 |base|^2 / sqrt(D) ~ 250 log2-units
+    out, plan = _run(device, q, kc, vc, r2t, pool, seq, Hq, Hkv, D)
+    assert plan["n_groups"] == 1
+    _check(out, q, kc, vc, r2t, pool, seq, D)
+    # the plain paged kernel on the same batch, one and several KV splits
+    K = _k()
+    for splits in (1, 4):
+        ws = K.decode_workspace(len(lens), Hq, D, splits, device) if splits > 1 else (None, None)
+        o = torch.empty((len(lens), Hq, D), dtype=BF, device=device)
+        K.decode_attention(q.to(device), kc.to(device), vc.to(device), o, r2t.to(device), pool.to(device), seq.to(device), D ** -0.5,
+                           splits, ws[0], ws[1])
+        assert not bool(torch.isnan(o.float()).any())
+        _check(o.cpu(), q, kc, vc, r2t, pool, seq, D)
