@@ -177,3 +177,46 @@ def test_cascade_and_plain_decode_survive_a_dominating_key(device, where):
                            splits, ws[0], ws[1])
         assert not bool(torch.isnan(o.float()).any())
         _check(o.cpu(), q, kc, vc, r2t, pool, seq, D)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_device_plan_equals_host_restatement_on_random_batches(device, seed):
+    """The plan kernel (parallel grouping passes, one wave accepting the groups, rank-by-counting member order) against
+    oracle/host.py cascade_plan on random batches: random group sizes and shared lengths, members diverging early,
+    singletons, one-token requests, interleaved batch order, up to 200 requests."""
+    import random
+
+    from oracle import host as oh
+
+    rnd = random.Random(seed)
+    Hq, Hkv, D = 32, 8, 128
+    B = rnd.choice([5, 37, 64, 130, 200])
+    n_groups = rnd.randint(1, max(1, B // 3))
+    lens, groups, shared = [], [], {}
+    for b in range(B):
+        gi = rnd.randint(-1, n_groups - 1) if rnd.random() < 0.8 else -1
+        groups.append(gi)
+        lens.append(rnd.choice([1, 2, 65, 129]) if rnd.random() < 0.1 else rnd.randint(130, 900))
+    for gi in range(n_groups):
+        shared[gi] = rnd.choice([40, 100, 128, 200, 384, 512, 700])
+    q, kc, vc, r2t, pool, seq = _batch(device, lens, groups, shared, Hq, Hkv, D, seed=seed)
+    for _ in range(3):                                    # some members leave the shared prefix early
+        b = rnd.randrange(B)
+        if lens[b] > 140:
+            cut = rnd.randint(1, lens[b] - 2)
+            r2t[b + 1, cut] = 0
+    K = _k()
+    ws = K.CascadeWorkspace(B, Hq, D, r2t.shape[1], device)
+    K.cascade_plan(ws, r2t.to(device), pool.to(device), seq.to(device), Hq, Hkv)
+    got = K.cascade_plan_summary(ws, B)
+    want = oh.cascade_plan(r2t.numpy(), pool.tolist(), lens, Hq // Hkv, chunk=K.native.lib().sgl_amd_cascade_chunk_tokens(),
+                           max_context_len=r2t.shape[1], max_items=ws.max_items)
+    assert got["req_shared"] == want["req_shared"]
+    assert got["n_groups"] == len(want["groups"])
+    assert got["group_kvlen"] == [kv for _, kv, _ in want["groups"]]
+    assert got["member_rows"] == want["member_rows"]
+    assert got["items"] == want["shared_items"]
+    assert sorted(got["private_items"]) == sorted(want["private_items"])
+    assert got["n_items"] == len(want["shared_items"]) + len(want["private_items"])
+    grouped = set(want["member_rows"])
+    assert got["batch_order"] == want["member_rows"] + [b for b in range(B) if b not in grouped]
