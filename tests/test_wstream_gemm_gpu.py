@@ -230,3 +230,35 @@ def test_wstream_chunk_major_epilogues(device, M):
     got = K_.wstream_gemm(_blocked(act), w2, epilogue="add_rmsnorm", residual=r2, norm_weight=nrm, eps=1e-5, splits=2,
                           out_blocked=True)
     assert torch.equal(K_.unblock(got), want) and torch.equal(r1, r2)
+
+
+@pytest.mark.parametrize("M", [1, 16, 37, 64])
+@pytest.mark.parametrize("N,K,nw,splits", [(128256, 4096, 4, 1), (4096, 4096, 2, 4), (6144, 896, 3, 2), (64, 256, 2, 1), (32, 128, 4, 1)])
+def test_wstream_two_tiles_per_wave_plain_epilogues(device, M, N, K, nw, splits):
+    """tiles_per_wave = 2 outside the silu form: a wave owns output tiles t and t + N/32 (the lm_head decomposition);
+    bias, split-K partials, chunk-major output, against the fp64 reference and bit-for-bit against itself with a
+    chunk-major input."""
+    K_ = _k()
+    if splits > K // 128:
+        pytest.skip("more splits than K chunks")
+    g = torch.Generator().manual_seed(M + N + K)
+    x = (torch.randn((M, K), generator=g) * 0.5).to(BF).to(device)
+    w = (torch.randn((N, K), generator=g) * 0.05).to(BF).to(device)
+    b = torch.randn(N, generator=g).to(BF).to(device)
+    ref = _ref_linear(x.cpu(), w.cpu(), b.cpu())
+    got = K_.wstream_gemm(x, w, bias=b, waves_per_group=nw, splits=splits, tiles_per_wave=2)
+    _check(got.cpu(), ref)
+    if N % 128 == 0 and K % 128 == 0:
+        blk = K_.wstream_gemm(_blocked(x), w, bias=b, waves_per_group=nw, splits=splits, tiles_per_wave=2, out_blocked=True)
+        assert torch.equal(K_.unblock(blk), got)
+
+
+def test_wstream_auto_decomposition_is_what_the_model_runs(device):
+    """No explicit decomposition: choose_wstream_decomposition (two-tile waves for the wide single-split launches)."""
+    K_ = _k()
+    g = torch.Generator().manual_seed(3)
+    for M, N, K in ((64, 128256, 4096), (5, 32000, 4096), (64, 28672, 4096)):
+        x = (torch.randn((M, K), generator=g) * 0.5).to(BF).to(device)
+        w = (torch.randn((N, K), generator=g) * 0.05).to(BF).to(device)
+        assert K_.choose_wstream_decomposition(M, N, K)[1] == 2
+        _check(K_.wstream_gemm(x, w).cpu(), _ref_linear(x.cpu(), w.cpu()))
