@@ -593,6 +593,22 @@ __global__ __launch_bounds__(256) void wstream_combine_rope_kernel(RopeParams p)
   }
 }
 
+#ifdef WS_EXPERIMENT
+__global__ __launch_bounds__(256) void prefetch_head_kernel(const uint16_t* __restrict__ w, int64_t w_stride, int64_t N, int64_t K,
+                                                            int splits, int pd, uint32_t* __restrict__ sink, int64_t pieces) {
+  const int64_t i = blockIdx.x * 256ll + threadIdx.x;
+  if (i >= pieces) return;
+  const int per_row = splits * pd * 16;
+  const int64_t row = i / per_row;
+  const int rem = static_cast<int>(i - row * per_row);
+  const int sp = rem / (pd * 16), piece = rem - sp * (pd * 16);
+  const int64_t nch = K / kKC;
+  const int64_t cb = static_cast<int64_t>(sp) * nch / splits;
+  const U4 v = ld16(w + row * w_stride + cb * kKC + piece * 8);
+  if ((v.x ^ v.y ^ v.z ^ v.w) == 0x9e3779b9u && sink) sink[0] = v.x;       // keeps the load alive, practically never true
+}
+#endif
+
 // the activation image of a chunk grows with M: beyond 64 rows only the narrower groups keep a 3-deep ring
 template <int MT, int NW, int TPW>
 int launch_main(const WsParams& p, hipStream_t st, int row_blocks = 0) {
@@ -633,6 +649,17 @@ int launch_nw(const WsParams& p, int nw, bool two_tiles, hipStream_t st, int row
 }  // namespace
 
 extern "C" {
+
+#ifdef WS_EXPERIMENT
+// benchmarks/r02_exp16_prefetch.py: read the bytes a following weight-streaming launch asks for first (the first `pd`
+// K chunks of every row in each of its `splits` K ranges), so that they wait in the memory-side cache
+int sgl_amd_debug_prefetch_head(const void* w, int64_t w_row_stride, int64_t N, int64_t K, int splits, int pd, void* sink, void* stream) {
+  const int64_t pieces = N * splits * pd * 16;              // 16-byte pieces
+  hipLaunchKernelGGL(prefetch_head_kernel, dim3(static_cast<unsigned>((pieces + 255) / 256)), dim3(256), 0, as_stream(stream),
+                     static_cast<const uint16_t*>(w), w_row_stride, N, K, splits, pd, static_cast<uint32_t*>(sink), pieces);
+  return 0;
+}
+#endif
 
 #ifdef WS_TRACE
 int sgl_amd_debug_ws_trace(void* buf) {
