@@ -135,6 +135,9 @@ def parse_args():
     ap.add_argument("--page-size", type=int, default=1)
     ap.add_argument("--layers", type=int, default=0, help="override the layer count (NOT a valid bench line: the "
                                                            "config is marked reduced)")
+    ap.add_argument("--kv-cache-dtype", default="auto", choices=("auto", "bfloat16", "fp8_e4m3"),
+                    help="KV pool rows (server_args --kv-cache-dtype); fp8_e4m3 is NOT the baseline configuration: the "
+                         "line's config says so and the bf16-KV parity leg is skipped")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--operator-surface", action="store_true",
                     help="decode through the unfused per-operator hooks only (the path the sglang.srt registration "
@@ -211,7 +214,7 @@ def worker(args):
 
     runner = ModelRunner(cfg, max_total_tokens=B * (in_len + args.out) + 4096, max_running_requests=B,
                          max_context_len=ctx, page_size=args.page_size, device=dev, use_graph=not args.no_graph,
-                         graph_max_bs=B, strict_graph=True)
+                         graph_max_bs=B, strict_graph=True, kv_cache_dtype=args.kv_cache_dtype)
     if not args.no_graph and runner.graph_runner is None:
         raise SystemExit("hipGraph decode was requested but no graph runner exists")
     if runner.model.config.name != cfg.name:
@@ -288,7 +291,8 @@ def worker(args):
     # ---- rooflines ------------------------------------------------
     L, Hq, Hkv, D = cfg.num_hidden_layers, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
     kv_heads_rank = max(1, Hkv // world)
-    kv_row = 2 * L * kv_heads_rank * D * 2            # bytes per cached token on one rank, all layers (131072 for 8B TP=1)
+    kv_fp8 = args.kv_cache_dtype == "fp8_e4m3"
+    kv_row = 2 * L * kv_heads_rank * D * (1 if kv_fp8 else 2)   # bytes per cached token on one rank, all layers (131072 for 8B TP=1)
     plin = p_lin(cfg)
     w_act = decode_weight_bytes(cfg, B) / world
     mean_len = in_len + args.out / 2
@@ -320,6 +324,7 @@ def worker(args):
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"{cfg.name} shared-prefix batch: {G} groups x {P} prompts, {args.prefix} shared + "
                                f"{args.unique} unique in, {args.out} out, greedy, page_size {args.page_size}"
+                               + (" [fp8_e4m3 KV pool -- not the baseline configuration]" if kv_fp8 else "")
                                + (f" [REDUCED: {args.layers} layers -- not a valid bench line]" if reduced else ""),
                    "model": cfg.name, "global_batch": B, "seq_len": in_len, "parallelism": f"tp{world}",
                    "decode": decode_mode},
@@ -340,7 +345,7 @@ def worker(args):
             result.setdefault("roofline", {"error": f"{type(e).__name__}: {e}"})
 
     # ---- parity of this very job against the oracle's plain torch ops on the GPU ----------
-    if rank == 0 and world == 1 and not args.no_parity:
+    if rank == 0 and world == 1 and not args.no_parity and not kv_fp8:
         try:
             from oracle.parity import teacher_forced_parity
 

@@ -279,13 +279,16 @@ int sgl_amd_wstream_gemm(const void* x, const void* w, const void* bias, void* y
  * with the rounding points of QKVParallelLinear -> RotaryEmbedding.forward_native -> set_kv_buffer
  * (srt/layers/linear.py:1596, rotary_embedding/utils.py:49-57, base.py:385-417).  w_qkv is [(Hq+2Hkv)*D, K]
  * (q rows, k rows, v rows); cos_sin_cache [max_pos, D] = cos | sin halves, bf16 or fp32; ws_partials holds
- * sgl_amd_wstream_gemm_workspace_floats(M, (Hq+2Hkv)*D, num_k_splits) floats (always needed). */
+ * sgl_amd_wstream_gemm_workspace_floats(M, (Hq+2Hkv)*D, num_k_splits) floats (always needed).  The pool may be any
+ * format of sgl_amd_store_kv_cache_ex (kv_fp8: e4m3 of the bf16 row / scale; kv_layout_hnd: [pages, Hkv, page, D]);
+ * cache_row_stride = elements of one token's [Hkv, D] row. */
 int sgl_amd_wstream_qkv_rope(const void* x, const void* w_qkv, const void* bias, void* q_out, int64_t M,
                              int64_t K, int num_q_heads, int num_kv_heads, int head_dim,
                              int64_t x_row_stride, int64_t x_chunk_stride, int64_t w_row_stride, int64_t q_row_stride,
                              const int64_t* positions, const void* cos_sin_cache, int cache_is_f32,
                              int64_t rotary_dim, void* k_cache, void* v_cache, const int64_t* cache_loc,
-                             int64_t cache_row_stride, int waves_per_group, int tiles_per_wave,
+                             int64_t cache_row_stride, int kv_fp8, float k_scale, float v_scale,
+                             int page_size, int kv_layout_hnd, int waves_per_group, int tiles_per_wave,
                              int num_k_splits, void* ws_partials, void* stream);
 /* Grouped (mixture-of-experts) form of the weight-streaming GEMM, same contract as sgl_amd_moe_grouped_gemm
  * (fused_moe_triton_kernels.py:324,771) for shapes with N % 16 == 0 and K % 128 == 0, without split-K: one

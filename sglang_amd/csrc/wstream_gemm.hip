@@ -24,6 +24,7 @@
 //     split order (deterministic) and applies the epilogue the next operator would have been:
 //     bias, silu(gate)*up, or residual-add + RMSNorm, with the torch-native bf16 rounding points.
 #include "common.hpp"
+#include "kv_format.hpp"
 #include "sglang_amd.h"
 
 using namespace sgl_amd;
@@ -533,7 +534,28 @@ struct RopeParams {
   const void* cos_sin;          // [max_pos, D]  cos | sin halves, bf16 or fp32
   int64_t q_stride, cache_row_stride;
   int M, N, splits, num_q_heads, num_kv_heads, head_dim, cache_f32;
+  // pools other than bf16 token-major (memory_pool.py:2061-2117 HND pages, :2364-2374 fp8 rows of x / scale)
+  int generic;
+  KvFormat fmt;
+  float inv_k_scale, inv_v_scale;
 };
+
+// four values of a KV row to the pool: bf16 (8 bytes) or e4m3 of x / scale (4 bytes, the bf16-rounded value is what
+// the reference's set_kv_buffer quantises)
+__device__ __forceinline__ void put_kv4(unsigned char* row, int elem, const float (&v)[4], bool fp8, float inv_scale) {
+  if (fp8) {
+    float c[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c[j] = fminf(fmaxf(rbf(v[j]) * inv_scale, -448.f), 448.f);
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], w, true);
+    *reinterpret_cast<uint32_t*>(row + elem) = static_cast<uint32_t>(w);
+  } else {
+    uint2 w2;
+    w2.x = pack_bf2(v[0], v[1]); w2.y = pack_bf2(v[2], v[3]);
+    *reinterpret_cast<uint2*>(row + elem * 2) = w2;
+  }
+}
 
 __global__ __launch_bounds__(256) void wstream_combine_rope_kernel(RopeParams p) {
   const int m = blockIdx.x;
@@ -570,6 +592,12 @@ __global__ __launch_bounds__(256) void wstream_combine_rope_kernel(RopeParams p)
       o1[r] = rbf(x1 * c[r]) - rbf(x2 * sn[r]);
       o2[r] = rbf(x2 * c[r]) + rbf(x1 * sn[r]);
     }
+    if (p.generic && h >= p.num_q_heads) {
+      unsigned char* row = const_cast<unsigned char*>(kv_row(p.k_cache, p.fmt, static_cast<int>(slot), h - p.num_q_heads));
+      put_kv4(row, i, o1, p.fmt.fp8 != 0, p.inv_k_scale);
+      put_kv4(row, i + half, o2, p.fmt.fp8 != 0, p.inv_k_scale);
+      return;
+    }
     uint16_t* dst = h < p.num_q_heads ? p.q_out + static_cast<int64_t>(m) * p.q_stride + n1
                                       : p.k_cache + slot * p.cache_row_stride + (h - p.num_q_heads) * D + i;
     uint2 w1, w2;
@@ -586,6 +614,13 @@ __global__ __launch_bounds__(256) void wstream_combine_rope_kernel(RopeParams p)
     if (p.bias) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) a[r] += bf2f(p.bias[v0 + e + r]);
+    }
+    if (p.generic) {
+      const int vh = e / D;
+      const float av[4] = {a[0], a[1], a[2], a[3]};
+      put_kv4(const_cast<unsigned char*>(kv_row(p.v_cache, p.fmt, static_cast<int>(slot), vh)), e - vh * D, av, p.fmt.fp8 != 0,
+              p.inv_v_scale);
+      return;
     }
     uint2 w;
     w.x = pack_bf2(a[0], a[1]); w.y = pack_bf2(a[2], a[3]);
@@ -806,7 +841,8 @@ int sgl_amd_wstream_qkv_rope(const void* x, const void* w_qkv, const void* bias,
                              int num_q_heads, int num_kv_heads, int head_dim, int64_t x_row_stride, int64_t x_chunk_stride,
                              int64_t w_row_stride, int64_t q_row_stride, const int64_t* positions, const void* cos_sin_cache, int cache_is_f32,
                              int64_t rotary_dim, void* k_cache, void* v_cache, const int64_t* cache_loc,
-                             int64_t cache_row_stride, int waves_per_group, int tiles_per_wave, int num_k_splits,
+                             int64_t cache_row_stride, int kv_fp8, float k_scale, float v_scale, int page_size,
+                             int kv_layout_hnd, int waves_per_group, int tiles_per_wave, int num_k_splits,
                              void* ws_partials, void* stream) {
   SGL_CLEAR_STALE_ERROR();
   if (M == 0) return 0;
@@ -826,6 +862,11 @@ int sgl_amd_wstream_qkv_rope(const void* x, const void* w_qkv, const void* bias,
   r.q_stride = q_row_stride; r.cache_row_stride = cache_row_stride;
   r.M = static_cast<int>(M); r.N = static_cast<int>(N); r.splits = num_k_splits;
   r.num_q_heads = num_q_heads; r.num_kv_heads = num_kv_heads; r.head_dim = head_dim; r.cache_f32 = cache_is_f32;
+  r.generic = (kv_fp8 || kv_layout_hnd) ? 1 : 0;
+  SGL_CHECK_ARG(!kv_fp8 || (k_scale > 0.f && v_scale > 0.f), "wstream_qkv_rope: fp8 KV needs positive k_scale / v_scale");
+  SGL_CHECK_ARG(make_kv_format(&r.fmt, cache_row_stride, num_kv_heads, head_dim, page_size, kv_layout_hnd, kv_fp8),
+                "wstream_qkv_rope: HND pools need a power-of-two page_size (got %d); row / page strides below 4 GiB", page_size);
+  r.inv_k_scale = kv_fp8 ? 1.0f / k_scale : 1.0f; r.inv_v_scale = kv_fp8 ? 1.0f / v_scale : 1.0f;
   const int items = (num_q_heads + num_kv_heads) * (head_dim / 8) + num_kv_heads * head_dim / 4;
   hipLaunchKernelGGL(wstream_combine_rope_kernel, dim3(r.M, (items + 255) / 256), dim3(256), 0, st, r);
   SGL_CHECK_LAUNCH("wstream_qkv_rope");

@@ -222,7 +222,8 @@ class LlamaAttention(nn.Module):
         combine pair (returns the normed activations, residual updated in place)."""
         pool = forward_batch.token_to_kv_pool
         plain_pool = not getattr(pool, "is_fp8", False) and not getattr(pool, "use_hnd", False)
-        if not plain_pool:
+        streams = not OPERATOR_SURFACE_ONLY and self.qkv_proj.streams(hidden_states) and self.rotary_emb.is_neox_style
+        if not plain_pool and not streams:
             # fp8 / HND pools: rope, then the backend stores the rows in the pool's own format (set_kv_buffer)
             qkv = self.qkv_proj(hidden_states)
             q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
@@ -231,13 +232,14 @@ class LlamaAttention(nn.Module):
             if fused_norm is not None:
                 return self._o_proj_fused_norm(attn_output, fused_norm)
             return self.o_proj.forward_all_reduce(attn_output)
-        if not OPERATOR_SURFACE_ONLY and self.qkv_proj.streams(hidden_states) and self.rotary_emb.is_neox_style:
-            # decode batch: qkv GEMM, rope and the KV-row store in one GEMM + combine pair
+        if streams:
+            # decode batch: qkv GEMM, rope and the KV-row store (in the pool's format) in one GEMM + combine pair
             q = kernels.wstream_qkv_rope(hidden_states, self.qkv_proj.weight.data,
                                          self.qkv_proj.bias.data if self.qkv_proj.bias is not None else None, positions,
                                          self.rotary_emb.cos_sin_cache, self.num_heads, self.num_kv_heads, self.head_dim,
                                          pool.get_key_buffer(self.layer_id), pool.get_value_buffer(self.layer_id),
-                                         forward_batch.out_cache_loc)
+                                         forward_batch.out_cache_loc,
+                                         **({} if plain_pool else pool.kernel_format(self.attn)))
             attn_output = self.attn(q, None, None, forward_batch, save_kv_cache=False)
             if fused_norm is not None:
                 return self._o_proj_fused_norm(attn_output, fused_norm)

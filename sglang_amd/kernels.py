@@ -725,9 +725,11 @@ def wstream_qkv_rope(x: torch.Tensor, w_qkv: torch.Tensor, bias: Optional[torch.
                      cos_sin_cache: torch.Tensor, num_q_heads: int, num_kv_heads: int, head_dim: int,
                      k_cache: torch.Tensor, v_cache: torch.Tensor, cache_loc: torch.Tensor,
                      waves_per_group: Optional[int] = None, splits: Optional[int] = None,
-                     tiles_per_wave: Optional[int] = None) -> torch.Tensor:
+                     tiles_per_wave: Optional[int] = None, kv_fp8: bool = False, k_scale: float = 1.0,
+                     v_scale: float = 1.0, page_size: int = 1, hnd: bool = False) -> torch.Tensor:
     """Decode-batch qkv_proj + neox rotary embedding + KV-pool store (one GEMM + combine pair): returns the
-    rotated q [M, Hq*D]; the rotated k rows and the v rows land in k_cache / v_cache at cache_loc."""
+    rotated q [M, Hq*D]; the rotated k rows and the v rows land in k_cache / v_cache at cache_loc, in the pool's
+    format (kv_fp8 / hnd as in store_kv_cache)."""
     _dev(x, w_qkv, positions, cos_sin_cache, k_cache, v_cache, cache_loc)
     M, K, x_rs, x_cs = _x_layout(x, "wstream_qkv_rope")
     N = (num_q_heads + 2 * num_kv_heads) * head_dim
@@ -737,9 +739,17 @@ def wstream_qkv_rope(x: torch.Tensor, w_qkv: torch.Tensor, bias: Optional[torch.
           "wstream_qkv_rope: int64 positions / cache_loc of length M")
     _need(cos_sin_cache.dtype in (_BF16, torch.float32) and cos_sin_cache.is_contiguous() and cos_sin_cache.shape[-1] == head_dim,
           "wstream_qkv_rope: cos_sin_cache [max_pos, head_dim]")
-    kc, vc = k_cache.view(k_cache.shape[0], -1), v_cache.view(v_cache.shape[0], -1)
-    _need(kc.dtype == _BF16 and vc.dtype == _BF16 and kc.stride(0) == vc.stride(0) and kc.shape[1] == num_kv_heads * head_dim,
-          "wstream_qkv_rope: bf16 KV pool rows of Hkv*D")
+    row = num_kv_heads * head_dim
+    if kv_fp8 or hnd:
+        _need(k_cache.dtype == (torch.uint8 if kv_fp8 else _BF16) and v_cache.dtype == k_cache.dtype and k_cache.is_contiguous()
+              and v_cache.is_contiguous() and k_cache.numel() % row == 0 and v_cache.numel() == k_cache.numel(),
+              "wstream_qkv_rope: contiguous fp8 (uint8) / HND pool of Hkv*D rows")
+        kc, vc, cache_rs = k_cache, v_cache, row
+    else:
+        kc, vc = k_cache.view(k_cache.shape[0], -1), v_cache.view(v_cache.shape[0], -1)
+        _need(kc.dtype == _BF16 and vc.dtype == _BF16 and kc.stride(0) == vc.stride(0) and kc.shape[1] == row,
+              "wstream_qkv_rope: bf16 KV pool rows of Hkv*D")
+        cache_rs = kc.stride(0)
     if waves_per_group is None or splits is None:
         nw_auto, s_auto = choose_wstream_config(M, N, K, True)
     nw, s = waves_per_group or nw_auto, splits or s_auto
@@ -748,7 +758,8 @@ def wstream_qkv_rope(x: torch.Tensor, w_qkv: torch.Tensor, bias: Optional[torch.
     native.call("sgl_amd_wstream_qkv_rope", x.data_ptr(), w_qkv.data_ptr(), _ptr(bias), q_out.data_ptr(), M, K, num_q_heads,
                 num_kv_heads, head_dim, x_rs, x_cs, w_qkv.stride(0), q_out.stride(0), positions.data_ptr(),
                 cos_sin_cache.data_ptr(), 1 if cos_sin_cache.dtype == torch.float32 else 0, cos_sin_cache.shape[-1],
-                kc.data_ptr(), vc.data_ptr(), cache_loc.data_ptr(), kc.stride(0), nw, tiles_per_wave or 1, s, ws.data_ptr(), _stream())
+                kc.data_ptr(), vc.data_ptr(), cache_loc.data_ptr(), cache_rs, 1 if kv_fp8 else 0, float(k_scale), float(v_scale),
+                int(page_size), 1 if hnd else 0, nw, tiles_per_wave or 1, s, ws.data_ptr(), _stream())
     return q_out
 
 

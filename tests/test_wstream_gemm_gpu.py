@@ -181,6 +181,39 @@ def test_wstream_qkv_rope_store_equals_unfused_ops(device, M, Hq, Hkv, D, K, bia
     assert float(kc.cpu()[untouched].abs().max()) == 0.0 and float(vc.cpu()[untouched].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("M", [1, 23, 64])
+@pytest.mark.parametrize("fp8,hnd,page", [(True, False, 1), (False, True, 16), (True, True, 8), (True, False, 4)])
+@pytest.mark.parametrize("Hq,Hkv,D,K", [(32, 8, 128, 4096), (4, 2, 64, 256)])
+def test_wstream_qkv_rope_store_in_the_pool_format(device, M, fp8, hnd, page, Hq, Hkv, D, K):
+    """fp8 / HND pools: the fused combine writes the very bytes store_kv_cache(format) writes for the unfused
+    rope output (set_kv_buffer, memory_pool.py:2364-2374 / 2061-2117), and nothing else in the pool."""
+    K_ = _k()
+    g = torch.Generator().manual_seed(M * 11 + Hq + page)
+    N = (Hq + 2 * Hkv) * D
+    x = torch.randn((M, K), generator=g).to(BF).to(device)
+    w = (torch.randn((N, K), generator=g) * 0.03).to(BF).to(device)
+    max_pos = 512
+    cache = oo.cos_sin_cache(oo.rope_inv_freq(D, 10000.0), max_pos).to(BF)
+    positions = torch.randint(0, max_pos, (M,), generator=g)
+    slots = 256
+    loc = (torch.randperm(slots - page, generator=g)[:M] + page).to(device)
+    shape = (slots // page, Hkv, page, D) if hnd else (slots, Hkv, D)
+    dt = torch.uint8 if fp8 else BF
+    fmt = dict(kv_fp8=fp8, k_scale=0.75 if fp8 else 1.0, v_scale=1.5 if fp8 else 1.0, page_size=page, hnd=hnd)
+    splits = 2 if K >= 512 else 1
+    qkv = K_.wstream_gemm(x, w, splits=splits).cpu()
+    q_ref, k_ref, v_ref = qkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1)
+    q_ref, k_ref = oo.rotary_embedding(positions, q_ref.clone(), k_ref.clone(), D, cache, True)
+    kc_ref, vc_ref = torch.zeros(shape, dtype=dt, device=device), torch.zeros(shape, dtype=dt, device=device)
+    K_.store_kv_cache(k_ref.reshape(M, -1).contiguous().to(device), v_ref.contiguous().to(device), kc_ref, vc_ref, loc,
+                      num_kv_heads=Hkv, head_dim=D, **fmt)
+    kc, vc = torch.zeros(shape, dtype=dt, device=device), torch.zeros(shape, dtype=dt, device=device)
+    q = K_.wstream_qkv_rope(x, w, None, positions.to(device), cache.to(device), Hq, Hkv, D, kc, vc, loc, splits=splits, **fmt)
+    assert torch.equal(q.cpu(), q_ref.reshape(M, -1))
+    assert torch.equal(kc.cpu(), kc_ref.cpu()) and torch.equal(vc.cpu(), vc_ref.cpu())
+    assert int((kc_ref.cpu().view(torch.uint8) != 0).sum()) > 0
+
+
 def _blocked(x):
     """[M, K] -> chunk-major [K/128, M, 128]."""
     M, K = x.shape
