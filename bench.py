@@ -301,7 +301,7 @@ def worker(args):
     kv_write = B * kv_row
     step_bytes = w_act + kv_unique + kv_write
     step_traffic = None
-    if pmc and pmc.get("model") == cfg.name and pmc.get("batch") == B and world == 1:
+    if pmc and pmc.get("model") == cfg.name and pmc.get("batch") == B and world == 1 and not kv_fp8:
         step_traffic = pmc.get("phases", {}).get("decode", {}).get("hbm_bytes_per_step")
     step_roofline = dict(bound="hbm", achieved=step_bytes / t_decode_step / 1e9, peak=HBM_PEAK_GBPS, unit="GB/s",
                          frac=step_bytes / t_decode_step / 1e9 / HBM_PEAK_GBPS, traffic=step_traffic,
