@@ -281,11 +281,7 @@ int sgl_amd_wstream_gemm(const void* x, const void* w, const void* bias, void* y
  * (q rows, k rows, v rows); cos_sin_cache [max_pos, D] = cos | sin halves, bf16 or fp32; ws_partials holds
  * sgl_amd_wstream_gemm_workspace_floats(M, (Hq+2Hkv)*D, num_k_splits) floats (always needed).  The pool may be any
  * format of sgl_amd_store_kv_cache_ex (kv_fp8: e4m3 of the bf16 row / scale; kv_layout_hnd: [pages, Hkv, page, D]);
- * cache_row_stride = elements of one token's [Hkv, D] row.
- * tickets: NULL for the GEMM + combine pair.  Otherwise ceil((Hq+2Hkv)*D/16 / waves_per_group) uint32 counters that
- * are ZERO on entry (the kernel leaves them zero; one buffer per stream): ONE launch -- the last of the num_k_splits
- * workgroups of a column block to hand in its partials sums them in split order and finishes that block's heads
- * itself (same bits as the pair).  Needs M <= 64, tiles_per_wave 1 and waves_per_group * 16 a multiple of D. */
+ * cache_row_stride = elements of one token's [Hkv, D] row. */
 int sgl_amd_wstream_qkv_rope(const void* x, const void* w_qkv, const void* bias, void* q_out, int64_t M,
                              int64_t K, int num_q_heads, int num_kv_heads, int head_dim,
                              int64_t x_row_stride, int64_t x_chunk_stride, int64_t w_row_stride, int64_t q_row_stride,
@@ -293,7 +289,7 @@ int sgl_amd_wstream_qkv_rope(const void* x, const void* w_qkv, const void* bias,
                              int64_t rotary_dim, void* k_cache, void* v_cache, const int64_t* cache_loc,
                              int64_t cache_row_stride, int kv_fp8, float k_scale, float v_scale,
                              int page_size, int kv_layout_hnd, int waves_per_group, int tiles_per_wave,
-                             int num_k_splits, void* ws_partials, void* tickets, void* stream);
+                             int num_k_splits, void* ws_partials, void* stream);
 /* Grouped (mixture-of-experts) form of the weight-streaming GEMM, same contract as sgl_amd_moe_grouped_gemm
  * (fused_moe_triton_kernels.py:324,771) for shapes with N % 16 == 0 and K % 128 == 0, without split-K: one
  * workgroup per (row block of moe_align_block_size, group of weight tiles of that block's expert).  fuse_silu=1:

@@ -56,29 +56,14 @@ __device__ __forceinline__ int64_t blocked_off(int64_t m, int n, int64_t stride,
 
 // Sum of the split partials in split order (deterministic).  The loads of four consecutive splits are issued
 // together (clamped to the last split, so they need no predicate); only the adds are predicated.
-// AGENT: the partials were written by other workgroups of the SAME launch (ticketed finish) -- device-scope loads
-// (global_load sc1: served from the memory side, never from a stale line of this XCD's L2)
-template <bool AGENT>
-__device__ __forceinline__ f32x4_t ld_part(const float* p) {
-  if constexpr (AGENT) {
-    f32x4_t v;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = __hip_atomic_load(p + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return v;
-  } else {
-    return *reinterpret_cast<const f32x4_t*>(p);
-  }
-}
-
-template <bool AGENT = false>
 __device__ __forceinline__ f32x4_t sum_splits(const float* p0, int64_t split_stride, int splits) {
-  f32x4_t s = ld_part<AGENT>(p0);
+  f32x4_t s = *reinterpret_cast<const f32x4_t*>(p0);
   for (int sp = 1; sp < splits; sp += 4) {
     f32x4_t v[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int q = sp + j < splits ? sp + j : splits - 1;
-      v[j] = ld_part<AGENT>(p0 + q * split_stride);
+      v[j] = *reinterpret_cast<const f32x4_t*>(p0 + q * split_stride);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -130,7 +115,6 @@ __device__ __forceinline__ void put_kv4(unsigned char* row, int elem, const floa
 }
 
 // one 4-wide neox pair item of a q / k head: columns h * D + i .. + 4 and their partners half a head on
-template <bool AGENT = false>
 __device__ __forceinline__ void rope_pair_item(const RopeParams& p, int m, int h, int i) {
   const int D = p.head_dim, half = D >> 1;
   const int64_t ss = static_cast<int64_t>(p.M) * p.N;
@@ -138,8 +122,8 @@ __device__ __forceinline__ void rope_pair_item(const RopeParams& p, int m, int h
   const int64_t pos = p.positions[m];
   const int64_t slot = p.cache_loc[m];
   const int n1 = h * D + i, n2 = n1 + half;
-  f32x4_t a = sum_splits<AGENT>(row + n1, ss, p.splits);
-  f32x4_t b = sum_splits<AGENT>(row + n2, ss, p.splits);
+  f32x4_t a = sum_splits(row + n1, ss, p.splits);
+  f32x4_t b = sum_splits(row + n2, ss, p.splits);
   float c[4], sn[4];
   if (p.cache_f32) {
     const float* cs = static_cast<const float*>(p.cos_sin) + pos * D;
@@ -175,13 +159,12 @@ __device__ __forceinline__ void rope_pair_item(const RopeParams& p, int m, int h
 }
 
 // one 4-wide item of the v row: element e .. e + 4 of the token's [Hkv * D] values
-template <bool AGENT = false>
 __device__ __forceinline__ void rope_v_item(const RopeParams& p, int m, int e) {
   const int D = p.head_dim;
   const int64_t ss = static_cast<int64_t>(p.M) * p.N;
   const int v0 = (p.num_q_heads + p.num_kv_heads) * D;
   const int64_t slot = p.cache_loc[m];
-  f32x4_t a = sum_splits<AGENT>(p.part + static_cast<int64_t>(m) * p.N + v0 + e, ss, p.splits);
+  f32x4_t a = sum_splits(p.part + static_cast<int64_t>(m) * p.N + v0 + e, ss, p.splits);
   if (p.bias) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) a[r] += bf2f(p.bias[v0 + e + r]);
@@ -219,10 +202,6 @@ struct WsParams {
   int out_f32;                  // y is fp32 (the down projection ahead of moe_sum_reduce)
   int round_before_scale;       // round the accumulator to bf16 before the router weight (fused_moe_native.py:157-163)
   int pair_silu;                // two-tile waves: y[:, 16 t ..] = silu(tile t) * tile (t + ntiles/2) instead of two outputs
-  // ticketed qkv finish (ROPE instances): the last of the `splits` workgroups of a column block to hand in its partials
-  // runs the rope / KV-store epilogue of that block's heads itself -- no second launch
-  uint32_t* tickets;            // [gridDim.x], zero between launches (the finisher re-arms its counter)
-  RopeParams rope;
 };
 
 // ---- LDS-DMA plumbing ------------------------------------------------------------------------
@@ -278,7 +257,7 @@ constexpr int ring_depth(int mt, int nw, int tpw) {
 // TPW = 16-row weight tiles per wave.  TPW == 2: the wave owns tiles t and t + ntiles/2 (half the activation reads
 // per weight byte); with pair_silu they are a gate tile and its up tile and the wave writes
 // y[m, 16 t ..] = silu(gate) * up (no partials, no second launch).
-template <int MT, int NW, int TPW, bool GROUPED, bool ROPE = false>
+template <int MT, int NW, int TPW, bool GROUPED>
 __global__ __launch_bounds__(64 * NW, 1) void wstream_gemm_kernel(WsParams p) {
   constexpr int PD = ring_depth(MT, NW, TPW);
   constexpr int XPIECES = MT * 4;                       // 1 KiB pieces (4 rows x 256 B) of an activation chunk
@@ -477,55 +456,6 @@ __global__ __launch_bounds__(64 * NW, 1) void wstream_gemm_kernel(WsParams p) {
 #ifdef WS_TRACE
   struct StampAtExit { __device__ ~StampAtExit() { __builtin_amdgcn_s_waitcnt(0); WS_STAMP(3); } } stamp_at_exit;
 #endif
-  if constexpr (ROPE) {
-    // ---- ticketed finish: partials out, then whoever completes the column block's set of K ranges reads all of
-    // them back (summed in split order, like the combine kernel) and applies rope + the KV store.  The partials
-    // travel as device-scope stores / loads (sc1: written through to, and read from, the memory side -- the L2 of
-    // another XCD never holds the only copy), so the hand-off needs no L2 write-back or invalidate: stores
-    // acknowledged (vmcnt 0), barrier, one relaxed device-scope ticket. ----
-    if (active && p.part) {
-      float* base = p.part + static_cast<int64_t>(split) * p.M * p.N + tile * 16 + g * 4;
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const int m = mt * 16 + r16;
-        if (m < p.M) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            __hip_atomic_store(base + static_cast<int64_t>(m) * p.N + r, acc[0][mt][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
-    }
-    __shared__ int s_last;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) s_last = atomicAdd(p.tickets + blockIdx.x, 1u) == static_cast<uint32_t>(p.splits - 1);
-    __syncthreads();
-    if (!s_last) return;
-    const RopeParams& r = p.rope;
-    const int D = r.head_dim, per_head = D >> 3;
-    const int rows = r.M;
-    const int heads_blk = NW * 16 / D;                   // whole heads per column block (host-checked)
-    const int h0 = blockIdx.x * heads_blk;
-    const int qk_heads = r.num_q_heads + r.num_kv_heads;
-    for (int hh = 0; hh < heads_blk; ++hh) {
-      const int h = h0 + hh;
-      if (h >= qk_heads + r.num_kv_heads) break;
-      if (h < qk_heads) {
-        for (int it = tid; it < rows * per_head; it += 64 * NW) {
-          const int m = it / per_head;
-          rope_pair_item<true>(r, m, h, (it - m * per_head) * 4);
-        }
-      } else {
-        const int vper = D >> 2;
-        for (int it = tid; it < rows * vper; it += 64 * NW) {
-          const int m = it / vper;
-          rope_v_item<true>(r, m, (h - qk_heads) * D + (it - m * vper) * 4);
-        }
-      }
-    }
-    if (tid == 0) p.tickets[blockIdx.x] = 0;             // re-armed for the next launch (kernel boundary orders it)
-    return;
-  }
   if (!active) return;
   // lane holds C[m = 16 mt + r16][n = 16 tile + 4 g + r]
   const int n0 = tile * 16 + g * 4;
@@ -694,7 +624,7 @@ __global__ __launch_bounds__(kNormThreads) void wstream_combine_norm_kernel(Comb
   }
 }
 
-// QKV combine as its own launch (the two-kernel form; the ticketed form finishes inside the GEMM): grid (token, item block)
+// grid (token, item block)
 __global__ __launch_bounds__(256) void wstream_combine_rope_kernel(RopeParams p) {
   const int m = blockIdx.x;
   const int per_head = p.head_dim >> 3;                 // 4-wide pair items per head
@@ -736,20 +666,6 @@ int launch_main(const WsParams& p, hipStream_t st, int row_blocks = 0) {
     } else {
       hipLaunchKernelGGL((wstream_gemm_kernel<MT, NW, TPW, false>), grid, dim3(64 * NW), 0, st, p);
     }
-    return 0;
-  } else {
-    return -1;
-  }
-}
-
-// ticketed qkv form: column blocks of whole heads (4 or 8 waves), at most 64 rows
-template <int MT>
-int launch_rope(const WsParams& p, int nw, hipStream_t st) {
-  if constexpr (MT <= 4) {
-    dim3 grid((p.ntiles + nw - 1) / nw, p.splits);
-    if (nw == 4) hipLaunchKernelGGL((wstream_gemm_kernel<MT, 4, 1, false, true>), grid, dim3(256), 0, st, p);
-    else if (nw == 8) hipLaunchKernelGGL((wstream_gemm_kernel<MT, 8, 1, false, true>), grid, dim3(512), 0, st, p);
-    else return -1;
     return 0;
   } else {
     return -1;
@@ -808,8 +724,7 @@ int64_t sgl_amd_wstream_gemm_workspace_floats(int64_t M, int64_t N, int num_k_sp
 static int wstream_launch_main(const char* who, const void* x, const void* w, const void* bias, void* y, int64_t M, int64_t N,
                                int64_t K, int64_t x_row_stride, int64_t x_chunk_stride, int64_t w_row_stride,
                                int64_t y_row_stride, int64_t y_chunk_stride, bool fused_silu, int tiles_per_wave,
-                               bool to_partials, int waves_per_group, int num_k_splits, void* ws_partials, hipStream_t st,
-                               const RopeParams* rope = nullptr, void* tickets = nullptr) {
+                               bool to_partials, int waves_per_group, int num_k_splits, void* ws_partials, hipStream_t st) {
   SGL_CHECK_ARG(M >= 1 && M <= 128, "%s: M=%lld rows (supported: 1..128)", who, (long long)M);
   SGL_CHECK_ARG(N > 0 && N % 16 == 0 && K >= kKC && K % kKC == 0,
                 "%s: need N %% 16 == 0 and K %% %d == 0 (got N=%lld K=%lld)", who, kKC, (long long)N, (long long)K);
@@ -837,23 +752,6 @@ static int wstream_launch_main(const char* who, const void* x, const void* w, co
   p.splits = num_k_splits; p.ntiles = static_cast<int>(N / 16);
   p.pair_silu = fused_silu ? 1 : 0;
   int rc;
-  if (rope) {
-    p.rope = *rope;
-    p.tickets = static_cast<uint32_t*>(tickets);
-    if (const char* e = getenv("SGL_AMD_TICKET_PROBE")) {     // TEMP probe: 1 = no epilogue work, 2 = also no partial stores
-      p.rope.M = 0;
-      if (e[0] == '2') p.part = nullptr;
-    }
-    switch (static_cast<int>((M + 15) / 16)) {
-      case 1: rc = launch_rope<1>(p, waves_per_group, st); break;
-      case 2: rc = launch_rope<2>(p, waves_per_group, st); break;
-      case 3: rc = launch_rope<3>(p, waves_per_group, st); break;
-      case 4: rc = launch_rope<4>(p, waves_per_group, st); break;
-      default: rc = -1; break;
-    }
-    SGL_CHECK_ARG(rc == 0, "%s: the ticketed form takes at most 64 rows and 4 or 8 waves per group", who);
-    return 0;
-  }
   switch (static_cast<int>((M + 15) / 16)) {
     case 1: rc = launch_nw<1>(p, waves_per_group, two_tiles, st); break;
     case 2: rc = launch_nw<2>(p, waves_per_group, two_tiles, st); break;
@@ -956,7 +854,7 @@ int sgl_amd_wstream_qkv_rope(const void* x, const void* w_qkv, const void* bias,
                              int64_t rotary_dim, void* k_cache, void* v_cache, const int64_t* cache_loc,
                              int64_t cache_row_stride, int kv_fp8, float k_scale, float v_scale, int page_size,
                              int kv_layout_hnd, int waves_per_group, int tiles_per_wave, int num_k_splits,
-                             void* ws_partials, void* tickets, void* stream) {
+                             void* ws_partials, void* stream) {
   SGL_CLEAR_STALE_ERROR();
   if (M == 0) return 0;
   SGL_CHECK_ARG(num_q_heads > 0 && num_kv_heads > 0 && head_dim % 16 == 0 && rotary_dim == head_dim,
@@ -977,14 +875,6 @@ int sgl_amd_wstream_qkv_rope(const void* x, const void* w_qkv, const void* bias,
   SGL_CHECK_ARG(make_kv_format(&r.fmt, cache_row_stride, num_kv_heads, head_dim, page_size, kv_layout_hnd, kv_fp8),
                 "wstream_qkv_rope: HND pools need a power-of-two page_size (got %d); row / page strides below 4 GiB", page_size);
   r.inv_k_scale = kv_fp8 ? 1.0f / k_scale : 1.0f; r.inv_v_scale = kv_fp8 ? 1.0f / v_scale : 1.0f;
-  if (tickets) {
-    // one launch: the workgroup that completes a column block's K ranges finishes its heads (see the ROPE instances)
-    SGL_CHECK_ARG(M <= 64 && tiles_per_wave == 1 && (waves_per_group == 4 || waves_per_group == 8) &&
-                      (waves_per_group * 16) % head_dim == 0,
-                  "wstream_qkv_rope: the ticketed form needs M <= 64, one tile per wave and 4 or 8 waves covering whole heads");
-    return wstream_launch_main("wstream_qkv_rope", x, w_qkv, nullptr, nullptr, M, N, K, x_row_stride, x_chunk_stride, w_row_stride,
-                               4, 0, false, 1, true, waves_per_group, num_k_splits, ws_partials, st, &r, tickets);
-  }
   if (int rc = wstream_launch_main("wstream_qkv_rope", x, w_qkv, nullptr, nullptr, M, N, K, x_row_stride, x_chunk_stride, w_row_stride,
                                    4, 0, false, tiles_per_wave, true, waves_per_group, num_k_splits, ws_partials, st))
     return rc;

@@ -7,7 +7,6 @@ launch.  No function here computes anything on the host or falls back to torch.
 from __future__ import annotations
 
 import functools
-import os
 from typing import Optional, Tuple
 
 import torch
@@ -722,35 +721,12 @@ def wstream_gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] 
     return out
 
 
-# SGLANG_AMD_QKV_TICKETED=1: qkv + rope + KV store as ONE launch (ticketed finish inside the GEMM) instead of GEMM + combine
-_QKV_TICKETED = os.environ.get("SGLANG_AMD_QKV_TICKETED", "0") == "1"
-_ROPE_TICKETS = {}
-
-
-def _rope_tickets(device, n: int) -> torch.Tensor:
-    """Zeroed uint32 counters of the ticketed qkv launch; the kernel leaves them zero, launches on one stream share them."""
-    t = _ROPE_TICKETS.get(device)
-    if t is None or t.numel() < n:
-        t = _ROPE_TICKETS[device] = torch.zeros(max(n, 1024), dtype=torch.int32, device=device)
-    return t
-
-
-def choose_ticketed_qkv_config(N: int, K: int, head_dim: int) -> Tuple[int, int]:
-    """(waves_per_group, k_splits) of the ticketed qkv launch: groups of whole heads, as many K ranges as keep the grid
-    inside one round of the 256 CUs."""
-    nw = 8 if (8 * 16) % head_dim == 0 else 4
-    groups = -(-(N // 16) // nw)
-    s = max(1, min(_NUM_CUS // groups, K // 128 // 2))
-    return nw, s
-
-
 def wstream_qkv_rope(x: torch.Tensor, w_qkv: torch.Tensor, bias: Optional[torch.Tensor], positions: torch.Tensor,
                      cos_sin_cache: torch.Tensor, num_q_heads: int, num_kv_heads: int, head_dim: int,
                      k_cache: torch.Tensor, v_cache: torch.Tensor, cache_loc: torch.Tensor,
                      waves_per_group: Optional[int] = None, splits: Optional[int] = None,
                      tiles_per_wave: Optional[int] = None, kv_fp8: bool = False, k_scale: float = 1.0,
-                     v_scale: float = 1.0, page_size: int = 1, hnd: bool = False,
-                     ticketed: Optional[bool] = None) -> torch.Tensor:
+                     v_scale: float = 1.0, page_size: int = 1, hnd: bool = False) -> torch.Tensor:
     """Decode-batch qkv_proj + neox rotary embedding + KV-pool store (one GEMM + combine pair): returns the
     rotated q [M, Hq*D]; the rotated k rows and the v rows land in k_cache / v_cache at cache_loc, in the pool's
     format (kv_fp8 / hnd as in store_kv_cache)."""
@@ -774,18 +750,7 @@ def wstream_qkv_rope(x: torch.Tensor, w_qkv: torch.Tensor, bias: Optional[torch.
         _need(kc.dtype == _BF16 and vc.dtype == _BF16 and kc.stride(0) == vc.stride(0) and kc.shape[1] == row,
               "wstream_qkv_rope: bf16 KV pool rows of Hkv*D")
         cache_rs = kc.stride(0)
-    if ticketed is None:
-        ticketed = _QKV_TICKETED and waves_per_group is None and splits is None and tiles_per_wave in (None, 1)
-    tickets = 0
-    if ticketed:
-        # one launch: column blocks of whole heads, the last workgroup of a block finishes its heads (sglang_amd.h)
-        _need(M <= 64 and tiles_per_wave in (None, 1), "wstream_qkv_rope: the ticketed form takes at most 64 rows, one tile per wave")
-        if waves_per_group is None or splits is None:
-            nw_auto, s_auto = choose_ticketed_qkv_config(N, K, head_dim)
-        nw_t = waves_per_group or nw_auto
-        _need(nw_t in (4, 8) and (nw_t * 16) % head_dim == 0, "wstream_qkv_rope: ticketed groups are 4 or 8 waves covering whole heads")
-        tickets = _rope_tickets(x.device, -(-(N // 16) // nw_t)).data_ptr()
-    elif waves_per_group is None or splits is None:
+    if waves_per_group is None or splits is None:
         nw_auto, s_auto = choose_wstream_config(M, N, K, True)
     nw, s = waves_per_group or nw_auto, splits or s_auto
     q_out = torch.empty((M, num_q_heads * head_dim), dtype=_BF16, device=x.device)
@@ -794,7 +759,7 @@ def wstream_qkv_rope(x: torch.Tensor, w_qkv: torch.Tensor, bias: Optional[torch.
                 num_kv_heads, head_dim, x_rs, x_cs, w_qkv.stride(0), q_out.stride(0), positions.data_ptr(),
                 cos_sin_cache.data_ptr(), 1 if cos_sin_cache.dtype == torch.float32 else 0, cos_sin_cache.shape[-1],
                 kc.data_ptr(), vc.data_ptr(), cache_loc.data_ptr(), cache_rs, 1 if kv_fp8 else 0, float(k_scale), float(v_scale),
-                int(page_size), 1 if hnd else 0, nw, tiles_per_wave or 1, s, ws.data_ptr(), tickets, _stream())
+                int(page_size), 1 if hnd else 0, nw, tiles_per_wave or 1, s, ws.data_ptr(), _stream())
     return q_out
 
 

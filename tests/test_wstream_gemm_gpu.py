@@ -214,37 +214,6 @@ def test_wstream_qkv_rope_store_in_the_pool_format(device, M, fp8, hnd, page, Hq
     assert int((kc_ref.cpu().view(torch.uint8) != 0).sum()) > 0
 
 
-@pytest.mark.parametrize("M", [1, 23, 64])
-@pytest.mark.parametrize("Hq,Hkv,D,K,nw,splits", [(32, 8, 128, 4096, 8, 4), (32, 8, 128, 4096, 8, 5), (14, 2, 64, 896, 4, 3),
-                                                   (14, 2, 64, 896, 8, 1), (8, 1, 128, 1024, 8, 2)])
-@pytest.mark.parametrize("fp8", [False, True])
-def test_wstream_qkv_rope_ticketed_launch_writes_the_same_bits(device, M, Hq, Hkv, D, K, nw, splits, fp8):
-    """One launch (the last workgroup of a column block finishes its heads) == GEMM + combine with the same
-    decomposition: same partials, summed in the same order.  Run three times on one ticket buffer: the counters
-    re-arm themselves."""
-    K_ = _k()
-    g = torch.Generator().manual_seed(M * 13 + Hq + splits)
-    N = (Hq + 2 * Hkv) * D
-    x = torch.randn((M, K), generator=g).to(BF).to(device)
-    w = (torch.randn((N, K), generator=g) * 0.03).to(BF).to(device)
-    b = torch.randn(N, generator=g).to(BF).to(device) if D == 64 else None
-    cache = oo.cos_sin_cache(oo.rope_inv_freq(D, 10000.0), 512).to(BF).to(device)
-    positions = torch.randint(0, 512, (M,), generator=g).to(device)
-    slots = 200
-    loc = (torch.randperm(slots - 1, generator=g)[:M] + 1).to(device)
-    dt = torch.uint8 if fp8 else BF
-    fmt = dict(kv_fp8=fp8, k_scale=0.75 if fp8 else 1.0, v_scale=1.5 if fp8 else 1.0)
-    kc_ref, vc_ref = torch.zeros((slots, Hkv, D), dtype=dt, device=device), torch.zeros((slots, Hkv, D), dtype=dt, device=device)
-    q_ref = K_.wstream_qkv_rope(x, w, b, positions, cache, Hq, Hkv, D, kc_ref, vc_ref, loc, waves_per_group=nw, splits=splits,
-                                ticketed=False, **fmt)
-    for _ in range(3):
-        kc, vc = torch.zeros_like(kc_ref), torch.zeros_like(vc_ref)
-        q = K_.wstream_qkv_rope(x, w, b, positions, cache, Hq, Hkv, D, kc, vc, loc, waves_per_group=nw, splits=splits,
-                                ticketed=True, **fmt)
-        assert torch.equal(q, q_ref) and torch.equal(kc, kc_ref) and torch.equal(vc, vc_ref)
-    assert int(K_._rope_tickets(x.device, 1).abs().sum()) == 0
-
-
 def _blocked(x):
     """[M, K] -> chunk-major [K/128, M, 128]."""
     M, K = x.shape
