@@ -411,9 +411,17 @@ def kernel_rooflines(args, cfg, runner, result, B, G, P, in_len, ctx, t_decode_s
     mlps = [layer.mlp for layer in runner.model.layers if hasattr(layer.mlp, "gate_up_proj")]
     Mg = min(B, 64)               # the weight-streaming design point (larger per-rank batches: DESIGN.md)
     if mlps and K.wstream_preferred(Mg, *mlps[0].gate_up_proj.weight.shape):
-        xg = torch.randn((Mg, cfg.hidden_size), device=dev).to(torch.bfloat16)
         wN, wK = mlps[0].gate_up_proj.weight.shape
-        t_g = graph_time(lambda: [K.wstream_gemm(xg, m.gate_up_proj.weight.data, epilogue="silu_and_mul") for m in mlps], len(mlps))
+        # the call the timed decode step makes: the fused TP=1 layer hands activations between its GEMMs chunk-major
+        # ([K/128, M, 128], LlamaMLP.forward_fused_norm); the operator-surface path passes plain [M, K] rows
+        blocked = world == 1 and not args.operator_surface and cfg.hidden_size % 128 == 0 and wN % 256 == 0
+        if blocked:
+            xg = K.blocked_activation(Mg, cfg.hidden_size, dev)
+            xg.copy_(torch.randn(xg.shape, device=dev).to(torch.bfloat16))
+        else:
+            xg = torch.randn((Mg, cfg.hidden_size), device=dev).to(torch.bfloat16)
+        t_g = graph_time(lambda: [K.wstream_gemm(xg, m.gate_up_proj.weight.data, epilogue="silu_and_mul", out_blocked=blocked)
+                                  for m in mlps], len(mlps))
         alg = wN * wK * 2 + Mg * wK * 2 + Mg * (wN // 2) * 2      # weights once + activations in + out
         nw_s = K.choose_wstream_config(Mg, wN, wK, True, True)
         rec = pmc_kernel(pmc, "decode", "wstream_gemm_kernel<4, 4, 2") if (Mg, wN, wK) == (64, 28672, 4096) else None
@@ -423,7 +431,10 @@ def kernel_rooflines(args, cfg, runner, result, B, G, P, in_len, ctx, t_decode_s
                                                 "request) + WRITE_SIZE, KiB per dispatch",
                               "kernel": "wstream_gemm_kernel<4,4,2> (gate_up_proj + silu_and_mul)",
                               "us_per_launch": t_g * 1e6, "bytes_per_launch": alg,
-                              "shape": {"M": Mg, "N": wN, "K": wK, "waves_per_group": nw_s[0], "k_splits": nw_s[1]},
+                              "shape": {"M": Mg, "N": wN, "K": wK, "waves_per_group": nw_s[0], "k_splits": nw_s[1],
+                                        "activations": "chunk-major [K/128, M, 128]" if blocked else "row-major [M, K]"},
+                              "rocprof_note": "the --stats row of this instance averages the layers' gate_up launches with the "
+                                              "step's one lm_head launch (same template instance, 4.4 x the bytes)",
                               "share_of_decode_step": len(mlps) * t_g / t_decode_step}
 
     # (1b) mixture-of-experts models: the dominant kernels are the two grouped expert GEMMs of fused_experts at the
