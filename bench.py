@@ -387,16 +387,18 @@ def kernel_rooflines(args, cfg, runner, result, B, G, P, in_len, ctx, t_decode_s
 
     D = cfg.head_dim
 
-    def graph_time(fn, launches, reps=5):
+    def graph_time(fn, launches, reps=10, warm=10):
         """Average duration of one launch: `fn` (which enqueues `launches` kernels) captured into a
-        hipGraph, replayed `reps` times between two HIP events on the current stream."""
+        hipGraph, replayed `reps` times between two HIP events on the current stream.  `warm` untimed replays run
+        first, back to back with the timed ones: the first replays after host-side work measure 8-10 % slower
+        (benchmarks/r02_exp19_model_weights.py: 45.5 us, then 41.8 us for the same launches)."""
         fn()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             fn()
-        g.replay()
-        torch.cuda.synchronize()
+        for _ in range(warm):
+            g.replay()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
