@@ -65,7 +65,6 @@ struct SkinnyParams {
   int splits;
   int out_f32;
   int round_before_scale;       // grouped: round the accumulator to bf16 before the router weight
-  int dbg;
 };
 
 // Columns per workgroup: each of the 4 waves owns NTW 16-column tiles (FUSE: one gate + one up tile).
@@ -221,7 +220,6 @@ __global__ __launch_bounds__(kThreads, (MT * NTW <= 4) ? 4 : 3) void skinny_gemm
   const int k_last8 = p.K - 8;
 
   auto load_w = [&](int c, U4 (&dst)[NTW][kKSteps]) {
-    if (p.dbg & 2) return;
     const int k0 = c * kKC;
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt)
@@ -233,7 +231,6 @@ __global__ __launch_bounds__(kThreads, (MT * NTW <= 4) ? 4 : 3) void skinny_gemm
       }
   };
   auto load_x = [&](int c) {
-    if (p.dbg & 1) return;
     int k = c * kKC + my_slot_k;
     const bool in_k = k <= k_last8;
     if (!in_k) k = k_last8;
@@ -245,7 +242,6 @@ __global__ __launch_bounds__(kThreads, (MT * NTW <= 4) ? 4 : 3) void skinny_gemm
     }
   };
   auto store_x = [&](int stage) {
-    if (p.dbg & 1) return;
 #pragma unroll
     for (int j = 0; j < XL; ++j) xs[stage][xdst[j]] = xr[j];
   };
@@ -404,7 +400,6 @@ int sgl_amd_skinny_gemm(const void* x, const void* w, const void* bias, void* y,
   p.x_stride = x_row_stride; p.w_stride = w_row_stride; p.w_expert_stride = 0; p.y_stride = y_row_stride;
   p.M = static_cast<int>(M); p.N = static_cast<int>(N); p.K = static_cast<int>(K);
   p.topk_div = 1; p.splits = num_k_splits; p.out_f32 = 0; p.round_before_scale = 0;
-  { const char* d = getenv("SGL_AMD_SKINNY_DEBUG"); p.dbg = d ? atoi(d) : 0; }
   dispatch<false>(p, static_cast<int>((M + 15) / 16), 1, fuse_silu, tiles_per_wave, as_stream(stream));
   SGL_CHECK_LAUNCH("skinny_gemm");
   return 0;
@@ -436,7 +431,6 @@ int sgl_amd_moe_grouped_gemm(const void* a, const void* w, void* c, const int32_
   p.x_stride = a_row_stride; p.w_stride = w_row_stride; p.w_expert_stride = w_expert_stride; p.y_stride = c_row_stride;
   p.M = static_cast<int>(num_valid_ids); p.N = static_cast<int>(N); p.K = static_cast<int>(K);
   p.topk_div = top_k_div; p.splits = num_k_splits; p.out_f32 = out_f32; p.round_before_scale = round_before_scale;
-  p.dbg = 0;
   dispatch<true>(p, block_m / 16, static_cast<int>(max_m_blocks), fuse_silu, tiles_per_wave, as_stream(stream));
   SGL_CHECK_LAUNCH("moe_grouped_gemm");
   return 0;
