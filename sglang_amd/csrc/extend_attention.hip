@@ -434,26 +434,28 @@ __device__ __forceinline__ float row_groups_max(float x) {
   return fmaxf(a, b);
 }
 
-template <int D>
+template <int D, bool QREG = false>
 struct SmemDbuf {
   static constexpr int kVSub = 64 * 32 + 32;                   // bytes of one 16-dim V sub-image + bank skew
   U4 k[2][kKvTile * D / 8];                                    // [token][chunk ^ swz]
   U4 v[2][(D / 16) * kVSub / 16];
-  U4 q[8 * 2 * (D / 32) * 64];                                 // [wave][M-tile][k-step][lane]: every lane's own Q^T fragments
+  U4 q[QREG ? 1 : 8 * 2 * (D / 32) * 64];                      // [wave][M-tile][k-step][lane]: every lane's own Q^T fragments
 };
 
 typedef short v4s16_t __attribute__((ext_vector_type(4)));
 
-template <int D>
+// QREG (SGL_AMD_EXTEND_QREG=1, not the default, NOT YET RUN ON HARDWARE): the Q^T fragments stay in 32 registers instead
+// of the lane-private LDS image -- the kernel has one workgroup per CU and 36 registers to spare.
+template <int D, bool QREG = false>
 __global__ __launch_bounds__(512, 2) void extend_attention_dbuf_kernel(ExtendParams p) {
-  __shared__ SmemDbuf<D> sm;
+  __shared__ SmemDbuf<D, QREG> sm;
   constexpr int MTW = 2;
   constexpr int CPR = D / 8;            // 16-byte chunks per KV row
   constexpr int KC = D / 32;            // MFMA k-steps over the head dim
   constexpr int ND = D / 16;            // 16-wide output tiles over the head dim
   constexpr int ROWS_PER_PASS = 512 / CPR;
   constexpr int LOADS = kKvTile / ROWS_PER_PASS;     // 16-byte loads per thread per operand per tile (2 at D = 128)
-  constexpr int VSUB16 = SmemDbuf<D>::kVSub / 16;    // sub-image stride in 16-byte units
+  constexpr int VSUB16 = SmemDbuf<D, QREG>::kVSub / 16;    // sub-image stride in 16-byte units
 
   // 1-D grid -> (query tile, kv head, request).  Two things ride on the order: (1) under a causal mask the last query
   // tile of a request walks the most KV tiles, so ALL pairs' heaviest tiles are handed out first and the light ones
@@ -504,7 +506,8 @@ __global__ __launch_bounds__(512, 2) void extend_attention_dbuf_kernel(ExtendPar
   int row_off[MTW];       // element offset of the row's head inside a q / out token
   // the Q^T fragments live in LDS, lane-private ([wave][mt][kc][lane], linear = conflict-free): 32 VGPRs the output
   // accumulators need more (two waves per SIMD: 256 registers each)
-  U4* qimg = sm.q + wid * (MTW * KC * 64) + lane;
+  U4* qimg = sm.q + (QREG ? 0 : wid * (MTW * KC * 64) + lane);
+  U4 qreg[MTW][KC];
 #pragma unroll
   for (int mt = 0; mt < MTW; ++mt) {
     const int r = wid * (16 * MTW) + mt * 16 + l15;
@@ -522,7 +525,8 @@ __global__ __launch_bounds__(512, 2) void extend_attention_dbuf_kernel(ExtendPar
         const int64_t qrow = q_begin + row_tok[mt];
         qf = ld16(p.q + qrow * p.q_stride + row_off[mt] + kc * 32 + g * 8);
       }
-      qimg[(mt * KC + kc) * 64] = qf;
+      if constexpr (QREG) qreg[mt][kc] = qf;
+      else qimg[(mt * KC + kc) * 64] = qf;
     }
   }
 
@@ -630,9 +634,9 @@ __global__ __launch_bounds__(512, 2) void extend_attention_dbuf_kernel(ExtendPar
         for (int kk = 0; kk < 2; ++kk) {
           typedef __attribute__((address_space(3))) v4s16_t* lds_v4_t;
           const v4s16_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (lds_v4_t)(vbase + n * SmemDbuf<D>::kVSub + kk * 1024));
+              (lds_v4_t)(vbase + n * SmemDbuf<D, QREG>::kVSub + kk * 1024));
           const v4s16_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (lds_v4_t)(vbase + n * SmemDbuf<D>::kVSub + kk * 1024 + 512));
+              (lds_v4_t)(vbase + n * SmemDbuf<D, QREG>::kVSub + kk * 1024 + 512));
           U4 vf;
           vf.x = __builtin_bit_cast(uint2, lo).x; vf.y = __builtin_bit_cast(uint2, lo).y;
           vf.z = __builtin_bit_cast(uint2, hi).x; vf.w = __builtin_bit_cast(uint2, hi).y;
@@ -658,9 +662,12 @@ __global__ __launch_bounds__(512, 2) void extend_attention_dbuf_kernel(ExtendPar
         for (int kc = 0; kc < KC; ++kc) {
           const U4 kf = kimg[row * CPR + ((kc * 4 + g) ^ ((row * CPR / 16) & (CPR - 1)))];
 #pragma unroll
-          for (int mt = 0; mt < MTW; ++mt)
-            st_acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                as_frag(kf), as_frag(qimg[(mt * KC + kc) * 64]), st_acc[mt][nt], 0, 0, 0);
+          for (int mt = 0; mt < MTW; ++mt) {
+            U4 qf;
+            if constexpr (QREG) qf = qreg[mt][kc];
+            else qf = qimg[(mt * KC + kc) * 64];
+            st_acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(kf), as_frag(qf), st_acc[mt][nt], 0, 0, 0);
+          }
         }
       }
     }
@@ -930,8 +937,12 @@ int sgl_amd_extend_attention_ex(const void* q, void* out, const void* k_cache, c
   if (dbuf) {
     p.num_tiles = tiles; p.batch = static_cast<int>(batch);
     const dim3 grid1(static_cast<unsigned>(tiles) * num_kv_heads * static_cast<unsigned>(batch));
-    if (head_dim == 128) hipLaunchKernelGGL((extend_attention_dbuf_kernel<128>), grid1, dim3(512), 0, st, p);
-    else hipLaunchKernelGGL((extend_attention_dbuf_kernel<64>), grid1, dim3(512), 0, st, p);
+    const char* qr = getenv("SGL_AMD_EXTEND_QREG");            // experiment switch, see the kernel's header comment
+    if (qr && atoi(qr) != 0) {
+      if (head_dim == 128) hipLaunchKernelGGL((extend_attention_dbuf_kernel<128, true>), grid1, dim3(512), 0, st, p);
+      else hipLaunchKernelGGL((extend_attention_dbuf_kernel<64, true>), grid1, dim3(512), 0, st, p);
+    } else if (head_dim == 128) hipLaunchKernelGGL((extend_attention_dbuf_kernel<128, false>), grid1, dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((extend_attention_dbuf_kernel<64, false>), grid1, dim3(512), 0, st, p);
     SGL_CHECK_LAUNCH("extend_attention");
     return 0;
   }

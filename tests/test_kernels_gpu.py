@@ -2,6 +2,7 @@
 and the committed golden fixtures.  Run with `pytest -m gpu` on an MI355X."""
 import json
 import math
+import os
 
 import numpy as np
 import pytest
@@ -350,6 +351,29 @@ def test_extend_attention_every_workgroup_shape(device, monkeypatch, shape, Hq, 
                               causal=causal, compute_dtype=torch.float32)
     o = _run_extend(c, device, causal=causal)
     torch.testing.assert_close(o.float(), ref.float(), atol=4e-3, rtol=1e-2)
+
+
+@pytest.mark.skipif(os.environ.get("SGLANG_AMD_RUN_EXPERIMENTS", "0") != "1",
+                    reason="prepared kernel variant that has not run on hardware yet (DESIGN.md section 7): opt in with "
+                           "SGLANG_AMD_RUN_EXPERIMENTS=1")
+@pytest.mark.parametrize("Hq,Hkv,D,causal", [(32, 8, 128, True), (8, 1, 128, True), (14, 2, 64, True), (16, 4, 128, False)])
+def test_extend_attention_q_in_registers_variant(device, monkeypatch, Hq, Hkv, D, causal):
+    """SGL_AMD_EXTEND_QREG=1: the double-buffered kernel with its Q^T fragments in registers instead of the lane-private
+    LDS image -- same case as the forced 8-wave shape above, and the very bits of the default form (same operands into
+    the same MFMAs in the same order)."""
+    monkeypatch.setenv("SGL_AMD_EXTEND_SHAPE", "82")
+    prefix = [0, 896, 5, 0, 63, 64, 200, 1000] if causal else [0, 0, 0, 0]
+    extend = [130, 128, 1, 333, 65, 64, 7, 70] if causal else [50, 64, 129, 300]
+    c = _random_case(len(prefix), Hq, Hkv, D, prefix, extend, seed=Hq + D + 82, spike=True)
+    c["q"][-3] = (c["k_cache"][c["req_to_token"][c["req_pool_indices"][-1], 3].long(), 0] * 30).to(BF)
+    ref = oo.extend_attention(c["q"], c["k_cache"], c["v_cache"], c["req_to_token"], c["req_pool_indices"],
+                              c["seq_lens"], c["extend_prefix_lens"], c["extend_seq_lens"], c["scaling"],
+                              causal=causal, compute_dtype=torch.float32)
+    o_default = _run_extend(c, device, causal=causal)
+    monkeypatch.setenv("SGL_AMD_EXTEND_QREG", "1")
+    o = _run_extend(c, device, causal=causal)
+    torch.testing.assert_close(o.float(), ref.float(), atol=4e-3, rtol=1e-2)
+    assert torch.equal(o, o_default)
 
 
 def test_decode_equals_extend_of_one_token(device):
