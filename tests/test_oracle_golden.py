@@ -165,3 +165,61 @@ def test_bruteforce_prefix_cache_matches_reference_trace(golden_dir):
                 assert model.insert(op["ids"], op["vals"]) == op["prefix_len"]
             elif op["op"] == "match":
                 assert model.match(op["ids"]) == op["indices"]
+
+
+# --------------------------------------------------------------------------------------------------------------
+# Logit soft cap, custom (verify) mask and sliding window pinned against the REFERENCE'S OWN Triton kernels
+# (tests/golden/attention_triton.pt: outputs of extend_attention_fwd / decode_attention_fwd run under triton-rocm on an
+# MI355X by tests/golden/gen_triton_golden.py).  The Triton kernels round P to bf16 before the PV product and write
+# bf16, the oracle evaluates in fp32 and rounds once: the two agree to one bf16 ulp of the output.
+def _triton_cases(golden_dir):
+    cases = torch.load(golden_dir / "attention_triton.pt")
+    return {k: v for k, v in cases.items() if not k.startswith("_")}
+
+
+def _close_1ulp(got, ref, what, max_abs=2.0 ** -7, rms=8e-4):
+    e = (got.float() - ref.float()).abs()
+    assert float(e.max()) <= max_abs * max(1.0, float(ref.float().abs().max())), (what, float(e.max()))
+    assert float(e.pow(2).mean().sqrt()) <= rms, (what, float(e.pow(2).mean().sqrt()))
+
+
+def test_oracle_extend_cap_window_match_reference_triton(golden_dir):
+    for name, d in _triton_cases(golden_dir).items():
+        kw = dict(k_cache=d["k_cache"], v_cache=d["v_cache"], req_to_token=d["req_to_token"], req_pool_indices=d["req_pool_indices"],
+                  seq_lens=d["seq_lens"], extend_prefix_lens=d["extend_prefix_lens"], extend_seq_lens=d["extend_seq_lens"],
+                  scaling=d["scaling"], compute_dtype=torch.float32)
+        cap, win = d["logit_cap"], d["sliding_window"]
+        for tag, opt in dict(causal={}, cap=dict(logit_cap=cap), window=dict(sliding_window=win),
+                             cap_window=dict(logit_cap=cap, sliding_window=win)).items():
+            _close_1ulp(oo.extend_attention(d["q"], **kw, **opt), d["out_extend_" + tag], f"{name} extend {tag}")
+        # the cap must matter on these inputs, or the case would pin nothing
+        assert float((d["out_extend_cap"].float() - d["out_extend_causal"].float()).abs().max()) > 0.05
+
+
+def test_oracle_verify_mask_matches_reference_triton(golden_dir):
+    for name, d in _triton_cases(golden_dir).items():
+        v = d["verify"]
+        kw = dict(k_cache=v["k_cache"], v_cache=v["v_cache"], req_to_token=v["req_to_token"], req_pool_indices=v["req_pool_indices"],
+                  seq_lens=v["seq_lens"], extend_prefix_lens=v["extend_prefix_lens"], extend_seq_lens=v["extend_seq_lens"],
+                  scaling=d["scaling"], compute_dtype=torch.float32)
+        for tag in ("verify", "verify_prefix_masked"):
+            for cap in (0.0, d["logit_cap"]):
+                o = oo.extend_attention(v["q"], custom_mask=d[tag + "_mask"], mask_indptr=d[tag + "_mask_indptr"].tolist(), logit_cap=cap, **kw)
+                _close_1ulp(o, d["out_" + tag + ("_cap" if cap else "")], f"{name} {tag} cap={cap}")
+        # a tree mask is not the causal mask: the fixture must tell them apart
+        o_causal = oo.extend_attention(v["q"], **kw)
+        assert float((o_causal.float() - d["out_verify"].float()).abs().max()) > 0.05
+
+
+def test_oracle_decode_cap_matches_reference_triton(golden_dir):
+    for name, d in _triton_cases(golden_dir).items():
+        kw = dict(k_cache=d["k_cache"], v_cache=d["v_cache"], req_to_token=d["req_to_token"], req_pool_indices=d["req_pool_indices"],
+                  seq_lens=d["seq_lens"], scaling=d["scaling"], compute_dtype=torch.float32)
+        # the reference's MHA decode kernel (kv_group_num == 1, decode_attention.py:362 `tl.sum(q[None, :] * k, 1)`)
+        # multiplies and sums the scores in bf16: at |score| ~ 40 that is a score error of ~0.1 -- its own outputs sit
+        # 6e-2 from an fp32 evaluation; the grouped kernel (tl.dot, fp32) pins the cap to one output ulp
+        loose = d["q_decode"].shape[1] == d["k_cache"].shape[1]
+        bars = dict(max_abs=0.08, rms=1e-2) if loose else {}
+        _close_1ulp(oo.decode_attention(d["q_decode"], **kw), d["out_decode"], f"{name} decode", **bars)
+        _close_1ulp(oo.decode_attention(d["q_decode"], logit_cap=d["logit_cap"], **kw), d["out_decode_cap"], f"{name} decode cap", **bars)
+        assert float((d["out_decode_cap"].float() - d["out_decode"].float()).abs().max()) > 0.05
