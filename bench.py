@@ -366,6 +366,20 @@ def worker(args):
             rep["north_star_tolerance"] = 1e-3
             result["parity"] = rep
             del trace, steps_l
+            # per layer / per stage from the oracle's own inputs (tests/test_layer_parity_gpu.py asserts the same figures)
+            if cfg.num_local_experts == 0:
+                import dataclasses
+
+                from oracle.layer_parity import _Patch, run_layer_parity, summarize
+
+                patch = _Patch()
+                try:
+                    lcfg = dataclasses.replace(cfg, num_hidden_layers=min(3, cfg.num_hidden_layers), name=cfg.name + "-3layers")
+                    lens = [33 + (7 * b) % 61 for b in range(64)]
+                    rep["per_layer"] = summarize(*run_layer_parity(lcfg, dev, lens, patch, operator_surface=args.operator_surface))
+                    rep["per_layer"]["workload"] = "the model's first three layers, B=64, prompts of 33..93 tokens: prefill + one decode step"
+                finally:
+                    patch.undo()
         except Exception as e:
             result["parity"] = {"error": f"{type(e).__name__}: {e}"}
 

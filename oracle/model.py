@@ -59,6 +59,17 @@ class OracleLM:
                               logit_cap=float(getattr(cfg, "logit_cap", 0.0) or 0.0))
         self.req_to_token = torch.zeros((max_reqs + 1, max_ctx), dtype=torch.int32, device=dev)
         self.next_slot = 1
+        # tests/test_layer_parity_gpu.py: set to [] to record, per forward() call, every layer's inputs and outputs
+        # (the tensors a product layer is then fed with: identical-input, per-layer comparison)
+        self.trace: Optional[list] = None
+        # a trace recorded by ANOTHER OracleLM run of the same job: when set, every layer of call k starts from that
+        # run's layer inputs (h_in, res_in) instead of its own -- per-layer comparison of two evaluations of the graph
+        self.inject: Optional[list] = None
+        self._calls = 0
+        # {layer: int tensor [requests, max_len, top_k]}: expert ids to use instead of the oracle's own top-k choice for
+        # the token of request b (req_pool index b + 1) at position t -- a whole-depth MoE comparison with the routing
+        # of the run under test, so that near-tie flips of the discrete choice do not decorrelate the two runs
+        self.forced_topk_ids: Optional[Dict[int, torch.Tensor]] = None
 
     # ---- one forward over a ragged batch --------------------------------------------------
     def forward(self, input_ids: torch.Tensor, positions: torch.Tensor, req_pool: torch.Tensor, seq_lens: torch.Tensor,
@@ -68,16 +79,32 @@ class OracleLM:
         D, Hq, Hkv = cfg.head_dim, self.Hq, self.Hkv
         h = input_embeds if input_embeds is not None else F.embedding(input_ids, w["embed_tokens"])
         residual = None
+        rec = None
+        if self.trace is not None:
+            rec = dict(decode=decode, positions=positions, out_loc=out_loc, layers=[])
+            self.trace.append(rec)
+        inj = self.inject[self._calls]["layers"] if self.inject is not None else None
+        self._calls += 1
         for i in range(cfg.num_hidden_layers):
             p = f"layers.{i}."
+            if inj is not None:
+                h, residual = inj[i]["h_in"], inj[i]["res_in"]
+            lr = None
+            if rec is not None:
+                lr = dict(h_in=h, res_in=residual)
+                rec["layers"].append(lr)
             if residual is None:
                 residual = h
                 h = ops.rmsnorm(h, w[p + "input_layernorm.weight"], cfg.rms_norm_eps)
             else:
                 h, residual = ops.fused_add_rmsnorm(h, residual, w[p + "input_layernorm.weight"], cfg.rms_norm_eps)
+            if lr is not None:
+                lr.update(normed=h, residual=residual)
             qkv = F.linear(h, w[p + "self_attn.qkv_proj.weight"], w.get(p + "self_attn.qkv_proj.bias"))
             q, k, v = qkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1)
             q, k = ops.rotary_embedding(positions, q, k, D, self.rope_cache, True)
+            if lr is not None:
+                lr.update(qkv=qkv, q_rot=q, k_rot=k, v=v)
             if self.kv_fp8:
                 ops.store_kv(ops.quantize_kv_fp8(k.reshape(-1, Hkv, D)), ops.quantize_kv_fp8(v.reshape(-1, Hkv, D)),
                              self.k_cache[i], self.v_cache[i], out_loc)
@@ -91,15 +118,32 @@ class OracleLM:
                 o = ops.extend_attention(q3, self.k_cache[i], self.v_cache[i], self.req_to_token, req_pool, seq_lens,
                                          prefix_lens, extend_lens, D ** -0.5, True, self.compute_dtype, **self.attn_opts)
             h = self._all_reduce(F.linear(o.reshape(-1, Hq * D), w[p + "self_attn.o_proj.weight"]))
+            if lr is not None:
+                lr.update(o_proj=h)
             h, residual = ops.fused_add_rmsnorm(h, residual, w[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps)
+            if lr is not None:
+                lr.update(post_normed=h)
             if cfg.num_local_experts > 0:
                 logits = F.linear(h, w[p + "mlp.gate.weight"])
                 tw, ti = ops.fused_topk(logits, cfg.num_experts_per_tok, True)
+                if self.forced_topk_ids is not None:
+                    rows = req_pool if decode else torch.repeat_interleave(req_pool, extend_lens)
+                    ti = self.forced_topk_ids[i][rows - 1, positions].to(ti.dtype)
+                    tw = ops.topk_weights_for_ids(logits, ti, True)
+                if lr is not None:
+                    lr.update(topk_ids=ti, topk_weights=tw, router_logits=logits)
                 h = self._all_reduce(ops.moe_forward(h, w[p + "mlp.experts.w13_weight"], w[p + "mlp.experts.w2_weight"], tw, ti))
             else:
                 gu = F.linear(h, w[p + "mlp.gate_up_proj.weight"])
-                h = self._all_reduce(F.linear(ops.silu_and_mul(gu), w[p + "mlp.down_proj.weight"]))
-        h, _ = ops.fused_add_rmsnorm(h, residual, w["norm.weight"], cfg.rms_norm_eps)
+                act = ops.silu_and_mul(gu)
+                if lr is not None:
+                    lr.update(act=act)
+                h = self._all_reduce(F.linear(act, w[p + "mlp.down_proj.weight"]))
+            if lr is not None:
+                lr.update(attn_out=o, out=h, res_out=residual)
+        h, final_res = ops.fused_add_rmsnorm(h, residual, w["norm.weight"], cfg.rms_norm_eps)
+        if rec is not None:
+            rec.update(final_normed=h, final_residual=final_res)
         if not decode:
             last = torch.cumsum(extend_lens, 0) - 1
             h = h[last]
@@ -110,6 +154,8 @@ class OracleLM:
             parts = [torch.empty_like(logits) for _ in range(self.tp_size)]
             dist.all_gather(parts, logits.contiguous(), group=self.tp_group)
             logits = torch.cat(parts, dim=-1)
+        if rec is not None:
+            rec["logits"] = logits
         return logits.float()
 
     def _all_reduce(self, x: torch.Tensor) -> torch.Tensor:

@@ -278,6 +278,14 @@ def fused_topk(gating_output: torch.Tensor, topk: int, renormalize: bool) -> Tup
     return w, ids.to(torch.int32)
 
 
+def topk_weights_for_ids(gating_output: torch.Tensor, ids: torch.Tensor, renormalize: bool) -> torch.Tensor:
+    """fused_topk's weights (topk.py:690-736) for a GIVEN expert choice: softmax scores gathered at `ids`, renormalised."""
+    w = gating_output.float().softmax(dim=-1).gather(1, ids.to(torch.int64))
+    if renormalize:
+        w = w / (w.sum(dim=-1, keepdim=True, dtype=torch.float32) + _RENORMALIZE_SUM_EPSILON)
+    return w
+
+
 def moe_forward(x: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, topk_weights: torch.Tensor,
                 topk_ids: torch.Tensor) -> torch.Tensor:
     """srt/layers/moe/fused_moe_native.py:61-164 (moe_forward_native, silu, no bias):

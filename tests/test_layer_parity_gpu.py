@@ -1,0 +1,105 @@
+"""Per-layer and per-stage, identical-input parity: the product's decoder layer against the fp32-accumulating oracle.
+
+The oracle (oracle/model.py = the reference's torch-native graph, attention evaluated in fp32) runs a prefill and a
+decode step over the benchmark's decode batch size (64 requests) and records every layer's inputs, intermediates and
+outputs.  The PRODUCT is then fed the ORACLE's bf16 tensors, so that nothing computed differently upstream can leak in:
+
+  * per STAGE -- every operator group of the layer starts from the oracle's input of that very stage:
+      qkv_proj (+ bias) -> rope -> KV-row store | attention over the oracle's KV rows | o_proj -> add + RMSNorm |
+      gate_up_proj -> SiLU-mul | down_proj (-> add + next RMSNorm) | router + experts (Mixtral, the oracle's expert ids)
+    Here one bf16 ulp is the bar: the only differences left are fp32 summation order (GEMMs) and P being rounded to
+    bf16 ahead of the PV product (attention, as in the reference's own Triton kernel and bf16 SDPA).
+  * per LAYER -- the whole layer from the oracle's (hidden, residual): one-ulp differences of the stages' outputs now
+    feed the next stage, and every GEMM turns 1-ulp input flips into ~1e-3 relative noise on its outputs, i.e. whole
+    ulps on a fraction of them.  That is a property of the bf16 graph, not of an implementation: the reference's OWN
+    two evaluations (literal bf16 SDPA vs fp32-accumulating attention, the two oracles of SURVEY 8(c)) fed the same
+    layer inputs differ by the same amount.  So the layer bar is relative to that reference-vs-reference figure
+    (<= 1.25 x its rms, <= 1.5 x its max), plus a signed-mean bound (|mean error| < 0.05 ulp) so that a systematic bias
+    cannot hide inside the noise band.
+
+Paths covered: prefill (`LlamaDecoderLayer.forward`: library GEMMs, rope + fused KV store, extend attention), the
+fused TP=1 decode layer (`forward_decode_fused`: weight-streaming GEMMs with rope / norm / SiLU epilogues + cascade
+attention), the operator-surface decode layer, final norm + lm_head -- at the shapes of BASELINE configs[1]
+(Llama-3-8B), configs[2] (one TP=8 rank of Llama-3-70B) and configs[3] (one TP=2 rank of Mixtral-8x7B).
+
+Unit: an error is counted in bf16 ulps of max(|ref|, rms of the row) -- the ulp of the value itself, with the ulp at
+the row's rms as the floor (elements that cancel towards zero keep the absolute noise of the sum they came from).
+Figures go to gpurun_out/layer_parity_<name>.json and into bench.py's `parity` block."""
+import dataclasses
+import json
+from pathlib import Path
+
+import pytest
+
+from oracle.layer_parity import run_layer_parity
+
+pytestmark = pytest.mark.gpu
+OUT = Path(__file__).resolve().parent.parent / "gpurun_out"
+
+
+def _write(name, report, stages, noise, extra):
+    OUT.mkdir(exist_ok=True)
+    (OUT / f"layer_parity_{name}.json").write_text(json.dumps(
+        {"name": name, **extra, "unit": "bf16 ulps of max(|ref|, row rms)", "stages_from_oracle_inputs": stages,
+         "whole_layer_from_oracle_inputs": report, "reference_vs_reference_literal_bf16_vs_fp32acc": noise}, indent=1))
+    w1 = min(stages.items(), key=lambda kv: kv[1]["frac_within_1ulp"])
+    mx = max(stages.items(), key=lambda kv: kv[1]["max_ulp"])
+    print(f"\n[layer parity {name}] stages: least within-1-ulp {w1[0]} {w1[1]['frac_within_1ulp']:.5f}, largest error {mx[0]} "
+          f"{mx[1]['max_ulp']:.2f} ulp; layers: rms " + ", ".join(f"{k.split('.', 1)[1]} {v['rms_ulp']:.3f}" for k, v in report.items() if k.startswith("layer0")))
+
+
+def _assert_bars(report, stages, noise, moe=False):
+    for k, st in stages.items():
+        # one stage from identical inputs: >= 99.9 % of the outputs within one ulp (measured: 99.99 % for attention,
+        # whose P is rounded to bf16 ahead of PV exactly like the reference's literal bf16 SDPA; >= 99.999 % for every
+        # GEMM / norm / rope / activation stage, most of them bit-identical), none beyond 3 (a silu(gate) * up whose
+        # gate flipped one rounding), no systematic sign
+        assert st["frac_within_1ulp"] >= 0.999, (k, st)
+        assert st["max_ulp"] <= 3.0, (k, st)
+        assert abs(st["mean_signed_ulp"]) < 0.01, (k, st)
+        if not k.endswith(".attention"):
+            assert st["frac_identical"] >= 0.985, (k, st)
+    for k, st in report.items():
+        assert abs(st["mean_signed_ulp"]) < 0.05, (k, st)
+        ref = noise[k]
+        assert st["rms_ulp"] <= 1.25 * ref["rms_ulp"] + 0.02, (k, st, ref)
+        assert st["max_ulp"] <= 1.5 * ref["max_ulp"] + 1.0, (k, st, ref)
+        assert st["frac_within_1ulp"] >= ref["frac_within_1ulp"] - 0.02, (k, st, ref)
+
+
+SHAPES = {
+    # BASELINE configs[1]: Llama-3-8B (three layers of it: the embedding's successor, mid-stream, last before the norm)
+    "llama3_8b": dict(base="llama-3-8b", layers=3),
+    # configs[2]: one TP=8 rank of Llama-3-70B: hidden 8192, 8 q / 1 kv heads, intermediate 3584, vocab shard 16032
+    "llama3_70b_tp8_rank": dict(cfg=("llama-3-70b-tp8-rank", 8192, 3584, 2, 8, 1, 128, 16032, 1e-5, 500000.0, None, 8192)),
+    # configs[3]: one TP=2 rank of Mixtral-8x7B: 16 q / 4 kv heads, 8 experts x (2 x 7168) x 4096, top-2
+    "mixtral_tp2_rank": dict(cfg=("mixtral-8x7b-tp2-rank", 4096, 7168, 2, 16, 4, 128, 32000, 1e-5, 1000000.0, None, 32768),
+                             moe=dict(num_local_experts=8, num_experts_per_tok=2)),
+}
+
+
+def _cfg(name):
+    from sglang_amd.harness.models import CONFIGS, ModelConfig
+
+    s = SHAPES[name]
+    if "base" in s:
+        return dataclasses.replace(CONFIGS[s["base"]], num_hidden_layers=s["layers"], name=f"{s['base']}-{s['layers']}layers")
+    return ModelConfig(*s["cfg"], **s.get("moe", {}))
+
+
+LENS = [33 + (7 * b) % 61 for b in range(64)]     # 64 requests (the benchmark's decode batch), ragged, 4.0k prefill tokens
+
+
+@pytest.mark.parametrize("name", list(SHAPES))
+def test_layer_identical_inputs(device, monkeypatch, name):
+    cfg = _cfg(name)
+    report, stages, noise = run_layer_parity(cfg, device, LENS, monkeypatch)
+    _write(name, report, stages, noise, {"workload": f"B=64, prompts of {min(LENS)}..{max(LENS)} tokens, {cfg.num_hidden_layers} layers"})
+    _assert_bars(report, stages, noise, moe=cfg.num_local_experts > 0)
+
+
+def test_layer_identical_inputs_operator_surface_decode(device, monkeypatch):
+    """The decode path the registration hooks reach without model-class patches (unfused operators)."""
+    report, stages, noise = run_layer_parity(_cfg("llama3_8b"), device, LENS, monkeypatch, operator_surface=True)
+    _write("llama3_8b_operator_surface", report, stages, noise, {"workload": "B=64, operator-surface decode"})
+    _assert_bars(report, stages, noise)
