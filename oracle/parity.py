@@ -99,10 +99,12 @@ class LogitStats:
 
 def teacher_forced_parity(cfg, model, prompts: Sequence[Sequence[int]], outs: Sequence[Sequence[int]],
                           step_logits: Sequence[torch.Tensor], *, device=None, flavours=("fp32acc", "literal"),
-                          max_ctx: Optional[int] = None, clear_margin_ulps: float = 16.0, batched_decode: bool = True
-                          ) -> Dict[str, Dict[str, float]]:
+                          max_ctx: Optional[int] = None, clear_margin_ulps: float = 16.0, batched_decode: bool = True,
+                          forced_topk_ids: Optional[Dict[int, torch.Tensor]] = None) -> Dict[str, Dict[str, float]]:
     """`step_logits[k]` = the product's [B, V] logits of output position k, rows in `prompts` order;
-    `outs[b]` = the product's tokens.  Returns {flavour: stats, "literal_vs_fp32acc": stats}."""
+    `outs[b]` = the product's tokens.  Returns {flavour: stats, "literal_vs_fp32acc": stats}.
+    `forced_topk_ids` ({layer: [B, max_len, top_k]}): mixture-of-experts models evaluated with the routing of the run
+    under test (OracleLM.forced_topk_ids), in both flavours."""
     device = device if device is not None else step_logits[0].device
     B, n_new = len(prompts), len(step_logits)
     total = sum(len(p) for p in prompts) + B * n_new + 64
@@ -113,6 +115,7 @@ def teacher_forced_parity(cfg, model, prompts: Sequence[Sequence[int]], outs: Se
     for fl in flavours:
         oracle = OracleLM(cfg, w, num_slots=total, max_ctx=ctx, max_reqs=B, device=device,
                           compute_dtype=torch.float32 if fl == "fp32acc" else None, batched_decode=batched_decode)
+        oracle.forced_topk_ids = forced_topk_ids
         st = LogitStats(clear_margin_ulps)
         # the second flavour is also compared with the first one: keep the first one's logits in bf16-exact form
         # (they are bf16 values widened to fp32, so the narrow copy loses nothing)
