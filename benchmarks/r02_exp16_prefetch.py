@@ -8,7 +8,7 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
-os.environ["SGLANG_AMD_LIB"] = str(ROOT / "scratch" / "variants" / "lib_ws_exp.so")
+os.environ["SGLANG_AMD_LIB"] = str(ROOT / "benchmarks" / "variants" / "lib_ws_exp.so")
 sys.path.insert(0, str(ROOT))
 import torch  # noqa: E402
 from sglang_amd import kernels as K, native  # noqa: E402

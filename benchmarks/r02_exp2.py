@@ -47,7 +47,7 @@ print("RESULT " + json.dumps(res))
 ''' % str(ROOT)
 out = {}
 for v in sys.argv[1:]:
-    env = dict(os.environ, SGLANG_AMD_LIB=str(ROOT / "scratch" / "variants" / f"lib_casc_{v}.so"))
+    env = dict(os.environ, SGLANG_AMD_LIB=str(ROOT / "benchmarks" / "variants" / f"lib_casc_{v}.so"))
     r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True)
     line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
     out[v] = json.loads(line[0][7:]) if line else {"error": r.stderr[-500:]}

@@ -7,7 +7,7 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
-os.environ["SGLANG_AMD_LIB"] = str(ROOT / "scratch" / "variants" / "lib_ext_trace.so")
+os.environ["SGLANG_AMD_LIB"] = str(ROOT / "benchmarks" / "variants" / "lib_ext_trace.so")
 sys.path.insert(0, str(ROOT))
 import torch  # noqa: E402
 from sglang_amd import kernels as K, native  # noqa: E402
@@ -60,4 +60,4 @@ for name, nreq, pre, e in (("cold", 4, 0, 1024), ("warm", 60, 896, 128)):
     out[name] = r
     print(name, json.dumps(r))
 (ROOT / "gpurun_out").mkdir(exist_ok=True)
-(ROOT / "gpurun_out" / "r02_exp9_ext_trace.json").write_text(json.dumps(out, indent=1))
+(ROOT / "gpurun_out" / "r03_exp9_ext_trace.json").write_text(json.dumps(out, indent=1))

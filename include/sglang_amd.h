@@ -405,6 +405,10 @@ int sgl_amd_extend_attention_ex(const void* q, void* out, const void* k_cache, c
                                 int causal, int kv_fp8, float k_scale, float v_scale, int page_size, int kv_layout_hnd,
                                 int sliding_window, float logit_cap, const void* custom_mask, const int64_t* mask_indptr,
                                 void* stream);
+/* Test / tuning override of the extend kernel's workgroup shape (process-wide; the library never reads the
+ * environment): shape 0 = automatic, 41 / 42 / 82 = waves x 16-row tiles per wave; flags bit 0 keeps bf16 8-wave
+ * launches on the single-image kernel.  Not part of the reference surface. */
+int sgl_amd_debug_extend_attention_shape(int shape, int flags);
 
 /* ---- row-tiled grouped GEMM for prefill-sized MoE batches (reference: fused_moe_triton_kernels.py:324,771 with
  *      BLOCK_SIZE_M >= 64; fused_experts, triton_utils/fused_moe.py:242-455) -------------------------------------

@@ -91,7 +91,14 @@ __global__ void rmsnorm_kernel(const uint16_t* __restrict__ x, uint16_t* __restr
 // (activation.py:141-143): s = bf16(silu(g)); out = bf16(s * u).
 // With ROUND_MID=false the product is formed in fp32 (the sgl_kernel form).
 // ---------------------------------------------------------------------------
-constexpr int kSiluVecPerThread = 4;   // 16-byte gate + up loads in flight per thread: 8
+constexpr int kSiluVecPerThread = 8;   // 16-byte gate + up loads in flight per thread: 16
+
+// The projection's output is read exactly once, here: non-temporal loads keep it from displacing what the next GEMM
+// wants in L2 (T = 4096: 67 -> 56 us, T = 7680: 127 -> 102 us = 6.3-6.5 TB/s; benchmarks/r03_exp2_elementwise.sh).
+__device__ __forceinline__ U4 ld16_once(const uint16_t* p) {
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  return __builtin_bit_cast(U4, __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p)));
+}
 
 template <bool ROUND_MID>
 __global__ __launch_bounds__(256) void silu_and_mul_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
@@ -102,15 +109,15 @@ __global__ __launch_bounds__(256) void silu_and_mul_kernel(const uint16_t* __res
   uint16_t* o = out + row * out_stride;
   const int nvec = d >> 3;
   // a workgroup owns kSiluVecPerThread consecutive 256-vector slabs of the row: all loads go out before the first
-  // exp, so a thread keeps 128 B of reads in flight instead of 32 (prefill rows: 352 MB per call, 79 -> 6x us)
+  // exp, so a thread keeps 256 B of reads in flight instead of 32
   const int v0 = blockIdx.x * (256 * kSiluVecPerThread) + threadIdx.x;
   U4 gv[kSiluVecPerThread], uv[kSiluVecPerThread];
 #pragma unroll
   for (int i = 0; i < kSiluVecPerThread; ++i) {
     const int v = v0 + i * 256;
     if (v < nvec) {
-      gv[i] = ld16(g + (static_cast<int64_t>(v) << 3));
-      uv[i] = ld16(u + (static_cast<int64_t>(v) << 3));
+      gv[i] = ld16_once(g + (static_cast<int64_t>(v) << 3));
+      uv[i] = ld16_once(u + (static_cast<int64_t>(v) << 3));
     }
   }
 #pragma unroll

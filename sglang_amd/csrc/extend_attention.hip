@@ -23,7 +23,6 @@
 //     running sum and the rescale factor never cross lanes, and the exp'd
 //     S^T registers ARE the P^T operand of the second MFMA (no LDS round trip);
 //   * fp32 accumulation, exp2 with the softmax scale folded in, bf16 output.
-#include <cstdlib>
 #include "common.hpp"
 #include "kv_format.hpp"
 #include "sglang_amd.h"
@@ -434,28 +433,28 @@ __device__ __forceinline__ float row_groups_max(float x) {
   return fmaxf(a, b);
 }
 
-template <int D, bool QREG = false>
+template <int D>
 struct SmemDbuf {
   static constexpr int kVSub = 64 * 32 + 32;                   // bytes of one 16-dim V sub-image + bank skew
   U4 k[2][kKvTile * D / 8];                                    // [token][chunk ^ swz]
   U4 v[2][(D / 16) * kVSub / 16];
-  U4 q[QREG ? 1 : 8 * 2 * (D / 32) * 64];                      // [wave][M-tile][k-step][lane]: every lane's own Q^T fragments
 };
 
 typedef short v4s16_t __attribute__((ext_vector_type(4)));
 
-// QREG (SGL_AMD_EXTEND_QREG=1, not the default, NOT YET RUN ON HARDWARE): the Q^T fragments stay in 32 registers instead
-// of the lane-private LDS image -- the kernel has one workgroup per CU and 36 registers to spare.
-template <int D, bool QREG = false>
+// The Q^T fragments stay in 32 registers per lane (round 2 kept them in a lane-private 64 KB LDS image: 5-8 % slower on
+// the bench's prefill shapes, profiles/r03_exp0_qreg.txt).  Token-major bf16 pools only (the layout the bench and the
+// reference's default pool use): paged head-major pools take the general kernel, so that no gathered row costs a branch.
+template <int D>
 __global__ __launch_bounds__(512, 2) void extend_attention_dbuf_kernel(ExtendParams p) {
-  __shared__ SmemDbuf<D, QREG> sm;
+  __shared__ SmemDbuf<D> sm;
   constexpr int MTW = 2;
   constexpr int CPR = D / 8;            // 16-byte chunks per KV row
   constexpr int KC = D / 32;            // MFMA k-steps over the head dim
   constexpr int ND = D / 16;            // 16-wide output tiles over the head dim
   constexpr int ROWS_PER_PASS = 512 / CPR;
   constexpr int LOADS = kKvTile / ROWS_PER_PASS;     // 16-byte loads per thread per operand per tile (2 at D = 128)
-  constexpr int VSUB16 = SmemDbuf<D, QREG>::kVSub / 16;    // sub-image stride in 16-byte units
+  constexpr int VSUB16 = SmemDbuf<D>::kVSub / 16;    // sub-image stride in 16-byte units
 
   // 1-D grid -> (query tile, kv head, request).  Two things ride on the order: (1) under a causal mask the last query
   // tile of a request walks the most KV tiles, so ALL pairs' heaviest tiles are handed out first and the light ones
@@ -504,10 +503,7 @@ __global__ __launch_bounds__(512, 2) void extend_attention_dbuf_kernel(ExtendPar
   int row_tok[MTW], row_limit[MTW];
   bool row_ok[MTW];
   int row_off[MTW];       // element offset of the row's head inside a q / out token
-  // the Q^T fragments live in LDS, lane-private ([wave][mt][kc][lane], linear = conflict-free): 32 VGPRs the output
-  // accumulators need more (two waves per SIMD: 256 registers each)
-  U4* qimg = sm.q + (QREG ? 0 : wid * (MTW * KC * 64) + lane);
-  U4 qreg[MTW][KC];
+  U4 qreg[MTW][KC];                                 // this lane's Q^T fragments
 #pragma unroll
   for (int mt = 0; mt < MTW; ++mt) {
     const int r = wid * (16 * MTW) + mt * 16 + l15;
@@ -525,8 +521,7 @@ __global__ __launch_bounds__(512, 2) void extend_attention_dbuf_kernel(ExtendPar
         const int64_t qrow = q_begin + row_tok[mt];
         qf = ld16(p.q + qrow * p.q_stride + row_off[mt] + kc * 32 + g * 8);
       }
-      if constexpr (QREG) qreg[mt][kc] = qf;
-      else qimg[(mt * KC + kc) * 64] = qf;
+      qreg[mt][kc] = qf;
     }
   }
 
@@ -553,23 +548,19 @@ __global__ __launch_bounds__(512, 2) void extend_attention_dbuf_kernel(ExtendPar
       dst[i] = idx_base[tok];
     }
   };
-  // token-major pools (the default): row = base + slot * row bytes, one v_mad_u64_u32 per gathered row; the paged
-  // head-major layout goes through the general formula
-  const bool nhd = p.fmt.page_mask == 0 && p.fmt.page_shift == 0;                  // workgroup-uniform
+  // token-major pool: row = base + slot * row bytes, one v_mad_u64_u32 per gathered row
   const unsigned char* k_rows = reinterpret_cast<const unsigned char*>(p.k_cache) + static_cast<uint64_t>(kvh) * p.fmt.head_stride + st_c * 16;
   const unsigned char* v_rows = reinterpret_cast<const unsigned char*>(p.v_cache) + static_cast<uint64_t>(kvh) * p.fmt.head_stride + st_c * 16;
   auto load_k = [&]() {
 #pragma unroll
     for (int i = 0; i < LOADS; ++i) {
-      if (nhd) kst[i] = ld16(k_rows + static_cast<uint64_t>(static_cast<uint32_t>(idx_k[i])) * p.fmt.page_stride);
-      else kst[i] = ld_kv8<false>(kv_row(p.k_cache, p.fmt, idx_k[i], kvh), st_c);
+      kst[i] = ld16(k_rows + static_cast<uint64_t>(static_cast<uint32_t>(idx_k[i])) * p.fmt.page_stride);
     }
   };
   auto load_v = [&]() {
 #pragma unroll
     for (int i = 0; i < LOADS; ++i) {
-      if (nhd) vst[i] = ld16(v_rows + static_cast<uint64_t>(static_cast<uint32_t>(idx_v[i])) * p.fmt.page_stride);
-      else vst[i] = ld_kv8<false>(kv_row(p.v_cache, p.fmt, idx_v[i], kvh), st_c);
+      vst[i] = ld16(v_rows + static_cast<uint64_t>(static_cast<uint32_t>(idx_v[i])) * p.fmt.page_stride);
     }
   };
   auto commit_k = [&](int buf) {
@@ -622,53 +613,69 @@ __global__ __launch_bounds__(512, 2) void extend_attention_dbuf_kernel(ExtendPar
   uint64_t tprev = __builtin_readcyclecounter();
   const uint64_t tstart = tprev;
 #endif
-  // matrix block of tile u: O^T += V^T P^T of tile u - 1, then S^T of tile u
+  // matrix block of tile u: O^T += V^T P^T of tile u - 1, then S^T of tile u.  The LDS fragment reads run ONE MFMA
+  // GROUP AHEAD of the products that use them (two register sets per operand): in program order hipcc waited for every
+  // group's own ds_reads with the matrix core drained (64 MFMAs took 1720 clocks instead of 1024).
+  auto read_v = [&](const unsigned char* vbase, int n, U4 (&dst)[2]) {
+    typedef __attribute__((address_space(3))) v4s16_t* lds_v4_t;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const v4s16_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(vbase + n * SmemDbuf<D>::kVSub + kk * 1024));
+      const v4s16_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(vbase + n * SmemDbuf<D>::kVSub + kk * 1024 + 512));
+      dst[kk].x = __builtin_bit_cast(uint2, lo).x; dst[kk].y = __builtin_bit_cast(uint2, lo).y;
+      dst[kk].z = __builtin_bit_cast(uint2, hi).x; dst[kk].w = __builtin_bit_cast(uint2, hi).y;
+    }
+  };
+  auto read_k = [&](const U4* kimg, int nt, U4 (&dst)[KC]) {
+    const int row = nt * 16 + l15;
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) dst[kc] = kimg[row * CPR + ((kc * 4 + g) ^ ((row * CPR / 16) & (CPR - 1)))];
+  };
   auto matrix_block = [&](int u) {
     EXT_T(5);
-    if (u - 1 >= t0 && u - 1 < n_tiles) {
+    const bool have_pv = u - 1 >= t0 && u - 1 < n_tiles, have_s = u < n_tiles;
+    const U4* kimg = sm.k[(u - t0) & 1];
+    U4 kf[2][KC];
+    if (have_s) {                                       // the first K fragments travel under the PV products
+      read_k(kimg, 0, kf[0]);
+      __builtin_amdgcn_sched_group_barrier(0x100, KC, 0);
+    }
+    if (have_pv) {
       // ---- O^T += V^T . P^T (tile u - 1) ----------------------------------
       const unsigned char* vbase = reinterpret_cast<const unsigned char*>(sm.v[(u - 1 - t0) & 1]) + v_lane;
+      U4 vf[2][2];
+      read_v(vbase, 0, vf[0]);
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
       for (int n = 0; n < ND; ++n) {
+        if (n + 1 < ND) read_v(vbase, n + 1, vf[(n + 1) & 1]);
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          typedef __attribute__((address_space(3))) v4s16_t* lds_v4_t;
-          const v4s16_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (lds_v4_t)(vbase + n * SmemDbuf<D, QREG>::kVSub + kk * 1024));
-          const v4s16_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (lds_v4_t)(vbase + n * SmemDbuf<D, QREG>::kVSub + kk * 1024 + 512));
-          U4 vf;
-          vf.x = __builtin_bit_cast(uint2, lo).x; vf.y = __builtin_bit_cast(uint2, lo).y;
-          vf.z = __builtin_bit_cast(uint2, hi).x; vf.w = __builtin_bit_cast(uint2, hi).y;
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
           for (int mt = 0; mt < MTW; ++mt)
-            ot[mt][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(vf), as_frag(pfrag[mt][kk]),
-                                                                 ot[mt][n], 0, 0, 0);
-        }
+            ot[mt][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(vf[n & 1][kk]), as_frag(pfrag[mt][kk]), ot[mt][n], 0, 0, 0);
+        // pin the order the source states: the NEXT group's four reads, then this group's four products
+        if (n + 1 < ND) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
       }
     }
     EXT_T(3);
-    if (u < n_tiles) {
+    if (have_s) {
       // ---- S^T = K . Q^T (tile u) -----------------------------------------
-      const U4* kimg = sm.k[(u - t0) & 1];
 #pragma unroll
       for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) st_acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
-        const int row = nt * 16 + l15;
+        if (nt + 1 < 4) read_k(kimg, nt + 1, kf[(nt + 1) & 1]);
 #pragma unroll
-        for (int kc = 0; kc < KC; ++kc) {
-          const U4 kf = kimg[row * CPR + ((kc * 4 + g) ^ ((row * CPR / 16) & (CPR - 1)))];
+        for (int kc = 0; kc < KC; ++kc)
 #pragma unroll
-          for (int mt = 0; mt < MTW; ++mt) {
-            U4 qf;
-            if constexpr (QREG) qf = qreg[mt][kc];
-            else qf = qimg[(mt * KC + kc) * 64];
-            st_acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(kf), as_frag(qf), st_acc[mt][nt], 0, 0, 0);
-          }
-        }
+          for (int mt = 0; mt < MTW; ++mt)
+            st_acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(kf[nt & 1][kc]), as_frag(qreg[mt][kc]), st_acc[mt][nt], 0, 0, 0);
+        if (nt + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, KC, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * KC, 0);
       }
     }
     EXT_T(1);
@@ -844,7 +851,21 @@ __global__ void mfma_probe_kernel(const uint16_t* __restrict__ a, const uint16_t
 
 }  // namespace
 
+// test / tuning overrides (process-wide, set through sgl_amd_debug_extend_attention_shape; never read from the environment)
+static int g_extend_debug_shape = 0;      // 0: automatic; 41 / 42 / 82: waves x M-tiles per wave
+static int g_extend_debug_flags = 0;      // bit 0: keep bf16 8-wave launches on the single-image kernel
+
 extern "C" {
+
+int sgl_amd_debug_extend_attention_shape(int shape, int flags) {
+  if (shape != 0 && shape != 41 && shape != 42 && shape != 82) {
+    set_last_error("debug_extend_attention_shape: shape must be 0 (automatic), 41, 42 or 82");
+    return -1;
+  }
+  g_extend_debug_shape = shape;
+  g_extend_debug_flags = flags;
+  return 0;
+}
 
 int sgl_amd_extend_attention(const void* q, void* out, const void* k_cache, const void* v_cache,
                              const int32_t* req_to_token, int64_t req_to_token_stride,
@@ -911,8 +932,7 @@ int sgl_amd_extend_attention_ex(const void* q, void* out, const void* k_cache, c
   int mtw = 2, nwv = 4;
   if (group <= 256 && wgs(256) >= 256) { mtw = 2; nwv = 8; }
   else if (group <= 64) { mtw = 1; nwv = 4; }
-  if (const char* f = getenv("SGL_AMD_EXTEND_SHAPE")) {       // tuning override: "41", "42", "82"
-    const int v = atoi(f);
+  if (const int v = g_extend_debug_shape) {                   // sgl_amd_debug_extend_attention_shape(): tests / tuning
     if (v == 41 && group <= 64) { nwv = 4; mtw = 1; }
     if (v == 42) { nwv = 4; mtw = 2; }
     if (v == 82) { nwv = 8; mtw = 2; }
@@ -931,18 +951,14 @@ int sgl_amd_extend_attention_ex(const void* q, void* out, const void* k_cache, c
   const int tiles = (max_extend_len + p.tokens_per_tile - 1) / p.tokens_per_tile;
   dim3 grid(tiles, num_kv_heads, batch);
   hipStream_t st = as_stream(stream);
-  // bf16 pools, 8-wave shape: the double-buffered kernel (SGL_AMD_EXTEND_DBUF=0 keeps the single-image one: A/B switch)
-  bool dbuf = !kv_fp8 && nwv == 8 && sliding_window < 0 && logit_cap == 0.f && custom_mask == nullptr;
-  if (const char* f = getenv("SGL_AMD_EXTEND_DBUF")) dbuf = dbuf && atoi(f) != 0;
+  // token-major bf16 pools, 8-wave shape: the double-buffered kernel
+  const bool dbuf = !kv_fp8 && !kv_layout_hnd && nwv == 8 && sliding_window < 0 && logit_cap == 0.f && custom_mask == nullptr &&
+                    (g_extend_debug_flags & 1) == 0;
   if (dbuf) {
     p.num_tiles = tiles; p.batch = static_cast<int>(batch);
     const dim3 grid1(static_cast<unsigned>(tiles) * num_kv_heads * static_cast<unsigned>(batch));
-    const char* qr = getenv("SGL_AMD_EXTEND_QREG");            // experiment switch, see the kernel's header comment
-    if (qr && atoi(qr) != 0) {
-      if (head_dim == 128) hipLaunchKernelGGL((extend_attention_dbuf_kernel<128, true>), grid1, dim3(512), 0, st, p);
-      else hipLaunchKernelGGL((extend_attention_dbuf_kernel<64, true>), grid1, dim3(512), 0, st, p);
-    } else if (head_dim == 128) hipLaunchKernelGGL((extend_attention_dbuf_kernel<128, false>), grid1, dim3(512), 0, st, p);
-    else hipLaunchKernelGGL((extend_attention_dbuf_kernel<64, false>), grid1, dim3(512), 0, st, p);
+    if (head_dim == 128) hipLaunchKernelGGL((extend_attention_dbuf_kernel<128>), grid1, dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((extend_attention_dbuf_kernel<64>), grid1, dim3(512), 0, st, p);
     SGL_CHECK_LAUNCH("extend_attention");
     return 0;
   }

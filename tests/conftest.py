@@ -27,3 +27,16 @@ def device():
     if not torch.cuda.is_available():
         pytest.skip("no HIP device")
     return torch.device("cuda:0")
+
+
+@pytest.fixture
+def extend_shape():
+    """Force the extend-attention workgroup shape for one test (sgl_amd_debug_extend_attention_shape: "82" = 8 waves x
+    2 M-tiles, "42" / "41" = the 4-wave forms, "auto"); the override is cleared afterwards."""
+    from sglang_amd import native
+
+    def force(shape, flags=0):
+        native.call("sgl_amd_debug_extend_attention_shape", 0 if shape in (None, "auto") else int(shape), int(flags))
+
+    yield force
+    native.call("sgl_amd_debug_extend_attention_shape", 0, 0)

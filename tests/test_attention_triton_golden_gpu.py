@@ -39,9 +39,8 @@ def _extend(device, c, q, scaling, **opt):
 
 
 @pytest.mark.parametrize("shape", ["auto", "82", "42", "41"])
-def test_extend_cap_window_vs_reference_triton(device, golden_dir, monkeypatch, shape):
-    if shape != "auto":
-        monkeypatch.setenv("SGL_AMD_EXTEND_SHAPE", shape)
+def test_extend_cap_window_vs_reference_triton(device, golden_dir, extend_shape, shape):
+    extend_shape(shape)
     for name, d in _cases(golden_dir).items():
         cap, win = d["logit_cap"], d["sliding_window"]
         for tag, opt in dict(causal={}, cap=dict(logit_cap=cap), window=dict(sliding_window=win),
