@@ -14,7 +14,10 @@
  *     unless a parameter says "host";
  *   - bf16 tensors are passed as void* / uint16 storage; strides are in ELEMENTS;
  *   - the caller owns every buffer, including workspaces -- the library never
- *     allocates device memory and keeps no mutable device state;
+ *     allocates device memory and keeps no mutable device state.  ONE exception:
+ *     the tensor-parallel communicator workspace comes from sgl_amd_xgmi_alloc()
+ *     (an uncached, hipIpc-exportable allocation no framework allocator hands
+ *     out) and goes back through sgl_amd_xgmi_free();
  *   - every function enqueues on `stream` (a hipStream_t passed as void*; NULL =
  *     the null stream), never synchronises, and is safe inside hipGraph capture;
  *   - return 0 on success, negative on error (-1 bad argument, -2 launch

@@ -76,7 +76,8 @@ struct Smem {
 };
 
 // MTW = 16-row M-tiles per wave: 2 shares every staged K/V tile between 128 rows (fewest gathers per flop) at
-// ~256 VGPRs = one workgroup per CU; 1 halves the rows per workgroup at ~130 VGPRs = three workgroups per CU,
+// ~256 VGPRs = one workgroup per CU; 1 halves the rows per workgroup at ~130 VGPRs = three workgroups per CU
+// (head dim 64; at 128 the 170-register budget of three workgroups spilled 16 registers inside the tile loop: two),
 // whose waves cover each other's barrier, softmax and gather stalls.
 // NWV = waves per workgroup: 8 (x 2 M-tiles = 256 rows) halves the K/V gathers per flop once more and puts two
 // waves on every SIMD (the whole register file: 512 threads x 256 VGPRs) -- the form for long prefixes, where the
@@ -84,7 +85,7 @@ struct Smem {
 // (The bf16 8-wave case has its own kernel below, extend_attention_dbuf_kernel; this one serves fp8 pools and the
 // 4-wave shapes.)
 template <int D, int MTW, int NWV, bool FP8>
-__global__ __launch_bounds__(64 * NWV, (MTW == 1 && NWV == 4) ? 3 : (NWV == 8 ? 2 : 1)) void extend_attention_kernel(ExtendParams p) {
+__global__ __launch_bounds__(64 * NWV, (MTW == 1 && NWV == 4) ? (D > 64 ? 2 : 3) : (NWV == 8 ? 2 : 1)) void extend_attention_kernel(ExtendParams p) {
   constexpr bool DEEP = false;
   __shared__ Smem<D> sm;
   const int block_x = blockIdx.x, block_z = blockIdx.z;

@@ -58,3 +58,14 @@ def test_extend_dbuf_kernels_keep_their_registers_and_lds(tmp_path):
         assert u["vgpr_spill_count"] == 0 and u["sgpr_spill_count"] == 0, (name, u)
         assert u["vgpr_count"] <= 256, (name, u)
         assert u["group_segment_fixed_size"] <= 80 * 1024, (name, u)
+
+
+@pytest.mark.skipif(not Path(HIPCC).exists(), reason="hipcc not installed")
+def test_general_extend_kernels_do_not_spill(tmp_path):
+    """Every instance of the general extend kernel (fp8 / paged pools, sliding window, soft cap, custom mask; the 4-wave
+    shapes of short extends): a spill would sit inside the KV-tile loop."""
+    usage = _resource_usage("extend_attention.hip", tmp_path)
+    gen = {k: v for k, v in usage.items() if "extend_attention_kernel" in k}
+    assert len(gen) == 12, sorted(usage)                        # head dim {64, 128} x {41, 42, 82} x {bf16, fp8}
+    for name, u in gen.items():
+        assert u["vgpr_spill_count"] == 0 and u["sgpr_spill_count"] == 0, (name, u)
