@@ -181,22 +181,6 @@ __device__ __forceinline__ void rope_v_item(const RopeParams& p, int m, int e) {
   *reinterpret_cast<uint2*>(p.v_cache + slot * p.cache_row_stride + e) = w;
 }
 
-// What the first `rows` workgroups of a PRO launch do before the weight stream needs its activations: finish the
-// PREVIOUS projection -- sum its split-K partials, add the residual, RMSNorm -- and write the rows into this launch's x.
-// Meanwhile every workgroup's first ring of weight chunks is already on its way from HBM: the dependent launch that
-// used to sit between the two GEMMs (4.9 us) is hidden behind the weight stream's own fill.
-struct Prologue {
-  const float* part;        // [splits, rows, N] fp32 partials of the previous projection (N = this GEMM's K)
-  const uint16_t* bias;     // optional [N]
-  uint16_t* residual;       // [rows, N], updated in place
-  const uint16_t* norm_w;   // [N]
-  int32_t* counters;        // [2] zero-initialised once; left at zero by every launch
-  int64_t res_stride;
-  int splits;
-  float eps;
-  int delay_ticks;          // WS_EXPERIMENT: spin this many 10 ns ticks instead (benchmarks/r03_exp1_prologue_mock.py)
-};
-
 struct WsParams {
   const uint16_t* x;     // [M, K]
   const uint16_t* w;     // [N, K]
@@ -218,8 +202,6 @@ struct WsParams {
   int out_f32;                  // y is fp32 (the down projection ahead of moe_sum_reduce)
   int round_before_scale;       // round the accumulator to bf16 before the router weight (fused_moe_native.py:157-163)
   int pair_silu;                // two-tile waves: y[:, 16 t ..] = silu(tile t) * tile (t + ntiles/2) instead of two outputs
-  // prologue form (PRO): the activations are produced INSIDE this launch by its first workgroups (see Prologue below)
-  Prologue pro;
 };
 
 // ---- LDS-DMA plumbing ------------------------------------------------------------------------
@@ -275,7 +257,7 @@ constexpr int ring_depth(int mt, int nw, int tpw) {
 // TPW = 16-row weight tiles per wave.  TPW == 2: the wave owns tiles t and t + ntiles/2 (half the activation reads
 // per weight byte); with pair_silu they are a gate tile and its up tile and the wave writes
 // y[m, 16 t ..] = silu(gate) * up (no partials, no second launch).
-template <int MT, int NW, int TPW, bool GROUPED, bool PRO = false>
+template <int MT, int NW, int TPW, bool GROUPED>
 __global__ __launch_bounds__(64 * NW, 1) void wstream_gemm_kernel(WsParams p) {
   constexpr int PD = ring_depth(MT, NW, TPW);
   constexpr int XPIECES = MT * 4;                       // 1 KiB pieces (4 rows x 256 B) of an activation chunk
@@ -448,38 +430,17 @@ __global__ __launch_bounds__(64 * NW, 1) void wstream_gemm_kernel(WsParams p) {
   };
 
   // ---- pipeline: weights PD chunks ahead, activations PD - 1, one barrier per chunk ----
-  if constexpr (PRO) {
-    // the weights do not depend on the prologue: all PD chunks are requested first, the activations once they exist
 #pragma unroll
-    for (int u = 0; u < PD; ++u) issue_w(u, u);
-    run_prologue<64 * NW>(p, ring3 + PD * CH);
-#pragma unroll
-    for (int u = 0; u < PD - 1; ++u) issue_x(u, u);
-  } else {
-#pragma unroll
-    for (int u = 0; u < PD - 1; ++u) {
-      issue_w(u, u);
-      issue_x(u, u);
-    }
-    issue_w(PD - 1, PD - 1);
+  for (int u = 0; u < PD - 1; ++u) {
+    issue_w(u, u);
+    issue_x(u, u);
   }
+  issue_w(PD - 1, PD - 1);
   int slot = 0, nslot = PD - 1;                          // slot of chunk c, slot of chunk c - 1 (= c + PD - 1)
   for (int c = 0; c < n; ++c) {
     // chunk c has landed once only the DMAs issued after its activations are outstanding:
     // weights of c+1 .. c+PD-1 and activations of c+1 .. c+PD-2
-    if constexpr (PRO) {
-      // issue order W0 .. W(PD-1) | X0 .. X(PD-2) | X(PD-1) W(PD) | X(PD) W(PD+1) ...: behind X(c) sit the rest of the
-      // activation prologue and min(c, PD-1) weight refills
-      static_assert(PD <= 6, "wait table");
-      if (c >= PD - 1) wait_vm<(PD - 2) * XP + (PD - 1) * WPC>();
-      else if (c == 0) wait_vm<(PD - 2) * XP>();
-      else if (c == 1) wait_vm<(PD - 2) * XP + WPC>();
-      else if (c == 2) wait_vm<(PD - 2) * XP + (PD > 3 ? 2 : PD - 1) * WPC>();
-      else if (c == 3) wait_vm<(PD - 2) * XP + (PD > 4 ? 3 : PD - 1) * WPC>();
-      else wait_vm<(PD - 2) * XP + (PD > 5 ? 4 : PD - 1) * WPC>();
-    } else {
-      wait_vm<(PD - 1) * WPC + (PD - 2) * XP>();
-    }
+    wait_vm<(PD - 1) * WPC + (PD - 2) * XP>();
     __builtin_amdgcn_s_barrier();                        // everyone's pieces of chunk c are visible,
                                                          // everyone is done reading the activations of chunk c - 1
     issue_x(c + PD - 1, nslot);
