@@ -353,7 +353,7 @@ int sgl_amd_probe_mfma_16x16x32(const void* a_16x32_bf16, const void* b_32x16_bf
  * The ONE place where the library owns device memory: a communicator workspace must be its own (uncached)
  * allocation to be exportable with hipIpcGetMemHandle, so it is allocated / freed here, once per process, by the
  * caller's communicator object (sglang_amd/distributed/xgmi_all_reduce.py).  Layout: an 8 KiB signal block
- * (per-workgroup start / end flags of every rank, the rank's own flag counters) + the data area.
+ * (per-workgroup start / middle / end flags of every rank, the rank's own flag counters) + the data area.
  * Every rank opens every peer's handle; `peer_workspaces_host` is a HOST array of `world` device pointers
  * (entry `rank` = the rank's own workspace).  All ranks must issue the same sequence of calls (sizes, num_blocks).
  * The launch itself has no host state (flag counters live in the workspace): hipGraph-capturable. */
@@ -373,6 +373,21 @@ int sgl_amd_xgmi_timed_out(const void* workspace);
 int sgl_amd_xgmi_one_shot_all_reduce(const void* inp, void* out, int64_t rows, int hidden, int rank, int world,
                                      const void* const* peer_workspaces_host, int64_t workspace_bytes, int epilogue,
                                      void* residual, const void* norm_weight, float eps, int num_blocks, void* stream);
+/* Arm the workspace after the start-up self-test: from then on a flag wait that gives up TRAPS (the stream fails and
+ * every later call on the rank raises) instead of letting an unreduced sum pass for a result. */
+int sgl_amd_xgmi_arm(void* workspace, int trap_on_timeout);
+/* Two-stage all-reduce for prefill-sized messages (custom_all_reduce_hip.cuh:595-652; custom_all_reduce.py:260-307
+ * picks it above the one-shot sizes): reduce-scatter + all-gather by pulling over the direct links, 2/world of the
+ * message per link direction instead of the whole message.  Every 8 KiB chunk is summed once, by its owner rank, in
+ * rank order: identical bits on all ranks.  The workspace's data area is cut in two (copies, published sums):
+ * needs workspace_bytes >= 8 KiB + 4 * numel (+ padding). */
+int sgl_amd_xgmi_two_stage_all_reduce(const void* inp, void* out, int64_t numel, int rank, int world,
+                                      const void* const* peer_workspaces_host, int64_t workspace_bytes, int num_blocks,
+                                      void* stream);
+/* out[rows, world * cols_per_rank] = the ranks' inp[rows, cols_per_rank] side by side (the vocab-parallel logits of
+ * logits_processor.py:676) -- one launch with the same flag protocol, so the decode graph holds no RCCL node. */
+int sgl_amd_xgmi_all_gather(const void* inp, void* out, int64_t rows, int cols_per_rank, int rank, int world,
+                            const void* const* peer_workspaces_host, int64_t workspace_bytes, int num_blocks, void* stream);
 
 /* ---- pool layouts / element formats / masks beyond the bf16 NHD default ----------
  * kv_fp8 = 1: the pools hold OCP e4m3 bytes of K / k_scale and V / v_scale (memory_pool.py:2364-2374,

@@ -37,8 +37,10 @@ constexpr int64_t kDataOffset = 8192;          // data area starts here (signal 
 struct Signal {
   uint32_t start[kMaxBlocks][kMaxWorld];
   uint32_t end[kMaxBlocks][kMaxWorld];
+  uint32_t mid[kMaxBlocks][kMaxWorld];       // two-stage kernel: "my slice of the sum is published"
   uint32_t flag[kMaxBlocks];
   uint32_t timed_out;                        // set when a flag wait gave up (a peer never arrived)
+  uint32_t trap_on_timeout;                  // armed by the host once the start-up self-test passed (sgl_amd_xgmi_arm)
 };
 static_assert(sizeof(Signal) <= kDataOffset, "signal block");
 
@@ -68,13 +70,16 @@ __device__ __forceinline__ void flag_barrier(const ArParams& p, uint32_t (Signal
     Signal* peer = reinterpret_cast<Signal*>(p.peers.base[t]);
     Signal* self = reinterpret_cast<Signal*>(p.peers.base[p.rank]);
     __hip_atomic_store(&(peer->*arr)[blockIdx.x][p.rank], flag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    // bounded: a peer that never launches (a crashed rank) must not wedge the GPU -- give up after ~seconds,
-    // leave a mark the host can read (sgl_amd_xgmi_timed_out) and let the kernel finish with garbage
+    // bounded: a peer that never launches (a crashed rank) must not wedge the GPU -- give up after ~seconds and leave
+    // a mark the host can read (sgl_amd_xgmi_timed_out).  During the start-up self-test the kernel then runs on (the
+    // host compares the result and drops the communicator on all ranks); once armed, an unreduced sum must never
+    // pass for a result: the kernel traps, the stream fails, every later call on this rank raises.
     int spins = 0;
     while (__hip_atomic_load(&(self->*arr)[blockIdx.x][t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < flag) {
       __builtin_amdgcn_s_sleep(8);
-      if (++spins > (1 << 22)) {
+      if (++spins > (1 << 25)) {          // about half a minute: host-side skew between ranks (a GC pause, a page fault storm) is not a crash
         self->timed_out = 1u;
+        if (self->trap_on_timeout) __builtin_trap();
         break;
       }
     }
@@ -174,6 +179,86 @@ __global__ __launch_bounds__(kArThreads) void xgmi_one_shot_all_reduce_kernel(Ar
           st16(p.out + static_cast<int64_t>(r) * p.hidden + c, o);
         }
       }
+    }
+  }
+  flag_barrier(p, &Signal::end, flag);
+  if (threadIdx.x == 0) self->flag[blockIdx.x] = flag;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Two-stage all-reduce for prefill-sized messages (custom_all_reduce_hip.cuh:595-652, selected by
+// custom_all_reduce.py:260-307 above the one-shot sizes): reduce-scatter, then all-gather, both by PULLING over the
+// direct links.  Rank r owns every WORLD-th 8 KiB chunk of a workgroup's share of the message: it reads that chunk
+// from all copies, adds in rank order (fp32, one rounding) and publishes the sum in the second half of its workspace;
+// after the middle barrier everybody reads every chunk from its owner.  Per link direction 2/world of the message
+// instead of the one-shot kernel's whole message; same bits on every rank (each sum is computed once, by its owner).
+// Chunk c of kArThreads 16-byte vectors belongs to workgroup c % grid in ALL phases on ALL ranks, so the per-workgroup
+// flag rows pair the same data on both sides of a link; its owner is rank (c / grid) % world.
+template <int WORLD>
+__global__ __launch_bounds__(kArThreads) void xgmi_two_stage_all_reduce_kernel(ArParams p, int64_t sums_offset) {
+  Signal* self = reinterpret_cast<Signal*>(p.peers.base[p.rank]);
+  const uint32_t flag = self->flag[blockIdx.x] + 1;
+  const int64_t nvec = p.numel / 8;
+  const int64_t nchunks = (nvec + kArThreads - 1) / kArThreads;
+  uint16_t* mine = reinterpret_cast<uint16_t*>(p.peers.base[p.rank] + kDataOffset);
+  uint16_t* my_sums = reinterpret_cast<uint16_t*>(p.peers.base[p.rank] + sums_offset);
+  for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    const int64_t i = c * kArThreads + threadIdx.x;
+    if (i < nvec) st16(mine + i * 8, ld16(p.inp + i * 8));
+  }
+  flag_barrier(p, &Signal::start, flag);
+  int64_t k = 0;
+  for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x, ++k) {
+    if (k % WORLD != p.rank) continue;
+    const int64_t i = c * kArThreads + threadIdx.x;
+    if (i < nvec) {
+      float acc[8];
+      gather_sum<WORLD>(p, i * 8, acc);
+      U4 o;
+      o.x = pack_bf2(acc[0], acc[1]); o.y = pack_bf2(acc[2], acc[3]);
+      o.z = pack_bf2(acc[4], acc[5]); o.w = pack_bf2(acc[6], acc[7]);
+      st16(my_sums + i * 8, o);
+    }
+  }
+  flag_barrier(p, &Signal::mid, flag);
+  k = 0;
+  for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x, ++k) {
+    const int64_t i = c * kArThreads + threadIdx.x;
+    if (i < nvec) {
+      const int owner = static_cast<int>(k % WORLD);
+      st16(p.out + i * 8, ld16(reinterpret_cast<const uint16_t*>(p.peers.base[owner] + sums_offset) + i * 8));
+    }
+  }
+  flag_barrier(p, &Signal::end, flag);
+  if (threadIdx.x == 0) self->flag[blockIdx.x] = flag;
+}
+
+// All-gather along the last dimension (the vocab-parallel logits of logits_processor.py:676 inside the decode graph):
+// out[row, r * cols + c] = rank r's inp[row, c].  One launch, same flag protocol, same chunk-to-workgroup map.
+template <int WORLD>
+__global__ __launch_bounds__(kArThreads) void xgmi_all_gather_kernel(ArParams p) {
+  Signal* self = reinterpret_cast<Signal*>(p.peers.base[p.rank]);
+  const uint32_t flag = self->flag[blockIdx.x] + 1;
+  const int64_t nvec = p.numel / 8;                 // of one rank's shard [rows, hidden]
+  const int64_t nchunks = (nvec + kArThreads - 1) / kArThreads;
+  const int vpr = p.hidden / 8;                     // vectors per shard row
+  uint16_t* mine = reinterpret_cast<uint16_t*>(p.peers.base[p.rank] + kDataOffset);
+  for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    const int64_t i = c * kArThreads + threadIdx.x;
+    if (i < nvec) st16(mine + i * 8, ld16(p.inp + i * 8));
+  }
+  flag_barrier(p, &Signal::start, flag);
+  for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    const int64_t i = c * kArThreads + threadIdx.x;
+    if (i < nvec) {
+      const int64_t row = i / vpr;
+      const int col = static_cast<int>(i - row * vpr) * 8;
+      U4 v[WORLD];
+#pragma unroll
+      for (int r = 0; r < WORLD; ++r) v[r] = ld16(reinterpret_cast<const uint16_t*>(p.peers.base[r] + kDataOffset) + i * 8);
+#pragma unroll
+      for (int r = 0; r < WORLD; ++r) st16(p.out + row * (static_cast<int64_t>(p.hidden) * WORLD) + static_cast<int64_t>(r) * p.hidden + col, v[r]);
     }
   }
   flag_barrier(p, &Signal::end, flag);
@@ -287,6 +372,86 @@ int sgl_amd_xgmi_one_shot_all_reduce(const void* inp, void* out, int64_t rows, i
     default: hipLaunchKernelGGL(xgmi_one_shot_all_reduce_kernel<8>, dim3(blocks), dim3(kArThreads), 0, st, p); break;
   }
   SGL_CHECK_LAUNCH("xgmi_one_shot_all_reduce");
+  return 0;
+}
+
+int sgl_amd_xgmi_arm(void* workspace, int trap_on_timeout) {
+  SGL_CLEAR_STALE_ERROR();
+  SGL_CHECK_ARG(workspace, "xgmi_arm: null workspace");
+  const uint32_t v = trap_on_timeout ? 1u : 0u;
+  hipError_t e = hipMemcpy(static_cast<unsigned char*>(workspace) + offsetof(Signal, trap_on_timeout), &v, 4, hipMemcpyHostToDevice);
+  SGL_CHECK_ARG(e == hipSuccess, "xgmi_arm: %s", hipGetErrorString(e));
+  return 0;
+}
+
+// shared argument checks of the two collectives below
+static int fill_peers(const char* who, ArParams* p, int rank, int world, const void* const* peer_workspaces_host) {
+  SGL_CHECK_ARG(world == 2 || world == 4 || world == 8, "%s: world=%d (supported: 2, 4, 8)", who, world);
+  SGL_CHECK_ARG(rank >= 0 && rank < world && peer_workspaces_host, "%s: bad rank / peers", who);
+  for (int r = 0; r < world; ++r) {
+    SGL_CHECK_ARG(peer_workspaces_host[r], "%s: peer %d is not mapped", who, r);
+    p->peers.base[r] = static_cast<unsigned char*>(const_cast<void*>(peer_workspaces_host[r]));
+  }
+  p->rank = rank; p->world = world;
+  return 0;
+}
+
+int sgl_amd_xgmi_two_stage_all_reduce(const void* inp, void* out, int64_t numel, int rank, int world,
+                                      const void* const* peer_workspaces_host, int64_t workspace_bytes, int num_blocks,
+                                      void* stream) {
+  SGL_CLEAR_STALE_ERROR();
+  SGL_CHECK_ARG(numel >= 0 && numel % 8 == 0 && inp && out, "xgmi_two_stage_all_reduce: numel=%lld must be a multiple of 8", (long long)numel);
+  if (numel == 0) return 0;
+  // the workspace's data area is cut in two: copies of the inputs, then the published sums
+  const int64_t half = ((workspace_bytes - kDataOffset) / 2) / 256 * 256;
+  SGL_CHECK_ARG(numel * 2 <= half, "xgmi_two_stage_all_reduce: message of %lld bytes needs a workspace of %lld (have %lld)",
+                (long long)(numel * 2), (long long)(kDataOffset + 4 * numel + 512), (long long)workspace_bytes);
+  ArParams p{};
+  if (int rc = fill_peers("xgmi_two_stage_all_reduce", &p, rank, world, peer_workspaces_host)) return rc;
+  p.inp = static_cast<const uint16_t*>(inp); p.out = static_cast<uint16_t*>(out); p.numel = numel;
+  int blocks = num_blocks;
+  if (blocks <= 0) {
+    const int64_t chunks = (numel / 8 + kArThreads - 1) / kArThreads;
+    blocks = static_cast<int>(chunks < kMaxBlocks ? (chunks < 1 ? 1 : chunks) : kMaxBlocks);
+  }
+  SGL_CHECK_ARG(blocks >= 1 && blocks <= kMaxBlocks, "xgmi_two_stage_all_reduce: num_blocks=%d (1..%d)", blocks, kMaxBlocks);
+  hipStream_t st = as_stream(stream);
+  const int64_t off = kDataOffset + half;
+  switch (world) {
+    case 2: hipLaunchKernelGGL(xgmi_two_stage_all_reduce_kernel<2>, dim3(blocks), dim3(kArThreads), 0, st, p, off); break;
+    case 4: hipLaunchKernelGGL(xgmi_two_stage_all_reduce_kernel<4>, dim3(blocks), dim3(kArThreads), 0, st, p, off); break;
+    default: hipLaunchKernelGGL(xgmi_two_stage_all_reduce_kernel<8>, dim3(blocks), dim3(kArThreads), 0, st, p, off); break;
+  }
+  SGL_CHECK_LAUNCH("xgmi_two_stage_all_reduce");
+  return 0;
+}
+
+int sgl_amd_xgmi_all_gather(const void* inp, void* out, int64_t rows, int cols_per_rank, int rank, int world,
+                            const void* const* peer_workspaces_host, int64_t workspace_bytes, int num_blocks, void* stream) {
+  SGL_CLEAR_STALE_ERROR();
+  SGL_CHECK_ARG(rows >= 0 && cols_per_rank > 0 && cols_per_rank % 8 == 0 && inp && out,
+                "xgmi_all_gather: cols_per_rank=%d must be a multiple of 8", cols_per_rank);
+  if (rows == 0) return 0;
+  const int64_t numel = rows * cols_per_rank;
+  SGL_CHECK_ARG(kDataOffset + numel * 2 <= workspace_bytes, "xgmi_all_gather: shard of %lld bytes does not fit the %lld-byte workspace",
+                (long long)(numel * 2), (long long)workspace_bytes);
+  ArParams p{};
+  if (int rc = fill_peers("xgmi_all_gather", &p, rank, world, peer_workspaces_host)) return rc;
+  p.inp = static_cast<const uint16_t*>(inp); p.out = static_cast<uint16_t*>(out); p.numel = numel;
+  p.rows = static_cast<int>(rows); p.hidden = cols_per_rank;
+  int blocks = num_blocks;
+  if (blocks <= 0) {
+    const int64_t chunks = (numel / 8 + kArThreads - 1) / kArThreads;
+    blocks = static_cast<int>(chunks < kMaxBlocks ? (chunks < 1 ? 1 : chunks) : kMaxBlocks);
+  }
+  SGL_CHECK_ARG(blocks >= 1 && blocks <= kMaxBlocks, "xgmi_all_gather: num_blocks=%d (1..%d)", blocks, kMaxBlocks);
+  hipStream_t st = as_stream(stream);
+  switch (world) {
+    case 2: hipLaunchKernelGGL(xgmi_all_gather_kernel<2>, dim3(blocks), dim3(kArThreads), 0, st, p); break;
+    case 4: hipLaunchKernelGGL(xgmi_all_gather_kernel<4>, dim3(blocks), dim3(kArThreads), 0, st, p); break;
+    default: hipLaunchKernelGGL(xgmi_all_gather_kernel<8>, dim3(blocks), dim3(kArThreads), 0, st, p); break;
+  }
+  SGL_CHECK_LAUNCH("xgmi_all_gather");
   return 0;
 }
 

@@ -90,6 +90,9 @@ def _start_xgmi():
         flag = torch.tensor([1 if good else 0], dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=_TP_CPU_GROUP)
     if int(flag) == 1:
+        # from here on an all-reduce that cannot complete must not hand back an unreduced sum: a flag wait that gives up
+        # traps the kernel (the stream fails, the next sync raises on this rank; its peers time out the same way)
+        xg.arm(True)
         return xg
     if xg is not None:
         warnings.warn("one-shot xGMI all-reduce failed its start-up self-test on some rank; using RCCL for every all-reduce")
@@ -135,8 +138,8 @@ def tensor_model_parallel_all_reduce(x: torch.Tensor) -> torch.Tensor:
     RCCL (which enqueues on its own stream behind an event on the current one)."""
     if _TP_SIZE == 1:
         return x
-    if _XGMI is not None and _XGMI.should_use(x):
-        return _XGMI.all_reduce(x)
+    if _XGMI is not None and (_XGMI.should_use(x) or _XGMI.should_use_two_stage(x)):
+        return _XGMI.all_reduce_any(x)
     dist.all_reduce(x, group=_TP_GROUP)
     return x
 
@@ -183,6 +186,9 @@ def tensor_model_parallel_all_gather(x: torch.Tensor, dim: int = -1) -> torch.Te
         return x
     if dim < 0:
         dim += x.dim()
+    if (_XGMI is not None and not _XGMI.disabled and x.is_cuda and x.dim() == 2 and dim == 1 and x.dtype == torch.bfloat16
+            and x.shape[1] % 8 == 0 and 8192 + x.numel() * 2 <= _XGMI.ws_bytes):
+        return _XGMI.all_gather(x.contiguous())          # one launch on the current stream: the decode graph holds no RCCL node
     if x.is_cuda and dist.get_backend(_TP_GROUP) == "gloo":
         # gloo moves device tensors only for broadcast / all_reduce: stage through the host (two ranks on one GPU in
         # the single-device tests; a real node runs RCCL)

@@ -24,11 +24,19 @@ import torch.distributed as dist
 from .. import native
 
 DEFAULT_MAX_BYTES = 2 * 1024 * 1024       # the one-shot regime (custom_all_reduce.py: max_size for the 1-stage kernel)
+DEFAULT_TWO_STAGE_BYTES = 64 * 1024 * 1024  # largest message of the two-stage kernel (a prefill chunk's [T, hidden] activations)
+
+
+def one_shot_limit(world: int, max_bytes: int) -> int:
+    """custom_all_reduce.py:260-307: two ranks always pull the whole message; with more ranks the one-shot kernel moves
+    (world - 1) copies per rank where the two-stage one moves 2 (world - 1) / world, at the price of a third flag
+    barrier (~2 us): 512 KiB at world 4, 256 KiB at world 8."""
+    return max_bytes if world == 2 else min(max_bytes, 512 * 1024 if world == 4 else 256 * 1024)
 
 
 class XgmiAllReduce:
     def __init__(self, group, rank: int, world: int, device: torch.device, max_bytes: int = DEFAULT_MAX_BYTES,
-                 handle_exchange=None):
+                 handle_exchange=None, two_stage_bytes: int = DEFAULT_TWO_STAGE_BYTES):
         """`group`: a process group every rank of the TP group is in (used once, for the handle exchange; may be a
         gloo group).  `handle_exchange(bytes) -> List[bytes]` overrides the collective (tests)."""
         lib = native.lib()
@@ -36,30 +44,46 @@ class XgmiAllReduce:
             raise ValueError(f"XgmiAllReduce: world size {world} (supported: 2, 4, 8)")
         self.rank, self.world, self.device = rank, world, device
         self.max_bytes = int(max_bytes)
-        self.ws_bytes = int(lib.sgl_amd_xgmi_workspace_bytes(self.max_bytes))
+        self.two_stage_bytes = int(two_stage_bytes)
+        # data area: the one-shot message, or the two halves (copies + published sums) of a two-stage message
+        self.ws_bytes = int(lib.sgl_amd_xgmi_workspace_bytes(max(self.max_bytes, 2 * self.two_stage_bytes + 512)))
         torch.cuda.set_device(device)
-        ptr = ctypes.c_void_p()
-        native.call("sgl_amd_xgmi_alloc", self.ws_bytes, ctypes.byref(ptr))
-        self._own = ptr.value
+        self._own, self._opened = None, []
         hbytes = lib.sgl_amd_xgmi_ipc_handle_bytes()
-        buf = ctypes.create_string_buffer(hbytes)
-        native.call("sgl_amd_xgmi_ipc_get_handle", self._own, buf)
-        mine = bytes(buf.raw)
+        # Local steps first, under a guard: a rank whose allocation / export fails must STILL take part in the handle
+        # exchange (with a None marker), or its peers would sit in the collective while it moves on to the next one.
+        mine, local_error = None, None
+        try:
+            ptr = ctypes.c_void_p()
+            native.call("sgl_amd_xgmi_alloc", self.ws_bytes, ctypes.byref(ptr))
+            self._own = ptr.value
+            buf = ctypes.create_string_buffer(hbytes)
+            native.call("sgl_amd_xgmi_ipc_get_handle", self._own, buf)
+            mine = bytes(buf.raw)
+        except Exception as e:                    # noqa: BLE001 -- reported after the exchange
+            local_error = e
         if handle_exchange is not None:
             handles = handle_exchange(mine)
         else:
             handles: List[Optional[bytes]] = [None] * world
             dist.all_gather_object(handles, mine, group=group)
-        self._opened: List[int] = []
-        peers = (ctypes.c_void_p * world)()
-        for r in range(world):
-            if r == rank:
-                peers[r] = self._own
-            else:
-                p = ctypes.c_void_p()
-                native.call("sgl_amd_xgmi_ipc_open_handle", ctypes.create_string_buffer(handles[r], hbytes), ctypes.byref(p))
-                peers[r] = p.value
-                self._opened.append(p.value)
+        try:
+            if local_error is not None:
+                raise local_error
+            if any(h is None for h in handles):
+                raise RuntimeError(f"XgmiAllReduce: rank(s) {[r for r, h in enumerate(handles) if h is None]} could not export a workspace")
+            peers = (ctypes.c_void_p * world)()
+            for r in range(world):
+                if r == rank:
+                    peers[r] = self._own
+                else:
+                    p = ctypes.c_void_p()
+                    native.call("sgl_amd_xgmi_ipc_open_handle", ctypes.create_string_buffer(handles[r], hbytes), ctypes.byref(p))
+                    peers[r] = p.value
+                    self._opened.append(p.value)
+        except Exception:
+            self.close()                          # unmap what was opened, free the workspace: nothing leaks on the error path
+            raise
         self._peers = peers                      # host array of device pointers (kept alive with the object)
         self.disabled = False
 
@@ -89,6 +113,40 @@ class XgmiAllReduce:
                     norm_weight.data_ptr() if norm_weight is not None else None, float(eps), int(num_blocks),
                     torch.cuda.current_stream().cuda_stream)
         return out
+
+    def should_use_two_stage(self, x: torch.Tensor) -> bool:
+        return (not self.disabled and x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and x.numel() % 8 == 0
+                and 0 < x.numel() * 2 <= self.two_stage_bytes)
+
+    def all_reduce_any(self, x: torch.Tensor) -> torch.Tensor:
+        """The reference's dispatch (custom_all_reduce.py:292-340): one-shot below the size where link traffic starts to
+        dominate, two-stage above."""
+        if self.should_use(x) and x.numel() * 2 <= one_shot_limit(self.world, self.max_bytes):
+            return self.all_reduce(x)
+        return self.two_stage_all_reduce(x)
+
+    def two_stage_all_reduce(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, num_blocks: int = 0) -> torch.Tensor:
+        if not self.should_use_two_stage(x):
+            raise ValueError(f"XgmiAllReduce.two_stage_all_reduce: bf16, contiguous, numel % 8 == 0, <= {self.two_stage_bytes} bytes")
+        if out is None:
+            out = torch.empty_like(x)
+        native.call("sgl_amd_xgmi_two_stage_all_reduce", x.data_ptr(), out.data_ptr(), x.numel(), self.rank, self.world, self._peers,
+                    self.ws_bytes, int(num_blocks), torch.cuda.current_stream().cuda_stream)
+        return out
+
+    def all_gather(self, x: torch.Tensor, num_blocks: int = 0) -> torch.Tensor:
+        """[rows, cols] per rank -> [rows, world * cols] (tensor_model_parallel_all_gather(dim=-1) of a 2-D tensor)."""
+        if not (x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and x.dim() == 2 and x.shape[1] % 8 == 0
+                and 8192 + x.numel() * 2 <= self.ws_bytes):
+            raise ValueError("XgmiAllReduce.all_gather: 2-D contiguous bf16 shard with cols % 8 == 0 that fits the workspace")
+        out = torch.empty((x.shape[0], x.shape[1] * self.world), dtype=x.dtype, device=x.device)
+        native.call("sgl_amd_xgmi_all_gather", x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], self.rank, self.world, self._peers,
+                    self.ws_bytes, int(num_blocks), torch.cuda.current_stream().cuda_stream)
+        return out
+
+    def arm(self, trap_on_timeout: bool = True) -> None:
+        """After the start-up self-test: a flag wait that gives up traps the kernel instead of returning garbage."""
+        native.call("sgl_amd_xgmi_arm", self._own, 1 if trap_on_timeout else 0)
 
     def timed_out(self) -> bool:
         """True when a flag wait gave up because a peer never arrived (synchronises the device)."""

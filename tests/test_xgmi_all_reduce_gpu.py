@@ -87,11 +87,58 @@ def _case_sum(rank, world, ps, dist):
         for rep in range(3):                                                         # flags advance call after call
             got = ps.tensor_model_parallel_all_reduce(xs[rank].to(dev).clone())
             assert xg.should_use(got) and torch.equal(got.cpu(), want), (rows, hidden, rep)
-    # above the one-shot limit: the group's own collective
+    # above the one-shot limit: the two-stage kernel (reduce-scatter + all-gather over the same mappings)
     big = torch.ones((1100, 1024), dtype=torch.bfloat16, device=dev)
-    assert not xg.should_use(big)
+    assert not xg.should_use(big) and xg.should_use_two_stage(big)
     assert torch.equal(ps.tensor_model_parallel_all_reduce(big).cpu(), torch.full((1100, 1024), float(world)).to(torch.bfloat16))
     return worst
+
+
+def _case_two_stage(rank, world, ps, dist):
+    """Prefill-sized messages: every chunk is summed once by its owner in rank order, so the result is the exact
+    fp32-sum-rounded-once on every rank; sizes that leave ragged last chunks and fewer chunks than ranks included."""
+    dev = torch.device("cuda", 0)
+    xg = ps.get_xgmi_all_reduce()
+    for i, (rows, hidden) in enumerate([(1, 8), (3, 1032), (1100, 1024), (2048, 4096), (517, 4104)]):
+        xs = _inputs(rank, world, rows, hidden, 40 + i)
+        want = torch.stack([x.float() for x in xs]).sum(0).to(torch.bfloat16)
+        for rep in range(2):
+            got = xg.two_stage_all_reduce(xs[rank].to(dev))
+            assert torch.equal(got.cpu(), want), (rows, hidden, rep)
+    # the dispatch of custom_all_reduce.py:292-340
+    from sglang_amd.distributed.xgmi_all_reduce import one_shot_limit
+
+    assert one_shot_limit(2, xg.max_bytes) == xg.max_bytes and one_shot_limit(8, xg.max_bytes) == 256 * 1024
+    return 0
+
+
+def _case_all_gather(rank, world, ps, dist):
+    """The vocab-parallel logits: [rows, V / world] per rank -> [rows, V], one launch, also inside a hipGraph."""
+    dev = torch.device("cuda", 0)
+    xg = ps.get_xgmi_all_reduce()
+    for i, (rows, cols) in enumerate([(64, 16032), (1, 8), (7, 1000)]):
+        xs = _inputs(rank, world, rows, cols, 60 + i)
+        want = torch.cat(xs, dim=1)
+        got = ps.tensor_model_parallel_all_gather(xs[rank].to(dev), dim=-1)
+        assert torch.equal(got.cpu(), want), (rows, cols)
+    static_in = torch.zeros((64, 2048), dtype=torch.bfloat16, device=dev)
+    out_holder = []
+    xg.all_gather(static_in)
+    torch.cuda.synchronize(); dist.barrier()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            out_holder.append(xg.all_gather(static_in))
+    torch.cuda.current_stream().wait_stream(s)
+    for i in range(3):
+        xs = _inputs(rank, world, 64, 2048, 70 + i)
+        static_in.copy_(xs[rank])
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out_holder[0].cpu(), torch.cat(xs, dim=1)), i
+    return 0
 
 
 def _case_add_rmsnorm(rank, world, ps, dist):
@@ -106,7 +153,12 @@ def _case_add_rmsnorm(rank, world, ps, dist):
         summed = torch.stack([x.float() for x in xs]).sum(0).to(torch.bfloat16)
         want_out, want_res = oo.fused_add_rmsnorm(summed, res0, w, 1e-5)
         res = res0.to(dev).clone()
-        out = ps.tensor_model_parallel_all_reduce_add_rmsnorm(xs[rank].to(dev), res, w.to(dev), 1e-5)
+        if world > 2:
+            # eight ranks SHARE this GPU: all their spinning workgroups must be resident at once, or the ones waiting
+            # for a CU are the ones the residents wait for -- keep the launches small (on a node every rank owns a GPU)
+            out = ps.get_xgmi_all_reduce().all_reduce(xs[rank].to(dev), residual=res, norm_weight=w.to(dev), eps=1e-5, num_blocks=4)
+        else:
+            out = ps.tensor_model_parallel_all_reduce_add_rmsnorm(xs[rank].to(dev), res, w.to(dev), 1e-5)
         assert torch.equal(res.cpu(), want_res), "residual"
         err = (out.cpu().float() - want_out.float()).abs()
         # one bf16 ulp on a few elements (fp32 reduction order of the row's sum of squares)
@@ -186,6 +238,31 @@ def test_all_reduce_with_add_rmsnorm_epilogue(device):
 
 def test_all_reduce_records_into_a_hipgraph(device):
     _run("graph")
+
+
+def test_two_stage_all_reduce_two_processes_one_gpu(device):
+    _run("two_stage")
+
+
+def test_all_gather_two_processes_one_gpu(device):
+    _run("all_gather")
+
+
+def _case_all(rank, world, ps, dist):
+    torch.set_num_threads(2)                   # eight processes on one host: no thread-pool oversubscription between launches
+    for case in ("sum", "add_rmsnorm", "two_stage", "all_gather", "graph"):
+        print(f"[rank {rank}] {case}", file=sys.stderr, flush=True)
+        globals()["_case_" + case](rank, world, ps, dist)
+        torch.cuda.synchronize()
+        dist.barrier()
+    return 0
+
+
+def test_world_of_eight_processes_one_gpu(device):
+    """The TP=8 communicator of configs[2] (eight ranks, seven peers each: flag rows, rank order of the sums, chunk
+    ownership k % 8, the armed timeout trap) with all eight processes on the one GPU of the lease: every case above,
+    one after the other in the same eight processes."""
+    _run("all", world=8, timeout=240)
 
 
 def test_tp2_engine_with_the_fused_all_reduce_layer(device):
