@@ -138,6 +138,10 @@ def parse_args():
     ap.add_argument("--kv-cache-dtype", default="auto", choices=("auto", "bfloat16", "fp8_e4m3"),
                     help="KV pool rows (server_args --kv-cache-dtype); fp8_e4m3 is NOT the baseline configuration: the "
                          "line's config says so and the bf16-KV parity leg is skipped")
+    ap.add_argument("--rank-of", type=int, default=0, metavar="TP",
+                    help="rank-shape run on ONE GPU: rank 0 of a TP-way job (that rank's weight shards, the weak-scaled batch "
+                         "64 x TP, every collective launched as a world-of-1 loopback of the xGMI kernels: all launches of the "
+                         "real job, no wire time).  The line is marked as such; it is NOT a multi-GPU measurement")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--operator-surface", action="store_true",
                     help="decode through the unfused per-operator hooks only (the path the sglang.srt registration "
@@ -191,6 +195,11 @@ def worker(args):
     ps.init_distributed_environment()
     world = ps.get_tensor_model_parallel_world_size()
     rank = int(os.environ.get("RANK", "0"))
+    if args.rank_of:
+        if world != 1 or args.gpus != 1:
+            raise SystemExit("--rank-of runs on one GPU (--gpus 1)")
+        ps.emulate_tensor_parallel_rank(0, args.rank_of, torch.device("cuda", torch.cuda.current_device()))
+    tp = args.rank_of or world           # the TP degree the shapes belong to
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the job has {world} rank(s) (WORLD_SIZE="
                          f"{os.environ.get('WORLD_SIZE', 'unset')}): refusing to report a {world}-GPU number as {args.gpus}")
@@ -205,7 +214,7 @@ def worker(args):
         cfg = dataclasses.replace(cfg, num_hidden_layers=args.layers)
         reduced = True
 
-    G = args.groups * world          # weak scaling: the batch grows with the TP degree
+    G = args.groups * tp             # weak scaling: the batch grows with the TP degree
     P = args.per_group
     B = G * P
     in_len = args.prefix + args.unique
@@ -290,11 +299,11 @@ def worker(args):
 
     # ---- rooflines ------------------------------------------------
     L, Hq, Hkv, D = cfg.num_hidden_layers, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
-    kv_heads_rank = max(1, Hkv // world)
+    kv_heads_rank = max(1, Hkv // tp)
     kv_fp8 = args.kv_cache_dtype == "fp8_e4m3"
     kv_row = 2 * L * kv_heads_rank * D * (1 if kv_fp8 else 2)   # bytes per cached token on one rank, all layers (131072 for 8B TP=1)
     plin = p_lin(cfg)
-    w_act = decode_weight_bytes(cfg, B) / world
+    w_act = decode_weight_bytes(cfg, B) / tp
     mean_len = in_len + args.out / 2
     kv_unique = (G * args.prefix + B * (mean_len - args.prefix)) * kv_row
     kv_nodedup = B * mean_len * kv_row
@@ -312,11 +321,11 @@ def worker(args):
     flops_cold = G * (2 * in_len * plin + pair * (in_len * (in_len + 1) / 2) + 2 * cfg.hidden_size * cfg.vocab_size)
     flops_warm = (B - G) * (2 * args.unique * plin + pair * (args.unique * args.prefix + args.unique * (args.unique + 1) / 2)
                             + 2 * cfg.hidden_size * cfg.vocab_size)
-    prefill_tflops = (flops_cold + flops_warm) / world / (cold + warm) / 1e12
+    prefill_tflops = (flops_cold + flops_warm) / tp / (cold + warm) / 1e12
 
     decode_mode = ("hipGraph" if runner.graph_runner is not None else "eager") + \
                   (", operator surface (unfused per-op hooks)" if args.operator_surface else ", fused TP=1 decode layer"
-                   if world == 1 else "")
+                   if tp == 1 else "")
     result = {
         "metric": "output tokens/s + p50 TTFT, Llama-3-8B TP=1 shared-prefix batch; 70B TP=8",
         "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -326,7 +335,10 @@ def worker(args):
                                f"{args.unique} unique in, {args.out} out, greedy, page_size {args.page_size}"
                                + (" [fp8_e4m3 KV pool -- not the baseline configuration]" if kv_fp8 else "")
                                + (f" [REDUCED: {args.layers} layers -- not a valid bench line]" if reduced else ""),
-                   "model": cfg.name, "global_batch": B, "seq_len": in_len, "parallelism": f"tp{world}",
+                   "model": cfg.name, "global_batch": B, "seq_len": in_len,
+                   "parallelism": f"tp{world}" if not args.rank_of else
+                   f"RANK SHAPES of tp{tp} on 1 GPU: rank 0's weight shards, the tp{tp} job's batch, collectives = world-of-1 "
+                   f"loopback launches of the xGMI kernels (no wire time) -- not a multi-GPU measurement",
                    "decode": decode_mode},
         "ttft_p50_ms": statistics.median(ttfts) * 1e3,
         "phase_ms": {"prefill_cold": cold * 1e3, "prefill_warm": warm * 1e3, "decode": dec * 1e3},
@@ -338,14 +350,14 @@ def worker(args):
     }
 
     # ---- dominant hand-written kernels, measured live with HIP events on torch's stream ----
-    if rank == 0 and not args.no_kernel_roofline:
+    if rank == 0 and not args.no_kernel_roofline and not args.rank_of:
         try:
             kernel_rooflines(args, cfg, runner, result, B, G, P, in_len, ctx, t_decode_step, pmc, dev, world)
         except Exception as e:      # the measured line must survive a failure of these side measurements
             result.setdefault("roofline", {"error": f"{type(e).__name__}: {e}"})
 
     # ---- parity of this very job against the oracle's plain torch ops on the GPU ----------
-    if rank == 0 and world == 1 and not args.no_parity and not kv_fp8:
+    if rank == 0 and world == 1 and not args.no_parity and not kv_fp8 and not args.rank_of:
         try:
             from oracle.parity import teacher_forced_parity
 
@@ -384,7 +396,7 @@ def worker(args):
             result["parity"] = {"error": f"{type(e).__name__}: {e}"}
 
     # ---- CPU baseline: the oracle (reference torch-native path) on host cores --------------
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.rank_of:
         try:
             result["cpu_baseline"] = cpu_baseline(args, cfg, runner, prompts)
         except Exception as e:
@@ -392,7 +404,7 @@ def worker(args):
 
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if world > 1 or args.rank_of:
         ps.destroy()
 
 

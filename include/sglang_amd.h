@@ -352,7 +352,7 @@ int sgl_amd_probe_mfma_16x16x32(const void* a_16x32_bf16, const void* b_32x16_bf
  *      GroupCoordinator.all_reduce, srt/distributed/parallel_state.py:648-758) -------------------------------
  * The ONE place where the library owns device memory: a communicator workspace must be its own (uncached)
  * allocation to be exportable with hipIpcGetMemHandle, so it is allocated / freed here, once per process, by the
- * caller's communicator object (sglang_amd/distributed/xgmi_all_reduce.py).  Layout: an 8 KiB signal block
+ * caller's communicator object (sglang_amd/distributed/xgmi_all_reduce.py).  Layout: a 32 KiB signal block
  * (per-workgroup start / middle / end flags of every rank, the rank's own flag counters) + the data area.
  * Every rank opens every peer's handle; `peer_workspaces_host` is a HOST array of `world` device pointers
  * (entry `rank` = the rank's own workspace).  All ranks must issue the same sequence of calls (sizes, num_blocks).
@@ -376,14 +376,18 @@ int sgl_amd_xgmi_one_shot_all_reduce(const void* inp, void* out, int64_t rows, i
 /* Arm the workspace after the start-up self-test: from then on a flag wait that gives up TRAPS (the stream fails and
  * every later call on the rank raises) instead of letting an unreduced sum pass for a result. */
 int sgl_amd_xgmi_arm(void* workspace, int trap_on_timeout);
+/* Test hook (several ranks sharing ONE GPU): cap on the automatically chosen workgroup counts of the collectives. */
+int sgl_amd_xgmi_debug_auto_blocks_cap(int cap);
 /* Two-stage all-reduce for prefill-sized messages (custom_all_reduce_hip.cuh:595-652; custom_all_reduce.py:260-307
  * picks it above the one-shot sizes): reduce-scatter + all-gather by pulling over the direct links, 2/world of the
  * message per link direction instead of the whole message.  Every 8 KiB chunk is summed once, by its owner rank, in
  * rank order: identical bits on all ranks.  The workspace's data area is cut in two (copies, published sums):
- * needs workspace_bytes >= 8 KiB + 4 * numel (+ padding). */
-int sgl_amd_xgmi_two_stage_all_reduce(const void* inp, void* out, int64_t numel, int rank, int world,
-                                      const void* const* peer_workspaces_host, int64_t workspace_bytes, int num_blocks,
-                                      void* stream);
+ * needs workspace_bytes >= 32 KiB + 4 * rows * hidden (+ padding).  epilogue 1 as in the one-shot kernel: the rows
+ * are the chunks, and the workgroup that gathers a row finishes residual add + RMSNorm (decode batches of a few
+ * hundred rows per rank: weak-scaled TP). */
+int sgl_amd_xgmi_two_stage_all_reduce(const void* inp, void* out, int64_t rows, int hidden, int rank, int world,
+                                      const void* const* peer_workspaces_host, int64_t workspace_bytes, int epilogue,
+                                      void* residual, const void* norm_weight, float eps, int num_blocks, void* stream);
 /* out[rows, world * cols_per_rank] = the ranks' inp[rows, cols_per_rank] side by side (the vocab-parallel logits of
  * logits_processor.py:676) -- one launch with the same flag protocol, so the decode graph holds no RCCL node. */
 int sgl_amd_xgmi_all_gather(const void* inp, void* out, int64_t rows, int cols_per_rank, int rank, int world,

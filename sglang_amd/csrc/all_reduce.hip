@@ -30,9 +30,9 @@ using namespace sgl_amd;
 namespace {
 
 constexpr int kMaxWorld = 8;
-constexpr int kMaxBlocks = 64;
+constexpr int kMaxBlocks = 256;            // one workgroup per CU at most: a phase is a few dependent round trips per chunk, width hides them
 constexpr int kArThreads = 512;
-constexpr int64_t kDataOffset = 8192;          // data area starts here (signal block padded to 8 KiB)
+constexpr int64_t kDataOffset = 32768;         // data area starts here (signal block padded to 32 KiB)
 
 struct Signal {
   uint32_t start[kMaxBlocks][kMaxWorld];
@@ -62,11 +62,13 @@ struct ArParams {
 };
 
 __device__ __forceinline__ void flag_barrier(const ArParams& p, uint32_t (Signal::*arr)[kMaxBlocks][kMaxWorld], uint32_t flag) {
-  // all data stores of this workgroup are ordered before the flags: every thread fences, then one barrier
-  __threadfence_system();
+  // All data stores of this workgroup are ordered before the flags: the workgroup barrier orders every wave's stores
+  // before the flag writers (it waits for their completion), and ONLY the flag writers pay the system-scope release
+  // (an L2 write-back per fence: with every thread of 256 workgroups fencing, a 4 MiB all-reduce spent 100 us in them).
   __syncthreads();
   const int t = threadIdx.x;
   if (t < p.world) {
+    __threadfence_system();
     Signal* peer = reinterpret_cast<Signal*>(p.peers.base[t]);
     Signal* self = reinterpret_cast<Signal*>(p.peers.base[p.rank]);
     __hip_atomic_store(&(peer->*arr)[blockIdx.x][p.rank], flag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -195,39 +197,142 @@ __global__ __launch_bounds__(kArThreads) void xgmi_one_shot_all_reduce_kernel(Ar
 // instead of the one-shot kernel's whole message; same bits on every rank (each sum is computed once, by its owner).
 // Chunk c of kArThreads 16-byte vectors belongs to workgroup c % grid in ALL phases on ALL ranks, so the per-workgroup
 // flag rows pair the same data on both sides of a link; its owner is rank (c / grid) % world.
+// `kUnroll` chunks of a workgroup are in flight together in every phase (a phase is a chain of dependent memory round
+// trips per chunk otherwise: 4 MiB took 39 us on local memory before, loopback).
+// epilogue 1 (rows x hidden messages, hidden <= kArThreads * 8 * 4): a chunk is a ROW, so that the workgroup that
+// gathers a row in the last phase holds all of it and finishes the operator that follows a row-parallel projection --
+// residual add + RMSNorm (layernorm.py:777-826), as in the one-shot kernel -- instead of a second launch reading the sum.
 template <int WORLD>
 __global__ __launch_bounds__(kArThreads) void xgmi_two_stage_all_reduce_kernel(ArParams p, int64_t sums_offset) {
+  constexpr int kUnroll = 4;
+  __shared__ float scratch[16];
   Signal* self = reinterpret_cast<Signal*>(p.peers.base[p.rank]);
   const uint32_t flag = self->flag[blockIdx.x] + 1;
-  const int64_t nvec = p.numel / 8;
-  const int64_t nchunks = (nvec + kArThreads - 1) / kArThreads;
   uint16_t* mine = reinterpret_cast<uint16_t*>(p.peers.base[p.rank] + kDataOffset);
   uint16_t* my_sums = reinterpret_cast<uint16_t*>(p.peers.base[p.rank] + sums_offset);
-  for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
-    const int64_t i = c * kArThreads + threadIdx.x;
-    if (i < nvec) st16(mine + i * 8, ld16(p.inp + i * 8));
-  }
-  flag_barrier(p, &Signal::start, flag);
-  int64_t k = 0;
-  for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x, ++k) {
-    if (k % WORLD != p.rank) continue;
-    const int64_t i = c * kArThreads + threadIdx.x;
-    if (i < nvec) {
-      float acc[8];
-      gather_sum<WORLD>(p, i * 8, acc);
-      U4 o;
-      o.x = pack_bf2(acc[0], acc[1]); o.y = pack_bf2(acc[2], acc[3]);
-      o.z = pack_bf2(acc[4], acc[5]); o.w = pack_bf2(acc[6], acc[7]);
-      st16(my_sums + i * 8, o);
+  if (p.epilogue == 0) {
+    const int64_t nvec = p.numel / 8;
+    const int64_t nchunks = (nvec + kArThreads - 1) / kArThreads;
+    const int64_t step = static_cast<int64_t>(gridDim.x) * kUnroll;
+    // chunk c belongs to workgroup (c / kUnroll) % grid; its owner is rank (c / (kUnroll * grid)) % world
+    for (int64_t c0 = static_cast<int64_t>(blockIdx.x) * kUnroll; c0 < nchunks; c0 += step) {
+      U4 v[kUnroll];
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        const int64_t i = (c0 + u) * kArThreads + threadIdx.x;
+        if (c0 + u < nchunks && i < nvec) v[u] = ld16(p.inp + i * 8);
+      }
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        const int64_t i = (c0 + u) * kArThreads + threadIdx.x;
+        if (c0 + u < nchunks && i < nvec) st16(mine + i * 8, v[u]);
+      }
     }
-  }
-  flag_barrier(p, &Signal::mid, flag);
-  k = 0;
-  for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x, ++k) {
-    const int64_t i = c * kArThreads + threadIdx.x;
-    if (i < nvec) {
-      const int owner = static_cast<int>(k % WORLD);
-      st16(p.out + i * 8, ld16(reinterpret_cast<const uint16_t*>(p.peers.base[owner] + sums_offset) + i * 8));
+    flag_barrier(p, &Signal::start, flag);
+    int64_t k = 0;
+    for (int64_t c0 = static_cast<int64_t>(blockIdx.x) * kUnroll; c0 < nchunks; c0 += step, ++k) {
+      if (k % WORLD != p.rank) continue;
+      float acc[kUnroll][8];
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        const int64_t i = (c0 + u) * kArThreads + threadIdx.x;
+        if (c0 + u < nchunks && i < nvec) gather_sum<WORLD>(p, i * 8, acc[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        const int64_t i = (c0 + u) * kArThreads + threadIdx.x;
+        if (c0 + u < nchunks && i < nvec) {
+          U4 o;
+          o.x = pack_bf2(acc[u][0], acc[u][1]); o.y = pack_bf2(acc[u][2], acc[u][3]);
+          o.z = pack_bf2(acc[u][4], acc[u][5]); o.w = pack_bf2(acc[u][6], acc[u][7]);
+          st16(my_sums + i * 8, o);
+        }
+      }
+    }
+    flag_barrier(p, &Signal::mid, flag);
+    k = 0;
+    for (int64_t c0 = static_cast<int64_t>(blockIdx.x) * kUnroll; c0 < nchunks; c0 += step, ++k) {
+      const uint16_t* src = reinterpret_cast<const uint16_t*>(p.peers.base[k % WORLD] + sums_offset);
+      U4 v[kUnroll];
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        const int64_t i = (c0 + u) * kArThreads + threadIdx.x;
+        if (c0 + u < nchunks && i < nvec) v[u] = ld16(src + i * 8);
+      }
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        const int64_t i = (c0 + u) * kArThreads + threadIdx.x;
+        if (c0 + u < nchunks && i < nvec) st16(p.out + i * 8, v[u]);
+      }
+    }
+  } else {
+    // rows: workgroup b owns rows b, b + grid, ...; the j-th of them is summed by rank j % world
+    constexpr int kMaxVec = 4;
+    for (int r = blockIdx.x; r < p.rows; r += gridDim.x)
+      for (int c = threadIdx.x * 8; c < p.hidden; c += kArThreads * 8)
+        st16(mine + static_cast<int64_t>(r) * p.hidden + c, ld16(p.inp + static_cast<int64_t>(r) * p.hidden + c));
+    flag_barrier(p, &Signal::start, flag);
+    int j = 0;
+    for (int r = blockIdx.x; r < p.rows; r += gridDim.x, ++j) {
+      if (j % WORLD != p.rank) continue;
+#pragma unroll
+      for (int kv = 0; kv < kMaxVec; ++kv) {
+        const int c = (kv * kArThreads + threadIdx.x) * 8;
+        if (c < p.hidden) {
+          const int64_t e = static_cast<int64_t>(r) * p.hidden + c;
+          float acc[8];
+          gather_sum<WORLD>(p, e, acc);
+          U4 o;
+          o.x = pack_bf2(acc[0], acc[1]); o.y = pack_bf2(acc[2], acc[3]);
+          o.z = pack_bf2(acc[4], acc[5]); o.w = pack_bf2(acc[6], acc[7]);
+          st16(my_sums + e, o);
+        }
+      }
+    }
+    flag_barrier(p, &Signal::mid, flag);
+    j = 0;
+    for (int r = blockIdx.x; r < p.rows; r += gridDim.x, ++j) {
+      const uint16_t* src = reinterpret_cast<const uint16_t*>(p.peers.base[j % WORLD] + sums_offset);
+      // h = the owner's bf16(sum);  t = h + residual (fp32);  residual <- bf16(t);  out = bf16(t * rsqrt(mean(t^2) + eps) * w)
+      float t[kMaxVec][8];
+      float sq = 0.f;
+#pragma unroll
+      for (int kv = 0; kv < kMaxVec; ++kv) {
+        const int c = (kv * kArThreads + threadIdx.x) * 8;
+        if (c < p.hidden) {
+          const int64_t e = static_cast<int64_t>(r) * p.hidden + c;
+          const U4 hv = ld16(src + e);
+          const U4 rv = ld16(p.residual + e);
+          const uint32_t hw[4] = {hv.x, hv.y, hv.z, hv.w}, rw[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            t[kv][2 * q] = bf_lo(hw[q]) + bf_lo(rw[q]);
+            t[kv][2 * q + 1] = bf_hi(hw[q]) + bf_hi(rw[q]);
+          }
+          U4 o;
+          o.x = pack_bf2(t[kv][0], t[kv][1]); o.y = pack_bf2(t[kv][2], t[kv][3]);
+          o.z = pack_bf2(t[kv][4], t[kv][5]); o.w = pack_bf2(t[kv][6], t[kv][7]);
+          st16(p.residual + e, o);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) sq += t[kv][q] * t[kv][q];
+        }
+      }
+      sq = block_sum(sq, scratch);
+      const float rs = 1.0f / sqrtf(sq / static_cast<float>(p.hidden) + p.eps);
+#pragma unroll
+      for (int kv = 0; kv < kMaxVec; ++kv) {
+        const int c = (kv * kArThreads + threadIdx.x) * 8;
+        if (c < p.hidden) {
+          const U4 wv = ld16(p.norm_w + c);
+          const uint32_t ww[4] = {wv.x, wv.y, wv.z, wv.w};
+          U4 o;
+          o.x = pack_bf2((t[kv][0] * rs) * bf_lo(ww[0]), (t[kv][1] * rs) * bf_hi(ww[0]));
+          o.y = pack_bf2((t[kv][2] * rs) * bf_lo(ww[1]), (t[kv][3] * rs) * bf_hi(ww[1]));
+          o.z = pack_bf2((t[kv][4] * rs) * bf_lo(ww[2]), (t[kv][5] * rs) * bf_hi(ww[2]));
+          o.w = pack_bf2((t[kv][6] * rs) * bf_lo(ww[3]), (t[kv][7] * rs) * bf_hi(ww[3]));
+          st16(p.out + static_cast<int64_t>(r) * p.hidden + c, o);
+        }
+      }
     }
   }
   flag_barrier(p, &Signal::end, flag);
@@ -267,7 +372,20 @@ __global__ __launch_bounds__(kArThreads) void xgmi_all_gather_kernel(ArParams p)
 
 }  // namespace
 
+// cap on the automatic workgroup counts (tests with several ranks on ONE GPU: all their spinning workgroups must be
+// resident together); explicit num_blocks arguments are not touched
+static int g_xgmi_auto_blocks_cap = kMaxBlocks;
+
 extern "C" {
+
+int sgl_amd_xgmi_debug_auto_blocks_cap(int cap) {
+  if (cap < 1 || cap > kMaxBlocks) {
+    set_last_error("xgmi_debug_auto_blocks_cap: 1..%d", kMaxBlocks);
+    return -1;
+  }
+  g_xgmi_auto_blocks_cap = cap;
+  return 0;
+}
 
 int64_t sgl_amd_xgmi_workspace_bytes(int64_t max_message_bytes) { return kDataOffset + ((max_message_bytes + 255) / 256) * 256; }
 
@@ -340,7 +458,9 @@ int sgl_amd_xgmi_one_shot_all_reduce(const void* inp, void* out, int64_t rows, i
                                      const void* const* peer_workspaces_host, int64_t workspace_bytes, int epilogue,
                                      void* residual, const void* norm_weight, float eps, int num_blocks, void* stream) {
   SGL_CLEAR_STALE_ERROR();
-  SGL_CHECK_ARG(world == 2 || world == 4 || world == 8, "xgmi_one_shot_all_reduce: world=%d (supported: 2, 4, 8)", world);
+  // world 1 = loopback: the rank-shape benchmarks run one rank of a TP job on one GPU with the collectives' launches
+  // (copy, flag barriers, sum of one copy, epilogue) in place and only the wire missing
+  SGL_CHECK_ARG(world == 1 || world == 2 || world == 4 || world == 8, "xgmi_one_shot_all_reduce: world=%d (supported: 1, 2, 4, 8)", world);
   SGL_CHECK_ARG(rank >= 0 && rank < world && peer_workspaces_host, "xgmi_one_shot_all_reduce: bad rank / peers");
   SGL_CHECK_ARG(rows >= 0 && hidden > 0 && hidden % 8 == 0, "xgmi_one_shot_all_reduce: hidden=%d must be a multiple of 8", hidden);
   if (rows == 0) return 0;
@@ -362,11 +482,13 @@ int sgl_amd_xgmi_one_shot_all_reduce(const void* inp, void* out, int64_t rows, i
   if (blocks <= 0) {
     // enough workgroups to keep ~7 links busy, never more than the flag table has rows
     const int64_t want = epilogue ? rows : (numel / 8 + kArThreads * 2 - 1) / (kArThreads * 2);
-    blocks = static_cast<int>(want < 1 ? 1 : (want > 32 ? 32 : want));
+    blocks = static_cast<int>(want < 1 ? 1 : (want > 64 ? 64 : want));
+    if (blocks > g_xgmi_auto_blocks_cap) blocks = g_xgmi_auto_blocks_cap;
   }
   SGL_CHECK_ARG(blocks >= 1 && blocks <= kMaxBlocks, "xgmi_one_shot_all_reduce: num_blocks=%d (1..%d)", blocks, kMaxBlocks);
   hipStream_t st = as_stream(stream);
   switch (world) {
+    case 1: hipLaunchKernelGGL(xgmi_one_shot_all_reduce_kernel<1>, dim3(blocks), dim3(kArThreads), 0, st, p); break;
     case 2: hipLaunchKernelGGL(xgmi_one_shot_all_reduce_kernel<2>, dim3(blocks), dim3(kArThreads), 0, st, p); break;
     case 4: hipLaunchKernelGGL(xgmi_one_shot_all_reduce_kernel<4>, dim3(blocks), dim3(kArThreads), 0, st, p); break;
     default: hipLaunchKernelGGL(xgmi_one_shot_all_reduce_kernel<8>, dim3(blocks), dim3(kArThreads), 0, st, p); break;
@@ -386,7 +508,7 @@ int sgl_amd_xgmi_arm(void* workspace, int trap_on_timeout) {
 
 // shared argument checks of the two collectives below
 static int fill_peers(const char* who, ArParams* p, int rank, int world, const void* const* peer_workspaces_host) {
-  SGL_CHECK_ARG(world == 2 || world == 4 || world == 8, "%s: world=%d (supported: 2, 4, 8)", who, world);
+  SGL_CHECK_ARG(world == 1 || world == 2 || world == 4 || world == 8, "%s: world=%d (supported: 1, 2, 4, 8)", who, world);
   SGL_CHECK_ARG(rank >= 0 && rank < world && peer_workspaces_host, "%s: bad rank / peers", who);
   for (int r = 0; r < world; ++r) {
     SGL_CHECK_ARG(peer_workspaces_host[r], "%s: peer %d is not mapped", who, r);
@@ -396,12 +518,16 @@ static int fill_peers(const char* who, ArParams* p, int rank, int world, const v
   return 0;
 }
 
-int sgl_amd_xgmi_two_stage_all_reduce(const void* inp, void* out, int64_t numel, int rank, int world,
-                                      const void* const* peer_workspaces_host, int64_t workspace_bytes, int num_blocks,
-                                      void* stream) {
+int sgl_amd_xgmi_two_stage_all_reduce(const void* inp, void* out, int64_t rows, int hidden, int rank, int world,
+                                      const void* const* peer_workspaces_host, int64_t workspace_bytes, int epilogue,
+                                      void* residual, const void* norm_weight, float eps, int num_blocks, void* stream) {
   SGL_CLEAR_STALE_ERROR();
-  SGL_CHECK_ARG(numel >= 0 && numel % 8 == 0 && inp && out, "xgmi_two_stage_all_reduce: numel=%lld must be a multiple of 8", (long long)numel);
-  if (numel == 0) return 0;
+  SGL_CHECK_ARG(rows >= 0 && hidden > 0 && hidden % 8 == 0 && inp && out, "xgmi_two_stage_all_reduce: hidden=%d must be a multiple of 8", hidden);
+  if (rows == 0) return 0;
+  const int64_t numel = rows * hidden;
+  SGL_CHECK_ARG(epilogue == 0 || epilogue == 1, "xgmi_two_stage_all_reduce: epilogue must be 0 (none) or 1 (add_rmsnorm)");
+  SGL_CHECK_ARG(epilogue == 0 || (residual && norm_weight && hidden <= kArThreads * 8 * 4),
+                "xgmi_two_stage_all_reduce: add_rmsnorm needs residual, norm_weight and hidden <= %d", kArThreads * 8 * 4);
   // the workspace's data area is cut in two: copies of the inputs, then the published sums
   const int64_t half = ((workspace_bytes - kDataOffset) / 2) / 256 * 256;
   SGL_CHECK_ARG(numel * 2 <= half, "xgmi_two_stage_all_reduce: message of %lld bytes needs a workspace of %lld (have %lld)",
@@ -409,15 +535,19 @@ int sgl_amd_xgmi_two_stage_all_reduce(const void* inp, void* out, int64_t numel,
   ArParams p{};
   if (int rc = fill_peers("xgmi_two_stage_all_reduce", &p, rank, world, peer_workspaces_host)) return rc;
   p.inp = static_cast<const uint16_t*>(inp); p.out = static_cast<uint16_t*>(out); p.numel = numel;
+  p.rows = static_cast<int>(rows); p.hidden = hidden; p.epilogue = epilogue; p.eps = eps;
+  p.residual = static_cast<uint16_t*>(residual); p.norm_w = static_cast<const uint16_t*>(norm_weight);
   int blocks = num_blocks;
   if (blocks <= 0) {
-    const int64_t chunks = (numel / 8 + kArThreads - 1) / kArThreads;
-    blocks = static_cast<int>(chunks < kMaxBlocks ? (chunks < 1 ? 1 : chunks) : kMaxBlocks);
+    const int64_t units = epilogue ? rows : ((numel / 8 + kArThreads - 1) / kArThreads + 3) / 4;
+    blocks = static_cast<int>(units < kMaxBlocks ? (units < 1 ? 1 : units) : kMaxBlocks);
+    if (blocks > g_xgmi_auto_blocks_cap) blocks = g_xgmi_auto_blocks_cap;
   }
   SGL_CHECK_ARG(blocks >= 1 && blocks <= kMaxBlocks, "xgmi_two_stage_all_reduce: num_blocks=%d (1..%d)", blocks, kMaxBlocks);
   hipStream_t st = as_stream(stream);
   const int64_t off = kDataOffset + half;
   switch (world) {
+    case 1: hipLaunchKernelGGL(xgmi_two_stage_all_reduce_kernel<1>, dim3(blocks), dim3(kArThreads), 0, st, p, off); break;
     case 2: hipLaunchKernelGGL(xgmi_two_stage_all_reduce_kernel<2>, dim3(blocks), dim3(kArThreads), 0, st, p, off); break;
     case 4: hipLaunchKernelGGL(xgmi_two_stage_all_reduce_kernel<4>, dim3(blocks), dim3(kArThreads), 0, st, p, off); break;
     default: hipLaunchKernelGGL(xgmi_two_stage_all_reduce_kernel<8>, dim3(blocks), dim3(kArThreads), 0, st, p, off); break;
@@ -443,10 +573,12 @@ int sgl_amd_xgmi_all_gather(const void* inp, void* out, int64_t rows, int cols_p
   if (blocks <= 0) {
     const int64_t chunks = (numel / 8 + kArThreads - 1) / kArThreads;
     blocks = static_cast<int>(chunks < kMaxBlocks ? (chunks < 1 ? 1 : chunks) : kMaxBlocks);
+    if (blocks > g_xgmi_auto_blocks_cap) blocks = g_xgmi_auto_blocks_cap;
   }
   SGL_CHECK_ARG(blocks >= 1 && blocks <= kMaxBlocks, "xgmi_all_gather: num_blocks=%d (1..%d)", blocks, kMaxBlocks);
   hipStream_t st = as_stream(stream);
   switch (world) {
+    case 1: hipLaunchKernelGGL(xgmi_all_gather_kernel<1>, dim3(blocks), dim3(kArThreads), 0, st, p); break;
     case 2: hipLaunchKernelGGL(xgmi_all_gather_kernel<2>, dim3(blocks), dim3(kArThreads), 0, st, p); break;
     case 4: hipLaunchKernelGGL(xgmi_all_gather_kernel<4>, dim3(blocks), dim3(kArThreads), 0, st, p); break;
     default: hipLaunchKernelGGL(xgmi_all_gather_kernel<8>, dim3(blocks), dim3(kArThreads), 0, st, p); break;

@@ -18,6 +18,20 @@ _TP_CPU_GROUP = None      # gloo group of the same ranks: control-plane exchange
 _TP_SIZE = 1
 _TP_RANK = 0
 _XGMI = None              # one-shot all-reduce communicator (decode-sized messages), None = RCCL only
+_EMULATED = None          # (rank, size): ONE rank of a TP job on one GPU, collectives = world-of-1 loopback launches
+
+
+def emulate_tensor_parallel_rank(rank: int, size: int, device) -> None:
+    """Rank-shape runs (bench.py --rank-of, tests): this process plays rank `rank` of a TP=`size` job on ONE GPU.
+    Models build that rank's weight shards and take the TP>1 code paths; every collective is the xGMI kernel of the
+    real job launched over a world of one (copy into the workspace, flag barriers, the sum of one copy, the fused
+    epilogue -- everything but the wire), so the launches sit in the decode graph where the real ones would.
+    Messages outside the kernels' sizes pass through unchanged.  NOT a multi-GPU measurement."""
+    global _TP_SIZE, _TP_RANK, _XGMI, _EMULATED
+    from .xgmi_all_reduce import XgmiAllReduce
+
+    _TP_SIZE, _TP_RANK, _EMULATED = size, rank, (rank, size)
+    _XGMI = XgmiAllReduce(None, 0, 1, device, handle_exchange=lambda h: [h])
 
 
 def init_distributed_environment(backend: Optional[str] = None, tp_size: Optional[int] = None,
@@ -104,7 +118,8 @@ def _start_xgmi():
 
 
 def destroy() -> None:
-    global _TP_GROUP, _TP_SIZE, _TP_RANK, _TP_CPU_GROUP, _XGMI
+    global _TP_GROUP, _TP_SIZE, _TP_RANK, _TP_CPU_GROUP, _XGMI, _EMULATED
+    _EMULATED = None
     if _XGMI is not None:
         torch.cuda.synchronize()
         if dist.is_initialized():
@@ -140,6 +155,8 @@ def tensor_model_parallel_all_reduce(x: torch.Tensor) -> torch.Tensor:
         return x
     if _XGMI is not None and (_XGMI.should_use(x) or _XGMI.should_use_two_stage(x)):
         return _XGMI.all_reduce_any(x)
+    if _EMULATED is not None:
+        return x
     dist.all_reduce(x, group=_TP_GROUP)
     return x
 
@@ -151,8 +168,9 @@ def tensor_model_parallel_all_reduce_add_rmsnorm(x: torch.Tensor, residual: torc
     With the one-shot communicator this is ONE kernel (sum + residual add + norm in the all-reduce's epilogue)."""
     from .. import kernels
 
-    if _TP_SIZE > 1 and _XGMI is not None and _XGMI.should_use(x) and residual.is_contiguous():
-        return _XGMI.all_reduce(x, residual=residual, norm_weight=norm_weight, eps=eps)
+    if (_TP_SIZE > 1 and _XGMI is not None and residual.is_contiguous() and x.shape[-1] <= 16384
+            and (_XGMI.should_use(x) or _XGMI.should_use_two_stage(x))):
+        return _XGMI.all_reduce_add_rmsnorm(x, residual, norm_weight, eps)
     x = tensor_model_parallel_all_reduce(x)
     kernels.fused_add_rmsnorm(x, residual, norm_weight, eps)
     return x
@@ -167,7 +185,7 @@ def row_parallel_linear(x: torch.Tensor, weight: torch.Tensor, min_rows_per_chun
     the GEMM that produced it takes -- hiding it is worth one extra GEMM launch per piece."""
     rows = x.shape[0]
     n = min(max_chunks, rows // max(1, min_rows_per_chunk))
-    if _TP_SIZE == 1 or n <= 1:
+    if _TP_SIZE == 1 or n <= 1 or _EMULATED is not None:
         return tensor_model_parallel_all_reduce(torch.nn.functional.linear(x, weight))
     out = torch.empty((rows, weight.shape[0]), dtype=x.dtype, device=x.device)
     step = (rows + n - 1) // n
@@ -187,8 +205,10 @@ def tensor_model_parallel_all_gather(x: torch.Tensor, dim: int = -1) -> torch.Te
     if dim < 0:
         dim += x.dim()
     if (_XGMI is not None and not _XGMI.disabled and x.is_cuda and x.dim() == 2 and dim == 1 and x.dtype == torch.bfloat16
-            and x.shape[1] % 8 == 0 and 8192 + x.numel() * 2 <= _XGMI.ws_bytes):
+            and x.shape[1] % 8 == 0 and 32768 + x.numel() * 2 <= _XGMI.ws_bytes):
         return _XGMI.all_gather(x.contiguous())          # one launch on the current stream: the decode graph holds no RCCL node
+    if _EMULATED is not None:
+        return x                                        # (loopback: the rank's own shard)
     if x.is_cuda and dist.get_backend(_TP_GROUP) == "gloo":
         # gloo moves device tensors only for broadcast / all_reduce: stage through the host (two ranks on one GPU in
         # the single-device tests; a real node runs RCCL)

@@ -4,7 +4,7 @@ Takes the place of `CustomAllreduce` (/root/reference/python/sglang/srt/distribu
 custom_all_reduce.py:40-340: buffer creation + IPC handle exchange :182-258, `should_custom_ar` :260-290, the
 dispatch :292-340) under `GroupCoordinator.all_reduce` (srt/distributed/parallel_state.py:648-758).
 
-One workspace per rank (8 KiB of flags + a data area for the largest message), allocated by the library as its own
+One workspace per rank (32 KiB of flags + a data area for the largest message), allocated by the library as its own
 uncached hipMalloc so that it can be exported; the 64-byte hipIpcMemHandles travel through the (CPU / gloo or RCCL)
 process group once, every rank maps every peer's workspace, and from then on a call is ONE kernel launch on the
 current stream with no host state -- it records into the decode hipGraph like any other kernel, no
@@ -40,8 +40,8 @@ class XgmiAllReduce:
         """`group`: a process group every rank of the TP group is in (used once, for the handle exchange; may be a
         gloo group).  `handle_exchange(bytes) -> List[bytes]` overrides the collective (tests)."""
         lib = native.lib()
-        if world not in (2, 4, 8) or world > lib.sgl_amd_xgmi_max_world():
-            raise ValueError(f"XgmiAllReduce: world size {world} (supported: 2, 4, 8)")
+        if world not in (1, 2, 4, 8) or world > lib.sgl_amd_xgmi_max_world():
+            raise ValueError(f"XgmiAllReduce: world size {world} (supported: 2, 4, 8; 1 = loopback for rank-shape runs)")
         self.rank, self.world, self.device = rank, world, device
         self.max_bytes = int(max_bytes)
         self.two_stage_bytes = int(two_stage_bytes)
@@ -115,8 +115,8 @@ class XgmiAllReduce:
         return out
 
     def should_use_two_stage(self, x: torch.Tensor) -> bool:
-        return (not self.disabled and x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and x.numel() % 8 == 0
-                and 0 < x.numel() * 2 <= self.two_stage_bytes)
+        return (not self.disabled and x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and x.dim() >= 1
+                and x.shape[-1] % 8 == 0 and 0 < x.numel() * 2 <= self.two_stage_bytes)
 
     def all_reduce_any(self, x: torch.Tensor) -> torch.Tensor:
         """The reference's dispatch (custom_all_reduce.py:292-340): one-shot below the size where link traffic starts to
@@ -125,19 +125,35 @@ class XgmiAllReduce:
             return self.all_reduce(x)
         return self.two_stage_all_reduce(x)
 
-    def two_stage_all_reduce(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, num_blocks: int = 0) -> torch.Tensor:
-        if not self.should_use_two_stage(x):
-            raise ValueError(f"XgmiAllReduce.two_stage_all_reduce: bf16, contiguous, numel % 8 == 0, <= {self.two_stage_bytes} bytes")
+    def two_stage_all_reduce(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, num_blocks: int = 0, *,
+                             residual: Optional[torch.Tensor] = None, norm_weight: Optional[torch.Tensor] = None,
+                             eps: float = 0.0) -> torch.Tensor:
+        if not self.should_use_two_stage(x) or x.shape[-1] % 8 != 0:
+            raise ValueError(f"XgmiAllReduce.two_stage_all_reduce: bf16, contiguous, last dim % 8 == 0, <= {self.two_stage_bytes} bytes")
         if out is None:
             out = torch.empty_like(x)
-        native.call("sgl_amd_xgmi_two_stage_all_reduce", x.data_ptr(), out.data_ptr(), x.numel(), self.rank, self.world, self._peers,
-                    self.ws_bytes, int(num_blocks), torch.cuda.current_stream().cuda_stream)
+        hidden = x.shape[-1]
+        epilogue = 0
+        if residual is not None:
+            if norm_weight is None or residual.shape != x.shape or not residual.is_contiguous() or hidden > 16384:
+                raise ValueError("XgmiAllReduce.two_stage_all_reduce: add_rmsnorm needs a contiguous residual of x's shape, norm_weight, hidden <= 16384")
+            epilogue = 1
+        native.call("sgl_amd_xgmi_two_stage_all_reduce", x.data_ptr(), out.data_ptr(), x.numel() // hidden, hidden, self.rank, self.world,
+                    self._peers, self.ws_bytes, epilogue, residual.data_ptr() if residual is not None else None,
+                    norm_weight.data_ptr() if norm_weight is not None else None, float(eps), int(num_blocks),
+                    torch.cuda.current_stream().cuda_stream)
         return out
+
+    def all_reduce_add_rmsnorm(self, x: torch.Tensor, residual: torch.Tensor, norm_weight: torch.Tensor, eps: float) -> torch.Tensor:
+        """RMSNorm(all_reduce(x) + residual) in ONE launch whatever the size class (residual updated in place)."""
+        if self.should_use(x) and x.numel() * 2 <= one_shot_limit(self.world, self.max_bytes):
+            return self.all_reduce(x, residual=residual, norm_weight=norm_weight, eps=eps)
+        return self.two_stage_all_reduce(x, residual=residual, norm_weight=norm_weight, eps=eps)
 
     def all_gather(self, x: torch.Tensor, num_blocks: int = 0) -> torch.Tensor:
         """[rows, cols] per rank -> [rows, world * cols] (tensor_model_parallel_all_gather(dim=-1) of a 2-D tensor)."""
         if not (x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and x.dim() == 2 and x.shape[1] % 8 == 0
-                and 8192 + x.numel() * 2 <= self.ws_bytes):
+                and 32768 + x.numel() * 2 <= self.ws_bytes):
             raise ValueError("XgmiAllReduce.all_gather: 2-D contiguous bf16 shard with cols % 8 == 0 that fits the workspace")
         out = torch.empty((x.shape[0], x.shape[1] * self.world), dtype=x.dtype, device=x.device)
         native.call("sgl_amd_xgmi_all_gather", x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], self.rank, self.world, self._peers,

@@ -293,9 +293,10 @@ class LlamaDecoderLayer(nn.Module):
         """The decode form below needs no collective between a projection and the norm behind it."""
         if OPERATOR_SURFACE_ONLY or not isinstance(self.mlp, LlamaMLP) or x.shape[1] > 16384:
             return False
-        if tp_size > 1:     # the add + norm ride in the one-shot all-reduce's epilogue
+        if tp_size > 1:     # the add + norm ride in the all-reduce's epilogue (one-shot or, for weak-scaled batches, two-stage)
             xg = ps.get_xgmi_all_reduce()
-            return xg is not None and x.is_cuda and x.dtype == BF and x.shape[0] * x.shape[1] * 2 <= xg.max_bytes
+            return (xg is not None and x.is_cuda and x.dtype == BF and x.dim() == 2
+                    and (xg.should_use(x) or xg.should_use_two_stage(x)))
         return (self.self_attn.o_proj.streams(x)
                 and kernels.wstream_preferred(x.shape[0], *self.mlp.down_proj.weight.shape))
 

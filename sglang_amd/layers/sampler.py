@@ -115,7 +115,8 @@ class Sampler(nn.Module):
         """sampler.py:497-512: MIN all-reduce of the ids (greedy and sampled alike) when requested (grammar / env)."""
         from ..distributed import parallel_state as ps
 
-        if getattr(sampling_info, "sync_token_ids_across_tp", False) and ps.get_tensor_model_parallel_world_size() > 1:
+        if (getattr(sampling_info, "sync_token_ids_across_tp", False) and ps.get_tensor_model_parallel_world_size() > 1
+                and ps.get_tp_group() is not None):
             import torch.distributed as dist
 
             dist.all_reduce(ids, op=dist.ReduceOp.MIN, group=ps.get_tp_group())

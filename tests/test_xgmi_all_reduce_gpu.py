@@ -33,6 +33,12 @@ def _worker(rank, world, port, case, q):
 
         from sglang_amd.distributed import parallel_state as ps
 
+        if world > 2:
+            # eight ranks SHARE this GPU: all their spinning workgroups must be resident at once, or the ones waiting
+            # for a CU are the ones the residents wait for (on a node every rank owns a GPU)
+            from sglang_amd import native
+
+            native.call("sgl_amd_xgmi_debug_auto_blocks_cap", 16)
         ps.init_distributed_environment(backend="gloo", device_index=0, xgmi_all_reduce=True)
         out = globals()["_case_" + case](rank, world, ps, dist)
         torch.cuda.synchronize()
@@ -145,7 +151,8 @@ def _case_add_rmsnorm(rank, world, ps, dist):
     from oracle import ops as oo
 
     dev = torch.device("cuda", 0)
-    for i, (rows, hidden) in enumerate([(64, 4096), (5, 8192), (64, 896)]):
+    # (512 x 4096 = 4 MiB: above the one-shot sizes -> the two-stage kernel's row-chunked epilogue)
+    for i, (rows, hidden) in enumerate([(64, 4096), (5, 8192), (64, 896), (512, 4096), (300, 1024)]):
         xs = _inputs(rank, world, rows, hidden, 10 + i)
         g = torch.Generator().manual_seed(77 + i)
         res0 = (torch.randn((rows, hidden), generator=g)).to(torch.bfloat16)
@@ -153,10 +160,9 @@ def _case_add_rmsnorm(rank, world, ps, dist):
         summed = torch.stack([x.float() for x in xs]).sum(0).to(torch.bfloat16)
         want_out, want_res = oo.fused_add_rmsnorm(summed, res0, w, 1e-5)
         res = res0.to(dev).clone()
-        if world > 2:
-            # eight ranks SHARE this GPU: all their spinning workgroups must be resident at once, or the ones waiting
-            # for a CU are the ones the residents wait for -- keep the launches small (on a node every rank owns a GPU)
-            out = ps.get_xgmi_all_reduce().all_reduce(xs[rank].to(dev), residual=res, norm_weight=w.to(dev), eps=1e-5, num_blocks=4)
+        xg = ps.get_xgmi_all_reduce()
+        if rows == 300:
+            out = xg.two_stage_all_reduce(xs[rank].to(dev), residual=res, norm_weight=w.to(dev), eps=1e-5)   # forced: small message
         else:
             out = ps.tensor_model_parallel_all_reduce_add_rmsnorm(xs[rank].to(dev), res, w.to(dev), 1e-5)
         assert torch.equal(res.cpu(), want_res), "residual"
