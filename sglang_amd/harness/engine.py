@@ -385,7 +385,11 @@ class Engine:
     def decode_step(self, sampling_info: Optional[SamplingBatchInfo] = None) -> torch.Tensor:
         r, dev, ps_ = self.r, self.device, self.r.page_size
         if not self.check_decode_mem():
+            before = list(self.running)
             self.waiting.extend(self.retract_decode())
+            if sampling_info is not None:               # the per-batch sampling parameters follow the survivors
+                pos = {id(q): i for i, q in enumerate(before)}
+                sampling_info = sampling_info.filter_batch([pos[id(q)] for q in self.running])
         reqs = self.running
         bs = len(reqs)
         st = self._decode_state
@@ -495,10 +499,18 @@ class Engine:
             st["free_host"].append(host)
 
     # ---- retraction under pool pressure (schedule_batch.py:2825-2925 retract_decode, mem_cache/common.py:198) ----
+    def _kv_lens(self) -> List[int]:
+        """Tokens with a KV row per running request.  With hand-offs in flight (flush_decode_outputs(lag >= 1)) the
+        requests' output_ids trail the device by the pending steps: the decode state's host-side lengths are exact."""
+        st = self._decode_state
+        if st is not None and st["bs"] == len(self.running) and all(a is b for a, b in zip(st["reqs"], self.running)):
+            return [int(x) for x in st["seq_lens_cpu"].tolist()]
+        return [q.seqlen - 1 for q in self.running]
+
     def new_tokens_required_next_decode(self) -> int:
         """schedule_batch.py:2791-2803: one slot per request, a whole page when its last page is full."""
         ps_ = self.r.page_size
-        return sum(1 for q in self.running if (q.seqlen - 1) % ps_ == 0) * ps_
+        return sum(1 for n in self._kv_lens() if n % ps_ == 0) * ps_
 
     def check_decode_mem(self) -> bool:
         alloc, tree = self.r.token_to_kv_pool_allocator, self.r.tree_cache
@@ -610,10 +622,34 @@ class Engine:
     # ---- convenience: run a set of requests to completion ---------------------------------
     def generate(self, reqs: Sequence[Req], sampling_info: Optional[SamplingBatchInfo] = None,
                  sync_every: int = 0) -> None:
+        """Run `reqs` to completion.  The scheduler loop in small: requests that a decode step retracted under pool
+        pressure wait in `self.waiting` and are prefilled again as soon as they fit (scheduler.py get_new_batch_prefill
+        over the waiting queue); finished requests leave the batch; a per-batch `sampling_info` follows the batch
+        composition through filter_batch (rows are looked up by request, so a re-admitted request keeps its own row)."""
+        row_of = {id(q): i for i, q in enumerate(reqs)}
+
+        def info_for(batch: Sequence[Req]):
+            return sampling_info.filter_batch([row_of[id(q)] for q in batch]) if sampling_info is not None else None
+
         self.prefill(reqs, sampling_info)
-        steps = max(q.max_new_tokens for q in reqs) - 1
-        for i in range(steps):
-            self.decode_step(sampling_info)
-            if sync_every and (i + 1) % sync_every == 0:
-                self.flush_decode_outputs()
-        self.finish(list(self.running))
+        del sync_every                                  # kept for callers; every step is handed off before the next here
+        steps = 0
+        limit = 4 * sum(q.max_new_tokens for q in reqs) + 16
+        cur_key, cur_info = None, None
+        while self.running or self.waiting:
+            steps += 1
+            if steps > limit:
+                raise RuntimeError("Engine.generate: no progress (pool too small for a single request?)")
+            if self.waiting and (not self.running or self._fits_with(self.waiting[0])):
+                q = self.waiting.pop(0)
+                self.prefill([q], info_for([q]))
+                continue
+            self.flush_decode_outputs()                 # (this convenience loop looks at every step's tokens before the next)
+            done = [q for q in self.running if q.finished()]
+            if done:
+                self.finish(done)
+                continue
+            key = tuple(id(q) for q in self.running)
+            if key != cur_key:
+                cur_key, cur_info = key, info_for(self.running)
+            self.decode_step(cur_info)                  # (a retraction inside the step filters cur_info down to the survivors)

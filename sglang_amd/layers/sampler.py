@@ -27,6 +27,14 @@ class SamplingBatchInfo:
     sampling_seed: Optional[torch.Tensor] = None   # [B] int64 -> deterministic gumbel sampling
     sync_token_ids_across_tp: bool = False
 
+    def filter_batch(self, keep_indices) -> "SamplingBatchInfo":
+        """The rows `keep_indices` of this batch, in that order (srt/sampling/sampling_batch_info.py filter_batch: the
+        scheduler calls it when requests leave the running batch -- finished or retracted)."""
+        idx = torch.as_tensor(keep_indices, dtype=torch.int64, device=self.top_ps.device)
+        return SamplingBatchInfo(self.temperatures[idx], self.top_ps[idx], self.top_ks[idx], self.min_ps[idx], self.is_all_greedy,
+                                 self.need_top_p_sampling, self.need_top_k_sampling, self.need_min_p_sampling,
+                                 self.sampling_seed[idx] if self.sampling_seed is not None else None, self.sync_token_ids_across_tp)
+
     @classmethod
     def greedy(cls, batch: int, device) -> "SamplingBatchInfo":
         return cls(torch.ones((batch, 1), device=device), torch.ones(batch, device=device),

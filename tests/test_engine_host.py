@@ -365,3 +365,56 @@ def test_retraction_under_pool_pressure_keeps_every_token(cpu_kernels):
         assert q.all_output_ids == _expected(p, new_tokens), q.rid
     alloc, tree = runner.token_to_kv_pool_allocator, runner.tree_cache
     assert alloc.available_size() + tree.evictable_size() == size and runner.req_to_token_pool.available_size() == 4
+
+
+def test_generate_drains_retracted_requests_and_keeps_sampling_rows_with_their_requests(cpu_kernels):
+    """Engine.generate() under pool pressure: requests retracted by a decode step are prefilled again and finished (none
+    is dropped), and the per-batch sampling parameters follow the batch through every change of its composition -- each
+    forward sees exactly the rows of the requests it runs, in their order."""
+    from sglang_amd.layers.sampler import SamplingBatchInfo
+
+    rnd = random.Random(6)
+    prompts = [[rnd.randrange(VOCAB) for _ in range(n)] for n in (20, 26, 23, 29)]
+    new_tokens = 12
+    size = 20 + 26 + 23 + 29 + 4 * 3
+    runner = _ToyRunner(4, 64, size, disable_radix=True)
+    seen_rows = []
+
+    def sample(logits_output, fb):
+        info = fb.sampling_info
+        assert info is not None and info.top_ps.numel() == logits_output.next_token_logits.shape[0]
+        seen_rows.append((fb.batch_size if hasattr(fb, "batch_size") else None, info.top_ks.tolist()))
+        return logits_output.next_token_logits.argmax(-1)
+
+    runner.sample = sample
+    eng = Engine(runner)
+    reqs = [Req(i, p, new_tokens) for i, p in enumerate(prompts)]
+    orig = [list(p) for p in prompts]
+    info = SamplingBatchInfo.greedy(4, torch.device("cpu"))
+    info.top_ks = torch.tensor([11, 22, 33, 44], dtype=torch.int32)        # a tag per request
+    eng.generate(reqs, info)
+    assert eng.stats.get("retracted", 0) >= 1 and not eng.running and not eng.waiting
+    for q, p in zip(reqs, orig):
+        assert q.all_output_ids == _expected(p, new_tokens), q.rid
+    # batches of fewer than four requests ran, each with its own requests' tags
+    assert any(len(tags) < 4 for _, tags in seen_rows)
+    assert all(set(tags) <= {11, 22, 33, 44} and len(set(tags)) == len(tags) for _, tags in seen_rows)
+    alloc, tree = runner.token_to_kv_pool_allocator, runner.tree_cache
+    assert alloc.available_size() + tree.evictable_size() == size and runner.req_to_token_pool.available_size() == 4
+
+
+def test_decode_memory_check_counts_the_steps_still_in_flight(cpu_kernels):
+    """With hand-offs in flight (lag 1) output_ids trail the device by a step: the page-boundary test of
+    new_tokens_required_next_decode must use the decode state's lengths, not len(output_ids)."""
+    prompts = _prompts(1, 3, 7, seed=2)
+    runner = _ToyRunner(3, 64, 3 * 64, page_size=4)
+    eng = Engine(runner)
+    reqs = [Req(i, p, 9) for i, p in enumerate(prompts)]
+    eng.prefill(reqs)
+    for _ in range(5):
+        eng.decode_step()
+        eng.flush_decode_outputs(lag=1)
+        true_lens = [int(x) for x in eng._decode_state["seq_lens_cpu"].tolist()]
+        assert eng._kv_lens() == true_lens
+        assert eng.new_tokens_required_next_decode() == sum(1 for n in true_lens if n % 4 == 0) * 4
+        assert any(q.seqlen - 1 != n for q, n in zip(eng.running, true_lens))      # the stale figure differs
