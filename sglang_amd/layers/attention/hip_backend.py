@@ -87,6 +87,24 @@ def runner_head_dims(model_runner):
     return hq, hkv, int(kbuf.shape[-1])
 
 
+def pool_kernel_format(pool, layer=None) -> dict:
+    """(kv_fp8, k_scale, v_scale, page_size, hnd) of ANY MHA pool for the attention / store kernels: this package's
+    pool, or the reference's MHATokenToKVPool under the drop-in path (memory_pool.py:1636-1653 `dtype` / `store_dtype`,
+    :1816 `use_hnd`, `page_size`).  The format is read off the pool's own attributes, never assumed; fp8 scales are the
+    layer's host floats (radix_attention.py:129-130 k_scale_float / v_scale_float, set when a checkpoint carries
+    scales) -- never float(device tensor), which would synchronise and break graph capture."""
+    dtype = getattr(pool, "dtype", torch.bfloat16)
+    if dtype in (getattr(torch, "float8_e5m2", None), getattr(torch, "float8_e4m3fnuz", None)):
+        raise NotImplementedError(f"KV pool dtype {dtype}: the gfx950 kernels read OCP e4m3 (float8_e4m3fn) or bf16 rows")
+    fp8 = dtype == torch.float8_e4m3fn
+    ks = vs = 1.0
+    if fp8 and layer is not None:
+        ks = float(getattr(layer, "k_scale_float", None) or 1.0)
+        vs = float(getattr(layer, "v_scale_float", None) or 1.0)
+    page = int(getattr(pool, "page_size", 1) or 1)
+    return dict(kv_fp8=fp8, k_scale=ks, v_scale=vs, page_size=page, hnd=bool(getattr(pool, "use_hnd", False)) and page > 1)
+
+
 class HipAttnBackend(AttentionBackend):
     needs_cpu_seq_lens = True
     # qo_indptr / lens are sized per forward, never preallocated at (req pool + 1) (base_attn_backend.py:117-122)
@@ -108,15 +126,13 @@ class HipAttnBackend(AttentionBackend):
         self._cascade_ws = None
         self._cascade_in_graph = False
         self.debug_flags = 0
-        # RadixAttention batches share KV prefixes; the cascade decode path reads a shared prefix once
-        # per group (SGLANG_AMD_CASCADE=0 falls back to the plain paged decode kernel)
-        import os
-
-        self.enable_cascade = os.environ.get("SGLANG_AMD_CASCADE", "1") != "0" and self.head_dim in (64, 128)
+        # RadixAttention batches share KV prefixes; the cascade decode path reads a shared prefix once per group
+        # (`model_runner.enable_cascade_attention = False` keeps every batch on the plain paged decode kernel)
+        self.enable_cascade = bool(getattr(model_runner, "enable_cascade_attention", True)) and self.head_dim in (64, 128)
         # the shared-prefix kernel reads every pool format (bf16 / fp8 rows, token-major / paged head-major); layers
         # with a sliding window or a logit cap take the plain paged kernel (forward_decode)
-        pool = self.token_to_kv_pool
-        self.plain_pool = not getattr(pool, "is_fp8", False) and not getattr(pool, "use_hnd", False)
+        fmt = pool_kernel_format(self.token_to_kv_pool, None)
+        self.plain_pool = not fmt["kv_fp8"] and not fmt["hnd"]
 
     # ------------------------------------------------------------------ metadata
     def _workspace(self, batch: int, splits: int):
@@ -195,8 +211,7 @@ class HipAttnBackend(AttentionBackend):
     def _layer_options(self, layer):
         """Pool format + the per-layer attention switches the reference kernels honour (radix_attention.py:115-148:
         logit_cap, sliding_window_size, k_scale / v_scale)."""
-        pool = self.token_to_kv_pool
-        opt = pool.kernel_format(layer) if hasattr(pool, "kernel_format") else {}
+        opt = pool_kernel_format(self.token_to_kv_pool, layer)
         win = getattr(layer, "sliding_window_size", -1)
         if win is not None and win > -1:
             opt["sliding_window"] = int(win)

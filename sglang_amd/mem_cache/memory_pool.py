@@ -118,8 +118,9 @@ class MHATokenToKVPool:
     def kernel_format(self, layer=None):
         """(kv_fp8, k_scale, v_scale, page_size, hnd) for the attention / store kernels.  Scales are the layer's
         (RadixAttention.k_scale / v_scale, loaded from the checkpoint) or 1.0 (memory_pool.py:2364-2369)."""
-        ks = float(getattr(layer, "k_scale_float", None) or getattr(layer, "k_scale", None) or 1.0) if self.is_fp8 else 1.0
-        vs = float(getattr(layer, "v_scale_float", None) or getattr(layer, "v_scale", None) or 1.0) if self.is_fp8 else 1.0
+        # host floats only (radix_attention.py:129-130): float(k_scale tensor) would synchronise inside a capture
+        ks = float(getattr(layer, "k_scale_float", None) or 1.0) if self.is_fp8 else 1.0
+        vs = float(getattr(layer, "v_scale_float", None) or 1.0) if self.is_fp8 else 1.0
         return dict(kv_fp8=self.is_fp8, k_scale=ks, v_scale=vs, page_size=self.page_size, hnd=self.use_hnd)
 
     # -- accessors used by attention backends (memory_pool.py:2292-2329) -------

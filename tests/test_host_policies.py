@@ -144,3 +144,32 @@ def test_bench_helpers():
     t = bench.hbm_bytes(bench.pmc_kernel(pmc, "decode", "wstream_gemm_kernel<4, 4, 2"))
     assert t is None or 0.9 * 237e6 < t < 1.2 * 237e6
     assert bench.hbm_bytes({"FETCH_SIZE": 100.0, "WRITE_SIZE": 10.0}) == 210 * 1024 and bench.hbm_bytes({}) is None
+
+
+def test_pool_format_is_read_off_the_pool_not_assumed():
+    """The drop-in path hands HipAttnBackend the REFERENCE's MHATokenToKVPool (platform.get_mha_kv_pool_cls): its format
+    comes from `dtype` / `page_size` / `use_hnd` (memory_pool.py:1636-1653,1816), fp8 scales from the layer's host floats
+    (radix_attention.py:129-130) -- a k_scale device tensor is never converted (it would synchronise inside a capture)."""
+    import types
+
+    import torch
+
+    from sglang_amd.layers.attention.hip_backend import pool_kernel_format
+
+    ref_pool = types.SimpleNamespace(dtype=torch.float8_e4m3fn, store_dtype=torch.uint8, page_size=16, use_hnd=True)
+
+    class _NoFloat(torch.Tensor):
+        def __float__(self):
+            raise AssertionError("float(k_scale tensor): a host sync")
+
+    layer = types.SimpleNamespace(k_scale=torch.ones(1).as_subclass(_NoFloat), v_scale=torch.ones(1).as_subclass(_NoFloat),
+                                  k_scale_float=0.5, v_scale_float=2.0)
+    assert pool_kernel_format(ref_pool, layer) == dict(kv_fp8=True, k_scale=0.5, v_scale=2.0, page_size=16, hnd=True)
+    unset = types.SimpleNamespace(k_scale=None, v_scale=None, k_scale_float=None, v_scale_float=None)
+    assert pool_kernel_format(ref_pool, unset)["k_scale"] == 1.0
+    bf16 = types.SimpleNamespace(dtype=torch.bfloat16, store_dtype=torch.bfloat16, page_size=1, use_hnd=True)
+    assert pool_kernel_format(bf16, layer) == dict(kv_fp8=False, k_scale=1.0, v_scale=1.0, page_size=1, hnd=False)
+    import pytest
+
+    with pytest.raises(NotImplementedError):
+        pool_kernel_format(types.SimpleNamespace(dtype=torch.float8_e5m2, page_size=1), None)
