@@ -1,0 +1,160 @@
+"""The TP=1 decode step of a Llama-style decoder as 9 launches per layer, on ANY model object wired like the reference's.
+
+What `LlamaModel.forward` (/root/reference/python/sglang/srt/models/llama.py:419-470) computes for a decode batch --
+per layer `input_layernorm -> qkv_proj -> rotary_emb (+ KV store) -> attn -> o_proj -> post_attention_layernorm ->
+gate_up_proj -> act_fn -> down_proj` (:341-370), then `norm` -- with every residual-add + RMSNorm executed by the
+PRECEDING projection's split-K combine kernel, rope + the KV-row store by the qkv projection's combine, SiLU-mul in the
+gate_up GEMM's epilogue:
+
+    wstream_qkv_rope -> attention (+ merge) -> o_proj GEMM + combine(add, norm) -> gate_up GEMM (silu epilogue)
+    -> down_proj GEMM + combine(add, NEXT layer's input norm)
+
+Same arithmetic and rounding points as the operator-by-operator path (tests/test_layer_parity_gpu.py feeds both with
+the oracle's inputs).  The functions below read the model through the attribute names the reference's classes carry
+(`layers[i].self_attn.{qkv_proj, o_proj, rotary_emb, attn}`, `.mlp.{gate_up_proj, down_proj}`, `.input_layernorm`,
+`.post_attention_layernorm`, `norm`, `embed_tokens`), so they run on the reference's `LlamaModel` unchanged --
+`plugin.load()` installs `llama_model_forward_hook` on it through the reference's own HookRegistry
+(srt/plugins/hook_registry.py:84 register, :146 apply_hooks; HookType.AROUND) -- and on this package's harness
+models (harness/models.py), which is how bench.py measures exactly what the plug-in delivers.
+
+Everything outside this form (prefill, TP > 1, pipeline stages, quantised or biased-MLP layers, MoE, captured aux
+hidden states, batches the weight-streaming GEMM does not take) goes to the original forward -- the reference's own
+code -- so the hook can never change a result it does not own.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import kernels
+
+_BF16 = torch.bfloat16
+
+
+def _plain_linear(lin) -> bool:
+    """An unquantised bf16 projection (UnquantizedLinearMethod, linear.py:1596-1660): weight [N, K] bf16, K contiguous."""
+    w = getattr(lin, "weight", None)
+    if w is None or w.dtype != _BF16 or w.dim() != 2 or w.stride(1) != 1 or not w.is_cuda:
+        return False
+    qm = getattr(lin, "quant_method", None)
+    return qm is None or type(qm).__name__ == "UnquantizedLinearMethod"
+
+
+def layer_fusable(layer, rows: int) -> bool:
+    """The layer is a dense Llama-style block whose four projections the weight-streaming GEMM takes at `rows` rows."""
+    attn, mlp = getattr(layer, "self_attn", None), getattr(layer, "mlp", None)
+    if attn is None or mlp is None or not hasattr(mlp, "gate_up_proj") or not hasattr(mlp, "down_proj"):
+        return False
+    lins = (attn.qkv_proj, attn.o_proj, mlp.gate_up_proj, mlp.down_proj)
+    if not all(_plain_linear(l) for l in lins):
+        return False
+    if getattr(attn.o_proj, "bias", None) is not None or getattr(mlp.gate_up_proj, "bias", None) is not None \
+            or getattr(mlp.down_proj, "bias", None) is not None:
+        return False
+    rope = attn.rotary_emb
+    if not getattr(rope, "is_neox_style", False) or getattr(rope, "rotary_dim", attn.head_dim) != attn.head_dim:
+        return False
+    if any(hasattr(attn, n) for n in ("q_norm", "k_norm")):            # (qwen3-style per-head norms: another layer form)
+        return False
+    hidden = attn.qkv_proj.weight.shape[1]
+    if hidden % 128 != 0 or hidden > 16384 or mlp.gate_up_proj.weight.shape[0] % 32 != 0:
+        return False
+    return all(kernels.wstream_preferred(rows, *l.weight.shape) for l in lins)
+
+
+def decode_layer(layer, positions: torch.Tensor, normed: torch.Tensor, forward_batch, residual: torch.Tensor,
+                 next_norm) -> torch.Tensor:
+    """One layer of the fused form: `normed` = this layer's input_layernorm output (row-major or chunk-major), `residual`
+    the residual stream (updated in place); returns next_norm(residual') -- chunk-major -- for the next layer / lm_head."""
+    from .layers.attention.hip_backend import pool_kernel_format
+
+    attn, mlp = layer.self_attn, layer.mlp
+    pool = forward_batch.token_to_kv_pool
+    layer_id = attn.attn.layer_id
+    fmt = pool_kernel_format(pool, attn.attn)
+    plain = not fmt["kv_fp8"] and not fmt["hnd"]
+    bias = getattr(attn.qkv_proj, "bias", None)
+    q = kernels.wstream_qkv_rope(normed, attn.qkv_proj.weight.data, bias.data if bias is not None else None, positions,
+                                 attn.rotary_emb.cos_sin_cache, attn.num_heads, attn.num_kv_heads, attn.head_dim,
+                                 pool.get_key_buffer(layer_id), pool.get_value_buffer(layer_id), forward_batch.out_cache_loc,
+                                 **({} if plain else fmt))
+    a = attn.attn(q, None, None, forward_batch, save_kv_cache=False)
+    post = layer.post_attention_layernorm
+    x = kernels.wstream_gemm(a, attn.o_proj.weight.data, epilogue="add_rmsnorm", residual=residual, norm_weight=post.weight.data,
+                             eps=post.variance_epsilon, out_blocked=True)
+    act = kernels.wstream_gemm(x, mlp.gate_up_proj.weight.data, epilogue="silu_and_mul",
+                               out_blocked=mlp.gate_up_proj.weight.shape[0] % 256 == 0)
+    return kernels.wstream_gemm(act, mlp.down_proj.weight.data, epilogue="add_rmsnorm", residual=residual,
+                                norm_weight=next_norm.weight.data, eps=next_norm.variance_epsilon, out_blocked=True)
+
+
+def decode_model(model, hidden_states: torch.Tensor, positions: torch.Tensor, forward_batch) -> torch.Tensor:
+    """The layer loop + final norm of LlamaModel.forward for a decode batch: returns norm(...) row-major [M, hidden]."""
+    layers = model.layers
+    residual = hidden_states                     # the embedding output becomes the residual stream (llama.py:349-353)
+    x = kernels.rmsnorm(hidden_states, layers[0].input_layernorm.weight.data, layers[0].input_layernorm.variance_epsilon)
+    for i, layer in enumerate(layers):
+        nxt = layers[i + 1].input_layernorm if i + 1 < len(layers) else model.norm
+        x = decode_layer(layer, positions, x, forward_batch, residual, nxt)
+    return x
+
+
+def model_fusable(model, hidden_states: torch.Tensor, forward_batch) -> bool:
+    if not (hidden_states.is_cuda and hidden_states.dtype == _BF16 and hidden_states.dim() == 2):
+        return False
+    mode = getattr(forward_batch, "forward_mode", None)
+    if mode is None or not mode.is_decode():
+        return False
+    rows = hidden_states.shape[0]
+    return len(model.layers) > 0 and all(layer_fusable(l, rows) for l in model.layers)
+
+
+def llama_model_forward_hook(original, self, input_ids, positions, forward_batch, input_embeds=None, pp_proxy_tensors=None):
+    """HookType.AROUND on sglang.srt.models.llama.LlamaModel.forward (llama.py:419-470).  Decode batches of a single
+    pipeline stage at TP = 1 run the fused layer loop; anything else is the reference's own forward."""
+    try:
+        ok = _reference_model_applies(self, forward_batch, input_embeds, pp_proxy_tensors)
+    except Exception:
+        ok = False
+    if ok:
+        hidden_states = self.embed_tokens(input_ids)
+        if model_fusable(self, hidden_states, forward_batch):
+            return kernels.unblock(decode_model(self, hidden_states, positions, forward_batch))
+    return original(self, input_ids, positions, forward_batch, input_embeds, pp_proxy_tensors)
+
+
+def _reference_model_applies(model, forward_batch, input_embeds, pp_proxy_tensors) -> bool:
+    if input_embeds is not None or pp_proxy_tensors is not None or getattr(model, "layers_to_capture", None):
+        return False
+    pp = getattr(model, "pp_group", None)
+    if pp is not None and not (pp.is_first_rank and pp.is_last_rank):
+        return False
+    if getattr(model, "start_layer", 0) != 0 or getattr(model, "end_layer", len(model.layers)) != len(model.layers):
+        return False
+    if _tp_size() != 1:
+        return False
+    mode = getattr(forward_batch, "forward_mode", None)
+    return mode is not None and mode.is_decode()
+
+
+def _tp_size() -> int:
+    """The reference's tensor-parallel degree (srt/runtime_context.py get_parallel().tp_size) when running under it,
+    else this package's own process group."""
+    try:
+        from sglang.srt.runtime_context import get_parallel
+
+        return int(get_parallel().tp_size)
+    except Exception:
+        from .distributed import parallel_state as ps
+
+        return ps.get_tensor_model_parallel_world_size()
+
+
+HOOK_TARGETS = ("sglang.srt.models.llama.LlamaModel.forward",)
+
+
+def install(registry, hook_type_around) -> None:
+    """plugin.load(): HookRegistry.register(target, hook, HookType.AROUND) for every model class of this form."""
+    for target in HOOK_TARGETS:
+        registry.register(target, llama_model_forward_hook, hook_type_around)

@@ -67,6 +67,17 @@ def load() -> None:
     BaseFusedOp.register_oot_forward(RotaryEmbedding, rotary_embedding.RotaryEmbedding.forward, DISPATCH_KEY)
     BaseFusedOp.register_oot_forward(TopK, hip_topk.TopK.forward, DISPATCH_KEY)
 
+    # ---- the fused TP=1 decode step (srt/plugins/hook_registry.py:84 register, :146 apply_hooks) ----------------
+    # An AROUND hook on LlamaModel.forward: decode batches run 9 launches per layer (fused_decode.py), everything else
+    # -- and every model the hook does not recognise -- the reference's own forward.  The reference applies the
+    # registered hooks once after all plug-ins are loaded (load_plugins -> HookRegistry.apply_hooks).
+    from sglang.srt.plugins.hook_registry import HookRegistry, HookType
+
+    from . import fused_decode
+
+    if not any(h is fused_decode.llama_model_forward_hook for t in fused_decode.HOOK_TARGETS for _, h, _ in HookRegistry._hooks.get(t, [])):
+        fused_decode.install(HookRegistry, HookType.AROUND)
+
 
 def _sampler_factory():
     """The factory must return a subclass of the reference Sampler (sampler.py:553-557): the gfx950 forward on

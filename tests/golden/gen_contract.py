@@ -44,6 +44,10 @@ WANT = {
     "sglang/srt/model_executor/forward_batch_info.py": ["ForwardBatch", "ForwardMode"],
     "sglang/srt/configs/model_config.py": ["ModelConfig.get_num_attention_heads", "ModelConfig.get_num_kv_heads"],
     "sglang/srt/model_executor/runner/decode_cuda_graph_runner.py": ["DecodeCudaGraphRunner"],
+    "sglang/srt/plugins/hook_registry.py": ["HookRegistry", "HookType", "_wrap_fn"],
+    "sglang/srt/models/llama.py": ["LlamaModel", "LlamaDecoderLayer", "LlamaAttention", "LlamaMLP"],
+    "sglang/srt/layers/quantization/unquant.py": ["UnquantizedLinearMethod"],
+    "sglang/srt/runtime_context.py": ["get_parallel"],
 }
 # sgl_kernel functional namespace (kernels/aot/python/sgl_kernel)
 KERNEL_NS = {
@@ -72,7 +76,9 @@ def sig(fn: ast.FunctionDef):
 
 def const(node):
     try:
-        return ast.literal_eval(node)
+        v = ast.literal_eval(node)
+        json.dumps(v)
+        return v
     except Exception:
         return ast.unparse(node)[:200]
 

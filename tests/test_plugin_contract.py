@@ -337,6 +337,51 @@ def fake_sglang(monkeypatch):
     created["sglang.srt.model_executor.runner.decode_cuda_graph_runner"].DecodeCudaGraphRunner = type("DecodeCudaGraphRunner", (), {})
     module("sglang.srt.mem_cache.allocator").PagedTokenToKVPoolAllocator = type("PagedTokenToKVPoolAllocator", (), {})
     plat_pkg._set = lambda p: current.__setitem__("platform", p)
+
+    # ---- HookRegistry (srt/plugins/hook_registry.py:67-330), restated: register() records, apply_hooks() resolves the
+    #      dotted target and wraps it; AROUND = hook(original_fn, *args, **kwargs) (:_wrap_fn) -------------------------
+    hr = created["sglang.srt.plugins.hook_registry"]
+    HookType = enum.Enum("HookType", {k: v for k, v in ref("sglang.srt.plugins.hook_registry", "HookType")["attrs"].items()})
+    hr.HookType = HookType
+
+    class HookRegistry:
+        _hooks = {}
+        _patched = set()
+
+        @classmethod
+        def register(cls, target, hook, hook_type=HookType.AFTER, *, source=None):
+            if isinstance(hook, type) and hook_type != HookType.REPLACE:
+                raise TypeError("class hooks need REPLACE")
+            cls._hooks.setdefault(target, []).append((hook_type, hook, source))
+
+        @classmethod
+        def apply_hooks(cls):
+            import functools
+            import pkgutil
+
+            for target, hooks in cls._hooks.items():
+                if target in cls._patched:
+                    continue
+                obj_path, attr = target.rsplit(".", 1)
+                obj = pkgutil.resolve_name(obj_path)
+                wrapped = getattr(obj, attr)
+                for ht, hook, _ in hooks:
+                    assert ht == HookType.AROUND, "the stand-in restates AROUND only"
+
+                    def wrapper(*args, __orig=wrapped, __hook=hook, **kwargs):
+                        return __hook(__orig, *args, **kwargs)
+
+                    wrapped = functools.wraps(wrapped)(wrapper)
+                setattr(obj, attr, wrapped)
+                cls._patched.add(target)
+
+        @classmethod
+        def reset(cls):
+            cls._hooks.clear()
+            cls._patched.clear()
+
+    hr.HookRegistry = HookRegistry
+    created["sglang.srt.runtime_context"].get_parallel = lambda: types.SimpleNamespace(tp_size=1, tp_rank=0)
     return created
 
 
@@ -432,6 +477,69 @@ def test_plugin_load_runs_against_the_reference_contract(fake_sglang):
     assert fn(disp, q, cfg_r) == "reference-result"                       # expert biases: not silently dropped
     # loading twice must not trip the pool's duplicate check (plugins are loaded once per process, but be safe)
     plugin.load()
+
+
+def test_model_level_hook_is_registered_and_falls_through_to_the_reference_forward(fake_sglang):
+    """plugin.load() registers the fused decode step as an AROUND hook on LlamaModel.forward through the reference's own
+    HookRegistry (hook_registry.py:84 register / :146 apply_hooks).  After apply_hooks() the stand-in LlamaModel -- the
+    reference's forward signature, the reference's attribute names -- is driven through the hook: whatever the hook
+    does not own (here: CPU tensors, then prefill, pipeline proxies, captured layers, TP > 1) reaches the ORIGINAL
+    forward with the original arguments.  The fused branch itself needs the GPU: tests/test_model_hook_gpu.py."""
+    from sglang_amd import fused_decode, plugin
+
+    g = fake_sglang
+    plugin.load()
+    hr = g["sglang.srt.plugins.hook_registry"]
+    target = "sglang.srt.models.llama.LlamaModel.forward"
+    assert fused_decode.HOOK_TARGETS == (target,)
+    assert [(ht.name, h) for ht, h, _ in hr.HookRegistry._hooks[target]] == [("AROUND", fused_decode.llama_model_forward_hook)]
+    # the hook binds to the reference's forward signature: (original, self, <reference parameters>)
+    import inspect
+
+    ref_names = [p["name"] for p in ref("sglang.srt.models.llama", "LlamaModel")["methods"]["forward"]["params"]]
+    assert list(inspect.signature(fused_decode.llama_model_forward_hook).parameters) == ["original"] + ref_names
+    assert [p["name"] for p in ref("sglang.srt.models.llama", "LlamaDecoderLayer")["methods"]["forward"]["params"]] == \
+        ["self", "positions", "hidden_states", "forward_batch", "residual"]
+
+    llama = g["sglang.srt.models.llama"]
+    calls = []
+
+    def reference_forward(self, input_ids, positions, forward_batch, input_embeds=None, pp_proxy_tensors=None):
+        calls.append((input_ids, positions, forward_batch, input_embeds, pp_proxy_tensors))
+        return "reference-forward"
+
+    llama.LlamaModel.forward = reference_forward
+    hr.HookRegistry.apply_hooks()
+    assert llama.LlamaModel.forward is not reference_forward
+
+    from sglang_amd.harness.models import CONFIGS, CausalLM
+
+    inner = CausalLM(CONFIGS["tiny-llama"], torch.device("cpu"))          # the reference's attribute names on every level
+    model = llama.LlamaModel.__new__(llama.LlamaModel)
+    model.layers, model.norm, model.layers_to_capture = inner.layers, inner.norm, []
+    model.embed_tokens = lambda ids: torch.nn.functional.embedding(ids, inner.embed_tokens)
+    model.pp_group = types.SimpleNamespace(is_first_rank=True, is_last_rank=True)
+    model.start_layer, model.end_layer = 0, len(inner.layers)
+    decode = types.SimpleNamespace(forward_mode=types.SimpleNamespace(is_decode=lambda: True))
+    extend = types.SimpleNamespace(forward_mode=types.SimpleNamespace(is_decode=lambda: False))
+    ids, pos = torch.tensor([1, 2, 3]), torch.tensor([5, 6, 7])
+    # decode batch on CPU tensors: the fused form does not apply -> the reference's own forward, same arguments
+    assert model.forward(ids, pos, decode) == "reference-forward" and calls[-1][:3] == (ids, pos, decode)
+    assert model.forward(ids, pos, extend) == "reference-forward"
+    assert model.forward(ids, pos, decode, input_embeds=torch.zeros(3, 4)) == "reference-forward" and calls[-1][3] is not None
+    assert model.forward(ids, pos, decode, None, {"hidden_states": None}) == "reference-forward"
+    model.layers_to_capture = [1]
+    assert model.forward(ids, pos, decode) == "reference-forward"
+    model.layers_to_capture = []
+    g["sglang.srt.runtime_context"].get_parallel = lambda: types.SimpleNamespace(tp_size=2, tp_rank=0)
+    assert not fused_decode._reference_model_applies(model, decode, None, None)
+    g["sglang.srt.runtime_context"].get_parallel = lambda: types.SimpleNamespace(tp_size=1, tp_rank=0)
+    assert fused_decode._reference_model_applies(model, decode, None, None)
+    # the layer test the hook applies: dense unquantised neox layers qualify, a quantised projection does not
+    layer = inner.layers[0]
+    assert not fused_decode.layer_fusable(layer, 4)                        # CPU weights
+    assert len(calls) == 5
+    hr.HookRegistry.reset()
 
 
 def test_runner_config_and_quant_info_fields_the_moe_hook_reads_exist():
