@@ -566,17 +566,56 @@ def kernel_rooflines(args, cfg, runner, result, B, G, P, in_len, ctx, t_decode_s
         result["prefill_mfma"]["mfma_util_source"] = ("profiles/r02_pmc.json: sum of SQ_VALU_MFMA_BUSY_CYCLES over the "
                                                       "cold prefill's dispatches / (sum of GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)")
 
+    # (4) the sampler at the decode batch: temperature 1, top_k 50, top_p 0.9, seeded, [B, vocab]
+    # logits in the model dtype -- Sampler.forward end to end (widen, softmax_temperature, radix-select top-k / top-p,
+    # seeded gumbel arg-max) and the greedy arg-max beside it
+    from sglang_amd.layers.sampler import LogitsProcessorOutput, Sampler, SamplingBatchInfo
+
+    V = cfg.vocab_size
+    Bs = min(B, 64)
+    lg = (torch.randn((Bs, V), device=dev) * 2.0).to(torch.bfloat16)
+    info = SamplingBatchInfo(torch.ones((Bs, 1), device=dev), torch.full((Bs,), 0.9, device=dev),
+                             torch.full((Bs,), 50, dtype=torch.int32, device=dev), torch.zeros(Bs, device=dev), False,
+                             need_top_p_sampling=True, need_top_k_sampling=True,
+                             sampling_seed=torch.arange(Bs, device=dev, dtype=torch.int64) + 1234)
+    pos_s = torch.full((Bs,), in_len, dtype=torch.int64, device=dev)
+    smp = Sampler()
+    t_s = graph_time(lambda: smp(LogitsProcessorOutput(next_token_logits=lg), info, positions=pos_s), 1, reps=20)
+    t_a = graph_time(lambda: K.argmax(lg), 1, reps=20)
+    alg_s = Bs * V * 4
+    result["sampler"] = {"bound": "hbm", "kernel": "Sampler.forward: widen + softmax_temperature_kernel + sample_kernel (4-level radix "
+                                                    "select, ballot compaction, fp64 gumbel arg-max with the reference's murmur hash)",
+                         "config": {"temperature": 1.0, "top_k": 50, "top_p": 0.9, "seeded": True, "batch": Bs, "vocab": V},
+                         "us_per_call": t_s * 1e6, "algorithmic_bytes": alg_s, "achieved": alg_s / t_s / 1e9, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": alg_s / t_s / 1e9 / HBM_PEAK_GBPS,
+                         "note": "B x V x 4 B = the fp32 probabilities read once; the kernels make 5-6 passes over a row "
+                                 "(0.5 MB, L2-resident after the first), so the figure is a floor on L2 traffic, not HBM traffic",
+                         "greedy_argmax_us": t_a * 1e6, "share_of_decode_step_if_sampling": t_s / t_decode_step}
+
 
 def cpu_baseline(args, cfg, runner, prompts):
     """the oracle (reference CPU torch-native path) timed on the host cores with the identical phases
     (cold prefill of the group leader, radix-style warm prefill of the others, greedy decode), wall clock via
-    perf_counter after one warm-up forward, bounded to about --cpu-budget-s: (a) Qwen2.5-0.5B end to end
-    (BASELINE configs[0]); (b) the benchmarked model at B=4 with its GPU weights copied to the host."""
+    perf_counter after one warm-up forward, bounded to about --cpu-budget-s:
+      (a) Qwen2.5-0.5B end to end (BASELINE configs[0]) at the WORKLOAD'S OWN prompt shape -- one group of 4 prompts,
+          896 shared + 128 unique tokens in, 16 out;
+      (b) the benchmarked model at B = 4 with its GPU weights copied to the host, the prompt shape sized from two probe
+          forwards so that the leg fits the budget, with tokens and FLOPs stated so that the figure can be scaled."""
     from oracle.model import OracleLM, weights_from_product_model
     from sglang_amd.harness.models import CONFIGS, CausalLM
 
     cores = torch.get_num_threads()
     legs = {}
+
+    def flops_of(cfg_x, pre, uni, n_req, n_out):
+        pl = p_lin(cfg_x)
+        pair = 4 * cfg_x.num_hidden_layers * cfg_x.num_attention_heads * cfg_x.head_dim
+        n_in = pre + uni
+        head = 2 * cfg_x.hidden_size * cfg_x.vocab_size
+        cold = 2 * n_in * pl + pair * n_in * (n_in + 1) / 2 + head
+        warm = (n_req - 1) * (2 * uni * pl + pair * (uni * pre + uni * (uni + 1) / 2) + head)
+        dec = sum(n_req * (2 * pl + pair * (n_in + s) + head) for s in range(1, n_out))
+        return cold + warm + dec
 
     def run(cfg_x, w, pre, uni, n_req, n_out, label):
         rnd = random.Random(1)
@@ -588,35 +627,49 @@ def cpu_baseline(args, cfg, runner, prompts):
         OracleLM(cfg_x, w, num_slots=slots, max_ctx=pre + uni + n_out + 8, max_reqs=n_req).generate(
             ps_, n_out, share_prefix_groups=[list(range(n_req))], shared_len=pre)
         dt = time.perf_counter() - t0
-        return {"tokens_per_s": n_req * n_out / dt, "wall_s": dt,
+        fl = flops_of(cfg_x, pre, uni, n_req, n_out)
+        return {"tokens_per_s": n_req * n_out / dt, "wall_s": dt, "tokens_in": n_req * (pre + uni),
+                "tokens_in_computed": pre + uni + (n_req - 1) * uni, "tokens_out": n_req * n_out, "flops": fl,
+                "gflops_per_s": fl / dt / 1e9,
                 "sample": f"{label}: 1 group x {n_req} prompts, {pre} shared + {uni} unique in, {n_out} out, greedy, "
                           f"bf16, cold + radix-style warm prefill + {n_out - 1} decode steps"}
 
     budget = args.cpu_budget_s
     t_begin = time.perf_counter()
-    # (a) Qwen2.5-0.5B end to end, the workload's own phases at reduced size
+    # (a) Qwen2.5-0.5B end to end at the workload's prompt shape
     qcfg = CONFIGS["qwen2.5-0.5b"]
     qm = CausalLM(qcfg, torch.device("cpu"), "cpu")
-    legs["qwen2.5-0.5b"] = run(qcfg, weights_from_product_model(qm), 224, 32, 4, 16, "qwen2.5-0.5b end to end")
+    legs["qwen2.5-0.5b"] = run(qcfg, weights_from_product_model(qm), args.prefix, args.unique, 4, 16, "qwen2.5-0.5b end to end")
     del qm
-    # (b) the benchmarked model, B=4: sized from a one-token probe so that the leg stays inside the budget
+    # (b) the benchmarked model, B = 4: a 2-token forward costs one pass over the weights (t_w), a 64-token forward adds
+    # 62 tokens of compute -> per-token cost c; then  cold + warm + decode = 11 u c + (n_out + 1) t_w  for prompts of 7 u + u
     w = weights_from_product_model(runner.model)
-    t0 = time.perf_counter()
-    OracleLM(cfg, w, num_slots=64, max_ctx=16, max_reqs=1).generate([[1, 2]], 1)
-    probe = time.perf_counter() - t0            # one 2-token forward = one pass over the weights
-    left = budget - (time.perf_counter() - t_begin) - probe
-    n_out = 16
-    fwd = max(2, int(left / max(probe, 1e-3)))  # forwards we can afford: 2 prefill passes + n_out - 1 decode steps
-    if fwd < n_out + 1:
-        n_out = max(2, fwd - 1)
-    pre, uni = (28, 4) if fwd < 40 else (112, 16)
-    legs[cfg.name] = run(cfg, w, pre, uni, 4, n_out, f"{cfg.name} (GPU weights copied to the host)")
+
+    def probe(n):
+        t0 = time.perf_counter()
+        OracleLM(cfg, w, num_slots=n + 8, max_ctx=n + 8, max_reqs=1).generate([list(range(1, n + 1))], 1)
+        return time.perf_counter() - t0
+
+    t_w = probe(2)
+    t_64 = probe(64)
+    c_tok = max((t_64 - t_w) / 62.0, 1e-4)
+    left = max(budget - (time.perf_counter() - t_begin), 4 * t_w)
+    n_out = 16 if left > 24 * t_w else max(2, int(left / t_w / 2))
+    u = int(max(0.0, left - (n_out + 1) * t_w) / (11.0 * c_tok))
+    u = max(4, min(args.unique, u // 4 * 4))
+    pre = u * (args.prefix // max(args.unique, 1)) if args.unique else 7 * u
+    legs[cfg.name] = run(cfg, w, pre, u, 4, n_out, f"{cfg.name} (GPU weights copied to the host)")
+    legs[cfg.name]["probe"] = {"weights_pass_s": t_w, "per_prompt_token_s": c_tok}
     main_leg = legs[cfg.name]
+    # the same job on the GPU side, for scale: FLOPs of the measured workload per second of the timed run
     return {"value": main_leg["tokens_per_s"], "unit": "tokens/s", "cores": cores, "kind": "port",
             "sample": main_leg["sample"] + f"; {main_leg['wall_s']:.1f} s wall", "host_cpu_count": os.cpu_count(),
-            "legs": legs, "note": "reported baseline, not the optimisation target; prompt lengths are scaled down so "
-                                  "that the default bench.py run stays within minutes (the phases and B=4 / 16 decode "
-                                  "steps are those of SURVEY 8(d))"}
+            "tokens_in": main_leg["tokens_in"], "tokens_out": main_leg["tokens_out"], "flops": main_leg["flops"],
+            "workload_flops_ratio": flops_of(cfg, args.prefix, args.unique, args.per_group, args.out) * args.groups / main_leg["flops"],
+            "legs": legs, "note": "reported baseline, not the optimisation target.  The Qwen2.5-0.5B leg runs the workload's own "
+                                  "prompt shape (896 + 128 in, B = 4, 16 out); the leg of the benchmarked model keeps B = 4 and the "
+                                  "7 : 1 shared : unique ratio but sizes the prompts to the CPU budget -- tokens_in / tokens_out / "
+                                  "flops are stated, workload_flops_ratio = FLOPs of the whole benchmarked job / FLOPs of this sample"}
 
 
 if __name__ == "__main__":
