@@ -54,6 +54,56 @@ def encode_images(pixel_values: torch.Tensor, w: Dict[str, torch.Tensor], *, pat
     return y.reshape(-1, y.shape[-1])
 
 
+def anyres_grid(image_size, pinpoints, tile: int):
+    """multimodal/mm_utils.py:114-151,211-248 (select_best_resolution + get_anyres_image_grid_shape): (tiles across, down)."""
+    ow, oh = image_size
+    best_fit, max_eff, min_waste = None, 0, float("inf")
+    for width, height in pinpoints:
+        scale = min(width / ow, height / oh)
+        dw, dh = int(ow * scale), int(oh * scale)
+        eff = min(dw * dh, ow * oh)
+        waste = width * height - eff
+        if eff > max_eff or (eff == max_eff and waste < min_waste):
+            max_eff, min_waste, best_fit = eff, waste, (width, height)
+    return best_fit[0] // tile, best_fit[1] // tile
+
+
+def unpad(t: torch.Tensor, image_size) -> torch.Tensor:
+    """mm_utils.py:341-369 unpad_image on a [C, H, W] map."""
+    ow, oh = image_size
+    ch, cw = t.shape[1:]
+    if ow / oh > cw / ch:
+        nh = int(oh * (cw / ow))
+        p = (ch - nh) // 2
+        return t[:, p: ch - p, :]
+    nw = int(ow * (ch / oh))
+    p = (cw - nw) // 2
+    return t[:, :, p: cw - p]
+
+
+def pack_anyres(feats: torch.Tensor, image_size, pinpoints, tile: int, image_newline: torch.Tensor) -> torch.Tensor:
+    """models/llava.py:251-358 ("spatial_unpad", anyres): [1 + gw * gh, side^2, H] -> [len, H]."""
+    base, rest = feats[0], feats[1:]
+    side = int(round(base.shape[0] ** 0.5))
+    gw, gh = anyres_grid(image_size, pinpoints, tile)
+    x = rest.view(gh, gw, side, side, -1).permute(4, 0, 2, 1, 3).contiguous().flatten(1, 2).flatten(2, 3)      # [H, gh*side, gw*side]
+    x = unpad(x, image_size)
+    x = torch.cat((x, image_newline.to(x.dtype)[:, None, None].expand(*x.shape[:-1], 1)), dim=-1)
+    return torch.cat((base, x.flatten(1, 2).transpose(0, 1)), dim=0)
+
+
+def anyres_len(image_size, pinpoints, tile: int, side: int) -> int:
+    """models/llava.py:96-127: pad tokens of an anyres image."""
+    gw, gh = anyres_grid(image_size, pinpoints, tile)
+    ow, oh = image_size
+    h, w = gh * side, gw * side
+    if ow / oh > w / h:
+        nh = int(oh * (w / ow)); p = (h - nh) // 2; nh, nw = h - 2 * p, w
+    else:
+        nw = int(ow * (h / oh)); p = (w - nw) // 2; nh, nw = h, w - 2 * p
+    return side * side + nh * (nw + 1)
+
+
 def embed_with_images(input_ids: Sequence[int], embed_weight: torch.Tensor, images: List[dict]) -> torch.Tensor:
     """mm_utils.py:463-503 for ONE whole prompt: clamp, embed, overwrite [offset, offset + len) of every image."""
     ids = torch.tensor(list(input_ids), dtype=torch.int64).clamp(0, embed_weight.shape[0] - 1)

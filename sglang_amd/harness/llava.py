@@ -4,8 +4,11 @@ embedding substitution (BASELINE configs[4]: LLaVA-1.6-7B image+text prefill; SU
 Reference (/root/reference/python/sglang/srt):
   models/clip.py:51-94 (patch + class + position embeddings), :143-300 (pre-LN encoder layer: LayerNorm -> MHA ->
   residual, LayerNorm -> fc1 -> quick_gelu -> fc2 -> residual), :430-486 (pre_layrnorm, encoder);
-  models/llava.py:79-143 pad_input_ids (the image token becomes `image_feature_len` copies of the image's pad value),
-  :145-168 encode_images (hidden state of `mm_vision_select_layer` = -2, CLS dropped, projector linear-GELU-linear);
+  models/llava.py:79-143 pad_input_ids (the image token becomes `image_feature_len` copies of the image's pad value;
+  LLaVA-1.6 "anyres": base tile + the unpadded high-resolution grid with one image_newline column per row),
+  :145-168 encode_images (hidden state of `mm_vision_select_layer` = -2, CLS dropped, projector linear-GELU-linear),
+  :251-358 anyres feature packing (grid view, spatial unpad, image_newline, base tile first);
+  multimodal/mm_utils.py:114-151 select_best_resolution, :211-248 get_anyres_image_grid_shape, :341-393 unpad_image(_shape);
   managers/schedule_batch.py:147-148,220-222 pad value = 1_000_000 + hash % 2^30;
   managers/mm_utils.py:463-503 embed_mm_inputs (clamp ids into the vocabulary, embed, scatter the image features over
   the pad-value positions of the EXTEND range -- image tokens that sit in the radix-cached prefix need no encoder run).
@@ -56,6 +59,7 @@ class ClipVisionConfig:
     layer_norm_eps: float = 1e-5
     select_layer: int = -2            # mm_vision_select_layer
     select_feature: str = "patch"     # drop the class token
+    image_grid_pinpoints: Optional[List[List[int]]] = None     # LLaVA-1.6: candidate canvases of the anyres grid
 
     @property
     def num_patches(self) -> int:
@@ -70,30 +74,104 @@ TINY_CLIP = ClipVisionConfig(hidden_size=128, intermediate_size=256, num_hidden_
                              image_size=56, patch_size=14)
 
 
+LLAVA16_GRID_PINPOINTS = [[336, 672], [672, 336], [672, 672], [1008, 336], [336, 1008]]    # llava-v1.6-*-7b config.json
+
+
+def select_best_resolution(original_size: Tuple[int, int], resolutions: Sequence[Sequence[int]]) -> Tuple[int, int]:
+    """mm_utils.py:114-151: the candidate (width, height) that keeps most of the image's pixels after an
+    aspect-preserving downscale; ties go to the one that wastes the least canvas."""
+    ow, oh = original_size
+    best, best_eff, best_waste = None, 0, float("inf")
+    for w, h in resolutions:
+        scale = min(w / ow, h / oh)
+        eff = min(int(ow * scale) * int(oh * scale), ow * oh)
+        waste = w * h - eff
+        if eff > best_eff or (eff == best_eff and waste < best_waste):
+            best, best_eff, best_waste = (w, h), eff, waste
+    return best
+
+
+def get_anyres_image_grid_shape(image_size: Tuple[int, int], grid_pinpoints: Sequence[Sequence[int]], tile_size: int) -> Tuple[int, int]:
+    """mm_utils.py:211-248 for an explicit pinpoint list: (tiles across, tiles down) of the high-resolution grid."""
+    w, h = select_best_resolution(image_size, grid_pinpoints)
+    return w // tile_size, h // tile_size
+
+
+def _unpad_bounds(cur_h: int, cur_w: int, original_size: Tuple[int, int]) -> Tuple[int, int, int, int]:
+    """(row0, row1, col0, col1) of the part of a [cur_h, cur_w] feature map that the resized image covers
+    (mm_utils.py:341-393: the image was scaled to fit and centred; the padding bands carry no image)."""
+    ow, oh = original_size
+    if ow / oh > cur_w / cur_h:                       # wider than the canvas: bands above and below
+        new_h = int(oh * (cur_w / ow))
+        pad = (cur_h - new_h) // 2
+        return pad, cur_h - pad, 0, cur_w
+    new_w = int(ow * (cur_h / oh))
+    pad = (cur_w - new_w) // 2
+    return 0, cur_h, pad, cur_w - pad
+
+
+def unpad_image_shape(cur_h: int, cur_w: int, original_size: Tuple[int, int]) -> Tuple[int, int]:
+    r0, r1, c0, c1 = _unpad_bounds(cur_h, cur_w, original_size)
+    return r1 - r0, c1 - c0
+
+
+def anyres_feature_len(image_size: Tuple[int, int], grid_pinpoints, tile_size: int, side: int) -> int:
+    """llava.py:96-127: base tile (side^2 features) + the unpadded grid, every row closed by one image_newline."""
+    gw, gh = get_anyres_image_grid_shape(image_size, grid_pinpoints, tile_size)
+    nh, nw = unpad_image_shape(gh * side, gw * side, image_size)
+    return side * side + nh * (nw + 1)
+
+
+def pack_anyres_features(feats: torch.Tensor, image_size: Tuple[int, int], grid_pinpoints, tile_size: int,
+                         image_newline: torch.Tensor) -> torch.Tensor:
+    """llava.py:251-358 ("spatial_unpad"): feats [1 + gw * gh, side^2, H] -> [feature_len, H].  The grid tiles are laid
+    out as one [gh * side, gw * side] map, cropped to the part the image covers, each row gets the image_newline
+    embedding appended, rows are concatenated; the base (whole-image) tile goes first."""
+    tiles, n, hid = feats.shape
+    side = int(round(n ** 0.5))
+    gw, gh = get_anyres_image_grid_shape(image_size, grid_pinpoints, tile_size)
+    if tiles != 1 + gw * gh or side * side != n:
+        raise ValueError(f"anyres: {tiles} tiles of {n} features for a {gw} x {gh} grid of {side} x {side} tiles")
+    grid = feats[1:].view(gh, gw, side, side, hid).permute(0, 2, 1, 3, 4).reshape(gh * side, gw * side, hid)
+    r0, r1, c0, c1 = _unpad_bounds(gh * side, gw * side, image_size)
+    grid = grid[r0:r1, c0:c1]
+    nl = image_newline.to(grid.dtype).view(1, 1, hid).expand(grid.shape[0], 1, hid)
+    return torch.cat([feats[0], torch.cat([grid, nl], dim=1).reshape(-1, hid)], dim=0)
+
+
 @dataclass
 class MultimodalItem:
-    """One image of a request (schedule_batch.py MultimodalDataItem: feature, pad_value, offsets)."""
+    """One image of a request (schedule_batch.py MultimodalDataItem: feature, pad_value, offsets, image_sizes)."""
 
     pixel_values: torch.Tensor            # [tiles, 3, S, S]
     pad_value: int = 0
     offset: int = -1                      # first pad position in the padded prompt
-    length: int = 0                       # number of pad tokens (tiles * image_feature_len)
+    length: int = 0                       # number of pad tokens
+    image_size: Optional[Tuple[int, int]] = None   # (width, height) of the original image: LLaVA-1.6 anyres packing
+                                                   # (tiles = base + grid); None: fixed tiles x image_feature_len
 
     def __post_init__(self):
         if not self.pad_value:
             self.pad_value = compute_pad_value(hash_pixels(self.pixel_values))
 
 
-def pad_input_ids(input_ids: Sequence[int], image_token_index: int, items: List[MultimodalItem], feature_len: int) -> List[int]:
-    """llava.py:79-143 for fixed-resolution tiles: every occurrence of the image token becomes `tiles * feature_len`
-    copies of the item's pad value; offsets / lengths are recorded on the items."""
+def pad_input_ids(input_ids: Sequence[int], image_token_index: int, items: List[MultimodalItem], feature_len: int,
+                  grid_pinpoints=None, tile_size: Optional[int] = None) -> List[int]:
+    """llava.py:79-143: every occurrence of the image token becomes the item's pad value repeated once per image
+    feature -- `tiles * feature_len` for fixed tiles, base + unpadded grid + newlines for an anyres item (which needs the
+    model's grid pinpoints and tile size); offsets / lengths are recorded on the items."""
     ids = list(input_ids)
     for it in items:
         try:
             off = ids.index(image_token_index)
         except ValueError:
             off = 0
-        n = int(it.pixel_values.shape[0]) * feature_len
+        if it.image_size is not None:
+            if grid_pinpoints is None or tile_size is None:
+                raise ValueError("pad_input_ids: anyres items need grid_pinpoints and tile_size")
+            n = anyres_feature_len(it.image_size, grid_pinpoints, tile_size, int(round(feature_len ** 0.5)))
+        else:
+            n = int(it.pixel_values.shape[0]) * feature_len
         ids = ids[:off] + [it.pad_value] * n + ids[off + 1:]
         it.offset, it.length = off, n
     return ids
@@ -211,6 +289,9 @@ class LlavaVision(nn.Module):
         self.vcfg = vcfg
         self.tower = ClipVisionTower(vcfg, device, init_device)
         self.projector = LlavaProjector(vcfg.hidden_size, text_hidden, device, init_device)
+        # language_model.model.image_newline (llava.py:338-345): closes every row of the unpadded anyres grid
+        self.image_newline = nn.Parameter(synth_weight("model.image_newline", (text_hidden,), init_device if init_device is not None else device).to(device),
+                                          requires_grad=False)
         self.encoder_runs = 0            # tests: how many tiles went through the tower
 
     def encode_images(self, pixel_values: torch.Tensor) -> torch.Tensor:
@@ -220,6 +301,15 @@ class LlavaVision(nn.Module):
         if self.vcfg.select_feature == "patch":
             hs = hs[:, 1:]
         return self.projector(hs).reshape(-1, self.projector.w2.shape[0])
+
+    def encode_item(self, item: "MultimodalItem") -> torch.Tensor:
+        """All features of one image in prompt order: [item.length, text_hidden]."""
+        feats = self.encode_images(item.pixel_values)
+        if item.image_size is None:
+            return feats
+        tiles = int(item.pixel_values.shape[0])
+        pins = self.vcfg.image_grid_pinpoints or LLAVA16_GRID_PINPOINTS
+        return pack_anyres_features(feats.view(tiles, -1, feats.shape[-1]), item.image_size, pins, self.vcfg.image_size, self.image_newline)
 
 
 def embed_mm_inputs(input_ids: torch.Tensor, embed_weight: torch.Tensor, reqs_items: Sequence[Optional[List[MultimodalItem]]],
@@ -238,7 +328,7 @@ def embed_mm_inputs(input_ids: torch.Tensor, embed_weight: torch.Tensor, reqs_it
             if lo < hi:
                 feats = cache.get(it.pad_value)
                 if feats is None:
-                    feats = cache[it.pad_value] = vision.encode_images(it.pixel_values)
+                    feats = cache[it.pad_value] = vision.encode_item(it)
                 embeds[start + lo - pre: start + hi - pre] = feats[lo - it.offset: hi - it.offset].to(embeds.dtype)
         start += ext
     return embeds

@@ -93,6 +93,8 @@ REAL = {
     "sglang.srt.layers.rotary_embedding.rope_variant",
     "sglang.srt.layers.sampler",
     "sglang.srt.model_executor.forward_batch_info",
+    "sglang.srt.models.llava",
+    "sglang.srt.multimodal.mm_utils",
 }
 FAILED = []
 
@@ -421,12 +423,85 @@ def gen_host_int():
         clamp_position=dict(seq=[0, 1, 5, 9], out=clamp.tolist()))))
 
 
+def gen_llava_anyres():
+    """LLaVA-1.6 anyres: the reference's own pad_input_ids (models/llava.py:79-143) and the feature packing + embedding
+    substitution of LlavaBaseForCausalLM.forward (:168-460: anyres grid, spatial unpad, image_newline column, base tile
+    first, then the copy into the extend range) driven with a stand-in `self` -- vision tower and language model are
+    replaced by recorders, every line in between is the reference's."""
+    import numpy as np
+
+    lv = ref("sglang.srt.models.llava")
+    mm = ref("sglang.srt.multimodal.mm_utils")
+    if not callable(getattr(lv.flatten_nested_list, "__code__", None) and lv.flatten_nested_list):
+        # sglang.srt.utils does not import here (its third-party dependencies are absent), so llava.py holds a stub for
+        # this one list helper; it is executed from the reference's own source text (utils/common.py flatten_nested_list)
+        import ast
+
+        src = (REF / "sglang/srt/utils/common.py").read_text()
+        fn = next(n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "flatten_nested_list")
+        ns = {}
+        exec(compile(ast.Module(body=[fn], type_ignores=[]), "utils/common.py", "exec"), ns)
+        lv.flatten_nested_list = ns["flatten_nested_list"]
+    g = torch.Generator().manual_seed(16)
+    S, P, HID, VOCAB, IMG = 336, 14, 8, 100, 90
+    pinpoints = [[336, 672], [672, 336], [672, 672], [1008, 336], [336, 1008]]            # llava-v1.6 config.json
+    side = S // P
+    flen = side * side
+    newline = torch.randn(HID, generator=g).to(torch.bfloat16)
+    table = torch.randn((VOCAB, HID), generator=g).to(torch.bfloat16)
+    out = dict(image_size=S, patch_size=P, hidden=HID, vocab=VOCAB, image_token_index=IMG, pinpoints=pinpoints,
+               image_newline=newline, embed_table=table, cases=[])
+    grid_cases = []
+    for wh in [(1000, 600), (600, 1000), (640, 480), (336, 336), (2000, 500), (300, 1200), (1024, 1024), (500, 333)]:
+        gw, gh = mm.get_anyres_image_grid_shape(wh, pinpoints, S)
+        grid_cases.append(dict(size=wh, grid=(gw, gh), unpad=mm.unpad_image_shape(gh * side, gw * side, wh)))
+    out["grid_cases"] = grid_cases
+
+    captured = {}
+
+    class FakeLM:
+        def __call__(self, input_ids, positions, forward_batch, input_embeds=None):
+            captured["embeds"] = input_embeds.clone()
+            return "lm-out"
+
+    fake_lm = FakeLM()
+    fake_lm.model = types.SimpleNamespace(embed_tokens=lambda ids: torch.nn.functional.embedding(ids, table).clone(), image_newline=newline)
+    for wh, prefix_len in [((1000, 600), 0), ((600, 1000), 0), ((640, 480), 7), ((336, 336), 0), ((2000, 500), 1500)]:
+        gw, gh = mm.get_anyres_image_grid_shape(wh, pinpoints, S)
+        tiles = 1 + gw * gh
+        feats = torch.randn((tiles, flen, HID), generator=g).to(torch.bfloat16)
+
+        fake = types.SimpleNamespace(
+            config=types.SimpleNamespace(vocab_size=VOCAB, image_grid_pinpoints=pinpoints, image_aspect_ratio="anyres",
+                                         image_token_index=IMG),
+            image_grid_pinpoints=pinpoints, image_size=S, patch_size=P, image_feature_len=flen, num_patches_per_side=side,
+            mm_patch_merge_type="spatial_unpad", vision_tower=types.SimpleNamespace(device="cpu", config=types.SimpleNamespace(image_size=S)),
+            language_model=fake_lm, encode_images=lambda pix, feats=feats: feats, _infer_image_aspect_ratio=lambda items: "anyres")
+        item = types.SimpleNamespace(feature=np.zeros((tiles, 3, 2, 2), dtype=np.float32), image_sizes=[wh], pad_value=1_000_123,
+                                     modality=lv.Modality.IMAGE)
+        inputs = types.SimpleNamespace(mm_items=[item], image_offsets=None, image_pad_len=None)
+        ids = array("q", [1, 2, 3, 4, 5, 6, 7, 8, 9, IMG, 11, 12, 13])
+        padded = lv.LlavaBaseForCausalLM.pad_input_ids(fake, ids, inputs)
+        total = len(padded)
+        ext = total - prefix_len
+        fb = types.SimpleNamespace(mm_inputs=[inputs], forward_mode=types.SimpleNamespace(is_extend=lambda: True, is_decode=lambda: False),
+                                   extend_start_loc=torch.tensor([0]), extend_seq_lens=torch.tensor([ext]),
+                                   extend_prefix_lens_cpu=[prefix_len], batch_size=1)
+        in_ids = torch.tensor(list(padded[prefix_len:]), dtype=torch.int64)
+        positions = torch.arange(prefix_len, total)
+        lv.LlavaBaseForCausalLM.forward(fake, in_ids.clone(), positions, fb)
+        out["cases"].append(dict(size=wh, grid=(gw, gh), tiles=tiles, tile_features=feats, prompt=list(ids), padded=list(padded),
+                                 offsets=list(inputs.image_offsets), pad_len=list(inputs.image_pad_len), prefix_len=prefix_len,
+                                 input_embeds=captured["embeds"]))
+    torch.save(out, OUT / "llava_anyres.pt")
+
+
 def main():
     if not REF.exists():
         raise SystemExit("/root/reference not present: goldens can only be regenerated in the build container")
     install_hook()
     torch.manual_seed(0)
-    for fn in (gen_attention, gen_elementwise, gen_moe, gen_sampler, gen_radix, gen_host_int):
+    for fn in (gen_attention, gen_elementwise, gen_moe, gen_sampler, gen_radix, gen_host_int, gen_llava_anyres):
         fn()
         print("ok", fn.__name__)
     print("degraded-to-stub reference modules:", len(FAILED))
