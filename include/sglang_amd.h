@@ -401,6 +401,8 @@ int sgl_amd_xgmi_all_gather(const void* inp, void* out, int64_t rows, int cols_p
  * page_size a power of two; 0: [slots, H_kv, D].
  * sliding_window >= 0: a query at position p sees kv positions [p - window, p] (torch_native_backend.py:36-48,
  * extend_attention.py:480-485); logit_cap > 0: s <- cap * tanh(s / cap) (extend_attention.py:546-547).
+ * skip_prefix_custom_mask = 1: the mask is consulted on the extend part only, the prefix stays fully visible (the
+ * reference's call form for TARGET_VERIFY: extend_attention.py:774 default, :437 `not SKIP_PREFIX_CUSTOM_MASK`).
  * custom_mask (extend only; speculative-decoding verify, triton_backend.py:860-919): request b's
  * [extend_len, kv_len] row-major uint8 mask at custom_mask + mask_indptr[b] replaces the causal rule. */
 int sgl_amd_store_kv_cache_ex(const void* k, const void* v, void* k_cache, void* v_cache, const int64_t* loc,
@@ -425,7 +427,7 @@ int sgl_amd_extend_attention_ex(const void* q, void* out, const void* k_cache, c
                                 int64_t q_token_stride, int64_t out_token_stride,
                                 int64_t k_cache_row_stride, int64_t v_cache_row_stride, float sm_scale,
                                 int causal, int kv_fp8, float k_scale, float v_scale, int page_size, int kv_layout_hnd,
-                                int sliding_window, float logit_cap, const void* custom_mask, const int64_t* mask_indptr,
+                                int sliding_window, float logit_cap, const void* custom_mask, const int64_t* mask_indptr, int skip_prefix_custom_mask,
                                 void* stream);
 /* Test / tuning override of the extend kernel's workgroup shape (process-wide; the library never reads the
  * environment): shape 0 = automatic, 41 / 42 / 82 = waves x 16-row tiles per wave; flags bit 0 keeps bf16 8-wave

@@ -66,6 +66,7 @@ struct ExtendParams {
   // causal rule on the extend part and is AND-ed with "inside the prefix" on the prefix part
   const uint8_t* custom_mask;
   const int64_t* mask_indptr;
+  int mask_skip_prefix;         // the prefix part of the mask is not consulted (extend_attention.py:774 skip_prefix_custom_mask)
   int num_tiles, batch;         // the double-buffered kernel's 1-D grid: query tiles per request, requests
 };
 
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(64 * NWV, (MTW == 1 && NWV == 4) ? (D > 64 ? 2 : 3)
           for (int r = 0; r < 4; ++r) {
             const int kvpos = kv0 + nt * 16 + g * 4 + r;
             bool on = kvpos < row_limit[mt] && kvpos >= row_start[mt];
-            if (cmask != nullptr && on)      // the mask row of this query token over all kv_len positions
+            if (cmask != nullptr && on && !(p.mask_skip_prefix && kvpos < prefix))   // the mask row of this query token over all kv_len positions
               on = cmask[static_cast<int64_t>(row_tok[mt]) * kv_len + kvpos] != 0;
             float s = st_acc[mt][nt][r] * p.scale_log2;
             if (p.cap_log2 != 0.f) s = soft_cap_log2(s, p.cap_log2, p.inv_cap_log2);
@@ -879,7 +880,7 @@ int sgl_amd_extend_attention(const void* q, void* out, const void* k_cache, cons
   return sgl_amd_extend_attention_ex(q, out, k_cache, v_cache, req_to_token, req_to_token_stride, req_pool_indices, seq_lens,
                                      prefix_lens, qo_indptr, batch, max_extend_len, num_q_heads, num_kv_heads, head_dim,
                                      q_token_stride, out_token_stride, k_cache_row_stride, v_cache_row_stride, sm_scale, causal,
-                                     0, 1.0f, 1.0f, 1, 0, -1, 0.0f, nullptr, nullptr, stream);
+                                     0, 1.0f, 1.0f, 1, 0, -1, 0.0f, nullptr, nullptr, 0, stream);
 }
 
 int sgl_amd_extend_attention_ex(const void* q, void* out, const void* k_cache, const void* v_cache,
@@ -891,7 +892,7 @@ int sgl_amd_extend_attention_ex(const void* q, void* out, const void* k_cache, c
                                 int64_t k_cache_row_stride, int64_t v_cache_row_stride, float sm_scale,
                                 int causal, int kv_fp8, float k_scale, float v_scale, int page_size, int kv_layout_hnd,
                                 int sliding_window, float logit_cap, const void* custom_mask, const int64_t* mask_indptr,
-                                void* stream) {
+                                int skip_prefix_custom_mask, void* stream) {
   SGL_CLEAR_STALE_ERROR();
   SGL_CHECK_ARG(k_cache_row_stride == v_cache_row_stride, "extend_attention: K and V pools must share a row stride");
   SGL_CHECK_ARG(!kv_fp8 || (k_scale > 0.f && v_scale > 0.f), "extend_attention: fp8 KV needs positive k_scale / v_scale");
@@ -947,6 +948,7 @@ int sgl_amd_extend_attention_ex(const void* q, void* out, const void* k_cache, c
   p.inv_cap_log2 = logit_cap > 0.f ? 1.0f / p.cap_log2 : 0.f;
   p.custom_mask = static_cast<const uint8_t*>(custom_mask);
   p.mask_indptr = mask_indptr;
+  p.mask_skip_prefix = skip_prefix_custom_mask ? 1 : 0;
   SGL_CHECK_ARG(make_kv_format(&p.fmt, k_cache_row_stride, num_kv_heads, head_dim, page_size, kv_layout_hnd, kv_fp8),
                 "extend_attention: HND pools need a power-of-two page_size (got %d); row / page strides must stay below 4 GiB", page_size);
   const int tiles = (max_extend_len + p.tokens_per_tile - 1) / p.tokens_per_tile;

@@ -30,7 +30,7 @@ from ..layers.sampler import Sampler, SamplingBatchInfo, create_sampler
 from ..mem_cache.allocator import PagedTokenToKVPoolAllocator, TokenToKVPoolAllocator
 from ..mem_cache.memory_pool import MHATokenToKVPool, ReqToTokenPool
 from ..mem_cache.radix_cache import EvictParams, MatchPrefixParams, RadixCache, RadixKey
-from ..model_executor.forward_batch_info import ForwardBatch, ForwardMode
+from ..model_executor.forward_batch_info import ForwardBatch, ForwardMode, VerifyInput
 from ..model_executor.graph_runner import DecodeGraphRunner
 from .models import CONFIGS, CausalLM, ModelConfig
 
@@ -608,6 +608,52 @@ class Engine:
             self.running.append(q)
 
     # ---- finish (batch_result_processor.py:863 -> mem_cache/common.py:198 release_kv_cache) ----
+    # ---- speculative decoding: one TARGET_VERIFY forward (speculative/eagle_info.py EagleVerifyInput.prepare_for_verify,
+    #      triton_backend.py:860-919) ----------------------------------------------------------------------------
+    def verify_tree(self, tree_tokens: Sequence[Sequence[int]], parents: Sequence[int]) -> torch.Tensor:
+        """Score a tree of draft tokens for every running request in ONE forward of the target model.  Node 0 is the
+        request's last sampled token (the only token without a KV row yet), node j > 0 a draft token whose parent is
+        node parents[j] < j; a node attends to the request's whole context and to its ancestors (incl. itself).
+        Returns the logits [B, nodes, vocab]: row j = the target model's distribution after the path to node j.
+        The draft rows are scratch: their KV slots go back to the allocator (a real worker would keep the accepted path)."""
+        r, dev = self.r, self.device
+        assert r.page_size == 1, "the verify step is wired for page_size 1"
+        self.flush_decode_outputs()
+        self._retire_decode_state()
+        reqs = self.running
+        B, nd = len(reqs), len(parents)
+        assert parents[0] == -1 and all(0 <= parents[j] < j for j in range(1, nd)) and all(len(t) == nd for t in tree_tokens)
+        assert all(t[0] == q.output_ids[-1] for t, q in zip(tree_tokens, reqs)), "node 0 is the last sampled token"
+        depth = [0] * nd
+        anc = torch.zeros((nd, nd), dtype=torch.bool)
+        for j in range(nd):
+            a = j
+            while a >= 0:
+                anc[j, a] = True
+                a = parents[a]
+            depth[j] = int(anc[j].sum()) - 1
+        kv = [q.seqlen - 1 for q in reqs]                           # tokens with a KV row
+        slots = self._alloc_token_slots(B * nd)
+        pool_idx = torch.tensor([q.req_pool_idx for q in reqs], dtype=torch.int64, device=dev)
+        kv_dev = torch.tensor(kv, dtype=torch.int32, device=dev)
+        cols = kv_dev.long()[:, None] + torch.arange(nd, device=dev)[None, :]
+        r.req_to_token_pool.req_to_token[pool_idx[:, None], cols] = slots.view(B, nd).to(torch.int32)
+        # the flat mask: request b's [nd, kv_b + nd] block, prefix visible, tree part = ancestors
+        mask = torch.cat([torch.cat([torch.ones((nd, n), dtype=torch.bool), anc], dim=1).flatten() for n in kv]).to(dev)
+        positions = (kv_dev.long()[:, None] + torch.tensor(depth, device=dev)[None, :]).flatten()
+        fb = ForwardBatch(forward_mode=ForwardMode.TARGET_VERIFY, batch_size=B,
+                          input_ids=torch.tensor([t for row in tree_tokens for t in row], dtype=torch.int64, device=dev),
+                          req_pool_indices=pool_idx, seq_lens=kv_dev, out_cache_loc=slots, seq_lens_sum=sum(kv),
+                          seq_lens_cpu=torch.tensor(kv, dtype=torch.int64), positions=positions,
+                          req_to_token_pool=r.req_to_token_pool, token_to_kv_pool=r.token_to_kv_pool, attn_backend=r.attn_backend,
+                          spec_info=VerifyInput(custom_mask=mask, draft_token_num=nd, positions=positions))
+        fb.extend_seq_lens_cpu, fb.extend_prefix_lens_cpu, fb.extend_num_tokens = [nd] * B, list(kv), B * nd
+        fb.extend_seq_lens = torch.full((B,), nd, dtype=torch.int32, device=dev)
+        fb.extend_prefix_lens = kv_dev
+        logits = r.forward(fb).next_token_logits
+        r.token_to_kv_pool_allocator.free(slots)
+        return logits.view(B, nd, -1)
+
     def finish(self, reqs: Sequence[Req]) -> None:
         self.flush_decode_outputs()
         tree, pool = self.r.tree_cache, self.r.req_to_token_pool

@@ -364,7 +364,9 @@ class CausalLM(nn.Module):
 
     def compute_logits(self, hidden_states: torch.Tensor, forward_batch) -> LogitsProcessorOutput:
         """logits_processor.py:652-700: last token of every request, vocab-parallel head + all-gather."""
-        if forward_batch.forward_mode.is_extend():
+        if getattr(forward_batch.forward_mode, "is_target_verify", lambda: False)():
+            hidden_states = kernels.unblock(hidden_states)          # every draft token is scored (logits_processor.py: verify keeps all rows)
+        elif forward_batch.forward_mode.is_extend():
             last = torch.cumsum(forward_batch.extend_seq_lens, dim=0, dtype=torch.int64) - 1
             hidden_states = kernels.unblock(hidden_states)[last]
         rows = hidden_states.shape[1] if hidden_states.dim() == 3 else hidden_states.shape[0]

@@ -281,7 +281,8 @@ def extend_attention(q: torch.Tensor, out: torch.Tensor, k_cache: torch.Tensor, 
                      prefix_lens: torch.Tensor, qo_indptr: torch.Tensor, max_extend_len: int, sm_scale: float,
                      causal: bool = True, kv_fp8: bool = False, k_scale: float = 1.0, v_scale: float = 1.0,
                      page_size: int = 1, hnd: bool = False, sliding_window: int = -1, logit_cap: float = 0.0,
-                     custom_mask: Optional[torch.Tensor] = None, mask_indptr: Optional[torch.Tensor] = None) -> torch.Tensor:
+                     custom_mask: Optional[torch.Tensor] = None, mask_indptr: Optional[torch.Tensor] = None,
+                     skip_prefix_custom_mask: bool = False) -> torch.Tensor:
     """q/out [T, Hq, D]; k_cache/v_cache [slots, Hkv, D] (HND / fp8 as in decode_attention); int32
     seq_lens/prefix_lens/qo_indptr; custom_mask uint8 / bool flat, mask_indptr int64 [B + 1]."""
     _dev(q, out, k_cache, v_cache, req_to_token, req_pool_indices, seq_lens, prefix_lens, qo_indptr)
@@ -303,7 +304,7 @@ def extend_attention(q: torch.Tensor, out: torch.Tensor, k_cache: torch.Tensor, 
                     prefix_lens.data_ptr(), qo_indptr.data_ptr(), seq_lens.numel(), int(max_extend_len), Hq, Hkv, D,
                     q.stride(0), out.stride(0), Hkv * D, Hkv * D, float(sm_scale), 1 if causal else 0, 1 if kv_fp8 else 0,
                     float(k_scale), float(v_scale), int(page_size), 1 if hnd else 0, int(sliding_window), float(logit_cap),
-                    _ptr(custom_mask), _ptr(mask_indptr), _stream())
+                    _ptr(custom_mask), _ptr(mask_indptr), 1 if skip_prefix_custom_mask else 0, _stream())
         return out
     _need(q.dtype == _BF16 and k_cache.dtype == _BF16 and v_cache.dtype == _BF16 and out.dtype == _BF16, "extend_attention: bf16 only")
     _need(seq_lens.dtype == torch.int32 and prefix_lens.dtype == torch.int32 and qo_indptr.dtype == torch.int32,

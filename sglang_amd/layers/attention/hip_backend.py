@@ -47,6 +47,7 @@ class _Meta:
     prefix_lens_i32: Optional[torch.Tensor] = None
     max_extend_len: int = 0
     cascade: Optional["kernels.CascadeWorkspace"] = None   # shared-prefix decode plan + split slots
+    mask_indptr: Optional[torch.Tensor] = None             # TARGET_VERIFY: offsets of the requests' blocks in the flat mask
 
 
 def choose_num_splits(batch: int, num_kv_heads: int, group: int, max_len: int, target_blocks: int = 512) -> int:
@@ -181,6 +182,18 @@ class HipAttnBackend(AttentionBackend):
             splits = choose_num_splits(fb.batch_size, self.num_kv_heads, self.num_q_heads // self.num_kv_heads, max_len)
             ws = self._workspace(fb.batch_size, splits) if splits > 1 else (None, None)
             self.forward_metadata = _Meta(seq_i32, splits, ws[0], ws[1])
+        elif getattr(fb.forward_mode, "is_target_verify", lambda: False)():
+            # triton_backend.py:860-919: every request extends by `draft_token_num` tokens over its whole context
+            # (forward_batch.seq_lens = the context BEFORE the draft tokens), qo_indptr = arange * draft_token_num, the
+            # mask block of request b holds draft_token_num x (seq_len + draft_token_num) entries
+            nd = int(getattr(fb.spec_info, "draft_token_num"))
+            bs = fb.batch_size
+            qo = torch.arange(0, (bs + 1) * nd, nd, dtype=torch.int32, device=self.device)
+            kv_i32 = seq_i32 + nd
+            sizes = nd * kv_i32.to(torch.int64)
+            mip = torch.zeros(bs + 1, dtype=torch.int64, device=self.device)
+            mip[1:] = torch.cumsum(sizes, 0)
+            self.forward_metadata = _Meta(kv_i32, qo_indptr=qo, prefix_lens_i32=seq_i32, max_extend_len=nd, mask_indptr=mip)
         elif fb.forward_mode.is_extend():
             ext = fb.extend_seq_lens_cpu
             qo = torch.zeros(fb.batch_size + 1, dtype=torch.int32)
@@ -236,7 +249,10 @@ class HipAttnBackend(AttentionBackend):
         spec = getattr(forward_batch, "spec_info", None)
         if spec is not None and getattr(spec, "custom_mask", None) is not None:
             opt["custom_mask"] = spec.custom_mask
-            opt["mask_indptr"] = self._mask_indptr(forward_batch, m)
+            opt["mask_indptr"] = m.mask_indptr if m.mask_indptr is not None else self._mask_indptr(forward_batch, m)
+            # the reference's verify call leaves skip_prefix_custom_mask at its default: the prefix is fully visible,
+            # the mask decides among the draft tokens only (extend_attention.py:774)
+            opt["skip_prefix_custom_mask"] = getattr(forward_batch.forward_mode, "is_target_verify", lambda: False)()
         kernels.extend_attention(q3, o, self.token_to_kv_pool.get_key_buffer(layer.layer_id),
                                  self.token_to_kv_pool.get_value_buffer(layer.layer_id),
                                  self.req_to_token_pool.req_to_token, self._pool_idx(forward_batch), m.seq_lens_i32,

@@ -19,9 +19,13 @@ class ForwardMode(IntEnum):
     DECODE = auto()
     MIXED = auto()
     IDLE = auto()
+    TARGET_VERIFY = auto()     # speculative decoding: verify a tree of draft tokens in the target model (:111-112)
 
     def is_extend(self) -> bool:
-        return self in (ForwardMode.EXTEND, ForwardMode.MIXED)
+        return self in (ForwardMode.EXTEND, ForwardMode.MIXED, ForwardMode.TARGET_VERIFY)      # :129-137
+
+    def is_target_verify(self) -> bool:
+        return self == ForwardMode.TARGET_VERIFY
 
     def is_decode(self) -> bool:
         return self == ForwardMode.DECODE
@@ -34,6 +38,17 @@ class ForwardMode(IntEnum):
 
     def is_prefill(self) -> bool:
         return self.is_extend()
+
+
+@dataclass
+class VerifyInput:
+    """What the attention backend reads of `forward_batch.spec_info` in TARGET_VERIFY mode (speculative/eagle_info.py
+    EagleVerifyInput; triton_backend.py:860-919): the flat boolean mask -- request b's [draft_token_num, seq_len + draft_token_num]
+    block, row j = what draft token j may attend to -- and the number of draft tokens per request."""
+
+    custom_mask: torch.Tensor
+    draft_token_num: int
+    positions: Optional[torch.Tensor] = None
 
 
 @dataclass

@@ -57,6 +57,20 @@ def test_verify_mask_vs_reference_triton(device, golden_dir):
                 _close(o, d["out_" + tag + ("_cap" if cap else "")], f"{name} {tag} cap={cap}")
 
 
+def test_verify_mask_prefix_part_is_not_consulted_with_skip_prefix(device, golden_dir):
+    """The reference's TARGET_VERIFY call leaves skip_prefix_custom_mask at its default (extend_attention.py:774): the
+    prefix columns of the mask are never read.  Zero them: with the flag the result is still the golden's."""
+    for name, d in _cases(golden_dir).items():
+        v = d["verify"]
+        mask, mip = d["verify_mask"].clone(), d["verify_mask_indptr"]
+        for b in range(len(v["seq_lens"])):
+            pre, ext, kv = int(v["extend_prefix_lens"][b]), int(v["extend_seq_lens"][b]), int(v["seq_lens"][b])
+            blk = mask[int(mip[b]): int(mip[b]) + ext * kv].view(ext, kv)
+            blk[:, :pre] = False
+        o = _extend(device, v, v["q"], d["scaling"], custom_mask=mask, mask_indptr=mip, skip_prefix_custom_mask=True)
+        _close(o, d["out_verify"], f"{name} verify, prefix part zeroed + skip_prefix")
+
+
 @pytest.mark.parametrize("splits", [1, 3])
 def test_decode_cap_vs_reference_triton(device, golden_dir, splits):
     from sglang_amd import kernels as K

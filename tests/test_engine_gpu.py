@@ -321,3 +321,47 @@ def test_retraction_on_the_gpu_matches_oracle(device):
         assert len(rows) == new_tokens
         for k, row in enumerate(rows):
             torch.testing.assert_close(row, ref[k][b], atol=2e-2, rtol=2e-2, msg=f"request {q.rid} token {k}")
+
+
+def test_target_verify_scores_a_draft_tree_like_its_linearised_paths(device):
+    """ForwardMode.TARGET_VERIFY (triton_backend.py:860-919): one forward scores every node of a draft tree -- the flat
+    verify mask from spec_info, prefix visible, draft tokens seeing their ancestors only, positions = context + depth.
+    Oracle: the plain causal model run over context + the path to a node gives that node's logits.  Also on a
+    radix-shared batch (the masked kernel reads shared prefix rows), with a logit soft cap on the second model."""
+    import dataclasses
+
+    from oracle.model import OracleLM, weights_from_product_model
+    from sglang_amd.harness.engine import Engine, ModelRunner, Req
+    from sglang_amd.harness.models import CONFIGS
+
+    parents = [-1, 0, 0, 1, 1, 2, 5]                      # a tree of 7 nodes, depth 3
+    for cfg in (CONFIGS["tiny-llama"], dataclasses.replace(CONFIGS["tiny-llama"], logit_cap=20.0, name="tiny-llama-cap")):
+        runner = ModelRunner(cfg, max_total_tokens=4096, max_running_requests=8, max_context_len=192, device=device, use_graph=False)
+        eng = Engine(runner)
+        g = torch.Generator().manual_seed(21)
+        shared = torch.randint(0, cfg.vocab_size, (70,), generator=g).tolist()
+        prompts = [shared + torch.randint(0, cfg.vocab_size, (n,), generator=g).tolist() for n in (5, 9, 1)]
+        reqs = [Req(i, p, 8) for i, p in enumerate(prompts)]
+        eng.prefill(reqs[:1]); eng.prefill(reqs[1:])
+        eng.decode_step(); eng.decode_step(); eng.flush_decode_outputs()
+        trees = [[q.output_ids[-1]] + torch.randint(0, cfg.vocab_size, (len(parents) - 1,), generator=g).tolist() for q in reqs]
+        free_before = runner.token_to_kv_pool_allocator.available_size()
+        got = eng.verify_tree(trees, parents)                                   # [B, nodes, vocab]
+        assert runner.token_to_kv_pool_allocator.available_size() == free_before
+        oracle = OracleLM(cfg, weights_from_product_model(runner.model, device), num_slots=8192, max_ctx=192, max_reqs=1,
+                          device=device, compute_dtype=torch.float32)
+        worst = 0.0
+        for b, q in enumerate(reqs):
+            ctx = q.origin_input_ids + q.output_ids[:-1]                        # tokens with a KV row
+            for j in range(len(parents)):
+                path, a = [], j
+                while a >= 0:
+                    path.append(trees[b][a]); a = parents[a]
+                seq = ctx + path[::-1]
+                oracle.next_slot = 1
+                ref = oracle.generate([seq], 1, return_logits=True)[1][0][0]
+                worst = max(worst, float((got[b, j].float() - ref).abs().max()))
+        assert worst < 3e-2, (cfg.name, worst)
+        # the engine goes on decoding afterwards (the verify step left no state behind)
+        eng.decode_step(); eng.flush_decode_outputs()
+        eng.finish(list(eng.running))

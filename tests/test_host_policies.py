@@ -173,3 +173,39 @@ def test_pool_format_is_read_off_the_pool_not_assumed():
 
     with pytest.raises(NotImplementedError):
         pool_kernel_format(types.SimpleNamespace(dtype=torch.float8_e5m2, page_size=1), None)
+
+
+def test_decode_attention_routing_rule_for_window_and_cap_layers(monkeypatch):
+    """The shared-prefix (cascade) decode kernel implements plain causal attention over any pool format; a layer with a
+    sliding window or a logit soft cap (radix_attention.py:115-148) is routed to the paged decode kernel, which honours
+    both -- per LAYER, inside one batch whose other layers keep the cascade path."""
+    import types
+
+    import torch
+
+    from sglang_amd import kernels
+    from sglang_amd.layers.attention import hip_backend as hb
+
+    calls = []
+    monkeypatch.setattr(kernels, "cascade_decode_attention", lambda *a, **k: calls.append(("cascade", sorted(k))))
+    monkeypatch.setattr(kernels, "decode_attention", lambda *a, **k: calls.append(("paged", {x: k[x] for x in ("sliding_window", "logit_cap") if x in k})))
+    pool = types.SimpleNamespace(dtype=torch.bfloat16, page_size=1, use_hnd=False, get_key_buffer=lambda i: torch.zeros((8, 2, 64), dtype=torch.bfloat16),
+                                 get_value_buffer=lambda i: torch.zeros((8, 2, 64), dtype=torch.bfloat16))
+    be = hb.HipAttnBackend.__new__(hb.HipAttnBackend)
+    be.token_to_kv_pool, be.debug_flags = pool, 0
+    be.req_to_token_pool = types.SimpleNamespace(req_to_token=torch.zeros((4, 16), dtype=torch.int32))
+    be.forward_metadata = hb._Meta(torch.ones(3, dtype=torch.int32), cascade=object())
+    fb = types.SimpleNamespace(req_pool_indices=torch.arange(3), out_cache_loc=torch.arange(3))
+
+    def layer(**kw):
+        return types.SimpleNamespace(tp_q_head_num=4, qk_head_dim=64, v_head_dim=64, layer_id=0, scaling=0.125, sliding_window_size=-1,
+                                     logit_cap=0.0, k_scale_float=None, v_scale_float=None, **kw)
+
+    q = torch.zeros((3, 4 * 64), dtype=torch.bfloat16)
+    be.forward_decode(q, None, None, layer(), fb, save_kv_cache=False)
+    win = layer(); win.sliding_window_size = 32
+    be.forward_decode(q, None, None, win, fb, save_kv_cache=False)
+    cap = layer(); cap.logit_cap = 30.0
+    be.forward_decode(q, None, None, cap, fb, save_kv_cache=False)
+    assert [c[0] for c in calls] == ["cascade", "paged", "paged"]
+    assert calls[1][1] == {"sliding_window": 32} and calls[2][1] == {"logit_cap": 30.0}
