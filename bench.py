@@ -51,7 +51,8 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_PEAK_TFLOPS = 2500.0     # bf16 dense
-PMC_FILE = ROOT / "profiles" / "r02_pmc.json"
+PMC_FILE = ROOT / "profiles" / "r03_pmc.json"
+PMC_NAME = "profiles/" + PMC_FILE.name
 
 
 def build_prompts(cfg, groups, per_group, prefix, unique, seed=1):
@@ -65,20 +66,43 @@ def build_prompts(cfg, groups, per_group, prefix, unique, seed=1):
 
 
 def load_pmc():
-    """profiles/r02_pmc.json (benchmarks/summarize_pmc_phases.py over the rocprofv3 --pmc passes of
-    benchmarks/pmc_workload.py): {"phases": {phase: {"kernels": {name: {"dispatches", counter: avg, ...}}}}}."""
+    """profiles/r03_pmc.json (benchmarks/summarize_pmc_phases.py over the rocprofv3 --pmc passes of
+    benchmarks/pmc_workload.py): {"stamp": {"sources": {file: sha}}, "phases": {phase: {"kernels": {name: {"dispatches",
+    counter: avg, ...}}}}}.  A record without a stamp is not quoted at all."""
     if not PMC_FILE.exists():
         return None
     try:
-        return json.loads(PMC_FILE.read_text())
+        pmc = json.loads(PMC_FILE.read_text())
     except Exception:
         return None
+    return pmc if isinstance(pmc.get("stamp", {}).get("sources"), dict) else None
 
 
-def pmc_kernel(pmc, phase, substr):
-    """Per-dispatch averages of the kernel of `phase` whose name contains `substr` (the most dispatched one when
-    several launch sizes of it ran: records are keyed by name + grid size)."""
+_SHARED_SOURCES = ("common.hpp", "kv_format.hpp")
+
+
+def pmc_current(pmc, *sources):
+    """The record's counters describe today's kernels of `sources` (csrc file names; none = every source): the sha256
+    stamped at collection time still matches the files this process was built from.  A stale record yields no traffic /
+    utilisation figure (null in the JSON line) rather than a number of some other revision's kernel."""
     if not pmc:
+        return False
+    import hashlib
+
+    stamped = pmc["stamp"]["sources"]
+    csrc = ROOT / "sglang_amd" / "csrc"
+    names = (tuple(sources) + _SHARED_SOURCES) if sources else tuple(stamped) + tuple(f.name for f in csrc.iterdir() if f.is_file())
+    for n in set(names):
+        f = csrc / n
+        if not f.is_file() or stamped.get(n) != hashlib.sha256(f.read_bytes()).hexdigest()[:16]:
+            return False
+    return True
+
+
+def pmc_kernel(pmc, phase, substr, *sources):
+    """Per-dispatch averages of the kernel of `phase` whose name contains `substr` (the most dispatched one when
+    several match), or None -- also when the record predates the current `sources` of that kernel."""
+    if not pmc or not pmc_current(pmc, *sources):
         return None
     hits = [rec for name, rec in pmc.get("phases", {}).get(phase, {}).get("kernels", {}).items() if substr in name]
     return max(hits, key=lambda r: r.get("dispatches", 0)) if hits else None
@@ -310,11 +334,11 @@ def worker(args):
     kv_write = B * kv_row
     step_bytes = w_act + kv_unique + kv_write
     step_traffic = None
-    if pmc and pmc.get("model") == cfg.name and pmc.get("batch") == B and world == 1 and not kv_fp8:
+    if pmc_current(pmc) and pmc.get("model") == cfg.name and pmc.get("batch") == B and world == 1 and not kv_fp8:
         step_traffic = pmc.get("phases", {}).get("decode", {}).get("hbm_bytes_per_step")
     step_roofline = dict(bound="hbm", achieved=step_bytes / t_decode_step / 1e9, peak=HBM_PEAK_GBPS, unit="GB/s",
                          frac=step_bytes / t_decode_step / 1e9 / HBM_PEAK_GBPS, traffic=step_traffic,
-                         traffic_source="profiles/r02_pmc.json: sum over one eager decode step's dispatches of "
+                         traffic_source=PMC_NAME + ": sum over one eager decode step's dispatches of "
                                         "2 x FETCH_SIZE + WRITE_SIZE (separate rocprofv3 --pmc passes)",
                          bytes_per_step=step_bytes, kv_bytes_no_dedup=kv_nodedup, ms_per_decode_step=t_decode_step * 1e3)
     pair = 4 * L * Hq * D
@@ -352,6 +376,8 @@ def worker(args):
     # ---- dominant hand-written kernels, measured live with HIP events on torch's stream ----
     if rank == 0 and not args.no_kernel_roofline and not args.rank_of:
         try:
+            result["pmc_record"] = {"file": PMC_NAME, "present": pmc is not None, "all_sources_current": pmc_current(pmc),
+                                    "git_revision": pmc["stamp"].get("git_revision") if pmc else None}
             kernel_rooflines(args, cfg, runner, result, B, G, P, in_len, ctx, t_decode_step, pmc, dev, world)
         except Exception as e:      # the measured line must survive a failure of these side measurements
             result.setdefault("roofline", {"error": f"{type(e).__name__}: {e}"})
@@ -452,10 +478,10 @@ def kernel_rooflines(args, cfg, runner, result, B, G, P, in_len, ctx, t_decode_s
                                   for m in mlps], len(mlps))
         alg = wN * wK * 2 + Mg * wK * 2 + Mg * (wN // 2) * 2      # weights once + activations in + out
         nw_s = K.choose_wstream_config(Mg, wN, wK, True, True)
-        rec = pmc_kernel(pmc, "decode", "wstream_gemm_kernel<4, 4, 2") if (Mg, wN, wK) == (64, 28672, 4096) else None
+        rec = pmc_kernel(pmc, "decode", "wstream_gemm_kernel<4, 4, 2", "wstream_gemm.hip") if (Mg, wN, wK) == (64, 28672, 4096) else None
         result["roofline"] = {"bound": "hbm", "achieved": alg / t_g / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                               "frac": alg / t_g / 1e9 / HBM_PEAK_GBPS, "traffic": hbm_bytes(rec),
-                              "traffic_source": "profiles/r02_pmc.json: 2 x FETCH_SIZE (gfx950 counts 64 B per 128 B "
+                              "traffic_source": PMC_NAME + ": 2 x FETCH_SIZE (gfx950 counts 64 B per 128 B "
                                                 "request) + WRITE_SIZE, KiB per dispatch",
                               "kernel": "wstream_gemm_kernel<4,4,2> (gate_up_proj + silu_and_mul)",
                               "us_per_launch": t_g * 1e6, "bytes_per_launch": alg,
@@ -521,7 +547,8 @@ def kernel_rooflines(args, cfg, runner, result, B, G, P, in_len, ctx, t_decode_s
         t_c = graph_time(lambda: K.cascade_decode_attention(cws, q, kc, vc, o, r2t, pool_idx, seq, D ** -0.5), 1, reps=20)
         uniq = (G * args.prefix + B * (len_k - args.prefix)) * row_bytes
         tr = None
-        rc, rm = pmc_kernel(pmc, "decode", "cascade_chunk_kernel"), pmc_kernel(pmc, "decode", "cascade_merge2_kernel")
+        casc_src = ("cascade_attention.hip", "cascade_plan.hpp")
+        rc, rm = pmc_kernel(pmc, "decode", "cascade_chunk_kernel", *casc_src), pmc_kernel(pmc, "decode", "cascade_merge2_kernel", *casc_src)
         if hbm_bytes(rc) is not None and hbm_bytes(rm) is not None:
             tr = hbm_bytes(rc) + hbm_bytes(rm)
         att["cascade"] = {"kernel": "cascade_chunk_kernel + cascade_merge2_kernel", "us_per_layer": t_c * 1e6,
@@ -554,16 +581,16 @@ def kernel_rooflines(args, cfg, runner, result, B, G, P, in_len, ctx, t_decode_s
         fl = nreq * 4 * Hq_r * D * (e * pre + e * (e + 1) / 2)
         ext[name] = {"us": t_x * 1e6, "tflops": fl / t_x / 1e12, "frac": fl / t_x / 1e12 / MFMA_PEAK_TFLOPS,
                      "shape": {"requests": nreq, "extend": e, "prefix": pre}}
-    rec = pmc_kernel(pmc, "prefill_cold", "extend_attention")
+    rec = pmc_kernel(pmc, "prefill_cold", "extend_attention", "extend_attention.hip")
     if rec and rec.get("GRBM_GUI_ACTIVE") and rec.get("SQ_VALU_MFMA_BUSY_CYCLES") is not None:
         # busy SIMD-cycles / (active cycles per XCD x 1024 SIMDs); GRBM_GUI_ACTIVE is summed over the 8 XCDs on gfx950
         ext["mfma_util_pmc"] = rec["SQ_VALU_MFMA_BUSY_CYCLES"] * 8 / (rec["GRBM_GUI_ACTIVE"] * 1024)
         ext["pmc"] = {k: rec[k] for k in rec if k != "dispatches"}
     result["prefill_mfma"]["extend_attention_kernel"] = ext
-    whole = pmc.get("phases", {}).get("prefill_cold", {}) if pmc else {}
+    whole = pmc.get("phases", {}).get("prefill_cold", {}) if pmc_current(pmc) else {}
     if whole.get("mfma_util") is not None:
         result["prefill_mfma"]["mfma_util"] = whole["mfma_util"]
-        result["prefill_mfma"]["mfma_util_source"] = ("profiles/r02_pmc.json: sum of SQ_VALU_MFMA_BUSY_CYCLES over the "
+        result["prefill_mfma"]["mfma_util_source"] = (PMC_NAME + ": sum of SQ_VALU_MFMA_BUSY_CYCLES over the "
                                                       "cold prefill's dispatches / (sum of GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)")
 
     # (4) the sampler at the decode batch: temperature 1, top_k 50, top_p 0.9, seeded, [B, vocab]

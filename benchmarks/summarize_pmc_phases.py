@@ -1,17 +1,29 @@
 """Merge the rocprofv3 --pmc passes of benchmarks/pmc_workload.py (one output directory per counter set) into
-profiles/r02_pmc.json: per phase (split at the mfma_probe_kernel sentinels) and per kernel, the average counter
+profiles/rNN_pmc.json: per phase (split at the mfma_probe_kernel sentinels) and per kernel, the average counter
 values per dispatch, plus the phase totals bench.py quotes (HBM bytes per decode step, MFMA-busy fraction).
 
     python benchmarks/summarize_pmc_phases.py OUT.json MODEL BATCH DECODE_STEPS DIR [DIR ...]
 """
 import csv
 import glob
+import hashlib
 import json
+import os
 import re
 import sys
 from collections import defaultdict
+from pathlib import Path
 
 PHASES = ["warmup", "prefill_cold", "prefill_warm", "decode", "tail"]
+CSRC = Path(__file__).resolve().parent.parent / "sglang_amd" / "csrc"
+
+
+def source_stamp():
+    """What the counters were collected ON: sha256 of every kernel source (bench.py quotes a kernel's counters only
+    while the sources that kernel is built from still hash to this) + the revision when the caller exports it (the GPU
+    box has no .git)."""
+    return {"git_revision": os.environ.get("SGLANG_AMD_GIT_REV") or None,
+            "sources": {f.name: hashlib.sha256(f.read_bytes()).hexdigest()[:16] for f in sorted(CSRC.iterdir()) if f.is_file()}}
 
 
 def short(name: str) -> str:
@@ -49,7 +61,7 @@ def main(out_path, model, batch, decode_steps, dirs):
                 a[0] += 1
                 a[1] += float(r["Counter_Value"])
                 phases[p]["totals"][r["Counter_Name"]] += float(r["Counter_Value"])
-    out = {"model": model, "batch": int(batch), "decode_steps": int(decode_steps),
+    out = {"model": model, "batch": int(batch), "decode_steps": int(decode_steps), "stamp": source_stamp(),
            "source": "rocprofv3 --pmc passes of benchmarks/pmc_workload.py (separate pass per counter set; eager launches)",
            "units": "FETCH_SIZE / WRITE_SIZE in KiB per dispatch (gfx950: double FETCH_SIZE for wide streaming reads); "
                     "SQ_* / GRBM_* raw counts per dispatch", "phases": {}}

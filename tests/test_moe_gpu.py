@@ -203,12 +203,28 @@ def test_wstream_moe_gemm_row_gather_scale_and_silu(device, M, E, k, N, Kd, bm):
     K.moe_wstream_gemm(a.to(device), w.to(device), c_plain, s, e, post, None, False, k, M * k, bm)
     c_silu = torch.zeros((M * k, N // 2), dtype=BF, device=device)
     K.moe_wstream_gemm(a.to(device), w.to(device), c_silu, s, e, post, None, False, k, M * k, bm, fuse_silu=True)
-    ref = oo.silu_and_mul(c_plain.cpu())
-    d = (c_silu.cpu().float() - ref.float()).abs()
-    # same products and rounding points; the two forms walk K from other staggered starting chunks (fp32 summation
-    # order), so a gate / up value on a bf16 rounding boundary may land on the other side (one ulp of a gate around -5
-    # moves silu(gate) by 2.5 %)
-    assert float((d > 0).float().mean()) < 0.02 and bool((d <= ref.float().abs() * 2.0 ** -4 + 1e-3).all())
+    # Same products and rounding points; the two launches walk K from other staggered starting chunks (fp32 summation
+    # order), so a gate / up accumulator that sits on a bf16 rounding boundary may round the other way in the fused
+    # launch.  That is the ONLY licence: every fused output must be silu_and_mul of bf16 (gate, up) values at most one
+    # ulp away from the plain launch's, to one ulp of the result -- an epilogue or ordering bug (percent-level errors on
+    # arbitrary elements) cannot pass -- and all but a few elements must come from the unshifted pair.
+    plain = c_plain.cpu()
+    gate, up = plain[:, : N // 2], plain[:, N // 2:]
+
+    def neighbour(x, step):                      # the bf16 value `step` ulps further from zero (sign-magnitude bits)
+        return (x.contiguous().view(torch.int16) + step).view(BF)
+
+    got = c_silu.cpu().float()
+    best = torch.full_like(got, float("inf"))
+    centre = None
+    for dg in (0, -1, 1):
+        for du in (0, -1, 1):
+            cand = oo.silu_and_mul(torch.cat([neighbour(gate, dg), neighbour(up, du)], dim=1)).float()
+            if centre is None:
+                centre = cand
+            best = torch.minimum(best, (got - cand).abs() - (cand.abs() * 2.0 ** -7 + 1e-6))
+    assert bool((best <= 0).all()), float(best.max())
+    assert float(((got - centre).abs() > centre.abs() * 2.0 ** -7 + 1e-6).float().mean()) < 0.02
 
 
 @pytest.mark.parametrize("M,E,k,N,Kd", [(900, 8, 2, 512, 1024), (2048, 8, 2, 7168, 4096), (1500, 4, 1, 320, 192)])
