@@ -206,13 +206,16 @@ def test_wstream_moe_gemm_row_gather_scale_and_silu(device, M, E, k, N, Kd, bm):
     # Same products and rounding points; the two launches walk K from other staggered starting chunks (fp32 summation
     # order), so a gate / up accumulator that sits on a bf16 rounding boundary may round the other way in the fused
     # launch.  That is the ONLY licence: every fused output must be silu_and_mul of bf16 (gate, up) values at most one
-    # ulp away from the plain launch's, to one ulp of the result -- an epilogue or ordering bug (percent-level errors on
+    # ulp away from the plain launch's, to one ulp of the result (the kernel's expf against torch's silu) -- an epilogue or ordering bug (percent-level errors on
     # arbitrary elements) cannot pass -- and all but a few elements must come from the unshifted pair.
     plain = c_plain.cpu()
     gate, up = plain[:, : N // 2], plain[:, N // 2:]
 
     def neighbour(x, step):                      # the bf16 value `step` ulps further from zero (sign-magnitude bits)
         return (x.contiguous().view(torch.int16) + step).view(BF)
+
+    def ulp(x):                                  # one bf16 ulp at magnitude x (8 significant bits)
+        return torch.ldexp(torch.ones_like(x), torch.frexp(x)[1] - 8)
 
     got = c_silu.cpu().float()
     best = torch.full_like(got, float("inf"))
@@ -222,9 +225,9 @@ def test_wstream_moe_gemm_row_gather_scale_and_silu(device, M, E, k, N, Kd, bm):
             cand = oo.silu_and_mul(torch.cat([neighbour(gate, dg), neighbour(up, du)], dim=1)).float()
             if centre is None:
                 centre = cand
-            best = torch.minimum(best, (got - cand).abs() - (cand.abs() * 2.0 ** -7 + 1e-6))
-    assert bool((best <= 0).all()), float(best.max())
-    assert float(((got - centre).abs() > centre.abs() * 2.0 ** -7 + 1e-6).float().mean()) < 0.02
+            best = torch.minimum(best, (got - cand).abs() - ulp(torch.maximum(got.abs(), cand.abs())))
+    assert bool((best <= 0).all()), float(best.max())          # (bf16 differences and ulps are exact in fp32)
+    assert float(((got - centre).abs() > ulp(torch.maximum(got.abs(), centre.abs()))).float().mean()) < 0.02
 
 
 @pytest.mark.parametrize("M,E,k,N,Kd", [(900, 8, 2, 512, 1024), (2048, 8, 2, 7168, 4096), (1500, 4, 1, 320, 192)])
