@@ -19,16 +19,22 @@ slots = 64 * 1200 + 4096
 kc = torch.randn((slots, Hkv, D), device=dev).to(BF)
 vc = torch.randn((slots, Hkv, D), device=dev).to(BF)
 ctx = 1160
-r2t = torch.zeros((65, ctx), dtype=torch.int32, device=dev)
+r2t = torch.zeros((65, 4100), dtype=torch.int32, device=dev)
 perm = (torch.randperm(slots - 1, device=dev) + 1).to(torch.int32)
 for b in range(64):
     r2t[b + 1, :1088] = perm[b * 1088:(b + 1) * 1088]
+for b in range(2):
+    r2t[b + 1, :4096] = perm[b * 4096:(b + 1) * 4096]
+if os.environ.get("EXT_LOCAL"):            # every row from 512 slots: the gathers hit L2 (is the staging time latency?)
+    r2t = (r2t % 512 + 1).to(torch.int32)
 fn = native.lib().sgl_amd_debug_ext_trace
 fn.argtypes = [C.c_void_p]
 fn.restype = C.c_int
 out = {}
-names = ["issue", "s_t", "softmax", "pv", "commit", "barrier"]
-for name, nreq, pre, e in (("cold", 4, 0, 1024), ("warm", 60, 896, 128)):
+FLAGS = int(os.environ.get("EXT_FLAGS", "0"))          # 2: the 32x32 form (phases: staging, s_t, max, pv_exp, tail, barrier)
+native.call("sgl_amd_debug_extend_attention_shape", 0, FLAGS)
+names = ["issue", "s_t", "softmax", "pv", "commit", "barrier"] if FLAGS == 0 else ["staging", "s_t", "max", "pv_exp", "tail", "barrier"]
+for name, nreq, pre, e in (("cold", 4, 0, 1024), ("warm", 60, 896, 128), ("long", 2, 0, 4096)):
     T = nreq * e
     qx = torch.randn((T, Hq, D), device=dev).to(BF)
     ox = torch.empty_like(qx)
@@ -60,4 +66,4 @@ for name, nreq, pre, e in (("cold", 4, 0, 1024), ("warm", 60, 896, 128)):
     out[name] = r
     print(name, json.dumps(r))
 (ROOT / "gpurun_out").mkdir(exist_ok=True)
-(ROOT / "gpurun_out" / "r03_exp9_ext_trace.json").write_text(json.dumps(out, indent=1))
+(ROOT / "gpurun_out" / ("r03_exp9_ext_trace.json" if FLAGS == 0 else "r03_exp9_ext_trace_form32" + ("_local" if os.environ.get("EXT_LOCAL") else "") + ".json")).write_text(json.dumps(out, indent=1))

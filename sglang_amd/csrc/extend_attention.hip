@@ -23,6 +23,8 @@
 //     running sum and the rescale factor never cross lanes, and the exp'd
 //     S^T registers ARE the P^T operand of the second MFMA (no LDS round trip);
 //   * fp32 accumulation, exp2 with the softmax scale folded in, bf16 output.
+#include <type_traits>
+
 #include "common.hpp"
 #include "kv_format.hpp"
 #include "sglang_amd.h"
@@ -832,6 +834,416 @@ __global__ __launch_bounds__(512, 2) void extend_attention_dbuf_kernel(ExtendPar
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The 32x32 form of the bf16 8-wave kernel (same launches as extend_attention_dbuf_kernel: token-major bf16 pool, causal
+// or not, no window / cap / mask).  What changes against the ping-pong kernel above:
+//   * v_mfma_f32_32x32x16_bf16: one wave = 32 rows (query token x head of the group), a 64-key tile = two 32-key blocks.
+//     S^T = K . Q^T leaves lane (q = lane & 31, h = lane >> 5) with 32 scores of ONE row (keys 32 blk + (r & 3) +
+//     8 (r >> 2) + 4 h): the row maximum is an in-lane chain + ONE v_permlane32_swap, the row sum stays a per-lane partial
+//     until the epilogue, and bf16(P) of registers 8 ks .. 8 ks + 7 IS the B operand of O^T += V^T . P^T for the 16 keys
+//     {32 blk + 16 ks + (j & 3) + 8 (j >> 2) + 4 h}; the V^T operand is read in that key order (two ds_read_b64_tr_b16:
+//     keys kb + 4 h + 0..3 and kb + 8 + 4 h + 0..3).  Half the LDS fragment reads per flop of the 16x16x32 shape;
+//   * no role split and ONE barrier per tile: every wave runs  S^T(t)  ->  max(t)  ->  [ O^T += V^T P^T of tile t - 1  ||
+//     P(t) = exp2(S(t) - m) ]  with the exponentials, sums and packs of tile t placed between the matrix instructions of
+//     tile t - 1 (two P register sets); the two waves of a SIMD drift apart inside a tile and cover each other's
+//     vector-only stretches;
+//   * V image per 32 head dims: [64 tokens][64 B] (+ a bank skew between the sub-images), so that the four 16-lane groups
+//     of a transposing read cover 512 contiguous bytes;
+//   * a raised maximum (rare: kDeferMax) is applied to O and l AFTER the pending products of tile t - 1, which were
+//     exponentiated against the old one (the order the softmax-rescale hazard asks for);
+//   * the epilogue swaps 4-dim pieces between the lane halves and stores 16 bytes per lane.
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+template <int D>
+struct SmemLadder {
+  static constexpr int kVSub = 64 * 64 + (D == 128 ? 64 : 128);   // bytes of one 32-dim V sub-image + bank skew
+  U4 k[2][kKvTile * D / 8];                                       // [token][chunk ^ swz]
+  U4 v[2][(D / 32) * kVSub / 16];
+};
+
+__device__ __forceinline__ float lane_pair_max(float x) {         // max over lanes l and l ^ 32
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return fmaxf(a, b);
+}
+
+// NWV = waves per workgroup: 8 (256 rows share a staged tile, one workgroup per CU) or 4 (128 rows, two workgroups per
+// CU with their own barriers: one multiplies while the other stages, waits or runs its prologue / epilogue).
+template <int D, int NWV>
+__global__ __launch_bounds__(64 * NWV, 2) void extend_attention_ladder_kernel(ExtendParams p) {
+  __shared__ SmemLadder<D> sm;
+  constexpr int CPR = D / 8;            // 16-byte chunks per KV row
+  constexpr int KS = D / 16;            // MFMA k-steps over the head dim
+  constexpr int ND = D / 32;            // 32-wide output blocks over the head dim
+  constexpr int ROWS_PER_PASS = 64 * NWV / CPR;
+  constexpr int LOADS = kKvTile / ROWS_PER_PASS;     // 16-byte loads per thread per operand per tile (2 at D = 128, 8 waves)
+  constexpr int VSUB = SmemLadder<D>::kVSub;
+  constexpr int NPV = ND * 4;           // PV products per tile
+
+  // grid -> (query tile, kv head, request): as in the ping-pong kernel (heaviest tiles first, a pair stays on one XCD)
+  int tile, kvh, b;
+  {
+    const int L = blockIdx.x;
+    const int pairs = p.batch * p.num_kv_heads;
+    int pair, rank;
+    if (pairs % 8 == 0) {
+      const int per_xcd = pairs / 8;
+      const int j = L >> 3;
+      pair = (j % per_xcd) * 8 + (L & 7);
+      rank = j / per_xcd;
+    } else {
+      pair = L % pairs;
+      rank = L / pairs;
+    }
+    tile = p.num_tiles - 1 - rank;
+    kvh = pair % p.num_kv_heads;
+    b = pair / p.num_kv_heads;
+  }
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int l31 = lane & 31;
+  const int hi = lane >> 5;
+
+  const int q_begin = p.qo_indptr[b];
+  const int ext_len = p.qo_indptr[b + 1] - q_begin;
+  const int kv_len = p.seq_lens[b];
+  const int prefix = p.prefix_lens[b];
+  const int32_t* idx_base = p.req_to_token + p.req_pool_indices[b] * p.r2t_stride;
+  const int q0 = tile * p.tokens_per_tile;
+  if (q0 >= ext_len) return;
+  int q1 = q0 + p.tokens_per_tile;
+  if (q1 > ext_len) q1 = ext_len;
+  const bool causal = p.causal != 0;
+  const int kv_end = causal ? (prefix + q1 < kv_len ? prefix + q1 : kv_len) : kv_len;
+  const int n_tiles = (kv_end + kKvTile - 1) / kKvTile;
+
+  // ---- this lane's row (both lane halves of a row hold the same query, other head dims / keys) ----
+  const int r_row = wid * 32 + l31;
+  const int r_tok = r_row / p.group;
+  const int r_hg = r_row - r_tok * p.group;
+  const bool row_ok = (r_tok < p.tokens_per_tile) && (q0 + r_tok < q1);
+  int row_limit = row_ok ? (causal ? prefix + q0 + r_tok + 1 : kv_len) : 0;
+  if (row_limit > kv_len) row_limit = kv_len;
+  const int row_off = (kvh * p.group + r_hg) * D;
+  U4 qreg[KS];                                      // Q^T operand of k-step s: dims 16 s + 8 h .. + 7 of the row
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    U4 qf = U4{0u, 0u, 0u, 0u};
+    if (row_ok) qf = ld16(p.q + static_cast<int64_t>(q_begin + q0 + r_tok) * p.q_stride + row_off + s * 16 + hi * 8);
+    qreg[s] = qf;
+  }
+
+  f32x16_t ot[ND];
+#pragma unroll
+  for (int n = 0; n < ND; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[n][r] = 0.f;
+  float m_run = kNegBig, l_run = 0.f;               // l: this lane's share of the row sum
+
+  // ---- staging: thread = (row st_r + ROWS_PER_PASS i, 16-byte chunk st_c) of a K tile and of a V tile ----
+  const int st_c = tid % CPR, st_r = tid / CPR;
+  int32_t idx_k[LOADS], idx_v[LOADS];
+  U4 kst[LOADS], vst[LOADS];
+  auto load_idx = [&](int t, int32_t (&dst)[LOADS]) {
+    const int last = kv_end - 1;
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+      int tok = t * kKvTile + st_r + ROWS_PER_PASS * i;
+      if (tok > last) tok = last;
+      dst[i] = idx_base[tok];
+    }
+  };
+  const unsigned char* k_rows = reinterpret_cast<const unsigned char*>(p.k_cache) + static_cast<uint64_t>(kvh) * p.fmt.head_stride + st_c * 16;
+  const unsigned char* v_rows = reinterpret_cast<const unsigned char*>(p.v_cache) + static_cast<uint64_t>(kvh) * p.fmt.head_stride + st_c * 16;
+  auto load_k = [&]() {
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) kst[i] = ld16(k_rows + static_cast<uint64_t>(static_cast<uint32_t>(idx_k[i])) * p.fmt.page_stride);
+  };
+  auto load_v = [&]() {
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) vst[i] = ld16(v_rows + static_cast<uint64_t>(static_cast<uint32_t>(idx_v[i])) * p.fmt.page_stride);
+  };
+  auto commit_k = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+      const int row = st_r + ROWS_PER_PASS * i;
+      sm.k[buf][row * CPR + (st_c ^ ((row * CPR / 16) & (CPR - 1)))] = kst[i];
+    }
+  };
+  auto commit_v = [&](int buf) {
+    unsigned char* base = reinterpret_cast<unsigned char*>(sm.v[buf]) + (st_c >> 2) * VSUB + (st_c & 3) * 16;
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+      const int row = st_r + ROWS_PER_PASS * i;
+      *reinterpret_cast<U4*>(base + row * 64) = vst[i];
+    }
+  };
+  // V^T operand reads: lane i of 16-lane group g points at token row 4 (g >> 1) + (i >> 2), dims 16 (g & 1) + 4 (i & 3)
+  const int v_lane = (4 * hi + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
+
+  // what step 0 expects: K(0) in LDS; V(0) and K(1) on their way to the staging registers; the ids of V(1), K(2) too
+  load_idx(0, idx_k);
+  load_k();                                          // K tile 0
+  load_idx(0, idx_v);
+  load_v();                                          // V tile 0 (written to LDS in step 0)
+  load_idx(1, idx_k);
+  load_idx(1, idx_v);
+  commit_k(0);
+  load_k();                                          // K tile 1 (written in step 0)
+  load_idx(2, idx_k);
+  __syncthreads();
+
+  f32x16_t sacc[2];
+  // bf16(P): [2 blk + ks] -> the 16 keys of one PV k-step.  ONE set: the second half of the products reads entries 2, 3
+  // of tile t - 1 while the exponentials of tile t fill entries 0, 1 and then -- each behind the last product that
+  // reads it -- 2 and 3
+  U4 pp[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) pp[i] = U4{0u, 0u, 0u, 0u};
+
+  // One tile step.  HAVE_S: scores of tile t are made and exponentiated; HAVE_PV: the products of tile t - 1 run
+  // (first step: scores only, last step: products only -- three straight-line copies, no branch between the products).
+#ifdef EXT_TRACE
+  uint64_t tacc[6] = {0, 0, 0, 0, 0, 0};            // [staging, S^T, max, PV || exp, tail, barrier] clocks over the walk
+  uint64_t tprev = __builtin_readcyclecounter();
+  const uint64_t tstart = tprev;
+#endif
+  auto step = [&](int t, auto have_s_tag, auto have_pv_tag) {
+    constexpr bool HAVE_S = decltype(have_s_tag)::value, HAVE_PV = decltype(have_pv_tag)::value;
+    // ---- staging: what was asked for a whole step ago goes to LDS first (V(t), K(t + 1): images nobody reads before
+    // the barrier below); the same registers are asked for V(t + 1), K(t + 2) and the slot ids of the tiles after them
+    // BETWEEN the S^T products, one request per product or two: issued in one burst after the barrier the eight waves'
+    // 64 requests queue for the CU's one address unit (~850 clocks per tile, benchmarks/r02_exp9_ext_trace.py).
+    // No tile-count conditions: a walk's last steps re-read its last row (load_idx clamps) into images nobody reads.
+    if constexpr (HAVE_S) {
+      commit_v(t & 1);
+      commit_k((t + 1) & 1);
+    }
+    auto request = [&](int j) __attribute__((always_inline)) {
+#ifdef EXT_LADDER_X_NOLOAD                           // timing experiment only (wrong results): what the requests cost
+      return;
+#endif
+      const int last = kv_end - 1;
+      if (j < LOADS) {
+        vst[j] = ld16(v_rows + static_cast<uint64_t>(static_cast<uint32_t>(idx_v[j])) * p.fmt.page_stride);
+      } else if (j < 2 * LOADS) {
+        int tok = (t + 2) * kKvTile + st_r + ROWS_PER_PASS * (j - LOADS);
+        idx_v[j - LOADS] = idx_base[tok > last ? last : tok];
+      } else if (j < 3 * LOADS) {
+        kst[j - 2 * LOADS] = ld16(k_rows + static_cast<uint64_t>(static_cast<uint32_t>(idx_k[j - 2 * LOADS])) * p.fmt.page_stride);
+      } else {
+        int tok = (t + 3) * kKvTile + st_r + ROWS_PER_PASS * (j - 3 * LOADS);
+        idx_k[j - 3 * LOADS] = idx_base[tok > last ? last : tok];
+      }
+    };
+    constexpr int RSTRIDE = (2 * KS) / (4 * LOADS);   // products per request (2 at D = 128 with 8 waves)
+    static_assert(RSTRIDE >= 1 && RSTRIDE * 4 * LOADS == 2 * KS, "requests spread evenly over the S^T products");
+    EXT_T(0);
+    // ---- S^T(t) = K(t) . Q^T: the two key blocks alternate (independent accumulators back to back), fragments are
+    // read two products ahead ---------------------------------------------------------------------------------
+    if constexpr (HAVE_S) {
+      const U4* kimg = sm.k[t & 1];
+      U4 kf[3];
+      auto read_k = [&](int i) {                     // product i = (block i & 1, k-step i >> 1)
+        const int row = (i & 1) * 32 + l31;
+        return kimg[row * CPR + ((2 * (i >> 1) + hi) ^ ((row * CPR / 16) & (CPR - 1)))];
+      };
+      kf[0] = read_k(0);
+      kf[1] = read_k(1);
+#pragma unroll
+      for (int i = 0; i < 2 * KS; ++i) {
+        if (i + 2 < 2 * KS) kf[(i + 2) % 3] = read_k(i + 2);
+        f32x16_t acc = sacc[i & 1];
+        if (i < 2) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        }
+        sacc[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(kf[i % 3]), as_frag(qreg[i >> 1]), acc, 0, 0, 0);
+        if (i % RSTRIDE == 0) request(i / RSTRIDE);
+        __builtin_amdgcn_sched_barrier(0);           // one read (two products ahead) and at most one request per product
+      }
+    }
+    EXT_T(1);
+    // ---- O^T += V^T(t - 1) . P^T(t - 1), first half of the products  ||  max(t) and the rescale decision.
+    // In-order issue: a wave cannot start vector work while its matrix instructions queue for the pipe, so the maxima
+    // of an unmasked tile are placed BETWEEN the products (four per product); a tile that needs the mask (the diagonal
+    // ones) takes its maxima first and the bare products after them.
+    float m_new = m_run, alpha = 1.f, neg_m = 0.f, psum = 0.f;
+    bool raise = false;
+    const unsigned char* vbase = reinterpret_cast<const unsigned char*>(sm.v[(t - 1) & 1]) + v_lane;
+    typedef __attribute__((address_space(3))) v4s16_t* lds_v4_t;
+    auto read_v = [&](int i) __attribute__((always_inline)) {    // product i = (output block i % ND, k-step i / ND of the tile)
+      const unsigned char* a = vbase + (i % ND) * VSUB + (i / ND) * (16 * 64);
+      const v4s16_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(a));
+      const v4s16_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(a + 8 * 64));
+      U4 o;
+      o.x = __builtin_bit_cast(uint2, lo).x; o.y = __builtin_bit_cast(uint2, lo).y;
+      o.z = __builtin_bit_cast(uint2, hi4).x; o.w = __builtin_bit_cast(uint2, hi4).y;
+      return o;
+    };
+    U4 vf[3];
+    auto product = [&](int i) __attribute__((always_inline)) {   // fragments two products ahead
+      if (i + 2 < NPV) vf[(i + 2) % 3] = read_v(i + 2);
+      ot[i % ND] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(vf[i % 3]), as_frag(pp[i / ND]), ot[i % ND], 0, 0, 0);
+    };
+    constexpr int H1 = NPV / 2;                       // products that run beside the maxima
+    if constexpr (HAVE_PV) {
+      vf[0] = read_v(0);
+      vf[1] = read_v(1);
+    }
+    if constexpr (HAVE_S) {
+      const int kv0 = t * kKvTile;
+      const bool full = __ballot(kv0 + kKvTile > row_limit) == 0ull;        // wave-uniform
+      if (!full) {
+        // the sentinel goes in BEFORE the scale: exp2(sentinel * scale - m) = 0 whatever m is
+#pragma unroll
+        for (int bk = 0; bk < 2; ++bk)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int kvpos = kv0 + 32 * bk + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            sacc[bk][r] = kvpos < row_limit ? sacc[bk][r] : kNegBig;
+          }
+      }
+      // 31 maxima as four chains: the first H1 products carry 24 / H1 links each (D = 128: three per product)
+      float m4[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) m4[c] = fmaxf(sacc[0][c], sacc[1][c]);
+      constexpr int LINKS = 24;                       // registers 4 .. 15 of both blocks
+      constexpr int PER = (LINKS + H1 - 1) / H1;
+#pragma unroll
+      for (int i = 0; i < H1; ++i) {
+        if constexpr (HAVE_PV) product(i);
+#pragma unroll
+        for (int j = PER * i; j < PER * (i + 1) && j < LINKS; ++j) {
+          const int bk = j / 12, r = 4 + j % 12;
+          m4[r & 3] = fmaxf(m4[r & 3], sacc[bk][r]);
+        }
+        if constexpr (HAVE_PV) __builtin_amdgcn_sched_barrier(0);
+      }
+      const float mraw = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+      float mx = mraw > 0.5f * kNegBig ? mraw * p.scale_log2 : kNegBig;     // a row with every key masked keeps the sentinel
+      mx = lane_pair_max(mx);
+      raise = __ballot(mx > m_run + kDeferMax) != 0ull;                     // wave-uniform
+      if (raise) {
+        m_new = fmaxf(m_run, mx);
+        alpha = fast_exp2(m_run - m_new);
+      }
+      // rows that have seen no key yet keep the sentinel as maximum: their (all masked) scores must give 0, not 1
+      neg_m = m_new > 0.5f * kNegBig ? -m_new : 0.f;
+    } else {
+#pragma unroll
+      for (int i = 0; i < H1; ++i) product(i);
+    }
+    EXT_T(2);
+    // ---- second half of the products  ||  P(t) = exp2(S(t) scale - m): the 32 exponentials as a three-stage software
+    // pipeline over the remaining products, so that no instruction of a group waits for one issued just before it:
+    // A(i) scale + subtract,  B(i) exp2,  C(i) sum + pack ----------------------------------------------------------
+    {
+      constexpr int H2 = NPV - H1;                    // products of this half
+      constexpr int SPP2 = 32 / H2;                   // scores beside each of them (4 at D = 128, 8 at D = 64)
+      float ta[SPP2], eb[SPP2];
+      auto stage_a = [&](int i) {
+#pragma unroll
+        for (int j = 0; j < SPP2; ++j) {
+          const int x = SPP2 * i + j;                 // flat score index: block x >> 4, register x & 15
+          ta[j] = fmaf(sacc[x >> 4][x & 15], p.scale_log2, neg_m);
+        }
+      };
+      auto stage_b = [&]() {
+#pragma unroll
+        for (int j = 0; j < SPP2; ++j) eb[j] = fast_exp2(ta[j]);
+      };
+      auto stage_c = [&](int i) {
+        uint32_t* pw = reinterpret_cast<uint32_t*>(pp);
+#pragma unroll
+        for (int j = 0; j < SPP2; j += 2) {
+          psum += eb[j] + eb[j + 1];
+          pw[(SPP2 * i + j) >> 1] = pack_bf2(eb[j], eb[j + 1]);   // word (x & 7) >> 1 of pp[x >> 3]
+        }
+      };
+      if constexpr (HAVE_S) stage_a(0);
+#pragma unroll
+      for (int i = 0; i < H2; ++i) {
+        if constexpr (HAVE_PV) product(H1 + i);
+        if constexpr (HAVE_S) {
+          if (i >= 1) stage_c(i - 1);
+          stage_b();
+          if (i + 1 < H2) stage_a(i + 1);
+        }
+        // groups stay as written: hipcc otherwise issues the products first and the vector work behind them
+        if constexpr (HAVE_S && HAVE_PV) __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (HAVE_S) stage_c(H2 - 1);
+      if constexpr (HAVE_S) {
+        // P(t) and its sum are "used" here: without it hipcc sinks the whole exponential stream below the (rare)
+        // rescale branch, out of the matrix instructions' shadow
+        asm volatile("" : "+v"(psum));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(pp[i].x), "+v"(pp[i].y), "+v"(pp[i].z), "+v"(pp[i].w));
+      }
+    }
+    EXT_T(3);
+    // ---- the raised maximum reaches O and l only now: the products above were exponentiated against the old one ----
+    if constexpr (HAVE_S) {
+      if (raise) {
+        l_run *= alpha;
+#pragma unroll
+        for (int n = 0; n < ND; ++n) ot[n] *= alpha;
+        m_run = m_new;
+      }
+      l_run += psum;
+    }
+    EXT_T(4);
+#ifndef EXT_LADDER_X_NOBARRIER                       // timing experiment only (races): what the barrier costs
+    __syncthreads();
+#endif
+    EXT_T(5);
+  };
+#ifdef EXT_LADDER_PRIO
+  if (__builtin_amdgcn_readfirstlane(wid) >= NWV / 2) __builtin_amdgcn_s_setprio(1);   // the younger half of the waves
+#endif
+  if (n_tiles > 0) {
+    step(0, std::true_type{}, std::false_type{});
+    for (int t = 1; t < n_tiles; ++t) step(t, std::true_type{}, std::true_type{});
+    step(n_tiles, std::false_type{}, std::true_type{});
+  }
+#ifdef EXT_TRACE
+  if (g_ext_trace && lane == 0) {
+    uint64_t* o = g_ext_trace + static_cast<int64_t>(blockIdx.x) * 64 + wid * 8;
+    for (int i = 0; i < 6; ++i) o[i] = tacc[i];
+    o[6] = n_tiles;
+    o[7] = tstart;
+  }
+#endif
+
+  // ---- epilogue: lane (q, h) holds O^T[d = 32 n + 8 c + 4 h + e][q], c = 0..3, e = 0..3.  The lane halves trade
+  // 4-dim pieces (v_permlane32_swap on the packed words) so that h = 0 owns the 8 dims of c = 0, 2 and h = 1 those of
+  // c = 1, 3: eight 16-byte stores per lane instead of sixteen 8-byte ones ------------------------------------
+  float l = l_run;
+  l += __shfl_xor(l, 32, 64);
+  const float inv = (l > 0.f) ? 1.0f / l : 0.f;
+  uint16_t* op = p.out + static_cast<int64_t>(q_begin + q0 + r_tok) * p.out_stride + row_off;
+#pragma unroll
+  for (int n = 0; n < ND; ++n) {
+#pragma unroll
+    for (int cp = 0; cp < 2; ++cp) {                  // the piece pair (c = 2 cp, c = 2 cp + 1)
+      uint32_t a0 = pack_bf2(ot[n][8 * cp + 0] * inv, ot[n][8 * cp + 1] * inv);
+      uint32_t a1 = pack_bf2(ot[n][8 * cp + 2] * inv, ot[n][8 * cp + 3] * inv);
+      uint32_t b0 = pack_bf2(ot[n][8 * cp + 4] * inv, ot[n][8 * cp + 5] * inv);
+      uint32_t b1 = pack_bf2(ot[n][8 * cp + 6] * inv, ot[n][8 * cp + 7] * inv);
+      // swap: upper half of a <-> lower half of b.  Afterwards a = dims 0-3, b = dims 4-7 of the lane's own piece
+      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a0), "+v"(b0));
+      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a1), "+v"(b1));
+      if (row_ok) {
+        U4 w;
+        w.x = a0; w.y = a1; w.z = b0; w.w = b1;
+        *reinterpret_cast<U4*>(op + n * 32 + (2 * cp + hi) * 8) = w;
+      }
+    }
+  }
+}
+
 // Test-only probe: C[16x16] = A[16x32] . B[32x16] with the operand/result lane
 // maps this file assumes (A row = lane&15, k = 8*(lane>>4)+j; C row = 4*(lane>>4)+r,
 // col = lane&15).  tests/ checks it against a plain matmul.
@@ -855,7 +1267,7 @@ __global__ void mfma_probe_kernel(const uint16_t* __restrict__ a, const uint16_t
 
 // test / tuning overrides (process-wide, set through sgl_amd_debug_extend_attention_shape; never read from the environment)
 static int g_extend_debug_shape = 0;      // 0: automatic; 41 / 42 / 82: waves x M-tiles per wave
-static int g_extend_debug_flags = 0;      // bit 0: keep bf16 8-wave launches on the single-image kernel
+static int g_extend_debug_flags = 0;      // bit 0: keep bf16 8-wave launches on the single-image kernel; bit 1: the 32x32 form
 
 extern "C" {
 
@@ -954,13 +1366,25 @@ int sgl_amd_extend_attention_ex(const void* q, void* out, const void* k_cache, c
   const int tiles = (max_extend_len + p.tokens_per_tile - 1) / p.tokens_per_tile;
   dim3 grid(tiles, num_kv_heads, batch);
   hipStream_t st = as_stream(stream);
+  const bool plain_bf16 = !kv_fp8 && !kv_layout_hnd && sliding_window < 0 && logit_cap == 0.f && custom_mask == nullptr;
+  if (plain_bf16 && nwv == 4 && mtw == 2 && (g_extend_debug_flags & 2) != 0) {   // the 32x32 form, 128 rows per workgroup
+    p.num_tiles = tiles; p.batch = static_cast<int>(batch);
+    const dim3 grid1(static_cast<unsigned>(tiles) * num_kv_heads * static_cast<unsigned>(batch));
+    if (head_dim == 128) hipLaunchKernelGGL((extend_attention_ladder_kernel<128, 4>), grid1, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((extend_attention_ladder_kernel<64, 4>), grid1, dim3(256), 0, st, p);
+    SGL_CHECK_LAUNCH("extend_attention");
+    return 0;
+  }
   // token-major bf16 pools, 8-wave shape: the double-buffered kernel
   const bool dbuf = !kv_fp8 && !kv_layout_hnd && nwv == 8 && sliding_window < 0 && logit_cap == 0.f && custom_mask == nullptr &&
                     (g_extend_debug_flags & 1) == 0;
   if (dbuf) {
     p.num_tiles = tiles; p.batch = static_cast<int>(batch);
     const dim3 grid1(static_cast<unsigned>(tiles) * num_kv_heads * static_cast<unsigned>(batch));
-    if (head_dim == 128) hipLaunchKernelGGL((extend_attention_dbuf_kernel<128>), grid1, dim3(512), 0, st, p);
+    if ((g_extend_debug_flags & 2) != 0) {            // the 32x32 form
+      if (head_dim == 128) hipLaunchKernelGGL((extend_attention_ladder_kernel<128, 8>), grid1, dim3(512), 0, st, p);
+      else hipLaunchKernelGGL((extend_attention_ladder_kernel<64, 8>), grid1, dim3(512), 0, st, p);
+    } else if (head_dim == 128) hipLaunchKernelGGL((extend_attention_dbuf_kernel<128>), grid1, dim3(512), 0, st, p);
     else hipLaunchKernelGGL((extend_attention_dbuf_kernel<64>), grid1, dim3(512), 0, st, p);
     SGL_CHECK_LAUNCH("extend_attention");
     return 0;

@@ -374,6 +374,32 @@ def test_extend_attention_double_buffered_equals_single_image_kernel(device, ext
     torch.testing.assert_close(o_dbuf.float(), o_single.float(), atol=2.0 ** -7, rtol=2.0 ** -7)
 
 
+@pytest.mark.parametrize("Hq,Hkv,D,causal", [(32, 8, 128, True), (8, 1, 128, True), (14, 2, 64, True), (16, 4, 128, False),
+                                             (4, 4, 64, False), (4, 4, 128, True), (64, 1, 128, True)])
+def test_extend_attention_32x32_form(device, extend_shape, Hq, Hkv, D, causal):
+    """The 32x32-MFMA form of the 8-wave kernel (one barrier per tile, exponentials between the previous tile's
+    products, raised maxima applied after the pending products): ragged batch with cached prefixes, one-token and
+    tile-straddling extends, GQA groups 1 .. 64 (7: rows of the last tile stay empty), and a late dominating key on a
+    late query (the deferred-rescale path, where the order of the rescale against the pending products matters)."""
+    prefix = [0, 896, 5, 0, 63, 64, 200, 1000] if causal else [0, 0, 0, 0]
+    extend = [130, 128, 1, 333, 65, 64, 7, 70] if causal else [50, 64, 129, 300]
+    c = _random_case(len(prefix), Hq, Hkv, D, prefix, extend, seed=Hq + D + 3232, spike=True)
+    c["q"][-3] = (c["k_cache"][c["req_to_token"][c["req_pool_indices"][-1], 3].long(), 0] * 30).to(BF)
+    # ... and a key deep inside a long walk that dominates a query of the fourth request only from its tile on
+    tok = c["req_to_token"][c["req_pool_indices"][3], 200].long()
+    c["k_cache"][tok, 0] = (c["q"][int(sum(extend[:3])) + extend[3] - 20, 0] * 60).to(BF)
+    ref = oo.extend_attention(c["q"], c["k_cache"], c["v_cache"], c["req_to_token"], c["req_pool_indices"],
+                              c["seq_lens"], c["extend_prefix_lens"], c["extend_seq_lens"], c["scaling"],
+                              causal=causal, compute_dtype=torch.float32)
+    extend_shape("82")
+    o_pp = _run_extend(c, device, causal=causal)
+    for shape in ("82", "42"):                    # 8 waves (256 rows per workgroup) and 4 waves (128 rows, two per CU)
+        extend_shape(shape, flags=2)
+        o = _run_extend(c, device, causal=causal)
+        torch.testing.assert_close(o.float(), ref.float(), atol=4e-3, rtol=1e-2, msg=shape)
+        torch.testing.assert_close(o.float(), o_pp.float(), atol=2.0 ** -7, rtol=2.0 ** -7, msg=shape)
+
+
 def test_decode_equals_extend_of_one_token(device):
     """Size-independent property: decoding token n == extending by one token over prefix n-1."""
     lens = [700, 1024, 33]
