@@ -31,9 +31,9 @@ fn = native.lib().sgl_amd_debug_ext_trace
 fn.argtypes = [C.c_void_p]
 fn.restype = C.c_int
 out = {}
-FLAGS = int(os.environ.get("EXT_FLAGS", "0"))          # 2: the 32x32 form (phases: staging, s_t, max, pv_exp, tail, barrier)
+FLAGS = int(os.environ.get("EXT_FLAGS", "0"))          # 0: the 32x32 two-score-set kernel; 2: the ping-pong kernel
 native.call("sgl_amd_debug_extend_attention_shape", 0, FLAGS)
-names = ["issue", "s_t", "softmax", "pv", "commit", "barrier"] if FLAGS == 0 else ["staging", "s_t", "max", "pv_exp", "tail", "barrier"]
+names = {2: ["issue", "s_t", "softmax", "pv", "commit", "barrier"], 0: ["commit", "s_exp", "mask", "pv_max", "decision", "barrier"]}[FLAGS]
 for name, nreq, pre, e in (("cold", 4, 0, 1024), ("warm", 60, 896, 128), ("long", 2, 0, 4096)):
     T = nreq * e
     qx = torch.randn((T, Hq, D), device=dev).to(BF)
@@ -66,4 +66,4 @@ for name, nreq, pre, e in (("cold", 4, 0, 1024), ("warm", 60, 896, 128), ("long"
     out[name] = r
     print(name, json.dumps(r))
 (ROOT / "gpurun_out").mkdir(exist_ok=True)
-(ROOT / "gpurun_out" / ("r03_exp9_ext_trace.json" if FLAGS == 0 else "r03_exp9_ext_trace_form32" + ("_local" if os.environ.get("EXT_LOCAL") else "") + ".json")).write_text(json.dumps(out, indent=1))
+(ROOT / "gpurun_out" / (("r03_exp9_ext_trace_pingpong" if FLAGS == 2 else "r03_exp9_ext_trace_32x32") + ("_local" if os.environ.get("EXT_LOCAL") else "") + ".json")).write_text(json.dumps(out, indent=1))

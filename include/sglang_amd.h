@@ -430,8 +430,9 @@ int sgl_amd_extend_attention_ex(const void* q, void* out, const void* k_cache, c
                                 int sliding_window, float logit_cap, const void* custom_mask, const int64_t* mask_indptr, int skip_prefix_custom_mask,
                                 void* stream);
 /* Test / tuning override of the extend kernel's workgroup shape (process-wide; the library never reads the
- * environment): shape 0 = automatic, 41 / 42 / 82 = waves x 16-row tiles per wave; flags bit 0 keeps bf16 8-wave
- * launches on the single-image kernel.  Not part of the reference surface. */
+ * environment): shape 0 = automatic, 41 / 42 / 82 = waves x 16-row tiles per wave (rows per workgroup 64 / 128 / 256);
+ * flags bit 0 keeps bf16 8-wave launches on the general single-image kernel, bit 1 sends them to the ping-pong
+ * 16x16x32 kernel the 32x32 two-score-set kernel replaced (A/B runs).  Not part of the reference surface. */
 int sgl_amd_debug_extend_attention_shape(int shape, int flags);
 
 /* ---- row-tiled grouped GEMM for prefill-sized MoE batches (reference: fused_moe_triton_kernels.py:324,771 with

@@ -835,23 +835,25 @@ __global__ __launch_bounds__(512, 2) void extend_attention_dbuf_kernel(ExtendPar
 }
 
 // ---------------------------------------------------------------------------------------------
-// The 32x32 form of the bf16 8-wave kernel (same launches as extend_attention_dbuf_kernel: token-major bf16 pool, causal
-// or not, no window / cap / mask).  What changes against the ping-pong kernel above:
+// The 32x32 form of the bf16 8-wave kernel: what every prefill of the bench runs (token-major bf16 pool, causal or not,
+// no window / cap / mask; the ping-pong kernel above stays selectable for A/B runs).  What changes against it:
 //   * v_mfma_f32_32x32x16_bf16: one wave = 32 rows (query token x head of the group), a 64-key tile = two 32-key blocks.
 //     S^T = K . Q^T leaves lane (q = lane & 31, h = lane >> 5) with 32 scores of ONE row (keys 32 blk + (r & 3) +
 //     8 (r >> 2) + 4 h): the row maximum is an in-lane chain + ONE v_permlane32_swap, the row sum stays a per-lane partial
 //     until the epilogue, and bf16(P) of registers 8 ks .. 8 ks + 7 IS the B operand of O^T += V^T . P^T for the 16 keys
 //     {32 blk + 16 ks + (j & 3) + 8 (j >> 2) + 4 h}; the V^T operand is read in that key order (two ds_read_b64_tr_b16:
 //     keys kb + 4 h + 0..3 and kb + 8 + 4 h + 0..3).  Half the LDS fragment reads per flop of the 16x16x32 shape;
-//   * no role split and ONE barrier per tile: every wave runs  S^T(t)  ->  max(t)  ->  [ O^T += V^T P^T of tile t - 1  ||
-//     P(t) = exp2(S(t) - m) ]  with the exponentials, sums and packs of tile t placed between the matrix instructions of
-//     tile t - 1 (two P register sets); the two waves of a SIMD drift apart inside a tile and cover each other's
-//     vector-only stretches;
+//   * no role split and ONE barrier per tile; the vector work of a tile rides between the matrix instructions of its
+//     NEIGHBOURS (two score sets, see the kernel's own header);
 //   * V image per 32 head dims: [64 tokens][64 B] (+ a bank skew between the sub-images), so that the four 16-lane groups
 //     of a transposing read cover 512 contiguous bytes;
-//   * a raised maximum (rare: kDeferMax) is applied to O and l AFTER the pending products of tile t - 1, which were
-//     exponentiated against the old one (the order the softmax-rescale hazard asks for);
+//   * a raised maximum (rare: kDeferMax) is applied to O and l when everything exponentiated against the old one is
+//     inside them (the order the softmax-rescale hazard asks for);
 //   * the epilogue swaps 4-dim pieces between the lane halves and stores 16 bytes per lane.
+// Measured on MI355X (benchmarks/r03_exp4_ladder.py, profiles/r03_exp4_extend_32x32.json): 4 x 1024 cold 62 -> 52 us, 60 x 128
+// over 896 warm 197 -> 167 us, 2 x 4096 304 -> 279 us, 8 x 2952 676 -> 629 us.  A one-score-set version of the same
+// form (S^T(t) -> max(t) -> [products of t - 1 || exponentials of t]; commit 21c58e7..: 2-6 % slower) and its 4-wave /
+// two-workgroups-per-CU variant (slower again: twice the row requests per flop) were measured and dropped.
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
 template <int D>
@@ -867,10 +869,15 @@ __device__ __forceinline__ float lane_pair_max(float x) {         // max over la
   return fmaxf(a, b);
 }
 
-// NWV = waves per workgroup: 8 (256 rows share a staged tile, one workgroup per CU) or 4 (128 rows, two workgroups per
-// CU with their own barriers: one multiplies while the other stages, waits or runs its prologue / epilogue).
+// A step of the walk is two phases of products with the vector work of the NEIGHBOURING tiles spread between them:
+//     phase 1:  S^T(t + 1) = K(t + 1) . Q^T   ||  P(t) = exp2(S(t) scale - m)  and the row requests of the tiles ahead
+//     phase 2:  O^T += V^T(t) . P^T(t)        ||  mask + row maxima of S(t + 1)
+//     then the rescale decision for tile t + 1 (everything exponentiated against the old maximum -- P(t) -- is inside
+//     O and l by then), and ONE barrier.
+// Every product carries <= 7 vector instructions, none of them waiting for the product next to it; what is left outside
+// the products' shadow is the decision (a permlane, two ballots), four LDS writes and the barrier.
 template <int D, int NWV>
-__global__ __launch_bounds__(64 * NWV, 2) void extend_attention_ladder_kernel(ExtendParams p) {
+__global__ __launch_bounds__(64 * NWV, 2) void extend_attention_pipe_kernel(ExtendParams p) {
   __shared__ SmemLadder<D> sm;
   constexpr int CPR = D / 8;            // 16-byte chunks per KV row
   constexpr int KS = D / 16;            // MFMA k-steps over the head dim
@@ -982,231 +989,262 @@ __global__ __launch_bounds__(64 * NWV, 2) void extend_attention_ladder_kernel(Ex
   // V^T operand reads: lane i of 16-lane group g points at token row 4 (g >> 1) + (i >> 2), dims 16 (g & 1) + 4 (i & 3)
   const int v_lane = (4 * hi + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
 
-  // what step 0 expects: K(0) in LDS; V(0) and K(1) on their way to the staging registers; the ids of V(1), K(2) too
-  load_idx(0, idx_k);
-  load_k();                                          // K tile 0
-  load_idx(0, idx_v);
-  load_v();                                          // V tile 0 (written to LDS in step 0)
-  load_idx(1, idx_k);
-  load_idx(1, idx_v);
-  commit_k(0);
-  load_k();                                          // K tile 1 (written in step 0)
-  load_idx(2, idx_k);
+  auto load_rows = [&](const unsigned char* base, const int32_t (&ids)[LOADS], U4 (&dst)[LOADS]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) dst[i] = ld16(base + static_cast<uint64_t>(static_cast<uint32_t>(ids[i])) * p.fmt.page_stride);
+  };
+  auto put_k = [&](int buf, const U4 (&src)[LOADS]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+      const int row = st_r + ROWS_PER_PASS * i;
+      sm.k[buf][row * CPR + (st_c ^ ((row * CPR / 16) & (CPR - 1)))] = src[i];
+    }
+  };
+  auto put_v = [&](int buf, const U4 (&src)[LOADS]) __attribute__((always_inline)) {
+    unsigned char* base = reinterpret_cast<unsigned char*>(sm.v[buf]) + (st_c >> 2) * VSUB + (st_c & 3) * 16;
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) *reinterpret_cast<U4*>(base + (st_r + ROWS_PER_PASS * i) * 64) = src[i];
+  };
+  // ---- prologue: K(0), K(1), V(0) go to LDS in one round trip; K(2) and V(1) are asked for; ids of tiles 2 / 3 held.
+  // (Tiles behind the end of the walk: load_idx clamps to the walk's last row, nobody reads those images.) ----------
+  {
+    int32_t i0[LOADS], i1[LOADS];
+    U4 k0[LOADS], k1[LOADS], v0[LOADS];
+    load_idx(0, i0);
+    load_idx(1, i1);
+    load_rows(k_rows, i0, k0);
+    load_rows(k_rows, i1, k1);
+    load_rows(v_rows, i0, v0);
+    load_idx(2, idx_v);
+    load_idx(3, idx_k);
+    put_k(0, k0);
+    put_k(1, k1);
+    put_v(0, v0);
+    load_rows(k_rows, idx_v, kst);                   // K(2): written at the top of step 0
+    load_rows(v_rows, i1, vst);                      // V(1): same
+  }
   __syncthreads();
 
-  f32x16_t sacc[2];
-  // bf16(P): [2 blk + ks] -> the 16 keys of one PV k-step.  ONE set: the second half of the products reads entries 2, 3
-  // of tile t - 1 while the exponentials of tile t fill entries 0, 1 and then -- each behind the last product that
-  // reads it -- 2 and 3
-  U4 pp[4];
+  f32x16_t s_a[2], s_b[2];                           // the two score sets: tile t and tile t + 1 trade places every step
+  U4 pp[4];                                          // bf16(P(t)): [2 blk + ks] -> the 16 keys of one PV k-step
 #pragma unroll
   for (int i = 0; i < 4; ++i) pp[i] = U4{0u, 0u, 0u, 0u};
-
-  // One tile step.  HAVE_S: scores of tile t are made and exponentiated; HAVE_PV: the products of tile t - 1 run
-  // (first step: scores only, last step: products only -- three straight-line copies, no branch between the products).
 #ifdef EXT_TRACE
-  uint64_t tacc[6] = {0, 0, 0, 0, 0, 0};            // [staging, S^T, max, PV || exp, tail, barrier] clocks over the walk
+  uint64_t tacc[6] = {0, 0, 0, 0, 0, 0};            // [commit, phase 1, mask, phase 2, decision, barrier] clocks over the walk
   uint64_t tprev = __builtin_readcyclecounter();
   const uint64_t tstart = tprev;
 #endif
-  auto step = [&](int t, auto have_s_tag, auto have_pv_tag) {
-    constexpr bool HAVE_S = decltype(have_s_tag)::value, HAVE_PV = decltype(have_pv_tag)::value;
-    // ---- staging: what was asked for a whole step ago goes to LDS first (V(t), K(t + 1): images nobody reads before
-    // the barrier below); the same registers are asked for V(t + 1), K(t + 2) and the slot ids of the tiles after them
-    // BETWEEN the S^T products, one request per product or two: issued in one burst after the barrier the eight waves'
-    // 64 requests queue for the CU's one address unit (~850 clocks per tile, benchmarks/r02_exp9_ext_trace.py).
-    // No tile-count conditions: a walk's last steps re-read its last row (load_idx clamps) into images nobody reads.
-    if constexpr (HAVE_S) {
-      commit_v(t & 1);
-      commit_k((t + 1) & 1);
+
+  auto read_k = [&](const U4* kimg, int i) __attribute__((always_inline)) {   // product i = (block i & 1, k-step i >> 1)
+    const int row = (i & 1) * 32 + l31;
+    return kimg[row * CPR + ((2 * (i >> 1) + hi) ^ ((row * CPR / 16) & (CPR - 1)))];
+  };
+  // mask (when the tile needs it), the row maximum of the lane pair, and the rescale decision for tile t: m_run, l_run
+  // and O move to the new maximum together.  `links_done`: the in-lane maxima of registers 4..15 are in m4 already.
+  auto mask_tile = [&](f32x16_t (&sc)[2], int t) __attribute__((always_inline)) {
+    const int kv0 = t * kKvTile;
+    if (__ballot(kv0 + kKvTile > row_limit) != 0ull) {                      // wave-uniform
+      // the sentinel goes in BEFORE the scale: exp2(sentinel * scale - m) = 0 whatever m is
+#pragma unroll
+      for (int bk = 0; bk < 2; ++bk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kvpos = kv0 + 32 * bk + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          sc[bk][r] = kvpos < row_limit ? sc[bk][r] : kNegBig;
+        }
     }
-    auto request = [&](int j) __attribute__((always_inline)) {
-#ifdef EXT_LADDER_X_NOLOAD                           // timing experiment only (wrong results): what the requests cost
-      return;
-#endif
-      const int last = kv_end - 1;
-      if (j < LOADS) {
-        vst[j] = ld16(v_rows + static_cast<uint64_t>(static_cast<uint32_t>(idx_v[j])) * p.fmt.page_stride);
-      } else if (j < 2 * LOADS) {
-        int tok = (t + 2) * kKvTile + st_r + ROWS_PER_PASS * (j - LOADS);
-        idx_v[j - LOADS] = idx_base[tok > last ? last : tok];
-      } else if (j < 3 * LOADS) {
-        kst[j - 2 * LOADS] = ld16(k_rows + static_cast<uint64_t>(static_cast<uint32_t>(idx_k[j - 2 * LOADS])) * p.fmt.page_stride);
-      } else {
-        int tok = (t + 3) * kKvTile + st_r + ROWS_PER_PASS * (j - 3 * LOADS);
-        idx_k[j - 3 * LOADS] = idx_base[tok > last ? last : tok];
+  };
+  auto decide = [&](const float (&m4)[4], float psum) __attribute__((always_inline)) {
+    const float mraw = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+    float mx = mraw > 0.5f * kNegBig ? mraw * p.scale_log2 : kNegBig;      // a row with every key masked keeps the sentinel
+    mx = lane_pair_max(mx);
+    l_run += psum;
+    if (__ballot(mx > m_run + kDeferMax) != 0ull) {                         // wave-uniform; rare behind the first tiles
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = fast_exp2(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int n = 0; n < ND; ++n) ot[n] *= alpha;
+    }
+  };
+  constexpr int LINKS = 24;                          // in-lane maxima behind the first four: registers 4..15 of both blocks
+  auto link = [&](const f32x16_t (&sc)[2], float (&m4)[4], int j) __attribute__((always_inline)) {
+    const int bk = j / 12, r = 4 + j % 12;
+    m4[r & 3] = fmaxf(m4[r & 3], sc[bk][r]);
+  };
+
+  // ---- S(0) and its decision stand alone; the barrier keeps step 0's write of K(2) off the image they read --------
+  {
+    U4 kf[3];
+    kf[0] = read_k(sm.k[0], 0);
+    kf[1] = read_k(sm.k[0], 1);
+#pragma unroll
+    for (int i = 0; i < 2 * KS; ++i) {
+      if (i + 2 < 2 * KS) kf[(i + 2) % 3] = read_k(sm.k[0], i + 2);
+      f32x16_t acc = s_a[i & 1];
+      if (i < 2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
       }
-    };
-    constexpr int RSTRIDE = (2 * KS) / (4 * LOADS);   // products per request (2 at D = 128 with 8 waves)
-    static_assert(RSTRIDE >= 1 && RSTRIDE * 4 * LOADS == 2 * KS, "requests spread evenly over the S^T products");
+      s_a[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(kf[i % 3]), as_frag(qreg[i >> 1]), acc, 0, 0, 0);
+    }
+    mask_tile(s_a, 0);
+    float m4[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) m4[c] = fmaxf(s_a[0][c], s_a[1][c]);
+#pragma unroll
+    for (int j = 0; j < LINKS; ++j) link(s_a, m4, j);
+    decide(m4, 0.f);
+  }
+  __syncthreads();
+
+  auto step = [&](int t, f32x16_t (&sc)[2], f32x16_t (&sn)[2], auto have_next_tag) __attribute__((always_inline)) {
+    constexpr bool HAVE_NEXT = decltype(have_next_tag)::value;
+    // ---- what was asked for a step ago goes to LDS: K(t + 2), V(t + 1) -- images nobody reads before the barrier below.
+    // (Between the phases instead, with the requests beside the phase-2 products: same time per tile, the wait moves
+    // with the writes; and the registers no longer fit.)
+    put_k(t & 1, kst);
+    put_v((t + 1) & 1, vst);
     EXT_T(0);
-    // ---- S^T(t) = K(t) . Q^T: the two key blocks alternate (independent accumulators back to back), fragments are
-    // read two products ahead ---------------------------------------------------------------------------------
-    if constexpr (HAVE_S) {
-      const U4* kimg = sm.k[t & 1];
-      U4 kf[3];
-      auto read_k = [&](int i) {                     // product i = (block i & 1, k-step i >> 1)
-        const int row = (i & 1) * 32 + l31;
-        return kimg[row * CPR + ((2 * (i >> 1) + hi) ^ ((row * CPR / 16) & (CPR - 1)))];
-      };
-      kf[0] = read_k(0);
-      kf[1] = read_k(1);
-#pragma unroll
-      for (int i = 0; i < 2 * KS; ++i) {
-        if (i + 2 < 2 * KS) kf[(i + 2) % 3] = read_k(i + 2);
-        f32x16_t acc = sacc[i & 1];
-        if (i < 2) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        }
-        sacc[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(kf[i % 3]), as_frag(qreg[i >> 1]), acc, 0, 0, 0);
-        if (i % RSTRIDE == 0) request(i / RSTRIDE);
-        __builtin_amdgcn_sched_barrier(0);           // one read (two products ahead) and at most one request per product
-      }
-    }
-    EXT_T(1);
-    // ---- O^T += V^T(t - 1) . P^T(t - 1), first half of the products  ||  max(t) and the rescale decision.
-    // In-order issue: a wave cannot start vector work while its matrix instructions queue for the pipe, so the maxima
-    // of an unmasked tile are placed BETWEEN the products (four per product); a tile that needs the mask (the diagonal
-    // ones) takes its maxima first and the bare products after them.
-    float m_new = m_run, alpha = 1.f, neg_m = 0.f, psum = 0.f;
-    bool raise = false;
-    const unsigned char* vbase = reinterpret_cast<const unsigned char*>(sm.v[(t - 1) & 1]) + v_lane;
-    typedef __attribute__((address_space(3))) v4s16_t* lds_v4_t;
-    auto read_v = [&](int i) __attribute__((always_inline)) {    // product i = (output block i % ND, k-step i / ND of the tile)
-      const unsigned char* a = vbase + (i % ND) * VSUB + (i / ND) * (16 * 64);
-      const v4s16_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(a));
-      const v4s16_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(a + 8 * 64));
-      U4 o;
-      o.x = __builtin_bit_cast(uint2, lo).x; o.y = __builtin_bit_cast(uint2, lo).y;
-      o.z = __builtin_bit_cast(uint2, hi4).x; o.w = __builtin_bit_cast(uint2, hi4).y;
-      return o;
-    };
-    U4 vf[3];
-    auto product = [&](int i) __attribute__((always_inline)) {   // fragments two products ahead
-      if (i + 2 < NPV) vf[(i + 2) % 3] = read_v(i + 2);
-      ot[i % ND] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(vf[i % 3]), as_frag(pp[i / ND]), ot[i % ND], 0, 0, 0);
-    };
-    constexpr int H1 = NPV / 2;                       // products that run beside the maxima
-    if constexpr (HAVE_PV) {
-      vf[0] = read_v(0);
-      vf[1] = read_v(1);
-    }
-    if constexpr (HAVE_S) {
-      const int kv0 = t * kKvTile;
-      const bool full = __ballot(kv0 + kKvTile > row_limit) == 0ull;        // wave-uniform
-      if (!full) {
-        // the sentinel goes in BEFORE the scale: exp2(sentinel * scale - m) = 0 whatever m is
-#pragma unroll
-        for (int bk = 0; bk < 2; ++bk)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int kvpos = kv0 + 32 * bk + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            sacc[bk][r] = kvpos < row_limit ? sacc[bk][r] : kNegBig;
-          }
-      }
-      // 31 maxima as four chains: the first H1 products carry 24 / H1 links each (D = 128: three per product)
-      float m4[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) m4[c] = fmaxf(sacc[0][c], sacc[1][c]);
-      constexpr int LINKS = 24;                       // registers 4 .. 15 of both blocks
-      constexpr int PER = (LINKS + H1 - 1) / H1;
-#pragma unroll
-      for (int i = 0; i < H1; ++i) {
-        if constexpr (HAVE_PV) product(i);
-#pragma unroll
-        for (int j = PER * i; j < PER * (i + 1) && j < LINKS; ++j) {
-          const int bk = j / 12, r = 4 + j % 12;
-          m4[r & 3] = fmaxf(m4[r & 3], sacc[bk][r]);
-        }
-        if constexpr (HAVE_PV) __builtin_amdgcn_sched_barrier(0);
-      }
-      const float mraw = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
-      float mx = mraw > 0.5f * kNegBig ? mraw * p.scale_log2 : kNegBig;     // a row with every key masked keeps the sentinel
-      mx = lane_pair_max(mx);
-      raise = __ballot(mx > m_run + kDeferMax) != 0ull;                     // wave-uniform
-      if (raise) {
-        m_new = fmaxf(m_run, mx);
-        alpha = fast_exp2(m_run - m_new);
-      }
-      // rows that have seen no key yet keep the sentinel as maximum: their (all masked) scores must give 0, not 1
-      neg_m = m_new > 0.5f * kNegBig ? -m_new : 0.f;
-    } else {
-#pragma unroll
-      for (int i = 0; i < H1; ++i) product(i);
-    }
-    EXT_T(2);
-    // ---- second half of the products  ||  P(t) = exp2(S(t) scale - m): the 32 exponentials as a three-stage software
-    // pipeline over the remaining products, so that no instruction of a group waits for one issued just before it:
-    // A(i) scale + subtract,  B(i) exp2,  C(i) sum + pack ----------------------------------------------------------
+    // ---- phase 1 ------------------------------------------------------------------------------------------
+    constexpr int KF = 3;                            // K fragment sets: reads run two products ahead (1 or 3 ahead: same time)
+    constexpr int G1 = 2 * KS;                       // products (16 at D = 128)
+    constexpr int SPP = 32 / G1;                     // scores exponentiated beside each (2 at D = 128, 4 at D = 64)
+    const float neg_m = m_run > 0.5f * kNegBig ? -m_run : 0.f;   // rows without a key so far: exp2(sentinel * scale) = 0
+    float psum = 0.f;
     {
-      constexpr int H2 = NPV - H1;                    // products of this half
-      constexpr int SPP2 = 32 / H2;                   // scores beside each of them (4 at D = 128, 8 at D = 64)
-      float ta[SPP2], eb[SPP2];
-      auto stage_a = [&](int i) {
+      // the staging registers are free again: V(t + 2) rows, K(t + 3) rows, the ids of tile t + 4 -- one request per
+      // RSTRIDE products (in one burst the eight waves' requests queue for the CU's one address unit)
+      constexpr int NREQ = 3 * LOADS;
+      constexpr int RSTRIDE = G1 / NREQ > 0 ? G1 / NREQ : 1;
+      static_assert(NREQ * RSTRIDE <= G1, "requests fit the products of phase 1");
+      auto request = [&](int j) __attribute__((always_inline)) {
+        if (j < LOADS) {
+          vst[j] = ld16(v_rows + static_cast<uint64_t>(static_cast<uint32_t>(idx_v[j])) * p.fmt.page_stride);
+        } else if (j < 2 * LOADS) {
+          if (j == LOADS) {
 #pragma unroll
-        for (int j = 0; j < SPP2; ++j) {
-          const int x = SPP2 * i + j;                 // flat score index: block x >> 4, register x & 15
-          ta[j] = fmaf(sacc[x >> 4][x & 15], p.scale_log2, neg_m);
+            for (int i = 0; i < LOADS; ++i) idx_v[i] = idx_k[i];          // the ids of K(t + 3) are those of V(t + 3) a step on
+          }
+          kst[j - LOADS] = ld16(k_rows + static_cast<uint64_t>(static_cast<uint32_t>(idx_k[j - LOADS])) * p.fmt.page_stride);
+        } else {
+          const int last = kv_end - 1;
+          const int tok = (t + 4) * kKvTile + st_r + ROWS_PER_PASS * (j - 2 * LOADS);
+          idx_k[j - 2 * LOADS] = idx_base[tok > last ? last : tok];
         }
       };
-      auto stage_b = [&]() {
+      // the exponentials as a three-stage software pipeline:  A(i) scale + subtract,  B(i) exp2,  C(i) sum + pack
+      float ta[SPP], eb[SPP];
+      auto stage_a = [&](int i) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < SPP2; ++j) eb[j] = fast_exp2(ta[j]);
+        for (int j = 0; j < SPP; ++j) {
+          const int x = SPP * i + j;                 // flat score index: block x >> 4, register x & 15
+          ta[j] = fmaf(sc[x >> 4][x & 15], p.scale_log2, neg_m);
+        }
       };
-      auto stage_c = [&](int i) {
+      auto stage_b = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < SPP; ++j) eb[j] = fast_exp2(ta[j]);
+      };
+      auto stage_c = [&](int i) __attribute__((always_inline)) {
         uint32_t* pw = reinterpret_cast<uint32_t*>(pp);
 #pragma unroll
-        for (int j = 0; j < SPP2; j += 2) {
+        for (int j = 0; j < SPP; j += 2) {
           psum += eb[j] + eb[j + 1];
-          pw[(SPP2 * i + j) >> 1] = pack_bf2(eb[j], eb[j + 1]);   // word (x & 7) >> 1 of pp[x >> 3]
+          pw[(SPP * i + j) >> 1] = pack_bf2(eb[j], eb[j + 1]);   // word (x & 7) >> 1 of pp[x >> 3]
         }
       };
-      if constexpr (HAVE_S) stage_a(0);
+      const U4* kimg = sm.k[(t + 1) & 1];
+      U4 kf[KF];
+      if constexpr (HAVE_NEXT) {
 #pragma unroll
-      for (int i = 0; i < H2; ++i) {
-        if constexpr (HAVE_PV) product(H1 + i);
-        if constexpr (HAVE_S) {
-          if (i >= 1) stage_c(i - 1);
-          stage_b();
-          if (i + 1 < H2) stage_a(i + 1);
-        }
-        // groups stay as written: hipcc otherwise issues the products first and the vector work behind them
-        if constexpr (HAVE_S && HAVE_PV) __builtin_amdgcn_sched_barrier(0);
+        for (int i = 0; i < KF - 1; ++i) kf[i] = read_k(kimg, i);
       }
-      if constexpr (HAVE_S) stage_c(H2 - 1);
-      if constexpr (HAVE_S) {
-        // P(t) and its sum are "used" here: without it hipcc sinks the whole exponential stream below the (rare)
-        // rescale branch, out of the matrix instructions' shadow
-        asm volatile("" : "+v"(psum));
+      stage_a(0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(pp[i].x), "+v"(pp[i].y), "+v"(pp[i].z), "+v"(pp[i].w));
+      for (int i = 0; i < G1; ++i) {
+        if constexpr (HAVE_NEXT) {
+          if (i + KF - 1 < G1) kf[(i + KF - 1) % KF] = read_k(kimg, i + KF - 1);
+          f32x16_t acc = sn[i & 1];
+          if (i < 2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+          }
+          sn[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(kf[i % KF]), as_frag(qreg[i >> 1]), acc, 0, 0, 0);
+          if (i % RSTRIDE == 0 && i / RSTRIDE < NREQ) request(i / RSTRIDE);
+        }
+        if (i >= 1) stage_c(i - 1);
+        stage_b();
+        if (i + 1 < G1) stage_a(i + 1);
+        if constexpr (HAVE_NEXT) __builtin_amdgcn_sched_barrier(0);   // groups stay as written
+      }
+      stage_c(G1 - 1);
+      // P(t) and its sum are "used" here: hipcc otherwise sinks the exponential stream below later branches
+      asm volatile("" : "+v"(psum));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(pp[i].x), "+v"(pp[i].y), "+v"(pp[i].z), "+v"(pp[i].w));
+    }
+    EXT_T(1);
+    if constexpr (HAVE_NEXT) mask_tile(sn, t + 1);
+    EXT_T(2);
+    // ---- phase 2 ------------------------------------------------------------------------------------------
+    float m4[4];
+    {
+      const unsigned char* vbase = reinterpret_cast<const unsigned char*>(sm.v[t & 1]) + v_lane;
+      typedef __attribute__((address_space(3))) v4s16_t* lds_v4_t;
+      auto read_v = [&](int i) __attribute__((always_inline)) {   // product i = (output block i % ND, k-step i / ND of the tile)
+        const unsigned char* a = vbase + (i % ND) * VSUB + (i / ND) * (16 * 64);
+        const v4s16_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(a));
+        const v4s16_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4_t)(a + 8 * 64));
+        U4 o;
+        o.x = __builtin_bit_cast(uint2, lo).x; o.y = __builtin_bit_cast(uint2, lo).y;
+        o.z = __builtin_bit_cast(uint2, hi4).x; o.w = __builtin_bit_cast(uint2, hi4).y;
+        return o;
+      };
+      constexpr int LSTART = NPV / 4;                // the first products run while the last S^T products still finish
+      constexpr int PER = LINKS / (NPV - LSTART);    // maxima per product behind them (2 at D = 128, 4 at D = 64)
+      static_assert(PER * (NPV - LSTART) == LINKS, "maxima spread evenly");
+      U4 vf[3];
+      vf[0] = read_v(0);
+      vf[1] = read_v(1);
+#pragma unroll
+      for (int i = 0; i < NPV; ++i) {
+        if (i + 2 < NPV) vf[(i + 2) % 3] = read_v(i + 2);
+        ot[i % ND] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(vf[i % 3]), as_frag(pp[i / ND]), ot[i % ND], 0, 0, 0);
+        if constexpr (HAVE_NEXT) {
+          if (i == LSTART) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) m4[c] = fmaxf(sn[0][c], sn[1][c]);
+          }
+          if (i >= LSTART) {
+#pragma unroll
+            for (int j = PER * (i - LSTART); j < PER * (i - LSTART + 1); ++j) link(sn, m4, j);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
     EXT_T(3);
-    // ---- the raised maximum reaches O and l only now: the products above were exponentiated against the old one ----
-    if constexpr (HAVE_S) {
-      if (raise) {
-        l_run *= alpha;
-#pragma unroll
-        for (int n = 0; n < ND; ++n) ot[n] *= alpha;
-        m_run = m_new;
-      }
-      l_run += psum;
-    }
+    // ---- the decision for tile t + 1: P(t) is inside O and l, nothing at the new maximum exists yet ----------
+    if constexpr (HAVE_NEXT) decide(m4, psum);
+    else l_run += psum;
     EXT_T(4);
-#ifndef EXT_LADDER_X_NOBARRIER                       // timing experiment only (races): what the barrier costs
     __syncthreads();
-#endif
     EXT_T(5);
   };
-#ifdef EXT_LADDER_PRIO
-  if (__builtin_amdgcn_readfirstlane(wid) >= NWV / 2) __builtin_amdgcn_s_setprio(1);   // the younger half of the waves
-#endif
-  if (n_tiles > 0) {
-    step(0, std::true_type{}, std::false_type{});
-    for (int t = 1; t < n_tiles; ++t) step(t, std::true_type{}, std::true_type{});
-    step(n_tiles, std::false_type{}, std::true_type{});
+  {
+    int t = 0;
+    for (; t + 2 < n_tiles; t += 2) {
+      step(t, s_a, s_b, std::true_type{});
+      step(t + 1, s_b, s_a, std::true_type{});
+    }
+    if (n_tiles - t == 2) {
+      step(t, s_a, s_b, std::true_type{});
+      step(t + 1, s_b, s_a, std::false_type{});
+    } else {
+      step(t, s_a, s_b, std::false_type{});
+    }
   }
 #ifdef EXT_TRACE
   if (g_ext_trace && lane == 0) {
@@ -1267,7 +1305,7 @@ __global__ void mfma_probe_kernel(const uint16_t* __restrict__ a, const uint16_t
 
 // test / tuning overrides (process-wide, set through sgl_amd_debug_extend_attention_shape; never read from the environment)
 static int g_extend_debug_shape = 0;      // 0: automatic; 41 / 42 / 82: waves x M-tiles per wave
-static int g_extend_debug_flags = 0;      // bit 0: keep bf16 8-wave launches on the single-image kernel; bit 1: the 32x32 form
+static int g_extend_debug_flags = 0;      // bit 0: bf16 8-wave launches stay on the general single-image kernel; bit 1: they take the ping-pong kernel
 
 extern "C" {
 
@@ -1366,26 +1404,17 @@ int sgl_amd_extend_attention_ex(const void* q, void* out, const void* k_cache, c
   const int tiles = (max_extend_len + p.tokens_per_tile - 1) / p.tokens_per_tile;
   dim3 grid(tiles, num_kv_heads, batch);
   hipStream_t st = as_stream(stream);
-  const bool plain_bf16 = !kv_fp8 && !kv_layout_hnd && sliding_window < 0 && logit_cap == 0.f && custom_mask == nullptr;
-  if (plain_bf16 && nwv == 4 && mtw == 2 && (g_extend_debug_flags & 2) != 0) {   // the 32x32 form, 128 rows per workgroup
-    p.num_tiles = tiles; p.batch = static_cast<int>(batch);
-    const dim3 grid1(static_cast<unsigned>(tiles) * num_kv_heads * static_cast<unsigned>(batch));
-    if (head_dim == 128) hipLaunchKernelGGL((extend_attention_ladder_kernel<128, 4>), grid1, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((extend_attention_ladder_kernel<64, 4>), grid1, dim3(256), 0, st, p);
-    SGL_CHECK_LAUNCH("extend_attention");
-    return 0;
-  }
-  // token-major bf16 pools, 8-wave shape: the double-buffered kernel
-  const bool dbuf = !kv_fp8 && !kv_layout_hnd && nwv == 8 && sliding_window < 0 && logit_cap == 0.f && custom_mask == nullptr &&
+  // token-major bf16 pools, 8-wave shape: the 32x32 two-score-set kernel (debug flag bit 1: the ping-pong kernel it replaced)
+  const bool fast = !kv_fp8 && !kv_layout_hnd && nwv == 8 && sliding_window < 0 && logit_cap == 0.f && custom_mask == nullptr &&
                     (g_extend_debug_flags & 1) == 0;
-  if (dbuf) {
+  if (fast) {
     p.num_tiles = tiles; p.batch = static_cast<int>(batch);
     const dim3 grid1(static_cast<unsigned>(tiles) * num_kv_heads * static_cast<unsigned>(batch));
-    if ((g_extend_debug_flags & 2) != 0) {            // the 32x32 form
-      if (head_dim == 128) hipLaunchKernelGGL((extend_attention_ladder_kernel<128, 8>), grid1, dim3(512), 0, st, p);
-      else hipLaunchKernelGGL((extend_attention_ladder_kernel<64, 8>), grid1, dim3(512), 0, st, p);
-    } else if (head_dim == 128) hipLaunchKernelGGL((extend_attention_dbuf_kernel<128>), grid1, dim3(512), 0, st, p);
-    else hipLaunchKernelGGL((extend_attention_dbuf_kernel<64>), grid1, dim3(512), 0, st, p);
+    if ((g_extend_debug_flags & 2) != 0) {
+      if (head_dim == 128) hipLaunchKernelGGL((extend_attention_dbuf_kernel<128>), grid1, dim3(512), 0, st, p);
+      else hipLaunchKernelGGL((extend_attention_dbuf_kernel<64>), grid1, dim3(512), 0, st, p);
+    } else if (head_dim == 128) hipLaunchKernelGGL((extend_attention_pipe_kernel<128, 8>), grid1, dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((extend_attention_pipe_kernel<64, 8>), grid1, dim3(512), 0, st, p);
     SGL_CHECK_LAUNCH("extend_attention");
     return 0;
   }

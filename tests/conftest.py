@@ -31,8 +31,9 @@ def device():
 
 @pytest.fixture
 def extend_shape():
-    """Force the extend-attention workgroup shape for one test (sgl_amd_debug_extend_attention_shape: "82" = 8 waves x
-    2 M-tiles, "42" / "41" = the 4-wave forms, "auto"); the override is cleared afterwards."""
+    """Force the extend-attention workgroup shape for one test (sgl_amd_debug_extend_attention_shape: "82" = 8 waves, 256
+    rows per workgroup, "42" / "41" = the 4-wave forms, "auto"; flags 1 = general single-image kernel, 2 = the ping-pong
+    kernel, 0 = the 32x32 two-score-set kernel where it applies); the override is cleared afterwards."""
     from sglang_amd import native
 
     def force(shape, flags=0):

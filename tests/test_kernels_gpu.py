@@ -335,9 +335,9 @@ def test_extend_attention_noncausal(device):
                                              (4, 4, 64, False)])
 def test_extend_attention_every_workgroup_shape(device, extend_shape, shape, Hq, Hkv, D, causal):
     """The launcher picks the workgroup shape from the grid size, so small test batches rarely reach the 8-wave
-    double-buffered ping-pong kernel the bench's prefills run on: the `extend_shape` fixture forces each shape in turn
-    (82 = 8 waves x 2 M-tiles, the dbuf kernel; 42 / 41 = the 4-wave forms) on a ragged batch with cached prefixes,
-    one-token and tile-straddling extends, and a late dominating key (the deferred-rescale path)."""
+    kernel the bench's prefills run on: the `extend_shape` fixture forces each shape in turn (82 = 8 waves, 256 rows: the
+    32x32 two-score-set kernel; 42 / 41 = the 4-wave forms) on a ragged batch with cached prefixes, one-token and
+    tile-straddling extends, and a late dominating key (the deferred-rescale path)."""
     if shape == "41" and Hq // Hkv > 64:
         pytest.skip("the 64-row shape holds groups up to 64")
     extend_shape(shape)
@@ -354,10 +354,11 @@ def test_extend_attention_every_workgroup_shape(device, extend_shape, shape, Hq,
 
 
 @pytest.mark.parametrize("Hq,Hkv,D,causal", [(32, 8, 128, True), (14, 2, 64, True), (16, 4, 128, False)])
-def test_extend_attention_double_buffered_equals_single_image_kernel(device, extend_shape, Hq, Hkv, D, causal):
-    """The 8-wave ping-pong kernel (two LDS images, software-pipelined fragment reads, deferred rescale) against the
-    single-image 8-wave kernel on the same launch shape: both within the oracle bar, and within 2^-7 of each other
-    (the deferred row maximum scales P by up to 2^8 before its bf16 rounding, so the two are not bit-identical)."""
+def test_extend_attention_eight_wave_kernels_agree(device, extend_shape, Hq, Hkv, D, causal):
+    """The three kernels an 8-wave bf16 launch can take -- the 32x32 two-score-set kernel (default), the ping-pong
+    16x16x32 kernel it replaced (flag 2) and the general single-image kernel (flag 1) -- on the same launch shape: each
+    within the oracle bar, and within 2^-7 of each other (a deferred row maximum scales P by up to 2^8 before its bf16
+    rounding, so they are not bit-identical)."""
     prefix = [0, 896, 5, 0, 63, 64, 200, 1000] if causal else [0, 0, 0, 0]
     extend = [130, 128, 1, 333, 65, 64, 7, 70] if causal else [50, 64, 129, 300]
     c = _random_case(len(prefix), Hq, Hkv, D, prefix, extend, seed=Hq + D + 82, spike=True)
@@ -365,22 +366,23 @@ def test_extend_attention_double_buffered_equals_single_image_kernel(device, ext
     ref = oo.extend_attention(c["q"], c["k_cache"], c["v_cache"], c["req_to_token"], c["req_pool_indices"],
                               c["seq_lens"], c["extend_prefix_lens"], c["extend_seq_lens"], c["scaling"],
                               causal=causal, compute_dtype=torch.float32)
-    extend_shape("82")
-    o_dbuf = _run_extend(c, device, causal=causal)
-    extend_shape("82", flags=1)
-    o_single = _run_extend(c, device, causal=causal)
-    torch.testing.assert_close(o_dbuf.float(), ref.float(), atol=4e-3, rtol=1e-2)
-    torch.testing.assert_close(o_single.float(), ref.float(), atol=4e-3, rtol=1e-2)
-    torch.testing.assert_close(o_dbuf.float(), o_single.float(), atol=2.0 ** -7, rtol=2.0 ** -7)
+    outs = {}
+    for name, flags in (("32x32", 0), ("ping-pong", 2), ("single-image", 1)):
+        extend_shape("82", flags=flags)
+        outs[name] = _run_extend(c, device, causal=causal)
+        torch.testing.assert_close(outs[name].float(), ref.float(), atol=4e-3, rtol=1e-2, msg=name)
+    for name in ("ping-pong", "single-image"):
+        torch.testing.assert_close(outs["32x32"].float(), outs[name].float(), atol=2.0 ** -7, rtol=2.0 ** -7, msg=name)
 
 
 @pytest.mark.parametrize("Hq,Hkv,D,causal", [(32, 8, 128, True), (8, 1, 128, True), (14, 2, 64, True), (16, 4, 128, False),
                                              (4, 4, 64, False), (4, 4, 128, True), (64, 1, 128, True)])
 def test_extend_attention_32x32_form(device, extend_shape, Hq, Hkv, D, causal):
-    """The 32x32-MFMA form of the 8-wave kernel (one barrier per tile, exponentials between the previous tile's
-    products, raised maxima applied after the pending products): ragged batch with cached prefixes, one-token and
-    tile-straddling extends, GQA groups 1 .. 64 (7: rows of the last tile stay empty), and a late dominating key on a
-    late query (the deferred-rescale path, where the order of the rescale against the pending products matters)."""
+    """The 32x32-MFMA two-score-set kernel (one barrier per tile; the exponentials of tile t ride beside the score
+    products of tile t + 1, its maxima beside the output products of tile t - 1; a raised maximum reaches O and l when
+    everything exponentiated against the old one is inside them): ragged batch with cached prefixes, one-token and
+    tile-straddling extends (walks of 1, 2, 3 and many tiles: each tail of the two-step loop), GQA groups 1 .. 64 (7:
+    rows of the last tile stay empty), and dominating keys late in a walk (the deferred-rescale path)."""
     prefix = [0, 896, 5, 0, 63, 64, 200, 1000] if causal else [0, 0, 0, 0]
     extend = [130, 128, 1, 333, 65, 64, 7, 70] if causal else [50, 64, 129, 300]
     c = _random_case(len(prefix), Hq, Hkv, D, prefix, extend, seed=Hq + D + 3232, spike=True)
@@ -392,12 +394,11 @@ def test_extend_attention_32x32_form(device, extend_shape, Hq, Hkv, D, causal):
                               c["seq_lens"], c["extend_prefix_lens"], c["extend_seq_lens"], c["scaling"],
                               causal=causal, compute_dtype=torch.float32)
     extend_shape("82")
+    o = _run_extend(c, device, causal=causal)
+    extend_shape("82", flags=2)
     o_pp = _run_extend(c, device, causal=causal)
-    for shape in ("82", "42"):                    # 8 waves (256 rows per workgroup) and 4 waves (128 rows, two per CU)
-        extend_shape(shape, flags=2)
-        o = _run_extend(c, device, causal=causal)
-        torch.testing.assert_close(o.float(), ref.float(), atol=4e-3, rtol=1e-2, msg=shape)
-        torch.testing.assert_close(o.float(), o_pp.float(), atol=2.0 ** -7, rtol=2.0 ** -7, msg=shape)
+    torch.testing.assert_close(o.float(), ref.float(), atol=4e-3, rtol=1e-2)
+    torch.testing.assert_close(o.float(), o_pp.float(), atol=2.0 ** -7, rtol=2.0 ** -7)
 
 
 def test_decode_equals_extend_of_one_token(device):
