@@ -540,11 +540,15 @@ def kernel_rooflines(args, cfg, runner, result, B, G, P, in_len, ctx, t_decode_s
     kc, vc = runner.token_to_kv_pool.get_key_buffer(0), runner.token_to_kv_pool.get_value_buffer(0)
     kc.normal_(); vc.normal_()
     row_bytes = 2 * Hkv_r * D * 2
+    NREP = 8
     att = {}
     if D in (64, 128) and B >= 2:
         cws = K.CascadeWorkspace(B, Hq_r, D, ctx, dev)
         K.cascade_plan(cws, r2t, pool_idx, seq, Hq_r, Hkv_r)
-        t_c = graph_time(lambda: K.cascade_decode_attention(cws, q, kc, vc, o, r2t, pool_idx, seq, D ** -0.5), 1, reps=20)
+        # (NREP calls per captured graph, like the layer loop of a step: one call per replay adds the replay's own ~5 us
+        # to a 20 us launch pair)
+        t_c = graph_time(lambda: [K.cascade_decode_attention(cws, q, kc, vc, o, r2t, pool_idx, seq, D ** -0.5) for _ in range(NREP)],
+                         NREP, reps=10)
         uniq = (G * args.prefix + B * (len_k - args.prefix)) * row_bytes
         tr = None
         casc_src = ("cascade_attention.hip", "cascade_plan.hpp")
@@ -556,7 +560,8 @@ def kernel_rooflines(args, cfg, runner, result, B, G, P, in_len, ctx, t_decode_s
                           "traffic": tr}
     splits = choose_num_splits(B, Hkv_r, Hq_r // Hkv_r, len_k)
     ws = K.decode_workspace(B, Hq_r, D, splits, dev) if splits > 1 else (None, None)
-    t_k = graph_time(lambda: K.decode_attention(q, kc, vc, o, r2t, pool_idx, seq, D ** -0.5, splits, ws[0], ws[1]), 1, reps=20)
+    t_k = graph_time(lambda: [K.decode_attention(q, kc, vc, o, r2t, pool_idx, seq, D ** -0.5, splits, ws[0], ws[1]) for _ in range(NREP)],
+                     NREP, reps=10)
     alg = B * len_k * row_bytes     # len * (2*H_kv*D*2 B) per request and layer, no dedup
     att["plain"] = {"kernel": "decode_stage1_kernel", "us_per_layer": t_k * 1e6, "bytes_no_dedup": alg,
                     "achieved": alg / t_k / 1e9, "frac": alg / t_k / 1e9 / HBM_PEAK_GBPS}
@@ -577,7 +582,8 @@ def kernel_rooflines(args, cfg, runner, result, B, G, P, in_len, ctx, t_decode_s
         pre_x = torch.full((nreq,), pre, dtype=torch.int32, device=dev)
         qo = (torch.arange(nreq + 1, device=dev) * e).to(torch.int32)
         pool_x = torch.arange(1, nreq + 1, device=dev)
-        t_x = graph_time(lambda: K.extend_attention(qx, ox, kc, vc, r2t, pool_x, seq_x, pre_x, qo, e, D ** -0.5, True), 1, reps=10)
+        t_x = graph_time(lambda: [K.extend_attention(qx, ox, kc, vc, r2t, pool_x, seq_x, pre_x, qo, e, D ** -0.5, True) for _ in range(NREP)],
+                         NREP, reps=5)
         fl = nreq * 4 * Hq_r * D * (e * pre + e * (e + 1) / 2)
         ext[name] = {"us": t_x * 1e6, "tflops": fl / t_x / 1e12, "frac": fl / t_x / 1e12 / MFMA_PEAK_TFLOPS,
                      "shape": {"requests": nreq, "extend": e, "prefix": pre}}
