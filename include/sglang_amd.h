@@ -209,6 +209,13 @@ int sgl_amd_argmax_split(const void* logits, int logits_is_bf16, int64_t* ids, i
 /* in place: logits[b,:] = softmax(logits[b,:] / temperatures[b]) (fp32). */
 int sgl_amd_softmax_temperature(float* logits, const float* temperatures, int64_t batch,
                                 int64_t vocab, int64_t row_stride, void* stream);
+/* The same for decode-sized batches of wide rows (rows cut into num_splits <= 64 column ranges over the whole chip,
+ * partial (max, sum) pairs merged in range order: deterministic).  workspace:
+ * sgl_amd_softmax_temperature_split_workspace_bytes(batch, num_splits) bytes, caller-owned, no initial state; rows
+ * 16-byte aligned. */
+int64_t sgl_amd_softmax_temperature_split_workspace_bytes(int64_t batch, int num_splits);
+int sgl_amd_softmax_temperature_split(float* logits, const float* temperatures, int64_t batch, int64_t vocab,
+                                      int64_t row_stride, int num_splits, void* workspace, void* stream);
 
 /* Top-k / top-p / min-p sampling with the reference's deterministic gumbel mode
  * (sampler.py:567-612 top_k_top_p_min_p_sampling_from_probs_torch + :688-729

@@ -192,6 +192,77 @@ __global__ __launch_bounds__(kRowThreads) void softmax_temperature_kernel(
   for (int64_t i = threadIdx.x; i < vocab; i += blockDim.x) x[i] = expf(x[i] / t - mx) / sum;
 }
 
+// The same softmax for decode-sized batches of wide rows: a row is cut into `splits` column ranges so that the whole chip
+// works on 64 rows (one 1024-thread workgroup per row reads its 0.5 MB three times at one CU's bandwidth: 141 us for
+// [64, 128256]).  Pass 1: every range's maximum and sum of exp(x / t - that maximum); pass 2: every workgroup merges the
+// row's partials in range order (deterministic) and normalises its range.  16-byte loads; ranges are multiples of four.
+constexpr int kSplitThreads = 256;
+
+__device__ __forceinline__ void split_range(int64_t vocab, int splits, int64_t* begin, int64_t* end) {
+  const int64_t per = ((vocab + splits - 1) / splits + 3) / 4 * 4;
+  int64_t b = per * blockIdx.x, e = b + per;
+  if (b > vocab) b = vocab;
+  if (e > vocab) e = vocab;
+  *begin = b; *end = e;
+}
+
+__global__ __launch_bounds__(kSplitThreads) void softmax_partials_kernel(const float* __restrict__ logits, const float* __restrict__ temperatures,
+                                                                         int64_t vocab, int64_t row_stride, int splits,
+                                                                         float* __restrict__ partials) {
+  __shared__ float scratch[16];
+  const int64_t row = blockIdx.y;
+  const float* x = logits + row * row_stride;
+  const float t = temperatures[row];
+  int64_t b, e;
+  split_range(vocab, splits, &b, &e);
+  const int64_t e4 = b + (e - b) / 4 * 4;
+  float mx = -INFINITY;
+  for (int64_t i = b + 4 * threadIdx.x; i < e4; i += 4 * kSplitThreads) {
+    const float4 v = *reinterpret_cast<const float4*>(x + i);
+    mx = fmaxf(fmaxf(mx, v.x / t), fmaxf(v.y / t, fmaxf(v.z / t, v.w / t)));
+  }
+  for (int64_t i = e4 + threadIdx.x; i < e; i += kSplitThreads) mx = fmaxf(mx, x[i] / t);
+  mx = block_max(mx, scratch);
+  float sum = 0.f;
+  if (mx > -INFINITY) {
+    for (int64_t i = b + 4 * threadIdx.x; i < e4; i += 4 * kSplitThreads) {
+      const float4 v = *reinterpret_cast<const float4*>(x + i);
+      sum += expf(v.x / t - mx) + expf(v.y / t - mx) + expf(v.z / t - mx) + expf(v.w / t - mx);
+    }
+    for (int64_t i = e4 + threadIdx.x; i < e; i += kSplitThreads) sum += expf(x[i] / t - mx);
+  }
+  sum = block_sum(sum, scratch);
+  if (threadIdx.x == 0) {
+    partials[(row * splits + blockIdx.x) * 2 + 0] = mx;
+    partials[(row * splits + blockIdx.x) * 2 + 1] = sum;
+  }
+}
+
+__global__ __launch_bounds__(kSplitThreads) void softmax_normalize_kernel(float* __restrict__ logits, const float* __restrict__ temperatures,
+                                                                          int64_t vocab, int64_t row_stride, int splits,
+                                                                          const float* __restrict__ partials) {
+  const int64_t row = blockIdx.y;
+  float* x = logits + row * row_stride;
+  const float t = temperatures[row];
+  const float* pr = partials + row * splits * 2;
+  float mx = -INFINITY;
+  for (int s = 0; s < splits; ++s) mx = fmaxf(mx, pr[2 * s]);
+  float sum = 0.f;
+  for (int s = 0; s < splits; ++s) {
+    const float ms = pr[2 * s];
+    if (ms > -INFINITY) sum += pr[2 * s + 1] * expf(ms - mx);      // range order: the same bits in every workgroup
+  }
+  int64_t b, e;
+  split_range(vocab, splits, &b, &e);
+  const int64_t e4 = b + (e - b) / 4 * 4;
+  for (int64_t i = b + 4 * threadIdx.x; i < e4; i += 4 * kSplitThreads) {
+    float4 v = *reinterpret_cast<const float4*>(x + i);
+    v.x = expf(v.x / t - mx) / sum; v.y = expf(v.y / t - mx) / sum; v.z = expf(v.z / t - mx) / sum; v.w = expf(v.w / t - mx) / sum;
+    *reinterpret_cast<float4*>(x + i) = v;
+  }
+  for (int64_t i = e4 + threadIdx.x; i < e; i += kSplitThreads) x[i] = expf(x[i] / t - mx) / sum;
+}
+
 }  // namespace
 
 extern "C" {
@@ -244,6 +315,25 @@ int sgl_amd_softmax_temperature(float* logits, const float* temperatures, int64_
   hipLaunchKernelGGL(softmax_temperature_kernel, dim3(batch), dim3(kRowThreads), 0,
                      as_stream(stream), logits, temperatures, vocab, row_stride);
   SGL_CHECK_LAUNCH("softmax_temperature");
+  return 0;
+}
+
+int64_t sgl_amd_softmax_temperature_split_workspace_bytes(int64_t batch, int num_splits) { return batch * num_splits * 8; }
+
+int sgl_amd_softmax_temperature_split(float* logits, const float* temperatures, int64_t batch, int64_t vocab, int64_t row_stride,
+                                      int num_splits, void* workspace, void* stream) {
+  SGL_CLEAR_STALE_ERROR();
+  SGL_CHECK_ARG(vocab > 0 && batch <= 65535 && num_splits >= 1 && num_splits <= 64, "softmax_temperature_split: batch <= 65535, 1..64 splits");
+  SGL_CHECK_ARG(workspace && (reinterpret_cast<uintptr_t>(logits) & 15) == 0 && row_stride % 4 == 0,
+                "softmax_temperature_split: needs the workspace and 16-byte aligned rows");
+  if (batch == 0) return 0;
+  const dim3 grid(num_splits, static_cast<unsigned>(batch));
+  float* partials = static_cast<float*>(workspace);
+  hipLaunchKernelGGL(softmax_partials_kernel, grid, dim3(kSplitThreads), 0, as_stream(stream), logits, temperatures, vocab, row_stride,
+                     num_splits, partials);
+  hipLaunchKernelGGL(softmax_normalize_kernel, grid, dim3(kSplitThreads), 0, as_stream(stream), logits, temperatures, vocab, row_stride,
+                     num_splits, partials);
+  SGL_CHECK_LAUNCH("softmax_temperature_split");
   return 0;
 }
 

@@ -443,8 +443,15 @@ def softmax_temperature_(logits: torch.Tensor, temperatures: torch.Tensor) -> to
     _need(logits.dtype == torch.float32 and logits.dim() == 2 and logits.stride(1) == 1, "softmax: fp32 [B, V]")
     t = temperatures.reshape(-1)
     _need(t.dtype == torch.float32 and t.numel() == logits.shape[0] and t.is_contiguous(), "softmax: temperatures [B] fp32")
-    native.call("sgl_amd_softmax_temperature", logits.data_ptr(), t.data_ptr(), logits.shape[0], logits.shape[1],
-                logits.stride(0), _stream())
+    B, V = logits.shape
+    splits = min(64, 2048 // max(1, B))            # column ranges per row: ~2048 workgroups over the chip
+    if B and splits >= 2 and V >= 4096 * splits // 8 and logits.data_ptr() % 16 == 0 and logits.stride(0) % 4 == 0 and B <= 65535:
+        # (allocated per call: under graph capture it comes from the graph's pool like every other intermediate)
+        ws = torch.empty((B * splits * 2,), dtype=torch.float32, device=logits.device)
+        native.call("sgl_amd_softmax_temperature_split", logits.data_ptr(), t.data_ptr(), B, V, logits.stride(0), splits,
+                    ws.data_ptr(), _stream())
+        return logits
+    native.call("sgl_amd_softmax_temperature", logits.data_ptr(), t.data_ptr(), B, V, logits.stride(0), _stream())
     return logits
 
 
