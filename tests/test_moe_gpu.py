@@ -226,7 +226,21 @@ def test_wstream_moe_gemm_row_gather_scale_and_silu(device, M, E, k, N, Kd, bm):
             if centre is None:
                 centre = cand
             best = torch.minimum(best, (got - cand).abs() - ulp(torch.maximum(got.abs(), cand.abs())))
-    assert bool((best <= 0).all()), float(best.max())          # (bf16 differences and ulps are exact in fp32)
+    # (bf16 differences and ulps are exact in fp32.)  One more licence, for operands next to zero only: where |gate| or
+    # |up| < 2^-8 the fp32 summation-order noise of a K = 1024 dot product (~2^-16 absolute) exceeds the value's own bf16
+    # ulp -- cancellation -- so there the bound is the first-order propagation of that absolute noise,
+    # |d silu/dg| |up| dg + |silu(gate)| du, plus two output ulps.
+    gf, uf = gate.float(), up.float()
+    eta = 2.0 ** -16
+    small = (gf.abs() < 2.0 ** -8) | (uf.abs() < 2.0 ** -8)
+    sg = torch.sigmoid(gf)
+    slope = (sg * (1 + gf * (1 - sg))).abs()
+    bound = 1.05 * (slope * uf.abs() * torch.maximum(ulp(gf), torch.tensor(eta)) + (gf * sg).abs() * torch.maximum(ulp(uf), torch.tensor(eta))) \
+        + 2 * ulp(torch.maximum(got.abs(), centre.abs()))
+    near_zero_ok = small & ((got - centre).abs() <= bound)
+    bad = (best > 0) & ~near_zero_ok
+    assert not bool(bad.any()), (int(bad.sum()), float(best[bad].max()))
+    assert float(((best > 0) & near_zero_ok).float().mean()) < 1e-3          # the near-zero licence is rarely needed
     assert float(((got - centre).abs() > ulp(torch.maximum(got.abs(), centre.abs()))).float().mean()) < 0.02
 
 
