@@ -151,6 +151,12 @@ struct RowSmem {
   uint32_t digit_base[256];
 };
 
+// rows whose start is 16-byte aligned are read four values at a time up to this index (the tail, and unaligned rows
+// altogether, one by one)
+__device__ __forceinline__ int vec4_len(const float* x, int V) {
+  return (reinterpret_cast<uintptr_t>(x) & 15) == 0 ? (V & ~3) : 0;
+}
+
 // probabilities are >= 0: the fp32 bit pattern orders like the value.  -0.0 and NaN
 // are mapped to 0 / +inf bits so the order stays total.
 __device__ __forceinline__ uint32_t key_of(float p) {
@@ -175,15 +181,21 @@ __device__ Select radix_select(const float* __restrict__ x, int V, int64_t top_k
     if (tid < 256) { sm.hist_cnt[tid] = 0; sm.hist_sum[tid] = 0; }
     __syncthreads();
     const uint32_t prefix = sm.prefix;
-    for (int i = tid; i < V; i += kT) {
-      const float p = x[i];
+    auto tally = [&](float p) {
       const uint32_t key = key_of(p);
       if ((key & mask) == prefix) {
         const int b = (key >> shift) & 255;
         atomicAdd(&sm.hist_cnt[b], 1u);
         atomicAdd(&sm.hist_sum[b], static_cast<unsigned long long>(to_fix(p)));
       }
+    };
+    // four values per load: a pass of one value per thread and iteration is 125 dependent L2 round trips at V = 128 K
+    const int V4 = vec4_len(x, V);
+    for (int i = 4 * tid; i < V4; i += 4 * kT) {
+      const float4 v = *reinterpret_cast<const float4*>(x + i);
+      tally(v.x); tally(v.y); tally(v.z); tally(v.w);
     }
+    for (int i = V4 + tid; i < V; i += kT) tally(x[i]);
     __syncthreads();
     if (tid < 64) {
       // lane l owns bins 255-4l .. 252-4l (descending); inclusive scan over lanes.
@@ -269,8 +281,13 @@ __device__ int compact_kept(const float* __restrict__ x, int V, Select sel, uint
   int n_eq_keep = sel.n_eq_keep;
   if (min_key > thr) { thr = min_key; n_eq_keep = 0x7fffffff; }   // min_p cut is above the top-k/p cut: keep >= min_key
   // count strictly-greater elements (the ties go after them)
+  const int V4 = vec4_len(x, V);
   int cnt = 0;
-  for (int i = tid; i < V; i += kT) cnt += key_of(x[i]) > thr;
+  for (int i = 4 * tid; i < V4; i += 4 * kT) {
+    const float4 v = *reinterpret_cast<const float4*>(x + i);
+    cnt += (key_of(v.x) > thr) + (key_of(v.y) > thr) + (key_of(v.z) > thr) + (key_of(v.w) > thr);
+  }
+  for (int i = V4 + tid; i < V; i += kT) cnt += key_of(x[i]) > thr;
   cnt = static_cast<int>(wave_sum(static_cast<float>(cnt)) + 0.5f);
   __syncthreads();
   if (lane == 0) sm.wave_a[wid] = cnt;
@@ -279,7 +296,46 @@ __device__ int compact_kept(const float* __restrict__ x, int V, Select sel, uint
   for (int w = 0; w < kNW; ++w) n_gt += sm.wave_a[w];
   int base_gt = 0, base_eq = 0;
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  for (int i0 = 0; i0 < V; i0 += kT) {
+  // token order inside a tile of 4 kT values: thread, then the four values of its load (index i0 + 4 tid + j)
+  for (int i0 = 0; i0 < V4; i0 += 4 * kT) {
+    const int i = i0 + 4 * tid;
+    uint32_t key[4] = {0u, 0u, 0u, 0u};
+    if (i < V4) {
+      const float4 v = *reinterpret_cast<const float4*>(x + i);
+      key[0] = key_of(v.x); key[1] = key_of(v.y); key[2] = key_of(v.z); key[3] = key_of(v.w);
+    }
+    int before_g = 0, before_e = 0, wave_g = 0, wave_e = 0;
+    bool gt[4], eq[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      gt[j] = i < V4 && key[j] > thr;
+      eq[j] = i < V4 && key[j] == thr;
+      const unsigned long long bg = __ballot(gt[j]), be = __ballot(eq[j]);
+      before_g += __popcll(bg & lt_mask); before_e += __popcll(be & lt_mask);
+      wave_g += __popcll(bg); wave_e += __popcll(be);
+    }
+    __syncthreads();
+    if (lane == 0) { sm.wave_a[wid] = wave_g; sm.wave_b[wid] = wave_e; }
+    __syncthreads();
+    int og = 0, oe = 0, tg = 0, te = 0;
+    for (int w = 0; w < kNW; ++w) {
+      const int a = sm.wave_a[w], b = sm.wave_b[w];
+      if (w < wid) { og += a; oe += b; }
+      tg += a; te += b;
+    }
+    int pg = base_gt + og + before_g, pe = base_eq + oe + before_e;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (gt[j]) emit(pg++, key[j], i + j);
+      if (eq[j]) {
+        if (pe < n_eq_keep) emit(n_gt + pe, key[j], i + j);
+        ++pe;
+      }
+    }
+    base_gt += tg;
+    base_eq += te;
+  }
+  for (int i0 = V4; i0 < V; i0 += kT) {
     const int i = i0 + tid;
     uint32_t key = 0;
     bool gt = false, eq = false;
@@ -419,7 +475,12 @@ __global__ __launch_bounds__(kT) void sample_kernel(SampleParams p) {
   if (p.min_ps) {
     // sampler.py:590-591: threshold = probs_sort[:, 0] * min_p  (fp32), drop p < threshold
     float mx = 0.f;
-    for (int i = tid; i < V; i += kT) mx = fmaxf(mx, x[i]);
+    const int V4 = vec4_len(x, V);
+    for (int i = 4 * tid; i < V4; i += 4 * kT) {
+      const float4 v = *reinterpret_cast<const float4*>(x + i);
+      mx = fmaxf(fmaxf(mx, v.x), fmaxf(v.y, fmaxf(v.z, v.w)));
+    }
+    for (int i = V4 + tid; i < V; i += kT) mx = fmaxf(mx, x[i]);
     mx = block_max(mx, sm.red);
     min_key = key_of(mx * p.min_ps[row]);
   }
