@@ -47,6 +47,11 @@ def main():
     out["softmax_us"] = graph_time(lambda: K.softmax_temperature_(f32, info.temperatures))   # (in place on garbage from the 2nd call on: same work)
     out["sample_us"] = graph_time(lambda: K.top_k_top_p_min_p_sample(probs, info.top_ks, info.top_ps, None, info.sampling_seed, pos))
     out["argmax_us"] = graph_time(lambda: K.argmax(lg))
+    # temperature-only sampling (top_k = all, top_p = 1: sampler.py's "simple sampling case"): every token's gumbel score
+    info_s = SamplingBatchInfo(torch.ones((B, 1), device=DEV), torch.ones(B, device=DEV), torch.full((B,), 1 << 30, dtype=torch.int32, device=DEV),
+                               torch.zeros(B, device=DEV), False, sampling_seed=torch.arange(B, device=DEV, dtype=torch.int64) + 1234)
+    out["sampler_temperature_only_us"] = graph_time(lambda: smp(LogitsProcessorOutput(next_token_logits=lg), info_s, positions=pos))
+    out["sample_unfiltered_us"] = graph_time(lambda: K.top_k_top_p_min_p_sample(probs, None, None, None, info.sampling_seed, pos, filtered=False))
     print(json.dumps(out))
     Path("gpurun_out").mkdir(exist_ok=True)
     Path("gpurun_out/r03_exp6_sampler.json").write_text(json.dumps(out, indent=1))

@@ -225,7 +225,9 @@ int sgl_amd_softmax_temperature_split(float* logits, const float* temperatures, 
  * sampling_from_probs_torch (:732-750), no filter, column = token id.  seeds are required (for
  * unseeded sampling the caller draws fresh ones).  Nuclei larger than sgl_amd_sampling_lds_keep()
  * are ranked in the caller-owned workspaces ws_keys/ws_toks (each B*2*V 4-byte words);
- * without them such a row returns id -1.  top_ks/top_ps/min_ps/positions/out_n_keep may be NULL. */
+ * without them such a row returns id -1.  filtered=0 uses ws_keys only (256 bytes per row suffice; ws_toks any
+ * non-NULL pointer): given it, decode-sized batches are cut into column ranges over the whole chip -- same ids.
+ * top_ks/top_ps/min_ps/positions/out_n_keep may be NULL. */
 int sgl_amd_top_k_top_p_min_p_sample(const float* probs, int64_t row_stride, int64_t batch,
                                      int64_t vocab, const int32_t* top_ks, const float* top_ps,
                                      const float* min_ps, const int64_t* seeds,

@@ -127,9 +127,17 @@ struct Select {
   int n_eq_keep;      // how many elements == thr are kept (lowest token ids first)
 };
 
+constexpr int kHistCopies = 16;   // lane-group private copies of the select histograms
+constexpr int kHistStride = 257;  // ... one bank apart
+
 struct RowSmem {
   uint32_t hist_cnt[256];
   unsigned long long hist_sum[256];
+  // A softmax row lands in a handful of top-byte bins: 64 lanes of a wave adding to ONE LDS word serialise (two atomics
+  // per element: ~0.1 ms of the 0.18 ms kernel at V = 128 K).  Lane l adds to copy l & 15, the copies are summed into
+  // hist_cnt / hist_sum before the scan: integer and fixed-point sums, so the result does not depend on the split.
+  uint32_t part_cnt[kHistCopies * kHistStride];
+  unsigned long long part_sum[kHistCopies * kHistStride];
   int wave_a[kNW];
   int wave_b[kNW];
   double s_score[kNW];
@@ -178,15 +186,16 @@ __device__ Select radix_select(const float* __restrict__ x, int V, int64_t top_k
   uint32_t mask = 0;
   for (int level = 0; level < 4; ++level) {
     const int shift = 24 - 8 * level;
-    if (tid < 256) { sm.hist_cnt[tid] = 0; sm.hist_sum[tid] = 0; }
+    for (int z = tid; z < kHistCopies * kHistStride; z += kT) { sm.part_cnt[z] = 0; sm.part_sum[z] = 0; }
     __syncthreads();
     const uint32_t prefix = sm.prefix;
+    const int copy = (tid & (kHistCopies - 1)) * kHistStride;
     auto tally = [&](float p) {
       const uint32_t key = key_of(p);
       if ((key & mask) == prefix) {
-        const int b = (key >> shift) & 255;
-        atomicAdd(&sm.hist_cnt[b], 1u);
-        atomicAdd(&sm.hist_sum[b], static_cast<unsigned long long>(to_fix(p)));
+        const int b = copy + ((key >> shift) & 255);
+        atomicAdd(&sm.part_cnt[b], 1u);
+        atomicAdd(&sm.part_sum[b], static_cast<unsigned long long>(to_fix(p)));
       }
     };
     // four values per load: a pass of one value per thread and iteration is 125 dependent L2 round trips at V = 128 K
@@ -196,6 +205,15 @@ __device__ Select radix_select(const float* __restrict__ x, int V, int64_t top_k
       tally(v.x); tally(v.y); tally(v.z); tally(v.w);
     }
     for (int i = V4 + tid; i < V; i += kT) tally(x[i]);
+    __syncthreads();
+    if (tid < 256) {
+      uint32_t c = 0;
+      unsigned long long sfix = 0;
+#pragma unroll
+      for (int k = 0; k < kHistCopies; ++k) { c += sm.part_cnt[k * kHistStride + tid]; sfix += sm.part_sum[k * kHistStride + tid]; }
+      sm.hist_cnt[tid] = c;
+      sm.hist_sum[tid] = sfix;
+    }
     __syncthreads();
     if (tid < 64) {
       // lane l owns bins 255-4l .. 252-4l (descending); inclusive scan over lanes.
@@ -532,6 +550,65 @@ __global__ __launch_bounds__(kT) void sample_kernel(SampleParams p) {
   }
 }
 
+// ---- the unfiltered case for decode-sized batches: a row cut into column ranges over the whole chip -------------
+// sampling_from_probs scores EVERY token (fp32 log + an fp64 gumbel each): one workgroup per row keeps 64 of 256 CUs busy
+// (209 us for [64, 128256]).  Pass 1: grid (ranges, rows), every workgroup's best (score, token) of its range goes to the
+// caller's workspace; pass 2: one wave per row merges them -- the same comparison (NaN maximal, first index on ties), so
+// the token is the one the single-workgroup kernel returns.
+struct PartialBest {
+  double score;
+  int rank;
+  int token;
+};
+
+__global__ __launch_bounds__(kT) void sample_unfiltered_ranges_kernel(SampleParams p, int splits, PartialBest* __restrict__ partials) {
+  __shared__ double s_score[kNW];
+  __shared__ int s_rank[kNW];
+  __shared__ int s_tok[kNW];
+  const int row = blockIdx.y, tid = threadIdx.x;
+  const float* x = p.probs + static_cast<int64_t>(row) * p.row_stride;
+  const int V = p.V;
+  const int per = ((V + splits - 1) / splits + 3) / 4 * 4;
+  int b = per * static_cast<int>(blockIdx.x), e = b + per;
+  if (b > V) b = V;
+  if (e > V) e = V;
+  const uint64_t seed = static_cast<uint64_t>(p.seeds[row]);
+  const uint32_t pos = p.positions ? static_cast<uint32_t>(p.positions[row] & 0xffffffffll) : 0u;
+  const uint32_t hpre = murmur_prefix(seed, pos);
+  Best best{0.0, -1, 0};
+  for (int i = b + tid; i < e; i += kT) {
+    const double sc = static_cast<double>(logf(x[i])) + gumbel_from_hash(murmur_hash32(hpre, i));
+    Best c{sc, i, i};
+    if (best_better(best, c)) best = c;
+  }
+  best = block_best(best, s_score, s_rank, s_tok);
+  if (tid == 0) {
+    PartialBest o;
+    o.score = best.score; o.rank = best.rank; o.token = best.token;
+    partials[static_cast<int64_t>(row) * splits + blockIdx.x] = o;
+  }
+}
+
+__global__ __launch_bounds__(64) void sample_unfiltered_merge_kernel(SampleParams p, int splits, const PartialBest* __restrict__ partials) {
+  const int row = blockIdx.x, lane = threadIdx.x;
+  Best r{0.0, -1, 0};
+  if (lane < splits) {
+    const PartialBest o = partials[static_cast<int64_t>(row) * splits + lane];
+    r.score = o.score; r.rank = o.rank; r.token = o.token;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    Best o;
+    o.score = __shfl_xor(r.score, off, 64);
+    o.rank = __shfl_xor(r.rank, off, 64);
+    o.token = __shfl_xor(r.token, off, 64);
+    if (best_better(r, o)) r = o;
+  }
+  if (lane == 0) {
+    p.out_ids[row] = r.rank < 0 ? 0 : r.token;
+    if (p.out_n_keep) p.out_n_keep[row] = p.V;
+  }
+}
+
 // rank-0 token of an empty nucleus must be the arg max of the row; handled by a tiny fix-up
 // kernel so that the common path stays branch-free.
 __global__ __launch_bounds__(kT) void empty_nucleus_fixup_kernel(SampleParams p) {
@@ -608,6 +685,17 @@ int sgl_amd_top_k_top_p_min_p_sample(const float* probs, int64_t row_stride, int
   p.top_ks = top_ks; p.top_ps = top_ps; p.min_ps = min_ps; p.seeds = seeds; p.positions = positions;
   p.out_ids = out_ids; p.ws_keys = static_cast<uint32_t*>(ws_keys); p.ws_toks = static_cast<int32_t*>(ws_toks);
   p.out_n_keep = out_n_keep; p.filtered = filtered;
+  // the unfiltered case of a decode-sized batch: column ranges over the whole chip (the workspace holds the partials)
+  int splits = static_cast<int>(512 / batch);
+  if (splits > 16) splits = 16;
+  if (!filtered && ws_keys && splits >= 2 && vocab >= 4096 * splits && batch <= 65535) {
+    PartialBest* partials = static_cast<PartialBest*>(ws_keys);
+    hipLaunchKernelGGL(sample_unfiltered_ranges_kernel, dim3(splits, static_cast<unsigned>(batch)), dim3(kT), 0, as_stream(stream), p, splits,
+                       partials);
+    hipLaunchKernelGGL(sample_unfiltered_merge_kernel, dim3(batch), dim3(64), 0, as_stream(stream), p, splits, partials);
+    SGL_CHECK_LAUNCH("top_k_top_p_min_p_sample(unfiltered ranges)");
+    return 0;
+  }
   hipLaunchKernelGGL(sample_kernel, dim3(batch), dim3(kT), 0, as_stream(stream), p);
   SGL_CHECK_LAUNCH("top_k_top_p_min_p_sample");
   if (filtered && top_ks) {

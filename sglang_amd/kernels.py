@@ -499,7 +499,11 @@ def top_k_top_p_min_p_sample(probs: torch.Tensor, top_ks: Optional[torch.Tensor]
         min_ps = min_ps.to(torch.float32).contiguous()
     ids = torch.empty(B, dtype=torch.int32, device=dev)
     n_keep = torch.empty(B, dtype=torch.int32, device=dev) if return_n_keep else None
-    ws = _sample_workspace(B, V, dev) if (filtered and use_workspace) else (None, None)
+    if filtered:
+        ws = _sample_workspace(B, V, dev) if use_workspace else (None, None)
+    else:           # unfiltered: 256 bytes per row of range partials (the kernel spreads decode-sized batches over the chip)
+        small = torch.empty((B, 64), dtype=torch.int32, device=dev) if use_workspace else None
+        ws = (small, small)
     native.call("sgl_amd_top_k_top_p_min_p_sample", probs.data_ptr(), probs.stride(0), B, V, _ptr(top_ks), _ptr(top_ps),
                 _ptr(min_ps), seeds.data_ptr(), _ptr(positions), ids.data_ptr(), _ptr(ws[0]), _ptr(ws[1]),
                 _ptr(n_keep), 1 if filtered else 0, _stream())

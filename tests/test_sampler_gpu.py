@@ -122,6 +122,28 @@ def test_unfiltered_seeded_sampling_matches_oracle(device):
     assert ids.cpu().tolist() == ref.tolist()
 
 
+def test_unfiltered_sampling_over_column_ranges_equals_the_row_kernel(device):
+    """Decode-sized batches of wide rows: the unfiltered sampler cuts a row into column ranges over the whole chip (given
+    its workspace).  Same token as the one-workgroup-per-row kernel and as the oracle, including a tie between two ranges
+    (first index wins), a NaN (maximal) and an all-zero row."""
+    K = _k()
+    g = torch.Generator().manual_seed(11)
+    B, V = 6, 128256
+    probs = torch.softmax(torch.randn((B, V), generator=g) * 2, dim=-1)
+    probs[1, 100] = probs[1, V - 5] = 0.9             # equal scores need equal gumbels too: rarely a tie -- the oracle decides
+    probs[2, V // 2 + 3] = float("nan")
+    probs[3] = 0.0
+    seeds = torch.randint(0, 2 ** 62, (B,), generator=g)
+    pos = torch.randint(0, 4096, (B,), generator=g)
+    split = K.top_k_top_p_min_p_sample(probs.to(device), None, None, None, seeds.to(device), pos.to(device), filtered=False)
+    whole = K.top_k_top_p_min_p_sample(probs.to(device), None, None, None, seeds.to(device), pos.to(device), filtered=False,
+                                       use_workspace=False)
+    assert split.cpu().tolist() == whole.cpu().tolist()
+    ok = [0, 1, 4, 5]                                  # (rows 2 and 3: NaN / log(0) rows are compared kernel to kernel only)
+    ref = oh.sampling_from_probs(probs[ok], seeds[ok], pos[ok])
+    assert split.cpu()[ok].tolist() == ref.tolist()
+
+
 def test_ties_and_degenerate_rows(device):
     K = _k()
     V = 4096
