@@ -127,6 +127,7 @@ struct Select {
   int n_eq_keep;      // how many elements == thr are kept (lowest token ids first)
 };
 
+constexpr int kCand = 4096;       // candidate list capacity (4 per thread: one tile)
 constexpr int kHistCopies = 16;   // lane-group private copies of the select histograms
 constexpr int kHistStride = 257;  // ... one bank apart
 
@@ -138,6 +139,10 @@ struct RowSmem {
   // hist_cnt / hist_sum before the scan: integer and fixed-point sums, so the result does not depend on the split.
   uint32_t part_cnt[kHistCopies * kHistStride];
   unsigned long long part_sum[kHistCopies * kHistStride];
+  // candidates of the cut (sample_kernel): every element of the first-level bin the cut falls into and of the bins above
+  // it, in token order -- the later levels and the compaction run on this list instead of the row
+  alignas(16) uint32_t cand_val[kCand];
+  int cand_tok[kCand];
   int wave_a[kNW];
   int wave_b[kNW];
   double s_score[kNW];
@@ -174,17 +179,24 @@ __device__ __forceinline__ uint32_t key_of(float p) {
 
 // ---- 1. radix select ------------------------------------------------------------
 // top_k < 0 or >= V behaves as "all"; top_p >= 1 keeps everything the cumsum allows.
-__device__ Select radix_select(const float* __restrict__ x, int V, int64_t top_k, float top_p,
-                               RowSmem& sm) {
+// top_p >= 1 disables the filter: the exclusive cumsum of a softmax row never exceeds 1 in the
+// reference's fp32 arithmetic, while the exact fixed-point sum can be a few 2^-40 above it.
+__device__ __forceinline__ unsigned long long top_p_fix(float top_p) {
+  return top_p >= 1.0f ? ~0ull >> 1
+                       : static_cast<unsigned long long>(top_p > 0.f ? static_cast<double>(top_p) * kFix : 0.0);
+}
+
+__device__ __forceinline__ void select_begin(RowSmem& sm) {
+  if (threadIdx.x == 0) { sm.prefix = 0; sm.c_above = 0; sm.s_above = 0; sm.done_all = 0; sm.n_eq_keep = 0; }
+}
+
+// Levels [level_begin, level_end) of the select over the values x[0 .. V) (a row, or the candidate list in LDS); the
+// state (prefix, counts above, done_all, n_eq_keep) lives in `sm`.  Ends on a barrier.
+__device__ void select_levels(const float* __restrict__ x, int V, int level_begin, int level_end, int64_t top_k,
+                              unsigned long long p_fix, RowSmem& sm) {
   const int tid = threadIdx.x;
-  // top_p >= 1 disables the filter: the exclusive cumsum of a softmax row never exceeds 1 in the
-  // reference's fp32 arithmetic, while the exact fixed-point sum can be a few 2^-40 above it.
-  const unsigned long long p_fix =
-      top_p >= 1.0f ? ~0ull >> 1
-                    : static_cast<unsigned long long>(top_p > 0.f ? static_cast<double>(top_p) * kFix : 0.0);
-  if (tid == 0) { sm.prefix = 0; sm.c_above = 0; sm.s_above = 0; sm.done_all = 0; sm.n_eq_keep = 0; }
-  uint32_t mask = 0;
-  for (int level = 0; level < 4; ++level) {
+  uint32_t mask = level_begin > 0 ? 0xffffffffu << (32 - 8 * level_begin) : 0u;
+  for (int level = level_begin; level < level_end; ++level) {
     const int shift = 24 - 8 * level;
     for (int z = tid; z < kHistCopies * kHistStride; z += kT) { sm.part_cnt[z] = 0; sm.part_sum[z] = 0; }
     __syncthreads();
@@ -280,11 +292,79 @@ __device__ Select radix_select(const float* __restrict__ x, int V, int64_t top_k
     if (sm.done_all) break;
     mask |= 0xffu << shift;
   }
+}
+
+__device__ __forceinline__ Select select_result(RowSmem& sm) {
   Select r;
   if (sm.done_all) { r.thr_key = 0; r.n_eq_keep = 0x7fffffff; }
   else { r.thr_key = sm.prefix; r.n_eq_keep = sm.n_eq_keep; }
   __syncthreads();
   return r;
+}
+
+__device__ Select radix_select(const float* __restrict__ x, int V, int64_t top_k, float top_p, RowSmem& sm) {
+  select_begin(sm);
+  select_levels(x, V, 0, 4, top_k, top_p_fix(top_p), sm);
+  return select_result(sm);
+}
+
+// The candidates of the cut, in token order: every element whose first-level digit is >= `bin` (the bin the cut falls
+// into) -> (value bits, token) in sm.cand_*.  The caller has checked that they fit.
+__device__ void collect_candidates(const float* __restrict__ x, int V, int bin, RowSmem& sm) {
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const uint32_t lo = static_cast<uint32_t>(bin) << 24;
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const int V4 = vec4_len(x, V);
+  int base = 0;
+  for (int i0 = 0; i0 < V4; i0 += 4 * kT) {
+    const int i = i0 + 4 * tid;
+    float val[4] = {0.f, 0.f, 0.f, 0.f};
+    if (i < V4) {
+      const float4 v = *reinterpret_cast<const float4*>(x + i);
+      val[0] = v.x; val[1] = v.y; val[2] = v.z; val[3] = v.w;
+    }
+    bool in[4];
+    int before = 0, wave = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      in[j] = i < V4 && key_of(val[j]) >= lo;
+      const unsigned long long b = __ballot(in[j]);
+      before += __popcll(b & lt_mask);
+      wave += __popcll(b);
+    }
+    __syncthreads();
+    if (lane == 0) sm.wave_a[wid] = wave;
+    __syncthreads();
+    int o = 0, t = 0;
+    for (int w = 0; w < kNW; ++w) {
+      const int a = sm.wave_a[w];
+      if (w < wid) o += a;
+      t += a;
+    }
+    int pos = base + o + before;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (in[j]) { sm.cand_val[pos] = __float_as_uint(val[j]); sm.cand_tok[pos] = i + j; ++pos; }
+    base += t;
+  }
+  for (int i0 = V4; i0 < V; i0 += kT) {
+    const int i = i0 + tid;
+    const float v = i < V ? x[i] : 0.f;
+    const bool in = i < V && key_of(v) >= lo;
+    const unsigned long long b = __ballot(in);
+    __syncthreads();
+    if (lane == 0) sm.wave_a[wid] = __popcll(b);
+    __syncthreads();
+    int o = 0, t = 0;
+    for (int w = 0; w < kNW; ++w) {
+      const int a = sm.wave_a[w];
+      if (w < wid) o += a;
+      t += a;
+    }
+    if (in) { const int pos = base + o + __popcll(b & lt_mask); sm.cand_val[pos] = __float_as_uint(v); sm.cand_tok[pos] = i; }
+    base += t;
+  }
+  __syncthreads();
 }
 
 // ---- 2. compaction ---------------------------------------------------------------
@@ -487,18 +567,39 @@ __global__ __launch_bounds__(kT) void sample_kernel(SampleParams p) {
   if (top_k > V) top_k = V;
   if (top_k < 0) top_k = 0;
   const float top_p = p.top_ps ? p.top_ps[row] : 1.0f;
-  const Select sel = radix_select(x, V, top_k, top_p, sm);
+  // The first radix level reads the row; when the bin the cut falls into and the bins above it hold <= kCand elements
+  // (a softmax row with top-k 50 / top-p 0.9: a few hundred) they are collected into LDS in ONE more pass and the other
+  // three levels, the min-p maximum and the compaction run on that list: two full-row passes instead of six.
+  const unsigned long long p_fix = top_p_fix(top_p);
+  select_begin(sm);
+  select_levels(x, V, 0, 1, top_k, p_fix, sm);
+  const float* src = x;                              // what the rest of the selection reads: the row, or the candidates
+  int n_src = V;
+  bool from_cand = false;
+  if (!sm.done_all) {
+    const int bin = sm.found_bin;
+    const long long n_cand = static_cast<long long>(sm.c_above) + sm.hist_cnt[bin];
+    __syncthreads();                                 // (hist_cnt is rewritten by the next level)
+    if (n_cand <= kCand) {
+      collect_candidates(x, V, bin, sm);
+      src = reinterpret_cast<const float*>(sm.cand_val);
+      n_src = static_cast<int>(n_cand);
+      from_cand = true;
+    }
+    select_levels(src, n_src, 1, 4, top_k, p_fix, sm);
+  }
+  const Select sel = select_result(sm);
 
   uint32_t min_key = 0;
   if (p.min_ps) {
-    // sampler.py:590-591: threshold = probs_sort[:, 0] * min_p  (fp32), drop p < threshold
+    // sampler.py:590-591: threshold = probs_sort[:, 0] * min_p  (fp32), drop p < threshold (the row maximum is a candidate)
     float mx = 0.f;
-    const int V4 = vec4_len(x, V);
+    const int V4 = vec4_len(src, n_src);
     for (int i = 4 * tid; i < V4; i += 4 * kT) {
-      const float4 v = *reinterpret_cast<const float4*>(x + i);
+      const float4 v = *reinterpret_cast<const float4*>(src + i);
       mx = fmaxf(fmaxf(mx, v.x), fmaxf(v.y, fmaxf(v.z, v.w)));
     }
-    for (int i = V4 + tid; i < V; i += kT) mx = fmaxf(mx, x[i]);
+    for (int i = V4 + tid; i < n_src; i += kT) mx = fmaxf(mx, src[i]);
     mx = block_max(mx, sm.red);
     min_key = key_of(mx * p.min_ps[row]);
   }
@@ -506,7 +607,8 @@ __global__ __launch_bounds__(kT) void sample_kernel(SampleParams p) {
   // small nuclei are compacted into LDS, larger ones into the global workspace
   uint32_t* gk0 = p.ws_keys ? p.ws_keys + static_cast<int64_t>(row) * 2 * V : nullptr;
   int32_t* gt0 = p.ws_toks ? p.ws_toks + static_cast<int64_t>(row) * 2 * V : nullptr;
-  const int n_keep = compact_kept(x, V, sel, min_key, sm, [&](int posn, uint32_t key, int tok) {
+  const int n_keep = compact_kept(src, n_src, sel, min_key, sm, [&](int posn, uint32_t key, int idx) {
+    const int tok = from_cand ? sm.cand_tok[idx] : idx;
     if (posn < kLdsKeep) { sm.keys[posn] = key; sm.toks[posn] = tok; }
     if (gk0) { gk0[posn] = key; gt0[posn] = tok; }
   });
