@@ -53,6 +53,11 @@ def layer_fusable(layer, rows: int) -> bool:
             or getattr(mlp.down_proj, "bias", None) is not None:
         return False
     rope = attn.rotary_emb
+    # plain cos / sin-cache ropes only (rotary_embedding/base.py:78 RotaryEmbedding, rope_variant.py:537
+    # Llama3RotaryEmbedding: a scaled cache, the same forward); multimodal / long-rope / dual-chunk variants index the
+    # cache differently and stay with the reference
+    if type(rope).__name__ not in ("RotaryEmbedding", "Llama3RotaryEmbedding"):
+        return False
     if not getattr(rope, "is_neox_style", False) or getattr(rope, "rotary_dim", attn.head_dim) != attn.head_dim:
         return False
     if any(hasattr(attn, n) for n in ("q_norm", "k_norm")):            # (qwen3-style per-head norms: another layer form)
@@ -103,6 +108,9 @@ def decode_model(model, hidden_states: torch.Tensor, positions: torch.Tensor, fo
 def model_fusable(model, hidden_states: torch.Tensor, forward_batch) -> bool:
     if not (hidden_states.is_cuda and hidden_states.dtype == _BF16 and hidden_states.dim() == 2):
         return False
+    positions = getattr(forward_batch, "positions", None)
+    if positions is not None and positions.dim() != 1:                 # (multimodal 3-D positions: not this form)
+        return False
     mode = getattr(forward_batch, "forward_mode", None)
     if mode is None or not mode.is_decode():
         return False
@@ -111,8 +119,8 @@ def model_fusable(model, hidden_states: torch.Tensor, forward_batch) -> bool:
 
 
 def llama_model_forward_hook(original, self, input_ids, positions, forward_batch, input_embeds=None, pp_proxy_tensors=None):
-    """HookType.AROUND on sglang.srt.models.llama.LlamaModel.forward (llama.py:419-470).  Decode batches of a single
-    pipeline stage at TP = 1 run the fused layer loop; anything else is the reference's own forward."""
+    """HookType.AROUND on LlamaModel.forward (llama.py:419-470) and Qwen2Model.forward (qwen2.py:396-448).  Decode batches
+    of a single pipeline stage at TP = 1 run the fused layer loop; anything else is the reference's own forward."""
     try:
         ok = _reference_model_applies(self, forward_batch, input_embeds, pp_proxy_tensors)
     except Exception:
@@ -151,7 +159,9 @@ def _tp_size() -> int:
         return ps.get_tensor_model_parallel_world_size()
 
 
-HOOK_TARGETS = ("sglang.srt.models.llama.LlamaModel.forward",)
+# model classes whose forward is the loop above (same signature, same attribute names; Mistral and the other Llama-style
+# checkpoints are served by LlamaModel itself): llama.py:419-470, qwen2.py:396-448 (qkv bias: in the qkv combine)
+HOOK_TARGETS = ("sglang.srt.models.llama.LlamaModel.forward", "sglang.srt.models.qwen2.Qwen2Model.forward")
 
 
 def install(registry, hook_type_around) -> None:

@@ -46,6 +46,7 @@ WANT = {
     "sglang/srt/model_executor/runner/decode_cuda_graph_runner.py": ["DecodeCudaGraphRunner"],
     "sglang/srt/plugins/hook_registry.py": ["HookRegistry", "HookType", "_wrap_fn"],
     "sglang/srt/models/llama.py": ["LlamaModel", "LlamaDecoderLayer", "LlamaAttention", "LlamaMLP"],
+    "sglang/srt/models/qwen2.py": ["Qwen2Model", "Qwen2DecoderLayer", "Qwen2Attention", "Qwen2MLP"],
     "sglang/srt/layers/quantization/unquant.py": ["UnquantizedLinearMethod"],
     "sglang/srt/runtime_context.py": ["get_parallel"],
 }
@@ -96,6 +97,18 @@ def class_record(c: ast.ClassDef):
             for t in n.targets:
                 if isinstance(t, ast.Name):
                     rec["attrs"][t.id] = const(n.value)
+    # names the constructor binds on the instance (`self.x = ...` anywhere in __init__): what code written against the
+    # class reads as attributes
+    inst = set()
+    for n in c.body:
+        if isinstance(n, ast.FunctionDef) and n.name == "__init__":
+            for a in ast.walk(n):
+                if isinstance(a, (ast.Assign, ast.AnnAssign, ast.AugAssign)):
+                    for t in (a.targets if isinstance(a, ast.Assign) else [a.target]):
+                        for e in (t.elts if isinstance(t, ast.Tuple) else [t]):
+                            if isinstance(e, ast.Attribute) and isinstance(e.value, ast.Name) and e.value.id == "self":
+                                inst.add(e.attr)
+    rec["instance_attrs"] = sorted(inst)
     return rec
 
 

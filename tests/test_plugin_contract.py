@@ -491,15 +491,23 @@ def test_model_level_hook_is_registered_and_falls_through_to_the_reference_forwa
     plugin.load()
     hr = g["sglang.srt.plugins.hook_registry"]
     target = "sglang.srt.models.llama.LlamaModel.forward"
-    assert fused_decode.HOOK_TARGETS == (target,)
-    assert [(ht.name, h) for ht, h, _ in hr.HookRegistry._hooks[target]] == [("AROUND", fused_decode.llama_model_forward_hook)]
-    # the hook binds to the reference's forward signature: (original, self, <reference parameters>)
+    assert fused_decode.HOOK_TARGETS == (target, "sglang.srt.models.qwen2.Qwen2Model.forward")
+    # the hook binds to the reference's forward signature: (original, self, <reference parameters>) -- for every model
+    # class it is registered on, whose layers carry the attribute names the fused loop reads
     import inspect
 
-    ref_names = [p["name"] for p in ref("sglang.srt.models.llama", "LlamaModel")["methods"]["forward"]["params"]]
-    assert list(inspect.signature(fused_decode.llama_model_forward_hook).parameters) == ["original"] + ref_names
-    assert [p["name"] for p in ref("sglang.srt.models.llama", "LlamaDecoderLayer")["methods"]["forward"]["params"]] == \
-        ["self", "positions", "hidden_states", "forward_batch", "residual"]
+    for tgt, mod, prefix in ((target, "sglang.srt.models.llama", "Llama"), (fused_decode.HOOK_TARGETS[1], "sglang.srt.models.qwen2", "Qwen2")):
+        assert [(ht.name, h) for ht, h, _ in hr.HookRegistry._hooks[tgt]] == [("AROUND", fused_decode.llama_model_forward_hook)]
+        ref_names = [p["name"] for p in ref(mod, prefix + "Model")["methods"]["forward"]["params"]]
+        assert list(inspect.signature(fused_decode.llama_model_forward_hook).parameters) == ["original"] + ref_names
+        assert [p["name"] for p in ref(mod, prefix + "DecoderLayer")["methods"]["forward"]["params"]] == \
+            ["self", "positions", "hidden_states", "forward_batch", "residual"]
+        for cls, names in ((prefix + "Model", ("embed_tokens", "layers", "norm", "pp_group", "layers_to_capture")),
+                           (prefix + "DecoderLayer", ("self_attn", "mlp", "input_layernorm", "post_attention_layernorm")),
+                           (prefix + "Attention", ("qkv_proj", "o_proj", "rotary_emb", "attn", "num_heads", "num_kv_heads", "head_dim")),
+                           (prefix + "MLP", ("gate_up_proj", "down_proj", "act_fn"))):
+            have = set(ref(mod, cls)["instance_attrs"])
+            assert set(names) <= have, (cls, sorted(set(names) - have))
 
     llama = g["sglang.srt.models.llama"]
     calls = []
