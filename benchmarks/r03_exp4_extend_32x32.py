@@ -65,7 +65,7 @@ def main():
         out[name] = rec
         print(name, {k: (round(v['us'], 1), round(v['frac'], 3)) if isinstance(v, dict) else v for k, v in rec.items()})
     Path("gpurun_out").mkdir(exist_ok=True)
-    Path("gpurun_out/r03_exp4_ladder%s.json" % os.environ.get("EXP_TAG", "")).write_text(json.dumps(out, indent=1))
+    Path("gpurun_out/r03_exp4_extend_32x32%s.json" % os.environ.get("EXP_TAG", "")).write_text(json.dumps(out, indent=1))
 
 
 if __name__ == "__main__":

@@ -850,7 +850,7 @@ __global__ __launch_bounds__(512, 2) void extend_attention_dbuf_kernel(ExtendPar
 //   * a raised maximum (rare: kDeferMax) is applied to O and l when everything exponentiated against the old one is
 //     inside them (the order the softmax-rescale hazard asks for);
 //   * the epilogue swaps 4-dim pieces between the lane halves and stores 16 bytes per lane.
-// Measured on MI355X (benchmarks/r03_exp4_ladder.py, profiles/r03_exp4_extend_32x32.json): 4 x 1024 cold 62 -> 52 us, 60 x 128
+// Measured on MI355X (benchmarks/r03_exp4_extend_32x32.py, profiles/r03_exp4_extend_32x32.json): 4 x 1024 cold 62 -> 52 us, 60 x 128
 // over 896 warm 197 -> 167 us, 2 x 4096 304 -> 279 us, 8 x 2952 676 -> 629 us.  A one-score-set version of the same
 // form (S^T(t) -> max(t) -> [products of t - 1 || exponentials of t]; commit 21c58e7..: 2-6 % slower) and its 4-wave /
 // two-workgroups-per-CU variant (slower again: twice the row requests per flop) were measured and dropped.
@@ -876,7 +876,9 @@ __device__ __forceinline__ float lane_pair_max(float x) {         // max over la
 //     O and l by then), and ONE barrier.
 // Every product carries <= 7 vector instructions, none of them waiting for the product next to it; what is left outside
 // the products' shadow is the decision (a permlane, two ballots), four LDS writes and the barrier.
-template <int D, int NWV>
+// FP8: the pool holds e4m3 rows (8 bytes per lane and chunk, held raw in the staging registers, widened to bf16 -- exact --
+// on their way into the LDS images; k_scale rides in the softmax scale, v_scale in the epilogue).
+template <int D, int NWV, bool FP8>
 __global__ __launch_bounds__(64 * NWV, 2) void extend_attention_pipe_kernel(ExtendParams p) {
   __shared__ SmemLadder<D> sm;
   constexpr int CPR = D / 8;            // 16-byte chunks per KV row
@@ -951,7 +953,16 @@ __global__ __launch_bounds__(64 * NWV, 2) void extend_attention_pipe_kernel(Exte
   // ---- staging: thread = (row st_r + ROWS_PER_PASS i, 16-byte chunk st_c) of a K tile and of a V tile ----
   const int st_c = tid % CPR, st_r = tid / CPR;
   int32_t idx_k[LOADS], idx_v[LOADS];
-  U4 kst[LOADS], vst[LOADS];
+  typedef typename std::conditional<FP8, uint2, U4>::type Stage;   // a gathered 8-dim piece as it travels: raw bytes
+  Stage kst[LOADS], vst[LOADS];
+  auto ld_stage = [&](const unsigned char* ptr) __attribute__((always_inline)) -> Stage {
+    if constexpr (FP8) return *reinterpret_cast<const uint2*>(ptr);
+    else return ld16(ptr);
+  };
+  auto widen = [&](const Stage& v) __attribute__((always_inline)) -> U4 {
+    if constexpr (FP8) return fp8x8_to_bf16x8(v);
+    else return v;
+  };
   auto load_idx = [&](int t, int32_t (&dst)[LOADS]) {
     const int last = kv_end - 1;
 #pragma unroll
@@ -961,55 +972,32 @@ __global__ __launch_bounds__(64 * NWV, 2) void extend_attention_pipe_kernel(Exte
       dst[i] = idx_base[tok];
     }
   };
-  const unsigned char* k_rows = reinterpret_cast<const unsigned char*>(p.k_cache) + static_cast<uint64_t>(kvh) * p.fmt.head_stride + st_c * 16;
-  const unsigned char* v_rows = reinterpret_cast<const unsigned char*>(p.v_cache) + static_cast<uint64_t>(kvh) * p.fmt.head_stride + st_c * 16;
-  auto load_k = [&]() {
-#pragma unroll
-    for (int i = 0; i < LOADS; ++i) kst[i] = ld16(k_rows + static_cast<uint64_t>(static_cast<uint32_t>(idx_k[i])) * p.fmt.page_stride);
-  };
-  auto load_v = [&]() {
-#pragma unroll
-    for (int i = 0; i < LOADS; ++i) vst[i] = ld16(v_rows + static_cast<uint64_t>(static_cast<uint32_t>(idx_v[i])) * p.fmt.page_stride);
-  };
-  auto commit_k = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < LOADS; ++i) {
-      const int row = st_r + ROWS_PER_PASS * i;
-      sm.k[buf][row * CPR + (st_c ^ ((row * CPR / 16) & (CPR - 1)))] = kst[i];
-    }
-  };
-  auto commit_v = [&](int buf) {
-    unsigned char* base = reinterpret_cast<unsigned char*>(sm.v[buf]) + (st_c >> 2) * VSUB + (st_c & 3) * 16;
-#pragma unroll
-    for (int i = 0; i < LOADS; ++i) {
-      const int row = st_r + ROWS_PER_PASS * i;
-      *reinterpret_cast<U4*>(base + row * 64) = vst[i];
-    }
-  };
+  const unsigned char* k_rows = reinterpret_cast<const unsigned char*>(p.k_cache) + static_cast<uint64_t>(kvh) * p.fmt.head_stride + st_c * (FP8 ? 8 : 16);
+  const unsigned char* v_rows = reinterpret_cast<const unsigned char*>(p.v_cache) + static_cast<uint64_t>(kvh) * p.fmt.head_stride + st_c * (FP8 ? 8 : 16);
   // V^T operand reads: lane i of 16-lane group g points at token row 4 (g >> 1) + (i >> 2), dims 16 (g & 1) + 4 (i & 3)
   const int v_lane = (4 * hi + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
 
-  auto load_rows = [&](const unsigned char* base, const int32_t (&ids)[LOADS], U4 (&dst)[LOADS]) __attribute__((always_inline)) {
+  auto load_rows = [&](const unsigned char* base, const int32_t (&ids)[LOADS], Stage (&dst)[LOADS]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < LOADS; ++i) dst[i] = ld16(base + static_cast<uint64_t>(static_cast<uint32_t>(ids[i])) * p.fmt.page_stride);
+    for (int i = 0; i < LOADS; ++i) dst[i] = ld_stage(base + static_cast<uint64_t>(static_cast<uint32_t>(ids[i])) * p.fmt.page_stride);
   };
-  auto put_k = [&](int buf, const U4 (&src)[LOADS]) __attribute__((always_inline)) {
+  auto put_k = [&](int buf, const Stage (&src)[LOADS]) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < LOADS; ++i) {
       const int row = st_r + ROWS_PER_PASS * i;
-      sm.k[buf][row * CPR + (st_c ^ ((row * CPR / 16) & (CPR - 1)))] = src[i];
+      sm.k[buf][row * CPR + (st_c ^ ((row * CPR / 16) & (CPR - 1)))] = widen(src[i]);
     }
   };
-  auto put_v = [&](int buf, const U4 (&src)[LOADS]) __attribute__((always_inline)) {
+  auto put_v = [&](int buf, const Stage (&src)[LOADS]) __attribute__((always_inline)) {
     unsigned char* base = reinterpret_cast<unsigned char*>(sm.v[buf]) + (st_c >> 2) * VSUB + (st_c & 3) * 16;
 #pragma unroll
-    for (int i = 0; i < LOADS; ++i) *reinterpret_cast<U4*>(base + (st_r + ROWS_PER_PASS * i) * 64) = src[i];
+    for (int i = 0; i < LOADS; ++i) *reinterpret_cast<U4*>(base + (st_r + ROWS_PER_PASS * i) * 64) = widen(src[i]);
   };
   // ---- prologue: K(0), K(1), V(0) go to LDS in one round trip; K(2) and V(1) are asked for; ids of tiles 2 / 3 held.
   // (Tiles behind the end of the walk: load_idx clamps to the walk's last row, nobody reads those images.) ----------
   {
     int32_t i0[LOADS], i1[LOADS];
-    U4 k0[LOADS], k1[LOADS], v0[LOADS];
+    Stage k0[LOADS], k1[LOADS], v0[LOADS];
     load_idx(0, i0);
     load_idx(1, i1);
     load_rows(k_rows, i0, k0);
@@ -1121,13 +1109,13 @@ __global__ __launch_bounds__(64 * NWV, 2) void extend_attention_pipe_kernel(Exte
       static_assert(NREQ * RSTRIDE <= G1, "requests fit the products of phase 1");
       auto request = [&](int j) __attribute__((always_inline)) {
         if (j < LOADS) {
-          vst[j] = ld16(v_rows + static_cast<uint64_t>(static_cast<uint32_t>(idx_v[j])) * p.fmt.page_stride);
+          vst[j] = ld_stage(v_rows + static_cast<uint64_t>(static_cast<uint32_t>(idx_v[j])) * p.fmt.page_stride);
         } else if (j < 2 * LOADS) {
           if (j == LOADS) {
 #pragma unroll
             for (int i = 0; i < LOADS; ++i) idx_v[i] = idx_k[i];          // the ids of K(t + 3) are those of V(t + 3) a step on
           }
-          kst[j - LOADS] = ld16(k_rows + static_cast<uint64_t>(static_cast<uint32_t>(idx_k[j - LOADS])) * p.fmt.page_stride);
+          kst[j - LOADS] = ld_stage(k_rows + static_cast<uint64_t>(static_cast<uint32_t>(idx_k[j - LOADS])) * p.fmt.page_stride);
         } else {
           const int last = kv_end - 1;
           const int tok = (t + 4) * kKvTile + st_r + ROWS_PER_PASS * (j - 2 * LOADS);
@@ -1260,7 +1248,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void extend_attention_pipe_kernel(Exte
   // c = 1, 3: eight 16-byte stores per lane instead of sixteen 8-byte ones ------------------------------------
   float l = l_run;
   l += __shfl_xor(l, 32, 64);
-  const float inv = (l > 0.f) ? 1.0f / l : 0.f;
+  const float inv = (l > 0.f) ? p.v_scale / l : 0.f;
   uint16_t* op = p.out + static_cast<int64_t>(q_begin + q0 + r_tok) * p.out_stride + row_off;
 #pragma unroll
   for (int n = 0; n < ND; ++n) {
@@ -1404,17 +1392,21 @@ int sgl_amd_extend_attention_ex(const void* q, void* out, const void* k_cache, c
   const int tiles = (max_extend_len + p.tokens_per_tile - 1) / p.tokens_per_tile;
   dim3 grid(tiles, num_kv_heads, batch);
   hipStream_t st = as_stream(stream);
-  // token-major bf16 pools, 8-wave shape: the 32x32 two-score-set kernel (debug flag bit 1: the ping-pong kernel it replaced)
-  const bool fast = !kv_fp8 && !kv_layout_hnd && nwv == 8 && sliding_window < 0 && logit_cap == 0.f && custom_mask == nullptr &&
-                    (g_extend_debug_flags & 1) == 0;
+  // token-major pools (bf16 or e4m3 rows), 8-wave shape: the 32x32 two-score-set kernel (debug flag bit 1: the bf16
+  // ping-pong kernel it replaced)
+  const bool fast = !kv_layout_hnd && nwv == 8 && sliding_window < 0 && logit_cap == 0.f && custom_mask == nullptr &&
+                    (g_extend_debug_flags & 1) == 0 && !(kv_fp8 && (g_extend_debug_flags & 2) != 0);
   if (fast) {
     p.num_tiles = tiles; p.batch = static_cast<int>(batch);
     const dim3 grid1(static_cast<unsigned>(tiles) * num_kv_heads * static_cast<unsigned>(batch));
     if ((g_extend_debug_flags & 2) != 0) {
       if (head_dim == 128) hipLaunchKernelGGL((extend_attention_dbuf_kernel<128>), grid1, dim3(512), 0, st, p);
       else hipLaunchKernelGGL((extend_attention_dbuf_kernel<64>), grid1, dim3(512), 0, st, p);
-    } else if (head_dim == 128) hipLaunchKernelGGL((extend_attention_pipe_kernel<128, 8>), grid1, dim3(512), 0, st, p);
-    else hipLaunchKernelGGL((extend_attention_pipe_kernel<64, 8>), grid1, dim3(512), 0, st, p);
+    } else if (kv_fp8) {
+      if (head_dim == 128) hipLaunchKernelGGL((extend_attention_pipe_kernel<128, 8, true>), grid1, dim3(512), 0, st, p);
+      else hipLaunchKernelGGL((extend_attention_pipe_kernel<64, 8, true>), grid1, dim3(512), 0, st, p);
+    } else if (head_dim == 128) hipLaunchKernelGGL((extend_attention_pipe_kernel<128, 8, false>), grid1, dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((extend_attention_pipe_kernel<64, 8, false>), grid1, dim3(512), 0, st, p);
     SGL_CHECK_LAUNCH("extend_attention");
     return 0;
   }

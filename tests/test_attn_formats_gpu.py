@@ -137,8 +137,8 @@ def test_cascade_decode_attention_formats(device, case, Hq, Hkv, D):
 @pytest.mark.parametrize("case", CASES + [dict(mask=True), dict(mask=True, fp8=True)], ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
 def test_extend_attention_formats(device, case, extend_shape):
     K = _k()
-    # the small grid of this batch would pick a 4-wave shape: force the 8-wave one so that the bf16 layouts also go
-    # through the double-buffered kernel (fp8 / window / cap / mask cases stay on the general kernel by construction)
+    # the small grid of this batch would pick a 4-wave shape: force the 8-wave one so that the token-major layouts (bf16
+    # and e4m3 rows) go through the 32x32 kernel (HND / window / cap / mask cases stay on the general kernel by construction)
     extend_shape("82")
     Hq, Hkv, D = 8, 2, 128
     fp8, hnd, page = case.get("fp8", False), case.get("hnd", False), case.get("page", 1)

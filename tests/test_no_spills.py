@@ -53,9 +53,9 @@ def test_extend_eight_wave_kernels_keep_their_registers_and_lds(tmp_path):
     O^T (64), two score sets (64), Q^T (32), P (16), the staging rows (16) and three K fragments at ~245: a spill would
     sit between the matrix instructions; LDS = two K and two V images."""
     usage = _resource_usage("extend_attention.hip", tmp_path)
-    for kernel, lds in (("extend_attention_pipe_kernel", 72 * 1024), ("extend_attention_dbuf_kernel", 80 * 1024)):
+    for kernel, lds, n in (("extend_attention_pipe_kernel", 72 * 1024, 4), ("extend_attention_dbuf_kernel", 80 * 1024, 2)):
         inst = {k: v for k, v in usage.items() if kernel in k}
-        assert len(inst) == 2, sorted(usage)                    # head dim {64, 128}
+        assert len(inst) == n, sorted(usage)                    # head dim {64, 128} (x {bf16, e4m3 rows} for the 32x32 kernel)
         for name, u in inst.items():
             assert u["vgpr_spill_count"] == 0 and u["sgpr_spill_count"] == 0, (name, u)
             assert u["vgpr_count"] <= 256, (name, u)
