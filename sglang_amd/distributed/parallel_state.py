@@ -71,8 +71,8 @@ def init_distributed_environment(backend: Optional[str] = None, tp_size: Optiona
 
 
 def _start_xgmi():
-    """Create the one-shot communicator and PROVE it on this node before anything depends on it: every rank reduces a
-    known tensor through the xGMI kernel and through the group's own collective; unless all ranks see identical,
+    """Create the xGMI communicator and PROVE it on this node before anything depends on it: every rank runs a known
+    tensor through each of its kernels (one-shot, two-stage, all-gather) and through the group's own collectives; unless all ranks see identical,
     correct results (and no flag wait gave up) the communicator is dropped on EVERY rank and RCCL carries all
     all-reduces -- the reference degrades the same way when its custom all-reduce cannot be set up
     (custom_all_reduce.py:100-180).  A rank-local failure must not leave the ranks with different algorithms."""
@@ -96,8 +96,20 @@ def _start_xgmi():
             mine = xg.all_reduce(x.clone())
             ref = x.float().clone()
             dist.all_reduce(ref, group=_TP_GROUP)                       # fp32 sum through the group's collective
+            # ... and the other two kernels the decode graph may hold (weak-scaling batches put 256 / 512 rows on a rank:
+            # two-stage all-reduce; vocab-parallel logits: all-gather), on shapes with ragged row chunks
+            y = (torch.randn((301, 1024), generator=g) * 0.5).to(torch.bfloat16).to(dev)
+            mine2 = xg.two_stage_all_reduce(y.clone())
+            ref2 = y.float().clone()
+            dist.all_reduce(ref2, group=_TP_GROUP)
+            z = (torch.randn((17, 256), generator=g) * 0.5).to(torch.bfloat16).to(dev)
+            mine3 = xg.all_gather(z)
+            parts = [torch.empty_like(z) for _ in range(_TP_SIZE)]
+            dist.all_gather(parts, z, group=_TP_GROUP)
             torch.cuda.synchronize()
-            good = (not xg.timed_out()) and bool(((mine.float() - ref).abs() <= 2.0 ** -7 * ref.abs() + 1e-2).all())
+            good = (not xg.timed_out()) and bool(((mine.float() - ref).abs() <= 2.0 ** -7 * ref.abs() + 1e-2).all()) \
+                and bool(((mine2.float() - ref2).abs() <= 2.0 ** -7 * ref2.abs() + 1e-2).all()) \
+                and bool(torch.equal(mine3, torch.cat(parts, dim=1)))
         except Exception as e:
             warnings.warn(f"one-shot xGMI all-reduce self-test raised {type(e).__name__}: {e}")
             good = False
