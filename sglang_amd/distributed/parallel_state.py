@@ -31,7 +31,7 @@ def emulate_tensor_parallel_rank(rank: int, size: int, device) -> None:
     from .xgmi_all_reduce import XgmiAllReduce
 
     _TP_SIZE, _TP_RANK, _EMULATED = size, rank, (rank, size)
-    _XGMI = XgmiAllReduce(None, 0, 1, device, handle_exchange=lambda h: [h])
+    _XGMI = XgmiAllReduce(None, 0, 1, device, handle_exchange=lambda h: [h], policy_world=size)
 
 
 def init_distributed_environment(backend: Optional[str] = None, tp_size: Optional[int] = None,

@@ -36,13 +36,16 @@ def one_shot_limit(world: int, max_bytes: int) -> int:
 
 class XgmiAllReduce:
     def __init__(self, group, rank: int, world: int, device: torch.device, max_bytes: int = DEFAULT_MAX_BYTES,
-                 handle_exchange=None, two_stage_bytes: int = DEFAULT_TWO_STAGE_BYTES):
+                 handle_exchange=None, two_stage_bytes: int = DEFAULT_TWO_STAGE_BYTES, policy_world: Optional[int] = None):
         """`group`: a process group every rank of the TP group is in (used once, for the handle exchange; may be a
-        gloo group).  `handle_exchange(bytes) -> List[bytes]` overrides the collective (tests)."""
+        gloo group).  `handle_exchange(bytes) -> List[bytes]` overrides the collective (tests).  `policy_world`: the
+        TP degree whose one-shot / two-stage switch point applies (a world-of-1 loopback communicator standing in for one
+        rank of a TP job launches the kernels that job would)."""
         lib = native.lib()
         if world not in (1, 2, 4, 8) or world > lib.sgl_amd_xgmi_max_world():
             raise ValueError(f"XgmiAllReduce: world size {world} (supported: 2, 4, 8; 1 = loopback for rank-shape runs)")
         self.rank, self.world, self.device = rank, world, device
+        self.policy_world = int(policy_world or world)
         self.max_bytes = int(max_bytes)
         self.two_stage_bytes = int(two_stage_bytes)
         # data area: the one-shot message, or the two halves (copies + published sums) of a two-stage message
@@ -121,7 +124,7 @@ class XgmiAllReduce:
     def all_reduce_any(self, x: torch.Tensor) -> torch.Tensor:
         """The reference's dispatch (custom_all_reduce.py:292-340): one-shot below the size where link traffic starts to
         dominate, two-stage above."""
-        if self.should_use(x) and x.numel() * 2 <= one_shot_limit(self.world, self.max_bytes):
+        if self.should_use(x) and x.numel() * 2 <= one_shot_limit(self.policy_world, self.max_bytes):
             return self.all_reduce(x)
         return self.two_stage_all_reduce(x)
 
@@ -146,7 +149,7 @@ class XgmiAllReduce:
 
     def all_reduce_add_rmsnorm(self, x: torch.Tensor, residual: torch.Tensor, norm_weight: torch.Tensor, eps: float) -> torch.Tensor:
         """RMSNorm(all_reduce(x) + residual) in ONE launch whatever the size class (residual updated in place)."""
-        if self.should_use(x) and x.numel() * 2 <= one_shot_limit(self.world, self.max_bytes):
+        if self.should_use(x) and x.numel() * 2 <= one_shot_limit(self.policy_world, self.max_bytes):
             return self.all_reduce(x, residual=residual, norm_weight=norm_weight, eps=eps)
         return self.two_stage_all_reduce(x, residual=residual, norm_weight=norm_weight, eps=eps)
 
