@@ -18,8 +18,9 @@
 //   phase 3  end barrier: nobody overwrites its buffer for the next call while a peer may still read it
 // The flags are monotonically increasing counters kept in device memory (the kernel increments its own), so a
 // launch has no host-side state: it can be captured into the decode hipGraph and replayed.
-// Flags are written with system-scope release stores straight into the PEER's signal block and polled locally with
-// system-scope acquire loads; the buffers are hipDeviceMallocUncached so neither side can hit a stale L2 line.
+// Flags are written with system-scope stores straight into the PEER's signal block and polled locally; the workspaces
+// are hipDeviceMallocUncached (stores bypass L2: a release is the completion of the data stores, not a cache write-back;
+// no side can hit a stale L2 line), see flag_barrier.
 #include <cstddef>
 #include <cstring>
 #include "common.hpp"
@@ -62,22 +63,25 @@ struct ArParams {
 };
 
 __device__ __forceinline__ void flag_barrier(const ArParams& p, uint32_t (Signal::*arr)[kMaxBlocks][kMaxWorld], uint32_t flag) {
-  // All data stores of this workgroup are ordered before the flags: the workgroup barrier orders every wave's stores
-  // before the flag writers (it waits for their completion), and ONLY the flag writers pay the system-scope release
-  // (an L2 write-back per fence: with every thread of 256 workgroups fencing, a 4 MiB all-reduce spent 100 us in them).
+  // RELEASE.  What a peer reads from this rank lives in this rank's OWN workspace, allocated uncached on this device:
+  // those stores bypass L2, so publishing them needs no cache write-back -- only their completion.  Every wave waits for
+  // its own stores (s_waitcnt vmcnt(0): the wait the memory model prescribes ahead of a system-scope release), the
+  // workgroup barrier collects the waves, then the flag goes out.  (A system-scope release fence here also writes back
+  // every dirty L2 line of the device -- the projection's output, the residual stream: 24 us of a 33 us two-stage launch
+  // at 256 rows, 1.5 ms of a TP 4 rank's 5.8 ms decode step.)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const int t = threadIdx.x;
   if (t < p.world) {
-    __threadfence_system();
     Signal* peer = reinterpret_cast<Signal*>(p.peers.base[t]);
     Signal* self = reinterpret_cast<Signal*>(p.peers.base[p.rank]);
-    __hip_atomic_store(&(peer->*arr)[blockIdx.x][p.rank], flag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&(peer->*arr)[blockIdx.x][p.rank], flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     // bounded: a peer that never launches (a crashed rank) must not wedge the GPU -- give up after ~seconds and leave
     // a mark the host can read (sgl_amd_xgmi_timed_out).  During the start-up self-test the kernel then runs on (the
     // host compares the result and drops the communicator on all ranks); once armed, an unreduced sum must never
     // pass for a result: the kernel traps, the stream fails, every later call on this rank raises.
     int spins = 0;
-    while (__hip_atomic_load(&(self->*arr)[blockIdx.x][t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < flag) {
+    while (__hip_atomic_load(&(self->*arr)[blockIdx.x][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < flag) {
       __builtin_amdgcn_s_sleep(8);
       if (++spins > (1 << 25)) {          // about half a minute: host-side skew between ranks (a GC pause, a page fault storm) is not a crash
         self->timed_out = 1u;
@@ -85,6 +89,10 @@ __device__ __forceinline__ void flag_barrier(const ArParams& p, uint32_t (Signal
         break;
       }
     }
+    // ACQUIRE, once per workgroup and barrier (not once per poll): whatever this CU's L1 or this XCD's L2 may hold of
+    // the peers' workspaces is dropped before anybody reads them (the peers' pages are mapped uncached too, so this is
+    // belt and braces -- but it is the half of the fence pair that costs little).
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
   }
   __syncthreads();
 }

@@ -92,24 +92,28 @@ def _start_xgmi():
     if int(flag) == 1:
         try:
             g = torch.Generator(device="cpu").manual_seed(1234 + _TP_RANK)
-            x = (torch.randn((64, 4096), generator=g) * 0.5).to(torch.bfloat16).to(dev)
-            mine = xg.all_reduce(x.clone())
-            ref = x.float().clone()
-            dist.all_reduce(ref, group=_TP_GROUP)                       # fp32 sum through the group's collective
-            # ... and the other two kernels the decode graph may hold (weak-scaling batches put 256 / 512 rows on a rank:
-            # two-stage all-reduce; vocab-parallel logits: all-gather), on shapes with ragged row chunks
-            y = (torch.randn((301, 1024), generator=g) * 0.5).to(torch.bfloat16).to(dev)
-            mine2 = xg.two_stage_all_reduce(y.clone())
-            ref2 = y.float().clone()
-            dist.all_reduce(ref2, group=_TP_GROUP)
-            z = (torch.randn((17, 256), generator=g) * 0.5).to(torch.bfloat16).to(dev)
-            mine3 = xg.all_gather(z)
-            parts = [torch.empty_like(z) for _ in range(_TP_SIZE)]
-            dist.all_gather(parts, z, group=_TP_GROUP)
-            torch.cuda.synchronize()
-            good = (not xg.timed_out()) and bool(((mine.float() - ref).abs() <= 2.0 ** -7 * ref.abs() + 1e-2).all()) \
-                and bool(((mine2.float() - ref2).abs() <= 2.0 ** -7 * ref2.abs() + 1e-2).all()) \
-                and bool(torch.equal(mine3, torch.cat(parts, dim=1)))
+            good = True
+            # three rounds on fresh data through the SAME workspaces: a stale line of a peer's workspace (the one failure
+            # the uncached mappings and the acquire fence must exclude) would show from the second round on
+            for _ in range(3):
+                x = (torch.randn((64, 4096), generator=g) * 0.5).to(torch.bfloat16).to(dev)
+                mine = xg.all_reduce(x.clone())
+                ref = x.float().clone()
+                dist.all_reduce(ref, group=_TP_GROUP)                   # fp32 sum through the group's collective
+                # ... and the other two kernels the decode graph may hold (weak-scaling batches put 256 / 512 rows on a
+                # rank: two-stage all-reduce; vocab-parallel logits: all-gather), on shapes with ragged row chunks
+                y = (torch.randn((301, 1024), generator=g) * 0.5).to(torch.bfloat16).to(dev)
+                mine2 = xg.two_stage_all_reduce(y.clone())
+                ref2 = y.float().clone()
+                dist.all_reduce(ref2, group=_TP_GROUP)
+                z = (torch.randn((17, 256), generator=g) * 0.5).to(torch.bfloat16).to(dev)
+                mine3 = xg.all_gather(z)
+                parts = [torch.empty_like(z) for _ in range(_TP_SIZE)]
+                dist.all_gather(parts, z, group=_TP_GROUP)
+                torch.cuda.synchronize()
+                good = good and (not xg.timed_out()) and bool(((mine.float() - ref).abs() <= 2.0 ** -7 * ref.abs() + 1e-2).all()) \
+                    and bool(((mine2.float() - ref2).abs() <= 2.0 ** -7 * ref2.abs() + 1e-2).all()) \
+                    and bool(torch.equal(mine3, torch.cat(parts, dim=1)))
         except Exception as e:
             warnings.warn(f"one-shot xGMI all-reduce self-test raised {type(e).__name__}: {e}")
             good = False
