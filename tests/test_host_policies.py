@@ -209,3 +209,44 @@ def test_decode_attention_routing_rule_for_window_and_cap_layers(monkeypatch):
     be.forward_decode(q, None, None, cap, fb, save_kv_cache=False)
     assert [c[0] for c in calls] == ["cascade", "paged", "paged"]
     assert calls[1][1] == {"sliding_window": 32} and calls[2][1] == {"logit_cap": 30.0}
+
+
+def test_all_reduce_switch_points_and_fused_layer_gates():
+    """Pure host rules: (1) one-shot / two-stage switch of the xGMI all-reduce (custom_all_reduce.py:260-307: two ranks
+    always one-shot, 512 KiB at four, 256 KiB at eight) -- a loopback communicator standing in for one rank of a TP job
+    applies THAT job's switch; (2) the fused decode layer takes plain cos / sin-cache ropes only."""
+    import types
+
+    from sglang_amd import fused_decode
+    from sglang_amd.distributed.xgmi_all_reduce import DEFAULT_MAX_BYTES, one_shot_limit
+
+    assert one_shot_limit(2, DEFAULT_MAX_BYTES) == DEFAULT_MAX_BYTES
+    assert one_shot_limit(4, DEFAULT_MAX_BYTES) == 512 * 1024 and one_shot_limit(8, DEFAULT_MAX_BYTES) == 256 * 1024
+    assert one_shot_limit(1, DEFAULT_MAX_BYTES) == 256 * 1024          # (an unqualified loopback world is the most conservative)
+
+    # layer_fusable rejects before it ever touches a kernel: missing pieces, quantised / biased-MLP projections, exotic ropes
+    w = torch.zeros((8, 128), dtype=torch.bfloat16)
+    lin = lambda **kw: types.SimpleNamespace(weight=w, quant_method=None, bias=None, **kw)    # noqa: E731
+    rope = type("MRotaryEmbedding", (), {})()
+    rope.is_neox_style, rope.rotary_dim = True, 64
+    attn = types.SimpleNamespace(qkv_proj=lin(), o_proj=lin(), rotary_emb=rope, head_dim=64, num_heads=2, num_kv_heads=1, attn=None)
+    mlp = types.SimpleNamespace(gate_up_proj=lin(), down_proj=lin())
+    layer = types.SimpleNamespace(self_attn=attn, mlp=mlp)
+    assert not fused_decode.layer_fusable(layer, 4)                     # CPU weights: _plain_linear says no first
+    assert not fused_decode._plain_linear(types.SimpleNamespace(weight=None))
+    assert not fused_decode.layer_fusable(types.SimpleNamespace(self_attn=None, mlp=None), 4)
+    # the rope gate itself, with the projection gate out of the way
+    import unittest.mock as um
+
+    with um.patch.object(fused_decode, "_plain_linear", lambda l: True), \
+            um.patch.object(fused_decode.kernels, "wstream_preferred", lambda *a: True):
+        assert not fused_decode.layer_fusable(layer, 4)                 # MRotaryEmbedding: not this form
+        good = type("RotaryEmbedding", (), {})()
+        good.is_neox_style, good.rotary_dim = True, 64
+        attn.rotary_emb = good
+        assert not fused_decode.layer_fusable(layer, 4)                 # hidden = 128 is fine, but 8 gate_up rows % 32 != 0
+        big = torch.zeros((64, 128), dtype=torch.bfloat16)
+        mlp.gate_up_proj = types.SimpleNamespace(weight=big, quant_method=None, bias=None)
+        assert fused_decode.layer_fusable(layer, 4)
+        good.is_neox_style = False
+        assert not fused_decode.layer_fusable(layer, 4)                 # GPT-J style pairs: not this form
