@@ -62,6 +62,7 @@ struct ArParams {
   float eps;
 };
 
+template <bool ACQUIRE = true>
 __device__ __forceinline__ void flag_barrier(const ArParams& p, uint32_t (Signal::*arr)[kMaxBlocks][kMaxWorld], uint32_t flag) {
   // RELEASE.  What a peer reads from this rank lives in this rank's OWN workspace, allocated uncached on this device:
   // those stores bypass L2, so publishing them needs no cache write-back -- only their completion.  Every wave waits for
@@ -91,8 +92,10 @@ __device__ __forceinline__ void flag_barrier(const ArParams& p, uint32_t (Signal
     }
     // ACQUIRE, once per workgroup and barrier (not once per poll): whatever this CU's L1 or this XCD's L2 may hold of
     // the peers' workspaces is dropped before anybody reads them (the peers' pages are mapped uncached too, so this is
-    // belt and braces -- but it is the half of the fence pair that costs little).
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    // belt and braces -- but it is the half of the fence pair that costs little).  The END barrier of a launch is
+    // followed by no read of a peer's memory -- it only keeps this rank from overwriting its workspace in the next
+    // call while a peer still reads it -- and skips it.
+    if constexpr (ACQUIRE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
   }
   __syncthreads();
 }
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(kArThreads) void xgmi_one_shot_all_reduce_kernel(Ar
       }
     }
   }
-  flag_barrier(p, &Signal::end, flag);
+  flag_barrier<false>(p, &Signal::end, flag);
   if (threadIdx.x == 0) self->flag[blockIdx.x] = flag;
 }
 
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(kArThreads) void xgmi_two_stage_all_reduce_kernel(A
       }
     }
   }
-  flag_barrier(p, &Signal::end, flag);
+  flag_barrier<false>(p, &Signal::end, flag);
   if (threadIdx.x == 0) self->flag[blockIdx.x] = flag;
 }
 
@@ -374,7 +377,7 @@ __global__ __launch_bounds__(kArThreads) void xgmi_all_gather_kernel(ArParams p)
       for (int r = 0; r < WORLD; ++r) st16(p.out + row * (static_cast<int64_t>(p.hidden) * WORLD) + static_cast<int64_t>(r) * p.hidden + col, v[r]);
     }
   }
-  flag_barrier(p, &Signal::end, flag);
+  flag_barrier<false>(p, &Signal::end, flag);
   if (threadIdx.x == 0) self->flag[blockIdx.x] = flag;
 }
 
