@@ -1,4 +1,7 @@
-"""One decoder layer's projections at the bench shapes (Llama-3-8B, M = 64), rotating weights, hipGraph-timed:
+"""(History: the kernel variant this script drives -- `wstream_gemm_prenorm` -- was measured and NOT kept; the script
+documents how profiles/r03_exp3_prenorm.json was taken and does not run against the current library.)
+
+One decoder layer's projections at the bench shapes (Llama-3-8B, M = 64), rotating weights, hipGraph-timed:
   chain A = today's launches: o (GEMM + combine_norm) -> gate_up+silu -> down (GEMM + combine_norm) -> qkv (GEMM + combine_rope)
   chain B = pre-norm launches: o (partials) -> [norm ⊕ gate_up+silu] -> down (partials) -> [norm ⊕ qkv] + combine_rope"""
 import json
