@@ -333,6 +333,68 @@ __global__ __launch_bounds__(kThreads, 5) void cascade_chunk_kernel(ChunkParams 
 constexpr int kPlanThreads = 1024;
 constexpr int kPlanMaxBatch = 1024;
 
+// First launch of the plan: every request's leader (the lowest batch index with the same first slot) and the length of
+// the prefix it shares with that leader.  One WAVE per request, sixteen requests per workgroup: inside ONE workgroup the
+// sixteen waves walked their requests one after the other, a memory round trip each -- 26 / 183 us at 64 / 512 requests
+// (benchmarks/r03_exp7_plan_batch.py).  Results go through the plan buffer's `compare` scratch to the second launch.
+__global__ __launch_bounds__(kPlanThreads) void cascade_plan_compare_kernel(
+    const int32_t* __restrict__ req_to_token, int64_t r2t_stride, const int64_t* __restrict__ req_pool_indices,
+    const int32_t* __restrict__ seq_lens, int batch, int32_t* __restrict__ compare) {
+  __shared__ int first_slot[kPlanMaxBatch];
+  __shared__ int pool_row[kPlanMaxBatch], len_s[kPlanMaxBatch];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  for (int b = tid; b < batch; b += kPlanThreads) {
+    const int len = seq_lens[b];
+    const int row = static_cast<int>(req_pool_indices[b]);
+    pool_row[b] = row;
+    len_s[b] = len;
+    first_slot[b] = len > 1 ? req_to_token[static_cast<int64_t>(row) * r2t_stride] : -1 - b;   // unique when too short
+  }
+  __syncthreads();
+  const int b = static_cast<int>(blockIdx.x) * (kPlanThreads / 64) + wid;
+  if (b >= batch) return;
+  int l = b;
+  const int fs = first_slot[b];
+  for (int c0 = 0; c0 < b; c0 += 64) {
+    const int c = c0 + lane;
+    const unsigned long long m = __ballot(c < b && first_slot[c] == fs);
+    if (m != 0ull) { l = c0 + __ffsll(static_cast<long long>(m)) - 1; break; }
+  }
+  // 2048 positions per round (32 loads in flight per lane and row)
+  constexpr int kCmpLoads = 32;
+  int common = 0;
+  if (l != b) {
+    const int32_t* ra = req_to_token + static_cast<int64_t>(pool_row[b]) * r2t_stride;
+    const int32_t* rb = req_to_token + static_cast<int64_t>(pool_row[l]) * r2t_stride;
+    int lim = len_s[b] - 1;                    // the newest token's slot is never shared
+    const int ll = len_s[l] - 1;
+    if (ll < lim) lim = ll;
+    common = lim;
+    for (int t0 = 0; t0 < lim; t0 += 64 * kCmpLoads) {
+      int va[kCmpLoads], vb[kCmpLoads];
+#pragma unroll
+      for (int u = 0; u < kCmpLoads; ++u) {
+        const int t = t0 + 64 * u + lane;
+        const int tc = t < lim ? t : lim - 1;
+        va[u] = ra[tc];
+        vb[u] = rb[tc];
+      }
+      int first = 0x7fffffff;
+#pragma unroll
+      for (int u = kCmpLoads - 1; u >= 0; --u) {
+        const int t = t0 + 64 * u + lane;
+        const unsigned long long mm = __ballot(t < lim && va[u] != vb[u]);
+        if (mm != 0ull) first = t0 + 64 * u + __ffsll(static_cast<long long>(mm)) - 1;
+      }
+      if (first != 0x7fffffff) { common = first; break; }
+    }
+  }
+  if (lane == 0) {
+    compare[b] = l;
+    compare[batch + b] = common;
+  }
+}
+
 __global__ __launch_bounds__(kPlanThreads) void cascade_plan_kernel(
     const int32_t* __restrict__ req_to_token, int64_t r2t_stride, const int64_t* __restrict__ req_pool_indices,
     const int32_t* __restrict__ seq_lens, int batch, int min_shared, int chunk_tokens, int tokens_per_tile,
@@ -353,57 +415,17 @@ __global__ __launch_bounds__(kPlanThreads) void cascade_plan_kernel(
   const CascadePlanView pv = cascade_plan_view(plan, batch, max_items);
   for (int i = tid; i < max_items; i += kPlanThreads) pv.items[8 * i + 3] = 0;   // members == 0: end of list
   for (int b = tid; b < batch; b += kPlanThreads) {
-    const int len = seq_lens[b];
-    const int row = static_cast<int>(req_pool_indices[b]);
-    pool_row[b] = row;
-    len_s[b] = len;
-    first_slot[b] = len > 1 ? req_to_token[static_cast<int64_t>(row) * r2t_stride] : -1 - b;   // unique when too short
+    pool_row[b] = static_cast<int>(req_pool_indices[b]);
+    len_s[b] = seq_lens[b];
+    leader[b] = pv.compare[b];                         // first launch: leader and common prefix of every request
     grp_min[b] = 0x7fffffff;
     grp_cnt[b] = 0;
   }
   __syncthreads();
   for (int b = tid; b < batch; b += kPlanThreads) {
-    int l = b;
-    const int fs = first_slot[b];
-    for (int c = 0; c < b; ++c)
-      if (first_slot[c] == fs) { l = c; break; }
-    leader[b] = l;
-  }
-  __syncthreads();
-  // common prefix with the leader: one wave per request, 2048 positions per round (32 loads in flight per row): a wave
-  // walks its batch / 16 requests one after the other, so every round is a full memory round trip of the plan
-  constexpr int kCmpLoads = 32;
-  for (int b = wid; b < batch; b += kPlanThreads / 64) {
     const int l = leader[b];
-    int common = 0;
     if (l != b) {
-      const int32_t* ra = req_to_token + static_cast<int64_t>(pool_row[b]) * r2t_stride;
-      const int32_t* rb = req_to_token + static_cast<int64_t>(pool_row[l]) * r2t_stride;
-      int lim = len_s[b] - 1;                    // the newest token's slot is never shared
-      const int ll = len_s[l] - 1;
-      if (ll < lim) lim = ll;
-      common = lim;
-      for (int t0 = 0; t0 < lim; t0 += 64 * kCmpLoads) {
-        int va[kCmpLoads], vb[kCmpLoads];
-#pragma unroll
-        for (int u = 0; u < kCmpLoads; ++u) {
-          const int t = t0 + 64 * u + lane;
-          const int tc = t < lim ? t : lim - 1;
-          va[u] = ra[tc];
-          vb[u] = rb[tc];
-        }
-        int first = 0x7fffffff;
-#pragma unroll
-        for (int u = kCmpLoads - 1; u >= 0; --u) {
-          const int t = t0 + 64 * u + lane;
-          const unsigned long long mm = __ballot(t < lim && va[u] != vb[u]);
-          if (mm != 0ull) first = t0 + 64 * u + __ffsll(static_cast<long long>(mm)) - 1;
-        }
-        if (first != 0x7fffffff) { common = first; break; }
-      }
-    }
-    if (lane == 0 && l != b) {
-      atomicMin(&grp_min[l], common);
+      atomicMin(&grp_min[l], pv.compare[batch + b]);
       atomicAdd(&grp_cnt[l], 1);
     }
   }
@@ -642,6 +664,10 @@ int sgl_amd_cascade_plan(const int32_t* req_to_token, int64_t req_to_token_strid
   SGL_CHECK_ARG(max_items >= 2 * batch * (chunks + 1),
                 "cascade_plan: max_items=%lld too small for batch=%lld x %d chunks (need >= %lld)", (long long)max_items,
                 (long long)batch, chunks + 1, (long long)(2 * batch * (chunks + 1)));
+  const CascadePlanView pv = cascade_plan_view(plan, batch, max_items);
+  hipLaunchKernelGGL(cascade_plan_compare_kernel, dim3(static_cast<unsigned>((batch + kPlanThreads / 64 - 1) / (kPlanThreads / 64))),
+                     dim3(kPlanThreads), 0, as_stream(stream), req_to_token, req_to_token_stride, req_pool_indices, seq_lens,
+                     static_cast<int>(batch), pv.compare);
   hipLaunchKernelGGL(cascade_plan_kernel, dim3(1), dim3(kPlanThreads), 0, as_stream(stream), req_to_token,
                      req_to_token_stride, req_pool_indices, seq_lens, static_cast<int>(batch), min_shared_len,
                      kChunk, members_per_item, 64, chunks * kChunk, plan, static_cast<int>(max_items));

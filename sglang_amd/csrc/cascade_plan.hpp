@@ -11,6 +11,7 @@
 //   items[8 * max_items] self-contained records: (group, kv chunk, row tile, members, first member_rows
 //                        index, kv tokens, req_to_token row of the leader, 0); members == 0: unused entry
 //   batch_order[B]       permutation of the batch: grouped requests (group by group) first, then the rest
+//   compare[2 B]         scratch between the plan's two launches: leader of request b, its common prefix with the leader
 #pragma once
 #include <stdint.h>
 
@@ -25,10 +26,11 @@ struct CascadePlanView {
   int32_t* group_kvlen;
   int32_t* items;
   int32_t* batch_order;
+  int32_t* compare;
 };
 
 __host__ __device__ inline int64_t cascade_plan_ints(int64_t batch, int64_t max_items) {
-  return 8 + batch + batch + (batch + 1) + batch + batch + 8 * max_items + batch;
+  return 8 + batch + batch + (batch + 1) + batch + batch + 8 * max_items + batch + 2 * batch;
 }
 
 __host__ __device__ inline CascadePlanView cascade_plan_view(const int32_t* plan, int64_t batch, int64_t max_items) {
@@ -41,7 +43,8 @@ __host__ __device__ inline CascadePlanView cascade_plan_view(const int32_t* plan
   v.group_pool_row = p; p += batch;
   v.group_kvlen = p; p += batch;
   v.items = p; p += 8 * max_items;
-  v.batch_order = p;
+  v.batch_order = p; p += batch;
+  v.compare = p;
   return v;
 }
 
