@@ -157,7 +157,7 @@ int sgl_amd_extend_attention(const void* q, void* out, const void* k_cache, cons
 /* ---- Shared-prefix (cascade) decode attention ---------------------------------------------------
  * RadixAttention batches share KV rows: requests whose req_to_token rows start with the same slots
  * read the same pool rows (reference: the Triton decode path of triton_backend.py:136-1012 re-reads
- * them once per request).  sgl_amd_cascade_plan (one launch per decode STEP, device-only, graph-safe)
+ * them once per request).  sgl_amd_cascade_plan (two launches per decode STEP, device-only, graph-safe)
  * groups such requests; sgl_amd_cascade_decode_attention (per layer, two launches) cuts every group's
  * shared prefix and every request's private suffix into sgl_amd_cascade_chunk_tokens()-token items,
  * reads each item's K/V rows once for all its member requests (MFMA), and merges the per-item
