@@ -401,6 +401,21 @@ int sgl_amd_xgmi_two_stage_all_reduce(const void* inp, void* out, int64_t rows, 
  * logits_processor.py:676) -- one launch with the same flag protocol, so the decode graph holds no RCCL node. */
 int sgl_amd_xgmi_all_gather(const void* inp, void* out, int64_t rows, int cols_per_rank, int rank, int world,
                             const void* const* peer_workspaces_host, int64_t workspace_bytes, int num_blocks, void* stream);
+/* Protocol switch of the flag barriers (process-wide, read when a collective is ENQUEUED -- a captured graph keeps the
+ * setting it was captured with).  0 (default): everything a peer reads is written with system-scope write-through
+ * stores and published by their completion (s_waitcnt vmcnt(0)) + a relaxed system-scope flag; 1: a full system-scope
+ * RELEASE fence precedes every flag as well -- the reference's protocol (custom_all_reduce_hip.cuh:150-236
+ * __atomic_store_n(..., __ATOMIC_RELEASE) after __threadfence_system), slower by the write-back of the device's
+ * dirty L2, kept as the fallback should the light protocol ever misbehave across physical xGMI links. */
+int sgl_amd_xgmi_set_release_fence(int on);
+/* Byte offset of the data area inside a workspace (the signal block precedes it). */
+int64_t sgl_amd_xgmi_data_offset(void);
+/* Host-side mirror of the two-stage kernel's work split, for tests and sizing: units_per_rank[r] = number of units
+ * (8 KiB chunks, or rows with epilogue 1) rank r sums and publishes for a [rows, hidden] message; returns the
+ * workgroup count used (num_blocks <= 0: the automatic one), < 0 on a bad argument.  A balanced split is what makes
+ * the per-link traffic 2/world of the message. */
+int sgl_amd_xgmi_two_stage_owner_units(int64_t rows, int hidden, int world, int epilogue, int num_blocks,
+                                       int64_t* units_per_rank /* host, [world] */);
 
 /* ---- pool layouts / element formats / masks beyond the bf16 NHD default ----------
  * kv_fp8 = 1: the pools hold OCP e4m3 bytes of K / k_scale and V / v_scale (memory_pool.py:2364-2374,

@@ -18,9 +18,12 @@
 //   phase 3  end barrier: nobody overwrites its buffer for the next call while a peer may still read it
 // The flags are monotonically increasing counters kept in device memory (the kernel increments its own), so a
 // launch has no host-side state: it can be captured into the decode hipGraph and replayed.
-// Flags are written with system-scope stores straight into the PEER's signal block and polled locally; the workspaces
-// are hipDeviceMallocUncached (stores bypass L2: a release is the completion of the data stores, not a cache write-back;
-// no side can hit a stale L2 line), see flag_barrier.
+// Flags are written with system-scope stores straight into the PEER's signal block and polled locally.  Everything a
+// peer reads is written with SYSTEM-SCOPE (sc0 sc1) stores -- write-through past this device's L2 whatever MTYPE the pages
+// carry -- and read with system-scope loads, so that a release is the completion of the data stores (s_waitcnt vmcnt(0)),
+// not a write-back of the whole L2, and does not rest on the workspace pages being mapped uncached on both sides
+// (they are allocated hipDeviceMallocUncached as well); see flag_barrier.  sgl_amd_xgmi_set_release_fence(1) puts a full
+// system-scope release fence in front of every flag as a fallback.
 #include <cstddef>
 #include <cstring>
 #include "common.hpp"
@@ -60,16 +63,36 @@ struct ArParams {
   int rank, world;
   int epilogue;                 // 0 none, 1 residual add + RMSNorm
   float eps;
+  int ws_bytes;                 // size of every rank's workspace (buffer range of the system-scope accesses)
+  int release_fence;            // 1: system-scope release fence ahead of every flag (fallback, sgl_amd_xgmi_set_release_fence)
 };
+
+// System-scope 16-byte accesses to a workspace (own or a peer's): buffer instructions with sc0 sc1 -- stores write
+// through to memory, loads bypass this device's caches -- at byte offset `off` of the workspace `base` points to.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ws_rsrc(unsigned char* base, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(base, 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ U4 ld16_sys(__amdgpu_buffer_rsrc_t r, int64_t off) {
+  return __builtin_bit_cast(U4, __builtin_amdgcn_raw_buffer_load_b128(r, static_cast<int>(off), 0, 17));
+}
+__device__ __forceinline__ void st16_sys(__amdgpu_buffer_rsrc_t r, int64_t off, const U4& v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r, static_cast<int>(off), 0, 17);
+}
+
+// two-stage kernel: the rank that sums (and publishes) the k-th unit -- kUnroll chunks, or a row -- of workgroup `block`
+__host__ __device__ __forceinline__ int two_stage_owner(int64_t block, int64_t k, int world) { return static_cast<int>((block + k) % world); }
 
 template <bool ACQUIRE = true>
 __device__ __forceinline__ void flag_barrier(const ArParams& p, uint32_t (Signal::*arr)[kMaxBlocks][kMaxWorld], uint32_t flag) {
-  // RELEASE.  What a peer reads from this rank lives in this rank's OWN workspace, allocated uncached on this device:
-  // those stores bypass L2, so publishing them needs no cache write-back -- only their completion.  Every wave waits for
-  // its own stores (s_waitcnt vmcnt(0): the wait the memory model prescribes ahead of a system-scope release), the
-  // workgroup barrier collects the waves, then the flag goes out.  (A system-scope release fence here also writes back
-  // every dirty L2 line of the device -- the projection's output, the residual stream: 24 us of a 33 us two-stage launch
-  // at 256 rows, 1.5 ms of a TP 4 rank's 5.8 ms decode step.)
+  // RELEASE.  What a peer reads from this rank lives in this rank's OWN workspace and was written with system-scope
+  // (sc0 sc1) stores: they write through L2 to memory, so publishing them needs no cache write-back -- only their
+  // completion.  Every wave waits for its own stores (s_waitcnt vmcnt(0): the wait the memory model prescribes ahead of a
+  // system-scope release; inline asm, so the compiler cannot drop it), the workgroup barrier collects the waves, then the
+  // flag goes out.  (A system-scope release fence here also writes back every dirty L2 line of the device -- the
+  // projection's output, the residual stream: 24 us of a 33 us two-stage launch at 256 rows, 1.5 ms of a TP 4 rank's
+  // 5.8 ms decode step.  It stays available as the fallback: release_fence.)
+  if (p.release_fence) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const int t = threadIdx.x;
@@ -91,7 +114,7 @@ __device__ __forceinline__ void flag_barrier(const ArParams& p, uint32_t (Signal
       }
     }
     // ACQUIRE, once per workgroup and barrier (not once per poll): whatever this CU's L1 or this XCD's L2 may hold of
-    // the peers' workspaces is dropped before anybody reads them (the peers' pages are mapped uncached too, so this is
+    // the peers' workspaces is dropped before anybody reads them (the reads are system-scope loads as well, so this is
     // belt and braces -- but it is the half of the fence pair that costs little).  The END barrier of a launch is
     // followed by no read of a peer's memory -- it only keeps this rank from overwriting its workspace in the next
     // call while a peer still reads it -- and skips it.
@@ -105,7 +128,7 @@ template <int WORLD>
 __device__ __forceinline__ void gather_sum(const ArParams& p, int64_t e, float (&acc)[8]) {
   U4 v[WORLD];
 #pragma unroll
-  for (int r = 0; r < WORLD; ++r) v[r] = ld16(reinterpret_cast<const uint16_t*>(p.peers.base[r] + kDataOffset) + e);
+  for (int r = 0; r < WORLD; ++r) v[r] = ld16_sys(ws_rsrc(p.peers.base[r], p.ws_bytes), kDataOffset + e * 2);
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = 0.f;
 #pragma unroll
@@ -127,15 +150,15 @@ __global__ __launch_bounds__(kArThreads) void xgmi_one_shot_all_reduce_kernel(Ar
   const int64_t nvec = p.numel / 8;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kArThreads;
   // phase 0: my copy
-  uint16_t* mine = reinterpret_cast<uint16_t*>(p.peers.base[p.rank] + kDataOffset);
+  const __amdgpu_buffer_rsrc_t mine = ws_rsrc(p.peers.base[p.rank], p.ws_bytes);
   if (p.epilogue == 0) {
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kArThreads + threadIdx.x; i < nvec; i += stride)
-      st16(mine + i * 8, ld16(p.inp + i * 8));
+      st16_sys(mine, kDataOffset + i * 16, ld16(p.inp + i * 8));
   } else {
     // row-wise ownership: the rows a workgroup will finish are the rows it publishes
     for (int r = blockIdx.x; r < p.rows; r += gridDim.x)
       for (int c = threadIdx.x * 8; c < p.hidden; c += kArThreads * 8)
-        st16(mine + static_cast<int64_t>(r) * p.hidden + c, ld16(p.inp + static_cast<int64_t>(r) * p.hidden + c));
+        st16_sys(mine, kDataOffset + (static_cast<int64_t>(r) * p.hidden + c) * 2, ld16(p.inp + static_cast<int64_t>(r) * p.hidden + c));
   }
   flag_barrier(p, &Signal::start, flag);
 
@@ -207,7 +230,7 @@ __global__ __launch_bounds__(kArThreads) void xgmi_one_shot_all_reduce_kernel(Ar
 // after the middle barrier everybody reads every chunk from its owner.  Per link direction 2/world of the message
 // instead of the one-shot kernel's whole message; same bits on every rank (each sum is computed once, by its owner).
 // Chunk c of kArThreads 16-byte vectors belongs to workgroup c % grid in ALL phases on ALL ranks, so the per-workgroup
-// flag rows pair the same data on both sides of a link; its owner is rank (c / grid) % world.
+// flag rows pair the same data on both sides of a link; its owner is rank (c % grid + c / grid) % world.
 // `kUnroll` chunks of a workgroup are in flight together in every phase (a phase is a chain of dependent memory round
 // trips per chunk otherwise: 4 MiB took 39 us on local memory before, loopback).
 // epilogue 1 (rows x hidden messages, hidden <= kArThreads * 8 * 4): a chunk is a ROW, so that the workgroup that
@@ -219,13 +242,14 @@ __global__ __launch_bounds__(kArThreads) void xgmi_two_stage_all_reduce_kernel(A
   __shared__ float scratch[16];
   Signal* self = reinterpret_cast<Signal*>(p.peers.base[p.rank]);
   const uint32_t flag = self->flag[blockIdx.x] + 1;
-  uint16_t* mine = reinterpret_cast<uint16_t*>(p.peers.base[p.rank] + kDataOffset);
-  uint16_t* my_sums = reinterpret_cast<uint16_t*>(p.peers.base[p.rank] + sums_offset);
+  const __amdgpu_buffer_rsrc_t mine = ws_rsrc(p.peers.base[p.rank], p.ws_bytes);   // copies at kDataOffset, sums at sums_offset
   if (p.epilogue == 0) {
     const int64_t nvec = p.numel / 8;
     const int64_t nchunks = (nvec + kArThreads - 1) / kArThreads;
     const int64_t step = static_cast<int64_t>(gridDim.x) * kUnroll;
-    // chunk c belongs to workgroup (c / kUnroll) % grid; its owner is rank (c / (kUnroll * grid)) % world
+    // chunk c belongs to workgroup b = (c / kUnroll) % grid; its owner is rank (b + c / (kUnroll * grid)) % world -- the
+    // workgroup index is part of it, or a message of one iteration per workgroup (anything up to 8 MiB at the automatic
+    // grid) would be summed by rank 0 alone
     for (int64_t c0 = static_cast<int64_t>(blockIdx.x) * kUnroll; c0 < nchunks; c0 += step) {
       U4 v[kUnroll];
 #pragma unroll
@@ -236,13 +260,13 @@ __global__ __launch_bounds__(kArThreads) void xgmi_two_stage_all_reduce_kernel(A
 #pragma unroll
       for (int u = 0; u < kUnroll; ++u) {
         const int64_t i = (c0 + u) * kArThreads + threadIdx.x;
-        if (c0 + u < nchunks && i < nvec) st16(mine + i * 8, v[u]);
+        if (c0 + u < nchunks && i < nvec) st16_sys(mine, kDataOffset + i * 16, v[u]);
       }
     }
     flag_barrier(p, &Signal::start, flag);
     int64_t k = 0;
     for (int64_t c0 = static_cast<int64_t>(blockIdx.x) * kUnroll; c0 < nchunks; c0 += step, ++k) {
-      if (k % WORLD != p.rank) continue;
+      if (two_stage_owner(blockIdx.x, k, WORLD) != p.rank) continue;
       float acc[kUnroll][8];
 #pragma unroll
       for (int u = 0; u < kUnroll; ++u) {
@@ -256,19 +280,19 @@ __global__ __launch_bounds__(kArThreads) void xgmi_two_stage_all_reduce_kernel(A
           U4 o;
           o.x = pack_bf2(acc[u][0], acc[u][1]); o.y = pack_bf2(acc[u][2], acc[u][3]);
           o.z = pack_bf2(acc[u][4], acc[u][5]); o.w = pack_bf2(acc[u][6], acc[u][7]);
-          st16(my_sums + i * 8, o);
+          st16_sys(mine, sums_offset + i * 16, o);
         }
       }
     }
     flag_barrier(p, &Signal::mid, flag);
     k = 0;
     for (int64_t c0 = static_cast<int64_t>(blockIdx.x) * kUnroll; c0 < nchunks; c0 += step, ++k) {
-      const uint16_t* src = reinterpret_cast<const uint16_t*>(p.peers.base[k % WORLD] + sums_offset);
+      const __amdgpu_buffer_rsrc_t src = ws_rsrc(p.peers.base[two_stage_owner(blockIdx.x, k, WORLD)], p.ws_bytes);   // the chunks' owner
       U4 v[kUnroll];
 #pragma unroll
       for (int u = 0; u < kUnroll; ++u) {
         const int64_t i = (c0 + u) * kArThreads + threadIdx.x;
-        if (c0 + u < nchunks && i < nvec) v[u] = ld16(src + i * 8);
+        if (c0 + u < nchunks && i < nvec) v[u] = ld16_sys(src, sums_offset + i * 16);
       }
 #pragma unroll
       for (int u = 0; u < kUnroll; ++u) {
@@ -277,15 +301,15 @@ __global__ __launch_bounds__(kArThreads) void xgmi_two_stage_all_reduce_kernel(A
       }
     }
   } else {
-    // rows: workgroup b owns rows b, b + grid, ...; the j-th of them is summed by rank j % world
+    // rows: workgroup b owns rows b, b + grid, ...; the j-th of them is summed by rank (b + j) % world
     constexpr int kMaxVec = 4;
     for (int r = blockIdx.x; r < p.rows; r += gridDim.x)
       for (int c = threadIdx.x * 8; c < p.hidden; c += kArThreads * 8)
-        st16(mine + static_cast<int64_t>(r) * p.hidden + c, ld16(p.inp + static_cast<int64_t>(r) * p.hidden + c));
+        st16_sys(mine, kDataOffset + (static_cast<int64_t>(r) * p.hidden + c) * 2, ld16(p.inp + static_cast<int64_t>(r) * p.hidden + c));
     flag_barrier(p, &Signal::start, flag);
     int j = 0;
     for (int r = blockIdx.x; r < p.rows; r += gridDim.x, ++j) {
-      if (j % WORLD != p.rank) continue;
+      if (two_stage_owner(blockIdx.x, j, WORLD) != p.rank) continue;
 #pragma unroll
       for (int kv = 0; kv < kMaxVec; ++kv) {
         const int c = (kv * kArThreads + threadIdx.x) * 8;
@@ -296,14 +320,14 @@ __global__ __launch_bounds__(kArThreads) void xgmi_two_stage_all_reduce_kernel(A
           U4 o;
           o.x = pack_bf2(acc[0], acc[1]); o.y = pack_bf2(acc[2], acc[3]);
           o.z = pack_bf2(acc[4], acc[5]); o.w = pack_bf2(acc[6], acc[7]);
-          st16(my_sums + e, o);
+          st16_sys(mine, sums_offset + e * 2, o);
         }
       }
     }
     flag_barrier(p, &Signal::mid, flag);
     j = 0;
     for (int r = blockIdx.x; r < p.rows; r += gridDim.x, ++j) {
-      const uint16_t* src = reinterpret_cast<const uint16_t*>(p.peers.base[j % WORLD] + sums_offset);
+      const __amdgpu_buffer_rsrc_t src = ws_rsrc(p.peers.base[two_stage_owner(blockIdx.x, j, WORLD)], p.ws_bytes);   // the row's owner
       // h = the owner's bf16(sum);  t = h + residual (fp32);  residual <- bf16(t);  out = bf16(t * rsqrt(mean(t^2) + eps) * w)
       float t[kMaxVec][8];
       float sq = 0.f;
@@ -312,7 +336,7 @@ __global__ __launch_bounds__(kArThreads) void xgmi_two_stage_all_reduce_kernel(A
         const int c = (kv * kArThreads + threadIdx.x) * 8;
         if (c < p.hidden) {
           const int64_t e = static_cast<int64_t>(r) * p.hidden + c;
-          const U4 hv = ld16(src + e);
+          const U4 hv = ld16_sys(src, sums_offset + e * 2);
           const U4 rv = ld16(p.residual + e);
           const uint32_t hw[4] = {hv.x, hv.y, hv.z, hv.w}, rw[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
@@ -359,10 +383,10 @@ __global__ __launch_bounds__(kArThreads) void xgmi_all_gather_kernel(ArParams p)
   const int64_t nvec = p.numel / 8;                 // of one rank's shard [rows, hidden]
   const int64_t nchunks = (nvec + kArThreads - 1) / kArThreads;
   const int vpr = p.hidden / 8;                     // vectors per shard row
-  uint16_t* mine = reinterpret_cast<uint16_t*>(p.peers.base[p.rank] + kDataOffset);
+  const __amdgpu_buffer_rsrc_t mine = ws_rsrc(p.peers.base[p.rank], p.ws_bytes);
   for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
     const int64_t i = c * kArThreads + threadIdx.x;
-    if (i < nvec) st16(mine + i * 8, ld16(p.inp + i * 8));
+    if (i < nvec) st16_sys(mine, kDataOffset + i * 16, ld16(p.inp + i * 8));
   }
   flag_barrier(p, &Signal::start, flag);
   for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
@@ -372,7 +396,7 @@ __global__ __launch_bounds__(kArThreads) void xgmi_all_gather_kernel(ArParams p)
       const int col = static_cast<int>(i - row * vpr) * 8;
       U4 v[WORLD];
 #pragma unroll
-      for (int r = 0; r < WORLD; ++r) v[r] = ld16(reinterpret_cast<const uint16_t*>(p.peers.base[r] + kDataOffset) + i * 8);
+      for (int r = 0; r < WORLD; ++r) v[r] = ld16_sys(ws_rsrc(p.peers.base[r], p.ws_bytes), kDataOffset + i * 16);
 #pragma unroll
       for (int r = 0; r < WORLD; ++r) st16(p.out + row * (static_cast<int64_t>(p.hidden) * WORLD) + static_cast<int64_t>(r) * p.hidden + col, v[r]);
     }
@@ -386,6 +410,15 @@ __global__ __launch_bounds__(kArThreads) void xgmi_all_gather_kernel(ArParams p)
 // cap on the automatic workgroup counts (tests with several ranks on ONE GPU: all their spinning workgroups must be
 // resident together); explicit num_blocks arguments are not touched
 static int g_xgmi_auto_blocks_cap = kMaxBlocks;
+// 1: every flag is preceded by a system-scope release fence (fallback protocol, sgl_amd_xgmi_set_release_fence)
+static int g_xgmi_release_fence = 0;
+
+static int two_stage_auto_blocks(int64_t rows, int64_t numel, int epilogue) {
+  const int64_t units = epilogue ? rows : ((numel / 8 + kArThreads - 1) / kArThreads + 3) / 4;
+  int blocks = static_cast<int>(units < kMaxBlocks ? (units < 1 ? 1 : units) : kMaxBlocks);
+  if (blocks > g_xgmi_auto_blocks_cap) blocks = g_xgmi_auto_blocks_cap;
+  return blocks;
+}
 
 extern "C" {
 
@@ -396,6 +429,35 @@ int sgl_amd_xgmi_debug_auto_blocks_cap(int cap) {
   }
   g_xgmi_auto_blocks_cap = cap;
   return 0;
+}
+
+int sgl_amd_xgmi_set_release_fence(int on) {
+  g_xgmi_release_fence = on ? 1 : 0;
+  return 0;
+}
+
+int64_t sgl_amd_xgmi_data_offset(void) { return kDataOffset; }
+
+int sgl_amd_xgmi_two_stage_owner_units(int64_t rows, int hidden, int world, int epilogue, int num_blocks, int64_t* units_per_rank) {
+  SGL_CHECK_ARG(world >= 1 && world <= kMaxWorld && units_per_rank && rows >= 0 && hidden > 0 && hidden % 8 == 0,
+                "xgmi_two_stage_owner_units: bad argument");
+  const int64_t numel = rows * hidden;
+  const int blocks = num_blocks > 0 ? num_blocks : two_stage_auto_blocks(rows, numel, epilogue);
+  for (int r = 0; r < world; ++r) units_per_rank[r] = 0;
+  if (epilogue) {                                    // unit = a row
+    for (int64_t b = 0; b < blocks; ++b) {
+      int64_t j = 0;
+      for (int64_t r = b; r < rows; r += blocks, ++j) units_per_rank[two_stage_owner(b, j, world)] += 1;
+    }
+  } else {                                           // unit = a chunk of kArThreads 16-byte vectors
+    const int64_t nvec = numel / 8, nchunks = (nvec + kArThreads - 1) / kArThreads;
+    for (int64_t b = 0; b < blocks; ++b) {
+      int64_t k = 0;
+      for (int64_t c0 = b * 4; c0 < nchunks; c0 += static_cast<int64_t>(blocks) * 4, ++k)
+        for (int u = 0; u < 4 && c0 + u < nchunks; ++u) units_per_rank[two_stage_owner(b, k, world)] += 1;
+    }
+  }
+  return blocks;
 }
 
 int64_t sgl_amd_xgmi_workspace_bytes(int64_t max_message_bytes) { return kDataOffset + ((max_message_bytes + 255) / 256) * 256; }
@@ -489,6 +551,7 @@ int sgl_amd_xgmi_one_shot_all_reduce(const void* inp, void* out, int64_t rows, i
   p.inp = static_cast<const uint16_t*>(inp); p.out = static_cast<uint16_t*>(out);
   p.residual = static_cast<uint16_t*>(residual); p.norm_w = static_cast<const uint16_t*>(norm_weight);
   p.numel = numel; p.rows = static_cast<int>(rows); p.hidden = hidden; p.rank = rank; p.world = world; p.epilogue = epilogue; p.eps = eps;
+  p.ws_bytes = static_cast<int>(workspace_bytes); p.release_fence = g_xgmi_release_fence;
   int blocks = num_blocks;
   if (blocks <= 0) {
     // enough workgroups to keep ~7 links busy, never more than the flag table has rows
@@ -547,12 +610,11 @@ int sgl_amd_xgmi_two_stage_all_reduce(const void* inp, void* out, int64_t rows, 
   if (int rc = fill_peers("xgmi_two_stage_all_reduce", &p, rank, world, peer_workspaces_host)) return rc;
   p.inp = static_cast<const uint16_t*>(inp); p.out = static_cast<uint16_t*>(out); p.numel = numel;
   p.rows = static_cast<int>(rows); p.hidden = hidden; p.epilogue = epilogue; p.eps = eps;
+  p.ws_bytes = static_cast<int>(workspace_bytes); p.release_fence = g_xgmi_release_fence;
   p.residual = static_cast<uint16_t*>(residual); p.norm_w = static_cast<const uint16_t*>(norm_weight);
   int blocks = num_blocks;
   if (blocks <= 0) {
-    const int64_t units = epilogue ? rows : ((numel / 8 + kArThreads - 1) / kArThreads + 3) / 4;
-    blocks = static_cast<int>(units < kMaxBlocks ? (units < 1 ? 1 : units) : kMaxBlocks);
-    if (blocks > g_xgmi_auto_blocks_cap) blocks = g_xgmi_auto_blocks_cap;
+    blocks = two_stage_auto_blocks(rows, numel, epilogue);
   }
   SGL_CHECK_ARG(blocks >= 1 && blocks <= kMaxBlocks, "xgmi_two_stage_all_reduce: num_blocks=%d (1..%d)", blocks, kMaxBlocks);
   hipStream_t st = as_stream(stream);
@@ -580,6 +642,7 @@ int sgl_amd_xgmi_all_gather(const void* inp, void* out, int64_t rows, int cols_p
   if (int rc = fill_peers("xgmi_all_gather", &p, rank, world, peer_workspaces_host)) return rc;
   p.inp = static_cast<const uint16_t*>(inp); p.out = static_cast<uint16_t*>(out); p.numel = numel;
   p.rows = static_cast<int>(rows); p.hidden = cols_per_rank;
+  p.ws_bytes = static_cast<int>(workspace_bytes); p.release_fence = g_xgmi_release_fence;
   int blocks = num_blocks;
   if (blocks <= 0) {
     const int64_t chunks = (numel / 8 + kArThreads - 1) / kArThreads;

@@ -221,7 +221,7 @@ def tensor_model_parallel_all_gather(x: torch.Tensor, dim: int = -1) -> torch.Te
     if dim < 0:
         dim += x.dim()
     if (_XGMI is not None and not _XGMI.disabled and x.is_cuda and x.dim() == 2 and dim == 1 and x.dtype == torch.bfloat16
-            and x.shape[1] % 8 == 0 and 32768 + x.numel() * 2 <= _XGMI.ws_bytes):
+            and x.shape[1] % 8 == 0 and _XGMI.fits_all_gather(x)):
         return _XGMI.all_gather(x.contiguous())          # one launch on the current stream: the decode graph holds no RCCL node
     if _EMULATED is not None:
         return x                                        # (loopback: the rank's own shard)

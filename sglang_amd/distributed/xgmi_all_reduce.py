@@ -16,6 +16,7 @@ Messages above `max_bytes` (prefill activations) are left to RCCL.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import List, Optional
 
 import torch
@@ -48,6 +49,11 @@ class XgmiAllReduce:
         self.policy_world = int(policy_world or world)
         self.max_bytes = int(max_bytes)
         self.two_stage_bytes = int(two_stage_bytes)
+        self.data_offset = int(lib.sgl_amd_xgmi_data_offset())
+        # SGLANG_AMD_XGMI_RELEASE_FENCE=1: the fallback protocol (a system-scope release fence ahead of every flag);
+        # process-wide, read when a collective is enqueued / captured
+        if os.environ.get("SGLANG_AMD_XGMI_RELEASE_FENCE", "") not in ("", "0"):
+            lib.sgl_amd_xgmi_set_release_fence(1)
         # data area: the one-shot message, or the two halves (copies + published sums) of a two-stage message
         self.ws_bytes = int(lib.sgl_amd_xgmi_workspace_bytes(max(self.max_bytes, 2 * self.two_stage_bytes + 512)))
         torch.cuda.set_device(device)
@@ -153,10 +159,18 @@ class XgmiAllReduce:
             return self.all_reduce(x, residual=residual, norm_weight=norm_weight, eps=eps)
         return self.two_stage_all_reduce(x, residual=residual, norm_weight=norm_weight, eps=eps)
 
+    def fits_all_gather(self, x: torch.Tensor) -> bool:
+        return self.data_offset + x.numel() * 2 <= self.ws_bytes
+
+    @staticmethod
+    def set_release_fence(on: bool) -> None:
+        """Fallback switch of the flag protocol (include/sglang_amd.h: sgl_amd_xgmi_set_release_fence)."""
+        native.lib().sgl_amd_xgmi_set_release_fence(1 if on else 0)
+
     def all_gather(self, x: torch.Tensor, num_blocks: int = 0) -> torch.Tensor:
         """[rows, cols] per rank -> [rows, world * cols] (tensor_model_parallel_all_gather(dim=-1) of a 2-D tensor)."""
         if not (x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and x.dim() == 2 and x.shape[1] % 8 == 0
-                and 32768 + x.numel() * 2 <= self.ws_bytes):
+                and self.fits_all_gather(x)):
             raise ValueError("XgmiAllReduce.all_gather: 2-D contiguous bf16 shard with cols % 8 == 0 that fits the workspace")
         out = torch.empty((x.shape[0], x.shape[1] * self.world), dtype=x.dtype, device=x.device)
         native.call("sgl_amd_xgmi_all_gather", x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], self.rank, self.world, self._peers,

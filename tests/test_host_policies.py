@@ -250,3 +250,27 @@ def test_all_reduce_switch_points_and_fused_layer_gates():
         assert fused_decode.layer_fusable(layer, 4)
         good.is_neox_style = False
         assert not fused_decode.layer_fusable(layer, 4)                 # GPT-J style pairs: not this form
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("rows,hidden,epilogue", [(64, 4096, 0), (256, 8192, 0), (512, 4096, 1), (256, 8192, 1),
+                                                  (2048, 8192, 0), (100, 4096, 1), (8192, 4096, 0)])
+def test_two_stage_all_reduce_work_is_spread_over_the_ranks(world, rows, hidden, epilogue):
+    """at the automatic grid every workgroup runs ONE iteration for messages up to 8 MiB (<= 256 rows with
+    the fused epilogue); the owner of a unit must therefore depend on the workgroup index, or rank 0 sums everything
+    and every peer pulls the whole result from it (the one-shot kernel's link traffic plus a third barrier)."""
+    import ctypes
+
+    from sglang_amd import native
+
+    lib = native.lib()
+    units = (ctypes.c_int64 * world)()
+    blocks = lib.sgl_amd_xgmi_two_stage_owner_units(rows, hidden, world, epilogue, 0, units)
+    assert 1 <= blocks <= 256
+    got = list(units)
+    total = rows if epilogue else -(-(rows * hidden // 8) // 512)
+    assert sum(got) == total
+    # every rank sums its share to within one unit per workgroup iteration boundary (4 chunks per unrolled step)
+    slack = 1 if epilogue else 4
+    assert max(got) - min(got) <= slack * max(1, -(-total // (blocks * slack)) // world + 1), got
+    assert max(got) <= -(-total // world) + slack * 2, got
