@@ -32,8 +32,19 @@ from . import kernels
 _BF16 = torch.bfloat16
 
 
+# (decoder layer, attention, MLP) classes whose forwards are exactly the form decode_layer restates: llama.py:70-136 /
+# :138-281 / :283-370 and qwen2.py:63-124 / :126-235 / :237-313 (this package's harness classes carry the Llama names).
+# The test is on the EXACT class: a subclass that inherits the hooked model forward but changes the attention math
+# (Ministral3Attention scales q, llama.py users with per-head norms, ...) is not this form and stays with the reference.
+FUSABLE_FORMS = (("LlamaDecoderLayer", "LlamaAttention", "LlamaMLP"), ("Qwen2DecoderLayer", "Qwen2Attention", "Qwen2MLP"))
+
+
 def _plain_linear(lin) -> bool:
-    """An unquantised bf16 projection (UnquantizedLinearMethod, linear.py:1596-1660): weight [N, K] bf16, K contiguous."""
+    """An unquantised bf16 projection (UnquantizedLinearMethod, linear.py:1596-1660): weight [N, K] bf16, K contiguous.
+    A LoRA wrapper (lora/layers.py:39-50 BaseLayerWithLoRA: `.weight` aliases the base weight, no quant_method) is NOT one:
+    streaming its base weights would drop the adapter's delta."""
+    if hasattr(lin, "base_layer") or hasattr(lin, "set_lora") or hasattr(lin, "lora_backend"):
+        return False
     w = getattr(lin, "weight", None)
     if w is None or w.dtype != _BF16 or w.dim() != 2 or w.stride(1) != 1 or not w.is_cuda:
         return False
@@ -45,6 +56,8 @@ def layer_fusable(layer, rows: int) -> bool:
     """The layer is a dense Llama-style block whose four projections the weight-streaming GEMM takes at `rows` rows."""
     attn, mlp = getattr(layer, "self_attn", None), getattr(layer, "mlp", None)
     if attn is None or mlp is None or not hasattr(mlp, "gate_up_proj") or not hasattr(mlp, "down_proj"):
+        return False
+    if (type(layer).__name__, type(attn).__name__, type(mlp).__name__) not in FUSABLE_FORMS:
         return False
     lins = (attn.qkv_proj, attn.o_proj, mlp.gate_up_proj, mlp.down_proj)
     if not all(_plain_linear(l) for l in lins):
@@ -115,7 +128,17 @@ def model_fusable(model, hidden_states: torch.Tensor, forward_batch) -> bool:
     if mode is None or not mode.is_decode():
         return False
     rows = hidden_states.shape[0]
-    return len(model.layers) > 0 and all(layer_fusable(l, rows) for l in model.layers)
+    if not (len(model.layers) > 0 and all(layer_fusable(l, rows) for l in model.layers)):
+        return False
+    # a pool the kernels do not read (fp8_e5m2 rows, an unknown layout) must fall back BEFORE the first launch, not raise
+    # in the middle of the forward
+    try:
+        from .layers.attention.hip_backend import pool_kernel_format
+
+        pool_kernel_format(forward_batch.token_to_kv_pool, model.layers[0].self_attn.attn)
+    except Exception:
+        return False
+    return True
 
 
 def llama_model_forward_hook(original, self, input_ids, positions, forward_batch, input_embeds=None, pp_proxy_tensors=None):

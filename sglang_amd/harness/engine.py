@@ -673,6 +673,11 @@ class Engine:
         over the waiting queue); finished requests leave the batch; a per-batch `sampling_info` follows the batch
         composition through filter_batch (rows are looked up by request, so a re-admitted request keeps its own row)."""
         row_of = {id(q): i for i, q in enumerate(reqs)}
+        if sampling_info is not None:
+            foreign = [q.rid for q in list(self.waiting) + list(self.running) if id(q) not in row_of]
+            if foreign:
+                raise ValueError(f"Engine.generate: requests {foreign} were already queued / running before this call and have "
+                                 f"no row in `sampling_info`; pass them in `reqs` (with their rows) or drain them first")
 
         def info_for(batch: Sequence[Req]):
             return sampling_info.filter_batch([row_of[id(q)] for q in batch]) if sampling_info is not None else None

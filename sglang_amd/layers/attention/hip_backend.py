@@ -23,7 +23,7 @@ from typing import Optional
 import torch
 
 from ... import kernels
-from ...mem_cache.memory_pool import KVWriteLoc
+from ...mem_cache.memory_pool import KVWriteLoc, _host_scale
 from .base_attn_backend import AttentionBackend
 
 
@@ -100,8 +100,7 @@ def pool_kernel_format(pool, layer=None) -> dict:
     fp8 = dtype == torch.float8_e4m3fn
     ks = vs = 1.0
     if fp8 and layer is not None:
-        ks = float(getattr(layer, "k_scale_float", None) or 1.0)
-        vs = float(getattr(layer, "v_scale_float", None) or 1.0)
+        ks, vs = _host_scale(layer, "k_scale"), _host_scale(layer, "v_scale")
     page = int(getattr(pool, "page_size", 1) or 1)
     return dict(kv_fp8=fp8, k_scale=ks, v_scale=vs, page_size=page, hnd=bool(getattr(pool, "use_hnd", False)) and page > 1)
 

@@ -32,8 +32,18 @@ class RadixAttention(nn.Module):
         self.sliding_window_size = sliding_window_size or -1
         self.is_cross_attention = is_cross_attention
         self.attn_type = attn_type
+        # fp8 KV scales as the reference keeps them (radix_attention.py:125-130): tensors for kernels that want one, and
+        # HOST floats -- the pool / kernels here read only the floats (float(tensor) would synchronise inside a capture)
         self.k_scale = None
         self.v_scale = None
+        self.k_scale_float = None
+        self.v_scale_float = None
+
+    def set_kv_scales(self, k_scale: float, v_scale: float, device=None) -> None:
+        """Checkpoint k / v scales of an fp8 KV pool: both forms, set together."""
+        self.k_scale_float, self.v_scale_float = float(k_scale), float(v_scale)
+        self.k_scale = torch.tensor(self.k_scale_float, dtype=torch.float32, device=device)
+        self.v_scale = torch.tensor(self.v_scale_float, dtype=torch.float32, device=device)
 
     def forward(self, q, k, v, forward_batch, save_kv_cache: bool = True, **kwargs):
         if k is not None:

@@ -18,6 +18,21 @@ from typing import List, Optional
 import torch
 
 
+def _host_scale(layer, name: str) -> float:
+    """The layer's fp8 KV scale as a HOST float: `<name>_float` (radix_attention.py:129-130), else `<name>` when it is a
+    Python number, else 1.0 when the layer carries no scale at all.  A scale that exists only as a TENSOR raises: reading
+    it would synchronise (and fail inside a graph capture), ignoring it would silently store and dequantise with 1.0."""
+    v = getattr(layer, name + "_float", None)
+    if v is None:
+        v = getattr(layer, name, None)
+        if v is None:
+            return 1.0
+        if isinstance(v, torch.Tensor):
+            raise ValueError(f"fp8 KV pool: the layer's {name} exists only as a tensor; set {name}_float (a host float) when "
+                             f"the checkpoint scales are loaded (RadixAttention.set_kv_scales)")
+    return float(v)
+
+
 @dataclass
 class KVWriteLoc:
     """memory_pool.py KVWriteLoc(loc, swa_loc): where this step's K/V rows go."""
@@ -119,8 +134,8 @@ class MHATokenToKVPool:
         """(kv_fp8, k_scale, v_scale, page_size, hnd) for the attention / store kernels.  Scales are the layer's
         (RadixAttention.k_scale / v_scale, loaded from the checkpoint) or 1.0 (memory_pool.py:2364-2369)."""
         # host floats only (radix_attention.py:129-130): float(k_scale tensor) would synchronise inside a capture
-        ks = float(getattr(layer, "k_scale_float", None) or 1.0) if self.is_fp8 else 1.0
-        vs = float(getattr(layer, "v_scale_float", None) or 1.0) if self.is_fp8 else 1.0
+        ks = _host_scale(layer, "k_scale") if self.is_fp8 else 1.0
+        vs = _host_scale(layer, "v_scale") if self.is_fp8 else 1.0
         return dict(kv_fp8=self.is_fp8, k_scale=ks, v_scale=vs, page_size=self.page_size, hnd=self.use_hnd)
 
     # -- accessors used by attention backends (memory_pool.py:2292-2329) -------

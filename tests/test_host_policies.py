@@ -211,6 +211,14 @@ def test_decode_attention_routing_rule_for_window_and_cap_layers(monkeypatch):
     assert calls[1][1] == {"sliding_window": 32} and calls[2][1] == {"logit_cap": 30.0}
 
 
+def _named(class_name, **attrs):
+    """An attribute bag whose class carries a reference class NAME (what fused_decode's form test reads)."""
+    obj = type(class_name, (), {})()
+    for k, v in attrs.items():
+        setattr(obj, k, v)
+    return obj
+
+
 def test_all_reduce_switch_points_and_fused_layer_gates():
     """Pure host rules: (1) one-shot / two-stage switch of the xGMI all-reduce (custom_all_reduce.py:260-307: two ranks
     always one-shot, 512 KiB at four, 256 KiB at eight) -- a loopback communicator standing in for one rank of a TP job
@@ -229,9 +237,9 @@ def test_all_reduce_switch_points_and_fused_layer_gates():
     lin = lambda **kw: types.SimpleNamespace(weight=w, quant_method=None, bias=None, **kw)    # noqa: E731
     rope = type("MRotaryEmbedding", (), {})()
     rope.is_neox_style, rope.rotary_dim = True, 64
-    attn = types.SimpleNamespace(qkv_proj=lin(), o_proj=lin(), rotary_emb=rope, head_dim=64, num_heads=2, num_kv_heads=1, attn=None)
-    mlp = types.SimpleNamespace(gate_up_proj=lin(), down_proj=lin())
-    layer = types.SimpleNamespace(self_attn=attn, mlp=mlp)
+    attn = _named("LlamaAttention", qkv_proj=lin(), o_proj=lin(), rotary_emb=rope, head_dim=64, num_heads=2, num_kv_heads=1, attn=None)
+    mlp = _named("LlamaMLP", gate_up_proj=lin(), down_proj=lin())
+    layer = _named("LlamaDecoderLayer", self_attn=attn, mlp=mlp)
     assert not fused_decode.layer_fusable(layer, 4)                     # CPU weights: _plain_linear says no first
     assert not fused_decode._plain_linear(types.SimpleNamespace(weight=None))
     assert not fused_decode.layer_fusable(types.SimpleNamespace(self_attn=None, mlp=None), 4)
@@ -248,8 +256,20 @@ def test_all_reduce_switch_points_and_fused_layer_gates():
         big = torch.zeros((64, 128), dtype=torch.bfloat16)
         mlp.gate_up_proj = types.SimpleNamespace(weight=big, quant_method=None, bias=None)
         assert fused_decode.layer_fusable(layer, 4)
+        # the exact reference classes only -- a subclass that inherits the hooked model forward but changes the
+        # attention math (Ministral3Attention scales q) is not this form ...
+        sub = _named("Ministral3Attention", **vars(attn))
+        assert not fused_decode.layer_fusable(_named("LlamaDecoderLayer", self_attn=sub, mlp=mlp), 4)
+        assert not fused_decode.layer_fusable(_named("Ministral3DecoderLayer", self_attn=attn, mlp=mlp), 4)
+        assert fused_decode.layer_fusable(_named("Qwen2DecoderLayer", self_attn=_named("Qwen2Attention", **vars(attn)),
+                                                 mlp=_named("Qwen2MLP", **vars(mlp))), 4)
         good.is_neox_style = False
         assert not fused_decode.layer_fusable(layer, 4)                 # GPT-J style pairs: not this form
+    # ... and a LoRA-wrapped projection (lora/layers.py:39-50: .weight aliases the base weight, no quant_method) is not a
+    # plain linear: streaming the base weights would drop the adapter delta
+    gpu_like = types.SimpleNamespace(dtype=torch.bfloat16, dim=lambda: 2, stride=lambda i: 1, is_cuda=True)
+    assert fused_decode._plain_linear(types.SimpleNamespace(weight=gpu_like, quant_method=None))
+    assert not fused_decode._plain_linear(types.SimpleNamespace(weight=gpu_like, base_layer=object(), set_lora=False))
 
 
 @pytest.mark.parametrize("world", [2, 4, 8])
