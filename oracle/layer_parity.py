@@ -59,7 +59,20 @@ def _fake_fb(extend_lens=None, device=None):
     return type("FB", (), {"forward_mode": mode, "extend_seq_lens": torch.tensor(extend_lens or [0], device=device)})()
 
 
-def run_layer_parity(cfg, device, prompt_lens, monkeypatch, operator_surface=False):
+def _rows_of(record, rows, total):
+    """The per-token tensors of a trace record ([T_total, ...]) restricted to the token rows of one product batch."""
+    if rows is None or record is None:
+        return record
+    return {k: (v[rows] if isinstance(v, torch.Tensor) and v.dim() >= 1 and v.shape[0] == total else v) for k, v in record.items()}
+
+
+def run_layer_parity(cfg, device, prompt_lens, monkeypatch, operator_surface=False, shared_prefix=None):
+    """`shared_prefix` = dict(groups, per_group, prefix): the benchmark's geometry -- `groups` x `per_group` requests, the
+    first `prefix` tokens of a group's prompts shared, prompt_lens[b] tokens in all.  The product then runs as the bench
+    does: a COLD prefill of the group leaders, a WARM prefill of the others over the radix hit (extend over a `prefix`-token
+    prefix) and a decode step whose plan finds the groups (shared chunks + private chunks); every product batch is fed the
+    matching token rows of the oracle's one flat prefill.  Extra phase `prefill_warm` in the result keys; `report["_meta"]`
+    says what the radix cache and the decode plan did."""
     from sglang_amd import kernels as K
     from sglang_amd.harness import models as M
     from sglang_amd.harness.engine import Engine, ModelRunner, Req
@@ -69,7 +82,30 @@ def run_layer_parity(cfg, device, prompt_lens, monkeypatch, operator_surface=Fal
     monkeypatch.setattr(M, "OPERATOR_SURFACE_ONLY", operator_surface)
     B = len(prompt_lens)
     rnd = random.Random(7)
-    prompts = [[rnd.randrange(cfg.vocab_size) for _ in range(n)] for n in prompt_lens]
+    if shared_prefix is None:
+        prompts = [[rnd.randrange(cfg.vocab_size) for _ in range(n)] for n in prompt_lens]
+    else:
+        G, P, PFX = shared_prefix["groups"], shared_prefix["per_group"], shared_prefix["prefix"]
+        assert G * P == B and all(n > PFX for n in prompt_lens)
+        prompts = []
+        for g in range(G):
+            sys_p = [rnd.randrange(cfg.vocab_size) for _ in range(PFX)]
+            prompts += [sys_p + [rnd.randrange(cfg.vocab_size) for _ in range(prompt_lens[g * P + p] - PFX)] for p in range(P)]
+    T_total = sum(prompt_lens)
+    offs = [0]
+    for n in prompt_lens:
+        offs.append(offs[-1] + n)
+
+    def rows_for(req_ids, start):
+        """Token rows (oracle's flat prefill order) of requests `req_ids` from position `start` on."""
+        return torch.cat([torch.arange(offs[b] + start, offs[b + 1], device=device) for b in req_ids])
+
+    if shared_prefix is None:
+        phases = {"prefill": None}
+    else:
+        lead = [g * P for g in range(G)]
+        rest = [b for b in range(B) if b % P != 0]
+        phases = {"prefill": rows_for(lead, 0), "prefill_warm": rows_for(rest, PFX)}
     total = sum(prompt_lens) + 4 * B + 64
     ctx = max(prompt_lens) + 16
     runner = ModelRunner(cfg, max_total_tokens=total + 1024, max_running_requests=B, max_context_len=ctx, device=device, use_graph=False)
@@ -99,26 +135,31 @@ def run_layer_parity(cfg, device, prompt_lens, monkeypatch, operator_surface=Fal
         literal.forced_topk_ids = table
     literal.generate(prompts, 2, forced=forced)
     noise = {}
-    for tag, a, b in (("prefill", literal.trace[0], pre), ("decode", literal.trace[1], dec)):
+    for tag, a, b, rws in [(ph, literal.trace[0], pre, r) for ph, r in phases.items()] + [("decode", literal.trace[1], dec, None)]:
+        bfin = _rows_of({"final_normed": b["final_normed"], "final_residual": b["final_residual"]}, rws, T_total)
         for i in range(L):
-            la, lb = a["layers"][i], b["layers"][i]
+            la, lb = _rows_of(a["layers"][i], rws, T_total), _rows_of(b["layers"][i], rws, T_total)
             noise[f"layer{i}.{tag}.out"] = ulp_stats(la["out"], lb["out"])
             noise[f"layer{i}.{tag}.residual"] = ulp_stats(la["res_out"], lb["res_out"])
             noise[f"layer{i}.{tag}.attn"] = ulp_stats(la["attn_out"], lb["attn_out"])
             # behind the NEXT norm, where the fused decode layer ends
             wn = weights[f"layers.{i + 1}.input_layernorm.weight"] if i + 1 < L else weights["norm.weight"]
             xn, rn = oo.fused_add_rmsnorm(la["out"], la["res_out"], wn, cfg.rms_norm_eps)
-            nb = b["layers"][i + 1] if i + 1 < L else None
-            noise[f"layer{i}.{tag}.next_normed"] = ulp_stats(xn, nb["normed"] if nb is not None else b["final_normed"])
-            noise[f"layer{i}.{tag}.next_residual"] = ulp_stats(rn, nb["residual"] if nb is not None else b["final_residual"])
+            nb = _rows_of(b["layers"][i + 1], rws, T_total) if i + 1 < L else None
+            noise[f"layer{i}.{tag}.next_normed"] = ulp_stats(xn, nb["normed"] if nb is not None else bfin["final_normed"])
+            noise[f"layer{i}.{tag}.next_residual"] = ulp_stats(rn, nb["residual"] if nb is not None else bfin["final_residual"])
     del literal
     report, stages = {}, {}
-    state = {"rec": pre}
+    state = {"rec": pre, "rows": phases["prefill"], "phase": "prefill"}
+
+    def layer_rec(i):
+        rec = state["rec"]
+        return _rows_of(rec["layers"][i], None if rec["decode"] else state["rows"], T_total) if i < L else None
 
     def stage_checks(i, layer, positions, fb, tag):
         """Every operator group of layer i from the oracle's input of that stage."""
         rec = state["rec"]
-        lr = rec["layers"][i]
+        lr = layer_rec(i)
         A = layer.self_attn
         pool = fb.token_to_kv_pool
         kb, vb = pool.get_key_buffer(i), pool.get_value_buffer(i)
@@ -165,7 +206,7 @@ def run_layer_parity(cfg, device, prompt_lens, monkeypatch, operator_surface=Fal
         act = layer.mlp.gate_up_act(lr["post_normed"].clone(), out_blocked=fused)
         stages[f"{key}.gate_up_silu"] = ulp_stats(K.unblock(act), lr["act"])
         if fused:
-            nxt = rec["layers"][i + 1] if i + 1 < L else None
+            nxt = layer_rec(i + 1)
             norm = model.layers[i + 1].input_layernorm if nxt is not None else model.norm
             res = lr["res_out"].clone()
             x = layer.mlp.down_proj.forward_add_rmsnorm(lr["act"].clone(), res, norm)
@@ -180,23 +221,23 @@ def run_layer_parity(cfg, device, prompt_lens, monkeypatch, operator_surface=Fal
 
         def fwd(positions, hidden_states, forward_batch, residual):
             rec = state["rec"]
-            lr = rec["layers"][i]
-            tag = "decode_unfused" if rec["decode"] else "prefill"
+            lr = layer_rec(i)
+            tag = "decode_unfused" if rec["decode"] else state["phase"]
             stage_checks(i, layer, positions, forward_batch, tag)
             res_in = lr["res_in"].clone() if lr["res_in"] is not None else None
             h, r = orig_fwd(positions, lr["h_in"].clone(), forward_batch, res_in)
-            which = "decode" if rec["decode"] else "prefill"
+            which = "decode" if rec["decode"] else state["phase"]
             report[f"layer{i}.{which}.out"] = ulp_stats(h, lr["out"])
             report[f"layer{i}.{which}.residual"] = ulp_stats(r, lr["res_out"])
             return h, r
 
         def fused(positions, normed, forward_batch, residual, next_norm):
             rec = state["rec"]
-            lr = rec["layers"][i]
+            lr = layer_rec(i)
             stage_checks(i, layer, positions, forward_batch, "decode_fused")
             res = lr["residual"].clone()
             x = orig_fused(positions, lr["normed"].clone(), forward_batch, res, next_norm)
-            nxt = rec["layers"][i + 1] if i + 1 < L else None
+            nxt = layer_rec(i + 1)
             # the fused layer ends behind the NEXT norm; the unnormed MLP output is compared through the residual
             report[f"layer{i}.decode.next_normed"] = ulp_stats(K.unblock(x), nxt["normed"] if nxt is not None else rec["final_normed"])
             report[f"layer{i}.decode.next_residual"] = ulp_stats(res, nxt["residual"] if nxt is not None else rec["final_residual"])
@@ -211,26 +252,57 @@ def run_layer_parity(cfg, device, prompt_lens, monkeypatch, operator_surface=Fal
         wrap_layer(i, layer)
     eng = Engine(runner)
     reqs = [Req(b, p, 2) for b, p in enumerate(prompts)]
-    eng.prefill(reqs)
+    r2t_p = runner.req_to_token_pool.req_to_token
+    pool = runner.token_to_kv_pool
+
+    def copy_oracle_kv(which):
+        """The oracle's K / V rows of requests `which` into the product's slots of the same (request, position)."""
+        for b in which:
+            n = prompt_lens[b]
+            sp = r2t_p[reqs[b].req_pool_idx, :n].long()
+            so = oracle.req_to_token[b + 1, :n].long()
+            for l in range(L):
+                pool.get_key_buffer(l)[sp] = oracle.k_cache[l][so]
+                pool.get_value_buffer(l)[sp] = oracle.v_cache[l][so]
+
+    meta = {}
+    if shared_prefix is None:
+        eng.prefill(reqs)
+    else:
+        # as bench.py's job(): the leaders first (cold), then the rest over the radix hit (warm)
+        eng.prefill([reqs[b] for b in lead])
+        copy_oracle_kv(lead)                              # the warm pass attends to the ORACLE's prefix rows
+        state["rows"], state["phase"] = phases["prefill_warm"], "prefill_warm"
+        eng.prefill([reqs[b] for b in rest])
+        meta["radix_hit_tokens"] = sorted(set(int(reqs[b].cached_tokens) for b in rest))
+        # the members of a group computed the same prefix rows: the oracle's copies agree bit for bit, so it does not
+        # matter whose rows end up in the shared slots below
+        so0 = oracle.req_to_token[1, :PFX].long()
+        so1 = oracle.req_to_token[2, :PFX].long()
+        meta["oracle_prefix_rows_identical_across_members"] = bool(torch.equal(oracle.k_cache[0][so0], oracle.k_cache[0][so1])
+                                                                   and torch.equal(oracle.v_cache[L - 1][so0], oracle.v_cache[L - 1][so1]))
     # final norm + lm_head from the oracle's last hidden state
     hn, _ = model.norm(pre["layers"][-1]["out"].clone(), pre["layers"][-1]["res_out"].clone())
     stages["final_norm.prefill"] = ulp_stats(hn, pre["final_normed"])
     lg = model.compute_logits(pre["final_normed"].clone(), _fake_fb(prompt_lens, device))
     stages["lm_head.prefill"] = ulp_stats(lg.next_token_logits, pre["logits"])
     # ---- decode step on the ORACLE's KV rows: copy them to the product's slots of the same (request, position)
-    r2t_p = runner.req_to_token_pool.req_to_token
-    pool = runner.token_to_kv_pool
-    for b, q in enumerate(reqs):
-        n = prompt_lens[b]
-        sp = r2t_p[q.req_pool_idx, :n].long()
-        so = oracle.req_to_token[b + 1, :n].long()
-        for l in range(L):
-            pool.get_key_buffer(l)[sp] = oracle.k_cache[l][so]
-            pool.get_value_buffer(l)[sp] = oracle.v_cache[l][so]
+    copy_oracle_kv(range(B))
     state["rec"] = dec
+    if shared_prefix is not None:                     # the engine's batch order: leaders, then the rest -> back to request order
+        eng.running.sort(key=lambda q: q.rid)
+        eng._decode_state = None
     assert [q.rid for q in eng.running] == list(range(B))
     eng.decode_step()
     eng.flush_decode_outputs(lag=0)
+    if shared_prefix is not None:
+        m = getattr(runner.attn_backend, "forward_metadata", None)
+        ws = getattr(m, "cascade", None)
+        if ws is not None:
+            plan = ws.plan.cpu()
+            meta["decode_plan"] = dict(groups=int(plan[1]), items=int(plan[0]), shared_kv_tokens=sorted(set(plan[8:8 + B].tolist())))
+        meta["decode_contexts"] = [min(prompt_lens) + 1, max(prompt_lens) + 1]
+        report["_meta"] = meta
     fused_ran = any(".decode_fused." in k for k in stages)
     assert fused_ran == (not operator_surface and not moe), sorted(stages)
     lg = model.compute_logits(dec["final_normed"].clone(), _fake_fb())

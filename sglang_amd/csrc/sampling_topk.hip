@@ -186,6 +186,39 @@ __device__ __forceinline__ unsigned long long top_p_fix(float top_p) {
                        : static_cast<unsigned long long>(top_p > 0.f ? static_cast<double>(top_p) * kFix : 0.0);
 }
 
+// The sampler's cut is decided EXACTLY afterwards (exact_top_p_keep): the select only has to return a prefix of the sorted
+// order that contains every element the reference keeps.  The reference's test value fl32(fl32(S_i) - p_i) is the
+// exclusive prefix sum within 2^-24, the fixed-point sums are it within V * 2^-41 <= 2^-24: a margin of 2^-22 covers both.
+__device__ __forceinline__ unsigned long long top_p_fix_superset(float top_p) {
+  if (top_p > 1.001f) return ~0ull >> 1;             // a softmax row's prefix sums never get there
+  const double t = (top_p > 0.f ? static_cast<double>(top_p) : 0.0) + 2.384185791015625e-07;   // + 2^-22
+  return static_cast<unsigned long long>(t * kFix);
+}
+
+// sampler.py:577-580 on the torch CPU path, for sorted rank i with inclusive prefix sum S_i (torch.cumsum accumulates a
+// float row in double and rounds every prefix to float): the element is zeroed when  fl32(fl32(S_i) - p_i) > top_p.
+__device__ __forceinline__ bool exact_top_p_keep(double s_incl, float p, float top_p) {
+  const float cs = static_cast<float>(s_incl);
+  return !(__fsub_rn(cs, p) > top_p);
+}
+
+// inclusive scan of one double per thread over the workgroup, in thread order (fixed association: deterministic)
+__device__ __forceinline__ double block_scan_incl(double v, double* s_part /* kNW */) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const double o = __shfl_up(v, off, 64);
+    if (lane >= off) v += o;
+  }
+  __syncthreads();
+  if (lane == 63) s_part[wid] = v;
+  __syncthreads();
+  double base = 0.0;
+  for (int w = 0; w < wid; ++w) base += s_part[w];
+  __syncthreads();
+  return base + v;
+}
+
 __device__ __forceinline__ void select_begin(RowSmem& sm) {
   if (threadIdx.x == 0) { sm.prefix = 0; sm.c_above = 0; sm.s_above = 0; sm.done_all = 0; sm.n_eq_keep = 0; }
 }
@@ -570,7 +603,8 @@ __global__ __launch_bounds__(kT) void sample_kernel(SampleParams p) {
   // The first radix level reads the row; when the bin the cut falls into and the bins above it hold <= kCand elements
   // (a softmax row with top-k 50 / top-p 0.9: a few hundred) they are collected into LDS in ONE more pass and the other
   // three levels, the min-p maximum and the compaction run on that list: two full-row passes instead of six.
-  const unsigned long long p_fix = top_p_fix(top_p);
+  // (the select returns a SUPERSET prefix of the reference's kept set; the top-p rule itself is applied exactly below)
+  const unsigned long long p_fix = top_p_fix_superset(top_p);
   select_begin(sm);
   select_levels(x, V, 0, 1, top_k, p_fix, sm);
   const float* src = x;                              // what the rest of the selection reads: the row, or the candidates
@@ -612,34 +646,90 @@ __global__ __launch_bounds__(kT) void sample_kernel(SampleParams p) {
     if (posn < kLdsKeep) { sm.keys[posn] = key; sm.toks[posn] = tok; }
     if (gk0) { gk0[posn] = key; gt0[posn] = tok; }
   });
-  if (tid == 0 && p.out_n_keep) p.out_n_keep[row] = n_keep;
-
+  // The pairs are a prefix of the reference's sorted order (descending value, ties by token id) that contains its kept
+  // set.  Rank them, then apply sampler.py:577-580 element by element on the sorted list: inclusive prefix sums in
+  // double (what torch.cumsum computes on the CPU; a fixed tree here instead of its left-to-right loop: the two agree
+  // to ~1e-16 relative, far inside the fl32 rounding the rule applies next), the rule's own fp32 arithmetic, and the
+  // gumbel score of every surviving rank.  A zeroed element keeps its rank (the reference zeroes in place).
+  int kept = 0;
   if (n_keep <= kLdsKeep) {
+    // sorted copies alias the candidate list / the select's histograms (both dead by now)
+    uint32_t* s_key = sm.cand_val;
+    int* s_tok2 = sm.cand_tok;
     __syncthreads();
-    for (int e = tid; e < n_keep; e += kT) {
-      const uint32_t ke = sm.keys[e];
-      int rank = 0;
-      for (int j = 0; j < n_keep; ++j) {
-        const uint32_t kj = sm.keys[j];
-        rank += (kj > ke) || (kj == ke && j < e);
+    uint32_t my_key[kLdsKeep / kT];
+    int my_tok[kLdsKeep / kT], my_rank[kLdsKeep / kT];
+#pragma unroll
+    for (int u = 0; u < kLdsKeep / kT; ++u) {
+      const int e = tid + u * kT;
+      my_rank[u] = -1;
+      if (e < n_keep) {
+        const uint32_t ke = sm.keys[e];
+        int rank = 0;
+        for (int j = 0; j < n_keep; ++j) {
+          const uint32_t kj = sm.keys[j];
+          rank += (kj > ke) || (kj == ke && j < e);
+        }
+        my_key[u] = ke; my_tok[u] = sm.toks[e]; my_rank[u] = rank;
       }
-      const double sc = log(static_cast<double>(__uint_as_float(ke))) + gumbel_from_hash(murmur_hash32(hpre, rank));
-      Best c{sc, rank, sm.toks[e]};
-      if (best_better(best, c)) best = c;
+    }
+    __syncthreads();                                  // (cand_tok was read by the compaction's emit until here)
+#pragma unroll
+    for (int u = 0; u < kLdsKeep / kT; ++u)
+      if (my_rank[u] >= 0) { s_key[my_rank[u]] = my_key[u]; s_tok2[my_rank[u]] = my_tok[u]; }
+    __syncthreads();
+    // thread t owns sorted ranks 2t, 2t + 1
+    constexpr int kPer = kLdsKeep / kT;
+    float pv[kPer];
+    double loc = 0.0;
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      const int r = tid * kPer + u;
+      pv[u] = r < n_keep ? __uint_as_float(s_key[r]) : 0.f;
+      loc += static_cast<double>(pv[u]);
+    }
+    const double incl = block_scan_incl(loc, sm.s_score);
+    double run = incl - loc;
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      const int r = tid * kPer + u;
+      run += static_cast<double>(pv[u]);
+      if (r < n_keep && exact_top_p_keep(run, pv[u], top_p)) {
+        ++kept;
+        const double sc = log(static_cast<double>(pv[u])) + gumbel_from_hash(murmur_hash32(hpre, r));
+        Best c{sc, r, s_tok2[r]};
+        if (best_better(best, c)) best = c;
+      }
     }
   } else {
-    if (!gk0) {   // no workspace: cannot rank -- report the most probable kept token, flag via n_keep < 0
-      if (tid == 0) { p.out_ids[row] = -1; }
+    if (!gk0) {   // no workspace: cannot rank -- refuse the row (-1) instead of mis-sampling it
+      if (tid == 0) { p.out_ids[row] = -1; if (p.out_n_keep) p.out_n_keep[row] = n_keep; }
       return;
     }
     __threadfence_block();
     __syncthreads();
     radix_sort_desc(gk0, gt0, gk0 + V, gt0 + V, n_keep, sm);
-    for (int j = tid; j < n_keep; j += kT) {
-      const double sc = log(static_cast<double>(__uint_as_float(gk0[j]))) + gumbel_from_hash(murmur_hash32(hpre, j));
-      Best c{sc, j, gt0[j]};
-      if (best_better(best, c)) best = c;
+    // thread t owns the contiguous sorted ranks [t seg, (t + 1) seg)
+    const int seg = (n_keep + kT - 1) / kT;
+    const int r0 = tid * seg, r1 = r0 + seg < n_keep ? r0 + seg : n_keep;
+    double loc = 0.0;
+    for (int r = r0; r < r1; ++r) loc += static_cast<double>(__uint_as_float(gk0[r]));
+    const double incl = block_scan_incl(loc, sm.s_score);
+    double run = incl - loc;
+    for (int r = r0; r < r1; ++r) {
+      const float pr = __uint_as_float(gk0[r]);
+      run += static_cast<double>(pr);
+      if (exact_top_p_keep(run, pr, top_p)) {
+        ++kept;
+        const double sc = log(static_cast<double>(pr)) + gumbel_from_hash(murmur_hash32(hpre, r));
+        Best c{sc, r, gt0[r]};
+        if (best_better(best, c)) best = c;
+      }
     }
+  }
+  if (p.out_n_keep) {
+    const int total = static_cast<int>(block_sum(static_cast<float>(kept), sm.red) + 0.5f);   // (< 2^24: exact in fp32)
+    if (tid == 0) p.out_n_keep[row] = total;
   }
   best = block_best(best, sm.s_score, sm.s_rank, sm.s_tok);
   if (tid == 0) {

@@ -103,3 +103,28 @@ def test_layer_identical_inputs_operator_surface_decode(device, monkeypatch):
     report, stages, noise = run_layer_parity(_cfg("llama3_8b"), device, LENS, monkeypatch, operator_surface=True)
     _write("llama3_8b_operator_surface", report, stages, noise, {"workload": "B=64, operator-surface decode"})
     _assert_bars(report, stages, noise)
+
+
+# the benchmark's own geometry (BASELINE configs[1], bench.py): 4 groups x 16 requests, 896 shared + 128..255 unique tokens in,
+# so the decode step runs at contexts 1025..1152 over shared (7 x 128-token chunks per group) + private chunks
+BENCH_GEOMETRY = dict(groups=4, per_group=16, prefix=896)
+BENCH_LENS = [896 + 128 + (7 * b) % 128 for b in range(64)]
+
+
+def test_layer_identical_inputs_bench_geometry(device, monkeypatch):
+    """the attention stages at the benchmark's contexts, not at 33..93 tokens.  The product runs as
+    bench.py's job does -- cold prefill of the 4 leaders (1024+ new tokens), warm prefill of the other 60 over the 896-token
+    radix hit, one decode step whose plan groups the batch (shared chunks read once per group + private chunks) -- and every
+    stage of every layer is fed the oracle's own inputs for exactly those token rows.  Same one-ulp bars as above."""
+    cfg = _cfg("llama3_8b")
+    report, stages, noise = run_layer_parity(cfg, device, BENCH_LENS, monkeypatch, shared_prefix=BENCH_GEOMETRY)
+    meta = report.pop("_meta")
+    _write("llama3_8b_bench_geometry", report, stages, noise,
+           {"workload": f"4 groups x 16, 896 shared + 128..255 unique tokens in, decode contexts {meta['decode_contexts']}, "
+                        f"{cfg.num_hidden_layers} layers", "meta": meta})
+    # the radix cache and the decode plan did what the benchmark's run does
+    assert meta["radix_hit_tokens"] == [896], meta
+    assert meta["decode_plan"]["groups"] == 4 and meta["decode_plan"]["shared_kv_tokens"] == [896], meta
+    assert meta["oracle_prefix_rows_identical_across_members"], meta
+    assert any(k.endswith("prefill_warm.attention") for k in stages) and any(k.endswith("decode_fused.attention") for k in stages)
+    _assert_bars(report, stages, noise)

@@ -99,14 +99,38 @@ def test_large_nucleus_uses_global_radix_sort(device):
                                              seeds.to(device), pos.to(device), return_n_keep=True)
     want = _kept_counts(kept)
     assert all(int(n) > K.sampling_lds_keep() for n in want)
-    # the fp32 cumsum of the reference may move the top-p cut by a few ranks on a flat distribution
-    assert (n_keep.cpu() - want).abs().max() <= 4
-    same_cut = (n_keep.cpu() == want)
-    assert ids.cpu()[same_cut].tolist() == ref[same_cut].tolist()
+    # the top-p rule is the reference's own arithmetic on the sorted list (prefix sums in double rounded to fp32 as
+    # torch.cumsum does on the CPU, the fp32 subtraction and comparison of sampler.py:577-580): same cut, same ids
+    assert n_keep.cpu().tolist() == want.tolist()
+    assert ids.cpu().tolist() == ref.tolist()
     # without the workspace such rows are refused, not silently mis-sampled
     ids2 = K.top_k_top_p_min_p_sample(probs.to(device), top_ks.to(device), top_ps.to(device), None,
                                       seeds.to(device), pos.to(device), use_workspace=False)
     assert ids2.cpu().tolist() == [-1] * B
+
+
+@pytest.mark.parametrize("V,scale", [(128256, 1.0), (128256, 3.0), (50000, 0.3), (32000, 6.0)])
+def test_top_p_cut_is_the_references_own_arithmetic(device, V, scale):
+    """The cut of sampler.py:577-580 bit for bit, where it is hardest: top_p close to 1 puts the cut into the flat far tail
+    (p ~ 1e-7 .. 1e-9, well below one fp32 ulp of the prefix sum, so dozens of ranks sit inside the rounding noise of
+    the reference's cumsum and its zeroing is not even monotone in the rank), top_p = 1.0 exactly (a softmax row's fp32
+    values sum to 1 + a few 1e-7: the reference DOES zero part of the tail), small nuclei in LDS and large ones through
+    the global radix sort, with and without a top-k cut.  Kept counts and token ids must equal the oracle's."""
+    K = _k()
+    g = torch.Generator().manual_seed(V + int(scale * 10))
+    B = 12
+    probs = torch.softmax(torch.randn((B, V), generator=g) * scale, dim=-1)
+    top_ks = torch.tensor([TOP_K_ALL, TOP_K_ALL, TOP_K_ALL, TOP_K_ALL, 40000, TOP_K_ALL, 1500, TOP_K_ALL, 50, TOP_K_ALL, 3000,
+                           TOP_K_ALL], dtype=torch.int32)
+    top_ps = torch.tensor([0.999, 1.0, 0.9999, 0.99, 1.0, 0.99999, 0.999, 0.95, 1.0, 0.999999, 0.9999, 0.5])
+    seeds = torch.randint(0, 2 ** 62, (B,), generator=g)
+    pos = torch.randint(0, 4096, (B,), generator=g)
+    ref, kept, _ = oh.top_k_top_p_min_p_sampling_from_probs(probs.clone(), top_ks, top_ps, None, False, seeds, pos,
+                                                            return_kept=True)
+    ids, n_keep = K.top_k_top_p_min_p_sample(probs.to(device), top_ks.to(device), top_ps.to(device), None,
+                                             seeds.to(device), pos.to(device), return_n_keep=True)
+    assert n_keep.cpu().tolist() == _kept_counts(kept).tolist()
+    assert ids.cpu().tolist() == ref.tolist()
 
 
 def test_unfiltered_seeded_sampling_matches_oracle(device):
