@@ -1,0 +1,65 @@
+"""Where does the extend-attention kernel's rounding error come from?  (round 4: the bench-geometry layer parity shows the
+32x32 prefill kernel at rms 0.37 ulp against the fp32 oracle where torch's bf16 SDPA sits at 0.32.)
+
+One causal prefill, 4 x 1024 tokens, 32 q / 8 kv heads, D = 128, layer-0-like magnitudes; error of each evaluation
+against the fp64 softmax(QK^T)V of the same bf16 inputs, in bf16 ulps of max(|ref|, row rms):
+  kernel (32x32 two-score-set form) / the ping-pong 16x16x32 form / the general single-image form,
+  torch bf16 SDPA, and a plain-torch model of a flash kernel (P = bf16(exp(s - m)), l = sum of the fp32 exponentials)."""
+import json
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from oracle.layer_parity import ulp_stats  # noqa: E402
+from sglang_amd import kernels as K, native  # noqa: E402
+
+dev = torch.device("cuda")
+torch.manual_seed(0)
+B, T, Hq, Hkv, D = 4, 1024, 32, 8, 128
+scale = D ** -0.5
+out = {}
+for name, qs, vs in (("layer0-like", 0.8, 0.05), ("unit", 1.0, 1.0), ("peaked", 3.0, 1.0)):
+    q = (torch.randn(B * T, Hq, D, device=dev) * qs).bfloat16()
+    k = (torch.randn(B * T + 1, Hkv, D, device=dev) * qs).bfloat16()
+    v = (torch.randn(B * T + 1, Hkv, D, device=dev) * vs).bfloat16()
+    r2t = torch.zeros((B + 1, T), dtype=torch.int32, device=dev)
+    for b in range(B):
+        r2t[b + 1] = torch.arange(1 + b * T, 1 + (b + 1) * T, dtype=torch.int32, device=dev)
+    pool_idx = torch.arange(1, B + 1, device=dev)
+    seq = torch.full((B,), T, dtype=torch.int32, device=dev)
+    pre = torch.zeros((B,), dtype=torch.int32, device=dev)
+    qo = torch.arange(0, (B + 1) * T, T, dtype=torch.int32, device=dev)
+    # fp64 reference per request
+    ref = torch.empty((B * T, Hq, D), dtype=torch.float64, device=dev)
+    flash = torch.empty((B * T, Hq, D), dtype=torch.float32, device=dev)
+    sdpa = torch.empty((B * T, Hq, D), dtype=torch.bfloat16, device=dev)
+    mask = torch.tril(torch.ones(T, T, dtype=torch.bool, device=dev))
+    for b in range(B):
+        qb = q[b * T:(b + 1) * T].movedim(0, 1)                                  # [Hq, T, D]
+        kb = k[1 + b * T: 1 + (b + 1) * T].movedim(0, 1).repeat_interleave(Hq // Hkv, 0)
+        vb = v[1 + b * T: 1 + (b + 1) * T].movedim(0, 1).repeat_interleave(Hq // Hkv, 0)
+        s = (qb.double() @ kb.double().transpose(1, 2)) * scale
+        s = s.masked_fill(~mask, float("-inf"))
+        ref[b * T:(b + 1) * T] = (torch.softmax(s, -1) @ vb.double()).movedim(0, 1)
+        s32 = ((qb.float() @ kb.float().transpose(1, 2)) * scale).masked_fill(~mask, float("-inf"))
+        e = torch.exp(s32 - s32.max(-1, keepdim=True).values)
+        flash[b * T:(b + 1) * T] = ((e.bfloat16().float() @ vb.float()) / e.sum(-1, keepdim=True)).movedim(0, 1)
+        sdpa[b * T:(b + 1) * T] = torch.nn.functional.scaled_dot_product_attention(
+            qb.unsqueeze(0), kb.unsqueeze(0), vb.unsqueeze(0), scale=scale, is_causal=True).squeeze(0).movedim(0, 1)
+    refb = ref.float().bfloat16()
+    res = {"torch_sdpa_bf16": ulp_stats(sdpa, refb), "flash_model_bf16_P": ulp_stats(flash.bfloat16(), refb)}
+    for label, flags in (("kernel_32x32", 0), ("kernel_pingpong_16x16x32", 2), ("kernel_general_single_image", 1)):
+        native.lib().sgl_amd_debug_extend_attention_shape(0, flags)
+        o = torch.empty_like(q)
+        K.extend_attention(q, o, k, v, r2t, pool_idx, seq, pre, qo, T, scale)
+        torch.cuda.synchronize()
+        res[label] = ulp_stats(o, refb)
+    native.lib().sgl_amd_debug_extend_attention_shape(0, 0)
+    out[name] = {k2: {a: round(b2, 5) for a, b2 in v2.items() if a in ("rms_ulp", "frac_identical", "frac_within_1ulp", "max_ulp", "mean_signed_ulp")}
+                 for k2, v2 in res.items()}
+    for k2, v2 in out[name].items():
+        print(name, k2, v2)
+Path("gpurun_out").mkdir(exist_ok=True)
+Path("gpurun_out/r04_exp2_extend_error.json").write_text(json.dumps(out, indent=1))

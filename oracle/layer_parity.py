@@ -59,20 +59,14 @@ def _fake_fb(extend_lens=None, device=None):
     return type("FB", (), {"forward_mode": mode, "extend_seq_lens": torch.tensor(extend_lens or [0], device=device)})()
 
 
-def _rows_of(record, rows, total):
-    """The per-token tensors of a trace record ([T_total, ...]) restricted to the token rows of one product batch."""
-    if rows is None or record is None:
-        return record
-    return {k: (v[rows] if isinstance(v, torch.Tensor) and v.dim() >= 1 and v.shape[0] == total else v) for k, v in record.items()}
-
-
 def run_layer_parity(cfg, device, prompt_lens, monkeypatch, operator_surface=False, shared_prefix=None):
     """`shared_prefix` = dict(groups, per_group, prefix): the benchmark's geometry -- `groups` x `per_group` requests, the
     first `prefix` tokens of a group's prompts shared, prompt_lens[b] tokens in all.  The product then runs as the bench
     does: a COLD prefill of the group leaders, a WARM prefill of the others over the radix hit (extend over a `prefix`-token
-    prefix) and a decode step whose plan finds the groups (shared chunks + private chunks); every product batch is fed the
-    matching token rows of the oracle's one flat prefill.  Extra phase `prefill_warm` in the result keys; `report["_meta"]`
-    says what the radix cache and the decode plan did."""
+    prefix) and a decode step whose plan finds the groups (shared chunks + private chunks).  The oracle runs the same two
+    prefill passes (OracleLM.generate(share_prefix_groups=...): the others extend over the leader's slots, exactly what the
+    radix hit means), so every product batch has its own trace record.  Extra phase `prefill_warm` in the result keys;
+    `report["_meta"]` says what the radix cache and the decode plan did."""
     from sglang_amd import kernels as K
     from sglang_amd.harness import models as M
     from sglang_amd.harness.engine import Engine, ModelRunner, Req
@@ -91,21 +85,11 @@ def run_layer_parity(cfg, device, prompt_lens, monkeypatch, operator_surface=Fal
         for g in range(G):
             sys_p = [rnd.randrange(cfg.vocab_size) for _ in range(PFX)]
             prompts += [sys_p + [rnd.randrange(cfg.vocab_size) for _ in range(prompt_lens[g * P + p] - PFX)] for p in range(P)]
-    T_total = sum(prompt_lens)
-    offs = [0]
-    for n in prompt_lens:
-        offs.append(offs[-1] + n)
-
-    def rows_for(req_ids, start):
-        """Token rows (oracle's flat prefill order) of requests `req_ids` from position `start` on."""
-        return torch.cat([torch.arange(offs[b] + start, offs[b + 1], device=device) for b in req_ids])
-
-    if shared_prefix is None:
-        phases = {"prefill": None}
-    else:
+    gen_kw = {}
+    if shared_prefix is not None:
         lead = [g * P for g in range(G)]
         rest = [b for b in range(B) if b % P != 0]
-        phases = {"prefill": rows_for(lead, 0), "prefill_warm": rows_for(rest, PFX)}
+        gen_kw = dict(share_prefix_groups=[list(range(g * P, (g + 1) * P)) for g in range(G)], shared_len=PFX)
     total = sum(prompt_lens) + 4 * B + 64
     ctx = max(prompt_lens) + 16
     runner = ModelRunner(cfg, max_total_tokens=total + 1024, max_running_requests=B, max_context_len=ctx, device=device, use_graph=False)
@@ -118,9 +102,10 @@ def run_layer_parity(cfg, device, prompt_lens, monkeypatch, operator_surface=Fal
     oracle = OracleLM(cfg, weights, num_slots=total, max_ctx=ctx, max_reqs=B, device=device, compute_dtype=torch.float32)
     oracle.trace = []
     forced = [[5, 6] for _ in range(B)]
-    oracle.generate(prompts, 2, forced=forced)
-    pre, dec = oracle.trace
-    assert not pre["decode"] and dec["decode"] and len(pre["layers"]) == L
+    oracle.generate(prompts, 2, forced=forced, **gen_kw)
+    pre, dec = oracle.trace[0], oracle.trace[-1]
+    phases = {"prefill": 0} if shared_prefix is None else {"prefill": 0, "prefill_warm": 1}     # trace record of each prefill pass
+    assert len(oracle.trace) == len(phases) + 1 and not pre["decode"] and dec["decode"] and len(pre["layers"]) == L
     # ---- the reference against itself: the literal-bf16 oracle from the same per-layer inputs
     literal = OracleLM(cfg, weights, num_slots=total, max_ctx=ctx, max_reqs=B, device=device, compute_dtype=None)
     literal.trace, literal.inject = [], oracle.trace
@@ -128,33 +113,33 @@ def run_layer_parity(cfg, device, prompt_lens, monkeypatch, operator_surface=Fal
         table = {}
         for i in range(L):
             t = torch.zeros((B, ctx, cfg.num_experts_per_tok), dtype=torch.int32, device=device)
+            assert shared_prefix is None
             rows = torch.repeat_interleave(torch.arange(B, device=device), torch.tensor(prompt_lens, device=device))
             t[rows, pre["positions"]] = pre["layers"][i]["topk_ids"]
             t[torch.arange(B, device=device), dec["positions"]] = dec["layers"][i]["topk_ids"]
             table[i] = t
         literal.forced_topk_ids = table
-    literal.generate(prompts, 2, forced=forced)
+    literal.generate(prompts, 2, forced=forced, **gen_kw)
     noise = {}
-    for tag, a, b, rws in [(ph, literal.trace[0], pre, r) for ph, r in phases.items()] + [("decode", literal.trace[1], dec, None)]:
-        bfin = _rows_of({"final_normed": b["final_normed"], "final_residual": b["final_residual"]}, rws, T_total)
+    for tag, a, b in [(ph, literal.trace[k], oracle.trace[k]) for ph, k in phases.items()] + [("decode", literal.trace[-1], dec)]:
+        bfin = b
         for i in range(L):
-            la, lb = _rows_of(a["layers"][i], rws, T_total), _rows_of(b["layers"][i], rws, T_total)
+            la, lb = a["layers"][i], b["layers"][i]
             noise[f"layer{i}.{tag}.out"] = ulp_stats(la["out"], lb["out"])
             noise[f"layer{i}.{tag}.residual"] = ulp_stats(la["res_out"], lb["res_out"])
             noise[f"layer{i}.{tag}.attn"] = ulp_stats(la["attn_out"], lb["attn_out"])
             # behind the NEXT norm, where the fused decode layer ends
             wn = weights[f"layers.{i + 1}.input_layernorm.weight"] if i + 1 < L else weights["norm.weight"]
             xn, rn = oo.fused_add_rmsnorm(la["out"], la["res_out"], wn, cfg.rms_norm_eps)
-            nb = _rows_of(b["layers"][i + 1], rws, T_total) if i + 1 < L else None
+            nb = b["layers"][i + 1] if i + 1 < L else None
             noise[f"layer{i}.{tag}.next_normed"] = ulp_stats(xn, nb["normed"] if nb is not None else bfin["final_normed"])
             noise[f"layer{i}.{tag}.next_residual"] = ulp_stats(rn, nb["residual"] if nb is not None else bfin["final_residual"])
     del literal
     report, stages = {}, {}
-    state = {"rec": pre, "rows": phases["prefill"], "phase": "prefill"}
+    state = {"rec": pre, "phase": "prefill"}
 
     def layer_rec(i):
-        rec = state["rec"]
-        return _rows_of(rec["layers"][i], None if rec["decode"] else state["rows"], T_total) if i < L else None
+        return state["rec"]["layers"][i] if i < L else None
 
     def stage_checks(i, layer, positions, fb, tag):
         """Every operator group of layer i from the oracle's input of that stage."""
@@ -272,19 +257,15 @@ def run_layer_parity(cfg, device, prompt_lens, monkeypatch, operator_surface=Fal
         # as bench.py's job(): the leaders first (cold), then the rest over the radix hit (warm)
         eng.prefill([reqs[b] for b in lead])
         copy_oracle_kv(lead)                              # the warm pass attends to the ORACLE's prefix rows
-        state["rows"], state["phase"] = phases["prefill_warm"], "prefill_warm"
+        state["rec"], state["phase"] = oracle.trace[1], "prefill_warm"
         eng.prefill([reqs[b] for b in rest])
         meta["radix_hit_tokens"] = sorted(set(int(reqs[b].cached_tokens) for b in rest))
-        # the members of a group computed the same prefix rows: the oracle's copies agree bit for bit, so it does not
-        # matter whose rows end up in the shared slots below
-        so0 = oracle.req_to_token[1, :PFX].long()
-        so1 = oracle.req_to_token[2, :PFX].long()
-        meta["oracle_prefix_rows_identical_across_members"] = bool(torch.equal(oracle.k_cache[0][so0], oracle.k_cache[0][so1])
-                                                                   and torch.equal(oracle.v_cache[L - 1][so0], oracle.v_cache[L - 1][so1]))
+        # the oracle's members read the leader's prefix slots too (share_prefix_groups): one set of prefix rows per group
+        meta["oracle_shares_prefix_slots"] = bool(torch.equal(oracle.req_to_token[1, :PFX], oracle.req_to_token[2, :PFX]))
     # final norm + lm_head from the oracle's last hidden state
     hn, _ = model.norm(pre["layers"][-1]["out"].clone(), pre["layers"][-1]["res_out"].clone())
     stages["final_norm.prefill"] = ulp_stats(hn, pre["final_normed"])
-    lg = model.compute_logits(pre["final_normed"].clone(), _fake_fb(prompt_lens, device))
+    lg = model.compute_logits(pre["final_normed"].clone(), _fake_fb(prompt_lens if shared_prefix is None else [prompt_lens[b] for b in lead], device))
     stages["lm_head.prefill"] = ulp_stats(lg.next_token_logits, pre["logits"])
     # ---- decode step on the ORACLE's KV rows: copy them to the product's slots of the same (request, position)
     copy_oracle_kv(range(B))

@@ -400,10 +400,15 @@ __global__ __launch_bounds__(64 * NWV, (MTW == 1 && NWV == 4) ? (D > 64 ? 2 : 3)
 //     ds_read_b64_tr_b16 (lane i of a 16-lane group, element j <- row j, column i of the 4 x 16 block the group points
 //     at), two reads per operand: tokens 32 kk + 4 g + j and 32 kk + 16 + 4 g + j -- the token order of the P^T
 //     fragments built from the S^T accumulators.  No transposition through the VALU;
-//   * the running maximum is only raised when some row of the wave outgrows it by more than 2^8 (the rescale of the 64
-//     output accumulators is the largest VALU item of a tile); P stays below 2^8 in between, l and O carry the same factor.
+//   * the running maximum follows every tile (EXT_DEFER_MAX = 0).  Round 3 raised it only when a row outgrew it by 2^8
+//     (the rescale of the 64 output accumulators is the largest VALU item of a tile: 2.6-5.5 % of the kernel), but then
+//     the row's largest P is exp2(s - m_stale) instead of exp2(0) = 1: the dominant term of a peaked row picks up a bf16
+//     rounding error it does not have in the reference's kernels.  Against the fp64 result the deferred form measured
+//     rms 0.378 / 0.389 / 0.205 bf16 ulp (flat / unit / peaked scores) where torch's bf16 SDPA has 0.370 / 0.368 / 0.145;
+//     with the exact maximum this kernel's figures are the SDPA's to the last digit (benchmarks/r04_exp2_extend_error.py,
+//     profiles/r04_exp2_extend_error.json).
 #ifndef EXT_DEFER_MAX
-#define EXT_DEFER_MAX 8.0f
+#define EXT_DEFER_MAX 0.0f
 #endif
 constexpr float kDeferMax = EXT_DEFER_MAX;   // log2 units
 
@@ -847,7 +852,7 @@ __global__ __launch_bounds__(512, 2) void extend_attention_dbuf_kernel(ExtendPar
 //     NEIGHBOURS (two score sets, see the kernel's own header);
 //   * V image per 32 head dims: [64 tokens][64 B] (+ a bank skew between the sub-images), so that the four 16-lane groups
 //     of a transposing read cover 512 contiguous bytes;
-//   * a raised maximum (rare: kDeferMax) is applied to O and l when everything exponentiated against the old one is
+//   * a raised maximum is applied to O and l when everything exponentiated against the old one is
 //     inside them (the order the softmax-rescale hazard asks for);
 //   * the epilogue swaps 4-dim pieces between the lane halves and stores 16 bytes per lane.
 // Measured on MI355X (benchmarks/r03_exp4_extend_32x32.py, profiles/r03_exp4_extend_32x32.json): 4 x 1024 cold 62 -> 52 us, 60 x 128
@@ -1047,7 +1052,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void extend_attention_pipe_kernel(Exte
     float mx = mraw > 0.5f * kNegBig ? mraw * p.scale_log2 : kNegBig;      // a row with every key masked keeps the sentinel
     mx = lane_pair_max(mx);
     l_run += psum;
-    if (__ballot(mx > m_run + kDeferMax) != 0ull) {                         // wave-uniform; rare behind the first tiles
+    if (__ballot(mx > m_run + kDeferMax) != 0ull) {                         // wave-uniform
       const float m_new = fmaxf(m_run, mx);
       const float alpha = fast_exp2(m_run - m_new);
       m_run = m_new;

@@ -125,6 +125,6 @@ def test_layer_identical_inputs_bench_geometry(device, monkeypatch):
     # the radix cache and the decode plan did what the benchmark's run does
     assert meta["radix_hit_tokens"] == [896], meta
     assert meta["decode_plan"]["groups"] == 4 and meta["decode_plan"]["shared_kv_tokens"] == [896], meta
-    assert meta["oracle_prefix_rows_identical_across_members"], meta
+    assert meta["oracle_shares_prefix_slots"], meta
     assert any(k.endswith("prefill_warm.attention") for k in stages) and any(k.endswith("decode_fused.attention") for k in stages)
     _assert_bars(report, stages, noise)
