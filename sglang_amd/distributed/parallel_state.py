@@ -67,11 +67,13 @@ def init_distributed_environment(backend: Optional[str] = None, tp_size: Optiona
         xgmi_all_reduce = (torch.cuda.is_available() and _TP_SIZE in (2, 4, 8)
                            and os.environ.get("SGLANG_AMD_XGMI_AR", "1") != "0")
     if xgmi_all_reduce:
-        _XGMI = _start_xgmi()
+        _XGMI = start_xgmi(_TP_CPU_GROUP, _TP_GROUP, _TP_RANK, _TP_SIZE, torch.device("cuda", torch.cuda.current_device()))
 
 
-def _start_xgmi():
-    """Create the xGMI communicator and PROVE it on this node before anything depends on it: every rank runs a known
+def start_xgmi(cpu_group, device_group, rank: int, size: int, dev):
+    """`cpu_group` / `device_group`: the gloo and the RCCL process group of the SAME `size` ranks (`rank` = this process's
+    index in them) -- this package's own TP group, or the reference's GroupCoordinator.cpu_group / .device_group
+    (tp_hooks.attach).  Create the xGMI communicator and PROVE it on this node before anything depends on it: every rank runs a known
     tensor through each of its kernels (one-shot, two-stage, all-gather) and through the group's own collectives; unless all ranks see identical,
     correct results (and no flag wait gave up) the communicator is dropped on EVERY rank and RCCL carries all
     all-reduces -- the reference degrades the same way when its custom all-reduce cannot be set up
@@ -80,18 +82,17 @@ def _start_xgmi():
 
     from .xgmi_all_reduce import XgmiAllReduce
 
-    dev = torch.device("cuda", torch.cuda.current_device())
     xg, ok = None, 1
     try:
-        xg = XgmiAllReduce(_TP_CPU_GROUP, _TP_RANK, _TP_SIZE, dev)
+        xg = XgmiAllReduce(cpu_group, rank, size, dev)
     except Exception as e:                      # e.g. IPC not permitted between these devices
         warnings.warn(f"one-shot xGMI all-reduce unavailable ({type(e).__name__}: {e}); using RCCL")
         ok = 0
     flag = torch.tensor([ok], dtype=torch.int32)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=_TP_CPU_GROUP)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=cpu_group)
     if int(flag) == 1:
         try:
-            g = torch.Generator(device="cpu").manual_seed(1234 + _TP_RANK)
+            g = torch.Generator(device="cpu").manual_seed(1234 + rank)
             good = True
             # three rounds on fresh data through the SAME workspaces: a stale line of a peer's workspace (the one failure
             # the uncached mappings and the acquire fence must exclude) would show from the second round on
@@ -99,17 +100,17 @@ def _start_xgmi():
                 x = (torch.randn((64, 4096), generator=g) * 0.5).to(torch.bfloat16).to(dev)
                 mine = xg.all_reduce(x.clone())
                 ref = x.float().clone()
-                dist.all_reduce(ref, group=_TP_GROUP)                   # fp32 sum through the group's collective
+                dist.all_reduce(ref, group=device_group)                   # fp32 sum through the group's collective
                 # ... and the other two kernels the decode graph may hold (weak-scaling batches put 256 / 512 rows on a
                 # rank: two-stage all-reduce; vocab-parallel logits: all-gather), on shapes with ragged row chunks
                 y = (torch.randn((301, 1024), generator=g) * 0.5).to(torch.bfloat16).to(dev)
                 mine2 = xg.two_stage_all_reduce(y.clone())
                 ref2 = y.float().clone()
-                dist.all_reduce(ref2, group=_TP_GROUP)
+                dist.all_reduce(ref2, group=device_group)
                 z = (torch.randn((17, 256), generator=g) * 0.5).to(torch.bfloat16).to(dev)
                 mine3 = xg.all_gather(z)
-                parts = [torch.empty_like(z) for _ in range(_TP_SIZE)]
-                dist.all_gather(parts, z, group=_TP_GROUP)
+                parts = [torch.empty_like(z) for _ in range(size)]
+                dist.all_gather(parts, z, group=device_group)
                 torch.cuda.synchronize()
                 good = good and (not xg.timed_out()) and bool(((mine.float() - ref).abs() <= 2.0 ** -7 * ref.abs() + 1e-2).all()) \
                     and bool(((mine2.float() - ref2).abs() <= 2.0 ** -7 * ref2.abs() + 1e-2).all()) \
@@ -118,7 +119,7 @@ def _start_xgmi():
             warnings.warn(f"one-shot xGMI all-reduce self-test raised {type(e).__name__}: {e}")
             good = False
         flag = torch.tensor([1 if good else 0], dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=_TP_CPU_GROUP)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=cpu_group)
     if int(flag) == 1:
         # from here on an all-reduce that cannot complete must not hand back an unreduced sum: a flag wait that gives up
         # traps the kernel (the stream fails, the next sync raises on this rank; its peers time out the same way)

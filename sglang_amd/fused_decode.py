@@ -17,7 +17,7 @@ the oracle's inputs).  The functions below read the model through the attribute 
 (srt/plugins/hook_registry.py:84 register, :146 apply_hooks; HookType.AROUND) -- and on this package's harness
 models (harness/models.py), which is how bench.py measures exactly what the plug-in delivers.
 
-Everything outside this form (prefill, TP > 1, pipeline stages, quantised or biased-MLP layers, MoE, captured aux
+Everything outside this form (prefill, TP > 1 without the xGMI communicator, pipeline stages, quantised or biased-MLP layers, MoE, captured aux
 hidden states, batches the weight-streaming GEMM does not take) goes to the original forward -- the reference's own
 code -- so the hook can never change a result it does not own.
 """
@@ -82,9 +82,12 @@ def layer_fusable(layer, rows: int) -> bool:
 
 
 def decode_layer(layer, positions: torch.Tensor, normed: torch.Tensor, forward_batch, residual: torch.Tensor,
-                 next_norm) -> torch.Tensor:
+                 next_norm, comm=None) -> torch.Tensor:
     """One layer of the fused form: `normed` = this layer's input_layernorm output (row-major or chunk-major), `residual`
-    the residual stream (updated in place); returns next_norm(residual') -- chunk-major -- for the next layer / lm_head."""
+    the residual stream (updated in place); returns next_norm(residual') -- chunk-major at TP = 1 -- for the next layer /
+    lm_head.  `comm` (TP > 1): the TP group's xGMI communicator; the row-parallel projections (o_proj, down_proj:
+    linear.py RowParallelLinear, this rank's K shard) then produce partial sums and the all-reduce that follows carries
+    the residual add + RMSNorm in its epilogue -- the layer keeps its 9 launches."""
     from .layers.attention.hip_backend import pool_kernel_format
 
     attn, mlp = layer.self_attn, layer.mlp
@@ -99,27 +102,41 @@ def decode_layer(layer, positions: torch.Tensor, normed: torch.Tensor, forward_b
                                  **({} if plain else fmt))
     a = attn.attn(q, None, None, forward_batch, save_kv_cache=False)
     post = layer.post_attention_layernorm
+    blocked_act = mlp.gate_up_proj.weight.shape[0] % 256 == 0
+    if comm is not None:
+        y = kernels.wstream_gemm(a.reshape(a.shape[0], -1), attn.o_proj.weight.data)
+        x = comm.all_reduce_add_rmsnorm(y, residual, post.weight.data, post.variance_epsilon)
+        act = kernels.wstream_gemm(x, mlp.gate_up_proj.weight.data, epilogue="silu_and_mul", out_blocked=blocked_act)
+        y = kernels.wstream_gemm(act, mlp.down_proj.weight.data)
+        return comm.all_reduce_add_rmsnorm(y, residual, next_norm.weight.data, next_norm.variance_epsilon)
     x = kernels.wstream_gemm(a, attn.o_proj.weight.data, epilogue="add_rmsnorm", residual=residual, norm_weight=post.weight.data,
                              eps=post.variance_epsilon, out_blocked=True)
-    act = kernels.wstream_gemm(x, mlp.gate_up_proj.weight.data, epilogue="silu_and_mul",
-                               out_blocked=mlp.gate_up_proj.weight.shape[0] % 256 == 0)
+    act = kernels.wstream_gemm(x, mlp.gate_up_proj.weight.data, epilogue="silu_and_mul", out_blocked=blocked_act)
     return kernels.wstream_gemm(act, mlp.down_proj.weight.data, epilogue="add_rmsnorm", residual=residual,
                                 norm_weight=next_norm.weight.data, eps=next_norm.variance_epsilon, out_blocked=True)
 
 
-def decode_model(model, hidden_states: torch.Tensor, positions: torch.Tensor, forward_batch) -> torch.Tensor:
-    """The layer loop + final norm of LlamaModel.forward for a decode batch: returns norm(...) row-major [M, hidden]."""
+def decode_model(model, hidden_states: torch.Tensor, positions: torch.Tensor, forward_batch, comm=None) -> torch.Tensor:
+    """The layer loop + final norm of LlamaModel.forward for a decode batch: returns norm(...) [M, hidden] (chunk-major at
+    TP = 1: kernels.unblock)."""
     layers = model.layers
     residual = hidden_states                     # the embedding output becomes the residual stream (llama.py:349-353)
+    if comm is not None and not residual.is_contiguous():
+        residual = residual.contiguous()
     x = kernels.rmsnorm(hidden_states, layers[0].input_layernorm.weight.data, layers[0].input_layernorm.variance_epsilon)
     for i, layer in enumerate(layers):
         nxt = layers[i + 1].input_layernorm if i + 1 < len(layers) else model.norm
-        x = decode_layer(layer, positions, x, forward_batch, residual, nxt)
+        x = decode_layer(layer, positions, x, forward_batch, residual, nxt, comm)
     return x
 
 
-def model_fusable(model, hidden_states: torch.Tensor, forward_batch) -> bool:
+def model_fusable(model, hidden_states: torch.Tensor, forward_batch, comm=None) -> bool:
+    """`comm`: the TP group's communicator when TP > 1 -- the [rows, hidden] partial sums of the row-parallel projections
+    must be messages its kernels take (bf16, <= 64 MiB, hidden <= 16384 for the fused epilogue)."""
     if not (hidden_states.is_cuda and hidden_states.dtype == _BF16 and hidden_states.dim() == 2):
+        return False
+    if comm is not None and not (hidden_states.shape[1] <= 16384 and hidden_states.shape[1] % 8 == 0
+                                 and (comm.should_use(hidden_states.contiguous()) or comm.should_use_two_stage(hidden_states.contiguous()))):
         return False
     positions = getattr(forward_batch, "positions", None)
     if positions is not None and positions.dim() != 1:                 # (multimodal 3-D positions: not this form)
@@ -143,15 +160,21 @@ def model_fusable(model, hidden_states: torch.Tensor, forward_batch) -> bool:
 
 def llama_model_forward_hook(original, self, input_ids, positions, forward_batch, input_embeds=None, pp_proxy_tensors=None):
     """HookType.AROUND on LlamaModel.forward (llama.py:419-470) and Qwen2Model.forward (qwen2.py:396-448).  Decode batches
-    of a single pipeline stage at TP = 1 run the fused layer loop; anything else is the reference's own forward."""
+    of a single pipeline stage run the fused layer loop -- at TP > 1 with the TP group's xGMI all-reduce (add + RMSNorm
+    in its epilogue) behind the row-parallel projections; anything else is the reference's own forward."""
+    comm = None
     try:
         ok = _reference_model_applies(self, forward_batch, input_embeds, pp_proxy_tensors)
+        if ok:
+            tp, comm = _tp()
+            ok = tp == 1 or comm is not None         # TP > 1 without the xGMI communicator: the reference's own layer loop
+            comm = comm if tp > 1 else None
     except Exception:
         ok = False
     if ok:
         hidden_states = self.embed_tokens(input_ids)
-        if model_fusable(self, hidden_states, forward_batch):
-            return kernels.unblock(decode_model(self, hidden_states, positions, forward_batch))
+        if model_fusable(self, hidden_states, forward_batch, comm):
+            return kernels.unblock(decode_model(self, hidden_states, positions, forward_batch, comm))
     return original(self, input_ids, positions, forward_batch, input_embeds, pp_proxy_tensors)
 
 
@@ -163,23 +186,16 @@ def _reference_model_applies(model, forward_batch, input_embeds, pp_proxy_tensor
         return False
     if getattr(model, "start_layer", 0) != 0 or getattr(model, "end_layer", len(model.layers)) != len(model.layers):
         return False
-    if _tp_size() != 1:
-        return False
     mode = getattr(forward_batch, "forward_mode", None)
     return mode is not None and mode.is_decode()
 
 
-def _tp_size() -> int:
-    """The reference's tensor-parallel degree (srt/runtime_context.py get_parallel().tp_size) when running under it,
-    else this package's own process group."""
-    try:
-        from sglang.srt.runtime_context import get_parallel
+def _tp():
+    """(tensor-parallel degree, the TP group's xGMI communicator or None): the reference's TP group when running under it
+    (tp_hooks.attach built its communicator inside GroupCoordinator.__init__), else this package's own process group."""
+    from . import tp_hooks
 
-        return int(get_parallel().tp_size)
-    except Exception:
-        from .distributed import parallel_state as ps
-
-        return ps.get_tensor_model_parallel_world_size()
+    return tp_hooks.tp_communicator()
 
 
 # model classes whose forward is the loop above (same signature, same attribute names; Mistral and the other Llama-style

@@ -308,6 +308,11 @@ class LlamaDecoderLayer(nn.Module):
             # the very function plugin.load() hooks onto the reference's LlamaModel.forward: what bench.py times IS what
             # the plug-in delivers under unchanged reference model classes
             return fused_decode.decode_layer(self, positions, normed, forward_batch, residual, next_norm)
+        xg = ps.get_xgmi_all_reduce()
+        if xg is not None and fused_decode.layer_fusable(self, normed.shape[1] if normed.dim() == 3 else normed.shape[0]):
+            # TP > 1, decode batches the weight-streaming GEMM takes: the plug-in's own layer function with the TP
+            # group's communicator (what fused_decode.llama_model_forward_hook runs under the reference at TP > 1)
+            return fused_decode.decode_layer(self, positions, normed, forward_batch, residual, next_norm, xg)
         x = self.self_attn(positions, normed, forward_batch, fused_norm=(residual, self.post_attention_layernorm))
         return self.mlp.forward_fused_norm(x, residual, next_norm, ps.get_tensor_model_parallel_world_size())
 

@@ -78,6 +78,14 @@ def load() -> None:
     if not any(h is fused_decode.llama_model_forward_hook for t in fused_decode.HOOK_TARGETS for _, h, _ in HookRegistry._hooks.get(t, [])):
         fused_decode.install(HookRegistry, HookType.AROUND)
 
+    # ---- TP > 1: the reference's own groups carry the xGMI collectives (tp_hooks.py) -----------------------------
+    # AROUND hooks on GroupCoordinator.__init__ (communicator set-up from the group's own gloo / RCCL groups, proved by
+    # the start-up self-test or dropped on every rank), .all_reduce (parallel_state.py:648-758), .fused_allreduce_rmsnorm
+    # (:774-833, the add + RMSNorm epilogue) and .all_gather (:1273, the vocab-parallel logits).
+    from . import tp_hooks
+
+    tp_hooks.install(HookRegistry, HookType.AROUND)
+
 
 def _sampler_factory():
     """The factory must return a subclass of the reference Sampler (sampler.py:553-557): the gfx950 forward on

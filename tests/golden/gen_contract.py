@@ -49,6 +49,9 @@ WANT = {
     "sglang/srt/models/qwen2.py": ["Qwen2Model", "Qwen2DecoderLayer", "Qwen2Attention", "Qwen2MLP"],
     "sglang/srt/layers/quantization/unquant.py": ["UnquantizedLinearMethod"],
     "sglang/srt/runtime_context.py": ["get_parallel"],
+    "sglang/srt/distributed/parallel_state.py": ["GroupCoordinator", "get_tp_group"],
+    "sglang/srt/distributed/communication_op.py": ["tensor_model_parallel_all_reduce", "tensor_model_parallel_fused_allreduce_rmsnorm",
+                                                   "tensor_model_parallel_all_gather"],
 }
 # sgl_kernel functional namespace (kernels/aot/python/sgl_kernel)
 KERNEL_NS = {
