@@ -264,6 +264,88 @@ def _case_all(rank, world, ps, dist):
     return 0
 
 
+def _case_stress(rank, world, ps, dist):
+    """thousands of iterations of the three collectives under hipGraph replay, fresh data every iteration
+    (a stale line of a peer's workspace -- the failure the write-through stores, the flag protocol and the acquire fence
+    must exclude -- shows as a wrong sum), random host-side skew between the ranks' launches, every word checked on the
+    device.  Inputs are small integers, so every sum is exact in bf16 and the expected tensors have a closed form."""
+    import random
+    import time
+
+    from sglang_amd.distributed.xgmi_all_reduce import XgmiAllReduce
+
+    dev = torch.device("cuda", 0)
+    xg = ps.get_xgmi_all_reduce()
+    # (processes sharing ONE GPU are time-sliced by the driver: ~7 ms per iteration at two ranks, far more at eight -- the
+    # counts are sized for the lease, SGL_AMD_STRESS_ITERS raises them on a real node)
+    iters = int(os.environ.get("SGL_AMD_STRESS_ITERS", "10000" if world <= 2 else "600"))
+    shapes = {"one_shot": (64, 4096), "two_stage": (512, 1024), "gather": (16, 256)}
+    it = torch.zeros((), dtype=torch.int64, device=dev)            # the iteration counter lives on the device: part of the graph
+    bad = torch.zeros((), dtype=torch.int64, device=dev)
+    idx = {k: torch.arange(r * c, device=dev).view(r, c) for k, (r, c) in shapes.items()}
+
+    def value(k, r, step):                                          # rank r's input of iteration `step`: integers in [-6, 6]
+        return (((idx[k] + 17 * r + 31 * step) % 13) - 6).to(torch.bfloat16)
+
+    def body():
+        a = xg.all_reduce(value("one_shot", rank, it))
+        b = xg.two_stage_all_reduce(value("two_stage", rank, it))
+        c = xg.all_gather(value("gather", rank, it))
+        want_a = sum(value("one_shot", r, it).float() for r in range(world)).to(torch.bfloat16)
+        want_b = sum(value("two_stage", r, it).float() for r in range(world)).to(torch.bfloat16)
+        want_c = torch.cat([value("gather", r, it) for r in range(world)], dim=1)
+        bad.add_((a != want_a).sum() + (b != want_b).sum() + (c != want_c).sum())
+        it.add_(1)
+
+    def run(n, label):
+        body()
+        torch.cuda.synchronize(); dist.barrier()
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            with torch.cuda.graph(g, stream=s):
+                body()
+        torch.cuda.current_stream().wait_stream(s)
+        rnd = random.Random(1000 * rank + len(label))
+        t0 = time.perf_counter()
+        for i in range(n):
+            if rnd.random() < 0.05:                                 # a rank that falls behind: its peers wait in the flag barrier
+                time.sleep(rnd.random() * 3e-4)
+            g.replay()
+            if i % 512 == 511:
+                torch.cuda.synchronize()                            # bounded queue depth; also desynchronises the ranks again
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert not xg.timed_out(), f"{label}: a flag wait gave up"
+        assert int(bad) == 0, f"{label}: {int(bad)} wrong words after {int(it)} iterations"
+        dist.barrier()
+        return dt / n * 1e6
+
+    us = run(iters, "write-through protocol")
+    # the fallback protocol (system-scope release fence ahead of every flag) is captured into a fresh graph
+    XgmiAllReduce.set_release_fence(True)
+    try:
+        us_fence = run(max(100, iters // 10), "release-fence fallback")
+    finally:
+        XgmiAllReduce.set_release_fence(False)
+    return {"iterations": int(it), "us_per_iteration": us, "us_per_iteration_release_fence": us_fence}
+
+
+def test_stress_two_processes_graph_replay_fresh_data_random_skew(device):
+    res = _run("stress", world=2, timeout=420)
+    print(f"\n[xgmi stress, 2 ranks on one GPU] {res[0]}")
+    assert res[0]["iterations"] >= 10000
+
+
+def test_stress_eight_processes_graph_replay_fresh_data_random_skew(device):
+    """The TP = 8 communicator (seven peers per rank, two-stage ownership over eight ranks) under the same stress; all eight
+    processes share the one GPU of the lease, so what is exercised is the protocol (flags, ordering, stale data), not the wire."""
+    res = _run("stress", world=8, timeout=400)
+    print(f"\n[xgmi stress, 8 ranks on one GPU] {res[0]}")
+    assert res[0]["iterations"] >= 600
+
+
 def test_world_of_eight_processes_one_gpu(device):
     """The TP=8 communicator of configs[2] (eight ranks, seven peers each: flag rows, rank order of the sums, chunk
     ownership k % 8, the armed timeout trap) with all eight processes on the one GPU of the lease: every case above,
