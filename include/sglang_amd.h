@@ -471,6 +471,15 @@ int sgl_amd_moe_tiled_gemm(const void* a, const void* w, void* c, const int32_t*
                            int round_before_scale, int top_k_div, int64_t num_valid_ids, int64_t N, int64_t K,
                            int64_t a_row_stride, int64_t w_row_stride, int64_t w_expert_stride, int64_t c_row_stride,
                            int64_t max_m_blocks, int fuse_silu, int out_f32, void* stream);
+/* The same with the row geometry spelled out: `align_block_m` = the moe_align_block_size block the metadata was built with
+ * (128 or 256), `tile_rows` = rows of one expert per workgroup tile (128: the form above, also over a 256-row alignment;
+ * 256: the 256 x 256 x 64 form -- 8 waves, 128 x 64 outputs per wave, two 64 KiB LDS-DMA stages, one barrier per K step,
+ * XCD-patched workgroup order -- for experts that own a thousand rows or more; needs align_block_m == 256). */
+int sgl_amd_moe_tiled_gemm_ex(const void* a, const void* w, void* c, const int32_t* sorted_token_ids, const int32_t* expert_ids,
+                              const int32_t* num_tokens_post_padded, const float* topk_weights, int mul_routed_weight,
+                              int round_before_scale, int top_k_div, int64_t num_valid_ids, int64_t N, int64_t K,
+                              int64_t a_row_stride, int64_t w_row_stride, int64_t w_expert_stride, int64_t c_row_stride,
+                              int64_t max_m_blocks, int fuse_silu, int out_f32, int align_block_m, int tile_rows, void* stream);
 
 #ifdef __cplusplus
 }

@@ -817,11 +817,13 @@ def moe_tiled_gemm_block_m() -> int:
 def moe_tiled_gemm(a: torch.Tensor, w: torch.Tensor, c: torch.Tensor, sorted_token_ids: torch.Tensor,
                    expert_ids: torch.Tensor, num_tokens_post_padded: torch.Tensor, topk_weights: Optional[torch.Tensor],
                    mul_routed_weight: bool, top_k_div: int, num_valid_ids: int, block_m: int, fuse_silu: bool = False,
-                   round_before_scale: bool = False) -> torch.Tensor:
-    """moe_grouped_gemm on the row-tiled MFMA kernel (prefill-sized batches): block_m must be
-    moe_tiled_gemm_block_m(); a [rows, K] bf16, w [E, N(or 2N), K] bf16, c [num_valid_ids, N] bf16 or fp32."""
+                   round_before_scale: bool = False, tile_rows: Optional[int] = None) -> torch.Tensor:
+    """moe_grouped_gemm on the row-tiled MFMA kernels (prefill-sized batches): block_m = the align block size (128 or
+    256), tile_rows = rows of an expert per workgroup tile (128, or 256 over a 256 alignment: the 256 x 256 x 64 form);
+    a [rows, K] bf16, w [E, N(or 2N), K] bf16, c [num_valid_ids, N] bf16 or fp32."""
     _dev(a, w, c, sorted_token_ids, expert_ids, num_tokens_post_padded)
-    _need(block_m == moe_tiled_gemm_block_m(), "moe_tiled_gemm: the align block size must be moe_tiled_gemm_block_m()")
+    tile_rows = block_m if tile_rows is None else tile_rows
+    _need(block_m in (128, 256) and tile_rows in (128, 256) and tile_rows <= block_m, "moe_tiled_gemm: block_m / tile_rows in (128, 256)")
     _need(a.dtype == _BF16 and w.dtype == _BF16 and w.dim() == 3 and c.dtype in (_BF16, torch.float32) and c.dim() == 2,
           "moe_tiled_gemm: bf16 a / w[E,N,K], c bf16 / fp32")
     _need(sorted_token_ids.dtype == torch.int32 and expert_ids.dtype == torch.int32
@@ -835,14 +837,30 @@ def moe_tiled_gemm(a: torch.Tensor, w: torch.Tensor, c: torch.Tensor, sorted_tok
     if mul_routed_weight:
         _need(topk_weights is not None and topk_weights.dtype == torch.float32 and topk_weights.is_contiguous(),
               "moe_tiled_gemm: fp32 topk_weights")
-    native.call("sgl_amd_moe_tiled_gemm", a.data_ptr(), w.data_ptr(), c.data_ptr(), sorted_token_ids.data_ptr(),
+    native.call("sgl_amd_moe_tiled_gemm_ex", a.data_ptr(), w.data_ptr(), c.data_ptr(), sorted_token_ids.data_ptr(),
                 expert_ids.data_ptr(), num_tokens_post_padded.data_ptr(), _ptr(topk_weights), 1 if mul_routed_weight else 0,
                 1 if round_before_scale else 0, top_k_div, num_valid_ids, N, K, a.stride(0), w.stride(1), w.stride(0),
-                c.stride(0), max_m_blocks, 1 if fuse_silu else 0, 1 if c.dtype == torch.float32 else 0, _stream())
+                c.stride(0), max_m_blocks, 1 if fuse_silu else 0, 1 if c.dtype == torch.float32 else 0, int(block_m), int(tile_rows),
+                _stream())
     return c
 
 
+MOE_TILE_OVERRIDE = None                # tests / benchmarks: (align block, up tile rows, down tile rows)
 MOE_TILED_MIN_ROWS_PER_EXPERT = 96     # above this an expert fills most of a 128-row tile: the MFMA-bound form wins
+MOE_TILE256_MIN_ROWS_PER_EXPERT = 768  # above this the 256-row alignment's padding (128 rows per expert on average) is
+                                       # worth the 256 x 256 x 64 form's rate
+
+
+def moe_tile_plan(numel: int, num_experts: int, n_up: int, n_down: int):
+    """(align block, tile rows of the up projection, tile rows of the down projection) for a prefill-sized batch of
+    `numel` (token, k) pairs: the 256 x 256 x 64 form once an expert owns enough rows that the 256-row alignment's padding
+    (128 rows per expert on average) costs less than the form gains (measured on Mixtral's shapes, 4096 tokens = 1024 rows
+    per expert: up projection 977 vs 714 TF/s, down projection 820-870 vs 715 with its 2.25 rounds of workgroups;
+    profiles/r04_exp4_moe_gemm_ab.json)."""
+    rows = numel // max(1, num_experts)
+    if rows < MOE_TILE256_MIN_ROWS_PER_EXPERT:
+        return 128, 128, 128
+    return 256, 256, 256
 
 
 def moe_grouped_gemm(a: torch.Tensor, w: torch.Tensor, c: torch.Tensor, sorted_token_ids: torch.Tensor,
@@ -959,14 +977,17 @@ def fused_experts(hidden_states: torch.Tensor, w13: torch.Tensor, w2: torch.Tens
     if M == 0:
         return out
     if numel // E >= MOE_TILED_MIN_ROWS_PER_EXPERT and K % 64 == 0 and N % 64 == 0:
-        # prefill-sized batch: 128-row MFMA tiles, every expert's weights read once per 128 of its rows
-        block_m = moe_tiled_gemm_block_m()
+        # prefill-sized batch: row-tiled MFMA kernels, every expert's weights read once per 128 / 256 of its rows
+        block_m, up_rows, down_rows = moe_tile_plan(numel, E, N, K) if K % 64 == 0 else (128, 128, 128)
+        if MOE_TILE_OVERRIDE is not None:
+            block_m, up_rows, down_rows = MOE_TILE_OVERRIDE
         sorted_ids, expert_ids, post = moe_align_block_size(topk_ids, block_m, E)
         inter = torch.empty((numel, N), dtype=_BF16, device=dev)
-        moe_tiled_gemm(hidden_states, w13, inter, sorted_ids, expert_ids, post, None, False, topk, numel, block_m, fuse_silu=True)
+        moe_tiled_gemm(hidden_states, w13, inter, sorted_ids, expert_ids, post, None, False, topk, numel, block_m, fuse_silu=True,
+                       tile_rows=up_rows)
         down = torch.empty((numel, K), dtype=torch.float32, device=dev)
         moe_tiled_gemm(inter, w2, down, sorted_ids, expert_ids, post, topk_weights.reshape(-1).contiguous(), True, 1, numel,
-                       block_m, round_before_scale=True)
+                       block_m, round_before_scale=True, tile_rows=down_rows)
         moe_sum_reduce(down.view(M, topk, K), out, routed_scaling_factor)
         return out
     block_m = choose_moe_block_m(numel, E)

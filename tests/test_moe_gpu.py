@@ -262,6 +262,37 @@ def test_fused_experts_prefill_sized_batches_take_the_tiled_form(device, M, E, k
     _moe_check(out.cpu(), want.cpu())
 
 
+@pytest.mark.parametrize("plan", [(256, 256, 256), (256, 256, 128), (256, 128, 128)])
+@pytest.mark.parametrize("M,E,k,N,Kd", [(4096, 8, 2, 7168, 4096), (3000, 4, 2, 448, 320), (1100, 2, 1, 1024, 1024)])
+def test_fused_experts_256_row_tiles(device, monkeypatch, plan, M, E, k, N, Kd):
+    """The 256 x 256 x 64 form (moe_gemm256_kernel: 8 waves, two LDS-DMA stages, XCD-patched order) for the up projection
+    (silu epilogue), the down projection (router weight, fp32), or -- over the same 256-row alignment -- the 128-row tiles;
+    (4096, 8, 2, 7168, 4096) is one TP=2 rank of Mixtral-8x7B, the others have ragged column tiles, K = 5 steps and a
+    last row block that is mostly padding.  Same bars as the 128-row form, and the forms agree to one ulp."""
+    K = _k()
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn((M, Kd), generator=g).to(BF).to(device)
+    w13 = (torch.randn((E, 2 * N, Kd), generator=g) * 0.03).to(BF).to(device)
+    w2 = (torch.randn((E, Kd, N), generator=g) * 0.03).to(BF).to(device)
+    logits = torch.randn((M, E), generator=g).to(device)
+    tw, ti = oo.fused_topk(logits, k, True)
+    monkeypatch.setattr(K, "MOE_TILE_OVERRIDE", plan)
+    out = K.fused_experts(x, w13, w2, tw, ti)
+    want = oo.moe_forward(x, w13, w2, tw, ti)
+    _moe_check(out.cpu(), want.cpu())
+    monkeypatch.setattr(K, "MOE_TILE_OVERRIDE", (128, 128, 128))
+    base = K.fused_experts(x, w13, w2, tw, ti)
+    d = (out.float() - base.float()).abs()
+    assert float((d > 2.0 ** -7 * base.float().abs() + 1e-3).float().mean()) < 1e-3, float(d.max())
+
+
+def test_moe_tile_plan_policy():
+    K = _k()
+    assert K.moe_tile_plan(2 * 512, 8, 7168, 4096) == (128, 128, 128)                  # 128 rows per expert: the 128-row form
+    assert K.moe_tile_plan(2 * 2048, 8, 14336, 4096) == (128, 128, 128)                 # 512 rows: padding to 256 costs too much
+    assert K.moe_tile_plan(2 * 4096, 8, 14336, 4096) == (256, 256, 256)                 # Mixtral prefill: 1024 rows per expert
+
+
 def test_tiled_grouped_gemm_row_gather_and_scale(device):
     """The tiled grouped GEMM alone vs a per-pair loop: gather a[id // topk], scatter to c[id], router weight, ragged
     expert loads incl. an expert with no rows, N not a multiple of the tile."""
