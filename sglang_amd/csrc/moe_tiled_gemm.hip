@@ -228,6 +228,9 @@ __global__ __launch_bounds__(kThreads, 2) void moe_tiled_gemm_kernel(TiledParams
 #ifndef MOE256_ROTATE
 #define MOE256_ROTATE 0
 #endif
+#ifndef MOE256_GM
+#define MOE256_GM 8
+#endif
 #ifndef MOE256_PIN
 #define MOE256_PIN 1
 #endif
@@ -254,14 +257,15 @@ constexpr int kThreads2 = 512;
 __global__ __launch_bounds__(kThreads2, 1) void moe_gemm256_kernel(TiledParams p) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * kStage2];
   // ---- workgroup -> (row block, column tile).  Workgroups go to the XCDs round robin by their linear index; XCD x takes
-  // the patches x, x + 8, ... of 32 workgroups = 4 row blocks x 8 column tiles, consecutive patches walk the column
+  // the patches x, x + 8, ... of 32 workgroups = GM (8) row blocks x GN (4) column tiles (8 x 4 measured 1-4 % ahead of 4 x 8 and 16 x 2, 20 % ahead of 1 x 32: profiles/r04_exp4_moe_gemm_ab.json), consecutive patches walk the column
   // tiles of one group of row blocks (the eight XCDs then work on the same token rows: one copy in the memory-side cache).
   const int id = blockIdx.x;
   const int patch = (id >> 8) * 8 + (id & 7);
   const int within = (id >> 3) & 31;
-  const int npn = p.n_tiles >> 3;                      // column patches (n_tiles is padded to a multiple of 8 by the host)
-  const int rb = (patch / npn) * 4 + (within & 3);
-  const int nt0 = (patch % npn) * 8 + (within >> 2);
+  constexpr int GM = MOE256_GM, GN = 32 / GM;          // row blocks x column tiles of a patch
+  const int npn = p.n_tiles / GN;                      // column patches (n_tiles is padded to a multiple of GN by the host)
+  const int rb = (patch / npn) * GM + (within % GM);
+  const int nt0 = (patch % npn) * GN + (within / GM);
   if (rb * kT2 >= p.num_post_pad[0]) return;
   const int e = p.expert_ids[rb];
   if (e < 0) return;
@@ -521,8 +525,9 @@ int sgl_amd_moe_tiled_gemm_ex(const void* a, const void* w, void* c, const int32
   if (tile_rows == 256) {
     // one-dimensional grid of patches: 4 row blocks x 8 column tiles each, eight patches (one per XCD) per 256 workgroups
     const int cols = fuse_silu ? 128 : 256;
-    const int64_t nt = ((N + cols - 1) / cols + 7) / 8 * 8;
-    const int64_t patches = ((max_m_blocks + 3) / 4) * (nt / 8);
+    constexpr int GM = MOE256_GM, GN = 32 / GM;
+    const int64_t nt = ((N + cols - 1) / cols + GN - 1) / GN * GN;
+    const int64_t patches = ((max_m_blocks + GM - 1) / GM) * (nt / GN);
     const int64_t wgs = (patches + 7) / 8 * 256;
     SGL_CHECK_ARG(wgs <= 0x7fffffffLL, "moe_tiled_gemm: too many tiles");
     p.n_tiles = static_cast<int>(nt);
