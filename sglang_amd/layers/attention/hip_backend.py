@@ -125,6 +125,7 @@ class HipAttnBackend(AttentionBackend):
         self._graph_ws = {}
         self._cascade_ws = None
         self._cascade_in_graph = False
+        self._seq_i32, self._seq_src, self._seq_i32_in_graph = None, None, False
         self.debug_flags = 0
         # RadixAttention batches share KV prefixes; the cascade decode path reads a shared prefix once per group
         # (`model_runner.enable_cascade_attention = False` keeps every batch on the plain paged decode kernel)
@@ -160,15 +161,37 @@ class HipAttnBackend(AttentionBackend):
         """Pre-allocate the split workspaces for the largest bucket (reference :159)."""
         splits = choose_num_splits(1, self.num_kv_heads, self.num_q_heads // self.num_kv_heads, self.max_context_len)
         self._workspace(max_bs, max(splits, 1))
+        if self._seq_i32 is None or self._seq_i32.numel() < max_bs:
+            self._seq_i32 = torch.zeros(max(max_bs, 256), dtype=torch.int32, device=self.device)
         if self.enable_cascade and max_bs >= 2:
             self._cascade_workspace(min(max_bs, 1024))
 
     def get_cuda_graph_seq_len_fill_value(self):
         return 1
 
+    def _seq_lens_i32(self, fb):
+        """int32 view of the batch's seq_lens for the kernels.  The reference's batches carry int64 seq_lens
+        (schedule_batch.py): the conversion then goes through a PERSISTENT buffer that init_forward_metadata_in_graph
+        fills -- inside the decode graph, so a replay converts the step's own lengths (a `.to(int32)` here, outside the
+        graph, would leave the captured kernels reading the capture-time copy)."""
+        if fb.seq_lens.dtype == torch.int32:
+            return fb.seq_lens, None
+        bs = fb.seq_lens.numel()
+        buf = self._seq_i32
+        if buf is None or buf.numel() < bs:
+            if buf is not None and self._seq_i32_in_graph:
+                raise RuntimeError(f"seq_lens buffer holds {buf.numel()} requests and is referenced by captured graphs; "
+                                   f"a batch of {bs} needs init_cuda_graph_state(max_bs >= {bs})")
+            buf = self._seq_i32 = torch.zeros(max(bs, 256), dtype=torch.int32, device=self.device)
+        return buf[:bs], fb.seq_lens
+
     def init_forward_metadata_out_graph(self, forward_batch, in_capture: bool = False):
         fb = forward_batch
-        seq_i32 = fb.seq_lens if fb.seq_lens.dtype == torch.int32 else fb.seq_lens.to(torch.int32)
+        if fb.forward_mode.is_decode():
+            seq_i32, self._seq_src = self._seq_lens_i32(fb)
+            self._seq_i32_in_graph |= in_capture and self._seq_src is not None
+        else:
+            seq_i32, self._seq_src = (fb.seq_lens if fb.seq_lens.dtype == torch.int32 else fb.seq_lens.to(torch.int32)), None
         if fb.forward_mode.is_decode():
             if in_capture:
                 max_len = self.max_context_len       # the graph must be valid for any later length
@@ -207,6 +230,8 @@ class HipAttnBackend(AttentionBackend):
         """Device-only, static-shape work recorded into the decode graph: the shared-prefix plan of
         this step (one launch per step, reused by every layer).  The plain decode kernel needs nothing."""
         m = self.forward_metadata
+        if m is not None and self._seq_src is not None and forward_batch.forward_mode.is_decode():
+            m.seq_lens_i32.copy_(forward_batch.seq_lens)         # int64 -> int32, recorded into the graph
         if m is not None and m.cascade is not None and forward_batch.forward_mode.is_decode():
             kernels.cascade_plan(m.cascade, self.req_to_token_pool.req_to_token, self._pool_idx(forward_batch),
                                  m.seq_lens_i32, self.num_q_heads, self.num_kv_heads)
@@ -240,9 +265,9 @@ class HipAttnBackend(AttentionBackend):
         m = self.forward_metadata
         q3 = q.view(-1, layer.tp_q_head_num, layer.qk_head_dim)
         o = torch.empty(q3.shape, dtype=q3.dtype, device=q3.device)
-        from ..radix_attention import AttentionType
-
-        causal = not (layer.is_cross_attention or layer.attn_type == AttentionType.ENCODER_ONLY)
+        # (compared by VALUE: under sglang `layer` is the reference's RadixAttention and attn_type a member of the reference's
+        # own AttentionType enum, radix_attention.py:58-66 -- another class than this package's look-alike)
+        causal = not (layer.is_cross_attention or getattr(layer.attn_type, "value", layer.attn_type) == "encoder_only")
         opt = self._layer_options(layer)
         # speculative-decoding verify / tree attention (triton_backend.py:860-919): spec_info carries the flat mask
         spec = getattr(forward_batch, "spec_info", None)

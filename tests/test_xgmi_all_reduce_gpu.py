@@ -278,7 +278,7 @@ def _case_stress(rank, world, ps, dist):
     xg = ps.get_xgmi_all_reduce()
     # (processes sharing ONE GPU are time-sliced by the driver: ~7 ms per iteration at two ranks, far more at eight -- the
     # counts are sized for the lease, SGL_AMD_STRESS_ITERS raises them on a real node)
-    iters = int(os.environ.get("SGL_AMD_STRESS_ITERS", "10000" if world <= 2 else "600"))
+    iters = int(os.environ.get("SGL_AMD_STRESS_ITERS", "10000" if world <= 2 else "200"))
     shapes = {"one_shot": (64, 4096), "two_stage": (512, 1024), "gather": (16, 256)}
     it = torch.zeros((), dtype=torch.int64, device=dev)            # the iteration counter lives on the device: part of the graph
     bad = torch.zeros((), dtype=torch.int64, device=dev)
@@ -326,7 +326,7 @@ def _case_stress(rank, world, ps, dist):
     # the fallback protocol (system-scope release fence ahead of every flag) is captured into a fresh graph
     XgmiAllReduce.set_release_fence(True)
     try:
-        us_fence = run(max(100, iters // 10), "release-fence fallback")
+        us_fence = run(max(20, iters // 10), "release-fence fallback")
     finally:
         XgmiAllReduce.set_release_fence(False)
     return {"iterations": int(it), "us_per_iteration": us, "us_per_iteration_release_fence": us_fence}
@@ -343,7 +343,7 @@ def test_stress_eight_processes_graph_replay_fresh_data_random_skew(device):
     processes share the one GPU of the lease, so what is exercised is the protocol (flags, ordering, stale data), not the wire."""
     res = _run("stress", world=8, timeout=400)
     print(f"\n[xgmi stress, 8 ranks on one GPU] {res[0]}")
-    assert res[0]["iterations"] >= 600
+    assert res[0]["iterations"] >= 200
 
 
 def test_world_of_eight_processes_one_gpu(device):
