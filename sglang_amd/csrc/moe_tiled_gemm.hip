@@ -228,6 +228,9 @@ __global__ __launch_bounds__(kThreads, 2) void moe_tiled_gemm_kernel(TiledParams
 #ifndef MOE256_ROTATE
 #define MOE256_ROTATE 0
 #endif
+#ifndef MOE256_L2_AHEAD
+#define MOE256_L2_AHEAD 0
+#endif
 #ifndef MOE256_GM
 #define MOE256_GM 8
 #endif
@@ -402,15 +405,56 @@ __global__ __launch_bounds__(kThreads2, 1) void moe_gemm256_kernel(TiledParams p
   }
 
 #else
-  // (experiment switch MOE256_ROTATE=0: the plain form -- issue the next step's tiles, read and multiply this step's,
-  // wait, barrier)
+  // The plain form: issue the next step's tiles, read and multiply this step's, wait, barrier.
+  // MOE256_L2_AHEAD (experiment, default 0 = off; measured 5-7 % SLOWER at 1 / 2 / 3 steps ahead, so first-touch latency is
+  // not what the walk waits for -- profiles/r04_exp4_moe_gemm_ab.json): a step's tiles have ONE step to get from wherever they live into LDS -- and a weight
+  // or token row contributes one new 128-byte line per step, 8 KiB behind the previous one, so every line's first touch
+  // pays the full HBM / memory-side-cache latency inside that one step.  One extra 4-byte load per wave and step touches
+  // the 64 lines (32 weight rows, 32 token rows: the rows this wave's LDS-DMA moves) that the DMA of `AHEAD` steps later
+  // will ask for, so that they wait in L2 by then; its result is never used, only kept alive until the counted wait
+  // of the next step has certainly retired it.
   const int nk = p.K / kBK;
+#if MOE256_L2_AHEAD
+  const uint16_t* pf_row;
+  {
+    const int prow = wid * 32 + (lane & 31);             // the rows (wid * 4 + u) * 8 + dr of this wave's DMA
+    if (lane < 32) {
+      int wrow;
+      if (p.fuse_silu) {
+        const int half = prow >> 7, in = prow & 127;
+        const int col = nt0 * 128 + half * 64 + (in & 63);
+        wrow = (in < 64 ? 0 : p.N) + (col < p.N ? col : p.N - 1);
+      } else {
+        const int col = nt0 * 256 + prow;
+        wrow = col < p.N ? col : p.N - 1;
+      }
+      pf_row = wbase + static_cast<int64_t>(wrow) * p.w_row_stride;
+    } else {
+      const int sid = p.sorted_ids[rb * kT2 + prow];
+      pf_row = p.a + static_cast<int64_t>(sid < p.num_valid ? sid / p.topk_div : 0) * p.a_stride;
+    }
+  }
+  uint32_t pf_prev = 0, pf_cur = 0;
+  auto touch = [&](int kt) {
+    uint32_t v;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(pf_row + static_cast<int64_t>(kt) * kBK) : "memory");
+    return v;
+  };
+  if (MOE256_L2_AHEAD < nk) pf_cur = touch(MOE256_L2_AHEAD);      // (step 1's lines are asked for by the DMA right below)
+#endif
   issue(0, 0);
   wait_vm<0>();
   __builtin_amdgcn_s_barrier();
   for (int kt = 0; kt < nk; ++kt) {
     const int stage = kt & 1;
     if (kt + 1 < nk) MOE256_ISSUE(kt + 1, stage ^ 1);
+#if MOE256_L2_AHEAD
+    pf_prev = pf_cur;
+    {
+      const int ahead = kt + 1 + MOE256_L2_AHEAD < nk ? kt + 1 + MOE256_L2_AHEAD : nk - 1;   // (clamped: re-touches a resident line)
+      pf_cur = touch(ahead);
+    }
+#endif
     const uint32_t base = sm_addr + stage * kStage2;
     u32x4_t wf[2][4], xf[2][4];
     read_w(base, 0, 0, wf[0]);
@@ -430,9 +474,18 @@ __global__ __launch_bounds__(kThreads2, 1) void moe_gemm256_kernel(TiledParams p
     MOE256_PINNED();
     wait_lgkm<0>();
     products(1, wf[1], xf[1]);
+#if MOE256_L2_AHEAD
+    wait_vm<1>();                                      // in order: everything older than this step's touch, i.e. the DMA of step kt + 1
+    asm volatile("" ::"v"(pf_prev));                   // the touch of the step before has certainly returned: its register is free
+#else
     wait_vm<0>();
+#endif
     __builtin_amdgcn_s_barrier();
   }
+#if MOE256_L2_AHEAD
+  wait_vm<0>();
+  asm volatile("" ::"v"(pf_cur));
+#endif
 
 #endif
   // ---- epilogue: lane holds C^T[n = 16 i + 4 g + r][m = 16 j + r16] ----
