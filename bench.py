@@ -54,7 +54,7 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_PEAK_TFLOPS = 2500.0     # bf16 dense
-PMC_FILE = ROOT / "profiles" / "r03_pmc.json"
+PMC_FILE = ROOT / "profiles" / "r04_pmc.json"
 PMC_NAME = "profiles/" + PMC_FILE.name
 
 
@@ -69,7 +69,7 @@ def build_prompts(cfg, groups, per_group, prefix, unique, seed=1):
 
 
 def load_pmc():
-    """profiles/r03_pmc.json (benchmarks/summarize_pmc_phases.py over the rocprofv3 --pmc passes of
+    """profiles/r04_pmc.json (benchmarks/summarize_pmc_phases.py over the rocprofv3 --pmc passes of
     benchmarks/pmc_workload.py): {"stamp": {"sources": {file: sha}}, "phases": {phase: {"kernels": {name: {"dispatches",
     counter: avg, ...}}}}}.  A record without a stamp is not quoted at all."""
     if not PMC_FILE.exists():
