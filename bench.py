@@ -579,7 +579,10 @@ def kernel_rooflines(args, cfg, runner, result, B, G, P, in_len, ctx, t_decode_s
         twp, tip = K.topk_softmax(torch.randn((Mp, cfg.num_local_experts), device=dev), cfg.num_experts_per_tok, True)
         t_p = graph_time(lambda: K.fused_experts(xp, moes[0].w13_weight.data, moes[0].w2_weight.data, twp, tip), 1, reps=3)
         fl = Mp * cfg.num_experts_per_tok * 3 * (N2 // 2) * Kd * 2
-        result["moe_prefill_mfma"] = {"kernel": "moe_tiled_gemm_kernel (128 x 128 MFMA tiles) x 2 + moe_sum_reduce", "M": Mp,
+        plan = K.moe_tile_plan(Mp * cfg.num_experts_per_tok, cfg.num_local_experts, N2 // 2, Kd)
+        result["moe_prefill_mfma"] = {"kernel": ("moe_gemm256_kernel (256 x 256 x 64 tiles)" if plan[1] == 256 else
+                                                 "moe_tiled_gemm_kernel (128 x 128 tiles)") + " x 2 + moe_align + moe_sum_reduce",
+                                      "tile_plan(align, up rows, down rows)": list(plan), "M": Mp,
                                       "ms": t_p * 1e3, "achieved": fl / t_p / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                       "frac": fl / t_p / 1e12 / MFMA_PEAK_TFLOPS}
 

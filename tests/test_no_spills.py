@@ -71,3 +71,20 @@ def test_general_extend_kernels_do_not_spill(tmp_path):
     assert len(gen) == 12, sorted(usage)                        # head dim {64, 128} x {41, 42, 82} x {bf16, fp8}
     for name, u in gen.items():
         assert u["vgpr_spill_count"] == 0 and u["sgpr_spill_count"] == 0, (name, u)
+
+
+@pytest.mark.skipif(not Path(HIPCC).exists(), reason="hipcc not installed")
+def test_moe_256_tile_kernel_keeps_its_registers_and_lds(tmp_path):
+    """moe_gemm256_kernel runs two waves per SIMD in one workgroup per CU: 128 accumulator registers + two fragment sets
+    (64) + the eight LDS-DMA row pointers at ~213; a spill would sit between the products.  LDS = two 64 KiB stages."""
+    usage = _resource_usage("moe_tiled_gemm.hip", tmp_path)
+    k256 = {k: v for k, v in usage.items() if "moe_gemm256_kernel" in k}
+    assert len(k256) == 1, sorted(usage)
+    for name, u in k256.items():
+        assert u["vgpr_spill_count"] == 0 and u["sgpr_spill_count"] == 0, (name, u)
+        assert u["vgpr_count"] <= 256, (name, u)
+        assert u["group_segment_fixed_size"] == 128 * 1024, (name, u)
+    k128 = {k: v for k, v in usage.items() if "moe_tiled_gemm_kernel" in k}
+    assert len(k128) == 1
+    for name, u in k128.items():
+        assert u["vgpr_spill_count"] == 0 and u["sgpr_spill_count"] == 0 and u["vgpr_count"] <= 128, (name, u)   # two workgroups per CU
