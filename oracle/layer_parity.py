@@ -36,7 +36,12 @@ def ulp_stats(got: torch.Tensor, ref: torch.Tensor) -> dict:
     rms = r2.pow(2).mean(-1, keepdim=True).sqrt()
     e = (g2 - r2) / bf16_ulp(torch.maximum(r2.abs(), rms))
     a = e.abs()
+    # the same in the plain unit -- the bf16 ulp of the reference value itself, no floor at the row's rms -- reported beside
+    # the floored figures so that the floor's effect can be read off (elements that cancel towards zero carry the
+    # absolute noise of the sum they came from and count as many "plain" ulps in ANY evaluation, the reference's own too)
+    ap = ((g2 - r2) / bf16_ulp(r2)).abs()
     return dict(n=int(a.numel()), frac_identical=float((g2 == r2).float().mean()), frac_within_1ulp=float((a <= 1).float().mean()),
+                frac_within_1ulp_plain_unit=float((ap <= 1).float().mean()), frac_within_2ulp_plain_unit=float((ap <= 2).float().mean()),
                 frac_within_2ulp=float((a <= 2).float().mean()), max_ulp=float(a.max()), mean_signed_ulp=float(e.mean()),
                 rms_ulp=float(e.pow(2).mean().sqrt()), max_abs=float((g2 - r2).abs().max()), ref_rms=float(r2.pow(2).mean().sqrt()))
 
