@@ -27,14 +27,17 @@ from ...mem_cache.memory_pool import KVWriteLoc, _host_scale
 from .base_attn_backend import AttentionBackend
 
 
-def _kv_write_loc(loc):
-    """The pool's own KVWriteLoc type: the reference pool under sglang (memory_pool.py:1550-1575), ours otherwise."""
-    try:
-        from sglang.srt.mem_cache.memory_pool import KVWriteLoc as Ref
+def _kv_write_loc(pool, loc):
+    """The POOL's own KVWriteLoc type: the reference's for a reference pool (memory_pool.py:1550-1575), ours for ours --
+    decided by whose class the pool is, not by whether `sglang` happens to be importable in the process."""
+    if type(pool).__module__.startswith("sglang."):
+        try:
+            from sglang.srt.mem_cache.memory_pool import KVWriteLoc as Ref
 
-        return Ref(loc, None)
-    except Exception:
-        return KVWriteLoc(loc, None)
+            return Ref(loc, None)
+        except Exception:
+            pass
+    return KVWriteLoc(loc, None)
 
 
 @dataclass
@@ -126,6 +129,7 @@ class HipAttnBackend(AttentionBackend):
         self._cascade_ws = None
         self._cascade_in_graph = False
         self._seq_i32, self._seq_src, self._seq_i32_in_graph = None, None, False
+        self._verify_states, self._verify_nd = {}, 0
         self.debug_flags = 0
         # RadixAttention batches share KV prefixes; the cascade decode path reads a shared prefix once per group
         # (`model_runner.enable_cascade_attention = False` keeps every batch on the plain paged decode kernel)
@@ -185,6 +189,16 @@ class HipAttnBackend(AttentionBackend):
             buf = self._seq_i32 = torch.zeros(max(bs, 256), dtype=torch.int32, device=self.device)
         return buf[:bs], fb.seq_lens
 
+    def _verify_state(self, bs: int, nd: int):
+        st = self._verify_states.get((bs, nd))
+        if st is None:
+            dev = self.device
+            st = self._verify_states[(bs, nd)] = dict(
+                qo=torch.arange(0, (bs + 1) * nd, nd, dtype=torch.int32, device=dev), pre=torch.zeros(bs, dtype=torch.int32, device=dev),
+                kv=torch.zeros(bs, dtype=torch.int32, device=dev), kv64=torch.zeros(bs, dtype=torch.int64, device=dev),
+                mip=torch.zeros(bs + 1, dtype=torch.int64, device=dev))
+        return st
+
     def init_forward_metadata_out_graph(self, forward_batch, in_capture: bool = False):
         fb = forward_batch
         if fb.forward_mode.is_decode():
@@ -207,15 +221,14 @@ class HipAttnBackend(AttentionBackend):
         elif getattr(fb.forward_mode, "is_target_verify", lambda: False)():
             # triton_backend.py:860-919: every request extends by `draft_token_num` tokens over its whole context
             # (forward_batch.seq_lens = the context BEFORE the draft tokens), qo_indptr = arange * draft_token_num, the
-            # mask block of request b holds draft_token_num x (seq_len + draft_token_num) entries
+            # mask block of request b holds draft_token_num x (seq_len + draft_token_num) entries.  Every tensor lives in a
+            # per-(batch, draft tokens) state that persists, and the length-dependent ones are filled by
+            # init_forward_metadata_in_graph: a captured verify graph then recomputes them from the step's own seq_lens.
             nd = int(getattr(fb.spec_info, "draft_token_num"))
-            bs = fb.batch_size
-            qo = torch.arange(0, (bs + 1) * nd, nd, dtype=torch.int32, device=self.device)
-            kv_i32 = seq_i32 + nd
-            sizes = nd * kv_i32.to(torch.int64)
-            mip = torch.zeros(bs + 1, dtype=torch.int64, device=self.device)
-            mip[1:] = torch.cumsum(sizes, 0)
-            self.forward_metadata = _Meta(kv_i32, qo_indptr=qo, prefix_lens_i32=seq_i32, max_extend_len=nd, mask_indptr=mip)
+            st = self._verify_state(fb.batch_size, nd)
+            self._seq_src = fb.seq_lens
+            self.forward_metadata = _Meta(st["kv"], qo_indptr=st["qo"], prefix_lens_i32=st["pre"], max_extend_len=nd, mask_indptr=st["mip"])
+            self._verify_nd = nd
         elif fb.forward_mode.is_extend():
             ext = fb.extend_seq_lens_cpu
             qo = torch.zeros(fb.batch_size + 1, dtype=torch.int32)
@@ -230,6 +243,14 @@ class HipAttnBackend(AttentionBackend):
         """Device-only, static-shape work recorded into the decode graph: the shared-prefix plan of
         this step (one launch per step, reused by every layer).  The plain decode kernel needs nothing."""
         m = self.forward_metadata
+        if m is not None and getattr(forward_batch.forward_mode, "is_target_verify", lambda: False)():
+            st = self._verify_state(forward_batch.batch_size, self._verify_nd)
+            st["pre"].copy_(forward_batch.seq_lens)              # context before the draft tokens
+            torch.add(st["pre"], self._verify_nd, out=st["kv"])  # context incl. the draft tokens
+            st["kv64"].copy_(st["kv"])
+            st["kv64"].mul_(self._verify_nd)                     # mask entries per request
+            torch.cumsum(st["kv64"], 0, out=st["mip"][1:])
+            return
         if m is not None and self._seq_src is not None and forward_batch.forward_mode.is_decode():
             m.seq_lens_i32.copy_(forward_batch.seq_lens)         # int64 -> int32, recorded into the graph
         if m is not None and m.cascade is not None and forward_batch.forward_mode.is_decode():
@@ -238,7 +259,7 @@ class HipAttnBackend(AttentionBackend):
 
     # ------------------------------------------------------------------ forward
     def _save_kv(self, layer, forward_batch, k, v):
-        self.token_to_kv_pool.set_kv_buffer(layer, _kv_write_loc(forward_batch.out_cache_loc), k, v)
+        self.token_to_kv_pool.set_kv_buffer(layer, _kv_write_loc(self.token_to_kv_pool, forward_batch.out_cache_loc), k, v)
 
     @staticmethod
     def _pool_idx(forward_batch):

@@ -72,14 +72,18 @@ class TopK(nn.Module):
             return native(hidden_states, router_logits, num_token_non_padded=num_token_non_padded,
                           expert_location_dispatch_info=expert_location_dispatch_info)
         w, ids = fused_topk(hidden_states, router_logits, c.top_k, c.renormalize)
-        return _standard_output_cls()(w, ids, router_logits)
+        return _standard_output_cls(self)(w, ids, router_logits)
 
 
-def _standard_output_cls():
-    """Under sglang the reference's own StandardTopKOutput (the dispatcher checks its type: topk.py:238-260)."""
-    try:
-        from sglang.srt.layers.moe.topk import StandardTopKOutput as Ref
+def _standard_output_cls(op=None):
+    """Bound to a REFERENCE TopK instance (plugin.load() registers this forward on the reference's class) the result is the
+    reference's own StandardTopKOutput (its dispatcher checks the type: topk.py:238-260); this package's own modules get
+    this package's class.  Decided by whose instance `op` is, not by whether `sglang` happens to be importable."""
+    if op is not None and type(op).__module__.startswith("sglang."):
+        try:
+            from sglang.srt.layers.moe.topk import StandardTopKOutput as Ref
 
-        return Ref
-    except Exception:
-        return StandardTopKOutput
+            return Ref
+        except Exception:
+            pass
+    return StandardTopKOutput

@@ -42,8 +42,8 @@ class KVWriteLoc:
 
 
 def unwrap_write_loc(loc_info):
-    if isinstance(loc_info, KVWriteLoc):
-        return loc_info.loc, loc_info.swa_loc, None
+    if isinstance(loc_info, KVWriteLoc) or (not isinstance(loc_info, torch.Tensor) and hasattr(loc_info, "loc")):
+        return loc_info.loc, getattr(loc_info, "swa_loc", None), None       # (any KVWriteLoc-shaped record, the reference's too)
     return loc_info, None, None
 
 
