@@ -85,7 +85,9 @@ def test_tp2_sharded_model_matches_tp1(name):
         p.join(timeout=60)
     assert status == "ok", worst
     # bf16 partial sums are added in a different order under TP (two bf16 halves vs one fp32 sum)
-    assert worst < 6e-2, worst
+    # (measured 0.0059-0.0078 on all four models = one bf16 ulp of a logit of magnitude ~1; the bar is two of them -- the
+    # 6e-2 of earlier rounds was 8x looser than the data)
+    assert worst <= 2 * 2.0 ** -7, worst
 
 
 def test_single_process_defaults():
