@@ -86,6 +86,12 @@ def load() -> None:
 
     tp_hooks.install(HookRegistry, HookType.AROUND)
 
+    # ---- decode-sized unquantised projections of every model (linear_hook.py): UnquantizedLinearMethod.apply
+    # (quantization/unquant.py:243-293) streams the weights through wstream_gemm for batches of <= 64 (128) rows ----------
+    from . import linear_hook
+
+    linear_hook.install(HookRegistry, HookType.AROUND)
+
 
 def _sampler_factory():
     """The factory must return a subclass of the reference Sampler (sampler.py:553-557): the gfx950 forward on

@@ -85,3 +85,41 @@ def test_hook_takes_the_fused_branch_and_matches_the_operator_loop(device, monke
     # within one ulp, 99.94 % within two at the 8B shapes)
     assert st["frac_identical"] >= 0.95 and st["frac_within_1ulp"] >= 0.99 and st["frac_within_2ulp"] >= 0.998 and st["max_ulp"] <= 8.0, st
     eng.finish(list(eng.running))
+
+
+def test_linear_hook_streams_decode_sized_projections_and_leaves_the_rest(device):
+    """The AROUND hook on UnquantizedLinearMethod.apply (sglang_amd/linear_hook.py): decode-sized bf16 projections -- with
+    and without a bias, 2-D and 3-D inputs -- run the weight-streaming GEMM (the reference's method is not entered) and
+    equal F.linear to one bf16 ulp; a prefill-sized batch and an fp32 input reach the reference's method."""
+    from sglang_amd import linear_hook
+
+    g = torch.Generator().manual_seed(21)
+    called = []
+
+    def original(self, layer, x, bias=None):
+        called.append(x.shape)
+        return torch.nn.functional.linear(x, layer.weight, bias)
+
+    for N, K in ((6144, 4096), (4096, 1024), (1536, 896)):
+        w = torch.nn.Parameter((torch.randn((N, K), generator=g) * 0.02).to(BF).to(device), requires_grad=False)
+        layer = types.SimpleNamespace(weight=w)
+        b = (torch.randn(N, generator=g) * 0.1).to(BF).to(device)
+        for shape, bias in (((64, K), None), ((5, K), b), ((2, 7, K), None)):
+            x = torch.randn(shape, generator=g).to(BF).to(device)
+            n = len(called)
+            got = linear_hook.unquant_apply_hook(original, None, layer, x, bias)
+            assert len(called) == n, "the reference's method was entered for a decode-sized projection"
+            # (fp64 on the host: an fp32 GEMM on the device loads another library for one comparison)
+            want = torch.nn.functional.linear(x.double().cpu(), w.double().cpu(), bias.double().cpu() if bias is not None else None)
+            assert got.shape == want.shape
+            err = (got.double().cpu() - want).abs()
+            assert float((err > 2.0 ** -8 * want.abs() + 1e-3).float().mean()) == 0.0, float(err.max())
+        big = torch.randn((512, K), generator=g).to(BF).to(device)
+        n = len(called)
+        linear_hook.unquant_apply_hook(original, None, layer, big)
+        assert len(called) == n + 1                                       # prefill-sized: the library GEMM
+    x32 = torch.randn((4, 896), generator=g).to(device)
+    w32 = types.SimpleNamespace(weight=torch.nn.Parameter(torch.randn((1536, 896), generator=g).to(device), requires_grad=False))
+    n = len(called)
+    linear_hook.unquant_apply_hook(original, None, w32, x32)
+    assert len(called) == n + 1

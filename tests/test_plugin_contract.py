@@ -663,6 +663,49 @@ def test_tp_hooks_are_registered_on_the_group_coordinator_and_route_only_what_th
     hr.HookRegistry.reset()
 
 
+def test_linear_hook_is_registered_on_the_unquantized_method_and_falls_through(fake_sglang):
+    """Models without a model-level hook (Mixtral's attention, any other dense architecture) get the weight-streaming GEMM
+    for their decode-sized projections through an AROUND hook on UnquantizedLinearMethod.apply (unquant.py:243-293): bound
+    to the reference's parameter list; CPU tensors, prefill-sized batches, other dtypes and subclassed weights reach the
+    reference's own method with the original arguments.  The streamed branch: tests/test_model_hook_gpu.py."""
+    import inspect
+
+    from sglang_amd import linear_hook, plugin
+
+    g = fake_sglang
+    plugin.load()
+    hr = g["sglang.srt.plugins.hook_registry"]
+    assert [(ht.name, h) for ht, h, _ in hr.HookRegistry._hooks[linear_hook.HOOK_TARGET]] == [("AROUND", linear_hook.unquant_apply_hook)]
+    ref_ps = ref("sglang.srt.layers.quantization.unquant", "UnquantizedLinearMethod")["methods"]["apply"]["params"]
+    ours = list(inspect.signature(linear_hook.unquant_apply_hook).parameters.values())
+    assert [p.name for p in ours] == ["original"] + [p["name"] for p in ref_ps]
+    assert [p.default is not inspect.Parameter.empty for p in ours[1:]] == [p["default"] for p in ref_ps]
+    ULM = g["sglang.srt.layers.quantization.unquant"].UnquantizedLinearMethod
+    calls = []
+    ULM.apply = lambda self, layer, x, bias=None: calls.append((layer, x, bias)) or "reference-linear"
+    hr.HookRegistry.apply_hooks()
+    m = ULM.__new__(ULM)
+    layer = types.SimpleNamespace(weight=torch.nn.Parameter(torch.zeros((256, 128), dtype=torch.bfloat16), requires_grad=False))
+    x = torch.zeros((4, 128), dtype=torch.bfloat16)
+    assert m.apply(layer, x) == "reference-linear" and calls[-1][1] is x                  # CPU tensors
+    assert m.apply(layer, x, torch.zeros(256, dtype=torch.bfloat16)) == "reference-linear" and calls[-1][2] is not None
+    # the predicate itself, with the device check out of the way: only what the kernel's tiling takes
+    import unittest.mock as um
+
+    gpu = lambda t: um.patch.object(type(t), "is_cuda", property(lambda self: True))   # noqa: E731
+    with gpu(x):
+        w = layer.weight
+        assert linear_hook.takes(x, w, None)                                          # 4 rows, N = 256, K = 128
+        assert linear_hook.takes(torch.zeros((2, 3, 128), dtype=torch.bfloat16), w, None)   # leading dims flatten
+        assert not linear_hook.takes(torch.zeros((4096, 128), dtype=torch.bfloat16), w, None)      # prefill-sized: the library GEMM
+        assert not linear_hook.takes(x.float(), w, None) and not linear_hook.takes(x, w.float(), None)
+        assert not linear_hook.takes(x, torch.zeros((250, 128), dtype=torch.bfloat16), None)       # N % 16
+        assert not linear_hook.takes(torch.zeros((4, 96), dtype=torch.bfloat16), torch.zeros((256, 96), dtype=torch.bfloat16), None)   # K % 128
+        assert not linear_hook.takes(x, w, torch.zeros(256))                            # fp32 bias
+        assert not linear_hook.takes(x[:, ::1].t().t()[:, :], torch.zeros((256, 256), dtype=torch.bfloat16)[:, ::2], None)   # strided weight
+    hr.HookRegistry.reset()
+
+
 def test_runner_config_and_quant_info_fields_the_moe_hook_reads_exist():
     cfg_fields = [f["name"] for f in ref("sglang.srt.layers.moe.moe_runner.base", "MoeRunnerConfig")["fields"]]
     for f in ("activation", "is_gated", "inplace", "no_combine", "routed_scaling_factor", "apply_router_weight_on_input"):
