@@ -201,7 +201,8 @@ struct WsParams {
   int topk_div;                 // source row of pair id = id / topk_div
   int out_f32;                  // y is fp32 (the down projection ahead of moe_sum_reduce)
   int round_before_scale;       // round the accumulator to bf16 before the router weight (fused_moe_native.py:157-163)
-  int pair_silu;                // two-tile waves: y[:, 16 t ..] = silu(tile t) * tile (t + ntiles/2) instead of two outputs
+  int pair_silu;                // 1: two-tile waves, y[:, 16 t ..] = silu(tile t) * tile (t + ntiles/2) instead of two outputs;
+                                // 2: one-tile waves whose 16 weight rows are [8 gate rows | 8 up rows] of output columns 8 t .. 8 t + 7
 };
 
 // ---- LDS-DMA plumbing ------------------------------------------------------------------------
@@ -255,8 +256,12 @@ constexpr int ring_depth(int mt, int nw, int tpw) {
 }
 
 // TPW = 16-row weight tiles per wave.  TPW == 2: the wave owns tiles t and t + ntiles/2 (half the activation reads
-// per weight byte); with pair_silu they are a gate tile and its up tile and the wave writes
+// per weight byte); with pair_silu == 1 they are a gate tile and its up tile and the wave writes
 // y[m, 16 t ..] = silu(gate) * up (no partials, no second launch).
+// pair_silu == 2 (TPW == 1, round 4): a wave's ONE tile is made of 8 gate rows and the 8 up rows of the same output
+// columns, so any number of waves per workgroup keeps gate and up together: N / 16 tiles can then be dealt out in whole
+// rounds of 256 workgroups where N / 32 pairs cannot (Llama-3-8B gate_up: 1792 tiles = 256 x 7 waves, against 896 pairs =
+// 224 x 4 waves: 32 CUs idle).  Gate and up of a column sit 32 lanes apart in the accumulator: one lane swap in the epilogue.
 template <int MT, int NW, int TPW, bool GROUPED>
 __global__ __launch_bounds__(64 * NW, 1) void wstream_gemm_kernel(WsParams p) {
   constexpr int PD = ring_depth(MT, NW, TPW);
@@ -301,8 +306,10 @@ __global__ __launch_bounds__(64 * NW, 1) void wstream_gemm_kernel(WsParams p) {
 #pragma unroll
     for (int j = 0; j < kKSteps; ++j) {
       const int row = 4 * j + q4;
-      wsrc[t][j] = wbase + (static_cast<int64_t>((active ? tile : wtiles - 1) + t * wtiles) * 16 + row) * p.w_stride +
-                   ((s16 ^ row) & 15) * 8 + static_cast<int64_t>(cb) * kKC;
+      const int64_t tl = active ? tile : wtiles - 1;
+      const int64_t wrow = (TPW == 1 && p.pair_silu == 2) ? (row < 8 ? 0 : p.N / 2) + tl * 8 + (row & 7)
+                                                          : (tl + static_cast<int64_t>(t) * wtiles) * 16 + row;
+      wsrc[t][j] = wbase + wrow * p.w_stride + ((s16 ^ row) & 15) * 8 + static_cast<int64_t>(cb) * kKC;
     }
   const uint16_t* xsrc[XP];
   int xoff[XP];                                          // wave-uniform LDS offset inside a ring slot
@@ -490,6 +497,20 @@ __global__ __launch_bounds__(64 * NW, 1) void wstream_gemm_kernel(WsParams p) {
         *reinterpret_cast<uint2*>(p.y + blocked_off(m, nn, p.y_stride, p.y_cstride)) = w2;
       }
     };
+    if (TPW == 1 && !GROUPED && p.pair_silu == 2) {
+      // lanes g = 0, 1 hold the gate values of columns 8 tile + 4 g + r, lanes g = 2, 3 the up values of the same columns
+      float o[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float mine = acc[0][mt][r];
+        const float other = __shfl_xor(mine, 32, 64);
+        const float gb = rbf(g < 2 ? mine : other);
+        const float sl = rbf(gb / (1.0f + expf(-gb)));
+        o[r] = sl * rbf(g < 2 ? other : mine);
+      }
+      if (g < 2) put(o, tile * 8 + g * 4, false);
+      continue;
+    }
     if (TPW == 2 && p.pair_silu) {
       // linear -> bf16, silu -> bf16, product -> bf16 (activation.py:141-143)
       float o[4];
@@ -730,8 +751,10 @@ static int wstream_launch_main(const char* who, const void* x, const void* w, co
                 "%s: need N %% 16 == 0 and K %% %d == 0 (got N=%lld K=%lld)", who, kKC, (long long)N, (long long)K);
   SGL_CHECK_ARG(x_row_stride % 8 == 0 && w_row_stride % 8 == 0 && y_row_stride % 4 == 0,
                 "%s: row strides must keep 16-byte (x, w) / 8-byte (y) alignment", who);
-  const bool two_tiles = fused_silu || tiles_per_wave == 2;
-  SGL_CHECK_ARG(tiles_per_wave == 1 || tiles_per_wave == 2, "%s: tiles_per_wave must be 1 or 2", who);
+  // the fused silu epilogue has two forms: two tiles per wave (gate tile + up tile), or -- tiles_per_wave == 1 -- one tile of
+  // 8 gate + 8 up rows per wave
+  const bool two_tiles = (fused_silu && tiles_per_wave != 1) || tiles_per_wave == 2;
+  SGL_CHECK_ARG(tiles_per_wave == 0 || tiles_per_wave == 1 || tiles_per_wave == 2, "%s: tiles_per_wave must be 1 or 2 (0: the default of the form)", who);
   SGL_CHECK_ARG(!two_tiles || N % 32 == 0, "%s: two tiles per wave need N %% 32 == 0", who);
   SGL_CHECK_ARG(two_tiles ? (waves_per_group >= 2 && waves_per_group <= 4) : (waves_per_group >= 4 && waves_per_group <= 8),
                 "%s: waves_per_group must be 4..8 (2..4 with two tiles per wave), got %d", who, waves_per_group);
@@ -750,7 +773,7 @@ static int wstream_launch_main(const char* who, const void* x, const void* w, co
   p.y_cstride = y_chunk_stride ? y_chunk_stride : 128;
   p.M = static_cast<int>(M); p.N = static_cast<int>(N); p.K = static_cast<int>(K);
   p.splits = num_k_splits; p.ntiles = static_cast<int>(N / 16);
-  p.pair_silu = fused_silu ? 1 : 0;
+  p.pair_silu = fused_silu ? (two_tiles ? 1 : 2) : 0;
   int rc;
   switch (static_cast<int>((M + 15) / 16)) {
     case 1: rc = launch_nw<1>(p, waves_per_group, two_tiles, st); break;
@@ -772,7 +795,8 @@ int sgl_amd_wstream_gemm(const void* x, const void* w, const void* bias, void* y
   SGL_CLEAR_STALE_ERROR();
   if (M == 0) return 0;
   SGL_CHECK_ARG(epilogue >= 0 && epilogue <= 2, "wstream_gemm: epilogue must be 0 (bias), 1 (silu_and_mul) or 2 (add_rmsnorm)");
-  const bool fused_silu = epilogue == 1 && num_k_splits == 1 && N % 32 == 0 && !bias;   // silu(gate)*up in the GEMM's own epilogue
+  // silu(gate)*up in the GEMM's own epilogue: two tiles per wave (N % 32 == 0) or one interleaved tile (tiles_per_wave == 1, N % 16 == 0)
+  const bool fused_silu = epilogue == 1 && num_k_splits == 1 && !bias && (tiles_per_wave == 1 ? N % 16 == 0 : N % 32 == 0);
   const bool combine = !fused_silu && (num_k_splits > 1 || epilogue != 0);
   SGL_CHECK_ARG(epilogue != 1 || N % 8 == 0, "wstream_gemm: silu_and_mul needs N %% 8 == 0");
   SGL_CHECK_ARG(epilogue != 1 || !bias, "wstream_gemm: the silu_and_mul epilogue takes no bias");

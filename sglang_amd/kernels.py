@@ -607,6 +607,13 @@ def wstream_supported(M: int, N: int, K: int) -> bool:
     return 0 < M <= 128 and N % 16 == 0 and K % 128 == 0 and K >= 128
 
 
+# the one-tile (8 gate + 8 up rows per wave) form of the fused silu epilogue: whole rounds of 256 workgroups for Llama-3's gate_up
+# (256 x 7 waves instead of 224 x 4).  Measured EQUAL to the two-tile form (8B 39.8 vs 39.5 us, 70B 160.1 vs 162.5, M = 16 37.6 vs
+# 38.4: profiles/r04_exp6_gateup_interleaved.json) -- the stream sits at the chip's ~6.0 TB/s either way, the 32 idle CUs were not
+# the bound -- so the policy keeps the two-tile form; the kernel form stays selectable (tiles_per_wave = 1) and tested.
+WSTREAM_SILU_INTERLEAVED = False
+
+
 @functools.lru_cache(maxsize=None)
 def wstream_preferred(M: int, N: int, K: int) -> bool:
     """Policy on top of wstream_supported(): up to 64 rows the weight stream always beats the library GEMM
@@ -670,10 +677,6 @@ def choose_wstream_decomposition(M: int, N: int, K: int, need_combine: bool = Fa
     byte: lm_head 200 -> 174 us, the unfused gate_up 39.6 -> 39.1 (benchmarks/gemm_sweep.py --blocked).  With split-K
     the two-tile forms measured no faster (down 27.8 vs 27.5 us), so those keep one tile per wave."""
     nw, s = choose_wstream_config(M, N, K, need_combine, fused_silu)
-    if fused_silu:
-        return nw, 2, s
-    if s != 1 or M > 64 or N % 32 != 0:
-        return nw, 1, s
     nch = K // 128
 
     def rounds_time(groups: int, wg_bytes: int, chip: float, per_cu: float) -> float:
@@ -682,6 +685,21 @@ def choose_wstream_decomposition(M: int, N: int, K: int, need_combine: bool = Fa
         if rem:
             t += rem * wg_bytes / min(chip, rem * per_cu)
         return t
+
+    if fused_silu:
+        # two forms of the silu epilogue: (nw, 2) = every wave a gate tile + its up tile (N / 32 pairs to deal out), or
+        # (nw, 1) = every wave ONE tile of 8 gate + 8 up rows (N / 16 tiles).  The second one exists for the widths whose pairs
+        # do not make whole rounds of the chip: Llama-3-8B gate_up has 896 pairs = 224 workgroups of 4 waves (32 CUs idle)
+        # but 1792 tiles = 256 workgroups of 7 waves (measured equal: see WSTREAM_SILU_INTERLEAVED)
+        best = (rounds_time((N // 32 + nw - 1) // nw, nw * nch * 8192, 6.0e12, 26e9), nw, 2)
+        if WSTREAM_SILU_INTERLEAVED and M <= 64 and N % 16 == 0:
+            for nw1 in (8, 7, 6, 5, 4):
+                t1 = rounds_time((N // 16 + nw1 - 1) // nw1, nw1 * nch * 4096, 6.4e12, 26e9)
+                if t1 < best[0] * 0.97:
+                    best = (t1, nw1, 1)
+        return best[1], best[2], s
+    if s != 1 or M > 64 or N % 32 != 0:
+        return nw, 1, s
 
     one = rounds_time((N // 16 + nw - 1) // nw, nw * nch * 4096, 5.3e12, 24e9)
     best = (one, nw, 1)
@@ -717,15 +735,15 @@ def wstream_gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] 
     tpw_auto = 1
     if waves_per_group is None or splits is None:
         # silu_and_mul: one pass with two tiles per wave when the caller does not force a split
-        one_pass = ep == 1 and splits in (None, 1) and N % 32 == 0 and bias is None
+        one_pass = ep == 1 and splits in (None, 1) and (N % 32 == 0 or (tiles_per_wave == 1 and N % 16 == 0)) and bias is None
         if waves_per_group is None and splits is None and tiles_per_wave is None:
             nw_auto, tpw_auto, s_auto = choose_wstream_decomposition(M, N, K, ep != 0, one_pass)
         else:
             nw_auto, s_auto = choose_wstream_config(M, N, K, ep != 0, one_pass)
     nw = waves_per_group or nw_auto
     s = splits or s_auto
-    one_pass = ep == 1 and s == 1 and N % 32 == 0 and bias is None
-    tpw = 2 if one_pass else (tiles_per_wave or tpw_auto)
+    one_pass = ep == 1 and s == 1 and (N % 32 == 0 or (tiles_per_wave == 1 and N % 16 == 0)) and bias is None
+    tpw = (tiles_per_wave or (tpw_auto if (waves_per_group is None and splits is None) else 2)) if one_pass else (tiles_per_wave or tpw_auto)
     ws = _gemm_workspace(x.device, native.lib().sgl_amd_wstream_gemm_workspace_floats(M, N, s)) if ((s > 1 or ep) and not one_pass) else None
     native.call("sgl_amd_wstream_gemm", x.data_ptr(), w.data_ptr(), _ptr(bias), out.data_ptr(), M, N, K, x_rs, x_cs,
                 w.stride(0), y_rs, y_cs, ep, _ptr(residual), residual.stride(0) if residual is not None else 0,

@@ -50,6 +50,16 @@ def test_wstream_decomposition_on_the_bench_shapes():
     assert K.choose_wstream_decomposition(64, 128256, 4096) == (4, 2, 1)      # lm_head: 200 -> 174 us
     assert K.choose_wstream_decomposition(64, 4096, 14336)[1] == 1            # split-K shapes: one tile per wave
     assert K.choose_wstream_decomposition(64, 28672, 4096, True, True) == (4, 2, 1)
+    # the one-tile interleaved silu form (256 x 7 waves for Llama-3's gate_up) measured equal to the two-tile one: selectable,
+    # not the default (kernels.WSTREAM_SILU_INTERLEAVED)
+    import unittest.mock as um
+
+    with um.patch.object(K, "WSTREAM_SILU_INTERLEAVED", True):
+        K.choose_wstream_decomposition.cache_clear()
+        assert K.choose_wstream_decomposition(64, 28672, 4096, True, True) == (7, 1, 1)
+        assert K.choose_wstream_decomposition(64, 57344, 8192, True, True) == (7, 1, 1)
+        assert K.choose_wstream_decomposition(64, 14336, 4096, True, True)[1] == 2
+    K.choose_wstream_decomposition.cache_clear()
 
 
 def test_wstream_row_policy():

@@ -128,6 +128,36 @@ def test_wstream_rejects_unsupported_shapes(device):
         K_.wstream_gemm(x[:4, :200], w[:, :200])
 
 
+@pytest.mark.parametrize("M", [1, 20, 50, 64])
+@pytest.mark.parametrize("I,K,nw", [(14336, 4096, 7), (14336, 4096, None), (28672, 8192, 7), (1792, 1024, 4), (1792, 1024, 8), (4864, 896, 5), (24, 256, 6)])
+def test_wstream_one_pass_silu_interleaved_tiles(device, M, I, K, nw):
+    """The one-tile form of the fused silu epilogue (tiles_per_wave = 1: a wave's 16 weight rows are 8 gate rows + the 8 up rows
+    of the same output columns, gate and up swapped across lane halves in the epilogue): Llama-3-8B / 70B gate_up in whole
+    rounds of 256 workgroups x 7 waves, plus ragged tile counts, every waves-per-group the kernel has, a last workgroup with idle
+    waves.  Same bars as the two-tile form, and the two forms agree with each other to the same bound."""
+    K_ = _k()
+    g = torch.Generator().manual_seed(M + I)
+    x = torch.randn((M, K), generator=g).to(BF).to(device)
+    w = (torch.randn((2 * I, K), generator=g) * 0.03).to(BF).to(device)
+    gate_up = K_.wstream_gemm(x, w, splits=1, waves_per_group=4)
+    want = oo.silu_and_mul(gate_up.cpu())
+    if nw is None:                       # the form the policy would pick with the interleaved tiles enabled: 256 x 7 waves
+        got = K_.wstream_gemm(x, w, epilogue="silu_and_mul", splits=1, waves_per_group=7, tiles_per_wave=1).cpu()
+    else:
+        got = K_.wstream_gemm(x, w, epilogue="silu_and_mul", splits=1, waves_per_group=nw, tiles_per_wave=1).cpu()
+    d = (got.float() - want.float()).abs()
+    assert float((d > 0).float().mean()) < 0.03
+    assert bool((d <= want.float().abs() * 2.0 ** -4 + 1e-3).all())
+    two = K_.wstream_gemm(x, w, epilogue="silu_and_mul", splits=1, waves_per_group=2 if I % 32 == 0 else None, tiles_per_wave=2).cpu() if I % 16 == 0 else None
+    if two is not None:
+        d2 = (got.float() - two.float()).abs()
+        assert bool((d2 <= two.float().abs() * 2.0 ** -4 + 1e-3).all())
+    # chunk-major output (what the fused decode layer hands to down_proj)
+    if I % 128 == 0 and nw is not None:
+        blk = K_.wstream_gemm(x, w, epilogue="silu_and_mul", splits=1, waves_per_group=nw, tiles_per_wave=1, out_blocked=True)
+        assert torch.equal(K_.unblock(blk).cpu(), got)
+
+
 @pytest.mark.parametrize("M", [1, 20, 64, 100, 128])
 @pytest.mark.parametrize("I,K,nw", [(14336, 4096, None), (1792, 1024, 2), (1792, 1024, 3), (4864, 896, 4), (48, 256, None)])
 def test_wstream_one_pass_silu_equals_unfused_ops(device, M, I, K, nw):
@@ -140,7 +170,7 @@ def test_wstream_one_pass_silu_equals_unfused_ops(device, M, I, K, nw):
         pytest.skip("beyond 64 rows the one-pass form runs 2-wave groups")
     gate_up = K_.wstream_gemm(x, w, splits=1, waves_per_group=4)
     want = oo.silu_and_mul(gate_up.cpu())
-    got = K_.wstream_gemm(x, w, epilogue="silu_and_mul", splits=1, waves_per_group=nw).cpu()
+    got = K_.wstream_gemm(x, w, epilogue="silu_and_mul", splits=1, waves_per_group=nw, tiles_per_wave=2).cpu()
     d = (got.float() - want.float()).abs()
     # same products and rounding points; the K walk starts at other staggered chunks (fp32 summation order), so a gate
     # or up value sitting on a bf16 rounding boundary may land on the other side.  One ulp of a gate around -5 moves
