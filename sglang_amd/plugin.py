@@ -92,6 +92,12 @@ def load() -> None:
 
     linear_hook.install(HookRegistry, HookType.AROUND)
 
+    # ---- token positions of a batch (position_hooks.py): forward_batch_info.clamp_position / compute_position
+    # (forward_batch_info.py:871-896, 1771-1816) -> one launch each on device length vectors -------------------------------
+    from . import position_hooks
+
+    position_hooks.install(HookRegistry, HookType.AROUND)
+
 
 def _sampler_factory():
     """The factory must return a subclass of the reference Sampler (sampler.py:553-557): the gfx950 forward on

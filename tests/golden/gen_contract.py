@@ -41,7 +41,7 @@ WANT = {
     "sglang/kernels/ops/attention/rope.py": ["FusedSetKVBufferArg"],
     "sglang/srt/mem_cache/memory_pool.py": ["KVWriteLoc", "MHATokenToKVPool", "ReqToTokenPool"],
     "sglang/srt/mem_cache/radix_cache.py": ["RadixCache", "RadixKey"],
-    "sglang/srt/model_executor/forward_batch_info.py": ["ForwardBatch", "ForwardMode"],
+    "sglang/srt/model_executor/forward_batch_info.py": ["ForwardBatch", "ForwardMode", "compute_position", "_clamp_position_native"],
     "sglang/srt/configs/model_config.py": ["ModelConfig.get_num_attention_heads", "ModelConfig.get_num_kv_heads"],
     "sglang/srt/model_executor/runner/decode_cuda_graph_runner.py": ["DecodeCudaGraphRunner"],
     "sglang/srt/plugins/hook_registry.py": ["HookRegistry", "HookType", "_wrap_fn"],

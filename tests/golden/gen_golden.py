@@ -97,6 +97,8 @@ REAL = {
     "sglang.srt.multimodal.mm_utils",
 }
 FAILED = []
+NOT_FOUND = []            # sglang modules asked for that do not exist under REF (a staged copy that misses a file): stubbed
+TRY_PACKAGES = False      # ref_objects.py: run package __init__ files too (degrading to a stub when one cannot import)
 
 
 class _StubLoader(importlib.abc.Loader):
@@ -147,10 +149,11 @@ class _Finder(importlib.abc.MetaPathFinder):
         if root == "sglang":
             spec = importlib.machinery.PathFinder.find_spec(name, path)
             if spec is None:
+                NOT_FOUND.append(name)
                 return importlib.machinery.ModuleSpec(name, _StubLoader(), is_package=True)
             if name in REAL:
                 return spec
-            if spec.submodule_search_locations is not None:
+            if spec.submodule_search_locations is not None and not (TRY_PACKAGES and name != "sglang" and spec.loader is not None):
                 return importlib.machinery.ModuleSpec(
                     name, _PkgLoader(list(spec.submodule_search_locations)), is_package=True)
             spec.loader = _WrapLoader(spec.loader)

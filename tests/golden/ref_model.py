@@ -1,0 +1,649 @@
+"""The REAL reference model stack around the drop-in boundary -- `sglang.srt.plugins.load_plugins()` (entry-point discovery,
+srt/plugins/__init__.py:103-141), `sglang.srt.platforms.current_platform` (srt/platforms/__init__.py:49-150), `ServerArgs`,
+`init_distributed_environment` / `initialize_model_parallel` (srt/distributed/parallel_state.py), `LlamaForCausalLM` with
+its `load_weights` (srt/models/llama.py), `LogitsProcessor`, `ForwardBatch.init_new`, the reference pools -- importable
+WITHOUT an sglang install through gen_golden.py's import hook (ref_objects.py describes the hook and the staging).
+
+Test infrastructure only: nothing here restates the reference; every reference line that runs is the reference's own.
+
+The package under test is found the way an installed package is found: `fake_install()` writes the `*.dist-info` directory
+that `pip install -e /root/repo` would write (name, version and the two entry-point groups of pyproject.toml) into a scratch
+directory on sys.path, so `importlib.metadata.entry_points(group="sglang.srt.plugins" / "sglang.srt.platforms")` -- the
+reference's own discovery -- returns `sglang_amd.plugin:load` and `sglang_amd.platform:activate`.
+"""
+from __future__ import annotations
+
+import dataclasses
+import importlib
+import os
+import sys
+import tempfile
+import types
+from pathlib import Path
+
+# before anything of the reference is imported: aiter is not in this image (the reference's own default is off), and the
+# reference's `@torch.compile`d helpers (sampler.py multinomial_with_seed, ...) run as the plain torch code they wrap
+os.environ.setdefault("SGLANG_USE_AITER", "0")
+os.environ.setdefault("TORCHDYNAMO_DISABLE", "1")
+
+import torch  # noqa: E402
+
+HERE = Path(__file__).resolve().parent
+REPO = HERE.parents[1]
+sys.path.insert(0, str(HERE))
+import ref_objects as R  # noqa: E402
+
+# packages whose __init__ must run (the model files import names through them) + the modules of the model stack
+MODEL_REAL = {
+    "sglang.srt.utils", "sglang.srt.utils.hf_transformers", "sglang.srt.utils.hf_transformers_utils", "sglang.srt.server_args",
+    "sglang.srt.distributed", "sglang.srt.distributed.parallel_state", "sglang.srt.platforms", "sglang.srt.plugins",
+    "sglang.srt.plugins.hook_registry", "sglang.srt.layers.utils", "sglang.srt.layers.rotary_embedding", "sglang.srt.layers.linear",
+    "sglang.srt.layers.vocab_parallel_embedding", "sglang.srt.layers.logits_processor", "sglang.srt.layers.quantization.unquant",
+    "sglang.srt.layers.activation", "sglang.srt.layers.sampler", "sglang.srt.layers.attention.attention_registry",
+    "sglang.srt.layers.moe.moe_runner.base", "sglang.srt.models.llama",
+}
+STAGE = REPO / "oracle" / "_ref" / "sglang_model"      # its own staged copy: ref_objects.py's (a verified, smaller file set) stays as it is
+_state = {}
+
+
+def ref_root():
+    """The container's checkout, else the staged copy, else None (REF_OBJECTS_ROOT forces a root: tests of the staged copy)."""
+    forced = os.environ.get("REF_OBJECTS_ROOT")
+    if forced:
+        return Path(forced) if (Path(forced) / "sglang").exists() else None
+    if (R.CONTAINER_REF / "sglang").exists():
+        return R.CONTAINER_REF
+    return STAGE if (STAGE / "sglang").exists() else None
+
+
+def fake_install() -> Path:
+    """What `pip install -e .` leaves on sys.path: a dist-info directory with the entry points of pyproject.toml."""
+    if "dist" in _state:
+        return _state["dist"]
+    try:
+        import tomllib as toml
+    except ImportError:                                    # python 3.10
+        import tomli as toml
+    proj = toml.loads((REPO / "pyproject.toml").read_text())["project"]
+    d = Path(tempfile.mkdtemp(prefix="sglang_amd_site_"))
+    info = d / f"{proj['name'].replace('-', '_')}-{proj['version']}.dist-info"
+    info.mkdir()
+    (info / "METADATA").write_text(f"Metadata-Version: 2.1\nName: {proj['name']}\nVersion: {proj['version']}\n")
+    lines = []
+    for group, eps in proj["entry-points"].items():
+        lines.append(f"[{group}]")
+        lines += [f"{k} = {v}" for k, v in eps.items()]
+        lines.append("")
+    (info / "entry_points.txt").write_text("\n".join(lines))
+    sys.path.insert(0, str(d))
+    if str(REPO) not in sys.path:
+        sys.path.insert(0, str(REPO))
+    importlib.invalidate_caches()
+    _state["dist"] = d
+    return d
+
+
+def dry_run_on_cpu() -> bool:
+    """The build container has no GPU.  The same script then runs as a plumbing check: a gfx950 device is pretended for
+    the reference's import-time arch probes (`is_fp8_fnuz`), the reference's groups live on the CPU, and the reference's
+    own torch-native operators compute -- the plug-in is NOT loaded (its kernels need the GPU)."""
+    return not torch.cuda.is_available()
+
+
+def install(root: Path | None = None):
+    """Hook + the reference model stack imported.  Returns ref_objects' namespace with the extra modules attached."""
+    if "ns" in _state:
+        return _state["ns"]
+    root = root or ref_root()
+    if root is None:
+        return None
+    fake_install()
+    if dry_run_on_cpu():
+        props = types.SimpleNamespace(gcnArchName="gfx950:sramecc+:xnack-", name="AMD Instinct MI355X", total_memory=288 << 30,
+                                      multi_processor_count=256, major=9, minor=5)
+        torch.cuda.get_device_properties = lambda *a, **k: props
+        torch.cuda.get_device_capability = lambda *a, **k: (9, 5)
+        torch.cuda.get_device_name = lambda *a, **k: props.name
+    import gen_golden as G
+
+    G.REAL |= MODEL_REAL
+    ns = R.install(root)
+    for m in sorted(MODEL_REAL):
+        setattr(ns, m.replace("sglang.srt.", "").replace("sglang.", "").replace(".", "_"), importlib.import_module(m))
+    if dry_run_on_cpu():
+        # torch.version.hip is set in this image, so forward_batch_info binds `clamp_position` to the reference's
+        # JIT-compiled device kernel (forward_batch_info.py:1811-1816; needs tvm_ffi + a GPU): the dry run takes the
+        # reference's own other branch.  (On the GPU box the plug-in's hook serves the call -- position_hooks.py.)
+        ns.forward_batch_info.clamp_position = ns.forward_batch_info._clamp_position_native
+    _state["ns"] = ns
+    return ns
+
+
+def default_server_args(ns, **over):
+    """A ServerArgs carrying the reference's own field defaults (the dataclass defaults of server_args.py), without the
+    launch-time __post_init__ (which probes GPU memory, downloads configs ...); `over` = what the command line would set."""
+    SA = ns.server_args.ServerArgs
+    sa = object.__new__(SA)
+    for f in dataclasses.fields(SA):
+        if f.default is not dataclasses.MISSING:
+            setattr(sa, f.name, f.default)
+        elif f.default_factory is not dataclasses.MISSING:
+            setattr(sa, f.name, f.default_factory())
+        else:
+            setattr(sa, f.name, None)
+    for k, v in over.items():
+        assert hasattr(sa, k), k
+        setattr(sa, k, v)
+    ns.server_args.set_global_server_args_for_scheduler(sa)
+    return sa
+
+
+def init_parallel(ns, port: int = 0):
+    """World of one rank through the reference's own initialisers (RCCL on the GPU box, gloo in the dry run)."""
+    PS = ns.distributed_parallel_state
+    if dry_run_on_cpu():
+        PS.is_cuda_alike = lambda: False
+    if not PS.model_parallel_is_initialized():
+        port = port or 29500 + os.getpid() % 400
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        PS.init_distributed_environment(world_size=1, rank=0, distributed_init_method=f"tcp://127.0.0.1:{port}", local_rank=0,
+                                        backend="gloo" if dry_run_on_cpu() else "nccl")
+        PS.initialize_model_parallel(1)
+    return PS
+
+
+# ---- the job: cold extend, warm extend over a cached prefix, decode steps, on the reference's LlamaForCausalLM ---------
+DIMS = {
+    # hidden, intermediate, layers, q heads, kv heads, head dim, vocab
+    "tiny": (256, 512, 2, 8, 2, 64, 1024),
+    "llama3_8b_2layers": (4096, 14336, 2, 32, 8, 128, 128256),
+}
+
+
+def hf_checkpoint(dims, device, seed=1):
+    """Random weights under the Hugging Face checkpoint names `LlamaForCausalLM.load_weights` (llama.py:640-720) expects:
+    separate q / k / v and gate / up tensors, which the reference's own loader stacks into qkv_proj / gate_up_proj."""
+    H, I, L, Hq, Hkv, D, V = dims
+    g = torch.Generator(device="cpu").manual_seed(seed)
+
+    def rnd(*s, sc):
+        return (torch.randn(s, generator=g) * sc).to(torch.bfloat16).to(device)
+
+    sc_h, sc_i = H ** -0.5, I ** -0.5
+    hf = {"model.embed_tokens.weight": rnd(V, H, sc=0.5), "model.norm.weight": 1 + rnd(H, sc=0.1), "lm_head.weight": rnd(V, H, sc=sc_h)}
+    for i in range(L):
+        p = f"model.layers.{i}."
+        hf[p + "input_layernorm.weight"] = 1 + rnd(H, sc=0.1)
+        hf[p + "post_attention_layernorm.weight"] = 1 + rnd(H, sc=0.1)
+        hf[p + "self_attn.q_proj.weight"] = rnd(Hq * D, H, sc=sc_h)
+        hf[p + "self_attn.k_proj.weight"] = rnd(Hkv * D, H, sc=sc_h)
+        hf[p + "self_attn.v_proj.weight"] = rnd(Hkv * D, H, sc=sc_h)
+        hf[p + "self_attn.o_proj.weight"] = rnd(H, Hq * D, sc=(Hq * D) ** -0.5)
+        hf[p + "mlp.gate_proj.weight"] = rnd(I, H, sc=sc_h)
+        hf[p + "mlp.up_proj.weight"] = rnd(I, H, sc=sc_h)
+        hf[p + "mlp.down_proj.weight"] = rnd(H, I, sc=sc_i)
+    return hf
+
+
+def oracle_weights(model):
+    """The reference model's OWN parameters (after its loader stacked them) under the oracle's names."""
+    m = model.model
+    w = {"embed_tokens": m.embed_tokens.weight.data, "norm.weight": m.norm.weight.data, "lm_head": model.lm_head.weight.data}
+    for i, layer in enumerate(m.layers):
+        p = f"layers.{i}."
+        w[p + "input_layernorm.weight"] = layer.input_layernorm.weight.data
+        w[p + "post_attention_layernorm.weight"] = layer.post_attention_layernorm.weight.data
+        w[p + "self_attn.qkv_proj.weight"] = layer.self_attn.qkv_proj.weight.data
+        w[p + "self_attn.o_proj.weight"] = layer.self_attn.o_proj.weight.data
+        w[p + "mlp.gate_up_proj.weight"] = layer.mlp.gate_up_proj.weight.data
+        w[p + "mlp.down_proj.weight"] = layer.mlp.down_proj.weight.data
+    return w
+
+
+class _Batch:
+    """What ForwardBatch.init_new reads of a ScheduleBatch: the fields a generation batch carries, None for the rest."""
+
+    def __getattr__(self, n):
+        if n.startswith("__"):
+            raise AttributeError(n)
+        return None
+
+
+def build_model(ns, dims, device):
+    """`LlamaForCausalLM(config)` + `load_weights(checkpoint)` -- model_loader/loader.py:_initialize_model + load_weights
+    under the loader's bf16 default dtype."""
+    from transformers import LlamaConfig
+
+    H, I, L, Hq, Hkv, D, V = dims
+    cfg = LlamaConfig(hidden_size=H, intermediate_size=I, num_hidden_layers=L, num_attention_heads=Hq, num_key_value_heads=Hkv,
+                      vocab_size=V, max_position_embeddings=2048, rope_theta=10000.0, rms_norm_eps=1e-5, head_dim=D,
+                      tie_word_embeddings=False)
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        with torch.device(device):
+            model = ns.models_llama.LlamaForCausalLM(cfg)
+    finally:
+        torch.set_default_dtype(old)
+    model.load_weights(list(hf_checkpoint(dims, device).items()))
+    return cfg, model.eval()
+
+
+class Job:
+    """The reference stack around one model: `LlamaForCausalLM`, the reference pools, a runner-shaped namespace carrying
+    what `ForwardBatch.init_new` and the attention backend read of `ModelRunner`, the backend built by `backend_factory`,
+    and the oracle on the reference model's own parameters.  Every forward is `ForwardBatch.init_new(batch, runner)` ->
+    `backend.init_forward_metadata(fb)` -> `model.forward(input_ids, positions, fb)` inside `forward_context(...)`
+    (model_runner.py:1664-1690), followed by the oracle's forward over the same tokens and slots."""
+
+    def __init__(self, ns, dims, device, backend_factory, sa):
+        from oracle.model import OracleLM
+        from sglang_amd.harness.models import ModelConfig
+
+        self.ns, self.device, self.sa = ns, device, sa
+        mp, self.fbi, self.fc = ns.memory_pool, ns.forward_batch_info, ns.forward_context
+        H, I, L, Hq, Hkv, D, V = dims
+        self.V = V
+        self.cfg, self.model = build_model(ns, dims, device)
+        self.g = torch.Generator().manual_seed(7)
+        self.records = []
+        with R.single_rank(ns):
+            self.r2t = mp.ReqToTokenPool(8, 1024, device, False)
+            self.kv = mp.MHATokenToKVPool(4096, 1, torch.bfloat16, Hkv, D, L, device, False, enable_alt_stream=False)
+        mc = types.SimpleNamespace(model_is_mrope=False, get_num_attention_heads=lambda tp: Hq // tp, get_num_kv_heads=lambda tp: max(1, Hkv // tp),
+                                   num_attention_heads=Hq, num_key_value_heads=Hkv, head_dim=D, is_encoder_decoder=False, vocab_size=V,
+                                   hf_config=self.cfg, context_len=2048)
+        self.runner = types.SimpleNamespace(device=device, is_draft_worker=False, lora_manager=None, prefill_attention_backend_str=sa.attention_backend,
+                                            server_args=sa, ngram_embedding_manager=types.SimpleNamespace(enabled=False), model_config=mc,
+                                            ps=types.SimpleNamespace(attn_dcp_size=1, attn_dcp_rank=0), req_to_token_pool=self.r2t,
+                                            token_to_kv_pool=self.kv, sliding_window_size=None, tp_size=1, attn_tp_size=1, model=self.model,
+                                            dtype=torch.bfloat16, kv_cache_dtype=torch.bfloat16, page_size=1)
+        self.backend_factory = backend_factory
+        with R.single_rank(ns):
+            self.backend = backend_factory(self.runner)
+        self.olm = OracleLM(ModelConfig("ref", H, I, L, Hq, Hkv, D, V, 1e-5, 10000.0, None, 2048), oracle_weights(self.model), num_slots=4096,
+                            max_ctx=1024, max_reqs=7, device=device)
+        self.slots = (torch.randperm(4000, generator=self.g) + 1).to(torch.int64).to(device)     # scattered slots; 0 is the padding slot
+        self.cursor = 0
+        self.pools, self.lens, self.next_ids = [], [], None
+
+    def take(self, n):
+        loc = self.slots[self.cursor: self.cursor + n]
+        self.cursor += n
+        return loc
+
+    def batch(self, mode, ids, pools, seq, loc, extend=None, prefix=None):
+        b = _Batch()
+        b.forward_mode = mode
+        b.seq_lens = torch.tensor(seq, device=self.device)
+        b.seq_lens_cpu = torch.tensor(seq)
+        b.seq_lens_sum = int(sum(seq))
+        b.input_ids = ids
+        b.req_pool_indices = torch.tensor(pools, device=self.device)
+        b.out_cache_loc = loc
+        b.reqs, b.has_grammar, b.return_logprob = [], False, False
+        if extend is not None:
+            b.extend_lens, b.prefix_lens, b.extend_num_tokens = list(extend), list(prefix), int(sum(extend))
+            b.extend_logprob_start_lens = [0] * len(extend)
+            b.is_extend_in_batch = True
+        return b
+
+    def forward_batch(self, b, backend=None):
+        fbi = self.fbi
+        fb = fbi.ForwardBatch.init_new(b, self.runner, capture_hidden_mode=fbi.CaptureHiddenMode.NULL, return_hidden_states_before_norm=False)
+        fb.req_to_token_pool, fb.token_to_kv_pool, fb.attn_backend = self.r2t, self.kv, backend or self.backend   # model_runner.py: behind init_new
+        return fb
+
+    def oracle(self, b, fb, extend, prefix):
+        self.olm.req_to_token.copy_(self.r2t.req_to_token[:8])
+        dec = extend is None
+        dev = self.device
+        return self.olm.forward(b.input_ids, fb.positions, b.req_pool_indices, b.seq_lens, None if dec else torch.tensor(prefix, device=dev),
+                                None if dec else torch.tensor(extend, device=dev), b.out_cache_loc, dec)
+
+    def forward(self, mode, ids, pools, seq, loc, extend=None, prefix=None, what=""):
+        with R.single_rank(self.ns), torch.no_grad():
+            b = self.batch(mode, ids, pools, seq, loc, extend, prefix)
+            fb = self.forward_batch(b)
+            if extend is not None:                     # the reference computed the positions (through the plug-in's hook on the GPU)
+                want_pos = torch.cat([torch.arange(p, p + e) for p, e in zip(prefix, extend)])
+            else:
+                want_pos = torch.tensor(seq) - 1
+            assert torch.equal(fb.positions.cpu(), want_pos) and fb.positions.dtype == torch.int64, (what, fb.positions)
+            self.backend.init_forward_metadata(fb)
+            with self.fc.forward_context(self.fc.ForwardContext(attn_backend=self.backend)):    # model_runner.py:1671-1674
+                out = self.model.forward(fb.input_ids, fb.positions, fb)
+            want = self.oracle(b, fb, extend, prefix)
+        self.records.append(dict(what=what, got=out.next_token_logits.float().cpu(), want=want.float().cpu()))
+        return out.next_token_logits
+
+    def prefill(self):
+        fbi, r2t, g, dev = self.fbi, self.r2t, self.g, self.device
+        # cold extend: three requests
+        pools, lens = [1, 4, 2], [37, 130, 20]
+        T = sum(lens)
+        ids = torch.randint(0, self.V, (T,), generator=g).to(dev)
+        loc = self.take(T)
+        off = 0
+        for b_, n in enumerate(lens):
+            r2t.req_to_token[pools[b_], :n] = loc[off: off + n].to(torch.int32)
+            off += n
+        logits = self.forward(fbi.ForwardMode.EXTEND, ids, pools, lens, loc, extend=lens, prefix=[0, 0, 0], what="cold extend 37+130+20")
+        # warm extend: a fourth request whose first 64 tokens ARE request 4's slots (a radix hit), 50 new tokens
+        r2t.req_to_token[6, :64] = r2t.req_to_token[4, :64]
+        loc_w = self.take(50)
+        r2t.req_to_token[6, 64:114] = loc_w.to(torch.int32)
+        ids_w = torch.randint(0, self.V, (50,), generator=g).to(dev)
+        lw = self.forward(fbi.ForwardMode.EXTEND, ids_w, [6], [114], loc_w, extend=[50], prefix=[64], what="warm extend 50 over a 64-token prefix")
+        self.pools, self.lens = pools + [6], lens + [114]
+        self.next_ids = torch.cat([logits.argmax(-1), lw.argmax(-1)])
+
+    def advance(self):
+        """One new slot per request (what the scheduler's alloc_for_decode does before a decode forward)."""
+        dl = self.take(len(self.pools))
+        for b_, n in enumerate(self.lens):
+            self.r2t.req_to_token[self.pools[b_], n] = dl[b_].to(torch.int32)
+        self.lens = [n + 1 for n in self.lens]
+        return dl
+
+    def decode(self, steps=3):
+        for step in range(steps):
+            dl = self.advance()
+            lg = self.forward(self.fbi.ForwardMode.DECODE, self.next_ids, self.pools, self.lens, dl, what=f"decode step {step} (4 requests)")
+            self.next_ids = lg.argmax(-1)
+        return lg
+
+    def graph_decode(self, steps=2) -> dict:
+        """The decode forward of the WHOLE reference model inside a hipGraph, through the reference's capture / replay
+        protocol (base_attn_backend.py:65-107: init_cuda_graph_state; init_forward_metadata_out_graph(fb, in_capture=True)
+        before the capture, init_forward_metadata_in_graph(fb) inside it, init_forward_metadata_out_graph(fb) before every
+        replay) with the batch's tensors as the graph's static buffers -- what DecodeCudaGraphRunner does around
+        `model.forward`.  Each replay is compared with the oracle like an eager pass."""
+        fbi, fc, dev, B = self.fbi, self.fc, self.device, len(self.pools)
+        with R.single_rank(self.ns), torch.no_grad():
+            backend = self.backend_factory(self.runner)
+            backend.init_cuda_graph_state(B, B)
+            ctx = fc.ForwardContext(attn_backend=backend)
+            st_ids = self.next_ids.clone()
+            st_loc = torch.zeros(B, dtype=torch.int64, device=dev)                # slot 0: the padding slot
+            b = self.batch(fbi.ForwardMode.DECODE, st_ids, self.pools, self.lens, st_loc)
+            fb = self.forward_batch(b, backend)
+            st_seq, st_pos = fb.seq_lens, fb.positions
+            backend.init_forward_metadata_out_graph(fb, in_capture=True)
+            graph = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), fc.forward_context(ctx):
+                backend.init_forward_metadata_in_graph(fb)
+                self.model.forward(st_ids, st_pos, fb)                            # warm-up outside the capture
+                side.synchronize()
+                with torch.cuda.graph(graph, stream=side):
+                    backend.init_forward_metadata_in_graph(fb)
+                    out = self.model.forward(st_ids, st_pos, fb)
+            torch.cuda.current_stream().wait_stream(side)
+            for step in range(steps):
+                dl = self.advance()
+                st_ids.copy_(self.next_ids); st_loc.copy_(dl); st_seq.copy_(torch.tensor(self.lens)); st_pos.copy_(torch.tensor(self.lens) - 1)
+                fb.seq_lens_cpu = torch.tensor(self.lens)
+                backend.init_forward_metadata_out_graph(fb)
+                graph.replay()
+                torch.cuda.synchronize()
+                b2 = self.batch(fbi.ForwardMode.DECODE, st_ids.clone(), self.pools, self.lens, dl)
+                want = self.oracle(b2, types.SimpleNamespace(positions=st_pos.clone()), None, None)
+                self.records.append(dict(what=f"hipGraph decode replay {step} (4 requests)", got=out.next_token_logits.float().cpu(),
+                                         want=want.float().cpu()))
+                self.next_ids = out.next_token_logits.argmax(-1)
+        return dict(replays=steps)
+
+
+def sampler_leg(ns, sa, logits, positions, vocab, device) -> dict:
+    """`create_sampler(backend)` (sampler.py:545-566: the registered factory for the plug-in's backend name, the
+    reference's `Sampler()` for "pytorch") on the last decode step's logits, with a `SamplingBatchInfo` built by the
+    reference's own `from_schedule_batch`: greedy everywhere; on the GPU also temperature + top-k + top-p with per-request
+    seeds, where the plug-in's ids must EQUAL the ids of the reference's torch path on the same logits."""
+    sbi = importlib.import_module("sglang.srt.sampling.sampling_batch_info")
+    spm = importlib.import_module("sglang.srt.sampling.sampling_params")
+    smp, lpo = ns.layers_sampler, ns.layers_logits_processor.LogitsProcessorOutput
+    B = logits.shape[0]
+
+    def info(**kw):
+        reqs = []
+        for i in range(B):
+            p = spm.SamplingParams()               # (msgspec is absent here, and with it the Struct's generated constructor)
+            fields = dict(temperature=1.0, top_k=1 << 30, top_p=1.0, min_p=0.0, sampling_seed=None, logit_bias=None,
+                          custom_params=None, frequency_penalty=0.0, presence_penalty=0.0, repetition_penalty=1.0, min_new_tokens=0)
+            fields.update({k_: (v_[i] if isinstance(v_, list) else v_) for k_, v_ in kw.items()})
+            for k, v in fields.items():
+                setattr(p, k, v)
+            reqs.append(types.SimpleNamespace(sampling_params=p, custom_logit_processor=None, return_sampling_mask=False,
+                                              origin_input_ids=[1, 2, 3], output_ids=[], rid=str(i)))
+        return sbi.SamplingBatchInfo.from_schedule_batch(types.SimpleNamespace(reqs=reqs, device=device), vocab)
+
+    def run(backend, inf):
+        sa.sampling_backend = backend
+        ns.server_args.set_global_server_args_for_scheduler(sa)
+        out = lpo(next_token_logits=logits.clone())
+        ids = smp.create_sampler(backend)(out, inf, False, [0] * B, [None] * B, positions)
+        return ids.long().cpu()
+
+    under_test = "pytorch" if dry_run_on_cpu() else sa.attention_backend        # (the plug-in registers both under one name)
+    rep = dict(backend=under_test, sampler_class=type(smp.create_sampler(under_test)).__mro__[0].__name__,
+               is_reference_subclass=isinstance(smp.create_sampler(under_test), smp.Sampler))
+    greedy = run(under_test, info(temperature=0.0, top_k=1))
+    rep["greedy_equals_argmax"] = bool(torch.equal(greedy, logits.argmax(-1).cpu()))
+    if not dry_run_on_cpu():
+        kw = dict(temperature=0.8, top_k=[20 + 7 * i for i in range(B)], top_p=[0.9 - 0.1 * (i % 3) for i in range(B)],
+                  sampling_seed=[100 + i for i in range(B)])
+        mine, ref = run(under_test, info(**kw)), run("pytorch", info(**kw))
+        rep.update(seeded_ids=mine.tolist(), seeded_ids_reference=ref.tolist(), seeded_ids_equal=bool(torch.equal(mine, ref)))
+    return rep
+
+
+# ---- the three runs ----------------------------------------------------------------------------------------------------
+def run_cpu_oracle(dims_name="tiny") -> dict:
+    """Build container (no GPU, plug-in NOT loaded): the reference's `LlamaForCausalLM` with its torch-native attention
+    backend and torch fused-op forwards on the CPU, against oracle/model.py on the same weights, tokens and slots.
+    Pins the oracle's whole-model restatement: the logits must be IDENTICAL."""
+    ns = install()
+    from sglang.kernels import fused_op as FO
+    from sglang.kernels.spec import KernelBackend
+
+    # torch.version.hip is set in this image, so without a GPU the reference would still pick its HIP forwards (aiter /
+    # sgl_kernel, absent): the reference's own switch forces every fused op onto its torch forward (fused_op.py:236)
+    FO.set_fused_op_backend(KernelBackend.TORCH)
+    sa = default_server_args(ns, model_path="dummy", attention_backend="torch_native", enable_deterministic_inference=True)
+    init_parallel(ns)
+    tnb = importlib.import_module("sglang.srt.layers.attention.torch_native_backend")
+    job = Job(ns, DIMS[dims_name], "cpu", tnb.TorchNativeAttnBackend, sa)
+    job.prefill()
+    lg = job.decode(3)
+    sampler = sampler_leg(ns, sa, lg.clone(), torch.tensor(job.lens), job.V, "cpu")
+    records = job.records
+    return dict(mode="cpu-oracle", dims=dims_name, sampler=sampler,
+                passes=[dict(what=r["what"], identical=bool(torch.equal(r["got"], r["want"])),
+                             max_abs=float((r["got"] - r["want"]).abs().max()), ref_rms=float(r["want"].pow(2).mean().sqrt()))
+                        for r in records])
+
+
+def run_loader() -> dict:
+    """Any box: the reference's own `load_plugins()` discovers the package through its entry points and executes
+    `plugin.load()` against the REAL registries (no GPU work: registration only)."""
+    ns = install()
+    import sglang_amd.platform as P
+
+    if dry_run_on_cpu():
+        P.is_gfx950_visible = lambda: True            # activate() must answer as on the GPU box
+    plat_mod = importlib.import_module("sglang.srt.platforms")
+    plat_mod._current_platform = None                 # (resolved once at import of models/llama.py, before the line above)
+    from sglang.kernels import fused_op as FO
+
+    FO.clear_platform_caches()
+    platform = plat_mod.current_platform
+    PL = ns.plugins
+    PL.load_plugins()
+    from sglang.kernels.fused_op import BaseFusedOp
+    from sglang.srt.layers.attention.attention_registry import ATTENTION_BACKENDS
+    from sglang.srt.layers.moe.moe_runner.base import FusedOpPool
+    from sglang.srt.layers.sampler import _CUSTOM_SAMPLER_FACTORIES
+    from sglang.srt.plugins.hook_registry import HookRegistry
+    from sglang.srt.server_args import ATTENTION_BACKEND_CHOICES, SAMPLING_BACKEND_CHOICES
+
+    from sglang_amd.platform import BACKEND_NAME, DISPATCH_KEY
+
+    oot = BaseFusedOp._oot_forward_registry.get(DISPATCH_KEY, {})
+    return dict(mode="loader", platform=type(platform).__name__, out_of_tree=bool(platform.is_out_of_tree()),
+                dispatch_key=platform.get_dispatch_key_name() if platform.is_out_of_tree() else None,
+                default_attention_backend=platform.get_default_attention_backend() if platform.is_out_of_tree() else None,
+                attention_backend_registered=BACKEND_NAME in ATTENTION_BACKENDS,
+                attention_backend_choice=BACKEND_NAME in ATTENTION_BACKEND_CHOICES,
+                sampler_registered=BACKEND_NAME in _CUSTOM_SAMPLER_FACTORIES, sampler_choice=BACKEND_NAME in SAMPLING_BACKEND_CHOICES,
+                fused_moe_slot=getattr(FusedOpPool.get_fused_func("none", "triton"), "__qualname__", ""),
+                oot_forwards=sorted(c.__name__ for c in oot),
+                hooked=sorted(HookRegistry._hooks), hooks_applied=sorted(getattr(HookRegistry, "_patched", ())))
+
+
+def run_gpu(dims_name="tiny") -> dict:
+    """GPU box: plug-in discovered and loaded by the reference (launch_server.py:8 order: plug-ins first), the platform
+    resolved by the reference (out-of-tree -> the registered forwards), the attention backend built by the reference's
+    registry from the platform's default name, the reference's `LlamaForCausalLM` on cuda:0 -- and the job above.  The
+    decode passes go through the AROUND hook on `LlamaModel.forward` (9 launches per layer), the prefill passes through the
+    reference's own layer loop with the registered operator forwards and the hooked `UnquantizedLinearMethod.apply`."""
+    loader = run_loader()
+    ns = install()
+    assert loader["out_of_tree"], loader
+    from sglang.kernels import fused_op as FO
+    from sglang.srt.layers.attention.attention_registry import ATTENTION_BACKENDS
+    from sglang.srt.platforms import current_platform
+
+    import sglang_amd.fused_decode as fd
+    import sglang_amd.linear_hook as lh
+    from oracle.layer_parity import ulp_stats
+
+    sa = default_server_args(ns, model_path="dummy", attention_backend=current_platform.get_default_attention_backend(),
+                             enable_deterministic_inference=True)
+    init_parallel(ns)
+    counts = dict(fused_decode_models=0, streamed_linears=0, library_linears=0)
+    decode_model = fd.decode_model
+
+    def counting_decode_model(*a, **k):
+        counts["fused_decode_models"] += 1
+        return decode_model(*a, **k)
+
+    fd.decode_model = counting_decode_model
+    takes = lh.takes
+
+    def counting_takes(*a, **k):
+        ok = takes(*a, **k)
+        counts["streamed_linears" if ok else "library_linears"] += 1
+        return ok
+
+    lh.takes = counting_takes
+    FO.clear_fused_op_trace()
+    FO.enable_fused_op_trace()
+    import traceback
+
+    legs = {}
+
+    def leg(name, fn):
+        try:
+            legs[name] = dict(ok=True, **(fn() or {}))
+        except Exception:                                   # noqa: BLE001 -- every leg reports; the test asserts on all of them
+            legs[name] = dict(ok=False, error=traceback.format_exc()[-3000:])
+        return legs[name]["ok"]
+
+    job = None
+    last = {}
+
+    def build():
+        nonlocal job
+        with R.single_rank(ns):
+            job = Job(ns, DIMS[dims_name], "cuda", ATTENTION_BACKENDS[sa.attention_backend], sa)
+        return dict(backend=type(job.backend).__name__, model=type(job.model).__name__,
+                    rope=type(job.model.model.layers[0].self_attn.rotary_emb).__name__)
+
+    if leg("build", build):
+        if leg("prefill", job.prefill):
+            if leg("decode", lambda: last.update(lg=job.decode(3))):
+                leg("sampler", lambda: sampler_leg(ns, sa, last["lg"].clone(), torch.tensor(job.lens, device="cuda"), job.V, "cuda"))
+                sa.sampling_backend = None
+                leg("graph_decode", job.graph_decode)
+    torch.cuda.synchronize()
+    FO.disable_fused_op_trace()
+    trace = {}
+    for rec in FO.get_fused_op_trace():
+        trace[f"{rec.op}:{rec.backend}"] = trace.get(f"{rec.op}:{rec.backend}", 0) + 1
+    passes = []
+    for r in (job.records if job is not None else []):
+        st = ulp_stats(r["got"], r["want"])
+        top2 = r["want"].topk(2, dim=-1).values
+        clear = (top2[:, 0] - top2[:, 1]) > 4e-2
+        passes.append(dict(what=r["what"], **st, max_err_over_2e2_bar=float(((r["got"] - r["want"]).abs() / (2e-2 + 2e-2 * r["want"].abs())).max()),
+                           clear_rows=int(clear.sum()), argmax_agree=int((r["got"].argmax(-1)[clear] == r["want"].argmax(-1)[clear]).sum())))
+    import gen_golden as G
+
+    return dict(mode="gpu", dims=dims_name, loader=loader, legs=legs, counts=counts, fused_op_trace=trace, passes=passes,
+                degraded_reference_modules=[n for n, _ in G.FAILED], unstaged_reference_modules=sorted(set(getattr(G, "NOT_FOUND", []))))
+
+
+# directories staged whole (beyond the files the dry run executed): with a GPU present the reference takes import branches the
+# build container cannot execute (Triton kernels, ROCm-only modules); a module missing from the staged copy would silently
+# become a stub, so the packages the model stack draws from travel complete (model files: only the ones used)
+STAGE_DIRS = ("sglang/kernels/ops", "sglang/srt/layers", "sglang/srt/model_executor", "sglang/srt/mem_cache", "sglang/srt/distributed",
+              "sglang/srt/utils", "sglang/srt/platforms", "sglang/srt/plugins", "sglang/srt/sampling", "sglang/srt/configs",
+              "sglang/srt/model_loader", "sglang/srt/arg_groups", "sglang/srt/compilation", "sglang/srt/batch_invariant_ops",
+              "sglang/kernels/jit", "sglang/srt/connector", "sglang/srt/disaggregation", "sglang/srt/function_call", "sglang/srt/hardware_backend")
+STAGE_FILES = ("sglang/srt/models/llama.py", "sglang/srt/models/qwen2.py", "sglang/srt/models/utils.py", "sglang/srt/models/registry.py")
+
+
+def stage() -> None:
+    """Build container: run the dry-run legs (so that every lazily imported reference module is loaded), then copy the
+    reference files that were executed + STAGE_DIRS to oracle/_ref/sglang_model/ (git-ignored; travels with the gpurun
+    snapshot)."""
+    import shutil
+
+    if not (R.CONTAINER_REF / "sglang").exists():
+        raise SystemExit("/root/reference not present: staging only works in the build container")
+    ns = install(R.CONTAINER_REF)
+    run_cpu_oracle()
+    run_loader()
+    failed = {name for name, _ in ns.hook.FAILED}
+    files = set()
+    for name, mod in list(sys.modules.items()):
+        f = getattr(mod, "__file__", None)
+        if name.startswith("sglang") and f and R.CONTAINER_REF in Path(f).parents:      # (degraded modules too: the GPU box retries them)
+            files.add(Path(f))
+    for d in STAGE_DIRS:
+        files.update(p for p in (R.CONTAINER_REF / d).rglob("*.py"))
+    files.update(R.CONTAINER_REF / f for f in STAGE_FILES if (R.CONTAINER_REF / f).exists())
+    for top in ("sglang", "sglang/srt", "sglang/kernels"):                      # the single-file modules next to the packages
+        files.update(p for p in (R.CONTAINER_REF / top).glob("*.py"))
+    if STAGE.exists():
+        shutil.rmtree(STAGE)
+    for f in sorted(files):
+        dst = STAGE / f.relative_to(R.CONTAINER_REF)
+        dst.parent.mkdir(parents=True, exist_ok=True)
+        shutil.copyfile(f, dst)
+    total = sum(f.stat().st_size for f in files)
+    print(f"staged {len(files)} reference files ({total / 1e6:.1f} MB) under {STAGE}; degraded at import: {sorted(failed)}")
+
+
+if __name__ == "__main__":
+    import argparse
+    import json
+
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--run", choices=["cpu-oracle", "loader", "gpu", "stage"], required=True)
+    ap.add_argument("--dims", default="tiny", choices=sorted(DIMS))
+    ap.add_argument("--json", default=None)
+    a = ap.parse_args()
+    if a.run == "stage":
+        stage()
+        sys.exit(0)
+    rep = {"cpu-oracle": lambda: run_cpu_oracle(a.dims), "loader": run_loader, "gpu": lambda: run_gpu(a.dims)}[a.run]()
+    text = json.dumps(rep, indent=1)
+    if a.json:
+        Path(a.json).parent.mkdir(parents=True, exist_ok=True)
+        Path(a.json).write_text(text)
+    print(text)
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()

@@ -381,6 +381,9 @@ def fake_sglang(monkeypatch):
             cls._patched.clear()
 
     hr.HookRegistry = HookRegistry
+    # forward_batch_info.py:1807-1816: the module-level name `clamp_position` is bound to one of two functions at import
+    fbi_mod = created["sglang.srt.model_executor.forward_batch_info"]
+    fbi_mod.clamp_position = fbi_mod._clamp_position_native
     created["sglang.srt.runtime_context"].get_parallel = lambda: types.SimpleNamespace(tp_size=1, tp_rank=0)
     return created
 
@@ -703,6 +706,41 @@ def test_linear_hook_is_registered_on_the_unquantized_method_and_falls_through(f
         assert not linear_hook.takes(torch.zeros((4, 96), dtype=torch.bfloat16), torch.zeros((256, 96), dtype=torch.bfloat16), None)   # K % 128
         assert not linear_hook.takes(x, w, torch.zeros(256))                            # fp32 bias
         assert not linear_hook.takes(x[:, ::1].t().t()[:, :], torch.zeros((256, 256), dtype=torch.bfloat16)[:, ::2], None)   # strided weight
+    hr.HookRegistry.reset()
+
+
+def test_position_hooks_are_registered_on_the_two_module_functions_and_fall_through(fake_sglang):
+    """forward_batch_info.clamp_position / compute_position (:871-896, :1771-1816) carry AROUND hooks bound to the reference's
+    parameter lists; CPU tensors, float lengths and mixed dtypes reach the reference's own functions with the original
+    arguments.  The kernel branch: tests/test_reference_model_gpu.py (under the reference's own ForwardBatch.init_new)."""
+    import inspect
+
+    from sglang_amd import plugin, position_hooks
+
+    g = fake_sglang
+    plugin.load()
+    hr = g["sglang.srt.plugins.hook_registry"]
+    for target, hook in zip(position_hooks.HOOK_TARGETS, position_hooks._HOOKS):
+        assert [(ht.name, h) for ht, h, _ in hr.HookRegistry._hooks[target]] == [("AROUND", hook)]
+    ref_ps = [p["name"] for p in ref("sglang.srt.model_executor.forward_batch_info", "compute_position")["params"]]
+    assert list(inspect.signature(position_hooks.compute_position_hook).parameters) == ["original"] + ref_ps
+    ref_ps = [p["name"] for p in ref("sglang.srt.model_executor.forward_batch_info", "_clamp_position_native")["params"]]
+    assert list(inspect.signature(position_hooks.clamp_position_hook).parameters) == ["original"] + ref_ps
+    fbi = g["sglang.srt.model_executor.forward_batch_info"]
+    calls = []
+    fbi.clamp_position = lambda seq_lens: calls.append(("clamp", seq_lens)) or "reference-clamp"
+    fbi.compute_position = lambda attn_backend, extend_prefix_lens, extend_seq_lens, extend_seq_lens_sum: calls.append(
+        ("compute", attn_backend, extend_prefix_lens, extend_seq_lens, extend_seq_lens_sum)) or "reference-compute"
+    hr.HookRegistry.apply_hooks()
+    lens = torch.tensor([5, 9], dtype=torch.int32)
+    assert fbi.clamp_position(lens) == "reference-clamp" and calls[-1][1] is lens                     # CPU tensor
+    assert fbi.compute_position("triton", lens, lens, 14) == "reference-compute" and calls[-1][1:] == ("triton", lens, lens, 14)
+    import unittest.mock as um
+
+    with um.patch.object(torch.Tensor, "is_cuda", property(lambda self: True)):
+        assert not position_hooks._lens_ok(lens.float()) and not position_hooks._lens_ok(lens.view(1, 2)) and position_hooks._lens_ok(lens)
+        assert fbi.compute_position("triton", lens, lens.long(), 14) == "reference-compute"            # mixed dtypes
+        assert fbi.compute_position("triton", lens, lens, 0) == "reference-compute"                    # an empty extend
     hr.HookRegistry.reset()
 
 
