@@ -73,6 +73,13 @@ class _Stub(types.ModuleType):
     def __getattr__(self, name):
         if name.startswith("__") and name.endswith("__"):
             raise AttributeError(name)
+        # `from package import submodule` on a package whose __init__ was skipped: the attribute is the submodule, if there is one
+        if SUBMODULE_ATTRS and self.__dict__.get("__path__"):
+            full = f"{self.__name__}.{name}"
+            if full in sys.modules:
+                return sys.modules[full]
+            if importlib.machinery.PathFinder.find_spec(full, self.__dict__["__path__"]) is not None:
+                return importlib.import_module(full)
         return _Any
 
 
@@ -98,6 +105,7 @@ REAL = {
 }
 FAILED = []
 NOT_FOUND = []            # sglang modules asked for that do not exist under REF (a staged copy that misses a file): stubbed
+SUBMODULE_ATTRS = False   # ref_model.py: see _Stub.__getattr__
 TRY_PACKAGES = False      # ref_objects.py: run package __init__ files too (degrading to a stub when one cannot import)
 
 

@@ -25,10 +25,10 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT / "tests" / "golden"))
 
 
-def _run(mode, tmp_path, env=None, timeout=900):
+def _run(mode, tmp_path, env=None, timeout=900, extra=()):
     out = tmp_path / f"{mode}.json"
     e = dict(os.environ, **(env or {}))
-    p = subprocess.run([sys.executable, str(ROOT / "tests" / "golden" / "ref_model.py"), "--run", mode, "--json", str(out)],
+    p = subprocess.run([sys.executable, str(ROOT / "tests" / "golden" / "ref_model.py"), "--run", mode, "--json", str(out), *extra],
                        cwd=ROOT, env=e, capture_output=True, text=True, timeout=timeout)
     assert p.returncode == 0, p.stderr[-4000:]
     return json.loads(out.read_text())
@@ -52,6 +52,18 @@ def test_oracle_whole_model_equals_the_references_llama_forward(tmp_path):
         assert p["identical"] and p["max_abs"] == 0.0 and p["ref_rms"] > 0.5, p          # bit-identical logits, non-trivial ones
     s = rep["sampler"]
     assert s["sampler_class"] == "Sampler" and s["is_reference_subclass"] and s["greedy_equals_argmax"]
+
+
+@pytest.mark.parametrize("extra,what", [(("--dims", "qwen2.5_0.5b"), "BASELINE configs[0]'s architecture, whole depth, on Qwen2ForCausalLM"),
+                                        (("--tp", "2"), "two ranks: the reference's groups, row-parallel all-reduces, vocab-parallel embedding + logits all-gather")])
+def test_oracle_equals_the_reference_on_qwen2_and_at_tp2(tmp_path, extra, what):
+    """The same five passes: (a) the reference's `Qwen2ForCausalLM` at Qwen2.5-0.5B's own dimensions (24 layers, qkv bias, tied
+    embeddings: the configuration BASELINE.json runs on the CPU), (b) `LlamaForCausalLM` under `initialize_model_parallel(2)` --
+    two gloo processes, every rank's shards cut by the reference's own weight loader -- against the oracle's TP = 2 mode."""
+    _root_or_skip()
+    rep = _run("cpu-oracle", tmp_path, extra=extra)
+    assert len(rep["passes"]) == 5 and all(p["identical"] and p["ref_rms"] > 0.5 for p in rep["passes"]), (what, rep["passes"])
+    assert rep["tp"] == (2 if "--tp" in extra else 1)
 
 
 def test_the_references_loader_discovers_and_executes_the_plugin(tmp_path):

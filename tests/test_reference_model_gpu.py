@@ -28,16 +28,21 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT / "tests" / "golden"))
 
 
-@pytest.mark.parametrize("dims", ["tiny", "llama3_8b_2layers"])
-def test_plugin_under_the_references_model_stack(device, dims):
+@pytest.mark.parametrize("dims,tp", [("tiny", 1), ("llama3_8b_2layers", 1), ("tiny_qwen2", 1), ("tiny", 2)])
+def test_plugin_under_the_references_model_stack(device, dims, tp):
+    """tp = 2: two processes on GPU 0 under the reference's `initialize_model_parallel(2)` (gloo device groups: RCCL refuses
+    two ranks of one device) -- the reference's GroupCoordinator constructor attaches the xGMI communicator through the
+    plug-in's hook, the row-parallel projections and the vocab-parallel embedding all-reduce through the hooked
+    `GroupCoordinator.all_reduce`, the logits gather through the hooked `all_gather`, and the decode passes run the fused
+    layer with the all-reduce + add + RMSNorm epilogue."""
     import ref_model
 
     if ref_model.ref_root() is None:
         pytest.skip("reference sources are not staged (python tests/golden/ref_model.py --run stage in the build container)")
-    out = ROOT / "gpurun_out" / f"reference_model_{dims}.json"
+    out = ROOT / "gpurun_out" / f"reference_model_{dims}{'_tp%d' % tp if tp > 1 else ''}.json"
     env = dict(os.environ, SGLANG_USE_AITER="0")                     # (aiter is not in this image; the reference's default is off)
-    p = subprocess.run([sys.executable, str(ROOT / "tests" / "golden" / "ref_model.py"), "--run", "gpu", "--dims", dims, "--json", str(out)],
-                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    p = subprocess.run([sys.executable, str(ROOT / "tests" / "golden" / "ref_model.py"), "--run", "gpu", "--dims", dims, "--tp", str(tp),
+                        "--json", str(out)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-6000:]
     rep = json.loads(out.read_text())
     ld = rep["loader"]
@@ -47,7 +52,14 @@ def test_plugin_under_the_references_model_stack(device, dims):
     for name in ("build", "prefill", "decode", "sampler", "graph_decode"):
         assert rep["legs"].get(name, {}).get("ok"), (name, rep["legs"].get(name))
     b = rep["legs"]["build"]
-    assert (b["backend"], b["model"], b["rope"]) == ("HipAttnBackend", "LlamaForCausalLM", "RotaryEmbedding")
+    assert (b["backend"], b["model"], b["rope"]) == ("HipAttnBackend", "Qwen2ForCausalLM" if "qwen2" in dims else "LlamaForCausalLM",
+                                                     "RotaryEmbedding")
+    assert rep["tp"] == tp
+    if tp > 1:
+        c = rep["counts"]
+        # per layer of a prefill pass: o_proj + down_proj all-reduces (+ the embedding's); per fused decode layer: two all-reduces
+        # with the add + RMSNorm epilogue; every forward gathers the logits
+        assert c["xgmi_attached"] and c["xgmi_all_reduce"] >= 10 and c["xgmi_all_reduce_add_rmsnorm"] >= 20 and c["xgmi_all_gather"] >= 7, c
     # the decode passes ran the fused layer loop: 3 eager steps + the graph's warm-up and capture; the prefill passes did not
     assert rep["counts"]["fused_decode_models"] == 5, rep["counts"]
     # the hooked UnquantizedLinearMethod.apply saw the prefill projections: 187 rows -> the library GEMM, the 50-row warm extend
@@ -56,10 +68,15 @@ def test_plugin_under_the_references_model_stack(device, dims):
     # every fused-op call of the prefill passes was served by a forward plugin.load() registered (label = the method name,
     # fused_op.py `_dispatch_label`), none by the reference's torch / hip / triton forwards
     tr = rep["fused_op_trace"]
-    assert tr and all(k.endswith(":forward") for k in tr), tr
+    assert sorted(tr) == ["RMSNorm:forward", "RotaryEmbedding:forward", "SiluAndMul:forward"], tr
     assert len(rep["passes"]) == 7
     for ps in rep["passes"]:
-        assert ps["max_err_over_2e2_bar"] <= 1.0 and ps["argmax_agree"] == ps["clear_rows"], ps
-        assert ps["frac_within_2ulp"] >= 0.98, ps
+        # Two bf16 evaluations of a 2-layer model differ by a few logit ulps (the reference's literal evaluation vs its own
+        # fp32-accumulating one does): the plug-in's error against the fp32-accumulating oracle must stay inside the band of the
+        # reference's literal evaluation against the same oracle -- rms within 1.25x, the single worst logit within 2x -- and
+        # every clear-margin arg-max must agree with the literal evaluation.
+        assert ps["product_rms_err"] <= 1.25 * ps["reference_rms_err"] + 1e-4, ps
+        assert ps["product_max_err"] <= 2.0 * ps["reference_max_err"] + 1e-3, ps
+        assert ps["argmax_agree"] == ps["clear_rows"] and ps["max_ulp"] <= 8.0 and ps["frac_within_2ulp"] >= 0.95, ps
     s = rep["legs"]["sampler"]
     assert s["is_reference_subclass"] and s["greedy_equals_argmax"] and s["seeded_ids_equal"], s
