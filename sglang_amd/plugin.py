@@ -66,6 +66,24 @@ def load() -> None:
     BaseFusedOp.register_oot_forward(SiluAndMul, activation.SiluAndMul.forward, DISPATCH_KEY)
     BaseFusedOp.register_oot_forward(RotaryEmbedding, rotary_embedding.RotaryEmbedding.forward, DISPATCH_KEY)
     BaseFusedOp.register_oot_forward(TopK, hip_topk.TopK.forward, DISPATCH_KEY)
+    # The registry is keyed by the EXACT class of the op instance (fused_op.py:541 `.get(type(self))`): the rope classes that only
+    # change the cos / sin cache and inherit RotaryEmbedding.forward (rope_variant.py:537 Llama3RotaryEmbedding -- Llama-3.1's --,
+    # :643 DynamicNTKAlpha, :841 DynamicNTKScaling) would otherwise fall to forward_native on an out-of-tree platform.
+    import sglang.srt.layers.rotary_embedding.rope_variant as rope_variant
+
+    for name in ("Llama3RotaryEmbedding", "DynamicNTKAlphaRotaryEmbedding", "DynamicNTKScalingRotaryEmbedding"):
+        cls = getattr(rope_variant, name, None)
+        if isinstance(cls, type) and issubclass(cls, RotaryEmbedding) and "forward" not in vars(cls) and "forward_native" not in vars(cls):
+            BaseFusedOp.register_oot_forward(cls, rotary_embedding.RotaryEmbedding.forward, DISPATCH_KEY)
+
+    # UnquantizedFusedMoEMethod IS a BaseFusedOp (quantization/unquant.py:384): on an out-of-tree platform without a registered
+    # forward its dispatch ends in forward_native = forward_cpu = the per-expert torch loop (unquant.py:868-916) and never asks
+    # the MoeRunner -- and with it the fused function above -- at all.  The registered forward is the reference's OWN forward_cuda
+    # (unquant.py:783-866: TritonMoeQuantInfo from the layer's weights -> self.runner.run -> FusedOpPool's ("none", "triton")
+    # function = _adapt_fused_func's wrapper).
+    from sglang.srt.layers.quantization.unquant import UnquantizedFusedMoEMethod
+
+    BaseFusedOp.register_oot_forward(UnquantizedFusedMoEMethod, UnquantizedFusedMoEMethod.forward_cuda, DISPATCH_KEY)
 
     # ---- the fused TP=1 decode step (srt/plugins/hook_registry.py:84 register, :146 apply_hooks) ----------------
     # An AROUND hook on LlamaModel.forward: decode batches run 9 launches per layer (fused_decode.py), everything else

@@ -38,6 +38,7 @@ WANT = {
     "sglang/srt/layers/layernorm.py": ["RMSNorm"],
     "sglang/srt/layers/activation.py": ["SiluAndMul"],
     "sglang/srt/layers/rotary_embedding/base.py": ["RotaryEmbedding"],
+    "sglang/srt/layers/rotary_embedding/rope_variant.py": ["Llama3RotaryEmbedding", "DynamicNTKAlphaRotaryEmbedding", "DynamicNTKScalingRotaryEmbedding"],
     "sglang/kernels/ops/attention/rope.py": ["FusedSetKVBufferArg"],
     "sglang/srt/mem_cache/memory_pool.py": ["KVWriteLoc", "MHATokenToKVPool", "ReqToTokenPool"],
     "sglang/srt/mem_cache/radix_cache.py": ["RadixCache", "RadixKey"],
@@ -47,7 +48,7 @@ WANT = {
     "sglang/srt/plugins/hook_registry.py": ["HookRegistry", "HookType", "_wrap_fn"],
     "sglang/srt/models/llama.py": ["LlamaModel", "LlamaDecoderLayer", "LlamaAttention", "LlamaMLP"],
     "sglang/srt/models/qwen2.py": ["Qwen2Model", "Qwen2DecoderLayer", "Qwen2Attention", "Qwen2MLP"],
-    "sglang/srt/layers/quantization/unquant.py": ["UnquantizedLinearMethod"],
+    "sglang/srt/layers/quantization/unquant.py": ["UnquantizedLinearMethod", "UnquantizedFusedMoEMethod"],
     "sglang/srt/runtime_context.py": ["get_parallel"],
     "sglang/srt/distributed/parallel_state.py": ["GroupCoordinator", "get_tp_group"],
     "sglang/srt/distributed/communication_op.py": ["tensor_model_parallel_all_reduce", "tensor_model_parallel_fused_allreduce_rmsnorm",

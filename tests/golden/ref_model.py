@@ -109,6 +109,7 @@ def install(root: Path | None = None):
 
     G.REAL |= MODEL_REAL
     G.SUBMODULE_ATTRS = True
+    G.TRY_PACKAGES = True             # package __init__ files run too (degrading to a stub package when one cannot import)
     ns = R.install(root)
     for m in sorted(MODEL_REAL):
         setattr(ns, m.replace("sglang.srt.", "").replace("sglang.", "").replace(".", "_"), importlib.import_module(m))
@@ -182,10 +183,13 @@ DIMS = {
     # BASELINE.json configs[0]'s architecture (Qwen2.5-0.5B: qkv bias, tied embeddings, 14 / 2 heads of 64), whole depth
     "qwen2.5_0.5b": (896, 4864, 24, 14, 2, 64, 151936),
     "tiny_qwen2": (256, 384, 2, 4, 2, 64, 768),
+    # Mixtral's block (8 experts, top-2, renormalised softmax router) at small dimensions
+    "tiny_mixtral": (512, 512, 2, 8, 2, 64, 1024),
 }
-ARCH = {"qwen2.5_0.5b": "qwen2", "tiny_qwen2": "qwen2"}                     # default: llama
-ROPE_THETA = {"qwen2": 1000000.0, "llama": 10000.0}
-EPS = {"qwen2": 1e-6, "llama": 1e-5}
+ARCH = {"qwen2.5_0.5b": "qwen2", "tiny_qwen2": "qwen2", "tiny_mixtral": "mixtral"}      # default: llama
+ROPE_THETA = {"qwen2": 1000000.0, "llama": 10000.0, "mixtral": 1000000.0}
+EPS = {"qwen2": 1e-6, "llama": 1e-5, "mixtral": 1e-5}
+EXPERTS, TOP_K = 8, 2
 
 
 def hf_checkpoint(dims, device, seed=1, arch="llama"):
@@ -201,7 +205,7 @@ def hf_checkpoint(dims, device, seed=1, arch="llama"):
 
     sc_h, sc_i = H ** -0.5, I ** -0.5
     hf = {"model.embed_tokens.weight": rnd(V, H, sc=0.5 if arch == "llama" else sc_h * 4), "model.norm.weight": 1 + rnd(H, sc=0.1)}
-    if arch == "llama":
+    if arch != "qwen2":
         hf["lm_head.weight"] = rnd(V, H, sc=sc_h)
     for i in range(L):
         p = f"model.layers.{i}."
@@ -215,6 +219,13 @@ def hf_checkpoint(dims, device, seed=1, arch="llama"):
         hf[p + "self_attn.k_proj.weight"] = rnd(Hkv * D, H, sc=sc_h)
         hf[p + "self_attn.v_proj.weight"] = rnd(Hkv * D, H, sc=sc_h)
         hf[p + "self_attn.o_proj.weight"] = rnd(H, Hq * D, sc=(Hq * D) ** -0.5)
+        if arch == "mixtral":                            # mixtral.py:395-405: experts.{e}.w1 (gate) / w3 (up) / w2 (down)
+            hf[p + "block_sparse_moe.gate.weight"] = rnd(EXPERTS, H, sc=sc_h * 4)
+            for e in range(EXPERTS):
+                hf[p + f"block_sparse_moe.experts.{e}.w1.weight"] = rnd(I, H, sc=sc_h)
+                hf[p + f"block_sparse_moe.experts.{e}.w3.weight"] = rnd(I, H, sc=sc_h)
+                hf[p + f"block_sparse_moe.experts.{e}.w2.weight"] = rnd(H, I, sc=sc_i)
+            continue
         hf[p + "mlp.gate_proj.weight"] = rnd(I, H, sc=sc_h)
         hf[p + "mlp.up_proj.weight"] = rnd(I, H, sc=sc_h)
         hf[p + "mlp.down_proj.weight"] = rnd(H, I, sc=sc_i)
@@ -233,6 +244,12 @@ def oracle_weights(model):
         if getattr(layer.self_attn.qkv_proj, "bias", None) is not None:
             w[p + "self_attn.qkv_proj.bias"] = layer.self_attn.qkv_proj.bias.data
         w[p + "self_attn.o_proj.weight"] = layer.self_attn.o_proj.weight.data
+        if hasattr(layer, "block_sparse_moe"):
+            moe = layer.block_sparse_moe
+            w[p + "mlp.gate.weight"] = moe.gate.weight.data
+            w[p + "mlp.experts.w13_weight"] = moe.experts.w13_weight.data
+            w[p + "mlp.experts.w2_weight"] = moe.experts.w2_weight.data
+            continue
         w[p + "mlp.gate_up_proj.weight"] = layer.mlp.gate_up_proj.weight.data
         w[p + "mlp.down_proj.weight"] = layer.mlp.down_proj.weight.data
     return w
@@ -258,6 +275,11 @@ def build_model(ns, dims, device, arch="llama"):
 
         cfg = Qwen2Config(**common, tie_word_embeddings=True)
         cls = importlib.import_module("sglang.srt.models.qwen2").Qwen2ForCausalLM
+    elif arch == "mixtral":
+        from transformers import MixtralConfig
+
+        cfg = MixtralConfig(**common, num_local_experts=EXPERTS, num_experts_per_tok=TOP_K, tie_word_embeddings=False)
+        cls = importlib.import_module("sglang.srt.models.mixtral").MixtralForCausalLM
     else:
         from transformers import LlamaConfig
 
@@ -312,7 +334,8 @@ class Job:
         with parallel_ctx(ns):
             self.backend = backend_factory(self.runner)
         ocfg = ModelConfig("ref", H, I, L, Hq, Hkv, D, V, EPS[arch], ROPE_THETA[arch], None, 2048, attention_bias=arch == "qwen2",
-                           tie_word_embeddings=arch == "qwen2")
+                           tie_word_embeddings=arch == "qwen2", num_local_experts=EXPERTS if arch == "mixtral" else 0,
+                           num_experts_per_tok=TOP_K if arch == "mixtral" else 0)
         w = oracle_weights(self.model)
         tpg = None
         if tp > 1:
@@ -489,7 +512,9 @@ def sampler_leg(ns, sa, logits, positions, vocab, device) -> dict:
                 setattr(p, k, v)
             reqs.append(types.SimpleNamespace(sampling_params=p, custom_logit_processor=None, return_sampling_mask=False,
                                               origin_input_ids=[1, 2, 3], output_ids=[], rid=str(i)))
-        return sbi.SamplingBatchInfo.from_schedule_batch(types.SimpleNamespace(reqs=reqs, device=device), vocab)
+        batch = _Batch()                     # (the penalizer orchestrator keeps a weak reference to the batch)
+        batch.reqs, batch.device = reqs, device
+        return sbi.SamplingBatchInfo.from_schedule_batch(batch, vocab)
 
     def run(backend, inf):
         sa.sampling_backend = backend
@@ -610,6 +635,27 @@ def run_gpu(dims_name="tiny") -> dict:
         return ok
 
     lh.takes = counting_takes
+    # MoE: the function in FusedOpPool's ("none", "triton") slot is what MoeRunner.run calls (runner.py:143-147; read once, when the
+    # model is built): count its calls, and which of them the gfx950 grouped GEMMs served
+    from sglang.srt.layers.moe.moe_runner.base import FusedOpPool
+
+    import sglang_amd.layers.moe.fused_moe as hip_moe
+
+    counts.update(moe_fused_func_calls=0, moe_hip_calls=0)
+    slot = FusedOpPool._fused_funcs[("none", "triton")]
+
+    def counting_slot(*a, **k):
+        counts["moe_fused_func_calls"] += 1
+        return slot(*a, **k)
+
+    FusedOpPool._fused_funcs[("none", "triton")] = counting_slot
+    hip_experts = hip_moe.fused_experts_none_to_hip
+
+    def counting_hip_experts(*a, **k):
+        counts["moe_hip_calls"] += 1
+        return hip_experts(*a, **k)
+
+    hip_moe.fused_experts_none_to_hip = counting_hip_experts
     comm = None
     if tp_world()[0] > 1:
         # the communicator tp_hooks.attach built inside the reference's GroupCoordinator.__init__ (None = not attached: the test fails)
@@ -687,7 +733,8 @@ STAGE_DIRS = ("sglang/kernels/ops", "sglang/srt/layers", "sglang/srt/model_execu
               "sglang/srt/utils", "sglang/srt/platforms", "sglang/srt/plugins", "sglang/srt/sampling", "sglang/srt/configs",
               "sglang/srt/model_loader", "sglang/srt/arg_groups", "sglang/srt/compilation", "sglang/srt/batch_invariant_ops",
               "sglang/kernels/jit", "sglang/srt/connector", "sglang/srt/disaggregation", "sglang/srt/function_call", "sglang/srt/hardware_backend")
-STAGE_FILES = ("sglang/srt/models/llama.py", "sglang/srt/models/qwen2.py", "sglang/srt/models/utils.py", "sglang/srt/models/registry.py")
+STAGE_FILES = ("sglang/srt/models/llama.py", "sglang/srt/models/qwen2.py", "sglang/srt/models/mixtral.py", "sglang/srt/models/utils.py",
+               "sglang/srt/models/registry.py")
 
 
 def stage() -> None:
@@ -699,7 +746,8 @@ def stage() -> None:
     if not (R.CONTAINER_REF / "sglang").exists():
         raise SystemExit("/root/reference not present: staging only works in the build container")
     ns = install(R.CONTAINER_REF)
-    run_cpu_oracle()
+    for dims_name in ("tiny", "tiny_qwen2", "tiny_mixtral"):
+        run_cpu_oracle(dims_name)
     run_loader()
     failed = {name for name, _ in ns.hook.FAILED}
     files = set()

@@ -329,6 +329,19 @@ def fake_sglang(monkeypatch):
     ln.RMSNorm, tk.TopK = RMSNorm, TopK
     act.SiluAndMul = type("SiluAndMul", (BaseFusedOp,), {"forward_native": lambda self, x: "native-silu"})
     rope.RotaryEmbedding = type("RotaryEmbedding", (BaseFusedOp,), {"forward_native": lambda self, *a, **k: "native-rope"})
+    # rope_variant.py: the cache-only variants subclass RotaryEmbedding and define neither forward nor forward_native
+    rv = created["sglang.srt.layers.rotary_embedding.rope_variant"]
+    for vname in ("Llama3RotaryEmbedding", "DynamicNTKAlphaRotaryEmbedding", "DynamicNTKScalingRotaryEmbedding"):
+        rec = ref("sglang.srt.layers.rotary_embedding.rope_variant", vname)
+        assert rec["bases"] == ["RotaryEmbedding"] and "forward" not in rec["methods"] and "forward_native" not in rec["methods"], vname
+        setattr(rv, vname, type(vname, (rope.RotaryEmbedding,), {}))
+    # unquant.py:384: the MoE method is a BaseFusedOp whose forward_cuda asks the MoeRunner
+    uq = created["sglang.srt.layers.quantization.unquant"]
+    mrec = ref("sglang.srt.layers.quantization.unquant", "UnquantizedFusedMoEMethod")
+    assert "BaseFusedOp" in mrec["bases"] and [p["name"] for p in mrec["methods"]["forward_cuda"]["params"]] == ["self", "layer", "dispatch_output"]
+    uq.UnquantizedFusedMoEMethod = type("UnquantizedFusedMoEMethod", (BaseFusedOp,), {
+        "forward_cuda": lambda self, layer, dispatch_output: ("runner.run", layer, dispatch_output),
+        "forward_native": lambda self, layer, dispatch_output: "per-expert torch loop"})
     tk.StandardTopKOutput = __import__("collections").namedtuple("StandardTopKOutput", ref("sglang.srt.layers.moe.topk", "StandardTopKOutput")["__contract_fields__"]
                                                                    if False else [f["name"] for f in ref("sglang.srt.layers.moe.topk", "StandardTopKOutput")["fields"]])
     mp_ = created["sglang.srt.mem_cache.memory_pool"]
@@ -444,7 +457,15 @@ def test_plugin_load_runs_against_the_reference_contract(fake_sglang):
     BaseFusedOp = g["sglang.kernels.fused_op"].BaseFusedOp
     reg = BaseFusedOp._oot_forward_registry[platform.DISPATCH_KEY]
     ln = g["sglang.srt.layers.layernorm"]
-    assert set(c.__name__ for c in reg) == {"RMSNorm", "SiluAndMul", "RotaryEmbedding", "TopK"}
+    assert set(c.__name__ for c in reg) == {"RMSNorm", "SiluAndMul", "RotaryEmbedding", "TopK", "Llama3RotaryEmbedding",
+                                            "DynamicNTKAlphaRotaryEmbedding", "DynamicNTKScalingRotaryEmbedding", "UnquantizedFusedMoEMethod"}
+    # the cache-only rope variants get RotaryEmbedding's registered forward (the registry is keyed by the exact class) ...
+    rv = g["sglang.srt.layers.rotary_embedding.rope_variant"]
+    assert reg[rv.Llama3RotaryEmbedding] is reg[g["sglang.srt.layers.rotary_embedding.base"].RotaryEmbedding]
+    # ... and the MoE method dispatches to the reference's own forward_cuda (-> MoeRunner -> the fused function), not to its
+    # forward_native (the per-expert torch loop an out-of-tree platform would otherwise get)
+    uq = g["sglang.srt.layers.quantization.unquant"].UnquantizedFusedMoEMethod
+    assert reg[uq] is uq.forward_cuda and uq()("layer", "dispatch")[0] == "runner.run"
     norm = ln.RMSNorm(32)
     x, res, pra = (torch.zeros((3, 32), dtype=torch.bfloat16) for _ in range(3))
     # communicator.py:722 call form: (hidden_states, residual, post_residual_addition); CPU tensors -> the op hands

@@ -55,7 +55,8 @@ def test_oracle_whole_model_equals_the_references_llama_forward(tmp_path):
 
 
 @pytest.mark.parametrize("extra,what", [(("--dims", "qwen2.5_0.5b"), "BASELINE configs[0]'s architecture, whole depth, on Qwen2ForCausalLM"),
-                                        (("--tp", "2"), "two ranks: the reference's groups, row-parallel all-reduces, vocab-parallel embedding + logits all-gather")])
+                                        (("--tp", "2"), "two ranks: the reference's groups, row-parallel all-reduces, vocab-parallel embedding + logits all-gather"),
+                                        (("--dims", "tiny_mixtral"), "MixtralForCausalLM: router -> TopK -> FusedMoE's native forward (fused_moe_native.py)")])
 def test_oracle_equals_the_reference_on_qwen2_and_at_tp2(tmp_path, extra, what):
     """The same five passes: (a) the reference's `Qwen2ForCausalLM` at Qwen2.5-0.5B's own dimensions (24 layers, qkv bias, tied
     embeddings: the configuration BASELINE.json runs on the CPU), (b) `LlamaForCausalLM` under `initialize_model_parallel(2)` --
@@ -81,6 +82,7 @@ def test_the_references_loader_discovers_and_executes_the_plugin(tmp_path):
     assert rep["attention_backend_registered"] and rep["attention_backend_choice"]
     assert rep["sampler_registered"] and rep["sampler_choice"]
     assert rep["fused_moe_slot"].endswith("_adapt_fused_func.<locals>.wrapper")
-    assert rep["oot_forwards"] == ["RMSNorm", "RotaryEmbedding", "SiluAndMul", "TopK"]
+    assert rep["oot_forwards"] == ["DynamicNTKAlphaRotaryEmbedding", "DynamicNTKScalingRotaryEmbedding", "Llama3RotaryEmbedding", "RMSNorm",
+                                   "RotaryEmbedding", "SiluAndMul", "TopK", "UnquantizedFusedMoEMethod"]
     targets = sorted(fused_decode.HOOK_TARGETS + tp_hooks.HOOK_TARGETS + position_hooks.HOOK_TARGETS + (linear_hook.HOOK_TARGET,))
     assert rep["hooked"] == targets and rep["hooks_applied"] == targets          # every target resolved on the real modules
