@@ -129,30 +129,45 @@ def _sampler_factory():
     return cls()
 
 
+def outside_hip_moe(dispatch_output, quant_info, runner_config):
+    """Why a MoE call is NOT one the gfx950 grouped GEMMs take (a short reason), or None when it is (device aside)."""
+    import torch
+
+    q, c = quant_info, runner_config
+    for f in ("use_mxfp8", "use_fp8_w8a8", "use_int8_w8a8", "use_int8_w8a16", "use_int4_w4a16", "per_channel_quant", "fuse_swiglu_interleaved"):
+        if getattr(q, f, False):
+            return f
+    for f in ("b13", "b2", "w13_scale", "w2_scale", "w13_zp", "w2_zp", "a13_scale", "a2_scale", "block_shape"):
+        if getattr(q, f, None) is not None:
+            return f
+    if getattr(c, "activation", "silu") != "silu" or not getattr(c, "is_gated", True):
+        return "activation"
+    for f in ("no_combine", "apply_router_weight_on_input"):
+        if getattr(c, f, False):
+            return f
+    for f in ("swiglu_limit", "gemm1_alpha", "gemm1_clamp_limit"):
+        if getattr(c, f, None) is not None:
+            return f
+    if getattr(dispatch_output, "hidden_states_pre_quant", None) is not None:
+        return "hidden_states_pre_quant"
+    if dispatch_output.hidden_states.dtype != torch.bfloat16 or q.w13_weight.dtype != torch.bfloat16:
+        return "dtype"
+    return None
+
+
 def _adapt_fused_func(reference_fn):
     """(dispatch_output, quant_info: TritonMoeQuantInfo, runner_config) -> StandardCombineInput
     (moe_runner/triton.py:180-260).  Unquantised gated-silu experts without biases run on the gfx950 grouped GEMMs;
-    everything else (fp8 / int8 / int4 / mxfp8 weights, biases, interleaved gate-up rows, pre-quantised activations,
-    other activations, no_combine, router weight on input) stays with the reference's function."""
+    everything else (fp8 / int8 / int4 / mxfp8 weights, biases, the fused-swiglu row interleave, pre-quantised activations,
+    other activations, the alpha / limit swiglu forms, no_combine, router weight on input) stays with the reference's function.
+    (`MoeRunnerConfig.gate_up_interleaved` -- default True, base.py:63 -- only selects between the two alpha / limit swiglu kernels,
+    triton_utils/fused_moe.py:658-672; with gemm1_alpha None it is not read, so it does not decide anything here.)"""
     def wrapper(dispatch_output, quant_info, runner_config):
-        q = quant_info
-        quantised = any(getattr(q, f, False) for f in ("use_mxfp8", "use_fp8_w8a8", "use_int8_w8a8", "use_int8_w8a16",
-                                                        "use_int4_w4a16", "per_channel_quant", "fuse_swiglu_interleaved"))
-        extras = any(getattr(q, f, None) is not None for f in ("b13", "b2", "w13_scale", "w2_scale", "w13_zp", "w2_zp",
-                                                                "a13_scale", "a2_scale", "block_shape"))
-        c = runner_config
-        unsupported_cfg = (getattr(c, "activation", "silu") != "silu" or not getattr(c, "is_gated", True)
-                           or getattr(c, "no_combine", False) or getattr(c, "apply_router_weight_on_input", False)
-                           or getattr(c, "gate_up_interleaved", False) or getattr(c, "swiglu_limit", None) is not None
-                           or getattr(c, "gemm1_alpha", None) is not None or getattr(c, "gemm1_clamp_limit", None) is not None)
-        x = dispatch_output.hidden_states
-        import torch
-
-        if (quantised or extras or unsupported_cfg or getattr(dispatch_output, "hidden_states_pre_quant", None) is not None
-                or x.dtype != torch.bfloat16 or q.w13_weight.dtype != torch.bfloat16 or not x.is_cuda):
+        if outside_hip_moe(dispatch_output, quant_info, runner_config) is not None or not dispatch_output.hidden_states.is_cuda:
             if reference_fn is None:
                 raise NotImplementedError("this MoE configuration is outside the gfx950 path")
             return reference_fn(dispatch_output, quant_info, runner_config)
+        q, x = quant_info, dispatch_output.hidden_states
         from sglang.srt.layers.moe.token_dispatcher.standard import StandardCombineInput
 
         from .layers.moe.fused_moe import MoeQuantInfo, StandardDispatchOutput, fused_experts_none_to_hip

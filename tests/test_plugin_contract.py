@@ -497,6 +497,20 @@ def test_plugin_load_runs_against_the_reference_contract(fake_sglang):
     cfg_r = types.SimpleNamespace(activation="silu", is_gated=True, no_combine=False, apply_router_weight_on_input=False, inplace=False,
                                   routed_scaling_factor=None)
     assert fn(disp, q, cfg_r) == "reference-result" and tri.calls == ["reference"]
+    # A MoeRunnerConfig carrying the REFERENCE'S OWN field defaults (base.py:37-65; among them gate_up_interleaved = True, which only
+    # selects between the alpha / limit swiglu kernels) with unquantised bf16 weights is a call the gfx950 path takes ...
+    defaults = {k: v for k, v in ref("sglang.srt.layers.moe.moe_runner.base", "MoeRunnerConfig")["attrs"].items()}
+    assert defaults["gate_up_interleaved"] is True and defaults["activation"] == "silu" and defaults["is_gated"] is True
+    cfg_default = types.SimpleNamespace(**defaults)
+    q_plain = types.SimpleNamespace(**{f: (False if (f.startswith("use_") or f in ("per_channel_quant", "fuse_swiglu_interleaved")) else None) for f in fields})
+    q_plain.w13_weight, q_plain.w2_weight = q.w13_weight, q.w2_weight
+    assert plugin.outside_hip_moe(disp, q_plain, cfg_default) is None
+    # ... and each of these is not
+    for field, value, why in (("gemm1_alpha", 1.702, "gemm1_alpha"), ("swiglu_limit", 10.0, "swiglu_limit"), ("no_combine", True, "no_combine"),
+                              ("activation", "gelu", "activation"), ("apply_router_weight_on_input", True, "apply_router_weight_on_input")):
+        c2 = types.SimpleNamespace(**dict(defaults, **{field: value}))
+        assert plugin.outside_hip_moe(disp, q_plain, c2) == why
+    assert plugin.outside_hip_moe(disp, q, cfg_default) == "use_fp8_w8a8"
     q.use_fp8_w8a8, q.b13 = False, torch.zeros(2, 8)
     assert fn(disp, q, cfg_r) == "reference-result"                       # expert biases: not silently dropped
     # loading twice must not trip the pool's duplicate check (plugins are loaded once per process, but be safe)
