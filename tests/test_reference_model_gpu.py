@@ -74,7 +74,7 @@ def test_plugin_under_the_references_model_stack(device, dims, tp):
     # every fused-op call of the prefill passes was served by a forward plugin.load() registered (label = the method name,
     # fused_op.py `_dispatch_label`), none by the reference's torch / hip / triton forwards
     tr = rep["fused_op_trace"]
-    want_ops = ["RMSNorm:forward", "RotaryEmbedding:forward", "TopK:forward", "UnquantizedFusedMoEMethod:forward_cuda"] if moe else [
+    want_ops = ["RMSNorm:forward", "RotaryEmbedding:forward", "TopK:forward", "UnquantizedFusedMoEMethod:cuda"] if moe else [
         "RMSNorm:forward", "RotaryEmbedding:forward", "SiluAndMul:forward"]
     assert sorted(tr) == want_ops, tr
     assert len(rep["passes"]) == 7
