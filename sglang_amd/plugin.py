@@ -32,9 +32,7 @@ def load() -> None:
 
     @register_attention_backend(BACKEND_NAME)
     def _create(runner):
-        from .layers.attention.hip_backend import HipAttnBackend
-
-        return HipAttnBackend(runner)
+        return _backend_class()(runner)
 
     # ---- sampler (sampler.py:531-542 register_sampler_backend; created in model_runner.py:651) ---
     from sglang.srt.layers.sampler import register_sampler_backend
@@ -115,6 +113,24 @@ def load() -> None:
     from . import position_hooks
 
     position_hooks.install(HookRegistry, HookType.AROUND)
+
+
+_BACKEND_CLS = []
+
+
+def _backend_class():
+    """HipAttnBackend as a subclass of the REFERENCE's AttentionBackend (layers/attention/base_attn_backend.py:36-308): the
+    reference's runners read more of a backend than the forward / metadata methods -- `shared_read_ends`,
+    `supports_ragged_verify_graph`, `supports_full_cuda_graph_chunked_prefix`, `on_after_cuda_graph_warmup`,
+    `use_captured_forward_metadata_for_breakable_cuda_graph`, `verify_mask` ... (runner/decode_cuda_graph_runner.py:491, :724) --
+    and those keep the reference's own defaults; what this package defines comes first in the MRO."""
+    if not _BACKEND_CLS:
+        from sglang.srt.layers.attention.base_attn_backend import AttentionBackend as RefAttentionBackend
+
+        from .layers.attention.hip_backend import HipAttnBackend
+
+        _BACKEND_CLS.append(type("HipAttnBackend", (HipAttnBackend, RefAttentionBackend), {"__module__": HipAttnBackend.__module__}))
+    return _BACKEND_CLS[0]
 
 
 def _sampler_factory():

@@ -71,7 +71,7 @@ class _Any(metaclass=_AnyMeta):
 
 class _Stub(types.ModuleType):
     def __getattr__(self, name):
-        if name.startswith("__") and name.endswith("__"):
+        if (name.startswith("__") and name.endswith("__")) or name in ABSENT_ATTRS:
             raise AttributeError(name)
         # `from package import submodule` on a package whose __init__ was skipped: the attribute is the submodule, if there is one
         if SUBMODULE_ATTRS and self.__dict__.get("__path__"):
@@ -83,6 +83,159 @@ class _Stub(types.ModuleType):
         return _Any
 
 
+# ---- a working stand-in for msgspec.Struct (ref_model.py; MSGSPEC_EMULATION) ------------------------------------------------
+# The reference declares its request / parameter / record types as msgspec Structs.  With msgspec merely stubbed their generated
+# constructors are gone (fields keep their class-level defaults, keyword arguments vanish).  This is the documented behaviour of
+# msgspec.Struct restated as far as the reference's classes use it IN PROCESS (fields from annotations in definition order,
+# positional / keyword construction, defaults and default factories with fresh copies of empty mutable defaults, __post_init__,
+# field-wise equality and repr, structs.replace / asdict / fields / force_setattr); the serialisers stay stubs.
+MSGSPEC_EMULATION = False
+
+
+def _make_msgspec():
+    import abc
+    import copy
+
+    class _NoDefault:
+        def __repr__(self):
+            return "NODEFAULT"
+
+    NODEFAULT = _NoDefault()
+
+    class _Field:
+        def __init__(self, default=NODEFAULT, default_factory=NODEFAULT, name=None):
+            self.default, self.default_factory, self.name = default, default_factory, name
+
+    def field(*, default=NODEFAULT, default_factory=NODEFAULT, name=None):
+        return _Field(default, default_factory, name)
+
+    class StructMeta(abc.ABCMeta):
+        def __new__(mcls, name, bases, ns, **kwargs):
+            cls = super().__new__(mcls, name, bases, ns)
+            fields = {}
+            for b in reversed(cls.__mro__[1:]):
+                fields.update(b.__dict__.get("__struct_defaults_map__", {}))
+            for fname, typ in ns.get("__annotations__", {}).items():
+                if "ClassVar" in (typ if isinstance(typ, str) else getattr(typ, "__name__", repr(typ))):
+                    continue
+                default = ns.get(fname, NODEFAULT)
+                fields[fname] = default
+                if isinstance(default, _Field):
+                    delattr(cls, fname)
+            cls.__struct_defaults_map__ = fields
+            cls.__struct_fields__ = tuple(fields)
+            inherited = getattr(cls, "__struct_config__", None)
+            cfg = dict(vars(inherited)) if inherited is not None else {}
+            cfg.update(kwargs)
+            cls.__struct_config__ = types.SimpleNamespace(**cfg)
+            return cls
+
+        def __init__(cls, name, bases, ns, **kwargs):
+            super().__init__(name, bases, ns)
+
+    def _default_of(d):
+        if isinstance(d, _Field):
+            if d.default_factory is not NODEFAULT:
+                return d.default_factory()
+            d = d.default
+        if d is NODEFAULT:
+            raise KeyError
+        return copy.copy(d) if isinstance(d, (list, dict, set, bytearray)) else d
+
+    class Struct(metaclass=StructMeta):
+        def __init__(self, *args, **kwargs):
+            names = type(self).__struct_fields__
+            if len(args) > len(names):
+                raise TypeError(f"{type(self).__name__}: too many positional arguments")
+            vals = dict(zip(names, args))
+            for k, v in kwargs.items():
+                if k not in type(self).__struct_defaults_map__ or k in vals:
+                    raise TypeError(f"{type(self).__name__}: unexpected or repeated argument {k!r}")
+                vals[k] = v
+            for n in names:
+                if n not in vals:
+                    try:
+                        vals[n] = _default_of(type(self).__struct_defaults_map__[n])
+                    except KeyError:
+                        raise TypeError(f"{type(self).__name__}: missing required argument {n!r}") from None
+                object.__setattr__(self, n, vals[n])
+            post = getattr(self, "__post_init__", None)
+            if post is not None:
+                post()
+
+        def __repr__(self):
+            return f"{type(self).__name__}({', '.join(f'{n}={getattr(self, n)!r}' for n in type(self).__struct_fields__)})"
+
+        def __eq__(self, other):
+            if type(other) is not type(self):
+                return NotImplemented
+            return all(getattr(self, n) == getattr(other, n) for n in type(self).__struct_fields__)
+
+        def __hash__(self):
+            if getattr(type(self).__struct_config__, "frozen", False):
+                return hash(tuple(getattr(self, n) for n in type(self).__struct_fields__))
+            return id(self)
+
+        def __copy__(self):
+            new = object.__new__(type(self))
+            for n in type(self).__struct_fields__:
+                object.__setattr__(new, n, getattr(self, n))
+            return new
+
+        def __iter__(self):                         # array_like structs unpack like tuples nowhere in the path; keep explicit
+            raise TypeError(f"{type(self).__name__} is not iterable")
+
+    def replace(obj, **changes):
+        new = obj.__copy__()
+        for k, v in changes.items():
+            if k not in type(obj).__struct_defaults_map__:
+                raise TypeError(k)
+            object.__setattr__(new, k, v)
+        return new
+
+    def asdict(obj):
+        return {n: getattr(obj, n) for n in type(obj).__struct_fields__}
+
+    def fields(obj):
+        cls = obj if isinstance(obj, type) else type(obj)
+        out = []
+        for n, d in cls.__struct_defaults_map__.items():
+            f = d if isinstance(d, _Field) else _Field(default=d)
+            out.append(types.SimpleNamespace(name=n, encode_name=f.name or n, default=f.default, default_factory=f.default_factory,
+                                             type=cls.__annotations__.get(n) if hasattr(cls, "__annotations__") else None,
+                                             required=f.default is NODEFAULT and f.default_factory is NODEFAULT))
+        return tuple(out)
+
+    def force_setattr(obj, name, value):
+        object.__setattr__(obj, name, value)
+
+    m = _Stub("msgspec")
+    m.__path__ = []
+    st = _Stub("msgspec.structs")
+    st.replace, st.asdict, st.fields, st.force_setattr = replace, asdict, fields, force_setattr
+    st.astuple = lambda obj: tuple(getattr(obj, n) for n in type(obj).__struct_fields__)
+    m.Struct, m.StructMeta, m.field, m.NODEFAULT, m.structs = Struct, StructMeta, field, NODEFAULT, st
+    m.UNSET = type("UnsetType", (), {"__repr__": lambda self: "UNSET", "__bool__": lambda self: False})()
+    m.UnsetType = type(m.UNSET)
+    m.MsgspecError = type("MsgspecError", (Exception,), {})
+    m.DecodeError = type("DecodeError", (m.MsgspecError,), {})
+    m.ValidationError = type("ValidationError", (m.DecodeError,), {})
+    m.EncodeError = type("EncodeError", (m.MsgspecError,), {})
+    return m, st
+
+
+class _MsgspecLoader(importlib.abc.Loader):
+    def create_module(self, spec):
+        if "msgspec" not in _MSGSPEC:
+            _MSGSPEC["msgspec"], _MSGSPEC["msgspec.structs"] = _make_msgspec()
+        return _MSGSPEC.get(spec.name) or _Stub(spec.name)
+
+    def exec_module(self, m):
+        if not hasattr(m, "__path__"):
+            m.__path__ = []
+
+
+_MSGSPEC = {}
 MISSING = {"orjson", "msgspec", "zmq", "pybase64", "IPython", "uvloop", "setproctitle", "xgrammar",
            "sgl_kernel", "flashinfer", "aiter", "vllm"}
 REAL = {
@@ -105,6 +258,7 @@ REAL = {
 }
 FAILED = []
 NOT_FOUND = []            # sglang modules asked for that do not exist under REF (a staged copy that misses a file): stubbed
+ABSENT_ATTRS = set()      # names a stubbed module must NOT pretend to have (ref_model.py: "EntryClass", which the model registry probes)
 SUBMODULE_ATTRS = False   # ref_model.py: see _Stub.__getattr__
 TRY_PACKAGES = False      # ref_objects.py: run package __init__ files too (degrading to a stub when one cannot import)
 
@@ -152,6 +306,8 @@ class _WrapLoader(importlib.abc.Loader):
 class _Finder(importlib.abc.MetaPathFinder):
     def find_spec(self, name, path, target=None):
         root = name.split(".")[0]
+        if root == "msgspec" and MSGSPEC_EMULATION:
+            return importlib.machinery.ModuleSpec(name, _MsgspecLoader(), is_package=True)
         if root in MISSING:
             return importlib.machinery.ModuleSpec(name, _StubLoader(), is_package=True)
         if root == "sglang":

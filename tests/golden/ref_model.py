@@ -109,6 +109,8 @@ def install(root: Path | None = None):
 
     G.REAL |= MODEL_REAL
     G.SUBMODULE_ATTRS = True
+    G.ABSENT_ATTRS |= {"EntryClass"}     # models/registry.py registers every module that HAS an EntryClass: a stubbed one has none
+    G.MSGSPEC_EMULATION = True        # msgspec.Struct classes of the reference construct for real (gen_golden._make_msgspec)
     G.TRY_PACKAGES = True             # package __init__ files run too (degrading to a stub package when one cannot import)
     ns = R.install(root)
     for m in sorted(MODEL_REAL):
@@ -726,40 +728,190 @@ def run_gpu(dims_name="tiny") -> dict:
                 degraded_reference_modules=[n for n, _ in G.FAILED], unstaged_reference_modules=sorted(set(getattr(G, "NOT_FOUND", []))))
 
 
-# directories staged whole (beyond the files the dry run executed): with a GPU present the reference takes import branches the
-# build container cannot execute (Triton kernels, ROCm-only modules); a module missing from the staged copy would silently
-# become a stub, so the packages the model stack draws from travel complete (model files: only the ones used)
-STAGE_DIRS = ("sglang/kernels/ops", "sglang/srt/layers", "sglang/srt/model_executor", "sglang/srt/mem_cache", "sglang/srt/distributed",
-              "sglang/srt/utils", "sglang/srt/platforms", "sglang/srt/plugins", "sglang/srt/sampling", "sglang/srt/configs",
-              "sglang/srt/model_loader", "sglang/srt/arg_groups", "sglang/srt/compilation", "sglang/srt/batch_invariant_ops",
-              "sglang/kernels/jit", "sglang/srt/connector", "sglang/srt/disaggregation", "sglang/srt/function_call", "sglang/srt/hardware_backend")
+# ---- one level up: the reference's ModelRunner, driven by the reference's own static-batch harness ----------------------------
+def run_runner(dims_name="tiny") -> dict:
+    """`sglang.benchmark.one_batch` (the module behind `python -m sglang.bench_one_batch`) is the reference's own way to run a
+    model WITHOUT the scheduler process: `load_model` builds a real `ServerArgs` (its whole resolution pipeline), `ModelConfig`,
+    `ModelRunner` (distributed init, model loader, KV-cache configurator + memory pools + allocator, attention backend from the
+    registry, CUDA-graph runners) and `extend` / `decode` drive it with real `Req` / `ScheduleBatch` objects
+    (`prepare_for_extend` / `prepare_for_decode`: the reference's allocators pick the slots), `ForwardBatch.init_new`,
+    `ModelRunner.forward` (graph replay when the runner can) and `ModelRunner.sample`.  This run follows its correctness test
+    (one_batch.py:677-727): prefill of the first `cut` tokens, extend over that cached prefix, greedy decode steps.
+
+    Build container: device cpu, torch-native attention, no plug-in -> the oracle must reproduce every logit bit for bit.
+    MI355X: the plug-in loaded by the reference's loader, `attention_backend` left to the platform, the reference's decode graphs
+    captured around the hooked model -> the reference-vs-reference band."""
+    import json as _json
+    import tempfile as _tf
+
+    gpu = not dry_run_on_cpu()
+    loader = run_loader() if gpu else None
+    ns = install()
+    arch = ARCH.get(dims_name, "llama")
+    assert arch == "llama", "the runner run uses the Llama checkpoint layout"
+    H, I, L, Hq, Hkv, D, V = DIMS[dims_name]
+    d = Path(_tf.mkdtemp(prefix="ref_model_ckpt_"))
+    (d / "config.json").write_text(_json.dumps(dict(
+        architectures=["LlamaForCausalLM"], model_type="llama", hidden_size=H, intermediate_size=I, num_hidden_layers=L,
+        num_attention_heads=Hq, num_key_value_heads=Hkv, head_dim=D, vocab_size=V, max_position_embeddings=2048, rope_theta=ROPE_THETA[arch],
+        rms_norm_eps=EPS[arch], tie_word_embeddings=False, torch_dtype="bfloat16", hidden_act="silu", bos_token_id=1, eos_token_id=2)))
+    if not gpu:
+        from sglang.kernels import fused_op as FO
+        from sglang.kernels.spec import KernelBackend
+
+        FO.set_fused_op_backend(KernelBackend.TORCH)
+        common = importlib.import_module("sglang.srt.utils.common")
+        common.get_device_memory_capacity = ns.server_args.get_device_memory_capacity = lambda device=None: 288 * 1024   # (no rocminfo here)
+        ns.distributed_parallel_state.is_cuda_alike = lambda: False
+    else:
+        # ServerArgs sizes its defaults from the device memory; the reference parses `rocm-smi` for it (utils/common.py:585-600),
+        # which this box's image may not answer -- then the same number comes from the driver
+        common = importlib.import_module("sglang.srt.utils.common")
+        try:
+            common.get_device_memory_capacity("cuda")
+        except Exception:                                   # noqa: BLE001
+            mib = torch.cuda.mem_get_info()[1] // (1 << 20)
+            common.get_device_memory_capacity = ns.server_args.get_device_memory_capacity = lambda device=None: mib
+    OB = importlib.import_module("sglang.benchmark.one_batch")
+    # ---- what one_batch.load_model does (one_batch.py:299-362), minus the tokenizer -------------------------------------------
+    sa = ns.server_args.ServerArgs(
+        model_path=str(d), load_format="dummy", skip_tokenizer_init=True, dtype="bfloat16", device="cuda" if gpu else "cpu",
+        attention_backend=None if gpu else "torch_native", sampling_backend=loader["default_attention_backend"] if gpu else "pytorch",
+        max_total_tokens=8192, max_running_requests=16, cuda_graph_max_bs_decode=8, mem_fraction_static=0.3, disable_radix_cache=True,
+        random_seed=3)
+    model_config = importlib.import_module("sglang.srt.configs.model_config").ModelConfig.from_server_args(sa)
+    ps = importlib.import_module("sglang.srt.distributed.parallel_state_wrapper").ParallelState.trivial(gpu_id=0)
+    MR = importlib.import_module("sglang.srt.model_executor.model_runner")
+    counts = dict(fused_decode_models=0, graph_replays=0)
+    if gpu:
+        import sglang_amd.fused_decode as fd
+
+        decode_model = fd.decode_model
+
+        def counting_decode_model(*a, **k):
+            counts["fused_decode_models"] += 1
+            return decode_model(*a, **k)
+
+        fd.decode_model = counting_decode_model
+    runner = MR.ModelRunner(model_config=model_config, mem_fraction_static=sa.mem_fraction_static, gpu_id=0, ps=ps,
+                            nccl_port=29500 + os.getpid() % 400, server_args=sa)
+    runner.alloc_memory_pool()
+    runner.init_attention_backends()
+    # real weights instead of the dummy loader's +-1e-3 noise: in place, through the reference's own load_weights
+    runner.model.load_weights(list(hf_checkpoint(DIMS[dims_name], runner.device, arch=arch).items()))
+    runner.init_cuda_graphs()
+    captured = counts["fused_decode_models"]
+    graph_runner = getattr(runner, "decode_cuda_graph_runner", None)
+    if graph_runner is not None and hasattr(graph_runner, "execute"):
+        execute = graph_runner.execute
+
+        def counting_execute(*a, **k):
+            counts["graph_replays"] += 1
+            return execute(*a, **k)
+
+        graph_runner.execute = counting_execute
+    # ---- the oracle on the runner's own parameters, pools and slots -----------------------------------------------------------
+    from oracle.model import OracleLM
+    from sglang_amd.harness.models import ModelConfig as OCfg
+
+    ocfg = OCfg("ref", H, I, L, Hq, Hkv, D, V, EPS[arch], ROPE_THETA[arch], None, 2048)
+    dev = runner.device
+    w = oracle_weights(runner.model)
+    slots = int(runner.token_to_kv_pool.size) + int(runner.page_size) + 8
+    olm = OracleLM(ocfg, w, num_slots=slots, max_ctx=8, max_reqs=1, device=dev)
+    olm32 = OracleLM(ocfg, w, num_slots=slots, max_ctx=8, max_reqs=1, device=dev, compute_dtype=torch.float32) if gpu else None
+    records = []
+
+    def check(what, batch, logits, decode_):
+        seq = batch.seq_lens.to(dev)
+        if decode_:
+            positions, prefix, extend = (seq - 1).to(torch.int64), None, None
+        else:
+            prefix = torch.tensor(batch.prefix_lens, device=dev)
+            extend = torch.tensor(batch.extend_lens, device=dev)
+            positions = torch.cat([torch.arange(p, p + e) for p, e in zip(batch.prefix_lens, batch.extend_lens)]).to(dev)
+        outs = []
+        for o in (olm, olm32):
+            if o is None:
+                outs.append(None)
+                continue
+            o.req_to_token = runner.req_to_token_pool.req_to_token            # the reference pool's own table (read only)
+            outs.append(o.forward(batch.input_ids.to(dev), positions, batch.req_pool_indices.to(dev), seq, prefix, extend,
+                                  batch.out_cache_loc.to(dev), decode_).float().cpu())
+        records.append(dict(what=what, got=logits.float().cpu(), want=outs[0], want32=outs[1]))
+
+    # ---- the reference's correctness test, with token ids instead of prompts (one_batch.py:377-437, 677-727) -------------------
+    from array import array
+
+    g = torch.Generator().manual_seed(11)
+    cut, lens = 24, [61, 130, 37]
+    ids = [torch.randint(3, V, (n,), generator=g).tolist() for n in lens]
+    sp = importlib.import_module("sglang.srt.sampling.sampling_params").SamplingParams(temperature=0, max_new_tokens=8)
+    Req = importlib.import_module("sglang.srt.managers.schedule_batch").Req
+    reqs = []
+    for i, t in enumerate(ids):
+        req = Req(rid=i, origin_input_text="", origin_input_ids=array("q", t[:cut]), sampling_params=sp)
+        req.full_untruncated_fill_ids = req.origin_input_ids
+        req.logprob_start_len = -1
+        req.set_extend_range(len(req.prefix_indices), len(req.origin_input_ids))
+        reqs.append(req)
+    with torch.no_grad():
+        nxt, logits, batch = OB.extend(reqs, runner)
+        check(f"prefill of the first {cut} tokens (3 requests)", batch, logits, False)
+        for i, req in enumerate(reqs):                                       # prepare_extend_inputs_for_correctness_test
+            req.full_untruncated_fill_ids.extend(ids[i][cut:])
+            req.prefix_indices = runner.req_to_token_pool.req_to_token[req.req_pool_idx, :cut].to(req.prefix_indices.dtype)
+            req.logprob_start_len = -1
+            req.set_extend_range(len(req.prefix_indices), len(req.full_untruncated_fill_ids))
+        nxt, logits, batch = OB.extend(reqs, runner)
+        check(f"extend over the {cut}-token cached prefix (37 + 106 + 13 new tokens)", batch, logits, False)
+        sampled = [nxt.tolist()]
+        for step in range(4):
+            nxt, logits = OB.decode(nxt, batch, runner)
+            check(f"decode step {step} (3 requests)", batch, logits, True)
+            sampled.append(nxt.tolist())
+    passes = []
+    for r in records:
+        ps_ = dict(what=r["what"], identical=bool(torch.equal(r["got"], r["want"])), max_abs=float((r["got"] - r["want"]).abs().max()),
+                   ref_rms=float(r["want"].pow(2).mean().sqrt()), argmax_equal=bool(torch.equal(r["got"].argmax(-1), r["want"].argmax(-1))))
+        if r["want32"] is not None:
+            e_p, e_r = r["got"] - r["want32"], r["want"] - r["want32"]
+            ps_.update(product_rms_err=float(e_p.pow(2).mean().sqrt()), reference_rms_err=float(e_r.pow(2).mean().sqrt()),
+                       product_max_err=float(e_p.abs().max()), reference_max_err=float(e_r.abs().max()))
+        passes.append(ps_)
+    import gen_golden as G
+
+    return dict(mode="runner", dims=dims_name, device=str(dev), loader=loader, attention_backend=sa.attention_backend,
+                attn_backend_class=type(runner.attn_backend).__name__, sampler_class=type(runner.sampler).__name__,
+                model=type(runner.model).__name__, kv_pool=type(runner.token_to_kv_pool).__name__,
+                allocator=type(runner.token_to_kv_pool_allocator).__name__, max_total_num_tokens=int(runner.max_total_num_tokens),
+                graph_runner=type(graph_runner).__name__ if graph_runner is not None else None,
+                captured_batch_sizes=sorted(getattr(graph_runner, "capture_bs", []) or []) if graph_runner is not None else [],
+                fused_decode_models_during_capture=captured, counts=counts, sampled=sampled, passes=passes,
+                unstaged_reference_modules=sorted(set(getattr(G, "NOT_FOUND", []))))
+
+
+# The staged copy is the reference's whole python tree (.py files) minus the model zoo: with a GPU present the reference takes
+# import branches the build container cannot execute (Triton kernels, ROCm-only modules, the graph runners), and a module missing
+# from the staged copy would silently become a stub.
+STAGE_EXCLUDE = ("sglang/srt/models/",)       # ~200 model files; only the ones below travel (the model registry walks what is there)
 STAGE_FILES = ("sglang/srt/models/llama.py", "sglang/srt/models/qwen2.py", "sglang/srt/models/mixtral.py", "sglang/srt/models/utils.py",
-               "sglang/srt/models/registry.py")
+               "sglang/srt/models/registry.py", "sglang/srt/models/__init__.py")
 
 
 def stage() -> None:
-    """Build container: run the dry-run legs (so that every lazily imported reference module is loaded), then copy the
-    reference files that were executed + STAGE_DIRS to oracle/_ref/sglang_model/ (git-ignored; travels with the gpurun
-    snapshot)."""
+    """Build container: copy the reference's python tree (minus the model zoo) to oracle/_ref/sglang_model/ (git-ignored; travels
+    with the gpurun snapshot)."""
     import shutil
 
     if not (R.CONTAINER_REF / "sglang").exists():
         raise SystemExit("/root/reference not present: staging only works in the build container")
-    ns = install(R.CONTAINER_REF)
-    for dims_name in ("tiny", "tiny_qwen2", "tiny_mixtral"):
-        run_cpu_oracle(dims_name)
-    run_loader()
-    failed = {name for name, _ in ns.hook.FAILED}
     files = set()
-    for name, mod in list(sys.modules.items()):
-        f = getattr(mod, "__file__", None)
-        if name.startswith("sglang") and f and R.CONTAINER_REF in Path(f).parents:      # (degraded modules too: the GPU box retries them)
-            files.add(Path(f))
-    for d in STAGE_DIRS:
-        files.update(p for p in (R.CONTAINER_REF / d).rglob("*.py"))
+    for f in (R.CONTAINER_REF / "sglang").rglob("*.py"):
+        rel = f.relative_to(R.CONTAINER_REF).as_posix()
+        if not any(rel.startswith(x) for x in STAGE_EXCLUDE):
+            files.add(f)
     files.update(R.CONTAINER_REF / f for f in STAGE_FILES if (R.CONTAINER_REF / f).exists())
-    for top in ("sglang", "sglang/srt", "sglang/kernels"):                      # the single-file modules next to the packages
-        files.update(p for p in (R.CONTAINER_REF / top).glob("*.py"))
     if STAGE.exists():
         shutil.rmtree(STAGE)
     for f in sorted(files):
@@ -767,7 +919,7 @@ def stage() -> None:
         dst.parent.mkdir(parents=True, exist_ok=True)
         shutil.copyfile(f, dst)
     total = sum(f.stat().st_size for f in files)
-    print(f"staged {len(files)} reference files ({total / 1e6:.1f} MB) under {STAGE}; degraded at import: {sorted(failed)}")
+    print(f"staged {len(files)} reference files ({total / 1e6:.1f} MB) under {STAGE}")
 
 
 if __name__ == "__main__":
@@ -775,7 +927,7 @@ if __name__ == "__main__":
     import json
 
     ap = argparse.ArgumentParser()
-    ap.add_argument("--run", choices=["cpu-oracle", "loader", "gpu", "stage"], required=True)
+    ap.add_argument("--run", choices=["cpu-oracle", "loader", "gpu", "runner", "stage"], required=True)
     ap.add_argument("--dims", default="tiny", choices=sorted(DIMS))
     ap.add_argument("--json", default=None)
     ap.add_argument("--tp", type=int, default=1, help="tensor-parallel ranks: this process launches itself N times (rank 0 reports)")
@@ -804,7 +956,8 @@ if __name__ == "__main__":
     if a.run == "stage":
         stage()
         sys.exit(0)
-    rep = {"cpu-oracle": lambda: run_cpu_oracle(a.dims), "loader": run_loader, "gpu": lambda: run_gpu(a.dims)}[a.run]()
+    rep = {"cpu-oracle": lambda: run_cpu_oracle(a.dims), "loader": run_loader, "gpu": lambda: run_gpu(a.dims),
+           "runner": lambda: run_runner(a.dims)}[a.run]()
     rep["tp"] = tp_world()[0]
     text = json.dumps(rep, indent=1)
     if tp_world()[1] != 0:

@@ -434,6 +434,12 @@ def test_plugin_load_runs_against_the_reference_contract(fake_sglang):
                                    req_to_token_pool=types.SimpleNamespace(req_to_token=torch.zeros((9, 96), dtype=torch.int32), size=8))
     be = factory(runner)
     assert isinstance(be, HipAttnBackend) and (be.num_q_heads, be.num_kv_heads, be.head_dim, be.max_context_len) == (8, 2, 64, 96)
+    # ... and an instance of the REFERENCE's AttentionBackend: the runners read `shared_read_ends`, `supports_ragged_verify_graph`,
+    # `on_after_cuda_graph_warmup` ... of a backend (decode_cuda_graph_runner.py:491, :724), which keep the reference's defaults
+    ref_base = g["sglang.srt.layers.attention.base_attn_backend"].AttentionBackend
+    assert isinstance(be, ref_base) and type(be).__mro__.index(HipAttnBackend) < type(be).__mro__.index(ref_base)
+    for name in ("shared_read_ends", "supports_ragged_verify_graph", "on_after_cuda_graph_warmup", "supports_full_cuda_graph_chunked_prefix"):
+        assert hasattr(be, name), name
     assert be.support_triton() is False and be.get_cuda_graph_seq_len_fill_value() == 1
 
     # sampler: a subclass of the reference Sampler with the gfx950 forward and the reference's own helpers

@@ -93,3 +93,33 @@ def test_plugin_under_the_references_model_stack(device, dims, tp):
         assert ps["argmax_agree"] == ps["clear_rows"] and ps["max_ulp"] <= 8.0, ps
     s = rep["legs"]["sampler"]
     assert s["is_reference_subclass"] and s["greedy_equals_argmax"] and s["seeded_ids_equal"], s
+
+
+def test_plugin_under_the_references_model_runner(device):
+    """The reference's `ModelRunner` itself, on MI355X with the plug-in (tests/golden/ref_model.py run_runner; its CPU twin:
+    tests/test_reference_model.py): `ServerArgs(attention_backend=None)` resolves the backend name from the out-of-tree platform,
+    `ModelRunner` builds the model, the pools (the platform's `get_mha_kv_pool_cls`), the backend (the registry's factory) and the
+    decode graphs (the platform's `get_graph_runner_cls` -> the reference's DecodeCudaGraphRunner capturing the hooked model at
+    every batch size), and the reference's static-batch harness `sglang.benchmark.one_batch` drives prefill / extend-over-prefix /
+    decode with real `Req` / `ScheduleBatch` objects; decode forwards are graph replays, sampling goes through `ModelRunner.sample`."""
+    import ref_model
+
+    if ref_model.ref_root() is None:
+        pytest.skip("reference sources are not staged (python tests/golden/ref_model.py --run stage in the build container)")
+    out = ROOT / "gpurun_out" / "reference_model_runner.json"
+    p = subprocess.run([sys.executable, str(ROOT / "tests" / "golden" / "ref_model.py"), "--run", "runner", "--json", str(out)],
+                       cwd=ROOT, env=dict(os.environ, SGLANG_USE_AITER="0"), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-6000:]
+    rep = json.loads(out.read_text())
+    assert rep["loader"]["out_of_tree"] and rep["attention_backend"] == "hip_mi355x"          # resolved by ServerArgs from the platform
+    assert (rep["attn_backend_class"], rep["sampler_class"], rep["model"], rep["kv_pool"]) == ("HipAttnBackend", "HipSampler", "LlamaForCausalLM",
+                                                                                                "MHATokenToKVPool")
+    assert rep["graph_runner"] == "DecodeCudaGraphRunner" and rep["captured_batch_sizes"], rep
+    # every capture ran the fused decode layer loop; the four decode steps were graph replays (no further eager decode forward)
+    assert rep["fused_decode_models_during_capture"] >= len(rep["captured_batch_sizes"])
+    assert rep["counts"] == {"fused_decode_models": rep["fused_decode_models_during_capture"], "graph_replays": 4}, rep["counts"]
+    assert [u for u in rep["unstaged_reference_modules"] if not u.startswith("sglang._version")] == []
+    assert len(rep["passes"]) == 6
+    for ps in rep["passes"]:
+        assert ps["product_rms_err"] <= 1.25 * ps["reference_rms_err"] + 1e-4, ps
+        assert ps["product_max_err"] <= 2.0 * ps["reference_max_err"] + 1e-3, ps
