@@ -52,33 +52,47 @@ def _plain_linear(lin) -> bool:
     return qm is None or type(qm).__name__ == "UnquantizedLinearMethod"
 
 
-def layer_fusable(layer, rows: int) -> bool:
-    """The layer is a dense Llama-style block whose four projections the weight-streaming GEMM takes at `rows` rows."""
+def layer_unfusable_reason(layer, rows: int) -> Optional[str]:
+    """Why this layer is NOT a dense Llama-style block whose four projections the weight-streaming GEMM takes at `rows` rows
+    (None when it is).  Also what `explain()` reports to someone asking why a model stays on the operator-by-operator path."""
     attn, mlp = getattr(layer, "self_attn", None), getattr(layer, "mlp", None)
     if attn is None or mlp is None or not hasattr(mlp, "gate_up_proj") or not hasattr(mlp, "down_proj"):
-        return False
-    if (type(layer).__name__, type(attn).__name__, type(mlp).__name__) not in FUSABLE_FORMS:
-        return False
-    lins = (attn.qkv_proj, attn.o_proj, mlp.gate_up_proj, mlp.down_proj)
-    if not all(_plain_linear(l) for l in lins):
-        return False
+        return "no self_attn / mlp.gate_up_proj / mlp.down_proj"
+    form = (type(layer).__name__, type(attn).__name__, type(mlp).__name__)
+    if form not in FUSABLE_FORMS:
+        return f"layer classes {form} are not one of {FUSABLE_FORMS}"
+    lins = dict(qkv_proj=attn.qkv_proj, o_proj=attn.o_proj, gate_up_proj=mlp.gate_up_proj, down_proj=mlp.down_proj)
+    for name, l in lins.items():
+        if not _plain_linear(l):
+            w = getattr(l, "weight", None)
+            return (f"{name} is not a plain bf16 projection (weight {getattr(w, 'dtype', None)} {tuple(getattr(w, 'shape', ()))} "
+                    f"strides {w.stride() if w is not None else None} cuda {getattr(w, 'is_cuda', None)}, quant_method "
+                    f"{type(getattr(l, 'quant_method', None)).__name__})")
     if getattr(attn.o_proj, "bias", None) is not None or getattr(mlp.gate_up_proj, "bias", None) is not None \
             or getattr(mlp.down_proj, "bias", None) is not None:
-        return False
+        return "o_proj / gate_up_proj / down_proj carry a bias"
     rope = attn.rotary_emb
     # plain cos / sin-cache ropes only (rotary_embedding/base.py:78 RotaryEmbedding, rope_variant.py:537
     # Llama3RotaryEmbedding: a scaled cache, the same forward); multimodal / long-rope / dual-chunk variants index the
     # cache differently and stay with the reference
     if type(rope).__name__ not in ("RotaryEmbedding", "Llama3RotaryEmbedding"):
-        return False
+        return f"rope class {type(rope).__name__}"
     if not getattr(rope, "is_neox_style", False) or getattr(rope, "rotary_dim", attn.head_dim) != attn.head_dim:
-        return False
+        return "rope is not neox-style over the whole head"
     if any(hasattr(attn, n) for n in ("q_norm", "k_norm")):            # (qwen3-style per-head norms: another layer form)
-        return False
+        return "per-head q / k norms"
     hidden = attn.qkv_proj.weight.shape[1]
     if hidden % 128 != 0 or hidden > 16384 or mlp.gate_up_proj.weight.shape[0] % 32 != 0:
-        return False
-    return all(kernels.wstream_preferred(rows, *l.weight.shape) for l in lins)
+        return f"hidden size {hidden} / gate_up rows {mlp.gate_up_proj.weight.shape[0]} outside the kernels' tiling"
+    for name, l in lins.items():
+        if not kernels.wstream_preferred(rows, *l.weight.shape):
+            return f"{name} {tuple(l.weight.shape)} at {rows} rows is left to the library GEMM"
+    return None
+
+
+def layer_fusable(layer, rows: int) -> bool:
+    """The layer is a dense Llama-style block whose four projections the weight-streaming GEMM takes at `rows` rows."""
+    return layer_unfusable_reason(layer, rows) is None
 
 
 def decode_layer(layer, positions: torch.Tensor, normed: torch.Tensor, forward_batch, residual: torch.Tensor,
@@ -156,6 +170,45 @@ def model_fusable(model, hidden_states: torch.Tensor, forward_batch, comm=None) 
     except Exception:
         return False
     return True
+
+
+def explain(model, forward_batch, hidden_states=None, input_embeds=None, pp_proxy_tensors=None) -> Optional[str]:
+    """Why a forward of `model` (a LlamaModel / Qwen2Model) would NOT run the fused decode layer loop -- the first failing
+    condition of the hook below, in words -- or None when it would.  For users and tests: the hook itself never raises."""
+    if input_embeds is not None or pp_proxy_tensors is not None:
+        return "input_embeds / pp_proxy_tensors given"
+    if getattr(model, "layers_to_capture", None):
+        return "aux hidden states are captured (layers_to_capture)"
+    pp = getattr(model, "pp_group", None)
+    if pp is not None and not (pp.is_first_rank and pp.is_last_rank):
+        return "a pipeline stage"
+    if getattr(model, "start_layer", 0) != 0 or getattr(model, "end_layer", len(model.layers)) != len(model.layers):
+        return "start_layer / end_layer do not span the model"
+    mode = getattr(forward_batch, "forward_mode", None)
+    if mode is None or not mode.is_decode():
+        return f"forward mode {mode} is not DECODE"
+    tp, comm = _tp()
+    if tp > 1 and comm is None:
+        return f"TP = {tp} without an xGMI communicator on the TP group"
+    positions = getattr(forward_batch, "positions", None)
+    if positions is not None and positions.dim() != 1:
+        return "positions are not one-dimensional"
+    if hidden_states is not None and not (hidden_states.is_cuda and hidden_states.dtype == _BF16 and hidden_states.dim() == 2):
+        return f"hidden states {hidden_states.dtype} {tuple(hidden_states.shape)} cuda={hidden_states.is_cuda}"
+    rows = hidden_states.shape[0] if hidden_states is not None else int(forward_batch.batch_size)
+    if len(model.layers) == 0:
+        return "no layers"
+    for i, layer in enumerate(model.layers):
+        why = layer_unfusable_reason(layer, rows)
+        if why is not None:
+            return f"layer {i}: {why}"
+    try:
+        from .layers.attention.hip_backend import pool_kernel_format
+
+        pool_kernel_format(forward_batch.token_to_kv_pool, model.layers[0].self_attn.attn)
+    except Exception as e:                      # noqa: BLE001
+        return f"KV pool format: {type(e).__name__}: {e}"
+    return None
 
 
 def llama_model_forward_hook(original, self, input_ids, positions, forward_batch, input_embeds=None, pp_proxy_tensors=None):

@@ -793,6 +793,23 @@ def run_runner(dims_name="tiny") -> dict:
             return decode_model(*a, **k)
 
         fd.decode_model = counting_decode_model
+        # when a decode forward does NOT take the fused loop, say why (fused_decode.explain) -- first occurrence
+        hook_orig = fd._reference_model_applies
+        why = counts.setdefault("not_fused_because", [])
+
+        def recording_applies(model, forward_batch, input_embeds, pp_proxy_tensors):
+            ok = hook_orig(model, forward_batch, input_embeds, pp_proxy_tensors)
+            mode = getattr(forward_batch, "forward_mode", None)
+            if mode is not None and mode.is_decode() and len(why) < 3:
+                try:
+                    reason = fd.explain(model, forward_batch, None, input_embeds, pp_proxy_tensors)
+                except Exception as e:                      # noqa: BLE001
+                    reason = f"explain raised {type(e).__name__}: {e}"
+                if reason is not None:
+                    why.append(reason)
+            return ok
+
+        fd._reference_model_applies = recording_applies
     runner = MR.ModelRunner(model_config=model_config, mem_fraction_static=sa.mem_fraction_static, gpu_id=0, ps=ps,
                             nccl_port=29500 + os.getpid() % 400, server_args=sa)
     runner.alloc_memory_pool()
