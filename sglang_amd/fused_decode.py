@@ -95,6 +95,28 @@ def layer_fusable(layer, rows: int) -> bool:
     return layer_unfusable_reason(layer, rows) is None
 
 
+def kv_pool_of(forward_batch):
+    """The KV pool of the running forward.  The reference does not hang the pools on the ForwardBatch: they are resolved through the
+    active attention backend (model_executor/forward_context.py:70-76 get_token_to_kv_pool -> get_attn_backend().token_to_kv_pool,
+    published by ModelRunner._forward_raw and by the graph runners around model.forward); this package's own harness batch
+    carries the pool itself."""
+    pool = getattr(forward_batch, "token_to_kv_pool", None)
+    if pool is not None:
+        return pool
+    try:
+        from sglang.srt.model_executor.forward_context import get_token_to_kv_pool, has_forward_context
+
+        if has_forward_context():
+            return get_token_to_kv_pool()
+    except ImportError:
+        pass
+    backend = getattr(forward_batch, "attn_backend", None)
+    pool = getattr(backend, "token_to_kv_pool", None)
+    if pool is None:
+        raise AttributeError("no KV pool: neither forward_batch.token_to_kv_pool, an active forward context, nor forward_batch.attn_backend")
+    return pool
+
+
 def decode_layer(layer, positions: torch.Tensor, normed: torch.Tensor, forward_batch, residual: torch.Tensor,
                  next_norm, comm=None) -> torch.Tensor:
     """One layer of the fused form: `normed` = this layer's input_layernorm output (row-major or chunk-major), `residual`
@@ -105,7 +127,7 @@ def decode_layer(layer, positions: torch.Tensor, normed: torch.Tensor, forward_b
     from .layers.attention.hip_backend import pool_kernel_format
 
     attn, mlp = layer.self_attn, layer.mlp
-    pool = forward_batch.token_to_kv_pool
+    pool = kv_pool_of(forward_batch)
     layer_id = attn.attn.layer_id
     fmt = pool_kernel_format(pool, attn.attn)
     plain = not fmt["kv_fp8"] and not fmt["hnd"]
@@ -166,7 +188,7 @@ def model_fusable(model, hidden_states: torch.Tensor, forward_batch, comm=None) 
     try:
         from .layers.attention.hip_backend import pool_kernel_format
 
-        pool_kernel_format(forward_batch.token_to_kv_pool, model.layers[0].self_attn.attn)
+        pool_kernel_format(kv_pool_of(forward_batch), model.layers[0].self_attn.attn)
     except Exception:
         return False
     return True
@@ -205,7 +227,7 @@ def explain(model, forward_batch, hidden_states=None, input_embeds=None, pp_prox
     try:
         from .layers.attention.hip_backend import pool_kernel_format
 
-        pool_kernel_format(forward_batch.token_to_kv_pool, model.layers[0].self_attn.attn)
+        pool_kernel_format(kv_pool_of(forward_batch), model.layers[0].self_attn.attn)
     except Exception as e:                      # noqa: BLE001
         return f"KV pool format: {type(e).__name__}: {e}"
     return None

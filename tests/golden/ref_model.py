@@ -382,8 +382,7 @@ class Job:
     def forward_batch(self, b, backend=None):
         fbi = self.fbi
         fb = fbi.ForwardBatch.init_new(b, self.runner, capture_hidden_mode=fbi.CaptureHiddenMode.NULL, return_hidden_states_before_norm=False)
-        fb.req_to_token_pool, fb.token_to_kv_pool, fb.attn_backend = self.r2t, self.kv, backend or self.backend   # model_runner.py: behind init_new
-        return fb
+        return fb               # (nothing is attached: the reference resolves pools and backend through the forward context)
 
     def oracle(self, b, fb, extend, prefix):
         dec = extend is None

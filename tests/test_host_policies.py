@@ -304,3 +304,17 @@ def test_two_stage_all_reduce_work_is_spread_over_the_ranks(world, rows, hidden,
     slack = 1 if epilogue else 4
     assert max(got) - min(got) <= slack * max(1, -(-total // (blocks * slack)) // world + 1), got
     assert max(got) <= -(-total // world) + slack * 2, got
+
+
+def test_fused_decode_resolves_the_kv_pool_like_the_reference():
+    """The reference's ForwardBatch carries no pools (they are reached through the active attention backend,
+    forward_context.py:70-76); this package's harness batch carries `token_to_kv_pool`.  kv_pool_of() takes either."""
+    import types
+
+    from sglang_amd import fused_decode
+
+    pool_a, pool_b = object(), object()
+    assert fused_decode.kv_pool_of(types.SimpleNamespace(token_to_kv_pool=pool_a)) is pool_a
+    assert fused_decode.kv_pool_of(types.SimpleNamespace(attn_backend=types.SimpleNamespace(token_to_kv_pool=pool_b))) is pool_b
+    with pytest.raises(AttributeError):
+        fused_decode.kv_pool_of(types.SimpleNamespace())
