@@ -187,6 +187,9 @@ DIMS = {
     "tiny_qwen2": (256, 384, 2, 4, 2, 64, 768),
     # Mixtral's block (8 experts, top-2, renormalised softmax router) at small dimensions
     "tiny_mixtral": (512, 512, 2, 8, 2, 64, 1024),
+    # BASELINE.json configs[1]'s architecture, whole depth (the latency run: dummy weights)
+    "llama3_8b": (4096, 14336, 32, 32, 8, 128, 128256),
+    "tiny_v16k": (256, 512, 2, 8, 2, 64, 16384),           # (the reference's synthetic prompts draw token ids below 10000)
 }
 ARCH = {"qwen2.5_0.5b": "qwen2", "tiny_qwen2": "qwen2", "tiny_mixtral": "mixtral"}      # default: llama
 ROPE_THETA = {"qwen2": 1000000.0, "llama": 10000.0, "mixtral": 1000000.0}
@@ -907,6 +910,93 @@ def run_runner(dims_name="tiny") -> dict:
                 unstaged_reference_modules=sorted(set(getattr(G, "NOT_FOUND", []))))
 
 
+def run_latency(dims_name="tiny", batch_size=4, input_len=16, output_len=4) -> dict:
+    """The reference's own latency benchmark -- `python -m sglang.bench_one_batch --load-format dummy --batch-size B --input-len I
+    --output-len O` (benchmark/one_batch.py:877-990 latency_test: one warm-up pass, then `latency_test_run_once`, whose
+    timing code and result record are the reference's) -- on the reference's ModelRunner with the plug-in loaded.  Static
+    batch, no shared prefix, every decode step a replay of the reference's DecodeCudaGraphRunner graph."""
+    import json as _json
+    import tempfile as _tf
+
+    gpu = not dry_run_on_cpu()
+    loader = run_loader() if gpu else None
+    ns = install()
+    H, I, L, Hq, Hkv, D, V = DIMS[dims_name]
+    d = Path(_tf.mkdtemp(prefix="ref_model_ckpt_"))
+    (d / "config.json").write_text(_json.dumps(dict(
+        architectures=["LlamaForCausalLM"], model_type="llama", hidden_size=H, intermediate_size=I, num_hidden_layers=L,
+        num_attention_heads=Hq, num_key_value_heads=Hkv, head_dim=D, vocab_size=V, max_position_embeddings=8192, rope_theta=500000.0,
+        rms_norm_eps=1e-5, tie_word_embeddings=False, torch_dtype="bfloat16", hidden_act="silu", bos_token_id=1, eos_token_id=2)))
+    common = importlib.import_module("sglang.srt.utils.common")
+    if not gpu:
+        from sglang.kernels import fused_op as FO
+        from sglang.kernels.spec import KernelBackend
+
+        FO.set_fused_op_backend(KernelBackend.TORCH)
+        common.get_device_memory_capacity = ns.server_args.get_device_memory_capacity = lambda device=None: 288 * 1024
+        ns.distributed_parallel_state.is_cuda_alike = lambda: False
+    else:
+        try:
+            common.get_device_memory_capacity("cuda")
+        except Exception:                                   # noqa: BLE001
+            mib = torch.cuda.mem_get_info()[1] // (1 << 20)
+            common.get_device_memory_capacity = ns.server_args.get_device_memory_capacity = lambda device=None: mib
+    OB = importlib.import_module("sglang.benchmark.one_batch")
+    tokens = batch_size * (input_len + output_len)
+    sa = ns.server_args.ServerArgs(
+        model_path=str(d), load_format="dummy", skip_tokenizer_init=True, dtype="bfloat16", device="cuda" if gpu else "cpu",
+        attention_backend=None if gpu else "torch_native", sampling_backend=loader["default_attention_backend"] if gpu else "pytorch",
+        max_total_tokens=tokens + 4096, max_running_requests=max(16, batch_size), cuda_graph_max_bs_decode=batch_size,
+        mem_fraction_static=0.5, disable_radix_cache=True, random_seed=3)
+    model_config = importlib.import_module("sglang.srt.configs.model_config").ModelConfig.from_server_args(sa)
+    ps = importlib.import_module("sglang.srt.distributed.parallel_state_wrapper").ParallelState.trivial(gpu_id=0)
+    MR = importlib.import_module("sglang.srt.model_executor.model_runner")
+    counts = dict(fused_decode_models=0, graph_replays=0)
+    if gpu:
+        import sglang_amd.fused_decode as fd
+
+        decode_model = fd.decode_model
+
+        def counting_decode_model(*a, **k):
+            counts["fused_decode_models"] += 1
+            return decode_model(*a, **k)
+
+        fd.decode_model = counting_decode_model
+    runner = MR.ModelRunner(model_config=model_config, mem_fraction_static=sa.mem_fraction_static, gpu_id=0, ps=ps,
+                            nccl_port=29500 + os.getpid() % 400, server_args=sa)
+    runner.alloc_memory_pool()
+    runner.init_attention_backends()
+    runner.init_cuda_graphs()
+    graph_runner = getattr(runner, "decode_cuda_graph_runner", None)
+    if graph_runner is not None and hasattr(graph_runner, "execute"):
+        execute = graph_runner.execute
+
+        def counting_execute(*a, **k):
+            counts["graph_replays"] += 1
+            return execute(*a, **k)
+
+        graph_runner.execute = counting_execute
+    bench_runner = OB._TorchBenchRunner(runner)
+    lines = []
+
+    def rank_print(*a, **k):
+        lines.append(" ".join(str(x) for x in a))
+
+    kw = dict(log_decode_step=0, profile=False, profile_record_shapes=False, profile_activities=("CPU", "GPU"), profile_prefix="",
+              profile_stage="all", tp_rank=0, profile_start_step=None, profile_steps=None)
+    reqs = OB.prepare_synthetic_inputs_for_latency_test(batch_size, input_len)
+    OB.latency_test_run_once("warmup", bench_runner, rank_print, reqs, batch_size, input_len, min(32, output_len), **kw)
+    counts_before = dict(counts)
+    reqs = OB.prepare_synthetic_inputs_for_latency_test(batch_size, input_len)
+    result = OB.latency_test_run_once("sglang_amd", bench_runner, rank_print, reqs, batch_size, input_len, output_len, **kw)
+    return dict(mode="latency", dims=dims_name, device=str(runner.device), attention_backend=sa.attention_backend,
+                attn_backend_class=type(runner.attn_backend).__name__, graph_runner=type(graph_runner).__name__ if graph_runner is not None else None,
+                result={k: (float(v) if not isinstance(v, (str, int)) else v) for k, v in (result or {}).items()},
+                graph_replays_in_the_measured_run=counts["graph_replays"] - counts_before["graph_replays"],
+                eager_fused_decode_forwards_in_the_measured_run=counts["fused_decode_models"] - counts_before["fused_decode_models"],
+                log=lines[-12:])
+
+
 # The staged copy is the reference's whole python tree (.py files) minus the model zoo: with a GPU present the reference takes
 # import branches the build container cannot execute (Triton kernels, ROCm-only modules, the graph runners), and a module missing
 # from the staged copy would silently become a stub.
@@ -943,9 +1033,10 @@ if __name__ == "__main__":
     import json
 
     ap = argparse.ArgumentParser()
-    ap.add_argument("--run", choices=["cpu-oracle", "loader", "gpu", "runner", "stage"], required=True)
+    ap.add_argument("--run", choices=["cpu-oracle", "loader", "gpu", "runner", "latency", "stage"], required=True)
     ap.add_argument("--dims", default="tiny", choices=sorted(DIMS))
     ap.add_argument("--json", default=None)
+    ap.add_argument("--shape", default="4,16,4", help="latency run: batch size, input length, output length")
     ap.add_argument("--tp", type=int, default=1, help="tensor-parallel ranks: this process launches itself N times (rank 0 reports)")
     a = ap.parse_args()
     if a.tp > 1 and "REF_MODEL_RANK" not in os.environ:
@@ -973,7 +1064,7 @@ if __name__ == "__main__":
         stage()
         sys.exit(0)
     rep = {"cpu-oracle": lambda: run_cpu_oracle(a.dims), "loader": run_loader, "gpu": lambda: run_gpu(a.dims),
-           "runner": lambda: run_runner(a.dims)}[a.run]()
+           "runner": lambda: run_runner(a.dims), "latency": lambda: run_latency(a.dims, *[int(x) for x in a.shape.split(",")])}[a.run]()
     rep["tp"] = tp_world()[0]
     text = json.dumps(rep, indent=1)
     if tp_world()[1] != 0:
