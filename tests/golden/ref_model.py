@@ -910,6 +910,166 @@ def run_runner(dims_name="tiny") -> dict:
                 unstaged_reference_modules=sorted(set(getattr(G, "NOT_FOUND", []))))
 
 
+def run_shared_prefix_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, unique=8, out=4) -> dict:
+    """BASELINE.json's job shape (configs[1]: `groups` x `per_group` requests, the first `prefix` tokens of a group's prompts shared,
+    `unique` own tokens, `out` generated tokens, greedy) THROUGH THE REFERENCE'S RUNNER: the group leaders are prefilled cold, the
+    other requests extend over the leader's slots (`req.prefix_indices` = what the radix cache hands a request whose prefix is
+    cached -- set the way the reference's own correctness test sets it, one_batch.py:422-437), the two batches are merged with
+    `ScheduleBatch.merge_batch` (what the scheduler does with a finished prefill batch) and decoded with
+    `prepare_for_decode` -> `ModelRunner.forward` (graph replay) -> `ModelRunner.sample`.  One warm-up job, then the timed job.
+    Build container: tiny model, real weights, every pass against the oracle (bit-identical).  MI355X: Llama-3-8B architecture, dummy
+    weights, wall-clock tokens/s beside what bench.py measures on this package's harness."""
+    import json as _json
+    import tempfile as _tf
+    import time
+    from array import array
+
+    gpu = not dry_run_on_cpu()
+    loader = run_loader() if gpu else None
+    ns = install()
+    H, I, L, Hq, Hkv, D, V = DIMS[dims_name]
+    d = Path(_tf.mkdtemp(prefix="ref_model_ckpt_"))
+    (d / "config.json").write_text(_json.dumps(dict(
+        architectures=["LlamaForCausalLM"], model_type="llama", hidden_size=H, intermediate_size=I, num_hidden_layers=L,
+        num_attention_heads=Hq, num_key_value_heads=Hkv, head_dim=D, vocab_size=V, max_position_embeddings=8192, rope_theta=ROPE_THETA["llama"],
+        rms_norm_eps=1e-5, tie_word_embeddings=False, torch_dtype="bfloat16", hidden_act="silu", bos_token_id=1, eos_token_id=2)))
+    common = importlib.import_module("sglang.srt.utils.common")
+    if not gpu:
+        from sglang.kernels import fused_op as FO
+        from sglang.kernels.spec import KernelBackend
+
+        FO.set_fused_op_backend(KernelBackend.TORCH)
+        common.get_device_memory_capacity = ns.server_args.get_device_memory_capacity = lambda device=None: 288 * 1024
+        ns.distributed_parallel_state.is_cuda_alike = lambda: False
+    else:
+        try:
+            common.get_device_memory_capacity("cuda")
+        except Exception:                                   # noqa: BLE001
+            mib = torch.cuda.mem_get_info()[1] // (1 << 20)
+            common.get_device_memory_capacity = ns.server_args.get_device_memory_capacity = lambda device=None: mib
+    OB = importlib.import_module("sglang.benchmark.one_batch")
+    B = groups * per_group
+    tokens = groups * (prefix + unique) + (B - groups) * unique + B * out
+    sa = ns.server_args.ServerArgs(
+        model_path=str(d), load_format="dummy", skip_tokenizer_init=True, dtype="bfloat16", device="cuda" if gpu else "cpu",
+        attention_backend=None if gpu else "torch_native", sampling_backend=loader["default_attention_backend"] if gpu else "pytorch",
+        max_total_tokens=tokens + 4096, max_running_requests=max(16, B), cuda_graph_max_bs_decode=B, mem_fraction_static=0.5,
+        disable_radix_cache=True, random_seed=3)
+    model_config = importlib.import_module("sglang.srt.configs.model_config").ModelConfig.from_server_args(sa)
+    ps = importlib.import_module("sglang.srt.distributed.parallel_state_wrapper").ParallelState.trivial(gpu_id=0)
+    MR = importlib.import_module("sglang.srt.model_executor.model_runner")
+    runner = MR.ModelRunner(model_config=model_config, mem_fraction_static=sa.mem_fraction_static, gpu_id=0, ps=ps,
+                            nccl_port=29500 + os.getpid() % 400, server_args=sa)
+    runner.alloc_memory_pool()
+    runner.init_attention_backends()
+    if not gpu:
+        runner.model.load_weights(list(hf_checkpoint(DIMS[dims_name], runner.device).items()))
+    runner.init_cuda_graphs()
+    dev = runner.device
+    counts = dict(graph_replays=0)
+    graph_runner = getattr(runner, "decode_cuda_graph_runner", None)
+    if graph_runner is not None and hasattr(graph_runner, "execute"):
+        execute = graph_runner.execute
+
+        def counting_execute(*a, **k):
+            counts["graph_replays"] += 1
+            return execute(*a, **k)
+
+        graph_runner.execute = counting_execute
+    olm, records = None, []
+    if not gpu:
+        from oracle.model import OracleLM
+        from sglang_amd.harness.models import ModelConfig as OCfg
+
+        olm = OracleLM(OCfg("ref", H, I, L, Hq, Hkv, D, V, 1e-5, ROPE_THETA["llama"], None, 8192), oracle_weights(runner.model),
+                       num_slots=int(runner.token_to_kv_pool.size) + 16, max_ctx=8, max_reqs=1, device=dev)
+
+    def check(what, batch, logits, decode_):
+        if olm is None:
+            return
+        seq = batch.seq_lens.to(dev)
+        if decode_:
+            positions, pre, ext = (seq - 1).to(torch.int64), None, None
+        else:
+            pre, ext = torch.tensor(batch.prefix_lens, device=dev), torch.tensor(batch.extend_lens, device=dev)
+            positions = torch.cat([torch.arange(p, p + e) for p, e in zip(batch.prefix_lens, batch.extend_lens)]).to(dev)
+        olm.req_to_token = runner.req_to_token_pool.req_to_token
+        want = olm.forward(batch.input_ids.to(dev), positions, batch.req_pool_indices.to(dev), seq, pre, ext, batch.out_cache_loc.to(dev),
+                           decode_).float().cpu()
+        records.append(dict(what=what, identical=bool(torch.equal(logits.float().cpu(), want)), ref_rms=float(want.pow(2).mean().sqrt())))
+
+    SP = importlib.import_module("sglang.srt.sampling.sampling_params").SamplingParams
+    Req = importlib.import_module("sglang.srt.managers.schedule_batch").Req
+    g = torch.Generator().manual_seed(5)
+
+    def make_req(rid, ids, upto):
+        req = Req(rid=rid, origin_input_text="", origin_input_ids=array("q", ids[:upto]), sampling_params=SP(temperature=0, max_new_tokens=out))
+        req.full_untruncated_fill_ids = req.origin_input_ids
+        req.logprob_start_len = -1
+        req.set_extend_range(len(req.prefix_indices), len(req.origin_input_ids))
+        return req
+
+    def job(tag):
+        runner.req_to_token_pool.clear()
+        runner.token_to_kv_pool_allocator.clear()
+        shared = [torch.randint(3, min(V, 10000), (prefix,), generator=g).tolist() for _ in range(groups)]
+        own = [[torch.randint(3, min(V, 10000), (unique,), generator=g).tolist() for _ in range(per_group)] for _ in range(groups)]
+        if gpu:
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        leaders = [make_req(gi * per_group, shared[gi] + own[gi][0], prefix + unique) for gi in range(groups)]
+        nxt_a, logits, batch = OB.extend(leaders, runner)                       # cold prefill of one request per group
+        check(f"{tag}: cold prefill of {groups} group leaders ({prefix} + {unique} tokens)", batch, logits, False)
+        others = []
+        for gi in range(groups):
+            for j in range(1, per_group):
+                req = make_req(gi * per_group + j, shared[gi] + own[gi][j], prefix + unique)
+                # the radix hit: this request's first `prefix` tokens are the leader's slots (one_batch.py:429-433)
+                req.prefix_indices = runner.req_to_token_pool.req_to_token[leaders[gi].req_pool_idx, :prefix].to(req.prefix_indices.dtype)
+                req.set_extend_range(len(req.prefix_indices), len(req.full_untruncated_fill_ids))
+                others.append(req)
+        if gpu:
+            torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        nxt_b, logits, batch_b = OB.extend(others, runner)                     # warm prefill over the cached prefixes
+        check(f"{tag}: warm prefill of {len(others)} requests over a {prefix}-token cached prefix", batch_b, logits, False)
+        if gpu:
+            torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        batch.merge_batch(batch_b)                                              # scheduler: running_batch.merge_batch(last_batch)
+        nxt = torch.cat([nxt_a, nxt_b])
+        lat = []
+        for step in range(out - 1):
+            ts = time.perf_counter()
+            nxt, logits = OB.decode(nxt, batch, runner)
+            if step < 3:
+                check(f"{tag}: decode step {step} ({B} requests, {groups} shared prefixes)", batch, logits, True)
+            if gpu:
+                torch.cuda.synchronize()
+            lat.append(time.perf_counter() - ts)
+        t3 = time.perf_counter()
+        med = sorted(lat)[len(lat) // 2] if lat else 0.0
+        return dict(seconds=t3 - t0, cold_prefill_s=t1 - t0, warm_prefill_s=t2 - t1, decode_s=t3 - t2, median_decode_step_s=med,
+                    output_tokens_per_s=B * out / (t3 - t0))
+
+    with torch.no_grad():
+        warm = job("warm-up job")
+        before = counts["graph_replays"]
+        timed = job("timed job")
+    plan = None
+    ws = getattr(runner.attn_backend, "_cascade_ws", None)
+    if ws is not None:
+        try:
+            plan = dict(zip(("items", "groups", "member_rows"), ws.plan[:3].tolist()))     # cascade_plan.hpp header of the last decode step
+        except Exception:                                   # noqa: BLE001
+            plan = None
+    return dict(mode="shared-prefix-job", dims=dims_name, device=str(dev), shape=dict(groups=groups, per_group=per_group, prefix=prefix, unique=unique, out=out),
+                attention_backend=sa.attention_backend, attn_backend_class=type(runner.attn_backend).__name__,
+                graph_runner=type(graph_runner).__name__ if graph_runner is not None else None,
+                graph_replays_in_the_timed_job=counts["graph_replays"] - before, warm_up=warm, timed=timed, cascade_plan_last_step=plan,
+                passes=records)
+
+
 def run_latency(dims_name="tiny", batch_size=4, input_len=16, output_len=4) -> dict:
     """The reference's own latency benchmark -- `python -m sglang.bench_one_batch --load-format dummy --batch-size B --input-len I
     --output-len O` (benchmark/one_batch.py:877-990 latency_test: one warm-up pass, then `latency_test_run_once`, whose
@@ -1033,10 +1193,11 @@ if __name__ == "__main__":
     import json
 
     ap = argparse.ArgumentParser()
-    ap.add_argument("--run", choices=["cpu-oracle", "loader", "gpu", "runner", "latency", "stage"], required=True)
+    ap.add_argument("--run", choices=["cpu-oracle", "loader", "gpu", "runner", "latency", "shared-prefix", "stage"], required=True)
     ap.add_argument("--dims", default="tiny", choices=sorted(DIMS))
     ap.add_argument("--json", default=None)
     ap.add_argument("--shape", default="4,16,4", help="latency run: batch size, input length, output length")
+    ap.add_argument("--job", default="2,2,16,8,4", help="shared-prefix run: groups, requests per group, shared tokens, own tokens, output tokens")
     ap.add_argument("--tp", type=int, default=1, help="tensor-parallel ranks: this process launches itself N times (rank 0 reports)")
     a = ap.parse_args()
     if a.tp > 1 and "REF_MODEL_RANK" not in os.environ:
@@ -1064,7 +1225,8 @@ if __name__ == "__main__":
         stage()
         sys.exit(0)
     rep = {"cpu-oracle": lambda: run_cpu_oracle(a.dims), "loader": run_loader, "gpu": lambda: run_gpu(a.dims),
-           "runner": lambda: run_runner(a.dims), "latency": lambda: run_latency(a.dims, *[int(x) for x in a.shape.split(",")])}[a.run]()
+           "runner": lambda: run_runner(a.dims), "latency": lambda: run_latency(a.dims, *[int(x) for x in a.shape.split(",")]),
+           "shared-prefix": lambda: run_shared_prefix_job(a.dims if a.dims != "tiny" else "tiny_v16k", *[int(x) for x in a.job.split(",")])}[a.run]()
     rep["tp"] = tp_world()[0]
     text = json.dumps(rep, indent=1)
     if tp_world()[1] != 0:
