@@ -1009,7 +1009,7 @@ def run_shared_prefix_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=1
         req.set_extend_range(len(req.prefix_indices), len(req.origin_input_ids))
         return req
 
-    def job(tag):
+    def job(tag, sync_every_step):
         runner.req_to_token_pool.clear()
         runner.token_to_kv_pool_allocator.clear()
         shared = [torch.randint(3, min(V, 10000), (prefix,), generator=g).tolist() for _ in range(groups)]
@@ -1044,18 +1044,22 @@ def run_shared_prefix_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=1
             nxt, logits = OB.decode(nxt, batch, runner)
             if step < 3:
                 check(f"{tag}: decode step {step} ({B} requests, {groups} shared prefixes)", batch, logits, True)
-            if gpu:
+            if gpu and sync_every_step:
                 torch.cuda.synchronize()
             lat.append(time.perf_counter() - ts)
+        if gpu:
+            torch.cuda.synchronize()
         t3 = time.perf_counter()
         med = sorted(lat)[len(lat) // 2] if lat else 0.0
-        return dict(seconds=t3 - t0, cold_prefill_s=t1 - t0, warm_prefill_s=t2 - t1, decode_s=t3 - t2, median_decode_step_s=med,
+        return dict(seconds=t3 - t0, cold_prefill_s=t1 - t0, warm_prefill_s=t2 - t1, decode_s=t3 - t2,
+                    decode_s_per_step=(t3 - t2) / max(1, out - 1), median_synchronised_step_s=med if sync_every_step else None,
                     output_tokens_per_s=B * out / (t3 - t0))
 
     with torch.no_grad():
-        warm = job("warm-up job")
+        warm = job("warm-up job", True)
+        stepwise = job("step-synchronised job", True)        # a device synchronise after every decode step: per-step latency
         before = counts["graph_replays"]
-        timed = job("timed job")
+        timed = job("timed job", False)                       # synchronised at the phase boundaries only: throughput
     plan = None
     ws = getattr(runner.attn_backend, "_cascade_ws", None)
     if ws is not None:
@@ -1066,7 +1070,8 @@ def run_shared_prefix_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=1
     return dict(mode="shared-prefix-job", dims=dims_name, device=str(dev), shape=dict(groups=groups, per_group=per_group, prefix=prefix, unique=unique, out=out),
                 attention_backend=sa.attention_backend, attn_backend_class=type(runner.attn_backend).__name__,
                 graph_runner=type(graph_runner).__name__ if graph_runner is not None else None,
-                graph_replays_in_the_timed_job=counts["graph_replays"] - before, warm_up=warm, timed=timed, cascade_plan_last_step=plan,
+                graph_replays_in_the_timed_job=counts["graph_replays"] - before, warm_up=warm, step_synchronised=stepwise, timed=timed,
+                cascade_plan_last_step=plan,
                 passes=records)
 
 
