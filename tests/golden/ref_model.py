@@ -910,7 +910,7 @@ def run_runner(dims_name="tiny") -> dict:
                 unstaged_reference_modules=sorted(set(getattr(G, "NOT_FOUND", []))))
 
 
-def run_shared_prefix_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, unique=8, out=4) -> dict:
+def run_shared_prefix_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, unique=8, out=4, radix=False) -> dict:
     """BASELINE.json's job shape (configs[1]: `groups` x `per_group` requests, the first `prefix` tokens of a group's prompts shared,
     `unique` own tokens, `out` generated tokens, greedy) THROUGH THE REFERENCE'S RUNNER: the group leaders are prefilled cold, the
     other requests extend over the leader's slots (`req.prefix_indices` = what the radix cache hands a request whose prefix is
@@ -918,7 +918,13 @@ def run_shared_prefix_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=1
     `ScheduleBatch.merge_batch` (what the scheduler does with a finished prefill batch) and decoded with
     `prepare_for_decode` -> `ModelRunner.forward` (graph replay) -> `ModelRunner.sample`.  One warm-up job, then the timed job.
     Build container: tiny model, real weights, every pass against the oracle (bit-identical).  MI355X: Llama-3-8B architecture, dummy
-    weights, wall-clock tokens/s beside what bench.py measures on this package's harness."""
+    weights, wall-clock tokens/s beside what bench.py measures on this package's harness.
+
+    `radix=True`: the prefixes come out of the reference's REAL `RadixCache` instead: every request goes through
+    `Req.init_next_round_input(tree_cache)` (RadixCache.match_prefix -> prefix_indices, last_node), the batches are built on the tree
+    (`ScheduleBatch.init_new(tree_cache=...)`, so allocation may evict from it), and after each prefill the scheduler's
+    `tree_cache.cache_unfinished_req(req)` inserts the request's tokens -- the other requests of a group then HIT the leader's
+    `prefix` tokens; `cache_finished_req` releases everything at the end of the job."""
     import json as _json
     import tempfile as _tf
     import time
@@ -954,7 +960,7 @@ def run_shared_prefix_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=1
         model_path=str(d), load_format="dummy", skip_tokenizer_init=True, dtype="bfloat16", device="cuda" if gpu else "cpu",
         attention_backend=None if gpu else "torch_native", sampling_backend=loader["default_attention_backend"] if gpu else "pytorch",
         max_total_tokens=tokens + 4096, max_running_requests=max(16, B), cuda_graph_max_bs_decode=B, mem_fraction_static=0.5,
-        disable_radix_cache=True, random_seed=3)
+        disable_radix_cache=not radix, random_seed=3)
     model_config = importlib.import_module("sglang.srt.configs.model_config").ModelConfig.from_server_args(sa)
     ps = importlib.import_module("sglang.srt.distributed.parallel_state_wrapper").ParallelState.trivial(gpu_id=0)
     MR = importlib.import_module("sglang.srt.model_executor.model_runner")
@@ -966,6 +972,31 @@ def run_shared_prefix_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=1
         runner.model.load_weights(list(hf_checkpoint(DIMS[dims_name], runner.device).items()))
     runner.init_cuda_graphs()
     dev = runner.device
+    tree = None
+    if radix:
+        RC = importlib.import_module("sglang.srt.mem_cache.radix_cache").RadixCache
+        CIP = importlib.import_module("sglang.srt.mem_cache.cache_init_params").CacheInitParams
+        tree = RC(CIP(disable=False, req_to_token_pool=runner.req_to_token_pool, token_to_kv_pool_allocator=runner.token_to_kv_pool_allocator,
+                      page_size=int(runner.page_size)))
+        SB = importlib.import_module("sglang.srt.managers.schedule_batch")
+        SpecNone = importlib.import_module("sglang.srt.speculative.spec_info").SpeculativeAlgorithm.NONE
+        FBI = ns.forward_batch_info
+
+        def extend_on_tree(reqs):
+            """one_batch.extend (one_batch.py:487-523) with the real tree instead of its dummy namespace."""
+            b = SB.ScheduleBatch.init_new(reqs=reqs, req_to_token_pool=runner.req_to_token_pool,
+                                          token_to_kv_pool_allocator=runner.token_to_kv_pool_allocator, tree_cache=tree,
+                                          model_config=runner.model_config, enable_overlap=False, spec_algorithm=SpecNone)
+            b.prepare_for_extend()
+            OB._maybe_prepare_mlp_sync_batch(b, runner)
+            if b.input_ids is None and getattr(b, "prefill_input_ids_cpu", None) is not None:
+                b.input_ids = b.prefill_input_ids_cpu.to(b.device, non_blocking=True)
+                b.prefill_input_ids_cpu = None
+            fb = FBI.ForwardBatch.init_new(b, runner, return_hidden_states_before_norm=False)
+            lo = runner.forward(fb).logits_output
+            ids = runner.sample(lo, fb)
+            return ids, lo.next_token_logits, b
+    cached = []
     counts = dict(graph_replays=0)
     graph_runner = getattr(runner, "decode_cuda_graph_runner", None)
     if graph_runner is not None and hasattr(graph_runner, "execute"):
@@ -1012,26 +1043,43 @@ def run_shared_prefix_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=1
     def job(tag, sync_every_step):
         runner.req_to_token_pool.clear()
         runner.token_to_kv_pool_allocator.clear()
+        if tree is not None:
+            tree.reset()
+        extend = extend_on_tree if tree is not None else (lambda reqs: OB.extend(reqs, runner))
         shared = [torch.randint(3, min(V, 10000), (prefix,), generator=g).tolist() for _ in range(groups)]
         own = [[torch.randint(3, min(V, 10000), (unique,), generator=g).tolist() for _ in range(per_group)] for _ in range(groups)]
         if gpu:
             torch.cuda.synchronize()
         t0 = time.perf_counter()
         leaders = [make_req(gi * per_group, shared[gi] + own[gi][0], prefix + unique) for gi in range(groups)]
-        nxt_a, logits, batch = OB.extend(leaders, runner)                       # cold prefill of one request per group
+        if tree is not None:
+            for req in leaders:
+                req.init_next_round_input(tree)
+                req.set_extend_range(len(req.prefix_indices), len(req.full_untruncated_fill_ids))
+        nxt_a, logits, batch = extend(leaders)                                  # cold prefill of one request per group
+        if tree is not None:
+            for req in leaders:                                                 # scheduler, after a prefill batch: insert into the tree
+                tree.cache_unfinished_req(req)
         check(f"{tag}: cold prefill of {groups} group leaders ({prefix} + {unique} tokens)", batch, logits, False)
         others = []
         for gi in range(groups):
             for j in range(1, per_group):
                 req = make_req(gi * per_group + j, shared[gi] + own[gi][j], prefix + unique)
-                # the radix hit: this request's first `prefix` tokens are the leader's slots (one_batch.py:429-433)
-                req.prefix_indices = runner.req_to_token_pool.req_to_token[leaders[gi].req_pool_idx, :prefix].to(req.prefix_indices.dtype)
+                if tree is not None:
+                    req.init_next_round_input(tree)                             # RadixCache.match_prefix: the hit on the leader's tokens
+                    cached.append(len(req.prefix_indices))
+                else:
+                    # the radix hit: this request's first `prefix` tokens are the leader's slots (one_batch.py:429-433)
+                    req.prefix_indices = runner.req_to_token_pool.req_to_token[leaders[gi].req_pool_idx, :prefix].to(req.prefix_indices.dtype)
                 req.set_extend_range(len(req.prefix_indices), len(req.full_untruncated_fill_ids))
                 others.append(req)
         if gpu:
             torch.cuda.synchronize()
         t1 = time.perf_counter()
-        nxt_b, logits, batch_b = OB.extend(others, runner)                     # warm prefill over the cached prefixes
+        nxt_b, logits, batch_b = extend(others)                                # warm prefill over the cached prefixes
+        if tree is not None:
+            for req in others:
+                tree.cache_unfinished_req(req)
         check(f"{tag}: warm prefill of {len(others)} requests over a {prefix}-token cached prefix", batch_b, logits, False)
         if gpu:
             torch.cuda.synchronize()
@@ -1050,6 +1098,9 @@ def run_shared_prefix_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=1
         if gpu:
             torch.cuda.synchronize()
         t3 = time.perf_counter()
+        if tree is not None:
+            for req in leaders + others:                                        # scheduler, when a request finishes (prompt part:
+                tree.cache_finished_req(req, kv_len_to_handle=len(req.origin_input_ids))   # this harness keeps no output_ids on the Req)
         med = sorted(lat)[len(lat) // 2] if lat else 0.0
         return dict(seconds=t3 - t0, cold_prefill_s=t1 - t0, warm_prefill_s=t2 - t1, decode_s=t3 - t2,
                     decode_s_per_step=(t3 - t2) / max(1, out - 1), median_synchronised_step_s=med if sync_every_step else None,
@@ -1071,7 +1122,8 @@ def run_shared_prefix_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=1
                 attention_backend=sa.attention_backend, attn_backend_class=type(runner.attn_backend).__name__,
                 graph_runner=type(graph_runner).__name__ if graph_runner is not None else None,
                 graph_replays_in_the_timed_job=counts["graph_replays"] - before, warm_up=warm, step_synchronised=stepwise, timed=timed,
-                cascade_plan_last_step=plan,
+                cascade_plan_last_step=plan, radix_cache=type(tree).__name__ if tree is not None else None,
+                radix_hit_lengths=sorted(set(cached)),
                 passes=records)
 
 
@@ -1203,6 +1255,7 @@ if __name__ == "__main__":
     ap.add_argument("--json", default=None)
     ap.add_argument("--shape", default="4,16,4", help="latency run: batch size, input length, output length")
     ap.add_argument("--job", default="2,2,16,8,4", help="shared-prefix run: groups, requests per group, shared tokens, own tokens, output tokens")
+    ap.add_argument("--radix", action="store_true", help="shared-prefix run: prefixes from the reference's real RadixCache")
     ap.add_argument("--tp", type=int, default=1, help="tensor-parallel ranks: this process launches itself N times (rank 0 reports)")
     a = ap.parse_args()
     if a.tp > 1 and "REF_MODEL_RANK" not in os.environ:
@@ -1231,7 +1284,8 @@ if __name__ == "__main__":
         sys.exit(0)
     rep = {"cpu-oracle": lambda: run_cpu_oracle(a.dims), "loader": run_loader, "gpu": lambda: run_gpu(a.dims),
            "runner": lambda: run_runner(a.dims), "latency": lambda: run_latency(a.dims, *[int(x) for x in a.shape.split(",")]),
-           "shared-prefix": lambda: run_shared_prefix_job(a.dims if a.dims != "tiny" else "tiny_v16k", *[int(x) for x in a.job.split(",")])}[a.run]()
+           "shared-prefix": lambda: run_shared_prefix_job(a.dims if a.dims != "tiny" else "tiny_v16k", *[int(x) for x in a.job.split(",")],
+                                                          radix=a.radix)}[a.run]()
     rep["tp"] = tp_world()[0]
     text = json.dumps(rep, indent=1)
     if tp_world()[1] != 0:

@@ -82,6 +82,20 @@ def test_oracle_equals_the_reference_under_the_references_model_runner(tmp_path)
     assert len(rep["sampled"]) == 5 and all(len(s) == 3 for s in rep["sampled"])
 
 
+@pytest.mark.parametrize("radix", [False, True])
+def test_oracle_equals_the_reference_on_the_shared_prefix_job(tmp_path, radix):
+    """BASELINE.json's job shape, small, through the reference's ModelRunner (run_shared_prefix_job): group leaders prefilled cold, the
+    other requests extending over the leader's slots, `ScheduleBatch.merge_batch`, greedy decode.  radix=True: the prefixes come out
+    of the reference's REAL `RadixCache` (`Req.init_next_round_input` -> match_prefix, `cache_unfinished_req` after each prefill,
+    `cache_finished_req` at the end) and every non-leader request hits exactly the shared tokens.  Two jobs back to back (the second on
+    cleared pools / a reset tree); the oracle reproduces every checked pass bit for bit."""
+    _root_or_skip()
+    rep = _run("shared-prefix", tmp_path, extra=("--radix",) if radix else ())
+    assert len(rep["passes"]) == 15 and all(p["identical"] and p["ref_rms"] > 0.5 for p in rep["passes"]), rep["passes"]
+    assert rep["radix_cache"] == ("RadixCache" if radix else None) and rep["radix_hit_lengths"] == ([16] if radix else [])
+    assert rep["shape"] == dict(groups=2, per_group=2, prefix=16, unique=8, out=4)
+
+
 def test_the_references_loader_discovers_and_executes_the_plugin(tmp_path):
     import ref_model
 
