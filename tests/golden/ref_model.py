@@ -750,13 +750,19 @@ def run_runner(dims_name="tiny") -> dict:
     loader = run_loader() if gpu else None
     ns = install()
     arch = ARCH.get(dims_name, "llama")
-    assert arch == "llama", "the runner run uses the Llama checkpoint layout"
     H, I, L, Hq, Hkv, D, V = DIMS[dims_name]
     d = Path(_tf.mkdtemp(prefix="ref_model_ckpt_"))
-    (d / "config.json").write_text(_json.dumps(dict(
-        architectures=["LlamaForCausalLM"], model_type="llama", hidden_size=H, intermediate_size=I, num_hidden_layers=L,
-        num_attention_heads=Hq, num_key_value_heads=Hkv, head_dim=D, vocab_size=V, max_position_embeddings=2048, rope_theta=ROPE_THETA[arch],
-        rms_norm_eps=EPS[arch], tie_word_embeddings=False, torch_dtype="bfloat16", hidden_act="silu", bos_token_id=1, eos_token_id=2)))
+    cfg = dict(hidden_size=H, intermediate_size=I, num_hidden_layers=L, num_attention_heads=Hq, num_key_value_heads=Hkv, vocab_size=V,
+               max_position_embeddings=2048, rope_theta=ROPE_THETA[arch], rms_norm_eps=EPS[arch], torch_dtype="bfloat16", hidden_act="silu",
+               bos_token_id=1, eos_token_id=2)
+    if arch == "qwen2":
+        cfg.update(architectures=["Qwen2ForCausalLM"], model_type="qwen2", tie_word_embeddings=True)
+    elif arch == "mixtral":
+        cfg.update(architectures=["MixtralForCausalLM"], model_type="mixtral", tie_word_embeddings=False, num_local_experts=EXPERTS,
+                   num_experts_per_tok=TOP_K)
+    else:
+        cfg.update(architectures=["LlamaForCausalLM"], model_type="llama", tie_word_embeddings=False, head_dim=D)
+    (d / "config.json").write_text(_json.dumps(cfg))
     if not gpu:
         from sglang.kernels import fused_op as FO
         from sglang.kernels.spec import KernelBackend
@@ -833,7 +839,9 @@ def run_runner(dims_name="tiny") -> dict:
     from oracle.model import OracleLM
     from sglang_amd.harness.models import ModelConfig as OCfg
 
-    ocfg = OCfg("ref", H, I, L, Hq, Hkv, D, V, EPS[arch], ROPE_THETA[arch], None, 2048)
+    ocfg = OCfg("ref", H, I, L, Hq, Hkv, D, V, EPS[arch], ROPE_THETA[arch], None, 2048, attention_bias=arch == "qwen2",
+                tie_word_embeddings=arch == "qwen2", num_local_experts=EXPERTS if arch == "mixtral" else 0,
+                num_experts_per_tok=TOP_K if arch == "mixtral" else 0)
     dev = runner.device
     w = oracle_weights(runner.model)
     slots = int(runner.token_to_kv_pool.size) + int(runner.page_size) + 8

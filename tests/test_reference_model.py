@@ -67,7 +67,8 @@ def test_oracle_equals_the_reference_on_qwen2_and_at_tp2(tmp_path, extra, what):
     assert rep["tp"] == (2 if "--tp" in extra else 1)
 
 
-def test_oracle_equals_the_reference_under_the_references_model_runner(tmp_path):
+@pytest.mark.parametrize("dims,model", [("tiny", "LlamaForCausalLM"), ("tiny_qwen2", "Qwen2ForCausalLM"), ("tiny_mixtral", "MixtralForCausalLM")])
+def test_oracle_equals_the_reference_under_the_references_model_runner(tmp_path, dims, model):
     """One level up (tests/golden/ref_model.py run_runner): the reference's real `ServerArgs` (its whole resolution pipeline),
     `ModelConfig.from_server_args`, `ModelRunner` (distributed init, model loader, KV-cache configurator, pools, allocator, attention
     backend from the registry) driven by the reference's own static-batch harness `sglang.benchmark.one_batch` -- real `Req` /
@@ -75,8 +76,8 @@ def test_oracle_equals_the_reference_under_the_references_model_runner(tmp_path)
     `ModelRunner.forward`, `ModelRunner.sample` -- following its correctness test: prefill of a cut, extend over the cached prefix,
     greedy decode.  On the CPU with the torch-native backend the oracle reproduces every logit bit for bit."""
     _root_or_skip()
-    rep = _run("runner", tmp_path)
-    assert (rep["device"], rep["attn_backend_class"], rep["sampler_class"], rep["model"]) == ("cpu", "TorchNativeAttnBackend", "Sampler", "LlamaForCausalLM")
+    rep = _run("runner", tmp_path, extra=("--dims", dims))
+    assert (rep["device"], rep["attn_backend_class"], rep["sampler_class"], rep["model"]) == ("cpu", "TorchNativeAttnBackend", "Sampler", model)
     assert (rep["kv_pool"], rep["allocator"], rep["max_total_num_tokens"]) == ("MHATokenToKVPool", "TokenToKVPoolAllocator", 8192)
     assert len(rep["passes"]) == 6 and all(p["identical"] and p["ref_rms"] > 0.5 for p in rep["passes"]), rep["passes"]
     assert len(rep["sampled"]) == 5 and all(len(s) == 3 for s in rep["sampled"])

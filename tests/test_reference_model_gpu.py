@@ -95,7 +95,8 @@ def test_plugin_under_the_references_model_stack(device, dims, tp):
     assert s["is_reference_subclass"] and s["greedy_equals_argmax"] and s["seeded_ids_equal"], s
 
 
-def test_plugin_under_the_references_model_runner(device):
+@pytest.mark.parametrize("dims,model", [("tiny", "LlamaForCausalLM"), ("tiny_qwen2", "Qwen2ForCausalLM"), ("tiny_mixtral", "MixtralForCausalLM")])
+def test_plugin_under_the_references_model_runner(device, dims, model):
     """The reference's `ModelRunner` itself, on MI355X with the plug-in (tests/golden/ref_model.py run_runner; its CPU twin:
     tests/test_reference_model.py): `ServerArgs(attention_backend=None)` resolves the backend name from the out-of-tree platform,
     `ModelRunner` builds the model, the pools (the platform's `get_mha_kv_pool_cls`), the backend (the registry's factory) and the
@@ -106,21 +107,29 @@ def test_plugin_under_the_references_model_runner(device):
 
     if ref_model.ref_root() is None:
         pytest.skip("reference sources are not staged (python tests/golden/ref_model.py --run stage in the build container)")
-    out = ROOT / "gpurun_out" / "reference_model_runner.json"
-    p = subprocess.run([sys.executable, str(ROOT / "tests" / "golden" / "ref_model.py"), "--run", "runner", "--json", str(out)],
+    out = ROOT / "gpurun_out" / f"reference_model_runner{'' if dims == 'tiny' else '_' + dims}.json"
+    p = subprocess.run([sys.executable, str(ROOT / "tests" / "golden" / "ref_model.py"), "--run", "runner", "--dims", dims, "--json", str(out)],
                        cwd=ROOT, env=dict(os.environ, SGLANG_USE_AITER="0"), capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-6000:]
     rep = json.loads(out.read_text())
     assert rep["loader"]["out_of_tree"] and rep["attention_backend"] == "hip_mi355x"          # resolved by ServerArgs from the platform
-    assert (rep["attn_backend_class"], rep["sampler_class"], rep["model"], rep["kv_pool"]) == ("HipAttnBackend", "HipSampler", "LlamaForCausalLM",
-                                                                                                "MHATokenToKVPool")
+    assert (rep["attn_backend_class"], rep["sampler_class"], rep["model"], rep["kv_pool"]) == ("HipAttnBackend", "HipSampler", model, "MHATokenToKVPool")
     assert rep["graph_runner"] == "DecodeCudaGraphRunner" and rep["captured_batch_sizes"], rep
-    # every capture ran the fused decode layer loop; the four decode steps were graph replays (no further eager decode forward)
-    assert rep["fused_decode_models_during_capture"] >= len(rep["captured_batch_sizes"])
     c = rep["counts"]
-    assert (c["fused_decode_models"], c["graph_replays"], c["not_fused_because"]) == (rep["fused_decode_models_during_capture"], 4, []), c
+    moe = model == "MixtralForCausalLM"
+    if moe:
+        # MixtralModel.forward carries no model-level hook: the captured graphs hold the reference's layer loop with the hooked
+        # projections, the registered operator forwards and the MoE slot; the decode steps are graph replays all the same
+        assert rep["fused_decode_models_during_capture"] == 0 and c["graph_replays"] == 4, c
+    else:
+        # every capture ran the fused decode layer loop; the four decode steps were graph replays (no further eager decode forward)
+        assert rep["fused_decode_models_during_capture"] >= len(rep["captured_batch_sizes"])
+        assert (c["fused_decode_models"], c["graph_replays"], c["not_fused_because"]) == (rep["fused_decode_models_during_capture"], 4, []), c
     assert [u for u in rep["unstaged_reference_modules"] if not u.startswith("sglang._version")] == []
     assert len(rep["passes"]) == 6
     for ps in rep["passes"]:
+        if moe:                         # (discrete routing: see test_plugin_under_the_references_model_stack)
+            assert ps["product_rms_err"] <= 2.0 * ps["reference_rms_err"] + 1e-3, ps
+            continue
         assert ps["product_rms_err"] <= 1.25 * ps["reference_rms_err"] + 1e-4, ps
         assert ps["product_max_err"] <= 2.0 * ps["reference_max_err"] + 1e-3, ps
