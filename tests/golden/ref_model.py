@@ -1135,6 +1135,174 @@ def run_shared_prefix_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=1
                 passes=records)
 
 
+def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, unique=8, out=4) -> dict:
+    """The reference's `Scheduler` ITSELF (managers/scheduler.py: request intake, `PrefillAdder`, the real radix cache built by
+    `kv_cache_builder`, running-batch merge, `TpModelWorker` -> `ModelRunner`, result processing, output streaming) with the body of
+    its `event_loop_normal` (scheduler.py:1748-1780) executed here step by step instead of behind zmq sockets (zmq is not in this
+    image: the sockets are stubs; requests go in through `process_input_requests`, outputs are picked off `send_to_detokenizer`).
+    BASELINE.json's job shape arrives the way bench.py's harness feeds it: the group leaders first, and -- once their prefill has put the
+    shared prefixes into the radix tree -- the other requests, which then HIT `prefix` cached tokens; greedy decoding to `out` tokens.
+
+    Build container: tiny model with real weights, torch-native backend -> the generated token ids must equal the oracle's greedy
+    generation.  MI355X: the plug-in loaded by the reference's loader; Llama-3-8B architecture with dummy weights for the timed job."""
+    import json as _json
+    import tempfile as _tf
+    import time
+    from array import array
+
+    gpu = not dry_run_on_cpu()
+    loader = run_loader() if gpu else None
+    ns = install()
+    H, I, L, Hq, Hkv, D, V = DIMS[dims_name]
+    real_weights = L <= 4                               # the small models carry real weights (token-level check), the 8B one dummy weights
+    d = Path(_tf.mkdtemp(prefix="ref_model_ckpt_"))
+    (d / "config.json").write_text(_json.dumps(dict(
+        architectures=["LlamaForCausalLM"], model_type="llama", hidden_size=H, intermediate_size=I, num_hidden_layers=L,
+        num_attention_heads=Hq, num_key_value_heads=Hkv, head_dim=D, vocab_size=V, max_position_embeddings=8192, rope_theta=ROPE_THETA["llama"],
+        rms_norm_eps=1e-5, tie_word_embeddings=False, torch_dtype="bfloat16", hidden_act="silu", bos_token_id=1, eos_token_id=2)))
+    common = importlib.import_module("sglang.srt.utils.common")
+    if not gpu:
+        from sglang.kernels import fused_op as FO
+        from sglang.kernels.spec import KernelBackend
+
+        FO.set_fused_op_backend(KernelBackend.TORCH)
+        common.get_device_memory_capacity = ns.server_args.get_device_memory_capacity = lambda device=None: 288 * 1024
+        ns.distributed_parallel_state.is_cuda_alike = lambda: False
+    else:
+        try:
+            common.get_device_memory_capacity("cuda")
+        except Exception:                                   # noqa: BLE001
+            mib = torch.cuda.mem_get_info()[1] // (1 << 20)
+            common.get_device_memory_capacity = ns.server_args.get_device_memory_capacity = lambda device=None: mib
+    B = groups * per_group
+    tokens = 2 * (groups * (prefix + unique) + (B - groups) * unique + B * out)           # two jobs' worth: the tree keeps the first
+    sa = ns.server_args.ServerArgs(
+        model_path=str(d), load_format="dummy", skip_tokenizer_init=True, dtype="bfloat16", device="cuda" if gpu else "cpu",
+        attention_backend=None if gpu else "torch_native", sampling_backend=loader["default_attention_backend"] if gpu else "pytorch",
+        max_total_tokens=tokens + 4096, max_running_requests=max(16, B), cuda_graph_max_bs_decode=B, mem_fraction_static=0.5,
+        disable_overlap_schedule=True, random_seed=3)
+    ns.server_args.set_global_server_args_for_scheduler(sa)
+    pa = ns.server_args.PortArgs.init_new(sa)
+    counts = dict(fused_decode_models=0, graph_replays=0)
+    if gpu:
+        import sglang_amd.fused_decode as fd
+
+        decode_model = fd.decode_model
+
+        def counting_decode_model(*a, **k):
+            counts["fused_decode_models"] += 1
+            return decode_model(*a, **k)
+
+        fd.decode_model = counting_decode_model
+    S = importlib.import_module("sglang.srt.managers.scheduler")
+    sch = S.Scheduler(sa, pa, 0, 0, 0, 0, 0, 0, None)
+    sch.is_initializing = False
+    runner = sch.tp_worker.model_runner
+    if real_weights:
+        runner.model.load_weights(list(hf_checkpoint(DIMS[dims_name], runner.device).items()))
+    captured = counts["fused_decode_models"]
+    graph_runner = getattr(runner, "decode_cuda_graph_runner", None)
+    if graph_runner is not None and hasattr(graph_runner, "execute"):
+        execute = graph_runner.execute
+
+        def counting_execute(*a, **k):
+            counts["graph_replays"] += 1
+            return execute(*a, **k)
+
+        graph_runner.execute = counting_execute
+    outs = []
+    sch.ipc_channels.send_to_detokenizer.send_output = lambda output, recv_obj=None: outs.append(output)
+    io = importlib.import_module("sglang.srt.managers.io_struct")
+    SP = importlib.import_module("sglang.srt.sampling.sampling_params").SamplingParams
+    g = torch.Generator().manual_seed(5)
+
+    def request(rid, ids):
+        sp = SP(temperature=0, max_new_tokens=out, ignore_eos=True)
+        sp.normalize(None)
+        return io.TokenizedGenerateReqInput(rid=rid, input_text=None, input_ids=array("q", ids), input_embeds=None, mm_inputs=None,
+                                            token_type_ids=None, sampling_params=sp, return_logprob=False, logprob_start_len=-1,
+                                            top_logprobs_num=0, token_ids_logprob=None, stream=False)
+
+    def loop_until(done):
+        """The body of Scheduler.event_loop_normal (scheduler.py:1750-1778) without the socket read."""
+        batches = []
+        for _ in range(100000):
+            if done():
+                break
+            plan = sch.get_next_batch_to_run(running_batch=sch.running_batch, last_batch=sch.last_batch)
+            sch.running_batch = plan.running_batch
+            batch = plan.batch_to_run
+            if batch:
+                batches.append((batch.forward_mode.name, batch.batch_size()))
+                result = sch.run_batch(batch)
+                sch.process_batch_result(batch, result)
+            sch.last_batch = batch
+        return batches
+
+    def job(tag):
+        del outs[:]
+        shared = [torch.randint(3, min(V, 10000), (prefix,), generator=g).tolist() for _ in range(groups)]
+        prompts = {f"{tag}-g{gi}r{j}": shared[gi] + torch.randint(3, min(V, 10000), (unique,), generator=g).tolist()
+                   for gi in range(groups) for j in range(per_group)}
+        leaders = [f"{tag}-g{gi}r0" for gi in range(groups)]
+        others = [r for r in prompts if r not in leaders]
+        if gpu:
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sch.process_input_requests([request(r, prompts[r]) for r in leaders])
+        first = loop_until(lambda: not sch.waiting_queue)                   # the leaders' prefill batch has run: their prompts are in the tree
+        sch.process_input_requests([request(r, prompts[r]) for r in others])
+        finished = lambda: sum(len(o.rids) for o in outs if type(o).__name__ == "BatchTokenIDOutput" and all(f is not None for f in o.finished_reasons)) >= B   # noqa: E731
+        rest = loop_until(finished)
+        if gpu:
+            torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        got, cached = {}, {}
+        for o in outs:
+            if type(o).__name__ != "BatchTokenIDOutput":
+                continue
+            for i, rid in enumerate(o.rids):
+                if o.finished_reasons[i] is not None:
+                    got[rid] = list(o.output_ids[i])
+                    cached[rid] = int(o.cached_tokens[i])
+        return dict(seconds=t1 - t0, output_tokens_per_s=B * out / (t1 - t0), batches=first + rest, prompts=prompts, generated=got,
+                    cached_tokens=cached, leaders=leaders)
+
+    with torch.no_grad():
+        warm = job("warm")
+        before = dict(counts)
+        timed = job("timed")
+    rep = dict(mode="scheduler-job", dims=dims_name, device=str(runner.device), scheduler=type(sch).__name__, tree_cache=type(sch.tree_cache).__name__,
+               tp_worker=type(sch.tp_worker).__name__, attention_backend=sa.attention_backend, attn_backend_class=type(runner.attn_backend).__name__,
+               sampler_class=type(runner.sampler).__name__, graph_runner=type(graph_runner).__name__ if graph_runner is not None else None,
+               shape=dict(groups=groups, per_group=per_group, prefix=prefix, unique=unique, out=out),
+               fused_decode_models_during_capture=captured,
+               eager_fused_decode_forwards_in_the_timed_job=counts["fused_decode_models"] - before["fused_decode_models"],
+               graph_replays_in_the_timed_job=counts["graph_replays"] - before["graph_replays"])
+    for tag, j in (("warm_up", warm), ("timed", timed)):
+        hit = sorted(set(v for r, v in j["cached_tokens"].items() if r not in j["leaders"]))
+        modes = {}
+        for m, bs in j["batches"]:
+            modes[f"{m} x{bs}"] = modes.get(f"{m} x{bs}", 0) + 1
+        rep[tag] = dict(seconds=j["seconds"], output_tokens_per_s=j["output_tokens_per_s"], batches_run=modes,
+                        cached_tokens_of_leaders=sorted(set(j["cached_tokens"][r] for r in j["leaders"])), cached_tokens_of_others=hit,
+                        finished_requests=len(j["generated"]), tokens_per_request=sorted(set(len(v) for v in j["generated"].values())))
+    if real_weights:
+        # the oracle's greedy generation of the timed job's prompts, prefixes shared the same way
+        from oracle.model import OracleLM
+        from sglang_amd.harness.models import ModelConfig as OCfg
+
+        olm = OracleLM(OCfg("ref", H, I, L, Hq, Hkv, D, V, 1e-5, ROPE_THETA["llama"], None, 8192), oracle_weights(runner.model),
+                       num_slots=4 * tokens, max_ctx=prefix + unique + out + 8, max_reqs=B, device=runner.device)
+        rids = list(timed["prompts"])
+        grp = [[rids.index(f"timed-g{gi}r{j}") for j in range(per_group)] for gi in range(groups)]
+        want = olm.generate([timed["prompts"][r] for r in rids], out, share_prefix_groups=grp, shared_len=prefix)
+        same = sum(int(list(w) == timed["generated"].get(r)) for r, w in zip(rids, want))
+        rep["oracle"] = dict(requests=len(rids), requests_with_identical_tokens=same,
+                             token_agreement=sum(int(a == b) for r, w in zip(rids, want) for a, b in zip(w, timed["generated"].get(r, []))) / (len(rids) * out))
+    return rep
+
+
 def run_latency(dims_name="tiny", batch_size=4, input_len=16, output_len=4) -> dict:
     """The reference's own latency benchmark -- `python -m sglang.bench_one_batch --load-format dummy --batch-size B --input-len I
     --output-len O` (benchmark/one_batch.py:877-990 latency_test: one warm-up pass, then `latency_test_run_once`, whose
@@ -1258,7 +1426,7 @@ if __name__ == "__main__":
     import json
 
     ap = argparse.ArgumentParser()
-    ap.add_argument("--run", choices=["cpu-oracle", "loader", "gpu", "runner", "latency", "shared-prefix", "stage"], required=True)
+    ap.add_argument("--run", choices=["cpu-oracle", "loader", "gpu", "runner", "latency", "shared-prefix", "scheduler", "stage"], required=True)
     ap.add_argument("--dims", default="tiny", choices=sorted(DIMS))
     ap.add_argument("--json", default=None)
     ap.add_argument("--shape", default="4,16,4", help="latency run: batch size, input length, output length")
@@ -1292,6 +1460,7 @@ if __name__ == "__main__":
         sys.exit(0)
     rep = {"cpu-oracle": lambda: run_cpu_oracle(a.dims), "loader": run_loader, "gpu": lambda: run_gpu(a.dims),
            "runner": lambda: run_runner(a.dims), "latency": lambda: run_latency(a.dims, *[int(x) for x in a.shape.split(",")]),
+           "scheduler": lambda: run_scheduler_job(a.dims if a.dims != "tiny" else "tiny_v16k", *[int(x) for x in a.job.split(",")]),
            "shared-prefix": lambda: run_shared_prefix_job(a.dims if a.dims != "tiny" else "tiny_v16k", *[int(x) for x in a.job.split(",")],
                                                           radix=a.radix)}[a.run]()
     rep["tp"] = tp_world()[0]

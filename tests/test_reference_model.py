@@ -97,6 +97,22 @@ def test_oracle_equals_the_reference_on_the_shared_prefix_job(tmp_path, radix):
     assert rep["shape"] == dict(groups=2, per_group=2, prefix=16, unique=8, out=4)
 
 
+def test_oracle_equals_the_reference_under_the_references_scheduler(tmp_path):
+    """The top of the stack (run_scheduler_job): the reference's `Scheduler` object -- request intake, `PrefillAdder`, the radix cache
+    `kv_cache_builder` builds, running-batch merge, `TpModelWorker` / `ModelRunner`, result processing, output streaming -- with the
+    body of its `event_loop_normal` executed step by step (zmq is absent: requests enter through `process_input_requests`, outputs
+    are taken off `send_to_detokenizer`).  Group leaders arrive first, the other requests once the leaders' prefill is in the tree:
+    they hit exactly the shared tokens; every request's generated token ids equal the oracle's greedy generation."""
+    _root_or_skip()
+    rep = _run("scheduler", tmp_path)
+    assert (rep["scheduler"], rep["tp_worker"], rep["tree_cache"]) == ("Scheduler", "TpModelWorker", "UnifiedRadixCache")
+    for job in (rep["warm_up"], rep["timed"]):
+        assert job["batches_run"] == {"EXTEND x2": 2, "DECODE x4": 3}, job
+        assert job["cached_tokens_of_leaders"] == [0] and job["cached_tokens_of_others"] == [16]
+        assert job["finished_requests"] == 4 and job["tokens_per_request"] == [4]
+    assert rep["oracle"] == dict(requests=4, requests_with_identical_tokens=4, token_agreement=1.0)
+
+
 def test_the_references_loader_discovers_and_executes_the_plugin(tmp_path):
     import ref_model
 
