@@ -1135,7 +1135,7 @@ def run_shared_prefix_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=1
                 passes=records)
 
 
-def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, unique=8, out=4) -> dict:
+def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, unique=8, out=4, overlap=False) -> dict:
     """The reference's `Scheduler` ITSELF (managers/scheduler.py: request intake, `PrefillAdder`, the real radix cache built by
     `kv_cache_builder`, running-batch merge, `TpModelWorker` -> `ModelRunner`, result processing, output streaming) with the body of
     its `event_loop_normal` (scheduler.py:1748-1780) executed here step by step instead of behind zmq sockets (zmq is not in this
@@ -1144,7 +1144,10 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
     shared prefixes into the radix tree -- the other requests, which then HIT `prefix` cached tokens; greedy decoding to `out` tokens.
 
     Build container: tiny model with real weights, torch-native backend -> the generated token ids must equal the oracle's greedy
-    generation.  MI355X: the plug-in loaded by the reference's loader; Llama-3-8B architecture with dummy weights for the timed job."""
+    generation.  MI355X: the plug-in loaded by the reference's loader; Llama-3-8B architecture with dummy weights for the timed job.
+
+    `overlap=True`: the server's default loop instead -- the body of `event_loop_overlap` (scheduler.py:1783-1853: the forward of
+    batch N is launched before the results of batch N-1 are processed; future token ids, the result queue, `launch_batch_sample_if_needed`)."""
     import json as _json
     import tempfile as _tf
     import time
@@ -1180,7 +1183,7 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
         model_path=str(d), load_format="dummy", skip_tokenizer_init=True, dtype="bfloat16", device="cuda" if gpu else "cpu",
         attention_backend=None if gpu else "torch_native", sampling_backend=loader["default_attention_backend"] if gpu else "pytorch",
         max_total_tokens=tokens + 4096, max_running_requests=max(16, B), cuda_graph_max_bs_decode=B, mem_fraction_static=0.5,
-        disable_overlap_schedule=True, random_seed=3)
+        disable_overlap_schedule=not overlap, random_seed=3)
     ns.server_args.set_global_server_args_for_scheduler(sa)
     pa = ns.server_args.PortArgs.init_new(sa)
     counts = dict(fused_decode_models=0, graph_replays=0)
@@ -1223,21 +1226,34 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
                                             token_type_ids=None, sampling_params=sp, return_logprob=False, logprob_start_len=-1,
                                             top_logprobs_num=0, token_ids_logprob=None, stream=False)
 
-    def loop_until(done):
-        """The body of Scheduler.event_loop_normal (scheduler.py:1750-1778) without the socket read."""
-        batches = []
-        for _ in range(100000):
-            if done():
-                break
-            plan = sch.get_next_batch_to_run(running_batch=sch.running_batch, last_batch=sch.last_batch)
-            sch.running_batch = plan.running_batch
-            batch = plan.batch_to_run
-            if batch:
-                batches.append((batch.forward_mode.name, batch.batch_size()))
-                result = sch.run_batch(batch)
-                sch.process_batch_result(batch, result)
-            sch.last_batch = batch
-        return batches
+    # The reference's own loop runs -- `Scheduler.run_event_loop()` (scheduler.py:1696-1732: schedule stream, WAR barrier, dispatch to
+    # event_loop_normal / event_loop_overlap) -- with ONE substitution: the receiver's raw socket read (`_pull_raw_reqs`) hands out
+    # the scripted arrivals and raises the loop's own `gracefully_exit` flag when the job is done.
+    batches = []
+    run_batch = sch.run_batch
+
+    def logging_run_batch(batch, *a, **k):
+        batches.append((batch.forward_mode.name, batch.batch_size()))
+        return run_batch(batch, *a, **k)
+
+    sch.run_batch = logging_run_batch
+
+    def run_loop(arrivals, finished):
+        """arrivals: list of (ready() -> bool, [requests]); delivered in order, each once its predicate holds."""
+        pending = list(arrivals)
+
+        def pull():
+            if pending and pending[0][0]():
+                return pending.pop(0)[1]
+            if not pending and finished():
+                sch.gracefully_exit = True
+            return []
+
+        type(sch.request_receiver)._pull_raw_reqs = lambda self: pull()        # (the receiver is a frozen dataclass: patch the class)
+        sch.gracefully_exit = False
+        del batches[:]
+        sch.run_event_loop()
+        return list(batches)
 
     def job(tag):
         del outs[:]
@@ -1249,11 +1265,15 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
         if gpu:
             torch.cuda.synchronize()
         t0 = time.perf_counter()
-        sch.process_input_requests([request(r, prompts[r]) for r in leaders])
-        first = loop_until(lambda: not sch.waiting_queue)                   # the leaders' prefill batch has run: their prompts are in the tree
-        sch.process_input_requests([request(r, prompts[r]) for r in others])
-        finished = lambda: sum(len(o.rids) for o in outs if type(o).__name__ == "BatchTokenIDOutput" and all(f is not None for f in o.finished_reasons)) >= B   # noqa: E731
-        rest = loop_until(finished)
+        done = lambda: sum(sum(f is not None for f in o.finished_reasons) for o in outs if type(o).__name__ == "BatchTokenIDOutput")   # noqa: E731
+        # the other requests arrive once the leaders' prompts are in the radix tree: their prefill result has been processed (with the
+        # overlap loop that is one iteration after its launch), i.e. every leader is in the running batch with two tokens out
+        def in_tree():
+            rb = sch.running_batch
+            return rb is not None and len(rb.reqs) == groups and all(len(r.output_ids) >= 2 for r in rb.reqs)
+        ran = run_loop([(lambda: True, [request(r, prompts[r]) for r in leaders]), (in_tree, [request(r, prompts[r]) for r in others])],
+                       lambda: done() >= B)
+        first, rest = ran, []
         if gpu:
             torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -1261,9 +1281,9 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
         for o in outs:
             if type(o).__name__ != "BatchTokenIDOutput":
                 continue
-            for i, rid in enumerate(o.rids):
+            for i, rid in enumerate(o.rids):                  # (a request's ids arrive in increments: every forced stream interval + the end)
+                got.setdefault(rid, []).extend(list(o.output_ids[i]))
                 if o.finished_reasons[i] is not None:
-                    got[rid] = list(o.output_ids[i])
                     cached[rid] = int(o.cached_tokens[i])
         return dict(seconds=t1 - t0, output_tokens_per_s=B * out / (t1 - t0), batches=first + rest, prompts=prompts, generated=got,
                     cached_tokens=cached, leaders=leaders)
@@ -1272,7 +1292,7 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
         warm = job("warm")
         before = dict(counts)
         timed = job("timed")
-    rep = dict(mode="scheduler-job", dims=dims_name, device=str(runner.device), scheduler=type(sch).__name__, tree_cache=type(sch.tree_cache).__name__,
+    rep = dict(mode="scheduler-job", event_loop="overlap" if overlap else "normal", dims=dims_name, device=str(runner.device), scheduler=type(sch).__name__, tree_cache=type(sch.tree_cache).__name__,
                tp_worker=type(sch.tp_worker).__name__, attention_backend=sa.attention_backend, attn_backend_class=type(runner.attn_backend).__name__,
                sampler_class=type(runner.sampler).__name__, graph_runner=type(graph_runner).__name__ if graph_runner is not None else None,
                shape=dict(groups=groups, per_group=per_group, prefix=prefix, unique=unique, out=out),
@@ -1431,6 +1451,7 @@ if __name__ == "__main__":
     ap.add_argument("--json", default=None)
     ap.add_argument("--shape", default="4,16,4", help="latency run: batch size, input length, output length")
     ap.add_argument("--job", default="2,2,16,8,4", help="shared-prefix run: groups, requests per group, shared tokens, own tokens, output tokens")
+    ap.add_argument("--overlap", action="store_true", help="scheduler run: the body of event_loop_overlap (the server default)")
     ap.add_argument("--radix", action="store_true", help="shared-prefix run: prefixes from the reference's real RadixCache")
     ap.add_argument("--tp", type=int, default=1, help="tensor-parallel ranks: this process launches itself N times (rank 0 reports)")
     a = ap.parse_args()
@@ -1460,7 +1481,8 @@ if __name__ == "__main__":
         sys.exit(0)
     rep = {"cpu-oracle": lambda: run_cpu_oracle(a.dims), "loader": run_loader, "gpu": lambda: run_gpu(a.dims),
            "runner": lambda: run_runner(a.dims), "latency": lambda: run_latency(a.dims, *[int(x) for x in a.shape.split(",")]),
-           "scheduler": lambda: run_scheduler_job(a.dims if a.dims != "tiny" else "tiny_v16k", *[int(x) for x in a.job.split(",")]),
+           "scheduler": lambda: run_scheduler_job(a.dims if a.dims != "tiny" else "tiny_v16k", *[int(x) for x in a.job.split(",")],
+                                                  overlap=a.overlap),
            "shared-prefix": lambda: run_shared_prefix_job(a.dims if a.dims != "tiny" else "tiny_v16k", *[int(x) for x in a.job.split(",")],
                                                           radix=a.radix)}[a.run]()
     rep["tp"] = tp_world()[0]

@@ -97,17 +97,21 @@ def test_oracle_equals_the_reference_on_the_shared_prefix_job(tmp_path, radix):
     assert rep["shape"] == dict(groups=2, per_group=2, prefix=16, unique=8, out=4)
 
 
-def test_oracle_equals_the_reference_under_the_references_scheduler(tmp_path):
+@pytest.mark.parametrize("loop", ["normal", "overlap"])
+def test_oracle_equals_the_reference_under_the_references_scheduler(tmp_path, loop):
     """The top of the stack (run_scheduler_job): the reference's `Scheduler` object -- request intake, `PrefillAdder`, the radix cache
-    `kv_cache_builder` builds, running-batch merge, `TpModelWorker` / `ModelRunner`, result processing, output streaming -- with the
-    body of its `event_loop_normal` executed step by step (zmq is absent: requests enter through `process_input_requests`, outputs
-    are taken off `send_to_detokenizer`).  Group leaders arrive first, the other requests once the leaders' prefill is in the tree:
-    they hit exactly the shared tokens; every request's generated token ids equal the oracle's greedy generation."""
+    `kv_cache_builder` builds, running-batch merge, `TpModelWorker` / `ModelRunner`, result processing, output streaming -- running
+    its OWN `run_event_loop()` -> `event_loop_normal()` / `event_loop_overlap()` (scheduler.py:1696-1853; the server default is the
+    overlap loop).  zmq is absent, so one thing is substituted: the receiver's raw socket read hands out the scripted arrivals (group
+    leaders first, the other requests once the leaders are decoding) and raises the loop's own `gracefully_exit` when the job is
+    done; outputs are taken off `send_to_detokenizer`.  The later requests hit exactly the shared tokens in the radix tree, join the
+    running batch (continuous batching), and every request's generated token ids equal the oracle's greedy generation."""
     _root_or_skip()
-    rep = _run("scheduler", tmp_path)
-    assert (rep["scheduler"], rep["tp_worker"], rep["tree_cache"]) == ("Scheduler", "TpModelWorker", "UnifiedRadixCache")
+    rep = _run("scheduler", tmp_path, extra=("--overlap",) if loop == "overlap" else ())
+    assert (rep["scheduler"], rep["tp_worker"], rep["tree_cache"], rep["event_loop"]) == ("Scheduler", "TpModelWorker", "UnifiedRadixCache", loop)
     for job in (rep["warm_up"], rep["timed"]):
-        assert job["batches_run"] == {"EXTEND x2": 2, "DECODE x4": 3}, job
+        b = job["batches_run"]
+        assert b["EXTEND x2"] == 2 and b.get("DECODE x4", 0) >= 1 and sum(v for k, v in b.items() if k.startswith("DECODE")) >= 3, b
         assert job["cached_tokens_of_leaders"] == [0] and job["cached_tokens_of_others"] == [16]
         assert job["finished_requests"] == 4 and job["tokens_per_request"] == [4]
     assert rep["oracle"] == dict(requests=4, requests_with_identical_tokens=4, token_agreement=1.0)

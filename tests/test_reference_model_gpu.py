@@ -135,28 +135,32 @@ def test_plugin_under_the_references_model_runner(device, dims, model):
         assert ps["product_max_err"] <= 2.0 * ps["reference_max_err"] + 1e-3, ps
 
 
-def test_plugin_under_the_references_scheduler(device):
-    """The reference's `Scheduler` itself on MI355X with the plug-in (tests/golden/ref_model.py run_scheduler_job; CPU twin in
-    tests/test_reference_model.py): its own intake, prefill admission, radix cache, running-batch merge, `TpModelWorker` ->
-    `ModelRunner` -> the captured decode graphs, result processing and output streaming, with the body of `event_loop_normal` run
-    step by step.  The non-leader requests hit the shared tokens in the reference's radix tree; the plug-in's kernels produce the
-    tokens; decode batches are replays of the reference's graphs."""
+@pytest.mark.parametrize("loop", ["normal", "overlap"])
+def test_plugin_under_the_references_scheduler(device, loop):
+    """The reference's `Scheduler` itself on MI355X with the plug-in, running its own `run_event_loop()` (tests/golden/ref_model.py
+    run_scheduler_job; CPU twin in tests/test_reference_model.py): intake, prefill admission, radix cache, continuous batching,
+    `TpModelWorker` -> `ModelRunner` -> the captured decode graphs, result processing and output streaming -- `event_loop_normal`
+    and the server's default `event_loop_overlap` (forward of batch N launched before the results of batch N-1 are processed).  The
+    later requests hit the shared tokens in the reference's radix tree; the plug-in's kernels produce the tokens; decode batches
+    are replays of the reference's graphs."""
     import ref_model
 
     if ref_model.ref_root() is None:
         pytest.skip("reference sources are not staged (python tests/golden/ref_model.py --run stage in the build container)")
-    out = ROOT / "gpurun_out" / "reference_model_scheduler.json"
-    p = subprocess.run([sys.executable, str(ROOT / "tests" / "golden" / "ref_model.py"), "--run", "scheduler", "--json", str(out)],
+    out = ROOT / "gpurun_out" / f"reference_model_scheduler_{loop}.json"
+    p = subprocess.run([sys.executable, str(ROOT / "tests" / "golden" / "ref_model.py"), "--run", "scheduler", "--json", str(out)]
+                       + (["--overlap"] if loop == "overlap" else []),
                        cwd=ROOT, env=dict(os.environ, SGLANG_USE_AITER="0"), capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-6000:]
     rep = json.loads(out.read_text())
-    assert (rep["scheduler"], rep["tp_worker"], rep["attention_backend"], rep["attn_backend_class"], rep["sampler_class"], rep["graph_runner"]) == (
-        "Scheduler", "TpModelWorker", "hip_mi355x", "HipAttnBackend", "HipSampler", "DecodeCudaGraphRunner")
+    assert (rep["scheduler"], rep["tp_worker"], rep["attention_backend"], rep["attn_backend_class"], rep["sampler_class"], rep["graph_runner"],
+            rep["event_loop"]) == ("Scheduler", "TpModelWorker", "hip_mi355x", "HipAttnBackend", "HipSampler", "DecodeCudaGraphRunner", loop)
     for job in (rep["warm_up"], rep["timed"]):
-        assert job["batches_run"] == {"EXTEND x2": 2, "DECODE x4": 3}, job
+        b = job["batches_run"]
+        assert b["EXTEND x2"] == 2 and b.get("DECODE x4", 0) >= 1 and sum(v for k, v in b.items() if k.startswith("DECODE")) >= 3, b
         assert job["cached_tokens_of_leaders"] == [0] and job["cached_tokens_of_others"] == [16]
         assert job["finished_requests"] == 4 and job["tokens_per_request"] == [4]
     assert rep["fused_decode_models_during_capture"] > 0 and rep["eager_fused_decode_forwards_in_the_timed_job"] == 0
-    assert rep["graph_replays_in_the_timed_job"] == 3
-    # greedy tokens of a random-weight model: a near-tie may flip between two bf16 evaluations; most requests must agree exactly
+    assert rep["graph_replays_in_the_timed_job"] >= 3
+    # greedy tokens of a random-weight model: a near-tie may flip between two bf16 evaluations; most tokens must agree exactly
     assert rep["oracle"]["token_agreement"] >= 0.75, rep["oracle"]
