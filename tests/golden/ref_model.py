@@ -1135,7 +1135,7 @@ def run_shared_prefix_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=1
                 passes=records)
 
 
-def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, unique=8, out=4, overlap=False) -> dict:
+def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, unique=8, out=4, overlap=False, server_args=None) -> dict:
     """The reference's `Scheduler` ITSELF (managers/scheduler.py: request intake, `PrefillAdder`, the real radix cache built by
     `kv_cache_builder`, running-batch merge, `TpModelWorker` -> `ModelRunner`, result processing, output streaming) with the body of
     its `event_loop_normal` (scheduler.py:1748-1780) executed here step by step instead of behind zmq sockets (zmq is not in this
@@ -1183,7 +1183,7 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
         model_path=str(d), load_format="dummy", skip_tokenizer_init=True, dtype="bfloat16", device="cuda" if gpu else "cpu",
         attention_backend=None if gpu else "torch_native", sampling_backend=loader["default_attention_backend"] if gpu else "pytorch",
         max_total_tokens=tokens + 4096, max_running_requests=max(16, B), cuda_graph_max_bs_decode=B, mem_fraction_static=0.5,
-        disable_overlap_schedule=not overlap, random_seed=3)
+        disable_overlap_schedule=not overlap, random_seed=3, **(server_args or {}))
     ns.server_args.set_global_server_args_for_scheduler(sa)
     pa = ns.server_args.PortArgs.init_new(sa)
     counts = dict(fused_decode_models=0, graph_replays=0)
@@ -1292,7 +1292,8 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
         warm = job("warm")
         before = dict(counts)
         timed = job("timed")
-    rep = dict(mode="scheduler-job", event_loop="overlap" if overlap else "normal", dims=dims_name, device=str(runner.device), scheduler=type(sch).__name__, tree_cache=type(sch.tree_cache).__name__,
+    rep = dict(mode="scheduler-job", event_loop="overlap" if overlap else "normal", server_args=server_args or {}, page_size=int(sch.page_size),
+               chunked_prefill_size=sa.chunked_prefill_size, dims=dims_name, device=str(runner.device), scheduler=type(sch).__name__, tree_cache=type(sch.tree_cache).__name__,
                tp_worker=type(sch.tp_worker).__name__, attention_backend=sa.attention_backend, attn_backend_class=type(runner.attn_backend).__name__,
                sampler_class=type(runner.sampler).__name__, graph_runner=type(graph_runner).__name__ if graph_runner is not None else None,
                shape=dict(groups=groups, per_group=per_group, prefix=prefix, unique=unique, out=out),
@@ -1441,6 +1442,12 @@ def stage() -> None:
     print(f"staged {len(files)} reference files ({total / 1e6:.1f} MB) under {STAGE}")
 
 
+def _json_arg(text):
+    import json as _j
+
+    return _j.loads(text) if text else None
+
+
 if __name__ == "__main__":
     import argparse
     import json
@@ -1451,6 +1458,7 @@ if __name__ == "__main__":
     ap.add_argument("--json", default=None)
     ap.add_argument("--shape", default="4,16,4", help="latency run: batch size, input length, output length")
     ap.add_argument("--job", default="2,2,16,8,4", help="shared-prefix run: groups, requests per group, shared tokens, own tokens, output tokens")
+    ap.add_argument("--server-args", default=None, help='scheduler run: extra ServerArgs as JSON, e.g. {"page_size": 16, "chunked_prefill_size": 64}')
     ap.add_argument("--overlap", action="store_true", help="scheduler run: the body of event_loop_overlap (the server default)")
     ap.add_argument("--radix", action="store_true", help="shared-prefix run: prefixes from the reference's real RadixCache")
     ap.add_argument("--tp", type=int, default=1, help="tensor-parallel ranks: this process launches itself N times (rank 0 reports)")
@@ -1482,7 +1490,7 @@ if __name__ == "__main__":
     rep = {"cpu-oracle": lambda: run_cpu_oracle(a.dims), "loader": run_loader, "gpu": lambda: run_gpu(a.dims),
            "runner": lambda: run_runner(a.dims), "latency": lambda: run_latency(a.dims, *[int(x) for x in a.shape.split(",")]),
            "scheduler": lambda: run_scheduler_job(a.dims if a.dims != "tiny" else "tiny_v16k", *[int(x) for x in a.job.split(",")],
-                                                  overlap=a.overlap),
+                                                  overlap=a.overlap, server_args=_json_arg(a.server_args)),
            "shared-prefix": lambda: run_shared_prefix_job(a.dims if a.dims != "tiny" else "tiny_v16k", *[int(x) for x in a.job.split(",")],
                                                           radix=a.radix)}[a.run]()
     rep["tp"] = tp_world()[0]

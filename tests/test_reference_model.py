@@ -117,6 +117,20 @@ def test_oracle_equals_the_reference_under_the_references_scheduler(tmp_path, lo
     assert rep["oracle"] == dict(requests=4, requests_with_identical_tokens=4, token_agreement=1.0)
 
 
+def test_oracle_equals_the_reference_under_the_references_scheduler_with_chunked_prefill(tmp_path):
+    """The same under `--chunked-prefill-size 64`: the scheduler cuts the 104-token prompts into chunks (EXTEND batches of one, two and
+    three requests, each chunk extending over the request's own earlier chunks; the later requests over 80 cached tokens), mixes
+    them with the running decode batches, and the token ids still equal the oracle's greedy generation."""
+    _root_or_skip()
+    rep = _run("scheduler", tmp_path, extra=("--overlap", "--job", "2,3,80,24,6", "--server-args", '{"chunked_prefill_size": 64}'))
+    assert rep["chunked_prefill_size"] == 64 and rep["event_loop"] == "overlap"
+    for job in (rep["warm_up"], rep["timed"]):
+        assert sum(v for k, v in job["batches_run"].items() if k.startswith("EXTEND")) >= 4, job["batches_run"]      # chunks, not two prefills
+        assert job["cached_tokens_of_leaders"] == [0] and job["cached_tokens_of_others"] == [80]
+        assert job["finished_requests"] == 6 and job["tokens_per_request"] == [6]
+    assert rep["oracle"] == dict(requests=6, requests_with_identical_tokens=6, token_agreement=1.0)
+
+
 def test_the_references_loader_discovers_and_executes_the_plugin(tmp_path):
     import ref_model
 

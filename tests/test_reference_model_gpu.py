@@ -135,31 +135,43 @@ def test_plugin_under_the_references_model_runner(device, dims, model):
         assert ps["product_max_err"] <= 2.0 * ps["reference_max_err"] + 1e-3, ps
 
 
-@pytest.mark.parametrize("loop", ["normal", "overlap"])
+@pytest.mark.parametrize("loop", ["normal", "overlap", "overlap-paged-chunked"])
 def test_plugin_under_the_references_scheduler(device, loop):
     """The reference's `Scheduler` itself on MI355X with the plug-in, running its own `run_event_loop()` (tests/golden/ref_model.py
     run_scheduler_job; CPU twin in tests/test_reference_model.py): intake, prefill admission, radix cache, continuous batching,
     `TpModelWorker` -> `ModelRunner` -> the captured decode graphs, result processing and output streaming -- `event_loop_normal`
     and the server's default `event_loop_overlap` (forward of batch N launched before the results of batch N-1 are processed).  The
     later requests hit the shared tokens in the reference's radix tree; the plug-in's kernels produce the tokens; decode batches
-    are replays of the reference's graphs."""
+    are replays of the reference's graphs.  `overlap-paged-chunked`: `--page-size 16 --chunked-prefill-size 64` on top (the reference's
+    paged allocator and page-aligned radix keys; 104-token prompts prefilled in chunks that extend over the request's own earlier
+    chunks, mixed with the running decode batches)."""
     import ref_model
 
     if ref_model.ref_root() is None:
         pytest.skip("reference sources are not staged (python tests/golden/ref_model.py --run stage in the build container)")
     out = ROOT / "gpurun_out" / f"reference_model_scheduler_{loop}.json"
-    p = subprocess.run([sys.executable, str(ROOT / "tests" / "golden" / "ref_model.py"), "--run", "scheduler", "--json", str(out)]
-                       + (["--overlap"] if loop == "overlap" else []),
+    variant = loop == "overlap-paged-chunked"
+    extra = ["--overlap"] if loop != "normal" else []
+    if variant:
+        extra += ["--job", "2,3,80,24,6", "--server-args", '{"page_size": 16, "chunked_prefill_size": 64}']
+    p = subprocess.run([sys.executable, str(ROOT / "tests" / "golden" / "ref_model.py"), "--run", "scheduler", "--json", str(out)] + extra,
                        cwd=ROOT, env=dict(os.environ, SGLANG_USE_AITER="0"), capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-6000:]
     rep = json.loads(out.read_text())
     assert (rep["scheduler"], rep["tp_worker"], rep["attention_backend"], rep["attn_backend_class"], rep["sampler_class"], rep["graph_runner"],
-            rep["event_loop"]) == ("Scheduler", "TpModelWorker", "hip_mi355x", "HipAttnBackend", "HipSampler", "DecodeCudaGraphRunner", loop)
+            rep["event_loop"]) == ("Scheduler", "TpModelWorker", "hip_mi355x", "HipAttnBackend", "HipSampler", "DecodeCudaGraphRunner",
+                                   "normal" if loop == "normal" else "overlap")
     for job in (rep["warm_up"], rep["timed"]):
         b = job["batches_run"]
-        assert b["EXTEND x2"] == 2 and b.get("DECODE x4", 0) >= 1 and sum(v for k, v in b.items() if k.startswith("DECODE")) >= 3, b
-        assert job["cached_tokens_of_leaders"] == [0] and job["cached_tokens_of_others"] == [16]
-        assert job["finished_requests"] == 4 and job["tokens_per_request"] == [4]
+        if variant:
+            assert (rep["page_size"], rep["chunked_prefill_size"]) == (16, 64)
+            assert sum(v for k, v in b.items() if k.startswith("EXTEND")) >= 4 and b.get("DECODE x6", 0) >= 1, b
+            assert job["cached_tokens_of_leaders"] == [0] and job["cached_tokens_of_others"] == [80]
+            assert job["finished_requests"] == 6 and job["tokens_per_request"] == [6]
+        else:
+            assert b["EXTEND x2"] == 2 and b.get("DECODE x4", 0) >= 1 and sum(v for k, v in b.items() if k.startswith("DECODE")) >= 3, b
+            assert job["cached_tokens_of_leaders"] == [0] and job["cached_tokens_of_others"] == [16]
+            assert job["finished_requests"] == 4 and job["tokens_per_request"] == [4]
     assert rep["fused_decode_models_during_capture"] > 0 and rep["eager_fused_decode_forwards_in_the_timed_job"] == 0
     assert rep["graph_replays_in_the_timed_job"] >= 3
     # greedy tokens of a random-weight model: a near-tie may flip between two bf16 evaluations; most tokens must agree exactly
