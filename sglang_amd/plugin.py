@@ -8,11 +8,12 @@ in launch_server.py:8, i.e. before ServerArgs are parsed, so the new CLI choices
 point makes `current_platform.is_out_of_tree()` true so that the out-of-tree forwards registered below are the
 ones `BaseFusedOp` dispatches to (kernels/fused_op.py:196-203, 535-544).
 
-sglang itself cannot be imported in the build container (orjson / msgspec / zmq missing).  tests/test_plugin_contract.py
-executes `load()` against a stand-in `sglang` package generated from the reference's own sources
-(tests/golden/gen_contract.py ast-parses the cited files into tests/golden/reference_contract.json: module paths,
-function / method signatures, registry semantics), so every import and every registration call below is checked
-against the reference's names and arities.
+sglang itself cannot be installed in the build container (orjson / msgspec / zmq missing).  Two checks stand in for that:
+tests/test_plugin_contract.py executes `load()` against a stand-in `sglang` package generated from the reference's own sources
+(tests/golden/gen_contract.py ast-parses the cited files into tests/golden/reference_contract.json: module paths, function /
+method signatures, registry semantics); and tests/test_reference_model{,_gpu}.py import the REFERENCE'S OWN sources with only
+the absent third-party packages stubbed (tests/golden/ref_model.py) -- there `load()` is discovered and executed by the reference's
+`load_plugins()`, and the result runs under the reference's models, `ModelRunner` and `Scheduler`.
 """
 from __future__ import annotations
 
