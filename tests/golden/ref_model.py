@@ -730,6 +730,38 @@ def run_gpu(dims_name="tiny") -> dict:
                 degraded_reference_modules=[n for n, _ in G.FAILED], unstaged_reference_modules=sorted(set(getattr(G, "NOT_FOUND", []))))
 
 
+def write_checkpoint_config(dims_name, max_pos=2048) -> Path:
+    """A model directory holding config.json only (the weights come from `--load-format dummy` or from hf_checkpoint())."""
+    import json as _json
+    import tempfile as _tf
+
+    arch = ARCH.get(dims_name, "llama")
+    H, I, L, Hq, Hkv, D, V = DIMS[dims_name]
+    cfg = dict(hidden_size=H, intermediate_size=I, num_hidden_layers=L, num_attention_heads=Hq, num_key_value_heads=Hkv, vocab_size=V,
+               max_position_embeddings=max_pos, rope_theta=ROPE_THETA[arch], rms_norm_eps=EPS[arch], torch_dtype="bfloat16", hidden_act="silu",
+               bos_token_id=1, eos_token_id=2)
+    if arch == "qwen2":
+        cfg.update(architectures=["Qwen2ForCausalLM"], model_type="qwen2", tie_word_embeddings=True)
+    elif arch == "mixtral":
+        cfg.update(architectures=["MixtralForCausalLM"], model_type="mixtral", tie_word_embeddings=False, num_local_experts=EXPERTS,
+                   num_experts_per_tok=TOP_K)
+    else:
+        cfg.update(architectures=["LlamaForCausalLM"], model_type="llama", tie_word_embeddings=False, head_dim=D)
+    d = Path(_tf.mkdtemp(prefix="ref_model_ckpt_"))
+    (d / "config.json").write_text(_json.dumps(cfg))
+    return d
+
+
+def oracle_config(dims_name, max_pos=2048):
+    from sglang_amd.harness.models import ModelConfig as OCfg
+
+    arch = ARCH.get(dims_name, "llama")
+    H, I, L, Hq, Hkv, D, V = DIMS[dims_name]
+    return OCfg("ref", H, I, L, Hq, Hkv, D, V, EPS[arch], ROPE_THETA[arch], None, max_pos, attention_bias=arch == "qwen2",
+                tie_word_embeddings=arch == "qwen2", num_local_experts=EXPERTS if arch == "mixtral" else 0,
+                num_experts_per_tok=TOP_K if arch == "mixtral" else 0)
+
+
 # ---- one level up: the reference's ModelRunner, driven by the reference's own static-batch harness ----------------------------
 def run_runner(dims_name="tiny") -> dict:
     """`sglang.benchmark.one_batch` (the module behind `python -m sglang.bench_one_batch`) is the reference's own way to run a
@@ -1135,7 +1167,8 @@ def run_shared_prefix_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=1
                 passes=records)
 
 
-def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, unique=8, out=4, overlap=False, server_args=None) -> dict:
+def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, unique=8, out=4, overlap=False, server_args=None,
+                      logprobs=False) -> dict:
     """The reference's `Scheduler` ITSELF (managers/scheduler.py: request intake, `PrefillAdder`, the real radix cache built by
     `kv_cache_builder`, running-batch merge, `TpModelWorker` -> `ModelRunner`, result processing, output streaming) with the body of
     its `event_loop_normal` (scheduler.py:1748-1780) executed here step by step instead of behind zmq sockets (zmq is not in this
@@ -1158,11 +1191,8 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
     ns = install()
     H, I, L, Hq, Hkv, D, V = DIMS[dims_name]
     real_weights = L <= 4                               # the small models carry real weights (token-level check), the 8B one dummy weights
-    d = Path(_tf.mkdtemp(prefix="ref_model_ckpt_"))
-    (d / "config.json").write_text(_json.dumps(dict(
-        architectures=["LlamaForCausalLM"], model_type="llama", hidden_size=H, intermediate_size=I, num_hidden_layers=L,
-        num_attention_heads=Hq, num_key_value_heads=Hkv, head_dim=D, vocab_size=V, max_position_embeddings=8192, rope_theta=ROPE_THETA["llama"],
-        rms_norm_eps=1e-5, tie_word_embeddings=False, torch_dtype="bfloat16", hidden_act="silu", bos_token_id=1, eos_token_id=2)))
+    arch = ARCH.get(dims_name, "llama")
+    d = write_checkpoint_config(dims_name, max_pos=8192)
     common = importlib.import_module("sglang.srt.utils.common")
     if not gpu:
         from sglang.kernels import fused_op as FO
@@ -1202,7 +1232,7 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
     sch.is_initializing = False
     runner = sch.tp_worker.model_runner
     if real_weights:
-        runner.model.load_weights(list(hf_checkpoint(DIMS[dims_name], runner.device).items()))
+        runner.model.load_weights(list(hf_checkpoint(DIMS[dims_name], runner.device, arch=arch).items()))
     captured = counts["fused_decode_models"]
     graph_runner = getattr(runner, "decode_cuda_graph_runner", None)
     if graph_runner is not None and hasattr(graph_runner, "execute"):
@@ -1223,8 +1253,8 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
         sp = SP(temperature=0, max_new_tokens=out, ignore_eos=True)
         sp.normalize(None)
         return io.TokenizedGenerateReqInput(rid=rid, input_text=None, input_ids=array("q", ids), input_embeds=None, mm_inputs=None,
-                                            token_type_ids=None, sampling_params=sp, return_logprob=False, logprob_start_len=-1,
-                                            top_logprobs_num=0, token_ids_logprob=None, stream=False)
+                                            token_type_ids=None, sampling_params=sp, return_logprob=logprobs, logprob_start_len=-1,
+                                            top_logprobs_num=2 if logprobs else 0, token_ids_logprob=None, stream=False)
 
     # The reference's own loop runs -- `Scheduler.run_event_loop()` (scheduler.py:1696-1732: schedule stream, WAR barrier, dispatch to
     # event_loop_normal / event_loop_overlap) -- with ONE substitution: the receiver's raw socket read (`_pull_raw_reqs`) hands out
@@ -1277,16 +1307,19 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
         if gpu:
             torch.cuda.synchronize()
         t1 = time.perf_counter()
-        got, cached = {}, {}
+        got, cached, lp, top = {}, {}, {}, {}
         for o in outs:
             if type(o).__name__ != "BatchTokenIDOutput":
                 continue
             for i, rid in enumerate(o.rids):                  # (a request's ids arrive in increments: every forced stream interval + the end)
                 got.setdefault(rid, []).extend(list(o.output_ids[i]))
+                if logprobs and o.output_token_logprobs_val:
+                    lp.setdefault(rid, []).extend(float(x) for x in o.output_token_logprobs_val[i])
+                    top.setdefault(rid, []).extend([list(map(int, ix)) for ix in o.output_top_logprobs_idx[i]])
                 if o.finished_reasons[i] is not None:
                     cached[rid] = int(o.cached_tokens[i])
         return dict(seconds=t1 - t0, output_tokens_per_s=B * out / (t1 - t0), batches=first + rest, prompts=prompts, generated=got,
-                    cached_tokens=cached, leaders=leaders)
+                    cached_tokens=cached, leaders=leaders, logprobs=lp, top_idx=top)
 
     with torch.no_grad():
         warm = job("warm")
@@ -1311,9 +1344,8 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
     if real_weights:
         # the oracle's greedy generation of the timed job's prompts, prefixes shared the same way
         from oracle.model import OracleLM
-        from sglang_amd.harness.models import ModelConfig as OCfg
 
-        olm = OracleLM(OCfg("ref", H, I, L, Hq, Hkv, D, V, 1e-5, ROPE_THETA["llama"], None, 8192), oracle_weights(runner.model),
+        olm = OracleLM(oracle_config(dims_name, 8192), oracle_weights(runner.model),
                        num_slots=4 * tokens, max_ctx=prefix + unique + out + 8, max_reqs=B, device=runner.device)
         rids = list(timed["prompts"])
         grp = [[rids.index(f"timed-g{gi}r{j}") for j in range(per_group)] for gi in range(groups)]
@@ -1321,6 +1353,21 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
         same = sum(int(list(w) == timed["generated"].get(r)) for r, w in zip(rids, want))
         rep["oracle"] = dict(requests=len(rids), requests_with_identical_tokens=same,
                              token_agreement=sum(int(a == b) for r, w in zip(rids, want) for a, b in zip(w, timed["generated"].get(r, []))) / (len(rids) * out))
+        if logprobs:
+            # the log-probabilities the scheduler streamed with the tokens (sampler -> output_logprob_processor -> output streamer) against
+            # log_softmax of the oracle's logits, the oracle teacher-forced with the tokens the run produced
+            olm2 = OracleLM(oracle_config(dims_name, 8192), oracle_weights(runner.model), num_slots=4 * tokens,
+                            max_ctx=prefix + unique + out + 8, max_reqs=B, device=runner.device)
+            forced = [timed["generated"][r] for r in rids]
+            _, steps = olm2.generate([timed["prompts"][r] for r in rids], out, return_logits=True, forced=forced, share_prefix_groups=grp, shared_len=prefix)
+            worst, top_ok, n = 0.0, 0, 0
+            for t, lg in enumerate(steps):
+                ls = torch.log_softmax(lg.float(), dim=-1).cpu()
+                for bi, r in enumerate(rids):
+                    worst = max(worst, abs(float(ls[bi, forced[bi][t]]) - timed["logprobs"][r][t]))
+                    top_ok += int(sorted(ls[bi].topk(2).indices.tolist()) == sorted(timed["top_idx"][r][t]))
+                    n += 1
+            rep["oracle"].update(logprob_values=n, max_abs_logprob_diff=worst, top2_sets_equal=top_ok)
     return rep
 
 
@@ -1459,6 +1506,7 @@ if __name__ == "__main__":
     ap.add_argument("--shape", default="4,16,4", help="latency run: batch size, input length, output length")
     ap.add_argument("--job", default="2,2,16,8,4", help="shared-prefix run: groups, requests per group, shared tokens, own tokens, output tokens")
     ap.add_argument("--server-args", default=None, help='scheduler run: extra ServerArgs as JSON, e.g. {"page_size": 16, "chunked_prefill_size": 64}')
+    ap.add_argument("--logprobs", action="store_true", help="scheduler run: return_logprob + top-2 logprobs on every request")
     ap.add_argument("--overlap", action="store_true", help="scheduler run: the body of event_loop_overlap (the server default)")
     ap.add_argument("--radix", action="store_true", help="shared-prefix run: prefixes from the reference's real RadixCache")
     ap.add_argument("--tp", type=int, default=1, help="tensor-parallel ranks: this process launches itself N times (rank 0 reports)")
@@ -1490,7 +1538,7 @@ if __name__ == "__main__":
     rep = {"cpu-oracle": lambda: run_cpu_oracle(a.dims), "loader": run_loader, "gpu": lambda: run_gpu(a.dims),
            "runner": lambda: run_runner(a.dims), "latency": lambda: run_latency(a.dims, *[int(x) for x in a.shape.split(",")]),
            "scheduler": lambda: run_scheduler_job(a.dims if a.dims != "tiny" else "tiny_v16k", *[int(x) for x in a.job.split(",")],
-                                                  overlap=a.overlap, server_args=_json_arg(a.server_args)),
+                                                  overlap=a.overlap, server_args=_json_arg(a.server_args), logprobs=a.logprobs),
            "shared-prefix": lambda: run_shared_prefix_job(a.dims if a.dims != "tiny" else "tiny_v16k", *[int(x) for x in a.job.split(",")],
                                                           radix=a.radix)}[a.run]()
     rep["tp"] = tp_world()[0]

@@ -131,6 +131,20 @@ def test_oracle_equals_the_reference_under_the_references_scheduler_with_chunked
     assert rep["oracle"] == dict(requests=6, requests_with_identical_tokens=6, token_agreement=1.0)
 
 
+@pytest.mark.parametrize("extra,what", [(("--logprobs",), "return_logprob + top-2 logprobs on every request"),
+                                        (("--dims", "tiny_mixtral"), "MixtralForCausalLM under the scheduler")])
+def test_oracle_equals_the_reference_under_the_references_scheduler_logprobs_and_moe(tmp_path, extra, what):
+    """(a) every request asks for log-probabilities: the values the scheduler streams with the tokens (sampler ->
+    `output_logprob_processor` -> output streamer) equal `log_softmax` of the oracle's logits -- the oracle teacher-forced with the
+    produced tokens -- exactly, and so do the top-2 sets; (b) the MoE model under the same loop."""
+    _root_or_skip()
+    rep = _run("scheduler", tmp_path, extra=("--overlap",) + extra)
+    o = rep["oracle"]
+    assert (o["requests"], o["requests_with_identical_tokens"], o["token_agreement"]) == (4, 4, 1.0), (what, o)
+    if "--logprobs" in extra:
+        assert (o["logprob_values"], o["max_abs_logprob_diff"], o["top2_sets_equal"]) == (16, 0.0, 16), o
+
+
 def test_the_references_loader_discovers_and_executes_the_plugin(tmp_path):
     import ref_model
 

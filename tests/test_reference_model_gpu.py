@@ -135,7 +135,7 @@ def test_plugin_under_the_references_model_runner(device, dims, model):
         assert ps["product_max_err"] <= 2.0 * ps["reference_max_err"] + 1e-3, ps
 
 
-@pytest.mark.parametrize("loop", ["normal", "overlap", "overlap-paged-chunked"])
+@pytest.mark.parametrize("loop", ["normal", "overlap", "overlap-paged-chunked", "overlap-logprobs", "overlap-mixtral"])
 def test_plugin_under_the_references_scheduler(device, loop):
     """The reference's `Scheduler` itself on MI355X with the plug-in, running its own `run_event_loop()` (tests/golden/ref_model.py
     run_scheduler_job; CPU twin in tests/test_reference_model.py): intake, prefill admission, radix cache, continuous batching,
@@ -154,6 +154,10 @@ def test_plugin_under_the_references_scheduler(device, loop):
     extra = ["--overlap"] if loop != "normal" else []
     if variant:
         extra += ["--job", "2,3,80,24,6", "--server-args", '{"page_size": 16, "chunked_prefill_size": 64}']
+    if loop == "overlap-logprobs":      # every request with return_logprob + top-2: the plug-in sampler's log-probability outputs
+        extra += ["--logprobs"]
+    if loop == "overlap-mixtral":       # MixtralForCausalLM: no model-level hook; hooked projections, registered ops, the MoE slot
+        extra += ["--dims", "tiny_mixtral"]
     p = subprocess.run([sys.executable, str(ROOT / "tests" / "golden" / "ref_model.py"), "--run", "scheduler", "--json", str(out)] + extra,
                        cwd=ROOT, env=dict(os.environ, SGLANG_USE_AITER="0"), capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-6000:]
@@ -172,7 +176,14 @@ def test_plugin_under_the_references_scheduler(device, loop):
             assert b["EXTEND x2"] == 2 and b.get("DECODE x4", 0) >= 1 and sum(v for k, v in b.items() if k.startswith("DECODE")) >= 3, b
             assert job["cached_tokens_of_leaders"] == [0] and job["cached_tokens_of_others"] == [16]
             assert job["finished_requests"] == 4 and job["tokens_per_request"] == [4]
-    assert rep["fused_decode_models_during_capture"] > 0 and rep["eager_fused_decode_forwards_in_the_timed_job"] == 0
+    moe = loop == "overlap-mixtral"
+    assert (rep["fused_decode_models_during_capture"] == 0) == moe and rep["eager_fused_decode_forwards_in_the_timed_job"] == 0
     assert rep["graph_replays_in_the_timed_job"] >= 3
-    # greedy tokens of a random-weight model: a near-tie may flip between two bf16 evaluations; most tokens must agree exactly
-    assert rep["oracle"]["token_agreement"] >= 0.75, rep["oracle"]
+    # greedy tokens of a random-weight model: a near-tie may flip between two bf16 evaluations (for the MoE model a flipped expert
+    # choice too); most tokens must agree exactly
+    o = rep["oracle"]
+    assert o["token_agreement"] >= (0.6 if moe else 0.75), o
+    if loop == "overlap-logprobs":
+        # the streamed log-probabilities against log_softmax of the oracle's logits (teacher-forced with the produced tokens): bf16
+        # logits of rms 1 carry ~0.01-0.03 of evaluation noise
+        assert o["logprob_values"] == 16 and o["max_abs_logprob_diff"] <= 0.08 and o["top2_sets_equal"] >= 12, o
