@@ -145,6 +145,19 @@ def test_oracle_equals_the_reference_under_the_references_scheduler_logprobs_and
         assert (o["logprob_values"], o["max_abs_logprob_diff"], o["top2_sets_equal"]) == (16, 0.0, 16), o
 
 
+def test_the_references_scheduler_with_mixed_chunks(tmp_path):
+    """`--enable-mixed-chunk --chunked-prefill-size 64`: the scheduler puts a prefill chunk and the running decode requests into ONE
+    forward (`ForwardMode.MIXED`).  A decode token then goes through the extend path (one new token over a long prefix), whose bf16
+    reduction order differs from the decode path's -- in the reference's own torch-native backend too -- so a near-tie may flip: the
+    job's structure is asserted exactly, the tokens against the oracle's decode-path generation for most positions."""
+    _root_or_skip()
+    rep = _run("scheduler", tmp_path, extra=("--overlap", "--job", "2,3,80,24,6", "--server-args", '{"chunked_prefill_size": 64, "enable_mixed_chunk": true}'))
+    for job in (rep["warm_up"], rep["timed"]):
+        assert sum(v for k, v in job["batches_run"].items() if k.startswith("MIXED")) >= 2, job["batches_run"]
+        assert job["cached_tokens_of_others"] == [80] and job["finished_requests"] == 6 and job["tokens_per_request"] == [6]
+    assert rep["oracle"]["token_agreement"] >= 0.8, rep["oracle"]
+
+
 def test_the_references_loader_discovers_and_executes_the_plugin(tmp_path):
     import ref_model
 
