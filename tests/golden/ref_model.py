@@ -1209,11 +1209,12 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
             common.get_device_memory_capacity = ns.server_args.get_device_memory_capacity = lambda device=None: mib
     B = groups * per_group
     tokens = 2 * (groups * (prefix + unique) + (B - groups) * unique + B * out)           # two jobs' worth: the tree keeps the first
-    sa = ns.server_args.ServerArgs(
-        model_path=str(d), load_format="dummy", skip_tokenizer_init=True, dtype="bfloat16", device="cuda" if gpu else "cpu",
-        attention_backend=None if gpu else "torch_native", sampling_backend=loader["default_attention_backend"] if gpu else "pytorch",
-        max_total_tokens=tokens + 4096, max_running_requests=max(16, B), cuda_graph_max_bs_decode=B, mem_fraction_static=0.5,
-        disable_overlap_schedule=not overlap, random_seed=3, **(server_args or {}))
+    kw = dict(model_path=str(d), load_format="dummy", skip_tokenizer_init=True, dtype="bfloat16", device="cuda" if gpu else "cpu",
+              attention_backend=None if gpu else "torch_native", sampling_backend=loader["default_attention_backend"] if gpu else "pytorch",
+              max_total_tokens=tokens + 4096, max_running_requests=max(16, B), cuda_graph_max_bs_decode=B, mem_fraction_static=0.5,
+              disable_overlap_schedule=not overlap, random_seed=3)
+    kw.update(server_args or {})
+    sa = ns.server_args.ServerArgs(**kw)
     ns.server_args.set_global_server_args_for_scheduler(sa)
     pa = ns.server_args.PortArgs.init_new(sa)
     counts = dict(fused_decode_models=0, graph_replays=0)
@@ -1245,6 +1246,19 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
         graph_runner.execute = counting_execute
     outs = []
     sch.ipc_channels.send_to_detokenizer.send_output = lambda output, recv_obj=None: outs.append(output)
+    counts["retracted_requests"] = 0
+    SBcls = importlib.import_module("sglang.srt.managers.schedule_batch").ScheduleBatch
+    retract = SBcls.retract_decode
+
+    def counting_retract(self, *a_, **k_):
+        res = retract(self, *a_, **k_)
+        try:
+            counts["retracted_requests"] += len(res[0])
+        except Exception:                                   # noqa: BLE001
+            counts["retracted_requests"] += 1
+        return res
+
+    SBcls.retract_decode = counting_retract
     io = importlib.import_module("sglang.srt.managers.io_struct")
     SP = importlib.import_module("sglang.srt.sampling.sampling_params").SamplingParams
     g = torch.Generator().manual_seed(5)
@@ -1332,7 +1346,8 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
                shape=dict(groups=groups, per_group=per_group, prefix=prefix, unique=unique, out=out),
                fused_decode_models_during_capture=captured,
                eager_fused_decode_forwards_in_the_timed_job=counts["fused_decode_models"] - before["fused_decode_models"],
-               graph_replays_in_the_timed_job=counts["graph_replays"] - before["graph_replays"])
+               graph_replays_in_the_timed_job=counts["graph_replays"] - before["graph_replays"],
+               retracted_requests=counts["retracted_requests"], max_total_num_tokens=int(runner.max_total_num_tokens))
     for tag, j in (("warm_up", warm), ("timed", timed)):
         hit = sorted(set(v for r, v in j["cached_tokens"].items() if r not in j["leaders"]))
         modes = {}

@@ -158,6 +158,18 @@ def test_the_references_scheduler_with_mixed_chunks(tmp_path):
     assert rep["oracle"]["token_agreement"] >= 0.8, rep["oracle"]
 
 
+def test_the_references_scheduler_retracts_and_the_tokens_do_not_change(tmp_path):
+    """A KV pool too small for the eight requests' 40 output tokens, admitted aggressively (`--schedule-conservativeness 0.05`): the
+    scheduler runs out of slots in the middle of decoding, retracts a request (frees its slots, puts it back into the waiting queue),
+    re-prefills it later over whatever the radix tree still holds -- and every request still ends with the oracle's tokens."""
+    _root_or_skip()
+    rep = _run("scheduler", tmp_path, extra=("--overlap", "--job", "2,4,32,16,40", "--server-args", '{"max_total_tokens": 380, "schedule_conservativeness": 0.05}'))
+    assert rep["retracted_requests"] >= 1 and rep["max_total_num_tokens"] == 380
+    for job in (rep["warm_up"], rep["timed"]):
+        assert job["finished_requests"] == 8 and job["tokens_per_request"] == [40]
+    assert rep["oracle"] == dict(requests=8, requests_with_identical_tokens=8, token_agreement=1.0)
+
+
 def test_the_references_loader_discovers_and_executes_the_plugin(tmp_path):
     import ref_model
 

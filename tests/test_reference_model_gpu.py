@@ -135,7 +135,7 @@ def test_plugin_under_the_references_model_runner(device, dims, model):
         assert ps["product_max_err"] <= 2.0 * ps["reference_max_err"] + 1e-3, ps
 
 
-@pytest.mark.parametrize("loop", ["normal", "overlap", "overlap-paged-chunked", "overlap-logprobs", "overlap-mixtral", "overlap-mixed"])
+@pytest.mark.parametrize("loop", ["normal", "overlap", "overlap-paged-chunked", "overlap-logprobs", "overlap-mixtral", "overlap-mixed", "overlap-retract"])
 def test_plugin_under_the_references_scheduler(device, loop):
     """The reference's `Scheduler` itself on MI355X with the plug-in, running its own `run_event_loop()` (tests/golden/ref_model.py
     run_scheduler_job; CPU twin in tests/test_reference_model.py): intake, prefill admission, radix cache, continuous batching,
@@ -154,6 +154,8 @@ def test_plugin_under_the_references_scheduler(device, loop):
     extra = ["--overlap"] if loop != "normal" else []
     if variant:
         extra += ["--job", "2,3,80,24,6", "--server-args", '{"page_size": 16, "chunked_prefill_size": 64}']
+    if loop == "overlap-retract":       # a KV pool too small for the job, admitted aggressively: the scheduler retracts and re-prefills
+        extra += ["--job", "2,4,32,16,40", "--server-args", '{"max_total_tokens": 380, "schedule_conservativeness": 0.05}']
     if loop == "overlap-mixed":         # --enable-mixed-chunk: prefill chunks and running decodes in one ForwardMode.MIXED forward
         extra += ["--job", "2,3,80,24,6", "--server-args", '{"chunked_prefill_size": 64, "enable_mixed_chunk": true}']
     if loop == "overlap-logprobs":      # every request with return_logprob + top-2: the plug-in sampler's log-probability outputs
@@ -169,7 +171,9 @@ def test_plugin_under_the_references_scheduler(device, loop):
                                    "normal" if loop == "normal" else "overlap")
     for job in (rep["warm_up"], rep["timed"]):
         b = job["batches_run"]
-        if loop == "overlap-mixed":
+        if loop == "overlap-retract":
+            assert job["finished_requests"] == 8 and job["tokens_per_request"] == [40] and job["cached_tokens_of_leaders"] == [0]
+        elif loop == "overlap-mixed":
             assert sum(v for k, v in b.items() if k.startswith("MIXED")) >= 2, b
             assert job["cached_tokens_of_others"] == [80] and job["finished_requests"] == 6 and job["tokens_per_request"] == [6]
         elif variant:
@@ -184,6 +188,8 @@ def test_plugin_under_the_references_scheduler(device, loop):
     moe = loop == "overlap-mixtral"
     assert (rep["fused_decode_models_during_capture"] == 0) == moe and rep["eager_fused_decode_forwards_in_the_timed_job"] == 0
     assert rep["graph_replays_in_the_timed_job"] >= 3
+    if loop == "overlap-retract":
+        assert rep["retracted_requests"] >= 1 and rep["max_total_num_tokens"] == 380, rep["retracted_requests"]
     if loop == "overlap-mixed":         # (a decode token inside a MIXED forward takes the extend path: another reduction order)
         assert rep["oracle"]["token_agreement"] >= 0.6, rep["oracle"]
         return
