@@ -196,7 +196,8 @@ def test_plugin_under_the_references_scheduler(device, loop):
     # greedy tokens of a random-weight model: a near-tie may flip between two bf16 evaluations (for the MoE model a flipped expert
     # choice too); most tokens must agree exactly
     o = rep["oracle"]
-    assert o["token_agreement"] >= (0.6 if moe else 0.75), o
+    # (40 free-running greedy tokens per request in the retraction case: once a near-tie flips, the rest of that request differs)
+    assert o["token_agreement"] >= (0.6 if moe or loop == "overlap-retract" else 0.75), o
     if loop == "overlap-logprobs":
         # the streamed log-probabilities against log_softmax of the oracle's logits (teacher-forced with the produced tokens): bf16
         # logits of rms 1 carry ~0.01-0.03 of evaluation noise
