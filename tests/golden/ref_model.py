@@ -763,7 +763,7 @@ def oracle_config(dims_name, max_pos=2048):
 
 
 # ---- one level up: the reference's ModelRunner, driven by the reference's own static-batch harness ----------------------------
-def run_runner(dims_name="tiny") -> dict:
+def run_runner(dims_name="tiny", server_args=None) -> dict:
     """`sglang.benchmark.one_batch` (the module behind `python -m sglang.bench_one_batch`) is the reference's own way to run a
     model WITHOUT the scheduler process: `load_model` builds a real `ServerArgs` (its whole resolution pipeline), `ModelConfig`,
     `ModelRunner` (distributed init, model loader, KV-cache configurator + memory pools + allocator, attention backend from the
@@ -814,11 +814,12 @@ def run_runner(dims_name="tiny") -> dict:
             common.get_device_memory_capacity = ns.server_args.get_device_memory_capacity = lambda device=None: mib
     OB = importlib.import_module("sglang.benchmark.one_batch")
     # ---- what one_batch.load_model does (one_batch.py:299-362), minus the tokenizer -------------------------------------------
-    sa = ns.server_args.ServerArgs(
-        model_path=str(d), load_format="dummy", skip_tokenizer_init=True, dtype="bfloat16", device="cuda" if gpu else "cpu",
-        attention_backend=None if gpu else "torch_native", sampling_backend=loader["default_attention_backend"] if gpu else "pytorch",
-        max_total_tokens=8192, max_running_requests=16, cuda_graph_max_bs_decode=8, mem_fraction_static=0.3, disable_radix_cache=True,
-        random_seed=3)
+    kw = dict(model_path=str(d), load_format="dummy", skip_tokenizer_init=True, dtype="bfloat16", device="cuda" if gpu else "cpu",
+              attention_backend=None if gpu else "torch_native", sampling_backend=loader["default_attention_backend"] if gpu else "pytorch",
+              max_total_tokens=8192, max_running_requests=16, cuda_graph_max_bs_decode=8, mem_fraction_static=0.3, disable_radix_cache=True,
+              random_seed=3)
+    kw.update(server_args or {})
+    sa = ns.server_args.ServerArgs(**kw)
     model_config = importlib.import_module("sglang.srt.configs.model_config").ModelConfig.from_server_args(sa)
     ps = importlib.import_module("sglang.srt.distributed.parallel_state_wrapper").ParallelState.trivial(gpu_id=0)
     MR = importlib.import_module("sglang.srt.model_executor.model_runner")
@@ -877,8 +878,9 @@ def run_runner(dims_name="tiny") -> dict:
     dev = runner.device
     w = oracle_weights(runner.model)
     slots = int(runner.token_to_kv_pool.size) + int(runner.page_size) + 8
-    olm = OracleLM(ocfg, w, num_slots=slots, max_ctx=8, max_reqs=1, device=dev)
-    olm32 = OracleLM(ocfg, w, num_slots=slots, max_ctx=8, max_reqs=1, device=dev, compute_dtype=torch.float32) if gpu else None
+    kvd = "fp8_e4m3" if str(getattr(sa, "kv_cache_dtype", "auto")) == "fp8_e4m3" else "auto"       # the pool stores e4m3 rows (scale 1.0)
+    olm = OracleLM(ocfg, w, num_slots=slots, max_ctx=8, max_reqs=1, device=dev, kv_cache_dtype=kvd)
+    olm32 = OracleLM(ocfg, w, num_slots=slots, max_ctx=8, max_reqs=1, device=dev, compute_dtype=torch.float32, kv_cache_dtype=kvd) if gpu else None
     records = []
 
     def check(what, batch, logits, decode_):
@@ -940,7 +942,8 @@ def run_runner(dims_name="tiny") -> dict:
         passes.append(ps_)
     import gen_golden as G
 
-    return dict(mode="runner", dims=dims_name, device=str(dev), loader=loader, attention_backend=sa.attention_backend,
+    return dict(mode="runner", dims=dims_name, device=str(dev), loader=loader, attention_backend=sa.attention_backend, server_args=server_args or {},
+                kv_pool_dtype=str(getattr(runner.token_to_kv_pool, "dtype", None)),
                 attn_backend_class=type(runner.attn_backend).__name__, sampler_class=type(runner.sampler).__name__,
                 model=type(runner.model).__name__, kv_pool=type(runner.token_to_kv_pool).__name__,
                 allocator=type(runner.token_to_kv_pool_allocator).__name__, max_total_num_tokens=int(runner.max_total_num_tokens),
@@ -1551,7 +1554,7 @@ if __name__ == "__main__":
         stage()
         sys.exit(0)
     rep = {"cpu-oracle": lambda: run_cpu_oracle(a.dims), "loader": run_loader, "gpu": lambda: run_gpu(a.dims),
-           "runner": lambda: run_runner(a.dims), "latency": lambda: run_latency(a.dims, *[int(x) for x in a.shape.split(",")]),
+           "runner": lambda: run_runner(a.dims, _json_arg(a.server_args)), "latency": lambda: run_latency(a.dims, *[int(x) for x in a.shape.split(",")]),
            "scheduler": lambda: run_scheduler_job(a.dims if a.dims != "tiny" else "tiny_v16k", *[int(x) for x in a.job.split(",")],
                                                   overlap=a.overlap, server_args=_json_arg(a.server_args), logprobs=a.logprobs),
            "shared-prefix": lambda: run_shared_prefix_job(a.dims if a.dims != "tiny" else "tiny_v16k", *[int(x) for x in a.job.split(",")],

@@ -67,6 +67,15 @@ def test_oracle_equals_the_reference_on_qwen2_and_at_tp2(tmp_path, extra, what):
     assert rep["tp"] == (2 if "--tp" in extra else 1)
 
 
+def test_oracle_fp8_kv_mode_equals_the_references_fp8_pool(tmp_path):
+    """`--kv-cache-dtype fp8_e4m3`: the reference's `MHATokenToKVPool` stores float8_e4m3fn rows (memory_pool.py:2364-2374) and its
+    torch-native backend reads them back; the oracle's `kv_cache_dtype="fp8_e4m3"` mode reproduces every logit bit for bit."""
+    _root_or_skip()
+    rep = _run("runner", tmp_path, extra=("--server-args", '{"kv_cache_dtype": "fp8_e4m3"}'))
+    assert rep["kv_pool_dtype"] == "torch.float8_e4m3fn"
+    assert len(rep["passes"]) == 6 and all(p["identical"] and p["ref_rms"] > 0.5 for p in rep["passes"]), rep["passes"]
+
+
 @pytest.mark.parametrize("dims,model", [("tiny", "LlamaForCausalLM"), ("tiny_qwen2", "Qwen2ForCausalLM"), ("tiny_mixtral", "MixtralForCausalLM")])
 def test_oracle_equals_the_reference_under_the_references_model_runner(tmp_path, dims, model):
     """One level up (tests/golden/ref_model.py run_runner): the reference's real `ServerArgs` (its whole resolution pipeline),

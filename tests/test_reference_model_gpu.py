@@ -95,6 +95,28 @@ def test_plugin_under_the_references_model_stack(device, dims, tp):
     assert s["is_reference_subclass"] and s["greedy_equals_argmax"] and s["seeded_ids_equal"], s
 
 
+def test_plugin_under_the_references_model_runner_with_an_fp8_kv_pool(device):
+    """`--kv-cache-dtype fp8_e4m3` under the reference's ModelRunner: the reference's pool holds float8_e4m3fn rows, the plug-in's store /
+    attention kernels and the fused decode layer write and read them (captured in the reference's decode graphs); logits inside the band
+    of the reference's literal evaluation over the same e4m3 rows."""
+    import ref_model
+
+    if ref_model.ref_root() is None:
+        pytest.skip("reference sources are not staged (python tests/golden/ref_model.py --run stage in the build container)")
+    out = ROOT / "gpurun_out" / "reference_model_runner_fp8kv.json"
+    p = subprocess.run([sys.executable, str(ROOT / "tests" / "golden" / "ref_model.py"), "--run", "runner", "--server-args",
+                        '{"kv_cache_dtype": "fp8_e4m3"}', "--json", str(out)],
+                       cwd=ROOT, env=dict(os.environ, SGLANG_USE_AITER="0"), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-6000:]
+    rep = json.loads(out.read_text())
+    assert rep["kv_pool_dtype"] == "torch.float8_e4m3fn" and rep["attn_backend_class"] == "HipAttnBackend"
+    c = rep["counts"]
+    assert rep["fused_decode_models_during_capture"] > 0 and (c["graph_replays"], c["not_fused_because"]) == (4, []), c
+    for ps in rep["passes"]:
+        assert ps["product_rms_err"] <= 1.25 * ps["reference_rms_err"] + 1e-3, ps
+        assert ps["product_max_err"] <= 2.0 * ps["reference_max_err"] + 1e-2, ps
+
+
 @pytest.mark.parametrize("dims,model", [("tiny", "LlamaForCausalLM"), ("tiny_qwen2", "Qwen2ForCausalLM"), ("tiny_mixtral", "MixtralForCausalLM")])
 def test_plugin_under_the_references_model_runner(device, dims, model):
     """The reference's `ModelRunner` itself, on MI355X with the plug-in (tests/golden/ref_model.py run_runner; its CPU twin:
