@@ -29,6 +29,14 @@ def _need(cond: bool, msg: str) -> None:
         raise ValueError(msg)
 
 
+def _kv_rows_dtype_ok(cache: torch.Tensor, kv_fp8: bool) -> bool:
+    """bf16 rows, or OCP e4m3 rows held either as raw bytes (this package's pool: `store_dtype` uint8) or as the float8_e4m3fn
+    VIEW of them that the reference's pool hands out (memory_pool.py:2288-2290 `k_buffer[...].view(self.dtype)`): same bytes."""
+    if kv_fp8:
+        return cache.dtype in (torch.uint8, torch.float8_e4m3fn)
+    return cache.dtype == _BF16
+
+
 def _dev(*ts: torch.Tensor) -> None:
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -127,7 +135,7 @@ def store_kv_cache(k: torch.Tensor, v: torch.Tensor, k_cache: torch.Tensor, v_ca
         _need(num_kv_heads is not None and head_dim is not None, "store_kv_cache: fp8 / HND pools need num_kv_heads and head_dim")
         k2, v2 = k.view(T, -1), v.view(T, -1)
         _need(k2.dtype == _BF16 and v2.dtype == _BF16 and k2.shape[1] == num_kv_heads * head_dim, "store_kv_cache: bf16 [T, H_kv * D] rows")
-        _need(k_cache.dtype == (torch.uint8 if kv_fp8 else _BF16) and v_cache.dtype == k_cache.dtype, "store_kv_cache: pool dtype")
+        _need(_kv_rows_dtype_ok(k_cache, kv_fp8) and v_cache.dtype == k_cache.dtype, "store_kv_cache: pool dtype")
         native.call("sgl_amd_store_kv_cache_ex", k2.data_ptr(), v2.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), loc.data_ptr(),
                     T, num_kv_heads, head_dim, k2.stride(0), v2.stride(0), num_kv_heads * head_dim, 1 if kv_fp8 else 0,
                     float(k_scale), float(v_scale), int(page_size), 1 if hnd else 0, _stream())
@@ -252,7 +260,7 @@ def decode_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
     B, Hq, D = q.shape
     Hkv = k_cache.shape[1]
     if kv_fp8 or hnd or sliding_window >= 0 or logit_cap > 0:
-        _need(q.dtype == _BF16 and out.dtype == _BF16 and k_cache.dtype == (torch.uint8 if kv_fp8 else _BF16)
+        _need(q.dtype == _BF16 and out.dtype == _BF16 and _kv_rows_dtype_ok(k_cache, kv_fp8)
               and v_cache.dtype == k_cache.dtype and k_cache.is_contiguous() and v_cache.is_contiguous(), "decode_attention: dtypes / contiguous pools")
         _need(seq_lens.dtype == torch.int32 and req_to_token.dtype == torch.int32, "decode_attention: int32 seq_lens / req_to_token")
         _need(q.stride(2) == 1 and q.stride(1) == D and out.stride(2) == 1 and out.stride(1) == D, "decode_attention: q/out head layout")
@@ -289,7 +297,7 @@ def extend_attention(q: torch.Tensor, out: torch.Tensor, k_cache: torch.Tensor, 
     T, Hq, D = q.shape
     Hkv = k_cache.shape[1]
     if kv_fp8 or hnd or sliding_window >= 0 or logit_cap > 0 or custom_mask is not None:
-        _need(q.dtype == _BF16 and out.dtype == _BF16 and k_cache.dtype == (torch.uint8 if kv_fp8 else _BF16)
+        _need(q.dtype == _BF16 and out.dtype == _BF16 and _kv_rows_dtype_ok(k_cache, kv_fp8)
               and v_cache.dtype == k_cache.dtype and k_cache.is_contiguous() and v_cache.is_contiguous(), "extend_attention: dtypes / contiguous pools")
         _need(seq_lens.dtype == torch.int32 and prefix_lens.dtype == torch.int32 and qo_indptr.dtype == torch.int32, "extend_attention: int32 lens")
         _need(req_pool_indices.dtype == torch.int64 and req_to_token.dtype == torch.int32, "extend_attention: index dtypes")
@@ -364,7 +372,7 @@ def cascade_decode_attention(ws: CascadeWorkspace, q: torch.Tensor, k_cache: tor
     _dev(q, k_cache, v_cache, out)
     B, Hq, D = q.shape
     Hkv = k_cache.shape[1]
-    _need(q.dtype == _BF16 and out.dtype == _BF16 and k_cache.dtype == (torch.uint8 if kv_fp8 else _BF16)
+    _need(q.dtype == _BF16 and out.dtype == _BF16 and _kv_rows_dtype_ok(k_cache, kv_fp8)
           and v_cache.dtype == k_cache.dtype, "cascade: bf16 q / out, bf16 or uint8 (e4m3) pools")
     _need(q.stride(2) == 1 and q.stride(1) == D and out.stride(2) == 1 and out.stride(1) == D, "cascade: q/out head layout")
     if kv_fp8 or hnd:
@@ -771,7 +779,7 @@ def wstream_qkv_rope(x: torch.Tensor, w_qkv: torch.Tensor, bias: Optional[torch.
           "wstream_qkv_rope: cos_sin_cache [max_pos, head_dim]")
     row = num_kv_heads * head_dim
     if kv_fp8 or hnd:
-        _need(k_cache.dtype == (torch.uint8 if kv_fp8 else _BF16) and v_cache.dtype == k_cache.dtype and k_cache.is_contiguous()
+        _need(_kv_rows_dtype_ok(k_cache, kv_fp8) and v_cache.dtype == k_cache.dtype and k_cache.is_contiguous()
               and v_cache.is_contiguous() and k_cache.numel() % row == 0 and v_cache.numel() == k_cache.numel(),
               "wstream_qkv_rope: contiguous fp8 (uint8) / HND pool of Hkv*D rows")
         kc, vc, cache_rs = k_cache, v_cache, row

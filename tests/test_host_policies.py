@@ -318,3 +318,16 @@ def test_fused_decode_resolves_the_kv_pool_like_the_reference():
     assert fused_decode.kv_pool_of(types.SimpleNamespace(attn_backend=types.SimpleNamespace(token_to_kv_pool=pool_b))) is pool_b
     with pytest.raises(AttributeError):
         fused_decode.kv_pool_of(types.SimpleNamespace())
+
+
+def test_fp8_kv_rows_are_accepted_as_bytes_or_as_the_references_fp8_view():
+    """This package's pool stores e4m3 rows as uint8; the reference's pool hands out `k_buffer[...].view(torch.float8_e4m3fn)`
+    (memory_pool.py:2288-2290).  Same bytes: the kernels' argument checks take both, and nothing else, for an fp8 pool."""
+    import torch
+
+    from sglang_amd import kernels
+
+    raw = torch.zeros((4, 2, 64), dtype=torch.uint8)
+    assert kernels._kv_rows_dtype_ok(raw, True) and kernels._kv_rows_dtype_ok(raw.view(torch.float8_e4m3fn), True)
+    assert not kernels._kv_rows_dtype_ok(raw.view(torch.float8_e5m2), True) and not kernels._kv_rows_dtype_ok(torch.zeros(4, dtype=torch.bfloat16), True)
+    assert kernels._kv_rows_dtype_ok(torch.zeros(4, dtype=torch.bfloat16), False) and not kernels._kv_rows_dtype_ok(raw, False)
