@@ -250,7 +250,28 @@ def llama_model_forward_hook(original, self, input_ids, positions, forward_batch
         hidden_states = self.embed_tokens(input_ids)
         if model_fusable(self, hidden_states, forward_batch, comm):
             return kernels.unblock(decode_model(self, hidden_states, positions, forward_batch, comm))
+        _say_once_why_not(self, forward_batch, hidden_states)
     return original(self, input_ids, positions, forward_batch, input_embeds, pp_proxy_tensors)
+
+
+_SAID = set()
+
+
+def _say_once_why_not(model, forward_batch, hidden_states) -> None:
+    """A decode forward of a single-stage Llama-style model that does NOT take the fused loop is worth one log line per reason:
+    the operator-by-operator path is correct but slower, and the cause (a quantised projection, an exotic rope, a pool the kernels
+    do not read, a batch above the weight-stream's row limit ...) is otherwise invisible."""
+    if len(_SAID) >= 16:
+        return
+    try:
+        why = explain(model, forward_batch, hidden_states)
+    except Exception as e:                          # noqa: BLE001 -- never let a diagnostic break a forward
+        why = f"explain() raised {type(e).__name__}: {e}"
+    if why is not None and why not in _SAID and len(_SAID) < 16:
+        _SAID.add(why)
+        import logging
+
+        logging.getLogger("sglang_amd").info("decode forward of %s stays on the operator-by-operator path: %s", type(model).__name__, why)
 
 
 def _reference_model_applies(model, forward_batch, input_embeds, pp_proxy_tensors) -> bool:

@@ -331,3 +331,23 @@ def test_fp8_kv_rows_are_accepted_as_bytes_or_as_the_references_fp8_view():
     assert kernels._kv_rows_dtype_ok(raw, True) and kernels._kv_rows_dtype_ok(raw.view(torch.float8_e4m3fn), True)
     assert not kernels._kv_rows_dtype_ok(raw.view(torch.float8_e5m2), True) and not kernels._kv_rows_dtype_ok(torch.zeros(4, dtype=torch.bfloat16), True)
     assert kernels._kv_rows_dtype_ok(torch.zeros(4, dtype=torch.bfloat16), False) and not kernels._kv_rows_dtype_ok(raw, False)
+
+
+def test_fused_decode_says_once_why_a_decode_forward_is_not_fused(caplog):
+    """explain() names the first failing condition; the hook logs it once per reason and never raises."""
+    import logging
+    import types
+
+    from sglang_amd import fused_decode
+
+    mode = types.SimpleNamespace(is_decode=lambda: True)
+    model = types.SimpleNamespace(layers=[types.SimpleNamespace(self_attn=None, mlp=None)], layers_to_capture=[], pp_group=None)
+    fb = types.SimpleNamespace(forward_mode=mode, positions=None, batch_size=4)
+    assert fused_decode.explain(model, fb) == "layer 0: no self_attn / mlp.gate_up_proj / mlp.down_proj"
+    assert "not DECODE" in fused_decode.explain(model, types.SimpleNamespace(forward_mode=types.SimpleNamespace(is_decode=lambda: False)))
+    fused_decode._SAID.clear()
+    with caplog.at_level(logging.INFO, logger="sglang_amd"):
+        fused_decode._say_once_why_not(model, fb, None)
+        fused_decode._say_once_why_not(model, fb, None)
+    assert sum("stays on the operator-by-operator path" in r.message for r in caplog.records) == 1
+    fused_decode._SAID.clear()
