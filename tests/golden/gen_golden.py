@@ -480,7 +480,10 @@ def gen_sampler():
     torch.save(res, OUT / "sampler_torch.pt")
 
 
-def gen_radix():
+def gen_radix(seed_base=100, steps=220, pages=(1, 4), vocab=6, out=None):
+    """`out=None`: the committed fixture (seed 100, 220 steps, pages 1 / 4).  tests/test_radix_cache.py::test_live_differential_traces
+    calls this with other seeds / lengths / page sizes / vocabularies (a fresh process, an output path) and replays the result on
+    the product's tree: the comparison is then against the reference's live behaviour, not one recorded trace."""
     rc = ref("sglang.srt.mem_cache.radix_cache")
     bpc = ref("sglang.srt.mem_cache.base_prefix_cache")
     RadixCache, RadixKey = rc.RadixCache, rc.RadixKey
@@ -489,16 +492,15 @@ def gen_radix():
     def key(ids):
         return RadixKey(token_ids=array("q", ids))
 
-    for page_size in (1, 4):
-        rnd = random.Random(100 + page_size)
+    for page_size in pages:
+        rnd = random.Random(seed_base + page_size)
         alloc = mock.Mock()
         alloc.device = "cpu"
         tree = RadixCache.create_simulated(mock_allocator=alloc, page_size=page_size)
         ops = []
         next_slot = 1
         held = []  # nodes we locked
-        vocab = 6
-        for step in range(220):
+        for step in range(steps):
             r = rnd.random()
             if r < 0.45:
                 n = rnd.randint(1, 14)
@@ -541,7 +543,7 @@ def gen_radix():
         tree.insert(bpc.InsertParams(key=key(ids)))
     m = tree.match_prefix(bpc.MatchPrefixParams(key=key([1, 2, 3, 13, 14])))
     traces["main_scenario"] = dict(match=m.device_indices.tolist(), total=int(tree.total_size()))
-    (OUT / "radix_trace.json").write_text(json.dumps(traces))
+    Path(out or OUT / "radix_trace.json").write_text(json.dumps(traces))
 
 
 def gen_host_int():
@@ -667,6 +669,9 @@ def main():
     if not REF.exists():
         raise SystemExit("/root/reference not present: goldens can only be regenerated in the build container")
     install_hook()
+    if len(sys.argv) > 1 and sys.argv[1] == "--radix-live":            # --radix-live SEED STEPS VOCAB OUT: a fresh trace, pages 1 / 4 / 16
+        gen_radix(seed_base=int(sys.argv[2]), steps=int(sys.argv[3]), pages=(1, 4, 16), vocab=int(sys.argv[4]), out=sys.argv[5])
+        return
     torch.manual_seed(0)
     for fn in (gen_attention, gen_elementwise, gen_moe, gen_sampler, gen_radix, gen_host_int, gen_llava_anyres):
         fn()

@@ -49,6 +49,49 @@ def test_replay_reference_trace(golden_dir, page):
         assert tree.total_size() == op["total"], (i, op)
 
 
+@pytest.mark.parametrize("seed,steps,vocab", [(7, 600, 6), (31, 600, 3), (1234, 900, 12)])
+def test_live_differential_traces(golden_dir, tmp_path, seed, steps, vocab):
+    """Not one recorded trace: where the reference's sources are present (the build container), a fresh process drives the REAL
+    `RadixCache` through a new random sequence of insert / match (+ lock) / unlock / evict operations (tests/golden/gen_golden.py
+    gen_radix with another seed, length, vocabulary; page sizes 1 / 4 / 16) and the product's tree must reproduce every returned
+    prefix length, slot list, freed segment and size counter."""
+    import subprocess
+    import sys
+
+    gen = golden_dir / "gen_golden.py"
+    if not (__import__("pathlib").Path("/root/reference/python/sglang").exists()):
+        pytest.skip("/root/reference not present: the live trace needs the reference's own RadixCache")
+    out = tmp_path / "trace.json"
+    p = subprocess.run([sys.executable, str(gen), "--radix-live", str(seed), str(steps), str(vocab), str(out)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-3000:]
+    traces = json.loads(out.read_text())
+    for page in (1, 4, 16):
+        ops = traces[f"page{page}"]
+        assert len(ops) == steps
+        alloc = mock.Mock()
+        alloc.device = "cpu"
+        tree = RadixCache.create_simulated(mock_allocator=alloc, page_size=page)
+        held = []
+        for i, op in enumerate(ops):
+            if op["op"] == "insert":
+                res = tree.insert(InsertParams(key=_key(op["ids"]), value=torch.tensor(op["vals"], dtype=torch.int64)))
+                assert res.prefix_len == op["prefix_len"], (page, i, op)
+            elif op["op"] == "match":
+                m = tree.match_prefix(MatchPrefixParams(key=_key(op["ids"])))
+                assert m.device_indices.tolist() == op["indices"], (page, i, op)
+                if op["lock"]:
+                    tree.inc_lock_ref(m.last_device_node)
+                    held.append(m.last_device_node)
+            elif op["op"] == "unlock":
+                tree.dec_lock_ref(held.pop(op["which"]))
+            else:
+                alloc.reset_mock()
+                res = tree.evict(EvictParams(num_tokens=op["num_tokens"]))
+                assert res.num_tokens_evicted == op["num_evicted"], (page, i, op)
+                assert [c.args[0].tolist() for c in alloc.free_segment.call_args_list] == op["freed"], (page, i, op)
+            assert (tree.evictable_size(), tree.protected_size(), tree.total_size()) == (op["evictable"], op["protected"], op["total"]), (page, i, op)
+
+
 def test_reference_main_scenario(golden_dir):
     # radix_cache.py:849-863
     g = json.loads((golden_dir / "radix_trace.json").read_text())["main_scenario"]
