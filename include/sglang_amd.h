@@ -458,6 +458,11 @@ int sgl_amd_extend_attention_ex(const void* q, void* out, const void* k_cache, c
  * flags bit 0 keeps bf16 8-wave launches on the general single-image kernel, bit 1 sends them to the ping-pong
  * 16x16x32 kernel the 32x32 two-score-set kernel replaced (A/B runs).  Not part of the reference surface. */
 int sgl_amd_debug_extend_attention_shape(int shape, int flags);
+/* Test / tuning override of the shared-prefix chunk kernel's launch form (process-wide; the library never reads the
+ * environment).  A launch whose worst-case workgroup count (from the request table's width) is <= single_shot_units runs one
+ * workgroup per (item, kv head) unit; above it a grid of loop_grid resident workgroups walks the device-built item list.
+ * 0 restores a default (10240 / 1024).  Results are identical in both forms.  Not part of the reference surface. */
+int sgl_amd_debug_cascade_launch_form(int64_t single_shot_units, int64_t loop_grid);
 
 /* ---- row-tiled grouped GEMM for prefill-sized MoE batches (reference: fused_moe_triton_kernels.py:324,771 with
  *      BLOCK_SIZE_M >= 64; fused_experts, triton_utils/fused_moe.py:242-455) -------------------------------------

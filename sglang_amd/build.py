@@ -44,7 +44,7 @@ def sources() -> list[Path]:
 
 
 def _deps_mtime() -> float:
-    hdrs = list(CSRC.glob("*.hpp")) + list(INCLUDE.glob("*.h")) + list((PKG.parent / "include").glob("*.h"))
+    hdrs = list(CSRC.glob("*.hpp")) + list(CSRC.glob("*.inc")) + list(INCLUDE.glob("*.h")) + list((PKG.parent / "include").glob("*.h"))
     return max([h.stat().st_mtime for h in hdrs if h.exists()] + [0.0])
 
 

@@ -36,6 +36,10 @@ constexpr int kThreads = 256;
 constexpr int kChunk = 128;       // kv tokens per item
 constexpr int kRowsPerItem = 64;  // (member, q head) rows per item: 4 waves x one 16-row tile
 constexpr float kNegBig = -1.0e30f;
+// launch-form policy of the chunk kernel (see cascade_chunk_kernel); process-wide tuning knobs behind
+// sgl_amd_debug_cascade_launch_form, like the extend kernel's shape switch
+int64_t g_cascade_single_shot_units = 10240;   // worst-case workgroups up to which the one-workgroup-per-unit form is launched
+int64_t g_cascade_loop_grid = 256 * 4;         // resident workgroups of the looping form (256 CUs x 4)
 
 __device__ __forceinline__ bf16x8_t as_frag(const U4& v) { return __builtin_bit_cast(bf16x8_t, v); }
 
@@ -74,252 +78,63 @@ struct ChunkParams {
 // halves (64 dims x 128 tokens: each output tile is complete inside its half).  With <= 96 VGPRs that makes five
 // workgroups per CU resident -- 1280 on the chip: the bench batch's 1248 units run as one round
 // (at four per CU the last 224 started when the first finished, 7 us of a 20 us kernel, benchmarks/r02_exp8).
-// One workgroup per (item, kv head) unit; the grid covers the worst-case item count of the batch and the
-// workgroups behind the end of the device-built list leave after one load.  (A persistent loop over the
-// units was measured slower: hipcc hoists the lane-derived LDS addresses out of the loop and spills.)
+// Two forms of the launch.
+//   cascade_chunk_kernel: one workgroup per unit; the grid covers the worst-case item count of the batch and the workgroups behind
+//     the end of the device-built list leave after one load.  96 registers: five workgroups per CU.  Chosen while the worst
+//     case stays below kSingleShotUnits workgroups (a request table of a few thousand tokens: the bench's 1.2 k-token table
+//     asks for 9.5 k).
+//   cascade_chunk_loop_kernel: a grid of kLoopGrid resident workgroups walks the list -- workgroup w takes units w, 2 G - 1 - w, 2 G + w,
+//     ... (a snake over the passes: the shared items at the head of the list are the heavy ones, the workgroups that got
+//     them in one pass get the far end of the next) below the list's end, which every workgroup knows after ONE scalar load
+//     (header[0]) that travels with its first item record.  Chosen for large request tables: the worst case of a 64-request
+//     batch is 58 k workgroups at an 8 k-token table (Llama-3-8B's own context length under the reference's scheduler), ~1 M at
+//     128 k, and a workgroup behind the list's end costs ~0.25 ns of dispatch -- 20 -> 33.7 us per layer at 8 k, measured
+//     under the reference's scheduler (profiles/r05_sched_step_timeline_hooks.txt).  The loop keeps the thread index and the
+//     kernel arguments opaque per pass (nothing lane-derived or argument-derived is loop-invariant to the compiler: round 2's
+//     persistent loop died of hoisted LDS addresses), and it is given 128 registers -- four workgroups per CU, no spills --
+//     because at the 96 budget hipcc parks ~30 registers of the gather burst in scratch once there is a loop around it.
 template <int D, bool FP8, bool HND>
 __global__ __launch_bounds__(kThreads, 5) void cascade_chunk_kernel(ChunkParams p) {
-  constexpr int NP = D > 64 ? D / 64 : 1;   // parts the 16 KiB image is filled in: K by tokens, V^T by head dims
-  constexpr int RP = kChunk / NP;           // K rows (tokens) per part
-  constexpr int DH = D / NP;                // V^T rows (head dims) per part
-  constexpr int CPR = D / 8;                // 16-byte pieces per KV row
-  __shared__ U4 sm[RP * CPR];           // K: [token of the part][piece ^ swz];  V^T: [d of the part][8-token chunk ^ swz]
+  __shared__ U4 sm[(kChunk / (D > 64 ? D / 64 : 1)) * (D / 8)];   // K: [token of the part][piece ^ swz];  V^T: [d of the part][8-token chunk ^ swz]
   const int unit = blockIdx.x;
-  constexpr int KC = D / 32;            // MFMA k-steps over the head dim
-  constexpr int NDH = D / 16 / NP;      // 16-wide output tiles of one V^T part
-  constexpr int NT = kChunk / 16;       // 16-token tiles of the chunk
-  constexpr int NTP = NT / NP;          // ... of one K part
-  constexpr int NKK = kChunk / 32;      // MFMA k-steps over the tokens
-  constexpr int ROWS_PER_PASS = kThreads / CPR;
-  constexpr int NK_LOADS = kChunk / ROWS_PER_PASS;   // K 16-byte loads per thread (8 at D=128)
-  constexpr int LPP = NK_LOADS / NP;                 // ... per part
-  constexpr int V_THREADS = (kChunk / 8) * CPR;      // one 8x8 transposing block each
-  static_assert(RP % ROWS_PER_PASS == 0 && NT % NP == 0, "part boundaries");
+  const int tid = threadIdx.x;
+#include "cascade_chunk_body.inc"
+}
 
-  const CascadePlanView pv = cascade_plan_view(p.plan, p.batch, p.max_items);
+template <int D, bool FP8, bool HND>
+__device__ __forceinline__ void cascade_chunk_unit(const ChunkParams& p, U4* sm, const int unit, const int tid) {
+#include "cascade_chunk_body.inc"
+}
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int l15 = lane & 15, g = lane >> 4;
-  const int item = unit / p.num_kv_heads;
-  const int kvh = unit - item * p.num_kv_heads;
-  if (item >= p.max_items) return;
-  CASC_STAMP(0);
-  // ---- one hop to a self-contained record ---------------------------------------------------
-  // (the record is the same for every lane: readfirstlane moves it to scalar registers, the kernel lives at 96 VGPRs)
-  const int4 ra = *reinterpret_cast<const int4*>(pv.items + 8 * item);       // slot, kv_begin, kv_n, members
-  const int4 rb = *reinterpret_cast<const int4*>(pv.items + 8 * item + 4);   // member_begin | request, private, pool row, group
-  const int n_mem = __builtin_amdgcn_readfirstlane(ra.w);
-  if (n_mem == 0) return;                                                     // end of the list
-  CASC_STAMP(1);
-  const int slot = __builtin_amdgcn_readfirstlane(ra.x), kv_begin = __builtin_amdgcn_readfirstlane(ra.y),
-            kv_n = __builtin_amdgcn_readfirstlane(ra.z);
-  const int rec_x = __builtin_amdgcn_readfirstlane(rb.x), rec_private = __builtin_amdgcn_readfirstlane(rb.y),
-            rec_pool = __builtin_amdgcn_readfirstlane(rb.z);
-  const int32_t* idx_base = p.req_to_token + static_cast<int64_t>(rec_pool) * p.r2t_stride;
-  const int32_t* members = rec_private ? nullptr : pv.member_rows + rec_x;
-  const int last = kv_begin + kv_n - 1;
-  const int n_rows = n_mem * p.group;
-
-  // ---- this wave's 16 query rows: row = (member, q head of the kv head's group).  The member lookup goes first: the
-  // q loads depend on it and would otherwise wait, in order, behind the whole K / V burst ----------------------
-  const int r = wid * 16 + l15;
-  const bool wave_on = wid * 16 < n_rows;           // wave-uniform
-  const bool row_valid = r < n_rows;
-  const int mem_i = r / p.group, hg = r - mem_i * p.group;
-  int req = rec_x;
-  if (row_valid && members) req = members[mem_i];
-
-  // ---- gather burst: all K / V rows of the chunk --------------------------------------------
-  const int st_c = tid % CPR, st_r = tid / CPR;
-  const bool v_active = tid < V_THREADS;
-  // token-major pools (HND = false): row = base + slot * row bytes (slot ids are non-negative, the stride fits 32 bits:
-  // one v_mad_u64_u32 per gathered row); the paged head-major layout takes the general formula.  fp8 rows are 8 bytes
-  // per lane, widened to bf16 in registers on arrival (exact), so the images and the matrix work are the same.
-  const uint32_t row_bytes = p.fmt.page_stride;
-  const int lane_off = st_c * (FP8 ? 8 : 16);
-  const unsigned char* k_rows = reinterpret_cast<const unsigned char*>(p.k_cache) + static_cast<uint32_t>(kvh) * p.fmt.head_stride;
-  const unsigned char* v_rows = reinterpret_cast<const unsigned char*>(p.v_cache) + static_cast<uint32_t>(kvh) * p.fmt.head_stride;
-  U4 kst[NK_LOADS], vst[8], qfrag[KC];
-  int sl = 0;                                          // this row's partial slot (rows x slots_total fits 31 bits)
-  {
-    int32_t ks[NK_LOADS];
+template <int D, bool FP8, bool HND>
+__global__ __launch_bounds__(kThreads, 4) void cascade_chunk_loop_kernel(ChunkParams p) {
+  __shared__ U4 sm[(kChunk / (D > 64 ? D / 64 : 1)) * (D / 8)];
+  int n_items = __builtin_amdgcn_readfirstlane(p.plan[0]);                   // header[0]: the list's length
+  if (n_items > p.max_items) n_items = p.max_items;
+  const int n_units = n_items * p.num_kv_heads;
+  const int G = static_cast<int>(gridDim.x), w0 = static_cast<int>(blockIdx.x);
+  // The kernel's one argument sits at the start of the kernarg segment; every pass re-reads it through an address the
+  // compiler cannot see through, exactly as a fresh launch would (scalar loads, served by the scalar cache), and takes the
+  // thread index as an opaque value.
+  typedef const __attribute__((address_space(4))) uint64_t KernargWord;
+  const uint64_t kp = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
+  for (int base = 0, pass = 0; base < n_units; base += G, ++pass) {
+    const int unit = base + ((pass & 1) ? G - 1 - w0 : w0);
+    if (unit < n_units) {                                                     // (workgroup-uniform; false only in the last pass)
+      uint64_t ka = kp;
+      asm volatile("" : "+s"(ka));
+      KernargWord* kw = reinterpret_cast<KernargWord*>(ka);
+      static_assert(sizeof(ChunkParams) % 8 == 0 && std::is_trivially_copyable<ChunkParams>::value, "kernarg image copied as 8-byte words");
+      struct Raw { uint64_t w[sizeof(ChunkParams) / 8]; } raw;
 #pragma unroll
-    for (int i = 0; i < NK_LOADS; ++i) {
-      int tok = kv_begin + st_r + ROWS_PER_PASS * i;
-      if (tok > last) tok = last;      // (skipping the rows behind a short chunk's end instead measured no faster)
-      ks[i] = idx_base[tok];
-    }
-    // V block of this thread: k-step kk = st_r >> 2, lane group vg = st_r & 3; token order inside the
-    // block matches the P^T operand built from the S^T accumulators: i = 4a + r <-> 32 kk + 16 a + 4 vg + r
-    int32_t vs[8];
-    const int v_kk = st_r >> 2, v_g = st_r & 3;
-    if (v_active) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        int tok = kv_begin + 32 * v_kk + 16 * (i >> 2) + 4 * v_g + (i & 3);
-        if (tok > last) tok = last;
-        vs[i] = idx_base[tok];
-      }
-    }
-    // q goes out between the slot-id loads and the rows that depend on them: it waits for `req` only
-    if (wave_on) {
-      if (row_valid) {
-        const uint16_t* qp = p.q + static_cast<int64_t>(req) * p.q_stride + (kvh * p.group + hg) * D + g * 8;
-#pragma unroll
-        for (int kc = 0; kc < KC; ++kc) qfrag[kc] = ld16(qp + kc * 32);
-        sl = (req * p.num_q_heads + kvh * p.group + hg) * p.slots_total + slot;
-      } else {
-#pragma unroll
-        for (int kc = 0; kc < KC; ++kc) qfrag[kc] = U4{0u, 0u, 0u, 0u};
-      }
-    }
-    if constexpr (!HND) {
-#pragma unroll
-      for (int i = 0; i < NK_LOADS; ++i)
-        kst[i] = ld_kv8<FP8>(k_rows + static_cast<uint64_t>(static_cast<uint32_t>(ks[i])) * row_bytes + lane_off, 0);
-      if (v_active) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-          vst[i] = ld_kv8<FP8>(v_rows + static_cast<uint64_t>(static_cast<uint32_t>(vs[i])) * row_bytes + lane_off, 0);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < NK_LOADS; ++i) kst[i] = ld_kv8<FP8>(kv_row(p.k_cache, p.fmt, ks[i], kvh), st_c);
-      if (v_active) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) vst[i] = ld_kv8<FP8>(kv_row(p.v_cache, p.fmt, vs[i], kvh), st_c);
-      }
+      for (unsigned i = 0; i < sizeof(ChunkParams) / 8; ++i) raw.w[i] = kw[i];
+      const ChunkParams pl = __builtin_bit_cast(ChunkParams, raw);
+      int tid = threadIdx.x;
+      asm volatile("" : "+v"(tid));
+      cascade_chunk_unit<D, FP8, HND>(pl, sm, unit, tid);
+      __syncthreads();                                                        // the image is reused by the next unit
     }
   }
-
-  // Waves without query rows (three of four in a private item) only stage: they take their own copy of the code
-  // below with the matrix work compiled out -- same barriers, no accumulator registers kept alive for them.
-  auto body = [&](auto on_tag) {
-    constexpr bool ON = decltype(on_tag)::value;
-    const bool row_ok = ON && row_valid;
-    // ---- S^T = K . Q^T, one token part at a time: lane owns query row l15 of the wave, tokens 16 nt + 4 g + r.
-    // piece ^ swz(row) keeps the 16 rows of a fragment read on distinct banks (rows of 256 B: row & 15; 128 B:
-    // (row >> 1) & 7)
-    f32x4_t st_acc[NT];
-#pragma unroll
-    for (int h = 0; h < NP; ++h) {
-#pragma unroll
-      for (int i = 0; i < LPP; ++i) {
-        const int row = st_r + ROWS_PER_PASS * i;                     // row inside the part
-        sm[row * CPR + (st_c ^ ((row * CPR / 16) & (CPR - 1)))] = kst[h * LPP + i];
-      }
-      __syncthreads();
-#ifdef CASC_TRACE
-      if (h == 0) CASC_STAMP(2);
-#endif
-      if constexpr (ON) {
-#pragma unroll
-        for (int n2 = 0; n2 < NTP; ++n2) {
-          const int row = n2 * 16 + l15;
-          f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int kc = 0; kc < KC; ++kc) {
-            const U4 kf = sm[row * CPR + ((kc * 4 + g) ^ ((row * CPR / 16) & (CPR - 1)))];
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(kf), as_frag(qfrag[kc]), acc, 0, 0, 0);
-          }
-          st_acc[h * NTP + n2] = acc;
-          __builtin_amdgcn_sched_barrier(0);   // no fragment reads of the next tile hoisted up here: 96 VGPRs, no spill
-        }
-      }
-      __syncthreads();      // every wave is done with this part of the K image
-    }
-    float mx = kNegBig, psum = 0.f;
-    U4 pfrag[NKK];
-    if constexpr (ON) {
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const float sv = (nt * 16 + g * 4 + rr < kv_n) ? st_acc[nt][rr] * p.scale_log2 : kNegBig;
-          st_acc[nt][rr] = sv;
-          mx = fmaxf(mx, sv);
-        }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-#pragma unroll
-      for (int kk = 0; kk < NKK; ++kk) {
-        float e[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const float sv = st_acc[2 * kk + (i >> 2)][i & 3];
-          e[i] = (sv > 0.5f * kNegBig) ? fast_exp2(sv - mx) : 0.f;
-          psum += e[i];
-        }
-        pfrag[kk].x = pack_bf2(e[0], e[1]);
-        pfrag[kk].y = pack_bf2(e[2], e[3]);
-        pfrag[kk].z = pack_bf2(e[4], e[5]);
-        pfrag[kk].w = pack_bf2(e[6], e[7]);
-      }
-      psum += __shfl_xor(psum, 16, 64);
-      psum += __shfl_xor(psum, 32, 64);
-    }
-    CASC_STAMP(3);
-
-    // ---- O^T = V^T . P^T per head-dim part: the V^T image is built from 8x8 blocks transposed through registers;
-    // lane holds O^T[d = 16 n + 4 g + r][row l15] -------------------------------------------------------------
-    float* ap = nullptr;
-    if constexpr (ON) {
-      if (row_ok) {
-        int sl32 = sl;
-        asm volatile("" : "+v"(sl32));     // widened here, not carried as a register pair through the kernel
-        const int64_t sl64 = sl32;
-        ap = p.ws_acc + sl64 * D + g * 4;
-        if (g == 0) {
-          p.ws_ml[sl64 * 2 + 0] = mx;
-          p.ws_ml[sl64 * 2 + 1] = psum;
-        }
-      }
-    }
-#pragma unroll
-    for (int h = 0; h < NP; ++h) {
-      if (v_active && st_c * 8 / DH == h) {
-        const uint32_t* w = reinterpret_cast<const uint32_t*>(vst);   // vst[i] dword q -> w[4 i + q]
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int d = st_c * 8 + j;
-          U4 o;
-          uint32_t* ow = reinterpret_cast<uint32_t*>(&o);
-#pragma unroll
-          for (int qd = 0; qd < 4; ++qd) {
-            const uint32_t a = w[4 * (2 * qd) + (j >> 1)];
-            const uint32_t c = w[4 * (2 * qd + 1) + (j >> 1)];
-            ow[qd] = (j & 1) ? ((a >> 16) | (c & 0xffff0000u)) : ((a & 0xffffu) | (c << 16));
-          }
-          sm[(d - h * DH) * 16 + (st_r ^ ((d ^ (d >> 3)) & 15))] = o;
-        }
-      }
-      __syncthreads();
-#ifdef CASC_TRACE
-      if (h == 0) CASC_STAMP(4);
-#endif
-      if constexpr (ON) {
-#pragma unroll
-        for (int n2 = 0; n2 < NDH; ++n2) {
-          const int n = h * NDH + n2;
-          f32x4_t ot = f32x4_t{0.f, 0.f, 0.f, 0.f};
-          const int d = n * 16 + l15;
-#pragma unroll
-          for (int kk = 0; kk < NKK; ++kk) {
-            const U4 vf = sm[(d - h * DH) * 16 + ((kk * 4 + g) ^ ((d ^ (d >> 3)) & 15))];
-            ot = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(vf), as_frag(pfrag[kk]), ot, 0, 0, 0);
-          }
-          if (row_ok) *reinterpret_cast<f32x4_t*>(ap + n * 16) = ot;
-        }
-      }
-      if (h + 1 < NP) __syncthreads();
-    }
-  };
-  if (wave_on) body(std::true_type{});
-  else body(std::false_type{});
-#ifdef CASC_TRACE
-  __builtin_amdgcn_s_waitcnt(0);
-  CASC_STAMP(5);
-#endif
 }
 
 // ---- cascade plan: group the requests of a decode batch that share a KV prefix ----------------
@@ -733,22 +548,38 @@ int sgl_amd_cascade_decode_attention_ex(const void* q, const void* k_cache, cons
   const int64_t member_tiles = (batch + p.members_per_item - 1) / p.members_per_item + batch / 2 + 1;
   int64_t units = batch * (chunks + 1) + member_tiles * chunks;
   if (units > max_items) units = max_items;
-  dim3 grid(static_cast<unsigned>(units * num_kv_heads));
-#define SGL_LAUNCH_CASC(D_)                                                                                  \
+  const int64_t worst = units * num_kv_heads;
+  const bool loop = worst > g_cascade_single_shot_units;
+  dim3 grid(static_cast<unsigned>(loop ? (worst < g_cascade_loop_grid ? worst : g_cascade_loop_grid) : worst));
+#define SGL_LAUNCH_CASC2(D_, KERNEL_)                                                                                 \
   do {                                                                                                       \
-    if (kv_fp8 && kv_layout_hnd) hipLaunchKernelGGL((cascade_chunk_kernel<D_, true, true>), grid, dim3(kThreads), 0, st, p);   \
-    else if (kv_fp8) hipLaunchKernelGGL((cascade_chunk_kernel<D_, true, false>), grid, dim3(kThreads), 0, st, p);             \
-    else if (kv_layout_hnd) hipLaunchKernelGGL((cascade_chunk_kernel<D_, false, true>), grid, dim3(kThreads), 0, st, p);      \
-    else hipLaunchKernelGGL((cascade_chunk_kernel<D_, false, false>), grid, dim3(kThreads), 0, st, p);                        \
+    if (kv_fp8 && kv_layout_hnd) hipLaunchKernelGGL((KERNEL_<D_, true, true>), grid, dim3(kThreads), 0, st, p);   \
+    else if (kv_fp8) hipLaunchKernelGGL((KERNEL_<D_, true, false>), grid, dim3(kThreads), 0, st, p);             \
+    else if (kv_layout_hnd) hipLaunchKernelGGL((KERNEL_<D_, false, true>), grid, dim3(kThreads), 0, st, p);      \
+    else hipLaunchKernelGGL((KERNEL_<D_, false, false>), grid, dim3(kThreads), 0, st, p);                        \
+  } while (0)
+#define SGL_LAUNCH_CASC(D_)                                       \
+  do {                                                            \
+    if (loop) SGL_LAUNCH_CASC2(D_, cascade_chunk_loop_kernel);    \
+    else SGL_LAUNCH_CASC2(D_, cascade_chunk_kernel);              \
   } while (0)
   if (head_dim == 128) SGL_LAUNCH_CASC(128);
   else SGL_LAUNCH_CASC(64);
+#undef SGL_LAUNCH_CASC2
 #undef SGL_LAUNCH_CASC
   const int hpb = 256 / (head_dim / 4);
   hipLaunchKernelGGL(cascade_merge2_kernel, dim3(static_cast<unsigned>(batch), (num_q_heads + hpb - 1) / hpb), dim3(256), 0, st,
                      p.ws_acc, p.ws_ml, plan, seq_lens, static_cast<uint16_t*>(out), out_token_stride, p.batch, p.max_items,
                      num_q_heads, head_dim, slots_total, kv_fp8 ? v_scale : 1.0f);
   SGL_CHECK_LAUNCH("cascade_decode_attention");
+  return 0;
+}
+
+int sgl_amd_debug_cascade_launch_form(int64_t single_shot_units, int64_t loop_grid) {
+  SGL_CLEAR_STALE_ERROR();
+  SGL_CHECK_ARG(single_shot_units >= 0 && loop_grid >= 0 && loop_grid <= (1 << 20), "debug_cascade_launch_form: bad arguments");
+  g_cascade_single_shot_units = single_shot_units > 0 ? single_shot_units : 10240;
+  g_cascade_loop_grid = loop_grid > 0 ? loop_grid : 256 * 4;
   return 0;
 }
 

@@ -30,7 +30,7 @@ from .base_attn_backend import AttentionBackend
 def _kv_write_loc(pool, loc):
     """The POOL's own KVWriteLoc type: the reference's for a reference pool (memory_pool.py:1550-1575), ours for ours --
     decided by whose class the pool is, not by whether `sglang` happens to be importable in the process."""
-    if type(pool).__module__.startswith("sglang."):
+    if any(c.__module__.startswith("sglang.") for c in type(pool).__mro__):      # incl. mem_hooks' subclass of the reference pool
         try:
             from sglang.srt.mem_cache.memory_pool import KVWriteLoc as Ref
 
@@ -127,6 +127,7 @@ class HipAttnBackend(AttentionBackend):
         self.forward_metadata: Optional[_Meta] = None
         self._graph_ws = {}
         self._cascade_ws = None
+        self._cascade_ws_eager = None
         self._cascade_in_graph = False
         self._seq_i32, self._seq_src, self._seq_i32_in_graph = None, None, False
         self._verify_states, self._verify_nd = {}, 0
@@ -148,15 +149,24 @@ class HipAttnBackend(AttentionBackend):
             self._graph_ws[key] = ws
         return ws
 
-    def _cascade_workspace(self, batch: int):
+    def _cascade_workspace(self, batch: int, in_capture: bool = False):
         """ONE workspace, sized for the largest batch seen (the graph runner asks for max_bs first): the plan and
         the slot layout are addressed with the actual batch size of the step, and replays are stream-serialised,
         so every bucket and every eager batch can share it.  It only ever grows before graphs exist."""
         ws = self._cascade_ws
         if ws is None or ws.max_batch < batch:
             if ws is not None and self._cascade_in_graph:
-                raise RuntimeError(f"cascade workspace holds {ws.max_batch} requests and is referenced by captured "
-                                   f"graphs; a batch of {batch} needs init_cuda_graph_state(max_bs >= {batch})")
+                # A batch larger than every captured bucket can only be an EAGER forward (replays never exceed max_bs;
+                # decode_cuda_graph_runner.py:683-687 `cuda_graph_bs <= self.max_bs` sends it to the eager runner): it gets a
+                # workspace of its own, the captured graphs keep theirs.
+                if in_capture:
+                    raise RuntimeError(f"cascade workspace holds {ws.max_batch} requests and is referenced by captured "
+                                       f"graphs; capturing a batch of {batch} needs init_cuda_graph_state(max_bs >= {batch})")
+                ew = self._cascade_ws_eager
+                if ew is None or ew.max_batch < batch:
+                    ew = self._cascade_ws_eager = kernels.CascadeWorkspace(batch, self.num_q_heads, self.head_dim,
+                                                                           self.max_context_len, self.device)
+                return ew
             ws = self._cascade_ws = kernels.CascadeWorkspace(batch, self.num_q_heads, self.head_dim,
                                                              self.max_context_len, self.device)
         return ws
@@ -173,19 +183,23 @@ class HipAttnBackend(AttentionBackend):
     def get_cuda_graph_seq_len_fill_value(self):
         return 1
 
-    def _seq_lens_i32(self, fb):
+    def _seq_lens_i32(self, fb, in_capture: bool = False):
         """int32 view of the batch's seq_lens for the kernels.  The reference's batches carry int64 seq_lens
         (schedule_batch.py): the conversion then goes through a PERSISTENT buffer that init_forward_metadata_in_graph
         fills -- inside the decode graph, so a replay converts the step's own lengths (a `.to(int32)` here, outside the
-        graph, would leave the captured kernels reading the capture-time copy)."""
+        graph, would leave the captured kernels reading the capture-time copy).  A batch LARGER than the buffer the captured
+        graphs reference can only be an eager forward (`--cuda-graph-max-bs 256` with 300 running requests: the reference's
+        `can_run_graph` refuses it and the eager runner calls `init_forward_metadata_out_graph`): it is converted on the spot."""
         if fb.seq_lens.dtype == torch.int32:
             return fb.seq_lens, None
         bs = fb.seq_lens.numel()
         buf = self._seq_i32
         if buf is None or buf.numel() < bs:
             if buf is not None and self._seq_i32_in_graph:
-                raise RuntimeError(f"seq_lens buffer holds {buf.numel()} requests and is referenced by captured graphs; "
-                                   f"a batch of {bs} needs init_cuda_graph_state(max_bs >= {bs})")
+                if in_capture:
+                    raise RuntimeError(f"seq_lens buffer holds {buf.numel()} requests and is referenced by captured graphs; "
+                                       f"capturing a batch of {bs} needs init_cuda_graph_state(max_bs >= {bs})")
+                return fb.seq_lens.to(torch.int32), None
             buf = self._seq_i32 = torch.zeros(max(bs, 256), dtype=torch.int32, device=self.device)
         return buf[:bs], fb.seq_lens
 
@@ -202,7 +216,7 @@ class HipAttnBackend(AttentionBackend):
     def init_forward_metadata_out_graph(self, forward_batch, in_capture: bool = False):
         fb = forward_batch
         if fb.forward_mode.is_decode():
-            seq_i32, self._seq_src = self._seq_lens_i32(fb)
+            seq_i32, self._seq_src = self._seq_lens_i32(fb, in_capture)
             self._seq_i32_in_graph |= in_capture and self._seq_src is not None
         else:
             seq_i32, self._seq_src = (fb.seq_lens if fb.seq_lens.dtype == torch.int32 else fb.seq_lens.to(torch.int32)), None
@@ -212,7 +226,7 @@ class HipAttnBackend(AttentionBackend):
             else:
                 max_len = int(fb.seq_lens_cpu.max()) if fb.seq_lens_cpu is not None else self.max_context_len
             if self.enable_cascade and 2 <= fb.batch_size <= 1024:
-                self.forward_metadata = _Meta(seq_i32, cascade=self._cascade_workspace(fb.batch_size))
+                self.forward_metadata = _Meta(seq_i32, cascade=self._cascade_workspace(fb.batch_size, in_capture))
                 self._cascade_in_graph |= in_capture
                 return
             splits = choose_num_splits(fb.batch_size, self.num_kv_heads, self.num_q_heads // self.num_kv_heads, max_len)

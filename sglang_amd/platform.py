@@ -77,15 +77,18 @@ def _build_platform_class():
 
             return DecodeCudaGraphRunner
 
-        def get_mha_kv_pool_cls(self) -> type:    # NHD bf16 / fp8 pool layout is the reference's
-            from sglang.srt.mem_cache.memory_pool import MHATokenToKVPool
+        def get_mha_kv_pool_cls(self) -> type:    # the reference's pool (its NHD / HND bf16 / fp8 layouts) with the gfx950 store
+            # memory_pool.py:3707-3708; mem_hooks.py: set_kv_buffer -> sgl_amd_store_kv_cache{,_ex}
+            from . import mem_hooks
 
-            return MHATokenToKVPool
+            return mem_hooks.mha_kv_pool_class()
 
         def get_paged_allocator_cls(self) -> type:
-            from sglang.srt.mem_cache.allocator import PagedTokenToKVPoolAllocator
+            # kv_cache_configurator.py:1680-1688 (asked at EVERY page size, 1 included); mem_hooks.py: alloc_extend /
+            # alloc_decode -> sgl_amd_alloc_extend / sgl_amd_alloc_decode instead of the Triton kernels
+            from . import mem_hooks
 
-            return PagedTokenToKVPoolAllocator
+            return mem_hooks.paged_allocator_class()
 
         def init_backend(self) -> None:           # interface.py:125-127: once per worker
             from . import native

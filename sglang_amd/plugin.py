@@ -115,6 +115,14 @@ def load() -> None:
 
     position_hooks.install(HookRegistry, HookType.AROUND)
 
+    # ---- slot bookkeeping of a prefill (mem_hooks.py): allocation.write_cache_indices / get_last_loc (mem_cache/allocation.py:
+    # 54-148) would launch the reference's Triton kernels for this backend name (`support_triton("hip_mi355x")` is True,
+    # utils/common.py:1307) -> sgl_amd_write_req_to_token / sgl_amd_get_last_loc; the paged allocator and the KV pool's store
+    # come from the platform's class factories (platform.py) -------------------------------------------------------------
+    from . import mem_hooks
+
+    mem_hooks.install(HookRegistry, HookType.AROUND)
+
 
 _BACKEND_CLS = []
 

@@ -40,7 +40,10 @@ WANT = {
     "sglang/srt/layers/rotary_embedding/base.py": ["RotaryEmbedding"],
     "sglang/srt/layers/rotary_embedding/rope_variant.py": ["Llama3RotaryEmbedding", "DynamicNTKAlphaRotaryEmbedding", "DynamicNTKScalingRotaryEmbedding"],
     "sglang/kernels/ops/attention/rope.py": ["FusedSetKVBufferArg"],
-    "sglang/srt/mem_cache/memory_pool.py": ["KVWriteLoc", "MHATokenToKVPool", "ReqToTokenPool"],
+    "sglang/srt/mem_cache/memory_pool.py": ["KVWriteLoc", "MHATokenToKVPool", "ReqToTokenPool", "unwrap_write_loc", "_set_kv_buffer_impl"],
+    "sglang/srt/mem_cache/allocation.py": ["write_cache_indices", "get_last_loc", "alloc_for_extend", "alloc_for_decode"],
+    "sglang/srt/mem_cache/allocator/paged.py": ["PagedTokenToKVPoolAllocator"],
+    "sglang/srt/utils/common.py": ["get_num_new_pages", "support_triton"],
     "sglang/srt/mem_cache/radix_cache.py": ["RadixCache", "RadixKey"],
     "sglang/srt/model_executor/forward_batch_info.py": ["ForwardBatch", "ForwardMode", "compute_position", "_clamp_position_native"],
     "sglang/srt/configs/model_config.py": ["ModelConfig.get_num_attention_heads", "ModelConfig.get_num_kv_heads"],

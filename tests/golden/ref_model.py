@@ -1338,10 +1338,17 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
         return dict(seconds=t1 - t0, output_tokens_per_s=B * out / (t1 - t0), batches=first + rest, prompts=prompts, generated=got,
                     cached_tokens=cached, leaders=leaders, logprobs=lp, top_idx=top)
 
+    triton_launches = _count_triton_launches()
     with torch.no_grad():
         warm = job("warm")
         before = dict(counts)
-        timed = job("timed")
+        del triton_launches[:]
+        prof_path = os.environ.get("REF_SCHED_CPROFILE")
+        if prof_path:
+            timed = _profiled(lambda: job("timed"), prof_path)
+        else:
+            timed = job("timed")
+    triton_in_timed = sorted(set(triton_launches))
     rep = dict(mode="scheduler-job", event_loop="overlap" if overlap else "normal", server_args=server_args or {}, page_size=int(sch.page_size),
                chunked_prefill_size=sa.chunked_prefill_size, dims=dims_name, device=str(runner.device), scheduler=type(sch).__name__, tree_cache=type(sch.tree_cache).__name__,
                tp_worker=type(sch.tp_worker).__name__, attention_backend=sa.attention_backend, attn_backend_class=type(runner.attn_backend).__name__,
@@ -1350,7 +1357,9 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
                fused_decode_models_during_capture=captured,
                eager_fused_decode_forwards_in_the_timed_job=counts["fused_decode_models"] - before["fused_decode_models"],
                graph_replays_in_the_timed_job=counts["graph_replays"] - before["graph_replays"],
-               retracted_requests=counts["retracted_requests"], max_total_num_tokens=int(runner.max_total_num_tokens))
+               retracted_requests=counts["retracted_requests"], max_total_num_tokens=int(runner.max_total_num_tokens),
+               triton_launches_in_the_timed_job=len(triton_launches), triton_kernels_in_the_timed_job=triton_in_timed,
+               kv_pool_class=type(getattr(runner, "token_to_kv_pool", None)).__name__, allocator_class=type(getattr(runner, "token_to_kv_pool_allocator", None)).__name__)
     for tag, j in (("warm_up", warm), ("timed", timed)):
         hit = sorted(set(v for r, v in j["cached_tokens"].items() if r not in j["leaders"]))
         modes = {}
@@ -1387,6 +1396,70 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
                     n += 1
             rep["oracle"].update(logprob_values=n, max_abs_logprob_diff=worst, top2_sets_equal=top_ok)
     return rep
+
+
+def _count_triton_launches() -> list:
+    """Every Triton launch of the process lands in the returned list (kernel name): `JITFunction.run` is what `kernel[grid](...)`
+    calls.  The plug-in promises none on the path (north_star: "no Triton dispatch")."""
+    seen = []
+    try:
+        from triton.runtime.jit import JITFunction
+    except Exception:                                       # noqa: BLE001 -- no triton in this interpreter: nothing can launch
+        return seen
+    if getattr(JITFunction.run, "_counting", False):
+        return JITFunction.run._seen
+    run = JITFunction.run
+
+    def counting_run(self, *a, **k):
+        seen.append(getattr(self, "__name__", None) or getattr(getattr(self, "fn", None), "__name__", "?"))
+        return run(self, *a, **k)
+
+    counting_run._counting, counting_run._seen = True, seen
+    JITFunction.run = counting_run
+    return seen
+
+
+def _profiled(fn, path):
+    """cProfile around `fn`; `path` gets the host-time split by package (reference / plug-in / torch / other) and the top functions."""
+    import cProfile
+    import io
+    import pstats
+
+    pr = cProfile.Profile()
+    pr.enable()
+    try:
+        out = fn()
+    finally:
+        pr.disable()
+    st = pstats.Stats(pr)
+    groups = {}
+    for (file, line, name), (cc, nc, tt, ct, callers) in st.stats.items():
+        f = file.replace("\\", "/")
+        if "/sglang_amd/" in f:
+            g = "plug-in (sglang_amd/)"
+        elif "/sglang/" in f:
+            g = "reference (sglang/)"
+        elif "/torch/" in f or name.startswith("<built-in method torch") or "torch._C" in name:
+            g = "torch"
+        elif f.startswith("~") or f.startswith("<"):
+            g = "builtins (incl. torch C calls)"
+        else:
+            g = "other python"
+        groups[g] = groups.get(g, 0.0) + tt
+    buf = io.StringIO()
+    total = sum(groups.values())
+    buf.write(f"# cProfile of the timed scheduler job (host side; tottime by package; the profiler inflates Python frames)\n")
+    buf.write(f"# total profiled host seconds: {total:.3f}\n")
+    for g, t in sorted(groups.items(), key=lambda kv: -kv[1]):
+        buf.write(f"{t:9.3f} s  {100 * t / total:5.1f} %  {g}\n")
+    for key in ("tottime", "cumulative"):
+        buf.write(f"\n# top 60 by {key}\n")
+        s2 = io.StringIO()
+        pstats.Stats(pr, stream=s2).sort_stats(key).print_stats(60)
+        buf.write(s2.getvalue())
+    Path(path).parent.mkdir(parents=True, exist_ok=True)
+    Path(path).write_text(buf.getvalue())
+    return out
 
 
 def run_latency(dims_name="tiny", batch_size=4, input_len=16, output_len=4) -> dict:

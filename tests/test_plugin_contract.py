@@ -348,7 +348,9 @@ def fake_sglang(monkeypatch):
     mp_.KVWriteLoc = __import__("collections").namedtuple("KVWriteLoc", [f["name"] for f in ref("sglang.srt.mem_cache.memory_pool", "KVWriteLoc")["fields"]],
                                                           defaults=(None, None))
     created["sglang.srt.model_executor.runner.decode_cuda_graph_runner"].DecodeCudaGraphRunner = type("DecodeCudaGraphRunner", (), {})
-    module("sglang.srt.mem_cache.allocator").PagedTokenToKVPoolAllocator = type("PagedTokenToKVPoolAllocator", (), {})
+    # allocator/__init__.py:3-8 re-exports the paged allocator; memory_pool's pool / helpers are the contract's classes
+    module("sglang.srt.mem_cache.allocator").PagedTokenToKVPoolAllocator = created["sglang.srt.mem_cache.allocator.paged"].PagedTokenToKVPoolAllocator
+    mp_.unwrap_write_loc = lambda loc_info: (tuple(loc_info) + (None, None))[:3] if isinstance(loc_info, tuple) else (loc_info, None, None)   # memory_pool.py:1586-1600
     plat_pkg._set = lambda p: current.__setitem__("platform", p)
 
     # ---- HookRegistry (srt/plugins/hook_registry.py:67-330), restated: register() records, apply_hooks() resolves the
@@ -456,7 +458,18 @@ def test_plugin_load_runs_against_the_reference_contract(fake_sglang):
     p = cls()
     assert p.is_out_of_tree() and p.get_dispatch_key_name() == platform.DISPATCH_KEY
     assert p.get_default_attention_backend() == platform.BACKEND_NAME and p.support_cuda_graph()
-    assert p.get_graph_runner_cls().__name__ == "DecodeCudaGraphRunner" and p.get_paged_allocator_cls().__name__ == "PagedTokenToKVPoolAllocator"
+    assert p.get_graph_runner_cls().__name__ == "DecodeCudaGraphRunner"
+    # the pool / allocator classes the reference instantiates are ITS classes with the gfx950 launches in place of the Triton / JIT ones
+    alloc_cls, pool_cls = p.get_paged_allocator_cls(), p.get_mha_kv_pool_cls()
+    assert issubclass(alloc_cls, g["sglang.srt.mem_cache.allocator"].PagedTokenToKVPoolAllocator) and alloc_cls.__name__.startswith("Mi355x")
+    assert issubclass(pool_cls, g["sglang.srt.mem_cache.memory_pool"].MHATokenToKVPool) and pool_cls.__name__.startswith("Mi355x")
+    import inspect as _inspect
+
+    for cls_, mod_, base_, meths in ((alloc_cls, "sglang.srt.mem_cache.allocator.paged", "PagedTokenToKVPoolAllocator", ("alloc_extend", "alloc_decode")),
+                                     (pool_cls, "sglang.srt.mem_cache.memory_pool", "MHATokenToKVPool", ("set_kv_buffer",))):
+        for meth in meths:
+            assert meth in vars(cls_), (cls_, meth)
+            assert list(_inspect.signature(vars(cls_)[meth]).parameters)[1:] == [q_["name"] for q_ in ref_params(mod_, base_, meth)], (base_, meth)
     g["sglang.srt.platforms"]._set(p)
 
     # fused elementwise ops: BaseFusedOp dispatches to the registered forwards, which accept the reference call forms
@@ -782,6 +795,42 @@ def test_position_hooks_are_registered_on_the_two_module_functions_and_fall_thro
         assert not position_hooks._lens_ok(lens.float()) and not position_hooks._lens_ok(lens.view(1, 2)) and position_hooks._lens_ok(lens)
         assert fbi.compute_position("triton", lens, lens.long(), 14) == "reference-compute"            # mixed dtypes
         assert fbi.compute_position("triton", lens, lens, 0) == "reference-compute"                    # an empty extend
+    hr.HookRegistry.reset()
+
+
+def test_mem_hooks_are_registered_on_the_allocation_helpers_and_fall_through(fake_sglang):
+    """allocation.write_cache_indices / get_last_loc (mem_cache/allocation.py:54-148) carry AROUND hooks bound to the reference's
+    parameter lists; CPU tensors (the reference's torch-native runs) reach the reference's own functions with the original arguments.
+    `support_triton` keys on the backend NAME in this reference (utils/common.py:1307-1308) -- which is why the hooks exist.
+    The kernel branch: tests/test_reference_model_gpu.py (zero Triton launches in a prefill under the reference's scheduler)."""
+    import inspect
+
+    from sglang_amd import mem_hooks, plugin
+
+    g = fake_sglang
+    assert [q["name"] for q in ref("sglang.srt.utils.common", "support_triton")["params"]] == ["backend"]
+    plugin.load()
+    hr = g["sglang.srt.plugins.hook_registry"]
+    for target, hook in zip(mem_hooks.HOOK_TARGETS, mem_hooks._HOOKS):
+        assert [(ht.name, h) for ht, h, _ in hr.HookRegistry._hooks[target]] == [("AROUND", hook)]
+        fn = target.rsplit(".", 1)[1]
+        assert list(inspect.signature(hook).parameters) == ["original"] + [q["name"] for q in ref("sglang.srt.mem_cache.allocation", fn)["params"]]
+    al = g["sglang.srt.mem_cache.allocation"]
+    calls = []
+    al.write_cache_indices = lambda *a: calls.append(("write", a)) or "reference-write"
+    al.get_last_loc = lambda *a: calls.append(("last", a)) or "reference-last"
+    hr.HookRegistry.apply_hooks()
+    i64 = torch.tensor([1, 2], dtype=torch.int64)
+    pool = types.SimpleNamespace(req_to_token=torch.zeros((4, 8), dtype=torch.int32))
+    args = (i64, i64, i64, i64, i64, i64, i64, i64, i64, [i64, i64], pool)
+    assert al.write_cache_indices(*args) == "reference-write" and calls[-1] == ("write", args)            # CPU tensors
+    assert al.get_last_loc(pool.req_to_token, i64, i64) == "reference-last" and calls[-1][0] == "last"
+    import unittest.mock as um
+
+    with um.patch.object(torch.Tensor, "is_cuda", property(lambda self: True)):
+        assert mem_hooks._i64_cuda(i64) and not mem_hooks._i64_cuda(i64.int()) and not mem_hooks._i64_cuda(i64.view(1, 2))
+        assert al.get_last_loc(pool.req_to_token.long(), i64, i64) == "reference-last"                    # an int64 table is not this path's
+        assert al.write_cache_indices(*(args[:9] + ([i64.int(), i64], pool))) == "reference-write"        # int32 prefix slots
     hr.HookRegistry.reset()
 
 
