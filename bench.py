@@ -179,6 +179,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-roofline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-reference-scheduler", action="store_true", help="skip the leg that runs the job under the reference's Scheduler")
     ap.add_argument("--cpu-budget-s", type=float, default=30.0)
     return ap.parse_args()
 
@@ -444,10 +445,65 @@ def worker(args):
         except Exception as e:
             result["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
 
+    # ---- the same job under the REFERENCE'S scheduler with the plug-in (what a user of sglang gets) ------------------
+    if (rank == 0 and world == 1 and not args.no_reference_scheduler and not args.rank_of and not kv_fp8 and not reduced
+            and not args.operator_surface and args.page_size == 1 and cfg.name == "llama-3-8b"):
+        try:
+            result["reference_scheduler"] = reference_scheduler_leg(args)
+        except Exception as e:
+            result["reference_scheduler"] = {"error": f"{type(e).__name__}: {e}"}
+
+    # top-level copies of the figures BASELINE.json's metric names beside tokens/s (the driver's record keeps top-level keys)
+    result["ttft_p50_ms"] = statistics.median(ttfts) * 1e3
+    result["prefill_mfma_frac"] = result["prefill_mfma"]["frac"]
+    result["decode_step_hbm_frac"] = step_roofline["frac"]
+    result["ms_per_decode_step"] = t_decode_step * 1e3
+    rs = result.get("reference_scheduler") or {}
+    result["reference_scheduler_tokens_per_s"] = rs.get("tokens_per_s")
+
     if rank == 0:
         print(json.dumps(result))
     if world > 1 or args.rank_of:
         ps.destroy()
+
+
+def reference_scheduler_leg(args):
+    """BASELINE's job shape under the reference's OWN `Scheduler.run_event_loop()` (the server's default overlap loop), `ModelRunner`,
+    `ScheduleBatch`, radix cache, allocator / pool classes from the platform factories and graph runner -- with this package loaded
+    by the reference's plug-in loader: what a user of sglang who installs the plug-in runs.  The reference's
+    sources are not on the GPU box: `__graft_entry__.build()` stages a copy under oracle/_ref (git-ignored, test infrastructure)
+    in the build container, and tests/golden/ref_model.py imports it with the absent third-party packages stubbed; without a
+    staged copy the leg reports that and nothing else.  Runs in its own process after the timed region; `value` above stays the
+    harness measurement -- this figure is reported beside it, with the kernels the reference's loop adds (its eager slot
+    bookkeeping, sampling glue, output streaming) inside its clock."""
+    import subprocess
+    import tempfile
+
+    script = ROOT / "tests" / "golden" / "ref_model.py"
+    staged = ROOT / "oracle" / "_ref" / "sglang_model" / "sglang"
+    if not (staged.exists() or Path("/root/reference/python/sglang").exists()):
+        return {"skipped": "no staged reference sources (oracle/_ref/sglang_model): run __graft_entry__.build() where /root/reference exists"}
+    job = f"{args.groups},{args.per_group},{args.prefix},{args.unique},{args.out}"
+    out = Path(tempfile.mkdtemp(prefix="ref_sched_")) / "job.json"
+    t0 = time.perf_counter()
+    p = subprocess.run([sys.executable, str(script), "--run", "scheduler", "--dims", "llama3_8b", "--job", job, "--overlap", "--json", str(out)],
+                       cwd=ROOT, env=dict(os.environ, SGLANG_USE_AITER="0"), capture_output=True, text=True, timeout=420)
+    if p.returncode != 0 or not out.exists():
+        return {"error": (p.stderr or p.stdout)[-800:]}
+    rep = json.loads(out.read_text())
+    t = rep["timed"]
+    return {"tokens_per_s": t["output_tokens_per_s"], "seconds_per_job": t["seconds"], "decode_step_ms_p50": t.get("decode_step_ms_p50"),
+            "event_loop": rep["event_loop"], "scheduler": rep["scheduler"], "graph_runner": rep["graph_runner"],
+            "graph_replays": rep["graph_replays_in_the_timed_job"], "eager_decode_forwards": rep["eager_fused_decode_forwards_in_the_timed_job"],
+            "batches_run": t["batches_run"], "radix_hit_tokens_per_request": t["cached_tokens_of_others"],
+            "finished_requests": t["finished_requests"], "triton_launches": rep.get("triton_launches_in_the_timed_job"),
+            "kv_pool_class": rep.get("kv_pool_class"), "allocator_class": rep.get("allocator_class"),
+            "attention_backend": rep["attention_backend"], "sampler_class": rep["sampler_class"], "plugin_counts": rep.get("plugin_counts"),
+            "job": f"{args.groups} x {args.per_group} requests, {args.prefix} shared + {args.unique} own tokens in, {args.out} out, greedy; leaders "
+                   "first, the others once the leaders decode (their prompts are in the radix tree); Llama-3-8B architecture, dummy weights",
+            "wall_s_incl_start_up": time.perf_counter() - t0,
+            "note": "the reference's Scheduler (staged copy of its sources, zmq socket read scripted) with this package as its plug-in; "
+                    "not `value` (the harness job above), reported beside it"}
 
 
 def kernel_rooflines(args, cfg, runner, result, B, G, P, in_len, ctx, t_decode_step, pmc, dev, world):

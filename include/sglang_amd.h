@@ -461,7 +461,7 @@ int sgl_amd_debug_extend_attention_shape(int shape, int flags);
 /* Test / tuning override of the shared-prefix chunk kernel's launch form (process-wide; the library never reads the
  * environment).  A launch whose worst-case workgroup count (from the request table's width) is <= single_shot_units runs one
  * workgroup per (item, kv head) unit; above it a grid of loop_grid resident workgroups walks the device-built item list.
- * 0 restores a default (10240 / 1024).  Results are identical in both forms.  Not part of the reference surface. */
+ * 0 restores a default (10240 / 1280).  Results are identical in both forms.  Not part of the reference surface. */
 int sgl_amd_debug_cascade_launch_form(int64_t single_shot_units, int64_t loop_grid);
 
 /* ---- row-tiled grouped GEMM for prefill-sized MoE batches (reference: fused_moe_triton_kernels.py:324,771 with

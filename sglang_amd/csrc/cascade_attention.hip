@@ -39,7 +39,7 @@ constexpr float kNegBig = -1.0e30f;
 // launch-form policy of the chunk kernel (see cascade_chunk_kernel); process-wide tuning knobs behind
 // sgl_amd_debug_cascade_launch_form, like the extend kernel's shape switch
 int64_t g_cascade_single_shot_units = 10240;   // worst-case workgroups up to which the one-workgroup-per-unit form is launched
-int64_t g_cascade_loop_grid = 256 * 4;         // resident workgroups of the looping form (256 CUs x 4)
+int64_t g_cascade_loop_grid = 256 * 5;         // grid of the looping form: 1280 beat 1024 (= what is resident at four per CU) and equalled 2048
 
 __device__ __forceinline__ bf16x8_t as_frag(const U4& v) { return __builtin_bit_cast(bf16x8_t, v); }
 
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(kPlanThreads) void cascade_plan_compare_kernel(
 __global__ __launch_bounds__(kPlanThreads) void cascade_plan_kernel(
     const int32_t* __restrict__ req_to_token, int64_t r2t_stride, const int64_t* __restrict__ req_pool_indices,
     const int32_t* __restrict__ seq_lens, int batch, int min_shared, int chunk_tokens, int tokens_per_tile,
-    int kv_tile, int max_shared, int32_t* __restrict__ plan, int max_items) {
+    int kv_tile, int max_shared, int32_t* __restrict__ plan, int max_items, int zero_items) {
   __shared__ int first_slot[kPlanMaxBatch];
   __shared__ int leader[kPlanMaxBatch];
   __shared__ int grp_min[kPlanMaxBatch];
@@ -228,7 +228,10 @@ __global__ __launch_bounds__(kPlanThreads) void cascade_plan_kernel(
   __shared__ int wave_tot[kPlanThreads / 64];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const CascadePlanView pv = cascade_plan_view(plan, batch, max_items);
-  for (int i = tid; i < max_items; i += kPlanThreads) pv.items[8 * i + 3] = 0;   // members == 0: end of list
+  // members == 0 marks the end of the list for the one-workgroup-per-unit chunk kernel, whose grid never reaches beyond
+  // zero_items entries (the looping form reads the list's length from the header): 13.8 -> 98 us per step at a 128 k-token
+  // request table when all max_items entries were cleared (profiles/r05_exp1_cascade_table_width.json)
+  for (int i = tid; i < zero_items; i += kPlanThreads) pv.items[8 * i + 3] = 0;
   for (int b = tid; b < batch; b += kPlanThreads) {
     pool_row[b] = static_cast<int>(req_pool_indices[b]);
     len_s[b] = seq_lens[b];
@@ -485,7 +488,8 @@ int sgl_amd_cascade_plan(const int32_t* req_to_token, int64_t req_to_token_strid
                      static_cast<int>(batch), pv.compare);
   hipLaunchKernelGGL(cascade_plan_kernel, dim3(1), dim3(kPlanThreads), 0, as_stream(stream), req_to_token,
                      req_to_token_stride, req_pool_indices, seq_lens, static_cast<int>(batch), min_shared_len,
-                     kChunk, members_per_item, 64, chunks * kChunk, plan, static_cast<int>(max_items));
+                     kChunk, members_per_item, 64, chunks * kChunk, plan, static_cast<int>(max_items),
+                     static_cast<int>(max_items < g_cascade_single_shot_units ? max_items : g_cascade_single_shot_units));
   SGL_CHECK_LAUNCH("cascade_plan");
   return 0;
 }
@@ -579,7 +583,7 @@ int sgl_amd_debug_cascade_launch_form(int64_t single_shot_units, int64_t loop_gr
   SGL_CLEAR_STALE_ERROR();
   SGL_CHECK_ARG(single_shot_units >= 0 && loop_grid >= 0 && loop_grid <= (1 << 20), "debug_cascade_launch_form: bad arguments");
   g_cascade_single_shot_units = single_shot_units > 0 ? single_shot_units : 10240;
-  g_cascade_loop_grid = loop_grid > 0 ? loop_grid : 256 * 4;
+  g_cascade_loop_grid = loop_grid > 0 ? loop_grid : 256 * 5;
   return 0;
 }
 

@@ -14,6 +14,10 @@ from torch import nn
 
 from .. import kernels
 
+# calls served by the gfx950 kernels / handed to the bound reference instance's own forward_native (tests and the
+# reference-stack reports read it: a silent hand-over is a slower path, not an error)
+served = dict(hip=0, native=0)
+
 
 class RMSNorm(nn.Module):
     def __init__(self, hidden_size: int, eps: float = 1e-6, dtype: torch.dtype = torch.bfloat16, device=None):
@@ -28,7 +32,13 @@ class RMSNorm(nn.Module):
         """layernorm.py:474-480 signature.  `x` (and `residual`) are updated IN PLACE when a residual is given, like
         sgl_kernel.fused_add_rmsnorm (layernorm.py:739-751); `post_residual_addition` is folded into the residual
         first (layernorm.py:563-564: hidden_states + (residual + post_residual_addition))."""
-        outside = (quant_linear is not None or x.dtype != torch.bfloat16 or self.weight.dtype != torch.bfloat16
+        # `quant_linear` is only a HINT (the projection that consumes the output: llama.py:348-366 passes it on every call): the
+        # reference fuses an fp8 activation quantisation into the norm when that projection carries a static per-tensor
+        # input scale (layernorm.py:372-392, 508-521) and ignores it otherwise.  Round 4 treated ANY quant_linear as outside
+        # the path -- so under the reference's own LlamaDecoderLayer every prefill norm ran as eight torch launches of
+        # forward_native (found in round 5's kernel trace of the reference scheduler, profiles/r05_sched_kernel_stats_*).
+        fp8_fusion = quant_linear is not None and getattr(quant_linear, "input_scale", None) is not None
+        outside = (fp8_fusion or x.dtype != torch.bfloat16 or self.weight.dtype != torch.bfloat16
                    or getattr(self, "variance_size_override", None) is not None
                    or getattr(self, "cast_x_before_out_mul", False) or getattr(self, "fp32_residual", False)
                    or not x.is_cuda)
@@ -37,7 +47,9 @@ class RMSNorm(nn.Module):
             if native is None:
                 raise NotImplementedError("RMSNorm: this configuration (quant_linear / non-bf16 / variance override) is "
                                           "outside the gfx950 path")
+            served["native"] += 1
             return native(x, residual, post_residual_addition, quant_linear)
+        served["hip"] += 1
         if x.numel() == 0:                                   # layernorm.py:481-486
             if residual is not None:
                 if post_residual_addition is not None:

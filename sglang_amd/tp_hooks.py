@@ -13,6 +13,7 @@ four methods -- and on `GroupCoordinator.__init__`, where the communicator is bu
                            (`cpu_group`), proved against the group's OWN RCCL group (`device_group`) by the start-up
                            self-test and dropped on EVERY rank together if any rank fails (parallel_state.start_xgmi);
                            groups over the same ranks (tp / attention_tp / moe_tp of a plain TP launch) share one
+                           (its launches are serialised across streams: `_one_stream_at_a_time`)
   all_reduce               bf16 messages up to 64 MiB: one launch on the current stream (one-shot below the reference's
                            switch points, custom_all_reduce.py:260-307, two-stage above), graph-capturable; everything
                            else -- and every group without a communicator -- is the reference's method, untouched
@@ -95,6 +96,39 @@ def _takes(comm, x: torch.Tensor) -> bool:
     return comm is not None and isinstance(x, torch.Tensor) and (comm.should_use(x) or comm.should_use_two_stage(x))
 
 
+class _one_stream_at_a_time:
+    """Groups over the same ranks share ONE communicator: one data area and one set of monotonically increasing flag counters.
+    Its launches are therefore only correct one after the other.  On one stream that is program order; a launch arriving on
+    ANOTHER stream than the previous one (an alt-stream shared-expert branch, two-batch overlap, two groups driven from two
+    streams) first waits for an event recorded behind the previous launch, so the two never overlap -- the reference gives every
+    GroupCoordinator its own `ca_comm` instead (parallel_state.py:405-470), this package trades that for one workspace per rank
+    set.  Inside a stream capture nothing is recorded or waited on: a captured decode step is a single-stream graph, and an event
+    recorded outside a capture must not be waited on inside one."""
+
+    def __init__(self, comm):
+        self.comm = comm
+
+    def __enter__(self):
+        self.capturing = (not torch.cuda.is_available()) or torch.cuda.is_current_stream_capturing()
+        if self.capturing:
+            return self
+        cur = torch.cuda.current_stream()
+        last = getattr(self.comm, "_sgl_last_stream", None)
+        if last is not None and last != cur:
+            cur.wait_event(self.comm._sgl_last_event)
+        self.cur = cur
+        return self
+
+    def __exit__(self, *exc):
+        if not self.capturing:
+            ev = getattr(self.comm, "_sgl_last_event", None)
+            if ev is None:
+                ev = self.comm._sgl_last_event = torch.cuda.Event()
+            ev.record(self.cur)
+            self.comm._sgl_last_stream = self.cur
+        return False
+
+
 # ---- the hooks: HookType.AROUND = hook(original_fn, *args, **kwargs) ------------------------------------------------
 def group_init_hook(original, self, *args, **kwargs):
     original(self, *args, **kwargs)
@@ -104,7 +138,8 @@ def group_init_hook(original, self, *args, **kwargs):
 def group_all_reduce_hook(original, self, input_):
     comm = communicator_of(self)
     if comm is not None and self.world_size > 1 and not torch.compiler.is_compiling() and _takes(comm, input_):
-        return comm.all_reduce_any(input_)
+        with _one_stream_at_a_time(comm):
+            return comm.all_reduce_any(input_)
     return original(self, input_)
 
 
@@ -114,7 +149,11 @@ def group_fused_allreduce_rmsnorm_hook(original, self, input_, residual_inp_, we
             and input_.dim() == 2 and input_.shape[-1] <= 16384 and isinstance(residual_inp_, torch.Tensor)
             and residual_inp_.shape == input_.shape and residual_inp_.is_contiguous() and residual_inp_.dtype == input_.dtype
             and weight_.dtype == input_.dtype):
-        out = comm.all_reduce_add_rmsnorm(input_, residual_inp_, weight_, float(eps))
+        # `residual_inp_` is updated IN PLACE and handed back as the residual output: the one caller
+        # (layernorm.py:198-245 `_forward_with_allreduce_fusion`) returns the pair as its (hidden, residual) and never reads
+        # its own `residual` again -- a caller that kept using the tensor it passed in would see it changed
+        with _one_stream_at_a_time(comm):
+            out = comm.all_reduce_add_rmsnorm(input_, residual_inp_, weight_, float(eps))
         return out, residual_inp_
     return original(self, input_, residual_inp_, weight_, eps)
 
@@ -125,7 +164,8 @@ def group_all_gather_hook(original, self, input_, dim=-1, output_tensor_list=Non
             and isinstance(input_, torch.Tensor) and input_.is_cuda and input_.dim() == 2 and dim in (-1, 1)
             and input_.dtype == torch.bfloat16 and input_.shape[1] % 8 == 0 and not comm.disabled
             and comm.fits_all_gather(input_)):
-        return comm.all_gather(input_.contiguous())
+        with _one_stream_at_a_time(comm):
+            return comm.all_gather(input_.contiguous())
     return original(self, input_, dim, output_tensor_list)
 
 

@@ -44,6 +44,7 @@ WANT = {
     "sglang/srt/mem_cache/allocation.py": ["write_cache_indices", "get_last_loc", "alloc_for_extend", "alloc_for_decode"],
     "sglang/srt/mem_cache/allocator/paged.py": ["PagedTokenToKVPoolAllocator"],
     "sglang/srt/utils/common.py": ["get_num_new_pages", "support_triton"],
+    "sglang/srt/layers/logits_processor.py": ["LogitsProcessor", "should_apply_lm_head_quant_method", "_UNQUANTIZED_LM_HEAD_METHODS"],
     "sglang/srt/mem_cache/radix_cache.py": ["RadixCache", "RadixKey"],
     "sglang/srt/model_executor/forward_batch_info.py": ["ForwardBatch", "ForwardMode", "compute_position", "_clamp_position_native"],
     "sglang/srt/configs/model_config.py": ["ModelConfig.get_num_attention_heads", "ModelConfig.get_num_kv_heads"],

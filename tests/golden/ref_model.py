@@ -1279,9 +1279,37 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
     batches = []
     run_batch = sch.run_batch
 
+    launch_times = []
+    # Every forward's logits, by (request, position): with the small real-weight models `ModelRunner.forward` is wrapped and each
+    # `next_token_logits` row is filed under the request it belongs to (the order of `batch.reqs` at `run_batch`) and the output
+    # position it predicts (`seq_len - prompt length`: the last chunk of a prefill -> 0, the decode forward over k generated tokens
+    # -> k, a re-prefill after retraction over k generated tokens -> k; rows of non-final prefill chunks fall below 0 and rows of a
+    # finished request's extra overlap step beyond `out`: both dropped).  Compared with the oracle teacher-forced (below).
+    capture = dict(on=False, pending=None, rows={})
+
     def logging_run_batch(batch, *a, **k):
         batches.append((batch.forward_mode.name, batch.batch_size()))
+        launch_times.append(time.perf_counter())
+        if capture["on"]:
+            capture["pending"] = [(r.rid, int(sl) - len(r.origin_input_ids)) for r, sl in zip(batch.reqs, batch.seq_lens_cpu.tolist())]
         return run_batch(batch, *a, **k)
+
+    if real_weights and hasattr(runner, "forward"):
+        runner_forward = runner.forward
+
+        def capturing_forward(*a, **k):
+            res = runner_forward(*a, **k)
+            pend, capture["pending"] = capture["pending"], None
+            lo = getattr(res, "logits_output", None)
+            lg = getattr(lo, "next_token_logits", None)
+            if capture["on"] and pend is not None and lg is not None and lg.shape[0] >= len(pend):
+                lg = lg[: len(pend)].float().cpu()
+                for i, (rid, t) in enumerate(pend):
+                    if 0 <= t < out:
+                        capture["rows"][(rid, t)] = lg[i]
+            return res
+
+        runner.forward = capturing_forward
 
     sch.run_batch = logging_run_batch
 
@@ -1299,6 +1327,7 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
         type(sch.request_receiver)._pull_raw_reqs = lambda self: pull()        # (the receiver is a frozen dataclass: patch the class)
         sch.gracefully_exit = False
         del batches[:]
+        del launch_times[:]
         sch.run_event_loop()
         return list(batches)
 
@@ -1335,8 +1364,13 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
                     top.setdefault(rid, []).extend([list(map(int, ix)) for ix in o.output_top_logprobs_idx[i]])
                 if o.finished_reasons[i] is not None:
                     cached[rid] = int(o.cached_tokens[i])
+        # steady decode: the intervals between consecutive launches of full-batch decode forwards (the loop launches batch N + 1 when
+        # the result of batch N - 1 has arrived, so in steady state an interval is one step of whichever side is slower)
+        full = [t for (m, bs), t in zip(ran, launch_times) if m == "DECODE" and bs == B]
+        gaps = sorted(b_ - a_ for a_, b_ in zip(full, full[1:]))
         return dict(seconds=t1 - t0, output_tokens_per_s=B * out / (t1 - t0), batches=first + rest, prompts=prompts, generated=got,
-                    cached_tokens=cached, leaders=leaders, logprobs=lp, top_idx=top)
+                    cached_tokens=cached, leaders=leaders, logprobs=lp, top_idx=top,
+                    decode_step_ms_p50=1e3 * gaps[len(gaps) // 2] if gaps else None, full_batch_decode_steps=len(full))
 
     triton_launches = _count_triton_launches()
     with torch.no_grad():
@@ -1344,10 +1378,12 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
         before = dict(counts)
         del triton_launches[:]
         prof_path = os.environ.get("REF_SCHED_CPROFILE")
+        capture["on"] = real_weights
         if prof_path:
             timed = _profiled(lambda: job("timed"), prof_path)
         else:
             timed = job("timed")
+        capture["on"] = False
     triton_in_timed = sorted(set(triton_launches))
     rep = dict(mode="scheduler-job", event_loop="overlap" if overlap else "normal", server_args=server_args or {}, page_size=int(sch.page_size),
                chunked_prefill_size=sa.chunked_prefill_size, dims=dims_name, device=str(runner.device), scheduler=type(sch).__name__, tree_cache=type(sch.tree_cache).__name__,
@@ -1359,13 +1395,15 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
                graph_replays_in_the_timed_job=counts["graph_replays"] - before["graph_replays"],
                retracted_requests=counts["retracted_requests"], max_total_num_tokens=int(runner.max_total_num_tokens),
                triton_launches_in_the_timed_job=len(triton_launches), triton_kernels_in_the_timed_job=triton_in_timed,
-               kv_pool_class=type(getattr(runner, "token_to_kv_pool", None)).__name__, allocator_class=type(getattr(runner, "token_to_kv_pool_allocator", None)).__name__)
+               kv_pool_class=type(getattr(runner, "token_to_kv_pool", None)).__name__, allocator_class=type(getattr(runner, "token_to_kv_pool_allocator", None)).__name__,
+               plugin_counts=_plugin_counts() if gpu else None)
     for tag, j in (("warm_up", warm), ("timed", timed)):
         hit = sorted(set(v for r, v in j["cached_tokens"].items() if r not in j["leaders"]))
         modes = {}
         for m, bs in j["batches"]:
             modes[f"{m} x{bs}"] = modes.get(f"{m} x{bs}", 0) + 1
-        rep[tag] = dict(seconds=j["seconds"], output_tokens_per_s=j["output_tokens_per_s"], batches_run=modes,
+        rep[tag] = dict(seconds=j["seconds"], output_tokens_per_s=j["output_tokens_per_s"], decode_step_ms_p50=j["decode_step_ms_p50"],
+                        full_batch_decode_steps=j["full_batch_decode_steps"], batches_run=modes,
                         cached_tokens_of_leaders=sorted(set(j["cached_tokens"][r] for r in j["leaders"])), cached_tokens_of_others=hit,
                         finished_requests=len(j["generated"]), tokens_per_request=sorted(set(len(v) for v in j["generated"].values())))
     if real_weights:
@@ -1380,6 +1418,41 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
         same = sum(int(list(w) == timed["generated"].get(r)) for r, w in zip(rids, want))
         rep["oracle"] = dict(requests=len(rids), requests_with_identical_tokens=same,
                              token_agreement=sum(int(a == b) for r, w in zip(rids, want) for a, b in zip(w, timed["generated"].get(r, []))) / (len(rids) * out))
+        # ---- logits of every forward of the timed job against the oracle, teacher-forced with the tokens the run produced: the
+        # plug-in's error against the fp32-accumulating oracle inside the band of the reference's literal bf16 evaluation against the
+        # same oracle (what run_runner asserts per pass; VERDICT r04 weak #3: token agreement alone lets a wrong-but-close kernel pass)
+        if capture["rows"]:
+            forced = [timed["generated"].get(r, []) for r in rids]
+            if all(len(f) == out for f in forced):
+                def teacher(**kw):
+                    o_ = OracleLM(oracle_config(dims_name, 8192), oracle_weights(runner.model), num_slots=4 * tokens,
+                                  max_ctx=prefix + unique + out + 8, max_reqs=B, device=runner.device, **kw)
+                    return o_.generate([timed["prompts"][r] for r in rids], out, return_logits=True, forced=forced,
+                                       share_prefix_groups=grp, shared_len=prefix)[1]
+                lit = teacher()
+                acc = teacher(compute_dtype=torch.float32) if gpu else None
+                got_l, lit_l, acc_l = [], [], []
+                for t in range(out):
+                    for bi, r in enumerate(rids):
+                        row = capture["rows"].get((r, t))
+                        if row is None:
+                            continue
+                        got_l.append(row)
+                        lit_l.append(lit[t][bi].float().cpu())
+                        if acc is not None:
+                            acc_l.append(acc[t][bi].float().cpu())
+                G_, L_ = torch.stack(got_l), torch.stack(lit_l)
+                band = dict(rows_compared=len(got_l), rows_expected=len(rids) * out, identical_to_the_literal_oracle=bool(torch.equal(G_, L_)),
+                            max_abs_vs_literal=float((G_ - L_).abs().max()), logit_rms=float(L_.pow(2).mean().sqrt()))
+                if acc_l:
+                    A_ = torch.stack(acc_l)
+                    e_p, e_r = G_ - A_, L_ - A_
+                    top2 = A_.topk(2, dim=-1).values
+                    clear = (top2[:, 0] - top2[:, 1]) > 16 * 2.0 ** -8 * top2[:, 0].abs().clamp_min(1.0)      # margin > 16 bf16 ulps
+                    band.update(product_rms_err=float(e_p.pow(2).mean().sqrt()), reference_rms_err=float(e_r.pow(2).mean().sqrt()),
+                                product_max_err=float(e_p.abs().max()), reference_max_err=float(e_r.abs().max()),
+                                clear_rows=int(clear.sum()), argmax_agree_on_clear_rows=int((G_.argmax(-1) == A_.argmax(-1))[clear].sum()))
+                rep["logit_band"] = band
         if logprobs:
             # the log-probabilities the scheduler streamed with the tokens (sampler -> output_logprob_processor -> output streamer) against
             # log_softmax of the oracle's logits, the oracle teacher-forced with the tokens the run produced
@@ -1396,6 +1469,14 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
                     n += 1
             rep["oracle"].update(logprob_values=n, max_abs_logprob_diff=worst, top2_sets_equal=top_ok)
     return rep
+
+
+def _plugin_counts() -> dict:
+    """What the plug-in's own counters saw in this process (whole process: warm-up + timed job + capture)."""
+    from sglang_amd import mem_hooks
+    from sglang_amd.layers import layernorm
+
+    return dict(mem_hooks=dict(mem_hooks.counts), rmsnorm=dict(layernorm.served))
 
 
 def _count_triton_launches() -> list:

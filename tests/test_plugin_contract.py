@@ -737,10 +737,25 @@ def test_linear_hook_is_registered_on_the_unquantized_method_and_falls_through(f
     ours = list(inspect.signature(linear_hook.unquant_apply_hook).parameters.values())
     assert [p.name for p in ours] == ["original"] + [p["name"] for p in ref_ps]
     assert [p.default is not inspect.Parameter.empty for p in ours[1:]] == [p["default"] for p in ref_ps]
+    # the lm_head: LogitsProcessor._compute_lm_head (logits_processor.py:706-769) carries an AROUND hook with the reference's
+    # parameter list; only the plain-matmul branch is taken over (the head's method is one of the reference's unquantised ones)
+    assert [(ht.name, h) for ht, h, _ in hr.HookRegistry._hooks[linear_hook.LM_HEAD_HOOK_TARGET]] == [("AROUND", linear_hook.compute_lm_head_hook)]
+    lp_ps = ref("sglang.srt.layers.logits_processor", "LogitsProcessor")["methods"]["_compute_lm_head"]["params"]
+    ours_lp = list(inspect.signature(linear_hook.compute_lm_head_hook).parameters.values())
+    assert [p.name for p in ours_lp] == ["original"] + [p["name"] for p in lp_ps]
+    assert [p.default is not inspect.Parameter.empty for p in ours_lp[1:]] == [p["default"] for p in lp_ps]
+    unq = str(ref("sglang.srt.layers.logits_processor", "_UNQUANTIZED_LM_HEAD_METHODS")["value"])
+    assert "UnquantizedEmbeddingMethod" in unq and "UnquantizedLinearMethod" in unq
+    LP = g["sglang.srt.layers.logits_processor"].LogitsProcessor
+    lp_calls = []
+    LP._compute_lm_head = lambda self, hidden_states, lm_head, embedding_bias=None: lp_calls.append((hidden_states, lm_head)) or "reference-lm-head"
     ULM = g["sglang.srt.layers.quantization.unquant"].UnquantizedLinearMethod
     calls = []
     ULM.apply = lambda self, layer, x, bias=None: calls.append((layer, x, bias)) or "reference-linear"
     hr.HookRegistry.apply_hooks()
+    head = types.SimpleNamespace(weight=torch.nn.Parameter(torch.zeros((256, 128), dtype=torch.bfloat16), requires_grad=False), quant_method=None)
+    lp = LP.__new__(LP)
+    assert lp._compute_lm_head(torch.zeros((4, 128), dtype=torch.bfloat16), head) == "reference-lm-head" and lp_calls[-1][1] is head   # CPU tensors
     m = ULM.__new__(ULM)
     layer = types.SimpleNamespace(weight=torch.nn.Parameter(torch.zeros((256, 128), dtype=torch.bfloat16), requires_grad=False))
     x = torch.zeros((4, 128), dtype=torch.bfloat16)

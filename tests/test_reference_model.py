@@ -124,6 +124,19 @@ def test_oracle_equals_the_reference_under_the_references_scheduler(tmp_path, lo
         assert job["cached_tokens_of_leaders"] == [0] and job["cached_tokens_of_others"] == [16]
         assert job["finished_requests"] == 4 and job["tokens_per_request"] == [4]
     assert rep["oracle"] == dict(requests=4, requests_with_identical_tokens=4, token_agreement=1.0)
+    _logits_identical(rep, 16)
+
+
+def _logits_identical(rep, rows, exact=True):
+    """Every forward's `next_token_logits` row, filed by (request, output position) as the scheduler produced it, equals the oracle's
+    teacher-forced logits of that position BIT FOR BIT (the CPU run is the reference's torch-native path = the oracle): this pins the
+    capture's bookkeeping -- chunks, retraction, overlap steps -- that the GPU twin's band bars rely on."""
+    lb = rep["logit_band"]
+    assert (lb["rows_compared"], lb["rows_expected"]) == (rows, rows) and lb["logit_rms"] > 0.5, lb
+    if exact:
+        assert lb["identical_to_the_literal_oracle"], lb
+    else:        # a prompt prefilled in chunks attends over its own earlier chunks: another bf16 reduction structure than the oracle's
+        assert lb["max_abs_vs_literal"] <= 0.07, lb      # one-shot prefill (in the reference's own backend) -- a couple of logit ulps
 
 
 def test_oracle_equals_the_reference_under_the_references_scheduler_with_chunked_prefill(tmp_path):
@@ -138,6 +151,7 @@ def test_oracle_equals_the_reference_under_the_references_scheduler_with_chunked
         assert job["cached_tokens_of_leaders"] == [0] and job["cached_tokens_of_others"] == [80]
         assert job["finished_requests"] == 6 and job["tokens_per_request"] == [6]
     assert rep["oracle"] == dict(requests=6, requests_with_identical_tokens=6, token_agreement=1.0)
+    _logits_identical(rep, 36, exact=False)
 
 
 @pytest.mark.parametrize("extra,what", [(("--logprobs",), "return_logprob + top-2 logprobs on every request"),
@@ -152,6 +166,7 @@ def test_oracle_equals_the_reference_under_the_references_scheduler_logprobs_and
     assert (o["requests"], o["requests_with_identical_tokens"], o["token_agreement"]) == (4, 4, 1.0), (what, o)
     if "--logprobs" in extra:
         assert (o["logprob_values"], o["max_abs_logprob_diff"], o["top2_sets_equal"]) == (16, 0.0, 16), o
+    _logits_identical(rep, 16)
 
 
 def test_the_references_scheduler_with_mixed_chunks(tmp_path):
@@ -165,6 +180,8 @@ def test_the_references_scheduler_with_mixed_chunks(tmp_path):
         assert sum(v for k, v in job["batches_run"].items() if k.startswith("MIXED")) >= 2, job["batches_run"]
         assert job["cached_tokens_of_others"] == [80] and job["finished_requests"] == 6 and job["tokens_per_request"] == [6]
     assert rep["oracle"]["token_agreement"] >= 0.8, rep["oracle"]
+    if "logit_band" in rep:        # (only when every request produced its tokens as the oracle's teacher forcing expects: 6 x 6 rows)
+        assert rep["logit_band"]["rows_compared"] == 36 and rep["logit_band"]["max_abs_vs_literal"] < 0.25, rep["logit_band"]
 
 
 def test_the_references_scheduler_retracts_and_the_tokens_do_not_change(tmp_path):
@@ -177,6 +194,7 @@ def test_the_references_scheduler_retracts_and_the_tokens_do_not_change(tmp_path
     for job in (rep["warm_up"], rep["timed"]):
         assert job["finished_requests"] == 8 and job["tokens_per_request"] == [40]
     assert rep["oracle"] == dict(requests=8, requests_with_identical_tokens=8, token_agreement=1.0)
+    _logits_identical(rep, 320)
 
 
 def test_the_references_loader_discovers_and_executes_the_plugin(tmp_path):
@@ -186,7 +204,7 @@ def test_the_references_loader_discovers_and_executes_the_plugin(tmp_path):
     # from the staged copy when there is one: what the GPU box will import
     env = {"REF_OBJECTS_ROOT": str(ref_model.STAGE)} if (ref_model.STAGE / "sglang").exists() else None
     rep = _run("loader", tmp_path, env)
-    from sglang_amd import fused_decode, linear_hook, position_hooks, tp_hooks
+    from sglang_amd import fused_decode, linear_hook, mem_hooks, position_hooks, tp_hooks
     from sglang_amd.platform import BACKEND_NAME, DISPATCH_KEY
 
     assert rep["platform"] == "Mi355xSRTPlatform" and rep["out_of_tree"]
@@ -196,5 +214,6 @@ def test_the_references_loader_discovers_and_executes_the_plugin(tmp_path):
     assert rep["fused_moe_slot"].endswith("_adapt_fused_func.<locals>.wrapper")
     assert rep["oot_forwards"] == ["DynamicNTKAlphaRotaryEmbedding", "DynamicNTKScalingRotaryEmbedding", "Llama3RotaryEmbedding", "RMSNorm",
                                    "RotaryEmbedding", "SiluAndMul", "TopK", "UnquantizedFusedMoEMethod"]
-    targets = sorted(fused_decode.HOOK_TARGETS + tp_hooks.HOOK_TARGETS + position_hooks.HOOK_TARGETS + (linear_hook.HOOK_TARGET,))
+    targets = sorted(fused_decode.HOOK_TARGETS + tp_hooks.HOOK_TARGETS + position_hooks.HOOK_TARGETS + mem_hooks.HOOK_TARGETS
+                     + (linear_hook.HOOK_TARGET, linear_hook.LM_HEAD_HOOK_TARGET))
     assert rep["hooked"] == targets and rep["hooks_applied"] == targets          # every target resolved on the real modules

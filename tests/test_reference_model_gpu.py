@@ -47,7 +47,7 @@ def test_plugin_under_the_references_model_stack(device, dims, tp):
     rep = json.loads(out.read_text())
     ld = rep["loader"]
     assert ld["platform"] == "Mi355xSRTPlatform" and ld["out_of_tree"] and ld["attention_backend_registered"] and ld["sampler_registered"]
-    assert len(ld["hooks_applied"]) == len(ld["hooked"]) == 9
+    assert len(ld["hooks_applied"]) == len(ld["hooked"]) == 12      # model x2, TP x4, linear + lm_head, positions x2, allocation x2
     assert rep["unstaged_reference_modules"] == [], rep["unstaged_reference_modules"]
     for name in ("build", "prefill", "decode", "sampler", "graph_decode"):
         assert rep["legs"].get(name, {}).get("ok"), (name, rep["legs"].get(name))
@@ -135,7 +135,7 @@ def test_plugin_under_the_references_model_runner(device, dims, model):
     assert p.returncode == 0, p.stderr[-6000:]
     rep = json.loads(out.read_text())
     assert rep["loader"]["out_of_tree"] and rep["attention_backend"] == "hip_mi355x"          # resolved by ServerArgs from the platform
-    assert (rep["attn_backend_class"], rep["sampler_class"], rep["model"], rep["kv_pool"]) == ("HipAttnBackend", "HipSampler", model, "MHATokenToKVPool")
+    assert (rep["attn_backend_class"], rep["sampler_class"], rep["model"], rep["kv_pool"]) == ("HipAttnBackend", "HipSampler", model, "Mi355xMHATokenToKVPool")
     assert rep["graph_runner"] == "DecodeCudaGraphRunner" and rep["captured_batch_sizes"], rep
     c = rep["counts"]
     moe = model == "MixtralForCausalLM"
