@@ -44,7 +44,7 @@ def main():
     B, P, Hq, Hkv, D, prefix, unique, ctx = 64, 16, 32, 8, 128, 896, 128, 1088
     rows = []
     kcs = vcs = None
-    for width in (1160, 2048, 8192, 32768, 131072):
+    for width in (1160, 8192, 131072):
         r2t, slots = slot_table("allocator", B, P, ctx, prefix, unique, width)
         if kcs is None:
             kcs = [torch.randn((slots, Hkv, D), device=DEV).to(BF) for _ in range(L)]
@@ -57,7 +57,7 @@ def main():
         t_plan = timeit(lambda i: K.cascade_plan(ws, r2t, pool, seq, Hq, Hkv))
         uniq = (4 * prefix + B * (ctx - prefix)) * 2 * Hkv * D * 2
         for form, (single, grid) in (("single-shot", (1 << 40, 0)), ("loop-1024", (1, 1024)), ("loop-1280", (1, 1280)), ("loop-2048", (1, 2048)),
-                                     ("default", (0, 0))):
+                                     ("default", (0, 0))):    # (round 5 also ran a five-workgroups-per-CU looping instance: profiles/r05_exp1b_cascade_forms.json)
             if form == "single-shot" and width > 32768:
                 continue                               # ~1 M workgroups per launch: known, not worth the GPU seconds
             native.call("sgl_amd_debug_cascade_launch_form", single, grid)

@@ -401,13 +401,15 @@ int sgl_amd_xgmi_two_stage_all_reduce(const void* inp, void* out, int64_t rows, 
  * logits_processor.py:676) -- one launch with the same flag protocol, so the decode graph holds no RCCL node. */
 int sgl_amd_xgmi_all_gather(const void* inp, void* out, int64_t rows, int cols_per_rank, int rank, int world,
                             const void* const* peer_workspaces_host, int64_t workspace_bytes, int num_blocks, void* stream);
-/* Protocol switch of the flag barriers (process-wide, read when a collective is ENQUEUED -- a captured graph keeps the
- * setting it was captured with).  0 (default): everything a peer reads is written with system-scope write-through
+/* Protocol switch of the flag barriers, PER COMMUNICATOR: a word of `workspace`'s own signal block (this rank's workspace, as
+ * returned by sgl_amd_xgmi_alloc), read by the kernels when a launch RUNS -- a captured graph follows the current setting, and
+ * no process-wide state is kept in the library.  0 (default): everything a peer reads is written with system-scope write-through
  * stores and published by their completion (s_waitcnt vmcnt(0)) + a relaxed system-scope flag; 1: a full system-scope
  * RELEASE fence precedes every flag as well -- the reference's protocol (custom_all_reduce_hip.cuh:150-236
  * __atomic_store_n(..., __ATOMIC_RELEASE) after __threadfence_system), slower by the write-back of the device's
- * dirty L2, kept as the fallback should the light protocol ever misbehave across physical xGMI links. */
-int sgl_amd_xgmi_set_release_fence(int on);
+ * dirty L2, kept as the fallback should the light protocol ever misbehave across physical xGMI links.  Synchronous (a
+ * 4-byte host-to-device copy); every rank of a group sets its own. */
+int sgl_amd_xgmi_set_release_fence(void* workspace, int on);
 /* Byte offset of the data area inside a workspace (the signal block precedes it). */
 int64_t sgl_amd_xgmi_data_offset(void);
 /* Host-side mirror of the two-stage kernel's work split, for tests and sizing: units_per_rank[r] = number of units

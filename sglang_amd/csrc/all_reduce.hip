@@ -45,6 +45,8 @@ struct Signal {
   uint32_t flag[kMaxBlocks];
   uint32_t timed_out;                        // set when a flag wait gave up (a peer never arrived)
   uint32_t trap_on_timeout;                  // armed by the host once the start-up self-test passed (sgl_amd_xgmi_arm)
+  uint32_t release_fence;                    // 1: a system-scope release fence precedes every flag THIS rank sends (the fallback
+                                             // protocol; per communicator, read when a launch RUNS: sgl_amd_xgmi_set_release_fence)
 };
 static_assert(sizeof(Signal) <= kDataOffset, "signal block");
 
@@ -63,8 +65,8 @@ struct ArParams {
   int rank, world;
   int epilogue;                 // 0 none, 1 residual add + RMSNorm
   float eps;
-  int ws_bytes;                 // size of every rank's workspace (buffer range of the system-scope accesses)
-  int release_fence;            // 1: system-scope release fence ahead of every flag (fallback, sgl_amd_xgmi_set_release_fence)
+  int ws_bytes;                 // size of every rank's workspace: the buffer range of the system-scope accesses (buffer
+                                // descriptors carry 32-bit ranges and offsets: the entry points refuse workspaces of 2 GiB and more)
 };
 
 // System-scope 16-byte accesses to a workspace (own or a peer's): buffer instructions with sc0 sc1 -- stores write
@@ -92,7 +94,7 @@ __device__ __forceinline__ void flag_barrier(const ArParams& p, uint32_t (Signal
   // flag goes out.  (A system-scope release fence here also writes back every dirty L2 line of the device -- the
   // projection's output, the residual stream: 24 us of a 33 us two-stage launch at 256 rows, 1.5 ms of a TP 4 rank's
   // 5.8 ms decode step.  It stays available as the fallback: release_fence.)
-  if (p.release_fence) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  if (reinterpret_cast<const Signal*>(p.peers.base[p.rank])->release_fence) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const int t = threadIdx.x;
@@ -410,8 +412,6 @@ __global__ __launch_bounds__(kArThreads) void xgmi_all_gather_kernel(ArParams p)
 // cap on the automatic workgroup counts (tests with several ranks on ONE GPU: all their spinning workgroups must be
 // resident together); explicit num_blocks arguments are not touched
 static int g_xgmi_auto_blocks_cap = kMaxBlocks;
-// 1: every flag is preceded by a system-scope release fence (fallback protocol, sgl_amd_xgmi_set_release_fence)
-static int g_xgmi_release_fence = 0;
 
 static int two_stage_auto_blocks(int64_t rows, int64_t numel, int epilogue) {
   const int64_t units = epilogue ? rows : ((numel / 8 + kArThreads - 1) / kArThreads + 3) / 4;
@@ -431,8 +431,12 @@ int sgl_amd_xgmi_debug_auto_blocks_cap(int cap) {
   return 0;
 }
 
-int sgl_amd_xgmi_set_release_fence(int on) {
-  g_xgmi_release_fence = on ? 1 : 0;
+int sgl_amd_xgmi_set_release_fence(void* workspace, int on) {
+  SGL_CLEAR_STALE_ERROR();
+  SGL_CHECK_ARG(workspace, "xgmi_set_release_fence: null workspace");
+  const uint32_t v = on ? 1u : 0u;
+  hipError_t e = hipMemcpy(static_cast<unsigned char*>(workspace) + offsetof(Signal, release_fence), &v, 4, hipMemcpyHostToDevice);
+  SGL_CHECK_ARG(e == hipSuccess, "xgmi_set_release_fence: %s", hipGetErrorString(e));
   return 0;
 }
 
@@ -551,7 +555,8 @@ int sgl_amd_xgmi_one_shot_all_reduce(const void* inp, void* out, int64_t rows, i
   p.inp = static_cast<const uint16_t*>(inp); p.out = static_cast<uint16_t*>(out);
   p.residual = static_cast<uint16_t*>(residual); p.norm_w = static_cast<const uint16_t*>(norm_weight);
   p.numel = numel; p.rows = static_cast<int>(rows); p.hidden = hidden; p.rank = rank; p.world = world; p.epilogue = epilogue; p.eps = eps;
-  p.ws_bytes = static_cast<int>(workspace_bytes); p.release_fence = g_xgmi_release_fence;
+  SGL_CHECK_ARG(workspace_bytes > 0 && workspace_bytes < (int64_t{1} << 31), "xgmi: workspace_bytes=%lld (buffer descriptors address < 2 GiB)", (long long)workspace_bytes);
+  p.ws_bytes = static_cast<int>(workspace_bytes);
   int blocks = num_blocks;
   if (blocks <= 0) {
     // enough workgroups to keep ~7 links busy, never more than the flag table has rows
@@ -610,7 +615,8 @@ int sgl_amd_xgmi_two_stage_all_reduce(const void* inp, void* out, int64_t rows, 
   if (int rc = fill_peers("xgmi_two_stage_all_reduce", &p, rank, world, peer_workspaces_host)) return rc;
   p.inp = static_cast<const uint16_t*>(inp); p.out = static_cast<uint16_t*>(out); p.numel = numel;
   p.rows = static_cast<int>(rows); p.hidden = hidden; p.epilogue = epilogue; p.eps = eps;
-  p.ws_bytes = static_cast<int>(workspace_bytes); p.release_fence = g_xgmi_release_fence;
+  SGL_CHECK_ARG(workspace_bytes > 0 && workspace_bytes < (int64_t{1} << 31), "xgmi: workspace_bytes=%lld (buffer descriptors address < 2 GiB)", (long long)workspace_bytes);
+  p.ws_bytes = static_cast<int>(workspace_bytes);
   p.residual = static_cast<uint16_t*>(residual); p.norm_w = static_cast<const uint16_t*>(norm_weight);
   int blocks = num_blocks;
   if (blocks <= 0) {
@@ -642,7 +648,8 @@ int sgl_amd_xgmi_all_gather(const void* inp, void* out, int64_t rows, int cols_p
   if (int rc = fill_peers("xgmi_all_gather", &p, rank, world, peer_workspaces_host)) return rc;
   p.inp = static_cast<const uint16_t*>(inp); p.out = static_cast<uint16_t*>(out); p.numel = numel;
   p.rows = static_cast<int>(rows); p.hidden = cols_per_rank;
-  p.ws_bytes = static_cast<int>(workspace_bytes); p.release_fence = g_xgmi_release_fence;
+  SGL_CHECK_ARG(workspace_bytes > 0 && workspace_bytes < (int64_t{1} << 31), "xgmi: workspace_bytes=%lld (buffer descriptors address < 2 GiB)", (long long)workspace_bytes);
+  p.ws_bytes = static_cast<int>(workspace_bytes);
   int blocks = num_blocks;
   if (blocks <= 0) {
     const int64_t chunks = (numel / 8 + kArThreads - 1) / kArThreads;

@@ -92,7 +92,9 @@ struct ChunkParams {
 //     under the reference's scheduler (profiles/r05_sched_step_timeline_hooks.txt).  The loop keeps the thread index and the
 //     kernel arguments opaque per pass (nothing lane-derived or argument-derived is loop-invariant to the compiler: round 2's
 //     persistent loop died of hoisted LDS addresses), and it is given 128 registers -- four workgroups per CU, no spills --
-//     because at the 96 budget hipcc parks ~30 registers of the gather burst in scratch once there is a loop around it.
+//     because at the 96 budget hipcc parks ~30 registers in scratch once there is a loop around the body: that instance was
+//     built and measured (profiles/r05_exp1b_cascade_forms.json): 34.1 us per layer against 26.7 at four per CU and 25.6 for
+//     the one-workgroup-per-unit form on the bench's own table; grids of 1280 / 2048 equal, 1024 (= what is resident) 28.0.
 template <int D, bool FP8, bool HND>
 __global__ __launch_bounds__(kThreads, 5) void cascade_chunk_kernel(ChunkParams p) {
   __shared__ U4 sm[(kChunk / (D > 64 ? D / 64 : 1)) * (D / 8)];   // K: [token of the part][piece ^ swz];  V^T: [d of the part][8-token chunk ^ swz]
@@ -547,10 +549,12 @@ int sgl_amd_cascade_decode_attention_ex(const void* q, const void* k_cache, cons
   p.scale_log2 = sm_scale * 1.4426950408889634f * (kv_fp8 ? k_scale : 1.0f);
   SGL_CHECK_ARG(make_kv_format(&p.fmt, k_cache_row_stride, num_kv_heads, head_dim, page_size, kv_layout_hnd, kv_fp8),
                 "cascade_decode_attention: HND pools need a power-of-two page_size (got %d); row / page strides below 4 GiB", page_size);
-  // worst-case item count of this batch: every request's private chunks + the shared chunks of every member tile
-  // (at most batch/2 groups, and sum over groups of ceil(members / members_per_item) <= batch/members_per_item + groups)
-  const int64_t member_tiles = (batch + p.members_per_item - 1) / p.members_per_item + batch / 2 + 1;
-  int64_t units = batch * (chunks + 1) + member_tiles * chunks;
+  // worst-case item count of this batch.  A request of len tokens whose first s are its group's shared part owns
+  // ceil((len - s) / 128) private items and, as one of m members, 1 / m of the group's ceil(s / 128) x ceil(m / members_per_item)
+  // shared items -- at most ceil(s / 128) of them: never more than chunks + 1 items per request (tests/test_cascade_plan_host.py
+  // checks the bound on the host restatement of the plan).  Round 4 added member_tiles x chunks on top: 9552 instead of 5632
+  // workgroups for the bench batch, i.e. 3.9 k more workgroups that leave after one load (~0.25 ns of dispatch each).
+  int64_t units = batch * (chunks + 1);
   if (units > max_items) units = max_items;
   const int64_t worst = units * num_kv_heads;
   const bool loop = worst > g_cascade_single_shot_units;

@@ -50,10 +50,6 @@ class XgmiAllReduce:
         self.max_bytes = int(max_bytes)
         self.two_stage_bytes = int(two_stage_bytes)
         self.data_offset = int(lib.sgl_amd_xgmi_data_offset())
-        # SGLANG_AMD_XGMI_RELEASE_FENCE=1: the fallback protocol (a system-scope release fence ahead of every flag);
-        # process-wide, read when a collective is enqueued / captured
-        if os.environ.get("SGLANG_AMD_XGMI_RELEASE_FENCE", "") not in ("", "0"):
-            lib.sgl_amd_xgmi_set_release_fence(1)
         # data area: the one-shot message, or the two halves (copies + published sums) of a two-stage message
         self.ws_bytes = int(lib.sgl_amd_xgmi_workspace_bytes(max(self.max_bytes, 2 * self.two_stage_bytes + 512)))
         torch.cuda.set_device(device)
@@ -66,6 +62,10 @@ class XgmiAllReduce:
             ptr = ctypes.c_void_p()
             native.call("sgl_amd_xgmi_alloc", self.ws_bytes, ctypes.byref(ptr))
             self._own = ptr.value
+            # SGLANG_AMD_XGMI_RELEASE_FENCE=1: the fallback protocol (a system-scope release fence ahead of every flag) for every
+            # communicator this process builds; the setting itself lives in the communicator's own signal block
+            if os.environ.get("SGLANG_AMD_XGMI_RELEASE_FENCE", "") not in ("", "0"):
+                native.call("sgl_amd_xgmi_set_release_fence", self._own, 1)
             buf = ctypes.create_string_buffer(hbytes)
             native.call("sgl_amd_xgmi_ipc_get_handle", self._own, buf)
             mine = bytes(buf.raw)
@@ -162,10 +162,11 @@ class XgmiAllReduce:
     def fits_all_gather(self, x: torch.Tensor) -> bool:
         return self.data_offset + x.numel() * 2 <= self.ws_bytes
 
-    @staticmethod
-    def set_release_fence(on: bool) -> None:
-        """Fallback switch of the flag protocol (include/sglang_amd.h: sgl_amd_xgmi_set_release_fence)."""
-        native.lib().sgl_amd_xgmi_set_release_fence(1 if on else 0)
+    def set_release_fence(self, on: bool) -> None:
+        """Fallback switch of THIS communicator's flag protocol (include/sglang_amd.h: sgl_amd_xgmi_set_release_fence): a word of
+        its own signal block, read by the kernels when a launch runs (captured graphs follow it)."""
+        torch.cuda.synchronize(self.device)
+        native.call("sgl_amd_xgmi_set_release_fence", self._own, 1 if on else 0)
 
     def all_gather(self, x: torch.Tensor, num_blocks: int = 0) -> torch.Tensor:
         """[rows, cols] per rank -> [rows, world * cols] (tensor_model_parallel_all_gather(dim=-1) of a 2-D tensor)."""

@@ -37,6 +37,19 @@ _BF16 = torch.bfloat16
 # The test is on the EXACT class: a subclass that inherits the hooked model forward but changes the attention math
 # (Ministral3Attention scales q, llama.py users with per-head norms, ...) is not this form and stays with the reference.
 FUSABLE_FORMS = (("LlamaDecoderLayer", "LlamaAttention", "LlamaMLP"), ("Qwen2DecoderLayer", "Qwen2Attention", "Qwen2MLP"))
+# Sparse-MoE layers (round 5): the ATTENTION half is the same four fused launches (qkv + rope / store, attention, o_proj + add /
+# norm); the MoE block behind it runs through its own pieces -- replicated gate, TopK, FusedMoE (the grouped GEMMs in the fused-MoE
+# slot) -- and the residual add + next layer's input norm behind it is one launch.  mixtral.py:57-261 (MixtralMoE: `gate`, `topk`,
+# `experts`, an all-reduce at TP > 1); this package's harness layer carries the block as `mlp` (harness/moe_block.py).
+MOE_FORMS = (("MixtralDecoderLayer", "MixtralAttention", "MixtralMoE"), ("LlamaDecoderLayer", "LlamaAttention", "SparseMoeBlock"))
+
+
+def moe_block_of(layer):
+    """The sparse-MoE block of a decoder layer (mixtral.py:224 `block_sparse_moe`; the harness layer's `mlp`), or None."""
+    blk = getattr(layer, "block_sparse_moe", None)
+    if blk is None:
+        blk = getattr(layer, "mlp", None)
+    return blk if blk is not None and all(hasattr(blk, n) for n in ("gate", "topk", "experts")) else None
 
 
 def _plain_linear(lin) -> bool:
@@ -56,20 +69,28 @@ def layer_unfusable_reason(layer, rows: int) -> Optional[str]:
     """Why this layer is NOT a dense Llama-style block whose four projections the weight-streaming GEMM takes at `rows` rows
     (None when it is).  Also what `explain()` reports to someone asking why a model stays on the operator-by-operator path."""
     attn, mlp = getattr(layer, "self_attn", None), getattr(layer, "mlp", None)
-    if attn is None or mlp is None or not hasattr(mlp, "gate_up_proj") or not hasattr(mlp, "down_proj"):
-        return "no self_attn / mlp.gate_up_proj / mlp.down_proj"
-    form = (type(layer).__name__, type(attn).__name__, type(mlp).__name__)
-    if form not in FUSABLE_FORMS:
-        return f"layer classes {form} are not one of {FUSABLE_FORMS}"
-    lins = dict(qkv_proj=attn.qkv_proj, o_proj=attn.o_proj, gate_up_proj=mlp.gate_up_proj, down_proj=mlp.down_proj)
+    moe = moe_block_of(layer)
+    if attn is not None and moe is not None:
+        form = (type(layer).__name__, type(attn).__name__, type(moe).__name__)
+        if form not in MOE_FORMS:
+            return f"layer classes {form} are not one of {MOE_FORMS}"
+        lins = dict(qkv_proj=attn.qkv_proj, o_proj=attn.o_proj)
+        mlp = None
+    else:
+        if attn is None or mlp is None or not hasattr(mlp, "gate_up_proj") or not hasattr(mlp, "down_proj"):
+            return "no self_attn / mlp.gate_up_proj / mlp.down_proj"
+        form = (type(layer).__name__, type(attn).__name__, type(mlp).__name__)
+        if form not in FUSABLE_FORMS:
+            return f"layer classes {form} are not one of {FUSABLE_FORMS}"
+        lins = dict(qkv_proj=attn.qkv_proj, o_proj=attn.o_proj, gate_up_proj=mlp.gate_up_proj, down_proj=mlp.down_proj)
     for name, l in lins.items():
         if not _plain_linear(l):
             w = getattr(l, "weight", None)
             return (f"{name} is not a plain bf16 projection (weight {getattr(w, 'dtype', None)} {tuple(getattr(w, 'shape', ()))} "
                     f"strides {w.stride() if w is not None else None} cuda {getattr(w, 'is_cuda', None)}, quant_method "
                     f"{type(getattr(l, 'quant_method', None)).__name__})")
-    if getattr(attn.o_proj, "bias", None) is not None or getattr(mlp.gate_up_proj, "bias", None) is not None \
-            or getattr(mlp.down_proj, "bias", None) is not None:
+    if getattr(attn.o_proj, "bias", None) is not None or (mlp is not None and (
+            getattr(mlp.gate_up_proj, "bias", None) is not None or getattr(mlp.down_proj, "bias", None) is not None)):
         return "o_proj / gate_up_proj / down_proj carry a bias"
     rope = attn.rotary_emb
     # plain cos / sin-cache ropes only (rotary_embedding/base.py:78 RotaryEmbedding, rope_variant.py:537
@@ -82,8 +103,8 @@ def layer_unfusable_reason(layer, rows: int) -> Optional[str]:
     if any(hasattr(attn, n) for n in ("q_norm", "k_norm")):            # (qwen3-style per-head norms: another layer form)
         return "per-head q / k norms"
     hidden = attn.qkv_proj.weight.shape[1]
-    if hidden % 128 != 0 or hidden > 16384 or mlp.gate_up_proj.weight.shape[0] % 32 != 0:
-        return f"hidden size {hidden} / gate_up rows {mlp.gate_up_proj.weight.shape[0]} outside the kernels' tiling"
+    if hidden % 128 != 0 or hidden > 16384 or (mlp is not None and mlp.gate_up_proj.weight.shape[0] % 32 != 0):
+        return f"hidden size {hidden} / gate_up rows outside the kernels' tiling"
     for name, l in lins.items():
         if not kernels.wstream_preferred(rows, *l.weight.shape):
             return f"{name} {tuple(l.weight.shape)} at {rows} rows is left to the library GEMM"
@@ -152,6 +173,41 @@ def decode_layer(layer, positions: torch.Tensor, normed: torch.Tensor, forward_b
                                 norm_weight=next_norm.weight.data, eps=next_norm.variance_epsilon, out_blocked=True)
 
 
+def decode_layer_moe(layer, positions: torch.Tensor, normed: torch.Tensor, forward_batch, residual: torch.Tensor,
+                     next_norm, comm=None) -> torch.Tensor:
+    """A sparse-MoE decoder layer (mixtral.py:238-260) in the fused form: the attention half as in decode_layer() -- four
+    launches -- handing ROW-MAJOR normed activations to the MoE block's own pieces (gate -> TopK -> FusedMoE: the reference's
+    modules with the registered forwards / the fused-MoE slot), then the residual add + `next_norm` in one launch (at TP > 1: in
+    the epilogue of the all-reduce that follows the experts, mixtral.py:115-117).  Returns next_norm(residual'), row-major."""
+    from .layers.attention.hip_backend import pool_kernel_format
+
+    attn, moe = layer.self_attn, moe_block_of(layer)
+    pool = kv_pool_of(forward_batch)
+    layer_id = attn.attn.layer_id
+    fmt = pool_kernel_format(pool, attn.attn)
+    plain = not fmt["kv_fp8"] and not fmt["hnd"]
+    bias = getattr(attn.qkv_proj, "bias", None)
+    q = kernels.wstream_qkv_rope(normed, attn.qkv_proj.weight.data, bias.data if bias is not None else None, positions,
+                                 attn.rotary_emb.cos_sin_cache, attn.num_heads, attn.num_kv_heads, attn.head_dim,
+                                 pool.get_key_buffer(layer_id), pool.get_value_buffer(layer_id), forward_batch.out_cache_loc,
+                                 **({} if plain else fmt))
+    a = attn.attn(q, None, None, forward_batch, save_kv_cache=False)
+    post = layer.post_attention_layernorm
+    if comm is not None:
+        y = kernels.wstream_gemm(a.reshape(a.shape[0], -1), attn.o_proj.weight.data)
+        x = comm.all_reduce_add_rmsnorm(y, residual, post.weight.data, post.variance_epsilon)
+    else:
+        x = kernels.wstream_gemm(a, attn.o_proj.weight.data, epilogue="add_rmsnorm", residual=residual, norm_weight=post.weight.data,
+                                 eps=post.variance_epsilon)
+    r = moe.gate(x)
+    router_logits = r[0] if isinstance(r, tuple) else r              # (ReplicatedLinear returns (output, bias))
+    h = moe.experts(x, moe.topk(x, router_logits))
+    if comm is not None:
+        return comm.all_reduce_add_rmsnorm(h.contiguous(), residual, next_norm.weight.data, next_norm.variance_epsilon)
+    kernels.fused_add_rmsnorm(h, residual, next_norm.weight.data, next_norm.variance_epsilon)      # h <- norm(h + residual), in place
+    return h
+
+
 def decode_model(model, hidden_states: torch.Tensor, positions: torch.Tensor, forward_batch, comm=None) -> torch.Tensor:
     """The layer loop + final norm of LlamaModel.forward for a decode batch: returns norm(...) [M, hidden] (chunk-major at
     TP = 1: kernels.unblock)."""
@@ -162,7 +218,8 @@ def decode_model(model, hidden_states: torch.Tensor, positions: torch.Tensor, fo
     x = kernels.rmsnorm(hidden_states, layers[0].input_layernorm.weight.data, layers[0].input_layernorm.variance_epsilon)
     for i, layer in enumerate(layers):
         nxt = layers[i + 1].input_layernorm if i + 1 < len(layers) else model.norm
-        x = decode_layer(layer, positions, x, forward_batch, residual, nxt, comm)
+        step = decode_layer_moe if moe_block_of(layer) is not None else decode_layer
+        x = step(layer, positions, x, forward_batch, residual, nxt, comm)
     return x
 
 
@@ -171,16 +228,23 @@ def model_fusable(model, hidden_states: torch.Tensor, forward_batch, comm=None) 
     must be messages its kernels take (bf16, <= 64 MiB, hidden <= 16384 for the fused epilogue)."""
     if not (hidden_states.is_cuda and hidden_states.dtype == _BF16 and hidden_states.dim() == 2):
         return False
-    if comm is not None and not (hidden_states.shape[1] <= 16384 and hidden_states.shape[1] % 8 == 0
-                                 and (comm.should_use(hidden_states.contiguous()) or comm.should_use_two_stage(hidden_states.contiguous()))):
-        return False
+    return rows_fusable(model, hidden_states.shape[0], hidden_states.shape[1], forward_batch, comm)
+
+
+def rows_fusable(model, rows: int, hidden: int, forward_batch, comm=None) -> bool:
+    """model_fusable() from the SHAPE of the residual stream alone ([rows, hidden] bf16 on the device), so the hook can decide
+    before it runs the embedding: at TP > 1 the vocab-parallel embedding ends in an all-reduce, which a refused batch would
+    otherwise pay twice (once here, once inside the original forward)."""
+    if comm is not None:
+        nbytes = rows * hidden * 2
+        if not (hidden <= 16384 and hidden % 8 == 0 and not comm.disabled and 0 < nbytes <= max(comm.max_bytes, comm.two_stage_bytes)):
+            return False
     positions = getattr(forward_batch, "positions", None)
     if positions is not None and positions.dim() != 1:                 # (multimodal 3-D positions: not this form)
         return False
     mode = getattr(forward_batch, "forward_mode", None)
     if mode is None or not mode.is_decode():
         return False
-    rows = hidden_states.shape[0]
     if not (len(model.layers) > 0 and all(layer_fusable(l, rows) for l in model.layers)):
         return False
     # a pool the kernels do not read (fp8_e5m2 rows, an unknown layout) must fall back BEFORE the first launch, not raise
@@ -247,11 +311,24 @@ def llama_model_forward_hook(original, self, input_ids, positions, forward_batch
     except Exception:
         ok = False
     if ok:
-        hidden_states = self.embed_tokens(input_ids)
-        if model_fusable(self, hidden_states, forward_batch, comm):
-            return kernels.unblock(decode_model(self, hidden_states, positions, forward_batch, comm))
-        _say_once_why_not(self, forward_batch, hidden_states)
+        # decided from shapes BEFORE the embedding runs: a refused batch (more rows than the weight stream takes, a layer left to
+        # the library GEMM) must not embed -- and, at TP > 1, all-reduce the embedding -- here and again in the original forward
+        emb_w = getattr(getattr(self, "embed_tokens", None), "weight", None)
+        rows = int(input_ids.shape[0]) if isinstance(input_ids, torch.Tensor) and input_ids.dim() == 1 else -1
+        if (rows > 0 and emb_w is not None and emb_w.is_cuda and emb_w.dtype == _BF16 and emb_w.dim() == 2
+                and rows_fusable(self, rows, int(emb_w.shape[1]), forward_batch, comm)):
+            hidden_states = self.embed_tokens(input_ids)
+            if model_fusable(self, hidden_states, forward_batch, comm):      # (what the embedding returned is what was assumed)
+                return kernels.unblock(decode_model(self, hidden_states, positions, forward_batch, comm))
+            return _finish_unfused(original, self, hidden_states, positions, forward_batch)
+        _say_once_why_not(self, forward_batch, None)
     return original(self, input_ids, positions, forward_batch, input_embeds, pp_proxy_tensors)
+
+
+def _finish_unfused(original, model, hidden_states, positions, forward_batch):
+    """The embedding has run but its output is not the [rows, hidden] bf16 tensor the decision assumed (never seen; kept so that the
+    embedding is still not paid twice): hand the embeddings to the original forward as `input_embeds` (llama.py:433-437)."""
+    return original(model, None, positions, forward_batch, hidden_states, None)
 
 
 _SAID = set()
@@ -296,7 +373,8 @@ def _tp():
 
 # model classes whose forward is the loop above (same signature, same attribute names; Mistral and the other Llama-style
 # checkpoints are served by LlamaModel itself): llama.py:419-470, qwen2.py:396-448 (qkv bias: in the qkv combine)
-HOOK_TARGETS = ("sglang.srt.models.llama.LlamaModel.forward", "sglang.srt.models.qwen2.Qwen2Model.forward")
+HOOK_TARGETS = ("sglang.srt.models.llama.LlamaModel.forward", "sglang.srt.models.qwen2.Qwen2Model.forward",
+                "sglang.srt.models.mixtral.MixtralModel.forward")         # mixtral.py:300-335: the same loop over sparse-MoE layers
 
 
 def install(registry, hook_type_around) -> None:

@@ -291,12 +291,16 @@ class LlamaDecoderLayer(nn.Module):
 
     def fusable(self, x: torch.Tensor, tp_size: int) -> bool:
         """The decode form below needs no collective between a projection and the norm behind it."""
-        if OPERATOR_SURFACE_ONLY or not isinstance(self.mlp, LlamaMLP) or x.shape[1] > 16384:
+        if OPERATOR_SURFACE_ONLY or x.shape[1] > 16384:
+            return False
+        moe = fused_decode.moe_block_of(self) is not None
+        if not moe and not isinstance(self.mlp, LlamaMLP):
             return False
         if tp_size > 1:     # the add + norm ride in the all-reduce's epilogue (one-shot or, for weak-scaled batches, two-stage)
             xg = ps.get_xgmi_all_reduce()
             return (xg is not None and x.is_cuda and x.dtype == BF and x.dim() == 2
-                    and (xg.should_use(x) or xg.should_use_two_stage(x)))
+                    and (xg.should_use(x) or xg.should_use_two_stage(x))
+                    and (not moe or fused_decode.layer_fusable(self, x.shape[0])))     # (sparse-MoE layers: the fused attention half needs the weight stream)
         return x.is_cuda and fused_decode.layer_fusable(self, x.shape[0])     # the plug-in's own test (fused_decode.py)
 
     def forward_decode_fused(self, positions, normed: torch.Tensor, forward_batch, residual: torch.Tensor,
@@ -304,6 +308,11 @@ class LlamaDecoderLayer(nn.Module):
         """Same arithmetic as forward() (llama.py:341-370) for a TP=1 decode batch, with every
         residual-add + RMSNorm executed by the preceding projection's combine kernel.  `normed` is
         this layer's input_layernorm output; returns next_norm's output, residual updated in place."""
+        if fused_decode.moe_block_of(self) is not None:
+            # sparse-MoE layer (Mixtral): fused attention half + the block's own gate / TopK / experts + add-norm (fused_decode.py),
+            # what the AROUND hook on the reference's MixtralModel.forward runs
+            xg = ps.get_xgmi_all_reduce() if ps.get_tensor_model_parallel_world_size() > 1 else None
+            return fused_decode.decode_layer_moe(self, positions, normed, forward_batch, residual, next_norm, xg)
         if ps.get_tensor_model_parallel_world_size() == 1:
             # the very function plugin.load() hooks onto the reference's LlamaModel.forward: what bench.py times IS what
             # the plug-in delivers under unchanged reference model classes

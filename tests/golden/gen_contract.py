@@ -52,6 +52,7 @@ WANT = {
     "sglang/srt/plugins/hook_registry.py": ["HookRegistry", "HookType", "_wrap_fn"],
     "sglang/srt/models/llama.py": ["LlamaModel", "LlamaDecoderLayer", "LlamaAttention", "LlamaMLP"],
     "sglang/srt/models/qwen2.py": ["Qwen2Model", "Qwen2DecoderLayer", "Qwen2Attention", "Qwen2MLP"],
+    "sglang/srt/models/mixtral.py": ["MixtralModel", "MixtralDecoderLayer", "MixtralAttention", "MixtralMoE"],
     "sglang/srt/layers/quantization/unquant.py": ["UnquantizedLinearMethod", "UnquantizedFusedMoEMethod"],
     "sglang/srt/runtime_context.py": ["get_parallel"],
     "sglang/srt/distributed/parallel_state.py": ["GroupCoordinator", "get_tp_group"],

@@ -157,11 +157,18 @@ def init_parallel(ns, port: int = 0):
     world, rank = tp_world()
     if dry_run_on_cpu():
         PS.is_cuda_alike = lambda: False
+    # one GPU per rank where the box has them (the launcher below decides, REF_MODEL_MULTI_GPU): then the groups' device backend is
+    # RCCL and the xGMI communicator's peers are other DEVICES -- the first multi-GPU lease exercises exactly what a `--tp N`
+    # launch runs.  On a one-GPU box every rank sits on GPU 0 over gloo device groups (RCCL refuses several ranks of one device).
+    multi_gpu = world > 1 and os.environ.get("REF_MODEL_MULTI_GPU") == "1" and not dry_run_on_cpu()
+    if multi_gpu:
+        torch.cuda.set_device(rank)
     if not PS.model_parallel_is_initialized():
         port = port or int(os.environ.get("REF_MODEL_PORT", 29500 + os.getpid() % 400))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        PS.init_distributed_environment(world_size=world, rank=rank, distributed_init_method=f"tcp://127.0.0.1:{port}", local_rank=0,
-                                        backend="gloo" if (dry_run_on_cpu() or world > 1) else "nccl")
+        PS.init_distributed_environment(world_size=world, rank=rank, distributed_init_method=f"tcp://127.0.0.1:{port}",
+                                        local_rank=rank if multi_gpu else 0,
+                                        backend="gloo" if (dry_run_on_cpu() or (world > 1 and not multi_gpu)) else "nccl")
         PS.initialize_model_parallel(world)
         # ModelRunner.init_torch_distributed goes on to initialize_dp_attention(server_args, model_config) (dp_attention.py:343-375):
         # without dp attention that leaves the module at "one attention-dp replica, rank 0"
@@ -1688,9 +1695,14 @@ if __name__ == "__main__":
 
         port = 29500 + os.getpid() % 400
         procs = []
+        multi_gpu = torch.cuda.is_available() and torch.cuda.device_count() >= a.tp
         for r in range(a.tp):
             env = dict(os.environ, REF_MODEL_WORLD=str(a.tp), REF_MODEL_RANK=str(r), REF_MODEL_PORT=str(port),
-                       SGLANG_NCCL_SO_PATH="/nonexistent/librccl.so", SGLANG_USE_MESSAGE_QUEUE_BROADCASTER="false")
+                       SGLANG_USE_MESSAGE_QUEUE_BROADCASTER="false", HSA_ENABLE_IPC_MODE_LEGACY="0")
+            if multi_gpu:
+                env["REF_MODEL_MULTI_GPU"] = "1"              # one device per rank, RCCL device groups (init_parallel)
+            else:
+                env["SGLANG_NCCL_SO_PATH"] = "/nonexistent/librccl.so"      # all ranks on GPU 0: the reference's "no NCCL library" branch
             procs.append(subprocess.Popen([sys.executable, __file__] + sys.argv[1:], env=env,
                                           stdout=None if r == 0 else subprocess.DEVNULL, stderr=None))
         import time
@@ -1714,6 +1726,8 @@ if __name__ == "__main__":
            "shared-prefix": lambda: run_shared_prefix_job(a.dims if a.dims != "tiny" else "tiny_v16k", *[int(x) for x in a.job.split(",")],
                                                           radix=a.radix)}[a.run]()
     rep["tp"] = tp_world()[0]
+    rep["devices"] = ("one GPU per rank, RCCL device groups" if os.environ.get("REF_MODEL_MULTI_GPU") == "1" else
+                      "every rank on GPU 0, gloo device groups" if tp_world()[0] > 1 else "one rank")
     text = json.dumps(rep, indent=1)
     if tp_world()[1] != 0:
         text, a.json = "", None

@@ -58,6 +58,10 @@ def test_every_token_is_covered_exactly_once(seed, group):
         covered[b][kv_begin: kv_begin + kv_n] += 1
         assert slot not in slots[b]
         slots[b].add(slot)
+    # the chunk kernel's one-workgroup-per-unit grid is sized for batch x (chunks + 1) items (cascade_attention.hip): a request
+    # never owns more than that many, however the batch is grouped
+    chunks = (ctx + CH - 1) // CH
+    assert len(plan["shared_items"]) + len(plan["private_items"]) <= B * (chunks + 1)
     for b in range(B):
         assert (covered[b] == 1).all(), f"request {b}"
         n = (plan["req_shared"][b] + CH - 1) // CH + ((lens[b] - plan["req_shared"][b] + CH - 1) // CH if lens[b] > plan["req_shared"][b] else 0)
@@ -100,3 +104,29 @@ def test_no_sharing_means_private_chunks_only():
     plan = oh.cascade_plan(r2t, list(range(1, len(lens) + 1)), lens, 4, chunk=CH, max_context_len=1024)
     assert plan["groups"] == [] and plan["req_shared"] == [0] * len(lens)
     assert len(plan["private_items"]) == sum((n + CH - 1) // CH for n in lens)
+
+
+@pytest.mark.parametrize("group,members", [(1, 2), (1, 64), (4, 2), (4, 16), (4, 17), (4, 33), (16, 5), (64, 3), (64, 40)])
+def test_item_count_never_exceeds_the_grid_bound_for_adversarial_groupings(group, members):
+    """The grid bound of the one-workgroup-per-unit chunk kernel, batch x (ceil(width / chunk) + 1), on the groupings that maximise
+    shared items per member: groups of `members` requests (member tiles round UP) whose shared parts end at every offset around a
+    chunk boundary, lengths up to the table's width."""
+    width = 1160
+    chunks = (width + CH - 1) // CH
+    for shared in (128, 191, 192, 255, 256, 320, 896, 1087):
+        for tail in (1, 63, 64, 65, 127, 128, 129):
+            B = 2 * members + 3
+            lens = [min(width - 1, shared + tail + (b % 5)) for b in range(B)]
+            r2t = np.zeros((B + 1, width), dtype=np.int32)
+            nxt = 1
+            for b in range(B):
+                r2t[b + 1, :lens[b]] = np.arange(nxt, nxt + lens[b])
+                nxt += lens[b]
+            for g in range(2):                                  # two groups of `members`, three loners
+                lead = g * members
+                n = min(shared, min(lens[lead: lead + members]) - 1)
+                for b in range(lead + 1, lead + members):
+                    r2t[b + 1, :n] = r2t[lead + 1, :n]
+            plan = oh.cascade_plan(r2t, list(range(1, B + 1)), lens, group, chunk=CH, max_context_len=width)
+            n_items = len(plan["shared_items"]) + len(plan["private_items"])
+            assert n_items <= B * (chunks + 1), (shared, tail, n_items, B * (chunks + 1))

@@ -36,7 +36,10 @@ class RefShapedLlamaModel:
 
 
 # (the third case: the 8B shapes with a qkv bias -- the layer form of Qwen2Model, the hook's second target)
-@pytest.mark.parametrize("model_name,B", [("tiny-llama3-rope", 5), ("llama-3-8b-2l", 64), ("llama-3-8b-2l-qkvbias", 16)])
+# (the last two: sparse-MoE layers -- the form of MixtralModel, the hook's third target: fused attention half, the block's own gate /
+# TopK / experts, add + norm in one launch)
+@pytest.mark.parametrize("model_name,B", [("tiny-llama3-rope", 5), ("llama-3-8b-2l", 64), ("llama-3-8b-2l-qkvbias", 16),
+                                          ("tiny-mixtral", 5), ("mixtral-8x7b-2l", 32)])
 def test_hook_takes_the_fused_branch_and_matches_the_operator_loop(device, monkeypatch, model_name, B):
     import dataclasses
 
@@ -45,7 +48,8 @@ def test_hook_takes_the_fused_branch_and_matches_the_operator_loop(device, monke
     from sglang_amd.harness.engine import Engine, ModelRunner, Req
 
     cfg = (dataclasses.replace(M.CONFIGS["llama-3-8b"], num_hidden_layers=2, name=model_name, attention_bias=model_name.endswith("qkvbias"))
-           if model_name.startswith("llama-3-8b-2l") else M.CONFIGS[model_name])
+           if model_name.startswith("llama-3-8b-2l") else
+           dataclasses.replace(M.CONFIGS["mixtral-8x7b"], num_hidden_layers=2, name=model_name) if model_name == "mixtral-8x7b-2l" else M.CONFIGS[model_name])
     runner = ModelRunner(cfg, max_total_tokens=B * 80 + 512, max_running_requests=B, max_context_len=96, device=device, use_graph=False)
     ref_model = RefShapedLlamaModel(runner.model)
     seen = {}
@@ -83,7 +87,15 @@ def test_hook_takes_the_fused_branch_and_matches_the_operator_loop(device, monke
     # (the two paths pick different split-K decompositions for o_proj / down_proj -- with and without the norm in the
     # combine -- so a few sums round the other way and two layers carry that on: measured 98.1 % identical, 99.66 %
     # within one ulp, 99.94 % within two at the 8B shapes)
-    assert st["frac_identical"] >= 0.95 and st["frac_within_1ulp"] >= 0.99 and st["frac_within_2ulp"] >= 0.998 and st["max_ulp"] <= 8.0, st
+    if cfg.num_local_experts > 0:
+        # a one-ulp difference in a router input may move a token to another expert in either evaluation (a whole row then differs by
+        # far more than rounding): judged over the rows whose routing agreed -- all but at most one row of these small batches
+        rows_ok = ((seen["got"].float() - seen["want"].float()).abs().amax(-1) <= 0.05 * seen["want"].float().abs().amax(-1).clamp_min(1e-3))
+        assert int(rows_ok.sum()) >= B - 1, rows_ok
+        st = ulp_stats(seen["got"][rows_ok], seen["want"][rows_ok])
+        assert st["frac_identical"] >= 0.90 and st["frac_within_2ulp"] >= 0.99 and st["max_ulp"] <= 16.0, st
+    else:
+        assert st["frac_identical"] >= 0.95 and st["frac_within_1ulp"] >= 0.99 and st["frac_within_2ulp"] >= 0.998 and st["max_ulp"] <= 8.0, st
     eng.finish(list(eng.running))
 
 

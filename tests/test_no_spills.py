@@ -46,6 +46,7 @@ def test_cascade_chunk_kernel_fits_five_workgroups_per_cu(tmp_path):
         assert u["vgpr_count"] <= 96, (name, u)                 # 512 / 5 waves per SIMD, 8-register granules
         assert u["group_segment_fixed_size"] <= 16384, (name, u)  # five 16 KiB images of the 160 KiB (LDS granule 1280 B)
     # the looping form (large request tables: a bounded grid walks the item list) runs four workgroups per CU and must not spill at all
+    # (a five-per-CU instance parks ~29 registers in scratch and measured 34 against 26.7 us per layer: profiles/r05_exp1b_cascade_forms.json)
     loop = {k: v for k, v in usage.items() if "cascade_chunk_loop_kernel" in k}
     assert len(loop) == 8, sorted(usage)
     for name, u in loop.items():

@@ -548,7 +548,21 @@ def test_model_level_hook_is_registered_and_falls_through_to_the_reference_forwa
     plugin.load()
     hr = g["sglang.srt.plugins.hook_registry"]
     target = "sglang.srt.models.llama.LlamaModel.forward"
-    assert fused_decode.HOOK_TARGETS == (target, "sglang.srt.models.qwen2.Qwen2Model.forward")
+    assert fused_decode.HOOK_TARGETS == (target, "sglang.srt.models.qwen2.Qwen2Model.forward", "sglang.srt.models.mixtral.MixtralModel.forward")
+    # the sparse-MoE form (round 5): MixtralModel.forward has LlamaModel.forward's signature, its layers carry the block as
+    # `block_sparse_moe` with the pieces the fused layer calls -- gate, topk, experts (mixtral.py:57-118, 202-261)
+    mx = "sglang.srt.models.mixtral"
+    assert [(ht.name, h) for ht, h, _ in hr.HookRegistry._hooks[fused_decode.HOOK_TARGETS[2]]] == [("AROUND", fused_decode.llama_model_forward_hook)]
+    import inspect as _insp
+
+    assert list(_insp.signature(fused_decode.llama_model_forward_hook).parameters) == ["original"] + [q["name"] for q in ref(mx, "MixtralModel")["methods"]["forward"]["params"]]
+    for cls, names in (("MixtralModel", ("embed_tokens", "layers", "norm", "pp_group")),
+                       ("MixtralDecoderLayer", ("self_attn", "block_sparse_moe", "input_layernorm", "post_attention_layernorm")),
+                       ("MixtralAttention", ("qkv_proj", "o_proj", "rotary_emb", "attn", "num_heads", "num_kv_heads", "head_dim")),
+                       ("MixtralMoE", ("gate", "topk", "experts", "tp_size"))):
+        have = set(ref(mx, cls)["instance_attrs"])
+        assert set(names) <= have, (cls, sorted(set(names) - have))
+    assert ("MixtralDecoderLayer", "MixtralAttention", "MixtralMoE") in fused_decode.MOE_FORMS
     # the hook binds to the reference's forward signature: (original, self, <reference parameters>) -- for every model
     # class it is registered on, whose layers carry the attribute names the fused loop reads
     import inspect

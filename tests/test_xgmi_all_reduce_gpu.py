@@ -323,12 +323,12 @@ def _case_stress(rank, world, ps, dist):
         return dt / n * 1e6
 
     us = run(iters, "write-through protocol")
-    # the fallback protocol (system-scope release fence ahead of every flag) is captured into a fresh graph
-    XgmiAllReduce.set_release_fence(True)
+    # the fallback protocol (system-scope release fence ahead of every flag): this communicator's own switch
+    xg.set_release_fence(True)
     try:
         us_fence = run(max(20, iters // 10), "release-fence fallback")
     finally:
-        XgmiAllReduce.set_release_fence(False)
+        xg.set_release_fence(False)
     return {"iterations": int(it), "us_per_iteration": us, "us_per_iteration_release_fence": us_fence}
 
 
