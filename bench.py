@@ -34,6 +34,11 @@ The JSON line also carries
                       agreement, against the fp32-accumulating and the literal bf16 oracle (rank 0, N=1)
   cpu_baseline        the oracle = reference CPU torch-native path on the box's host cores, on a bounded sample
                       of the same phases: Qwen2.5-0.5B end to end and Llama-3-8B at B=4
+  reference_scheduler the same job under the REFERENCE'S own Scheduler.run_event_loop() (overlap loop), ModelRunner, radix cache
+                      and graph runner with this package as its plug-in (tests/golden/ref_model.py over the staged copy of the
+                      reference's sources; a subprocess after the timed region): tokens/s, decode interval, graph replays,
+                      radix hits, Triton launches (0), the pool / allocator classes.  Reported BESIDE `value`, never as it.
+  + top-level copies  ttft_p50_ms, prefill_mfma_frac, decode_step_hbm_frac, ms_per_decode_step, reference_scheduler_tokens_per_s
 """
 from __future__ import annotations
 
@@ -54,7 +59,7 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_PEAK_TFLOPS = 2500.0     # bf16 dense
-PMC_FILE = ROOT / "profiles" / "r04_pmc.json"
+PMC_FILE = ROOT / "profiles" / "r05_pmc.json"
 PMC_NAME = "profiles/" + PMC_FILE.name
 
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 --pmc passes over the bench job (benchmarks/pmc_workload.py), one counter set per pass and no trace
-# domain mixed in; merged into gpurun_out/r04_pmc.json (copy to profiles/ to commit).
+# domain mixed in; merged into gpurun_out/r05_pmc.json (copy to profiles/ to commit).
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
@@ -17,5 +17,5 @@ for S in "${SETS[@]}"; do
   DIRS="$DIRS $D"
   i=$((i+1))
 done
-python benchmarks/summarize_pmc_phases.py gpurun_out/r04_pmc.json llama-3-8b 64 $STEPS $DIRS > gpurun_out/r04_pmc_summary.txt 2>&1
-head -60 gpurun_out/r04_pmc_summary.txt
+python benchmarks/summarize_pmc_phases.py gpurun_out/r05_pmc.json llama-3-8b 64 $STEPS $DIRS > gpurun_out/r05_pmc_summary.txt 2>&1
+head -60 gpurun_out/r05_pmc_summary.txt

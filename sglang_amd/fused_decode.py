@@ -315,12 +315,21 @@ def llama_model_forward_hook(original, self, input_ids, positions, forward_batch
         # the library GEMM) must not embed -- and, at TP > 1, all-reduce the embedding -- here and again in the original forward
         emb_w = getattr(getattr(self, "embed_tokens", None), "weight", None)
         rows = int(input_ids.shape[0]) if isinstance(input_ids, torch.Tensor) and input_ids.dim() == 1 else -1
-        if (rows > 0 and emb_w is not None and emb_w.is_cuda and emb_w.dtype == _BF16 and emb_w.dim() == 2
-                and rows_fusable(self, rows, int(emb_w.shape[1]), forward_batch, comm)):
+        known = rows > 0 and isinstance(emb_w, torch.Tensor) and emb_w.dim() == 2
+        if known:
+            if emb_w.is_cuda and emb_w.dtype == _BF16 and rows_fusable(self, rows, int(emb_w.shape[1]), forward_batch, comm):
+                hidden_states = self.embed_tokens(input_ids)
+                if model_fusable(self, hidden_states, forward_batch, comm):      # (what the embedding returned is what was assumed)
+                    return kernels.unblock(decode_model(self, hidden_states, positions, forward_batch, comm))
+                _say_once_why_not(self, forward_batch, hidden_states)
+                return _finish_unfused(original, self, hidden_states, positions, forward_batch)
+        else:
+            # an embedding without a `.weight` to read the width from (not the reference's VocabParallelEmbedding): decided behind it
             hidden_states = self.embed_tokens(input_ids)
-            if model_fusable(self, hidden_states, forward_batch, comm):      # (what the embedding returned is what was assumed)
+            if model_fusable(self, hidden_states, forward_batch, comm):
                 return kernels.unblock(decode_model(self, hidden_states, positions, forward_batch, comm))
-            return _finish_unfused(original, self, hidden_states, positions, forward_batch)
+            _say_once_why_not(self, forward_batch, hidden_states)
+            return original(self, input_ids, positions, forward_batch, input_embeds, pp_proxy_tensors)
         _say_once_why_not(self, forward_batch, None)
     return original(self, input_ids, positions, forward_batch, input_embeds, pp_proxy_tensors)
 

@@ -96,8 +96,15 @@ def paged_allocator_class():
         def _hip_ok(self, *ts) -> bool:
             return _i64_cuda(self.free_pages, *ts) and not torch.compiler.is_compiling()
 
+        @staticmethod
+        def _as_i64(t):
+            """`last_loc` of a decode batch is read straight out of the int32 request table (allocation.py:531-533): widened
+            here (the Triton kernels take any integer width, the gfx950 kernels int64 metadata)."""
+            return t.to(torch.int64) if isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.int32 else t
+
         def alloc_extend(self, prefix_lens, prefix_lens_cpu, seq_lens, seq_lens_cpu, last_loc, extend_num_tokens: int,
                          num_new_pages: int = None):
+            last_loc = self._as_i64(last_loc)
             if not self._hip_ok(prefix_lens, seq_lens, last_loc):
                 return super().alloc_extend(prefix_lens, prefix_lens_cpu, seq_lens, seq_lens_cpu, last_loc, extend_num_tokens, num_new_pages)
             from . import kernels
@@ -122,6 +129,7 @@ def paged_allocator_class():
             return out_indices
 
         def alloc_decode(self, seq_lens, seq_lens_cpu, last_loc):
+            last_loc = self._as_i64(last_loc)
             if not self._hip_ok(seq_lens, last_loc):
                 return super().alloc_decode(seq_lens, seq_lens_cpu, last_loc)
             from . import kernels
