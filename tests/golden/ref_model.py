@@ -1550,6 +1550,121 @@ def _profiled(fn, path):
     return out
 
 
+def run_mem_hooks() -> dict:
+    """Differential run of round 5's slot-bookkeeping / KV-store take-overs against the REFERENCE'S OWN device code on MI355X (its
+    Triton kernels run here): the platform's allocator class vs the reference's `PagedTokenToKVPoolAllocator` driven through the
+    same random request histories (page sizes 1 / 4 / 16: extends over page-misaligned prefixes, then decode steps; outputs and
+    free lists compared after every call); the hooked `allocation.write_cache_indices` / `get_last_loc` vs the reference's Triton
+    kernels called the way its own code calls them (allocation.py:71-82, :121-135); the platform's pool class vs the reference's
+    `MHATokenToKVPool.set_kv_buffer` for bf16 and e4m3 pools (NHD) -- every comparison `torch.equal`."""
+    loader = run_loader()
+    ns = install()
+    dev = torch.device("cuda")
+    from sglang_amd import mem_hooks
+
+    AL = importlib.import_module("sglang.srt.mem_cache.allocation")
+    PG = importlib.import_module("sglang.srt.mem_cache.allocator.paged")
+    MP = importlib.import_module("sglang.srt.mem_cache.memory_pool")
+    KM = importlib.import_module("sglang.kernels.ops.memory.common")
+    triton_seen = _count_triton_launches()
+    g = torch.Generator().manual_seed(17)
+    rep = dict(mode="mem-hooks", loader=dict(platform=loader["platform"], hooked=loader["hooked"]), allocator=[], write_cache_indices=[],
+               get_last_loc=[], kv_store=[])
+
+    def ri(lo, hi):
+        return int(torch.randint(lo, hi, (1,), generator=g))
+
+    # ---- 1. the paged allocator ----------------------------------------------------------------------------------------------
+    Ours = mem_hooks.paged_allocator_class()
+    for page in (1, 4, 16):
+        size = 4096 * page
+        ref_a = PG.PagedTokenToKVPoolAllocator(size, page_size=page, dtype=torch.bfloat16, device="cuda", kvcache=None, need_sort=False)
+        our_a = Ours(size, page_size=page, dtype=torch.bfloat16, device="cuda", kvcache=None, need_sort=False)
+        calls = 0
+        for round_ in range(6):
+            bs = ri(1, 24)
+            prefix = [ri(0, 40) for _ in range(bs)]
+            last = []
+            # a request's cached prefix ends somewhere inside a page the request owns: the slot before the next free position
+            for b in range(bs):
+                last.append(-1 if prefix[b] == 0 else (1000 + b) * page + (prefix[b] - 1) % page)
+            ext = [ri(1, 50) for _ in range(bs)]
+            seq = [p_ + e for p_, e in zip(prefix, ext)]
+            pl_c, sl_c = torch.tensor(prefix, dtype=torch.int64), torch.tensor(seq, dtype=torch.int64)
+            pl, sl, ll = pl_c.to(dev), sl_c.to(dev), torch.tensor(last, dtype=torch.int64, device=dev)
+            n0 = len(triton_seen)
+            want = ref_a.alloc_extend(pl, pl_c, sl, sl_c, ll, sum(ext))
+            n1 = len(triton_seen)
+            got = our_a.alloc_extend(pl, pl_c, sl, sl_c, ll, sum(ext))
+            assert n1 > n0 and len(triton_seen) == n1, "the reference's allocator must launch Triton, the platform's must not"
+            ok = bool(torch.equal(got, want)) and bool(torch.equal(our_a.free_pages, ref_a.free_pages))
+            calls += 1
+            # decode steps on top: last_loc = the request's newest slot, read out of an int32 table as the reference does
+            off, newest = 0, []
+            for e in ext:
+                newest.append(int(want[off + e - 1]))
+                off += e
+            for step in range(3 if page > 1 else 0):          # (at page size 1 the reference takes `alloc()`, never `alloc_decode`: allocation.py:526-528)
+                seq = [x + 1 for x in seq]
+                sl_c = torch.tensor(seq, dtype=torch.int64)
+                sl = sl_c.to(dev)
+                ll32 = torch.tensor(newest, dtype=torch.int32, device=dev)
+                want_d = ref_a.alloc_decode(sl, sl_c, ll32)
+                got_d = our_a.alloc_decode(sl, sl_c, ll32)
+                ok = ok and bool(torch.equal(got_d, want_d)) and bool(torch.equal(our_a.free_pages, ref_a.free_pages))
+                newest = want_d.tolist()
+                calls += 1
+            if not ok:
+                break
+        rep["allocator"].append(dict(page_size=page, calls=calls, equal=ok))
+    # ---- 2. write_cache_indices / get_last_loc -------------------------------------------------------------------------------
+    for bs in (1, 7, 60):
+        width = 640
+        table_ref = torch.zeros((bs + 3, width), dtype=torch.int32, device=dev)
+        table_our = torch.zeros_like(table_ref)
+        pool_idx = torch.randperm(bs + 2, generator=g)[:bs].to(torch.int64) + 1
+        prefix = [ri(0, 200) for _ in range(bs)]
+        ext = [ri(1, 300) for _ in range(bs)]
+        seq = [p_ + e for p_, e in zip(prefix, ext)]
+        prefix_tensors = [torch.randint(1, 100000, (p_,), generator=g, dtype=torch.int64).to(dev) for p_ in prefix]
+        out_loc = torch.randint(1, 100000, (sum(ext),), generator=g, dtype=torch.int64).to(dev)
+        to = lambda xs: torch.tensor(xs, dtype=torch.int64)          # noqa: E731
+        pi_c, pl_c, sl_c, el_c = pool_idx.clone(), to(prefix), to(seq), to(ext)
+        pi, pl, sl, el = pi_c.to(dev), pl_c.to(dev), sl_c.to(dev), el_c.to(dev)
+        ptrs = torch.tensor([t.data_ptr() for t in prefix_tensors], dtype=torch.uint64).to(dev)
+        KM.write_req_to_token_pool_triton[(bs,)](table_ref, pi, ptrs, pl, sl, el, out_loc, table_ref.shape[1])      # allocation.py:71-82
+        before = mem_hooks.counts["write_cache_indices"]
+        n1 = len(triton_seen)
+        AL.write_cache_indices(out_loc, pi, pi_c, pl, pl_c, sl, sl_c, el, el_c, prefix_tensors, types.SimpleNamespace(req_to_token=table_our, device="cuda"))
+        rep["write_cache_indices"].append(dict(batch=bs, equal=bool(torch.equal(table_our, table_ref)),
+                                                served_by_the_hook=mem_hooks.counts["write_cache_indices"] == before + 1,
+                                                triton_launches=len(triton_seen) - n1))
+        want_l = KM.get_last_loc_triton_safe(table_ref, pi, pl)                                                        # allocation.py:121-135
+        before = mem_hooks.counts["get_last_loc"]
+        n1 = len(triton_seen)
+        got_l = AL.get_last_loc(table_our, pi, pl)
+        rep["get_last_loc"].append(dict(batch=bs, equal=bool(torch.equal(got_l, want_l)) and got_l.dtype == want_l.dtype,
+                                         served_by_the_hook=mem_hooks.counts["get_last_loc"] == before + 1, triton_launches=len(triton_seen) - n1))
+    # ---- 3. the KV store ------------------------------------------------------------------------------------------------------
+    OurPool = mem_hooks.mha_kv_pool_class()
+    layer = types.SimpleNamespace(layer_id=1)
+    for dtype in (torch.bfloat16, torch.float8_e4m3fn):
+        kw = dict(size=2048, page_size=1, dtype=dtype, head_num=4, head_dim=128, layer_num=2, device="cuda", enable_memory_saver=False)
+        ref_p, our_p = MP.MHATokenToKVPool(**kw), OurPool(**kw)
+        T = 333
+        loc = (torch.randperm(2048, generator=g)[:T] + 1).to(torch.int64).to(dev)
+        k = (torch.randn((T, 4, 128), generator=g) * 3).to(torch.bfloat16).to(dev)
+        v = (torch.randn((T, 4, 128), generator=g) * 3).to(torch.bfloat16).to(dev)
+        before = mem_hooks.counts["store_kv"]
+        ref_p.set_kv_buffer(layer, MP.KVWriteLoc(loc, None), k.clone(), v.clone())
+        our_p.set_kv_buffer(layer, MP.KVWriteLoc(loc, None), k.clone(), v.clone())
+        same = all(bool(torch.equal(a_.view(torch.uint8), b_.view(torch.uint8))) for a_, b_ in zip(ref_p.k_buffer + ref_p.v_buffer, our_p.k_buffer + our_p.v_buffer))
+        rep["kv_store"].append(dict(dtype=str(dtype), rows=T, equal=same, served_by_the_pool_class=mem_hooks.counts["store_kv"] == before + 1,
+                                    nonzero=bool(our_p.k_buffer[1].view(torch.uint8).any())))
+    rep["counts"] = dict(mem_hooks.counts)
+    return rep
+
+
 def run_latency(dims_name="tiny", batch_size=4, input_len=16, output_len=4) -> dict:
     """The reference's own latency benchmark -- `python -m sglang.bench_one_batch --load-format dummy --batch-size B --input-len I
     --output-len O` (benchmark/one_batch.py:877-990 latency_test: one warm-up pass, then `latency_test_run_once`, whose
@@ -1679,7 +1794,7 @@ if __name__ == "__main__":
     import json
 
     ap = argparse.ArgumentParser()
-    ap.add_argument("--run", choices=["cpu-oracle", "loader", "gpu", "runner", "latency", "shared-prefix", "scheduler", "stage"], required=True)
+    ap.add_argument("--run", choices=["cpu-oracle", "loader", "gpu", "runner", "latency", "shared-prefix", "scheduler", "mem-hooks", "stage"], required=True)
     ap.add_argument("--dims", default="tiny", choices=sorted(DIMS))
     ap.add_argument("--json", default=None)
     ap.add_argument("--shape", default="4,16,4", help="latency run: batch size, input length, output length")
@@ -1719,7 +1834,7 @@ if __name__ == "__main__":
     if a.run == "stage":
         stage()
         sys.exit(0)
-    rep = {"cpu-oracle": lambda: run_cpu_oracle(a.dims), "loader": run_loader, "gpu": lambda: run_gpu(a.dims),
+    rep = {"cpu-oracle": lambda: run_cpu_oracle(a.dims), "loader": run_loader, "gpu": lambda: run_gpu(a.dims), "mem-hooks": run_mem_hooks,
            "runner": lambda: run_runner(a.dims, _json_arg(a.server_args)), "latency": lambda: run_latency(a.dims, *[int(x) for x in a.shape.split(",")]),
            "scheduler": lambda: run_scheduler_job(a.dims if a.dims != "tiny" else "tiny_v16k", *[int(x) for x in a.job.split(",")],
                                                   overlap=a.overlap, server_args=_json_arg(a.server_args), logprobs=a.logprobs),

@@ -245,3 +245,25 @@ def test_plugin_under_the_references_scheduler(device, loop):
         # the streamed log-probabilities against log_softmax of the oracle's logits (teacher-forced with the produced tokens): bf16
         # logits of rms 1 carry ~0.01-0.03 of evaluation noise
         assert o["logprob_values"] == 16 and o["max_abs_logprob_diff"] <= 0.08 and o["top2_sets_equal"] >= 12, o
+
+
+def test_mem_hooks_equal_the_references_own_device_code(device):
+    """Round 5's take-overs of the scheduler's slot bookkeeping and KV store, differentially against the REFERENCE'S OWN device code
+    on the same inputs (tests/golden/ref_model.py run_mem_hooks; the reference's Triton kernels run on MI355X): the platform's paged
+    allocator against `PagedTokenToKVPoolAllocator` through random request histories at page sizes 1 / 4 / 16 (outputs AND free lists
+    after every call; int32 `last_loc` as `alloc_for_decode` reads it out of the request table), the hooked `write_cache_indices` /
+    `get_last_loc` against `write_req_to_token_pool_triton` / `get_last_loc_triton_safe`, the platform's pool class against
+    `MHATokenToKVPool.set_kv_buffer` for bf16 and e4m3 pools -- all bit-exact, none of ours launching Triton."""
+    import ref_model
+
+    if ref_model.ref_root() is None:
+        pytest.skip("reference sources are not staged (python tests/golden/ref_model.py --run stage in the build container)")
+    out = ROOT / "gpurun_out" / "reference_mem_hooks.json"
+    p = subprocess.run([sys.executable, str(ROOT / "tests" / "golden" / "ref_model.py"), "--run", "mem-hooks", "--json", str(out)],
+                       cwd=ROOT, env=dict(os.environ, SGLANG_USE_AITER="0"), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-6000:]
+    rep = json.loads(out.read_text())
+    assert [a["page_size"] for a in rep["allocator"]] == [1, 4, 16] and all(a["equal"] and a["calls"] >= 6 for a in rep["allocator"]), rep["allocator"]
+    for key in ("write_cache_indices", "get_last_loc"):
+        assert len(rep[key]) == 3 and all(r["equal"] and r["served_by_the_hook"] and r["triton_launches"] == 0 for r in rep[key]), rep[key]
+    assert len(rep["kv_store"]) == 2 and all(r["equal"] and r["served_by_the_pool_class"] and r["nonzero"] for r in rep["kv_store"]), rep["kv_store"]
