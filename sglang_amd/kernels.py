@@ -752,6 +752,10 @@ def wstream_gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] 
     s = splits or s_auto
     one_pass = ep == 1 and s == 1 and (N % 32 == 0 or (tiles_per_wave == 1 and N % 16 == 0)) and bias is None
     tpw = (tiles_per_wave or (tpw_auto if (waves_per_group is None and splits is None) else 2)) if one_pass else (tiles_per_wave or tpw_auto)
+    # what is launched is decided by the C side from the values PASSED (wstream_gemm.hip `fused_silu`): restated here with the final
+    # tiles-per-wave, so that the workspace below exists exactly when the launch has a combine pass -- a silu GEMM whose N is a
+    # multiple of 16 but not of 32 runs the interleaved one-pass form when the automatic decomposition says one tile per wave
+    one_pass = ep == 1 and s == 1 and bias is None and (N % 16 == 0 if tpw == 1 else N % 32 == 0)
     ws = _gemm_workspace(x.device, native.lib().sgl_amd_wstream_gemm_workspace_floats(M, N, s)) if ((s > 1 or ep) and not one_pass) else None
     native.call("sgl_amd_wstream_gemm", x.data_ptr(), w.data_ptr(), _ptr(bias), out.data_ptr(), M, N, K, x_rs, x_cs,
                 w.stride(0), y_rs, y_cs, ep, _ptr(residual), residual.stride(0) if residual is not None else 0,
