@@ -90,10 +90,16 @@ def _build_platform_class():
 
             return mem_hooks.paged_allocator_class()
 
-        def init_backend(self) -> None:           # interface.py:125-127: once per worker
+        def init_backend(self) -> None:           # interface.py:125-127: once per worker (model_runner.py:240, at module import)
             from . import native
+            from .tuning import load_gemm_selections
 
             native.lib()
+            # the prefill-sized projections stay on the library GEMMs; the committed per-shape hipBLASLt / rocBLAS selections
+            # (lookup only, SGLANG_AMD_TUNABLEOP=0 turns them off) were loaded by this package's own harness alone until round 5
+            # -- under the reference's ModelRunner the prefill GEMMs ran the libraries' default picks (547 vs ~450 us per layer GEMM
+            # group at the bench's prefill shapes, profiles/r05_sched_kernel_stats.txt)
+            load_gemm_selections()
 
     Mi355xSRTPlatform.__qualname__ = "Mi355xSRTPlatform"
     Mi355xSRTPlatform.__module__ = __name__
