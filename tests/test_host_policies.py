@@ -351,3 +351,39 @@ def test_fused_decode_says_once_why_a_decode_forward_is_not_fused(caplog):
         fused_decode._say_once_why_not(model, fb, None)
     assert sum("stays on the operator-by-operator path" in r.message for r in caplog.records) == 1
     fused_decode._SAID.clear()
+
+
+def test_eager_decode_batches_beyond_the_captured_buffers_do_not_raise():
+    """the reference's batches carry int64 seq_lens, so every decode goes through the backend's persistent int32
+    buffer (max(max_bs, 256) entries) and the shared-prefix workspace sized at capture.  A decode batch larger than
+    `--cuda-graph-max-bs` runs EAGERLY (decode_cuda_graph_runner.py:683-687 `cuda_graph_bs <= self.max_bs`): it must get its own
+    conversion / workspace instead of killing the scheduler; only a CAPTURE beyond the buffers is an error."""
+    import types
+
+    from sglang_amd.layers.attention.hip_backend import HipAttnBackend
+
+    be = HipAttnBackend.__new__(HipAttnBackend)
+    be.device = torch.device("cpu")
+    be._seq_i32, be._seq_src, be._seq_i32_in_graph = torch.zeros(256, dtype=torch.int32), None, True        # graphs captured at max_bs <= 256
+    lens = torch.arange(5, 305, dtype=torch.int64)
+    fb = types.SimpleNamespace(seq_lens=lens)
+    got, src = be._seq_lens_i32(fb)                              # 300 running requests, eager
+    assert src is None and got.dtype == torch.int32 and torch.equal(got.long(), lens) and be._seq_i32.numel() == 256
+    with pytest.raises(RuntimeError, match="capturing a batch of 300"):
+        be._seq_lens_i32(fb, in_capture=True)
+    small = types.SimpleNamespace(seq_lens=lens[:64])
+    buf, src = be._seq_lens_i32(small)                           # a replayed bucket: the persistent buffer, filled inside the graph
+    assert src is small.seq_lens and buf.data_ptr() == be._seq_i32.data_ptr() and buf.numel() == 64
+    i32 = types.SimpleNamespace(seq_lens=lens.int())
+    assert be._seq_lens_i32(i32) == (i32.seq_lens, None)         # this package's own harness: int32 already
+    # the shared-prefix workspace: graphs hold the one sized at capture, an eager batch beyond it gets another
+    be.num_q_heads, be.head_dim, be.max_context_len = 8, 64, 256
+    be._cascade_ws, be._cascade_ws_eager, be._cascade_in_graph = None, None, False
+    ws8 = be._cascade_workspace(8, in_capture=True)
+    be._cascade_in_graph = True
+    assert be._cascade_workspace(4) is ws8 and be._cascade_workspace(8) is ws8
+    eager = be._cascade_workspace(300)
+    assert eager is not ws8 and eager.max_batch >= 300 and be._cascade_ws is ws8
+    assert be._cascade_workspace(200) is eager                   # reused while it fits
+    with pytest.raises(RuntimeError, match="capturing a batch of 300"):
+        be._cascade_workspace(300, in_capture=True)

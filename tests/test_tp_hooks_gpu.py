@@ -257,3 +257,36 @@ def test_hooked_group_coordinator_two_processes_one_gpu(device):
             p.join(timeout=30)
             if p.is_alive():
                 p.kill()
+
+
+def test_launches_of_a_shared_communicator_are_serialised_across_streams(device):
+    """groups over the same ranks share one communicator (one data area, one set of flag counters), so two of its
+    launches must never overlap.  The hooks wrap every launch in `_one_stream_at_a_time`: a launch that arrives on another stream
+    than the previous one waits for an event recorded behind that one.  Observed here with a stand-in communicator: stream B's
+    "launch" reads what stream A's "launch" writes behind a long sleep -- it sees the value only if it waited."""
+    import types
+
+    import torch
+
+    from sglang_amd import tp_hooks
+
+    comm = types.SimpleNamespace()
+    x = torch.zeros(1, device=device)
+    a, b = torch.cuda.Stream(device), torch.cuda.Stream(device)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(a):
+        with tp_hooks._one_stream_at_a_time(comm):
+            torch.cuda._sleep(200_000_000)            # ~0.1 s of spinning ahead of the write
+            x.fill_(1.0)
+    with torch.cuda.stream(b):
+        with tp_hooks._one_stream_at_a_time(comm):
+            y = x.clone()
+    torch.cuda.synchronize()
+    assert float(y) == 1.0, "stream B's launch did not wait for stream A's"
+    assert comm._sgl_last_stream == b
+    # same stream again: no wait is needed, the event just moves on
+    with torch.cuda.stream(b):
+        with tp_hooks._one_stream_at_a_time(comm):
+            x.add_(1.0)
+    torch.cuda.synchronize()
+    assert float(x) == 2.0
