@@ -51,6 +51,7 @@ class _Meta:
     max_extend_len: int = 0
     cascade: Optional["kernels.CascadeWorkspace"] = None   # shared-prefix decode plan + split slots
     mask_indptr: Optional[torch.Tensor] = None             # TARGET_VERIFY: offsets of the requests' blocks in the flat mask
+    verify_mask: Optional[torch.Tensor] = None             # TARGET_VERIFY: the persistent copy of this step's flat tree mask
 
 
 def choose_num_splits(batch: int, num_kv_heads: int, group: int, max_len: int, target_blocks: int = 512) -> int:
@@ -131,6 +132,7 @@ class HipAttnBackend(AttentionBackend):
         self._cascade_in_graph = False
         self._seq_i32, self._seq_src, self._seq_i32_in_graph = None, None, False
         self._verify_states, self._verify_nd = {}, 0
+        self._verify_mask, self._verify_mask_in_graph = None, False      # the flat tree mask captured verify graphs read (see _verify_mask_buffer)
         self.debug_flags = 0
         # RadixAttention batches share KV prefixes; the cascade decode path reads a shared prefix once per group
         # (`model_runner.enable_cascade_attention = False` keeps every batch on the plain paged decode kernel)
@@ -179,6 +181,10 @@ class HipAttnBackend(AttentionBackend):
             self._seq_i32 = torch.zeros(max(max_bs, 256), dtype=torch.int32, device=self.device)
         if self.enable_cascade and max_bs >= 2:
             self._cascade_workspace(min(max_bs, 1024))
+        if max_num_tokens > max_bs and self._verify_mask is None:
+            # speculative decoding: the graphs are TARGET_VERIFY forwards of max_num_tokens / max_bs draft tokens per request; their
+            # masks hold draft_tokens x (context + draft_tokens) entries per request (triton_backend.py sizes its buffer the same way)
+            self._verify_mask = torch.zeros(int(max_num_tokens) * self.max_context_len, dtype=torch.uint8, device=self.device)
 
     def get_cuda_graph_seq_len_fill_value(self):
         return 1
@@ -202,6 +208,27 @@ class HipAttnBackend(AttentionBackend):
                 return fb.seq_lens.to(torch.int32), None
             buf = self._seq_i32 = torch.zeros(max(bs, 256), dtype=torch.int32, device=self.device)
         return buf[:bs], fb.seq_lens
+
+    def _verify_mask_buffer(self, mask: torch.Tensor, in_capture: bool):
+        """The flat tree mask of a TARGET_VERIFY forward, in a buffer that PERSISTS.  Every verify step builds a fresh mask tensor
+        (ngram_worker.py:352-369, eagle builds its own): a captured graph would keep reading the tensor of the step it was captured
+        on.  Like the reference's backends (triton_backend.py:559-566 `cuda_graph_custom_mask[: n] = spec_info.custom_mask`) the
+        step's mask is copied -- here, outside the graph, before every replay and every eager forward -- into one buffer sized for
+        the largest verify batch (tokens x context), and the kernels read THAT.  Round 5: found by running NGRAM speculative
+        decoding under the reference's scheduler -- eager verify steps reproduced greedy decoding, replayed ones did not."""
+        m8 = mask.view(torch.uint8) if mask.dtype == torch.bool else mask
+        m8 = m8.reshape(-1)
+        buf = self._verify_mask
+        if buf is None or buf.numel() < m8.numel():
+            if buf is not None and self._verify_mask_in_graph:
+                if in_capture:
+                    raise RuntimeError(f"verify-mask buffer holds {buf.numel()} entries and is referenced by captured graphs; capturing a "
+                                       f"mask of {m8.numel()} needs init_cuda_graph_state(max_num_tokens) to cover it")
+                return m8                                      # an eager verify batch beyond the captured sizes: its own tensor
+            buf = self._verify_mask = torch.zeros(max(m8.numel(), 1), dtype=torch.uint8, device=self.device)
+        buf[: m8.numel()].copy_(m8, non_blocking=True)
+        self._verify_mask_in_graph |= in_capture
+        return buf
 
     def _verify_state(self, bs: int, nd: int):
         st = self._verify_states.get((bs, nd))
@@ -243,6 +270,8 @@ class HipAttnBackend(AttentionBackend):
             self._seq_src = fb.seq_lens
             self.forward_metadata = _Meta(st["kv"], qo_indptr=st["qo"], prefix_lens_i32=st["pre"], max_extend_len=nd, mask_indptr=st["mip"])
             self._verify_nd = nd
+            cm = getattr(fb.spec_info, "custom_mask", None)
+            self.forward_metadata.verify_mask = self._verify_mask_buffer(cm, in_capture) if isinstance(cm, torch.Tensor) else None
         elif fb.forward_mode.is_extend():
             ext = fb.extend_seq_lens_cpu
             qo = torch.zeros(fb.batch_size + 1, dtype=torch.int32)
@@ -307,7 +336,9 @@ class HipAttnBackend(AttentionBackend):
         # speculative-decoding verify / tree attention (triton_backend.py:860-919): spec_info carries the flat mask
         spec = getattr(forward_batch, "spec_info", None)
         if spec is not None and getattr(spec, "custom_mask", None) is not None:
-            opt["custom_mask"] = spec.custom_mask
+            # (a verify forward reads the persistent copy init_forward_metadata_out_graph made: the tensor on spec_info is this
+            # step's own and would be baked into a captured graph)
+            opt["custom_mask"] = m.verify_mask if getattr(m, "verify_mask", None) is not None else spec.custom_mask
             opt["mask_indptr"] = m.mask_indptr if m.mask_indptr is not None else self._mask_indptr(forward_batch, m)
             # the reference's verify call leaves skip_prefix_custom_mask at its default: the prefix is fully visible,
             # the mask decides among the draft tokens only (extend_attention.py:774)

@@ -169,6 +169,20 @@ def mha_kv_pool_class():
     class Mi355xMHATokenToKVPool(base):
         """memory_pool.py:1759-2456; `set_kv_buffer` (:2331-2401) + `_store_kv_layer` (:2403-2456) for bf16 / e4m3 rows."""
 
+        def __init__(self, *args, **kwargs):
+            # The reference builds an out-of-tree platform's pool with the short argument list of `_build_oot_mha_kv_pool`
+            # (kv_cache_configurator.py:1183-1199): no `enable_kv_cache_copy`, which its own pool gets as "a speculative algorithm is
+            # configured" (:1660) -- without it `move_kv_cache` (the accepted-draft compaction of every verify step,
+            # spec_utils.py:754) asserts.  Found by running NGRAM speculative decoding under the reference's scheduler (round 5).
+            if "enable_kv_cache_copy" not in kwargs and len(args) < 17:
+                try:
+                    from sglang.srt.runtime_context import get_spec
+
+                    kwargs["enable_kv_cache_copy"] = get_spec().speculative_algorithm is not None
+                except Exception:                      # noqa: BLE001 -- no runtime context (unit tests): the class default
+                    pass
+            super().__init__(*args, **kwargs)
+
         def _hip_store_ok(self, cache_k, cache_v, dcp_kv_mask) -> bool:
             return (dcp_kv_mask is None and not self.is_quantized_kv_cache and self.dtype in (torch.bfloat16, torch.float8_e4m3fn)
                     and getattr(self, "kv_cache_layout", "nhd") in ("nhd", "hnd") and self.v_row_dim == self.row_dim

@@ -1178,7 +1178,7 @@ def run_shared_prefix_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=1
 
 
 def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, unique=8, out=4, overlap=False, server_args=None,
-                      logprobs=False) -> dict:
+                      logprobs=False, spec_ngram=0) -> dict:
     """The reference's `Scheduler` ITSELF (managers/scheduler.py: request intake, `PrefillAdder`, the real radix cache built by
     `kv_cache_builder`, running-batch merge, `TpModelWorker` -> `ModelRunner`, result processing, output streaming) with the body of
     its `event_loop_normal` (scheduler.py:1748-1780) executed here step by step instead of behind zmq sockets (zmq is not in this
@@ -1204,6 +1204,12 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
     arch = ARCH.get(dims_name, "llama")
     d = write_checkpoint_config(dims_name, max_pos=8192)
     common = importlib.import_module("sglang.srt.utils.common")
+    if spec_ngram:
+        # `--speculative-algorithm NGRAM --speculative-num-draft-tokens N`: decode batches become ForwardMode.TARGET_VERIFY forwards of
+        # N draft tokens per request under a tree mask (ngram_worker.py:310-397), captured by the reference's graph runner in that mode
+        assert real_weights, "the scripted drafter needs the oracle's greedy continuation: small real-weight models only"
+        _install_spec_standins(ns)
+        server_args = dict(server_args or {}, speculative_algorithm="NGRAM", speculative_num_draft_tokens=int(spec_ngram))
     if not gpu:
         from sglang.kernels import fused_op as FO
         from sglang.kernels.spec import KernelBackend
@@ -1301,10 +1307,14 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
             capture["pending"] = [(r.rid, int(sl) - len(r.origin_input_ids)) for r, sl in zip(batch.reqs, batch.seq_lens_cpu.tolist())]
         return run_batch(batch, *a, **k)
 
+    modes_seen = {}
     if real_weights and hasattr(runner, "forward"):
         runner_forward = runner.forward
 
         def capturing_forward(*a, **k):
+            fb_ = a[0] if a else k.get("forward_batch")
+            nm = getattr(getattr(fb_, "forward_mode", None), "name", "?")
+            modes_seen[nm] = modes_seen.get(nm, 0) + 1
             res = runner_forward(*a, **k)
             pend, capture["pending"] = capture["pending"], None
             lo = getattr(res, "logits_output", None)
@@ -1345,6 +1355,18 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
                    for gi in range(groups) for j in range(per_group)}
         leaders = [f"{tag}-g{gi}r0" for gi in range(groups)]
         others = [r for r in prompts if r not in leaders]
+        if spec_ngram:
+            # the scripted drafter proposes the ORACLE'S greedy continuation of each sequence (with one wrong token per draft)
+            from oracle.model import OracleLM as _OLM
+
+            rl = list(prompts)
+            o_ = _OLM(oracle_config(dims_name, 8192), oracle_weights(runner.model), num_slots=4 * tokens, max_ctx=prefix + unique + out + 8,
+                      max_reqs=B, device=runner.device)
+            gr = [[rl.index(f"{tag}-g{gi}r{j}") for j in range(per_group)] for gi in range(groups)]
+            cont = o_.generate([prompts[r] for r in rl], out + int(spec_ngram), share_prefix_groups=gr, shared_len=prefix)
+            SPEC_TRUTH[:] = [list(prompts[r]) + [int(t) for t in c] for r, c in zip(rl, cont)]
+            for k_ in SPEC_STATS:
+                SPEC_STATS[k_] = 0
         if gpu:
             torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -1385,7 +1407,8 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
         before = dict(counts)
         del triton_launches[:]
         prof_path = os.environ.get("REF_SCHED_CPROFILE")
-        capture["on"] = real_weights
+        capture["on"] = real_weights and not spec_ngram           # (a verify forward scores N rows per request: filed differently, not compared here)
+        modes_seen.clear()
         if prof_path:
             timed = _profiled(lambda: job("timed"), prof_path)
         else:
@@ -1403,7 +1426,9 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
                retracted_requests=counts["retracted_requests"], max_total_num_tokens=int(runner.max_total_num_tokens),
                triton_launches_in_the_timed_job=len(triton_launches), triton_kernels_in_the_timed_job=triton_in_timed,
                kv_pool_class=type(getattr(runner, "token_to_kv_pool", None)).__name__, allocator_class=type(getattr(runner, "token_to_kv_pool_allocator", None)).__name__,
-               plugin_counts=_plugin_counts() if gpu else None)
+               plugin_counts=_plugin_counts() if gpu else None,
+               spec=dict(draft_tokens=int(spec_ngram), drafter=dict(SPEC_STATS), forward_modes_in_the_timed_job=dict(modes_seen),
+                         worker=type(getattr(sch, "model_worker", None)).__name__) if spec_ngram else None)
     for tag, j in (("warm_up", warm), ("timed", timed)):
         hit = sorted(set(v for r, v in j["cached_tokens"].items() if r not in j["leaders"]))
         modes = {}
@@ -1423,6 +1448,8 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
         grp = [[rids.index(f"timed-g{gi}r{j}") for j in range(per_group)] for gi in range(groups)]
         want = olm.generate([timed["prompts"][r] for r in rids], out, share_prefix_groups=grp, shared_len=prefix)
         same = sum(int(list(w) == timed["generated"].get(r)) for r, w in zip(rids, want))
+        if spec_ngram:
+            rep["spec"]["generated_vs_oracle"] = [dict(generated=timed["generated"].get(r), oracle=[int(t) for t in w]) for r, w in zip(rids, want)]
         rep["oracle"] = dict(requests=len(rids), requests_with_identical_tokens=same,
                              token_agreement=sum(int(a == b) for r, w in zip(rids, want) for a, b in zip(w, timed["generated"].get(r, []))) / (len(rids) * out))
         # ---- logits of every forward of the timed job against the oracle, teacher-forced with the tokens the run produced: the
@@ -1476,6 +1503,136 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
                     n += 1
             rep["oracle"].update(logprob_values=n, max_abs_logprob_diff=worst, top2_sets_equal=top_ok)
     return rep
+
+
+SPEC_TRUTH = []          # scripted drafter: whole token sequences (prompt + the oracle's greedy continuation) of the running job
+SPEC_STATS = dict(lookups=0, matched=0, drafted_true_tokens=0)
+
+
+def _install_spec_standins(ns) -> None:
+    """TARGET_VERIFY under the reference's real scheduler (`--speculative-algorithm NGRAM`, speculative/ngram_worker.py): the
+    worker's draft source and two device helpers are compiled third-party code that is not in this image -- they get TEST stand-ins,
+    everything else (NGRAMWorker, NgramVerifyInput, eagle_sample, the KV mover, the scheduler's spec bookkeeping, the graph runner
+    capturing ForwardMode.TARGET_VERIFY) is the reference's own:
+      * the n-gram corpus (`kernels/ops/speculative/ngram_corpus.py`: a JIT-compiled C++ trie behind tvm_ffi) -> a SCRIPTED drafter:
+        per request a chain [last verified token, t1, t2, ...] whose continuation is the oracle's greedy continuation of that very
+        sequence with a deliberately wrong token at a position that varies with the length -- so every verify step accepts some
+        drafts and rejects others; mask = the chain's ancestor matrix, in the corpus' own output format (:94-110);
+      * `sgl_kernel.speculative.reconstruct_indices_from_tree_mask` (kernels/aot/csrc/speculative/ngram_utils.cu:16-82) -> the same
+        per-node loops on the host;
+      * `sgl_kernel.verify_tree_greedy` -> on the GPU the reference's OWN Triton form (`eagle_utils.verify_tree_greedy_triton`,
+        its XPU branch, :345-375); in the CPU dry run the greedy tree walk restated on the host."""
+    import numpy as np
+
+    class ScriptedNgramCorpus:
+        def __init__(self, capacity=0, max_trie_depth=18, min_bfs_breadth=1, max_bfs_breadth=8, draft_token_num=8, match_type="BFS",
+                     external_sam_budget=0, external_corpus_max_tokens=0):
+            self.n = int(draft_token_num)
+
+        def insert(self, batch_tokens):
+            pass
+
+        def synchronize(self):
+            pass
+
+        def reset(self):
+            pass
+
+        def erase_states(self, state_ids):
+            pass
+
+        def match_stateful(self, state_ids, batch_tokens, total_lens):
+            n = self.n
+            ids = np.zeros(len(batch_tokens) * n, dtype=np.int64)
+            mask = np.zeros((len(batch_tokens), n, n), dtype=np.int64)
+            for b, (tail, total) in enumerate(zip(batch_tokens, total_lens)):
+                tail, total = list(tail), int(total)
+                draft = [tail[-1]] + [7 + (total + 3 * i) % 5 for i in range(1, n)]            # no match: junk (all rejected)
+                SPEC_STATS["lookups"] += 1
+                for seq in SPEC_TRUTH:
+                    if len(seq) >= total and seq[total - len(tail): total] == tail:
+                        cont = seq[total: total + n - 1]
+                        wrong = 1 + total % n                                                  # 1..n: index n = nothing corrupted
+                        for i, t in enumerate(cont, start=1):
+                            draft[i] = t if i != wrong else (t + 1) % 1000 + 3
+                        SPEC_STATS["matched"] += 1
+                        SPEC_STATS["drafted_true_tokens"] += min(len(cont), wrong - 1)
+                        break
+                ids[b * n: (b + 1) * n] = draft
+                mask[b] = np.tril(np.ones((n, n), dtype=np.int64))                             # a chain: node i's ancestors are 0..i
+            return ids, mask.reshape(-1)
+
+    for modname in ("sglang.kernels.ops.speculative.ngram_corpus", "sglang.srt.speculative.cpp_ngram.ngram_corpus"):
+        mod = importlib.import_module(modname)
+        mod.get_ngram_corpus_cls = lambda: ScriptedNgramCorpus
+
+    def reconstruct_indices_from_tree_mask(tree_mask, verified_seq_len, positions, retrive_index, retrive_next_token, retrive_next_sibling,
+                                           batch_size, draft_token_num):
+        n = int(draft_token_num)
+        tm = tree_mask.reshape(batch_size, n, n).bool().cpu().numpy()
+        seq = verified_seq_len.cpu().tolist()
+        pos = np.zeros(batch_size * n, dtype=np.int64)
+        ri = np.zeros((batch_size, n), dtype=np.int64)
+        nt = np.full((batch_size, n), -1, dtype=np.int64)
+        nsib = np.full((batch_size, n), -1, dtype=np.int64)
+        for b in range(batch_size):
+            for t in range(n):
+                depth, parent = 0, -1
+                for i in range(t - 1, -1, -1):
+                    if tm[b, t, i]:
+                        depth += 1
+                        if parent == -1:
+                            parent = i
+                ri[b, t] = b * n + t
+                pos[b * n + t] = depth + seq[b]
+                for i in range(t + 1, n):
+                    if tm[b, i, t]:
+                        nt[b, t] = i
+                        break
+                if parent != -1:
+                    for i in range(t + 1, n):
+                        if tm[b, i, parent] and not tm[b, i, parent + 1: i].any():
+                            nsib[b, t] = i
+                            break
+        positions.copy_(torch.from_numpy(pos).to(positions.dtype))
+        retrive_index.copy_(torch.from_numpy(ri).to(retrive_index.dtype))
+        retrive_next_token.copy_(torch.from_numpy(nt).to(retrive_next_token.dtype))
+        retrive_next_sibling.copy_(torch.from_numpy(nsib).to(retrive_next_sibling.dtype))
+
+    NW = importlib.import_module("sglang.srt.speculative.ngram_worker")
+    NW.reconstruct_indices_from_tree_mask = reconstruct_indices_from_tree_mask
+    EU = importlib.import_module("sglang.srt.speculative.eagle_utils")
+
+    def verify_tree_greedy_func(predicts, accept_index, accept_token_num, candidates, retrieve_index, retrieve_next_token,
+                                retrieve_next_sibling, target_predict, topk=-1):
+        if predicts.is_cuda:
+            EU.verify_tree_greedy_triton(predicts=predicts, accept_index=accept_index, accept_token_num=accept_token_num, candidates=candidates,
+                                         retrieve_index=retrieve_index, retrieve_next_token=retrieve_next_token,
+                                         retrieve_next_sibling=retrieve_next_sibling, target_predict=target_predict)
+            return predicts, accept_index, accept_token_num
+        bs, n = candidates.shape
+        tp = target_predict.reshape(-1)
+        for b in range(bs):
+            last = int(retrieve_index[b, 0])
+            accept_index[b, 0] = last
+            acc, cur = 0, 0
+            for _ in range(1, accept_index.shape[1]):
+                cur = int(retrieve_next_token[b, cur])
+                while cur != -1:
+                    if int(candidates[b, cur]) == int(tp[last]):
+                        predicts[last] = int(tp[last])
+                        acc += 1
+                        last = int(retrieve_index[b, cur])
+                        accept_index[b, acc] = last
+                        break
+                    cur = int(retrieve_next_sibling[b, cur])
+                if cur == -1:
+                    break
+            accept_token_num[b] = acc
+            predicts[last] = int(tp[last])
+        return predicts, accept_index, accept_token_num
+
+    EU.verify_tree_greedy_func = verify_tree_greedy_func
 
 
 def _plugin_counts() -> dict:
@@ -1801,6 +1958,7 @@ if __name__ == "__main__":
     ap.add_argument("--job", default="2,2,16,8,4", help="shared-prefix run: groups, requests per group, shared tokens, own tokens, output tokens")
     ap.add_argument("--server-args", default=None, help='scheduler run: extra ServerArgs as JSON, e.g. {"page_size": 16, "chunked_prefill_size": 64}')
     ap.add_argument("--logprobs", action="store_true", help="scheduler run: return_logprob + top-2 logprobs on every request")
+    ap.add_argument("--spec-ngram", type=int, default=0, help="scheduler run: NGRAM speculative decoding with N draft tokens (scripted drafter): TARGET_VERIFY forwards")
     ap.add_argument("--overlap", action="store_true", help="scheduler run: the body of event_loop_overlap (the server default)")
     ap.add_argument("--radix", action="store_true", help="shared-prefix run: prefixes from the reference's real RadixCache")
     ap.add_argument("--tp", type=int, default=1, help="tensor-parallel ranks: this process launches itself N times (rank 0 reports)")
@@ -1837,7 +1995,7 @@ if __name__ == "__main__":
     rep = {"cpu-oracle": lambda: run_cpu_oracle(a.dims), "loader": run_loader, "gpu": lambda: run_gpu(a.dims), "mem-hooks": run_mem_hooks,
            "runner": lambda: run_runner(a.dims, _json_arg(a.server_args)), "latency": lambda: run_latency(a.dims, *[int(x) for x in a.shape.split(",")]),
            "scheduler": lambda: run_scheduler_job(a.dims if a.dims != "tiny" else "tiny_v16k", *[int(x) for x in a.job.split(",")],
-                                                  overlap=a.overlap, server_args=_json_arg(a.server_args), logprobs=a.logprobs),
+                                                  overlap=a.overlap, server_args=_json_arg(a.server_args), logprobs=a.logprobs, spec_ngram=a.spec_ngram),
            "shared-prefix": lambda: run_shared_prefix_job(a.dims if a.dims != "tiny" else "tiny_v16k", *[int(x) for x in a.job.split(",")],
                                                           radix=a.radix)}[a.run]()
     rep["tp"] = tp_world()[0]
