@@ -44,7 +44,9 @@ def write_cache_indices_hook(original, out_cache_loc, req_pool_indices_tensor, r
     ok = (isinstance(table, torch.Tensor) and table.is_cuda and table.dtype == torch.int32 and table.dim() == 2 and table.stride(1) == 1
           and _i64_cuda(out_cache_loc, req_pool_indices_tensor, prefix_lens_tensor, seq_lens_tensor, extend_lens_tensor)
           and req_pool_indices_tensor.numel() == len(prefix_tensors) > 0
-          and all(isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.int64 and (t.numel() == 0 or t.is_contiguous())
+          # (a request without a cached prefix carries an EMPTY tensor -- on the host under `--disable-radix-cache` (ChunkCache):
+          # never dereferenced, its address is passed as 0)
+          and all(isinstance(t, torch.Tensor) and (t.numel() == 0 or (t.is_cuda and t.dtype == torch.int64 and t.is_contiguous()))
                   for t in prefix_tensors)
           and not torch.compiler.is_compiling())
     if not ok:
@@ -53,7 +55,7 @@ def write_cache_indices_hook(original, out_cache_loc, req_pool_indices_tensor, r
     from . import kernels
 
     # the prefix tensors' addresses travel as one int64 vector (the reference sends the same list as uint64, :71-75)
-    ptrs = torch.tensor([t.data_ptr() for t in prefix_tensors], dtype=torch.int64,
+    ptrs = torch.tensor([t.data_ptr() if t.numel() else 0 for t in prefix_tensors], dtype=torch.int64,
                         pin_memory=True).to(table.device, non_blocking=True)
     kernels.write_req_to_token(table, req_pool_indices_tensor, ptrs, prefix_lens_tensor, seq_lens_tensor, extend_lens_tensor, out_cache_loc)
     counts["write_cache_indices"] += 1

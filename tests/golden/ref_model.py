@@ -1442,8 +1442,9 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
         # the oracle's greedy generation of the timed job's prompts, prefixes shared the same way
         from oracle.model import OracleLM
 
+        kvd = "fp8_e4m3" if str(getattr(sa, "kv_cache_dtype", "auto")) == "fp8_e4m3" else "auto"       # (the oracle's pool stores e4m3 rows too)
         olm = OracleLM(oracle_config(dims_name, 8192), oracle_weights(runner.model),
-                       num_slots=4 * tokens, max_ctx=prefix + unique + out + 8, max_reqs=B, device=runner.device)
+                       num_slots=4 * tokens, max_ctx=prefix + unique + out + 8, max_reqs=B, device=runner.device, kv_cache_dtype=kvd)
         rids = list(timed["prompts"])
         grp = [[rids.index(f"timed-g{gi}r{j}") for j in range(per_group)] for gi in range(groups)]
         want = olm.generate([timed["prompts"][r] for r in rids], out, share_prefix_groups=grp, shared_len=prefix)
@@ -1460,7 +1461,7 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
             if all(len(f) == out for f in forced):
                 def teacher(**kw):
                     o_ = OracleLM(oracle_config(dims_name, 8192), oracle_weights(runner.model), num_slots=4 * tokens,
-                                  max_ctx=prefix + unique + out + 8, max_reqs=B, device=runner.device, **kw)
+                                  max_ctx=prefix + unique + out + 8, max_reqs=B, device=runner.device, kv_cache_dtype=kvd, **kw)
                     return o_.generate([timed["prompts"][r] for r in rids], out, return_logits=True, forced=forced,
                                        share_prefix_groups=grp, shared_len=prefix)[1]
                 lit = teacher()
