@@ -1178,7 +1178,7 @@ def run_shared_prefix_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=1
 
 
 def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, unique=8, out=4, overlap=False, server_args=None,
-                      logprobs=False, spec_ngram=0) -> dict:
+                      logprobs=False, spec_ngram=0, sampling=None) -> dict:
     """The reference's `Scheduler` ITSELF (managers/scheduler.py: request intake, `PrefillAdder`, the real radix cache built by
     `kv_cache_builder`, running-batch merge, `TpModelWorker` -> `ModelRunner`, result processing, output streaming) with the body of
     its `event_loop_normal` (scheduler.py:1748-1780) executed here step by step instead of behind zmq sockets (zmq is not in this
@@ -1280,7 +1280,9 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
     g = torch.Generator().manual_seed(5)
 
     def request(rid, ids):
-        sp = SP(temperature=0, max_new_tokens=out, ignore_eos=True)
+        # `sampling` (e.g. {"temperature": 0.8, "top_k": 20, "top_p": 0.9}): every request samples -- the plug-in sampler's top-k / top-p
+        # path under the scheduler's SamplingBatchInfo; greedy otherwise
+        sp = SP(max_new_tokens=out, ignore_eos=True, **(sampling or dict(temperature=0)))
         sp.normalize(None)
         return io.TokenizedGenerateReqInput(rid=rid, input_text=None, input_ids=array("q", ids), input_embeds=None, mm_inputs=None,
                                             token_type_ids=None, sampling_params=sp, return_logprob=logprobs, logprob_start_len=-1,
@@ -1488,6 +1490,20 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
                                 product_max_err=float(e_p.abs().max()), reference_max_err=float(e_r.abs().max()),
                                 clear_rows=int(clear.sum()), argmax_agree_on_clear_rows=int((G_.argmax(-1) == A_.argmax(-1))[clear].sum()))
                 rep["logit_band"] = band
+        if sampling and capture["rows"]:
+            # sampled tokens are not the oracle's greedy tokens; what must hold: every token the scheduler delivered lies inside the
+            # top-k set of the very logits row it was sampled from (captured from the forward that produced it)
+            k_ = int(sampling.get("top_k", 0)) or V
+            inside = total = 0
+            for r in rids:
+                for t, tok in enumerate(timed["generated"].get(r, [])):
+                    row = capture["rows"].get((r, t))
+                    if row is None:
+                        continue
+                    total += 1
+                    inside += int(int(tok) in set(row.topk(min(k_, V)).indices.tolist()))
+            rep["sampling"] = dict(params=sampling, tokens_checked=total, tokens_inside_their_rows_top_k=inside,
+                                   distinct_first_tokens=len(set(tuple(v[:2]) for v in timed["generated"].values())))
         if logprobs:
             # the log-probabilities the scheduler streamed with the tokens (sampler -> output_logprob_processor -> output streamer) against
             # log_softmax of the oracle's logits, the oracle teacher-forced with the tokens the run produced
@@ -1959,6 +1975,7 @@ if __name__ == "__main__":
     ap.add_argument("--job", default="2,2,16,8,4", help="shared-prefix run: groups, requests per group, shared tokens, own tokens, output tokens")
     ap.add_argument("--server-args", default=None, help='scheduler run: extra ServerArgs as JSON, e.g. {"page_size": 16, "chunked_prefill_size": 64}')
     ap.add_argument("--logprobs", action="store_true", help="scheduler run: return_logprob + top-2 logprobs on every request")
+    ap.add_argument("--sampling", default=None, help='scheduler run: SamplingParams of every request as JSON, e.g. {"temperature": 0.8, "top_k": 20, "top_p": 0.9}')
     ap.add_argument("--spec-ngram", type=int, default=0, help="scheduler run: NGRAM speculative decoding with N draft tokens (scripted drafter): TARGET_VERIFY forwards")
     ap.add_argument("--overlap", action="store_true", help="scheduler run: the body of event_loop_overlap (the server default)")
     ap.add_argument("--radix", action="store_true", help="shared-prefix run: prefixes from the reference's real RadixCache")
@@ -1996,7 +2013,7 @@ if __name__ == "__main__":
     rep = {"cpu-oracle": lambda: run_cpu_oracle(a.dims), "loader": run_loader, "gpu": lambda: run_gpu(a.dims), "mem-hooks": run_mem_hooks,
            "runner": lambda: run_runner(a.dims, _json_arg(a.server_args)), "latency": lambda: run_latency(a.dims, *[int(x) for x in a.shape.split(",")]),
            "scheduler": lambda: run_scheduler_job(a.dims if a.dims != "tiny" else "tiny_v16k", *[int(x) for x in a.job.split(",")],
-                                                  overlap=a.overlap, server_args=_json_arg(a.server_args), logprobs=a.logprobs, spec_ngram=a.spec_ngram),
+                                                  overlap=a.overlap, server_args=_json_arg(a.server_args), logprobs=a.logprobs, spec_ngram=a.spec_ngram, sampling=_json_arg(a.sampling)),
            "shared-prefix": lambda: run_shared_prefix_job(a.dims if a.dims != "tiny" else "tiny_v16k", *[int(x) for x in a.job.split(",")],
                                                           radix=a.radix)}[a.run]()
     rep["tp"] = tp_world()[0]
