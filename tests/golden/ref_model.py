@@ -1431,6 +1431,15 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
                plugin_counts=_plugin_counts() if gpu else None,
                spec=dict(draft_tokens=int(spec_ngram), drafter=dict(SPEC_STATS), forward_modes_in_the_timed_job=dict(modes_seen),
                          worker=type(getattr(sch, "model_worker", None)).__name__) if spec_ngram else None)
+    if gpu:
+        # the shared-prefix decode plan of the LAST decode step (device buffer of the backend's workspace): groups found, items
+        try:
+            ws_ = getattr(runner.attn_backend, "_cascade_ws", None)
+            if ws_ is not None:
+                hdr = ws_.plan[:4].cpu().tolist()
+                rep["last_decode_plan"] = dict(items=int(hdr[0]), groups=int(hdr[1]), member_rows=int(hdr[2]), shared_items=int(hdr[3]))
+        except Exception as e:                              # noqa: BLE001
+            rep["last_decode_plan"] = dict(error=f"{type(e).__name__}: {e}")
     for tag, j in (("warm_up", warm), ("timed", timed)):
         hit = sorted(set(v for r, v in j["cached_tokens"].items() if r not in j["leaders"]))
         modes = {}

@@ -370,6 +370,8 @@ def test_plugin_under_the_references_scheduler_more_configurations(device, confi
         return
     if config.startswith("long-shared"):
         assert rep["timed"]["cached_tokens_of_others"] == [160]
+        # the backend's plan found the two groups in the reference's request table: their 128-token shared chunk is read once per group
+        assert rep["last_decode_plan"]["groups"] == 2 and rep["last_decode_plan"]["shared_items"] >= 2, rep["last_decode_plan"]
         # (48 free-running greedy tokens of a random-weight model: after a near-tie flips the rest of that request differs -- the
         # teacher-forced logit band above is the bar; most tokens still agree)
         assert rep["oracle"]["token_agreement"] >= 0.5, rep["oracle"]
