@@ -17,6 +17,7 @@ torch_native_backend.py:19-398).  Differences that matter on MI355X:
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -109,6 +110,19 @@ def pool_kernel_format(pool, layer=None) -> dict:
     return dict(kv_fp8=fp8, k_scale=ks, v_scale=vs, page_size=page, hnd=bool(getattr(pool, "use_hnd", False)) and page > 1)
 
 
+def cascade_wanted(model_runner) -> bool:
+    """Shared-prefix (cascade) decode plan or the plain paged decode kernel, decided once per server (the choice is baked into the
+    captured decode graphs): an explicit `model_runner.enable_cascade_attention`, else `SGLANG_AMD_CASCADE=0 / 1`, else ON -- also for
+    a server without a radix cache: on batches with nothing shared the plan's private items cost what the plain kernel costs
+    (the reference's bench_one_batch, Llama-3-8B, `profiles/r05_exp2_cascade_policy_unshared.json`: 64 x 1024 6.09 against 5.94 ms
+    per step, 16 x 4096 5.41 against 5.72 ms), so there is no rule worth keying on `disable_radix_cache`."""
+    wanted = getattr(model_runner, "enable_cascade_attention", None)
+    if wanted is None:
+        env = os.environ.get("SGLANG_AMD_CASCADE", "")
+        return env != "0"
+    return bool(wanted)
+
+
 class HipAttnBackend(AttentionBackend):
     needs_cpu_seq_lens = True
     # qo_indptr / lens are sized per forward, never preallocated at (req pool + 1) (base_attn_backend.py:117-122)
@@ -134,9 +148,8 @@ class HipAttnBackend(AttentionBackend):
         self._verify_states, self._verify_nd = {}, 0
         self._verify_mask, self._verify_mask_in_graph = None, False      # the flat tree mask captured verify graphs read (see _verify_mask_buffer)
         self.debug_flags = 0
-        # RadixAttention batches share KV prefixes; the cascade decode path reads a shared prefix once per group
-        # (`model_runner.enable_cascade_attention = False` keeps every batch on the plain paged decode kernel)
-        self.enable_cascade = bool(getattr(model_runner, "enable_cascade_attention", True)) and self.head_dim in (64, 128)
+        # RadixAttention batches share KV prefixes; the cascade decode path reads a shared prefix once per group (see cascade_wanted)
+        self.enable_cascade = cascade_wanted(model_runner) and self.head_dim in (64, 128)
         # the shared-prefix kernel reads every pool format (bf16 / fp8 rows, token-major / paged head-major); layers
         # with a sliding window or a logit cap take the plain paged kernel (forward_decode)
         fmt = pool_kernel_format(self.token_to_kv_pool, None)

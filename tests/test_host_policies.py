@@ -387,3 +387,22 @@ def test_eager_decode_batches_beyond_the_captured_buffers_do_not_raise():
     assert be._cascade_workspace(200) is eager                   # reused while it fits
     with pytest.raises(RuntimeError, match="capturing a batch of 300"):
         be._cascade_workspace(300, in_capture=True)
+
+
+def test_cascade_policy_switches(monkeypatch):
+    """The shared-prefix decode plan is chosen per server (it is baked into the captured decode graphs): on by default -- also
+    without a radix cache, where it measured level with the plain kernel -- and overridable by the environment and by the runner's
+    own attribute."""
+    from types import SimpleNamespace as NS
+
+    from sglang_amd.layers.attention.hip_backend import cascade_wanted
+
+    monkeypatch.delenv("SGLANG_AMD_CASCADE", raising=False)
+    assert cascade_wanted(NS()) is True                                                   # harness runner: no server_args
+    assert cascade_wanted(NS(server_args=NS(disable_radix_cache=True))) is True
+    assert cascade_wanted(NS(enable_cascade_attention=False)) is False
+    monkeypatch.setenv("SGLANG_AMD_CASCADE", "0")
+    assert cascade_wanted(NS(server_args=NS(disable_radix_cache=False))) is False
+    assert cascade_wanted(NS(enable_cascade_attention=True)) is True                      # the attribute wins
+    monkeypatch.setenv("SGLANG_AMD_CASCADE", "1")
+    assert cascade_wanted(NS()) is True
