@@ -65,4 +65,4 @@ res.update({"image_text_prefill_ms": t_cold * 1e3, "tokens_per_request": len(fir
             "same_image_second_question_ms": t_warm * 1e3, "radix_hit_tokens_per_request": again[0].cached_tokens})
 print(json.dumps(res))
 Path("gpurun_out").mkdir(exist_ok=True)
-Path("gpurun_out/r03_llava_prefill.json").write_text(json.dumps(res, indent=1))
+Path("gpurun_out/llava_prefill.json").write_text(json.dumps(res, indent=1))
