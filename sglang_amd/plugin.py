@@ -149,9 +149,45 @@ def _sampler_factory():
 
     from .layers.sampler import Sampler as HipSampler
 
-    cls = type("HipSampler", (RefSampler,), {"forward": HipSampler.forward,
-                                               "_write_logprobs": HipSampler._write_logprobs})
+    def forward(self, logits_output, sampling_info, return_logprob=False, top_logprobs_nums=None, token_ids_logprobs=None, positions=None):
+        why = sampler_declines(self, sampling_info, return_logprob)
+        if why is not None:
+            sampler_served["reference"] += 1
+            return RefSampler.forward(self, logits_output, sampling_info, return_logprob, top_logprobs_nums, token_ids_logprobs, positions)
+        sampler_served["hip"] += 1
+        return HipSampler.forward(self, logits_output, sampling_info, return_logprob, top_logprobs_nums, token_ids_logprobs, positions)
+
+    cls = type("HipSampler", (RefSampler,), {"forward": forward, "_write_logprobs": HipSampler._write_logprobs})
     return cls()
+
+
+sampler_served = dict(hip=0, reference=0)
+
+
+def sampler_declines(sampler, sampling_info, return_logprob):
+    """Why a `Sampler.forward` call is NOT one the gfx950 forward answers (a short reason), or None.  The gfx950 forward covers
+    the reference's standard path (sampler.py:133-146 greedy, :190-235 div / softmax / sample from probabilities, :237-247 the
+    log-probability outputs); what the reference computes differently on request stays ITS forward, on the same instance:
+    per-request sampling masks (:128,138,217), the RL on-policy target's log-softmax sampling (:159-189), log-probabilities that
+    must come from F.log_softmax under deterministic inference (:196-207) or from the unscaled logits
+    (SGLANG_RETURN_ORIGINAL_LOGPROB, :155-156,238-239)."""
+    if any(getattr(sampling_info, "return_sampling_masks", None) or []):
+        return "return_sampling_masks"
+    if getattr(sampler, "rl_on_policy_target", None) is not None or getattr(sampler, "use_log_softmax_logprob", False):
+        return "rl_on_policy_target"
+    if getattr(sampler, "use_ascend_backend", False):
+        return "ascend"
+    if return_logprob:
+        if getattr(sampler, "enable_deterministic", False):
+            return "deterministic log-probabilities"
+        try:
+            import sglang.srt.layers.sampler as ref
+
+            if getattr(ref, "SGLANG_RETURN_ORIGINAL_LOGPROB", False):
+                return "SGLANG_RETURN_ORIGINAL_LOGPROB"
+        except Exception:
+            pass
+    return None
 
 
 def outside_hip_moe(dispatch_output, quant_info, runner_config):

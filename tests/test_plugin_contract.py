@@ -238,8 +238,9 @@ def fake_sglang(monkeypatch):
         def _sync_token_ids_across_tp(self, batch_next_token_ids, sampling_info):
             self.synced += 1
 
-        def forward(self, *a, **k):
-            raise AssertionError("the reference forward must have been replaced")
+        def forward(self, *a, **k):            # reached only for the calls the gfx950 forward declines (plugin.sampler_declines)
+            self.reference_forwards = getattr(self, "reference_forwards", 0) + 1
+            return "the reference's forward"
 
     smp.Sampler = RefSampler
     smp.register_sampler_backend = lambda backend, factory: smp._SAMPLER_FACTORIES.__setitem__(backend, factory)   # sampler.py:531-542
@@ -450,6 +451,25 @@ def test_plugin_load_runs_against_the_reference_contract(fake_sglang):
     assert isinstance(s, smp.Sampler) and type(s).forward is not smp.Sampler.forward
     assert type(s)._sync_token_ids_across_tp is smp.Sampler._sync_token_ids_across_tp
     assert s.forward(types.SimpleNamespace(next_token_logits=torch.zeros((0, 8))), None, False, None, None, None).numel() == 0
+    # what the reference computes differently on request stays its own forward, on the same instance (sampler.py:128,159-207,238)
+    from sglang_amd import plugin as _plugin
+
+    lo = types.SimpleNamespace(next_token_logits=torch.zeros((0, 8)))
+    assert _plugin.sampler_declines(s, types.SimpleNamespace(return_sampling_masks=None), True) is None
+    assert _plugin.sampler_declines(s, types.SimpleNamespace(return_sampling_masks=[False, False]), False) is None
+    assert s.forward(lo, types.SimpleNamespace(return_sampling_masks=[False, True]), False, None, None, None) == "the reference's forward"
+    s.rl_on_policy_target = "fsdp"
+    assert s.forward(lo, types.SimpleNamespace(), False, None, None, None) == "the reference's forward"
+    s.rl_on_policy_target = None
+    s.enable_deterministic = True
+    assert _plugin.sampler_declines(s, types.SimpleNamespace(), False) is None             # seeded sampling itself is the gfx950 kernel
+    assert s.forward(lo, types.SimpleNamespace(), True, None, None, None) == "the reference's forward"
+    s.enable_deterministic = False
+    smp.SGLANG_RETURN_ORIGINAL_LOGPROB = True
+    assert _plugin.sampler_declines(s, types.SimpleNamespace(), True) == "SGLANG_RETURN_ORIGINAL_LOGPROB"
+    assert _plugin.sampler_declines(s, types.SimpleNamespace(), False) is None
+    smp.SGLANG_RETURN_ORIGINAL_LOGPROB = False
+    assert s.reference_forwards == 3 and s.forward(lo, None, False, None, None, None).numel() == 0
 
     # platform: out-of-tree, dispatch key = the key the forwards were registered under
     cls = platform._build_platform_class()
