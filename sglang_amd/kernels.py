@@ -110,6 +110,7 @@ def rotary_embedding(positions: torch.Tensor, query: torch.Tensor, key: torch.Te
     if fused:
         _need(value is not None and v_cache is not None and cache_loc is not None, "rotary_embedding: fused store args")
         _need(cache_loc.dtype == torch.int64, "rotary_embedding: cache_loc must be int64")
+        _need(k_cache.dtype == _BF16 and v_cache.dtype == _BF16 and value.dtype == _BF16, "rotary_embedding: the fused store writes bf16 rows")
         v2 = value.view(T, -1)
         kc = k_cache.view(k_cache.shape[0], -1)
         vc = v_cache.view(v_cache.shape[0], -1)

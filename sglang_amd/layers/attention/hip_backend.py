@@ -336,7 +336,24 @@ class HipAttnBackend(AttentionBackend):
             return {}
         return opt
 
+    @staticmethod
+    def _refuse_unsupported(layer, kwargs) -> None:
+        """What a model may ask of an attention backend through RadixAttention.forward's **kwargs / layer attributes
+        (radix_attention.py:150-159; triton_backend.py forward_extend / forward_decode honour them) and these kernels do not
+        compute: refused by name instead of answered without it."""
+        for name in ("sinks", "k_rope", "q_rope", "idx_q"):
+            if kwargs.get(name) is not None:
+                raise NotImplementedError(f"hip_mi355x attention backend: `{name}` (attention sinks / MLA rope split / sparse index "
+                                          f"attention) is not implemented; run this model with another --attention-backend")
+        if (getattr(layer, "xai_temperature_len", -1) or -1) > 0:
+            raise NotImplementedError("hip_mi355x attention backend: xai_temperature_len (Grok's length-dependent temperature) is not implemented")
+        if getattr(layer, "is_cross_attention", False):
+            raise NotImplementedError("hip_mi355x attention backend: cross attention (encoder KV rows) is not implemented")
+        if layer.qk_head_dim != layer.v_head_dim:
+            raise NotImplementedError(f"hip_mi355x attention backend: qk_head_dim {layer.qk_head_dim} != v_head_dim {layer.v_head_dim} (MLA layouts)")
+
     def forward_extend(self, q, k, v, layer, forward_batch, save_kv_cache: bool = True, **kwargs):
+        self._refuse_unsupported(layer, kwargs)
         if save_kv_cache and k is not None and v is not None:
             self._save_kv(layer, forward_batch, k, v)
         m = self.forward_metadata
@@ -344,7 +361,7 @@ class HipAttnBackend(AttentionBackend):
         o = torch.empty(q3.shape, dtype=q3.dtype, device=q3.device)
         # (compared by VALUE: under sglang `layer` is the reference's RadixAttention and attn_type a member of the reference's
         # own AttentionType enum, radix_attention.py:58-66 -- another class than this package's look-alike)
-        causal = not (layer.is_cross_attention or getattr(layer.attn_type, "value", layer.attn_type) == "encoder_only")
+        causal = getattr(layer.attn_type, "value", layer.attn_type) != "encoder_only"
         opt = self._layer_options(layer)
         # speculative-decoding verify / tree attention (triton_backend.py:860-919): spec_info carries the flat mask
         spec = getattr(forward_batch, "spec_info", None)
@@ -373,6 +390,7 @@ class HipAttnBackend(AttentionBackend):
         return out
 
     def forward_decode(self, q, k, v, layer, forward_batch, save_kv_cache: bool = True, **kwargs):
+        self._refuse_unsupported(layer, kwargs)
         if save_kv_cache and k is not None and v is not None:
             self._save_kv(layer, forward_batch, k, v)
         m = self.forward_metadata

@@ -3,8 +3,8 @@
 
 `RMSNorm.forward` is also what plugin.load() registers as the out-of-tree forward of the reference's RMSNorm
 (BaseFusedOp.register_oot_forward): bound to a reference instance it reads the same attributes (`weight`,
-`variance_epsilon`, and the optional `variance_size_override` / `cast_x_before_out_mul` / `fp32_residual`
-switches) and hands every configuration outside the bf16 hot path to that instance's own `forward_native`."""
+`variance_epsilon`, and the optional `variance_size_override` / `cast_x_before_out_mul` / `fp32_residual` /
+`override_orig_dtype` / `x_pad_to_multiple` switches) and hands every configuration outside the bf16 hot path to that instance's own `forward_native`."""
 from __future__ import annotations
 
 from typing import Optional, Tuple, Union
@@ -41,6 +41,7 @@ class RMSNorm(nn.Module):
         outside = (fp8_fusion or x.dtype != torch.bfloat16 or self.weight.dtype != torch.bfloat16
                    or getattr(self, "variance_size_override", None) is not None
                    or getattr(self, "cast_x_before_out_mul", False) or getattr(self, "fp32_residual", False)
+                   or getattr(self, "override_orig_dtype", None) is not None or (getattr(self, "x_pad_to_multiple", 0) or 0) > 0
                    or not x.is_cuda)
         if outside:
             native = getattr(self, "forward_native", None)

@@ -406,3 +406,30 @@ def test_cascade_policy_switches(monkeypatch):
     assert cascade_wanted(NS(enable_cascade_attention=True)) is True                      # the attribute wins
     monkeypatch.setenv("SGLANG_AMD_CASCADE", "1")
     assert cascade_wanted(NS()) is True
+
+
+def test_attention_backend_refuses_what_it_does_not_compute():
+    """RadixAttention.forward hands the backend whatever the model passed (**kwargs, radix_attention.py:150-159): attention sinks
+    (gpt_oss.py:496, granite.py:220), the MLA rope split, sparse index attention; layers carry Grok's xai_temperature_len and the
+    cross-attention switch.  The gfx950 kernels compute none of these: the call is refused by name, before any launch."""
+    import pytest
+    from types import SimpleNamespace as NS
+
+    from sglang_amd.layers.attention.hip_backend import HipAttnBackend
+
+    layer = NS(qk_head_dim=128, v_head_dim=128, is_cross_attention=False, xai_temperature_len=-1)
+    HipAttnBackend._refuse_unsupported(layer, {})
+    HipAttnBackend._refuse_unsupported(layer, dict(sinks=None, k_rope=None))
+    for name in ("sinks", "k_rope", "q_rope", "idx_q"):
+        with pytest.raises(NotImplementedError, match=name):
+            HipAttnBackend._refuse_unsupported(layer, {name: torch.zeros(4)})
+    with pytest.raises(NotImplementedError, match="xai_temperature_len"):
+        HipAttnBackend._refuse_unsupported(NS(qk_head_dim=128, v_head_dim=128, is_cross_attention=False, xai_temperature_len=1024), {})
+    with pytest.raises(NotImplementedError, match="cross attention"):
+        HipAttnBackend._refuse_unsupported(NS(qk_head_dim=128, v_head_dim=128, is_cross_attention=True), {})
+    with pytest.raises(NotImplementedError, match="v_head_dim"):
+        HipAttnBackend._refuse_unsupported(NS(qk_head_dim=192, v_head_dim=128, is_cross_attention=False), {})
+    be = HipAttnBackend.__new__(HipAttnBackend)
+    for fwd in (be.forward_extend, be.forward_decode):                   # the guard runs first: nothing else of the backend is touched
+        with pytest.raises(NotImplementedError, match="sinks"):
+            fwd(None, None, None, layer, None, sinks=torch.zeros(4))
