@@ -58,12 +58,15 @@ class TopK(nn.Module):
     def forward(self, hidden_states: torch.Tensor, router_logits: torch.Tensor, *, num_token_non_padded=None,
                 expert_location_dispatch_info=None):
         c = self.topk_config                                         # reference: TopK.topk_config (topk.py:215-232)
+        ref = _reference_side(self)
         plain = (not getattr(c, "use_grouped_topk", False) and getattr(c, "custom_routing_function", None) is None
                  and getattr(c, "correction_bias", None) is None and getattr(c, "scoring_func", "softmax") == "softmax"
                  and not getattr(c, "num_fused_shared_experts", 0)
                  and not getattr(c, "apply_routed_scaling_factor_on_output", False)
                  and getattr(getattr(c, "output_format", None), "name", "STANDARD") == "STANDARD"
                  and num_token_non_padded is None and expert_location_dispatch_info is None
+                 and getattr(self, "waterfill_balancer", None) is None and not getattr(self, "enable_waterfill", False)
+                 and (ref is None or ref.standard_output_expected(c))
                  and router_logits.is_cuda)
         if not plain:
             native = getattr(self, "forward_native", None)
@@ -72,7 +75,53 @@ class TopK(nn.Module):
             return native(hidden_states, router_logits, num_token_non_padded=num_token_non_padded,
                           expert_location_dispatch_info=expert_location_dispatch_info)
         w, ids = fused_topk(hidden_states, router_logits, c.top_k, c.renormalize)
+        if ref is not None:
+            ref.after_select(c, getattr(self, "layer_id", None), ids)
         return _standard_output_cls(self)(w, ids, router_logits)
+
+
+class _ReferenceSide:
+    """What the reference's `select_experts` does AROUND the routing kernel on the standard path, for a forward bound to a
+    reference TopK instance: the output format follows the MoE runner backend when the config names none (topk.py:511-533: anything
+    but the standard format is the reference's), the benchmark-only routing overrides are the reference's (:2286-2320), and the
+    chosen ids are reported to the routed-experts capturer and the expert-distribution recorder (:1945, :2332-2334; both no-ops
+    unless the server enabled them)."""
+
+    def __init__(self):
+        import sglang.srt.layers.moe.topk as rt
+
+        self.capture = rt.capture_routed_experts_if_allowed
+        self.recorder = rt.get_global_expert_distribution_recorder
+        self.backend = rt.get_moe_runner_backend
+        self.envs = rt.envs
+
+    def standard_output_expected(self, config) -> bool:
+        if self.envs.SGLANG_SIMULATE_UNIFORM_EXPERTS.get() or self.envs.SGLANG_SIMULATE_ROUND_ROBIN_EXPERTS.get():
+            return False
+        if getattr(config, "output_format", None) is not None:
+            return True                                               # (its name was checked by the caller)
+        b = self.backend()
+        return b.is_auto() or b.is_triton()
+
+    def after_select(self, config, layer_id, topk_ids) -> None:
+        self.capture(config, layer_id, topk_ids)
+        self.recorder().on_select_experts(topk_ids=topk_ids)
+
+
+_REF_SIDE = []
+
+
+def _reference_side(op):
+    """The _ReferenceSide of a forward bound to a reference instance, None for this package's own modules (and under a stand-in
+    `sglang` that lacks the hooks)."""
+    if not type(op).__module__.startswith("sglang."):
+        return None
+    if not _REF_SIDE:
+        try:
+            _REF_SIDE.append(_ReferenceSide())
+        except Exception:
+            _REF_SIDE.append(None)
+    return _REF_SIDE[0]
 
 
 def _standard_output_cls(op=None):

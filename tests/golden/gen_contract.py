@@ -29,11 +29,15 @@ WANT = {
     "sglang/srt/layers/attention/base_attn_backend.py": ["AttentionBackend"],
     "sglang/srt/layers/attention/torch_native_backend.py": ["TorchNativeAttnBackend"],
     "sglang/srt/layers/radix_attention.py": ["RadixAttention", "AttentionType"],
-    "sglang/srt/layers/sampler.py": ["Sampler", "register_sampler_backend", "create_sampler"],
+    "sglang/srt/layers/sampler.py": ["Sampler", "register_sampler_backend", "create_sampler", "SGLANG_RETURN_ORIGINAL_LOGPROB"],
+    "sglang/srt/sampling/sampling_batch_info.py": ["SamplingBatchInfo"],
     "sglang/srt/layers/moe/moe_runner/base.py": ["FusedOpPool", "register_fused_func", "MoeRunnerConfig"],
     "sglang/srt/layers/moe/moe_runner/triton.py": ["fused_experts_none_to_triton", "TritonMoeQuantInfo"],
     "sglang/srt/layers/moe/token_dispatcher/standard.py": ["StandardCombineInput", "StandardDispatchOutput"],
-    "sglang/srt/layers/moe/topk.py": ["TopK", "TopKConfig", "StandardTopKOutput"],
+    "sglang/srt/layers/moe/topk.py": ["TopK", "TopKConfig", "StandardTopKOutput", "select_experts", "capture_routed_experts_if_allowed",
+                                      "import:get_global_expert_distribution_recorder", "import:get_moe_runner_backend", "import:envs"],
+    "sglang/srt/layers/moe/utils.py": ["MoeRunnerBackend"],
+    "sglang/srt/eplb/expert_distribution.py": ["ExpertDistributionRecorder.on_select_experts"],
     "sglang/kernels/fused_op.py": ["BaseFusedOp", "_oot_dispatch_key"],
     "sglang/srt/layers/layernorm.py": ["RMSNorm"],
     "sglang/srt/layers/activation.py": ["SiluAndMul"],
@@ -133,8 +137,18 @@ def extract(path: Path, names):
                     top[t.id] = n
         elif isinstance(n, ast.AnnAssign) and isinstance(n.target, ast.Name):
             top[n.target.id] = n
+    imported = {}
+    for n in tree.body:                      # names a module binds by importing them (read as `module.name` by code written against it)
+        if isinstance(n, ast.ImportFrom):
+            for al in n.names:
+                imported[al.asname or al.name] = f"{'.' * n.level}{n.module or ''}.{al.name}"
     out = {}
     for name in names:
+        if name.startswith("import:"):
+            if name[7:] not in imported:
+                raise SystemExit(f"{path}: no longer imports {name[7:]}")
+            out[name] = {"kind": "import", "from": imported[name[7:]]}
+            continue
         cls, _, meth = name.partition(".")
         node = top.get(cls)
         if node is None:

@@ -455,6 +455,7 @@ def test_plugin_load_runs_against_the_reference_contract(fake_sglang):
     from sglang_amd import plugin as _plugin
 
     lo = types.SimpleNamespace(next_token_logits=torch.zeros((0, 8)))
+    smp.SGLANG_RETURN_ORIGINAL_LOGPROB = False         # (the contract records the expression, `get_bool_env_var(...)`: unset = False)
     assert _plugin.sampler_declines(s, types.SimpleNamespace(return_sampling_masks=None), True) is None
     assert _plugin.sampler_declines(s, types.SimpleNamespace(return_sampling_masks=[False, False]), False) is None
     assert s.forward(lo, types.SimpleNamespace(return_sampling_masks=[False, True]), False, None, None, None) == "the reference's forward"
@@ -896,3 +897,62 @@ def test_runner_config_and_quant_info_fields_the_moe_hook_reads_exist():
     assert [f["name"] for f in ref("sglang.srt.layers.moe.topk", "StandardTopKOutput")["fields"]] == ["topk_weights", "topk_ids", "router_logits"]
     assert [f["name"] for f in ref("sglang.srt.mem_cache.memory_pool", "KVWriteLoc")["fields"]][:2] == ["loc", "swa_loc"]
     assert [p["name"] for p in ref_params("sglang.srt.mem_cache.memory_pool", "MHATokenToKVPool", "set_kv_buffer")][:4] == ["layer", "loc_info", "cache_k", "cache_v"]
+
+
+def test_names_the_sampler_and_router_sides_read_exist(monkeypatch):
+    """plugin.sampler_declines and layers/moe/topk._ReferenceSide read instance attributes, dataclass fields, a module constant and
+    names the reference's topk module binds by IMPORT: all recorded by gen_contract.py, so a reference that renames one fails here
+    after a regeneration instead of silently never declining / never reporting."""
+    smp = ref("sglang.srt.layers.sampler", "Sampler")
+    for a in ("rl_on_policy_target", "enable_deterministic", "use_log_softmax_logprob", "use_ascend_backend", "output_logprob_processor"):
+        assert a in smp["instance_attrs"], a
+    assert MODS["sglang.srt.layers.sampler"]["names"]["SGLANG_RETURN_ORIGINAL_LOGPROB"]["kind"] == "constant"
+    sbi = [f["name"] for f in ref("sglang.srt.sampling.sampling_batch_info", "SamplingBatchInfo")["fields"]]
+    for f in ("return_sampling_masks", "is_all_greedy", "need_top_p_sampling", "need_top_k_sampling", "need_min_p_sampling", "sampling_seed",
+              "temperatures", "top_ps", "top_ks", "min_ps"):
+        assert f in sbi, f
+    tk = MODS["sglang.srt.layers.moe.topk"]["names"]
+    for a in ("enable_waterfill", "waterfill_balancer", "layer_id", "topk_config"):
+        assert a in tk["TopK"]["instance_attrs"], a
+    assert [q["name"] for q in tk["capture_routed_experts_if_allowed"]["params"]] == ["topk_config", "layer_id", "topk_ids"]
+    assert tk["import:get_global_expert_distribution_recorder"]["from"].endswith("expert_distribution.get_global_expert_distribution_recorder")
+    assert tk["import:get_moe_runner_backend"]["kind"] == "import" and tk["import:envs"]["from"] == "sglang.srt.environ.envs"
+    assert [q["name"] for q in MODS["sglang.srt.eplb.expert_distribution"]["names"]["ExpertDistributionRecorder.on_select_experts"]["params"]] == ["self", "topk_ids"]
+    backend = ref("sglang.srt.layers.moe.utils", "MoeRunnerBackend")
+    assert "is_auto" in backend["methods"] and "is_triton" in backend["methods"]
+    tkc = [f["name"] for f in tk["TopKConfig"]["fields"]]
+    for f in ("output_format", "num_fused_shared_experts", "apply_routed_scaling_factor_on_output", "allow_routed_experts_capture"):
+        assert f in tkc, f
+
+    # behaviour of the side object on a module shaped like the reference's
+    from types import SimpleNamespace as NS
+
+    from sglang_amd.layers.moe import topk as hip_topk
+
+    log = []
+    flag = lambda v: NS(get=lambda: v)                                                            # noqa: E731
+    fake = types.ModuleType("sglang.srt.layers.moe.topk")
+    fake.capture_routed_experts_if_allowed = lambda topk_config, layer_id, topk_ids: log.append(("capture", layer_id))
+    fake.get_global_expert_distribution_recorder = lambda: NS(on_select_experts=lambda topk_ids: log.append(("record", tuple(topk_ids.shape))))
+    state = dict(backend=NS(is_auto=lambda: True, is_triton=lambda: False))
+    fake.get_moe_runner_backend = lambda: state["backend"]
+    fake.envs = NS(SGLANG_SIMULATE_UNIFORM_EXPERTS=flag(False), SGLANG_SIMULATE_ROUND_ROBIN_EXPERTS=flag(False))
+    for name in ("sglang", "sglang.srt", "sglang.srt.layers", "sglang.srt.layers.moe"):
+        monkeypatch.setitem(sys.modules, name, types.ModuleType(name))
+    monkeypatch.setitem(sys.modules, "sglang.srt.layers.moe.topk", fake)
+    sys.modules["sglang.srt.layers.moe"].topk = fake
+    sys.modules["sglang.srt.layers"].moe = sys.modules["sglang.srt.layers.moe"]
+    sys.modules["sglang.srt"].layers = sys.modules["sglang.srt.layers"]
+    sys.modules["sglang"].srt = sys.modules["sglang.srt"]
+    side = hip_topk._ReferenceSide()
+    cfg = NS(output_format=None)
+    assert side.standard_output_expected(cfg)
+    state["backend"] = NS(is_auto=lambda: False, is_triton=lambda: False)                        # e.g. --moe-runner-backend triton_kernel
+    assert not side.standard_output_expected(cfg)
+    assert side.standard_output_expected(NS(output_format="STANDARD"))                            # a config that names the format decides
+    fake.envs.SGLANG_SIMULATE_ROUND_ROBIN_EXPERTS = flag(True)
+    assert not side.standard_output_expected(NS(output_format="STANDARD"))
+    side.after_select(cfg, 3, torch.zeros((5, 2), dtype=torch.int32))
+    assert log == [("capture", 3), ("record", (5, 2))]
+    # a forward bound to this package's own TopK has no reference side
+    assert hip_topk._reference_side(hip_topk.TopK(2)) is None
