@@ -13,6 +13,7 @@ import torch
 from torch import nn
 
 from .. import kernels
+from .activation import rows_vectorisable
 
 # calls served by the gfx950 kernels / handed to the bound reference instance's own forward_native (tests and the
 # reference-stack reports read it: a silent hand-over is a slower path, not an error)
@@ -42,7 +43,10 @@ class RMSNorm(nn.Module):
                    or getattr(self, "variance_size_override", None) is not None
                    or getattr(self, "cast_x_before_out_mul", False) or getattr(self, "fp32_residual", False)
                    or getattr(self, "override_orig_dtype", None) is not None or (getattr(self, "x_pad_to_multiple", 0) or 0) > 0
-                   or not x.is_cuda)
+                   or not x.is_cuda or x.shape[-1] > 65536 or not rows_vectorisable(x, x.shape[-1])
+                   or self.weight.shape[-1] != x.shape[-1] or self.weight.data_ptr() % 16 != 0
+                   or (residual is not None and (residual.dtype != x.dtype or residual.shape != x.shape
+                                                 or not rows_vectorisable(residual, x.shape[-1]))))
         if outside:
             native = getattr(self, "forward_native", None)
             if native is None:

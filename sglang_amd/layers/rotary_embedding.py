@@ -12,6 +12,8 @@ from torch import nn
 
 from .. import kernels
 
+served = dict(hip=0, native=0)
+
 
 @dataclass
 class FusedSetKVBufferArg:
@@ -49,7 +51,17 @@ class RotaryEmbedding(nn.Module):
     def forward(self, positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor,
                 offsets: Optional[torch.Tensor] = None,
                 fused_set_kv_buffer_arg: Optional[FusedSetKVBufferArg] = None) -> Tuple[torch.Tensor, torch.Tensor]:
-        """In place on query/key; returns them (base.py:236-243 signature)."""
+        """In place on query/key; returns them (base.py:236-243 signature).  Bound to a reference instance (plugin.load() registers
+        this forward out-of-tree), calls the kernel does not take -- another dtype than bf16, int32 positions, host tensors, a
+        cos / sin cache in another dtype than bf16 / fp32 -- go to that instance's own `forward_native`."""
+        native = getattr(self, "forward_native", None)
+        if native is not None and fused_set_kv_buffer_arg is None and not (
+                query.is_cuda and query.dtype == torch.bfloat16 and key.dtype == torch.bfloat16 and positions.dtype == torch.int64
+                and self.cos_sin_cache.dtype in (torch.bfloat16, torch.float32) and self.cos_sin_cache.is_contiguous()
+                and query.stride(-1) == 1 and key.stride(-1) == 1 and positions.dim() == 1):
+            served["native"] += 1
+            return native(positions, query, key, offsets)
+        served["hip"] += 1
         if offsets is not None:
             positions = positions + offsets
         f = fused_set_kv_buffer_arg

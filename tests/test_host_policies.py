@@ -433,3 +433,17 @@ def test_attention_backend_refuses_what_it_does_not_compute():
     for fwd in (be.forward_extend, be.forward_decode):                   # the guard runs first: nothing else of the backend is touched
         with pytest.raises(NotImplementedError, match="sinks"):
             fwd(None, None, None, layer, None, sinks=torch.zeros(4))
+
+
+def test_rows_the_elementwise_kernels_can_walk():
+    """layers/activation.rows_vectorisable: the gate in front of the RMSNorm / SiluAndMul kernels (16-byte vectors, no hidden copy)."""
+    from sglang_amd.layers.activation import rows_vectorisable
+
+    x = torch.zeros(6, 64, dtype=torch.bfloat16)
+    assert rows_vectorisable(x, 64) and rows_vectorisable(x[0], 64) and rows_vectorisable(x.view(2, 3, 64), 64)
+    assert rows_vectorisable(x[:, :32], 32)                       # a column slice keeps whole-vector row strides
+    assert not rows_vectorisable(x[:, 4:36], 32)                  # ... but not a 16-byte aligned base
+    assert not rows_vectorisable(x[:, ::2], 32)                   # strided last dimension
+    assert not rows_vectorisable(torch.zeros(6, 12, dtype=torch.bfloat16), 12)       # width outside the vector
+    assert not rows_vectorisable(x.view(2, 3, 64)[:, :2], 64)     # 3-D view that is not contiguous: a reshape would copy
+    assert not rows_vectorisable(x, 32) and not rows_vectorisable(torch.zeros((), dtype=torch.bfloat16), 1)

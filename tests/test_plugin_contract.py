@@ -520,6 +520,18 @@ def test_plugin_load_runs_against_the_reference_contract(fake_sglang):
                                 correction_bias=None, scoring_func="softmax", num_fused_shared_experts=0,
                                 apply_routed_scaling_factor_on_output=False, output_format=None)
     assert tk.TopK(cfg)(torch.zeros(2, 8), torch.zeros(2, 4)) == "native-topk"
+    # SiluAndMul / RotaryEmbedding: what the kernels do not take (host tensors, other dtypes, int32 positions) is the bound
+    # instance's own forward_native, not an exception
+    act_m, rope_m = g["sglang.srt.layers.activation"], g["sglang.srt.layers.rotary_embedding.base"]
+    assert act_m.SiluAndMul()(torch.zeros(2, 32, dtype=torch.float16)) == "native-silu"
+    assert act_m.SiluAndMul()(torch.zeros(2, 32, dtype=torch.bfloat16)) == "native-silu"            # (host tensor)
+    r = rope_m.RotaryEmbedding()
+    r.cos_sin_cache = torch.zeros(8, 16)
+    assert r(torch.zeros(2, dtype=torch.int64), torch.zeros(2, 32, dtype=torch.float16), torch.zeros(2, 16, dtype=torch.float16)) == "native-rope"
+    # RMSNorm: a width / layout outside the kernel's 16-byte vectors is forward_native too
+    odd = ln.RMSNorm(12)
+    odd(torch.zeros(3, 12, dtype=torch.bfloat16))
+    assert odd.native_args == (False, False, False)
 
     # fused MoE: the ("none", "triton") slot is ours, the reference's function is the fallback for what we do not cover
     pool = g["sglang.srt.layers.moe.moe_runner.base"].FusedOpPool
