@@ -137,6 +137,18 @@ class HipAttnBackend(AttentionBackend):
         self.req_to_token_pool = model_runner.req_to_token_pool
         self.token_to_kv_pool = model_runner.token_to_kv_pool
         self.num_q_heads, self.num_kv_heads, self.head_dim = runner_head_dims(model_runner)
+        # refused when the server builds its backend, not at the first prefill: the prefill kernel covers head dims 64 / 128
+        # (extend_attention.hip), activations are bf16, pool rows bf16 or OCP e4m3
+        if self.head_dim not in (64, 128):
+            raise NotImplementedError(f"hip_mi355x attention backend: head_dim {self.head_dim} (the gfx950 kernels cover 64 and 128); "
+                                      f"run this model with another --attention-backend")
+        act_dtype = getattr(model_runner, "dtype", None)
+        if isinstance(act_dtype, torch.dtype) and act_dtype != torch.bfloat16:
+            raise NotImplementedError(f"hip_mi355x attention backend: model dtype {act_dtype} (the gfx950 kernels compute in bf16: "
+                                      f"--dtype bfloat16, or another --attention-backend)")
+        pool_dtype = getattr(self.token_to_kv_pool, "dtype", torch.bfloat16)
+        if pool_dtype not in (torch.bfloat16, torch.float8_e4m3fn):
+            raise NotImplementedError(f"hip_mi355x attention backend: KV pool dtype {pool_dtype} (bf16 or float8_e4m3fn rows)")
         self.max_context_len = int(self.req_to_token_pool.req_to_token.shape[1])
         self.sliding_window_size = getattr(model_runner, "sliding_window_size", None)
         self.forward_metadata: Optional[_Meta] = None

@@ -437,6 +437,16 @@ def test_plugin_load_runs_against_the_reference_contract(fake_sglang):
                                    req_to_token_pool=types.SimpleNamespace(req_to_token=torch.zeros((9, 96), dtype=torch.int32), size=8))
     be = factory(runner)
     assert isinstance(be, HipAttnBackend) and (be.num_q_heads, be.num_kv_heads, be.head_dim, be.max_context_len) == (8, 2, 64, 96)
+    # what the kernels cannot serve is refused when the server BUILDS the backend (model_runner.py init_attention_backend), by name
+    for change, word in ((dict(dtype=torch.float16), "model dtype"), (dict(pool_dtype=torch.float16), "KV pool dtype"), (dict(head_dim=96), "head_dim 96")):
+        bad_pool = Pool()
+        if "head_dim" in change:
+            bad_pool.k = torch.zeros((64, 2, 96), dtype=torch.bfloat16)
+        if "pool_dtype" in change:
+            bad_pool.dtype = change["pool_dtype"]
+        bad = types.SimpleNamespace(**{**vars(runner), "token_to_kv_pool": bad_pool, **({"dtype": change["dtype"]} if "dtype" in change else {})})
+        with pytest.raises(NotImplementedError, match=word):
+            factory(bad)
     # ... and an instance of the REFERENCE's AttentionBackend: the runners read `shared_read_ends`, `supports_ragged_verify_graph`,
     # `on_after_cuda_graph_warmup` ... of a backend (decode_cuda_graph_runner.py:491, :724), which keep the reference's defaults
     ref_base = g["sglang.srt.layers.attention.base_attn_backend"].AttentionBackend
