@@ -135,14 +135,18 @@ __global__ __launch_bounds__(kThreads) void stream_chain_kernel(Params p) {
     if (streamer && ((p.handoff == 1) || (in_launch && p.act_mode && s > 0))) {
       const int slice = (blockIdx.x & 3) * kSliceBytes;
       if (in_launch && p.act_mode == 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // buffer_inv sc1
-#pragma unroll 4
-      for (int i = 0; i < kSliceBytes / (kStreamThreads * 16); ++i) {
-        const int off = slice + (i * kStreamThreads + t) * 16;
-        u32x4_t v;
-        if (in_launch && p.act_mode == 1) v = __builtin_amdgcn_raw_buffer_load_b128(act, off, 0, 16);   // sc1: past this XCD's L2
-        else v = *reinterpret_cast<const u32x4_t*>(p.act + off);
-        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+      // the whole slice in flight at once (16 loads per lane): the exchange is a latency chain otherwise
+      constexpr int NL = kSliceBytes / (kStreamThreads * 16);
+      u32x4_t xv[NL];
+      if (in_launch && p.act_mode == 1) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) xv[i] = __builtin_amdgcn_raw_buffer_load_b128(act, slice + (i * kStreamThreads + t) * 16, 0, 16);   // sc1
+      } else {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) xv[i] = *reinterpret_cast<const u32x4_t*>(p.act + slice + (i * kStreamThreads + t) * 16);
       }
+#pragma unroll
+      for (int i = 0; i < NL; ++i) acc ^= xv[i].x ^ xv[i].y ^ xv[i].z ^ xv[i].w;
     }
     // ---- the weight stream: buffer loads, ONE vector register of address (the lane's offset), the walk in scalar offsets ----
     if (streamer) {
