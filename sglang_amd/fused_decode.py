@@ -106,6 +106,8 @@ def layer_unfusable_reason(layer, rows: int) -> Optional[str]:
     if hidden % 128 != 0 or hidden > 16384 or (mlp is not None and mlp.gate_up_proj.weight.shape[0] % 32 != 0):
         return f"hidden size {hidden} / gate_up rows outside the kernels' tiling"
     for name, l in lins.items():
+        if name == "gate_up_proj" and kernels.wstream_supported(rows, *l.weight.shape):
+            continue     # at 65..128 rows the WIDE projection is the library's (wstream_preferred): decode_layer's hybrid form
         if not kernels.wstream_preferred(rows, *l.weight.shape):
             return f"{name} {tuple(l.weight.shape)} at {rows} rows is left to the library GEMM"
     return None
@@ -160,16 +162,24 @@ def decode_layer(layer, positions: torch.Tensor, normed: torch.Tensor, forward_b
     a = attn.attn(q, None, None, forward_batch, save_kv_cache=False)
     post = layer.post_attention_layernorm
     blocked_act = mlp.gate_up_proj.weight.shape[0] % 256 == 0
+    w_gu = mlp.gate_up_proj.weight.data
+    # 65..128 rows: the weight stream still wins for qkv / o / down, the wide gate_up is the library's (kernels.wstream_preferred):
+    # the layer keeps its fused combines around a library GEMM + silu_and_mul -- 11 launches instead of the operator path's 15
+    stream_gu = kernels.wstream_preferred(a.shape[0], *w_gu.shape)
+
+    def gate_up(x):
+        if stream_gu:
+            return kernels.wstream_gemm(x, w_gu, epilogue="silu_and_mul", out_blocked=blocked_act)
+        return kernels.silu_and_mul(torch.nn.functional.linear(x, w_gu))
+
     if comm is not None:
         y = kernels.wstream_gemm(a.reshape(a.shape[0], -1), attn.o_proj.weight.data)
         x = comm.all_reduce_add_rmsnorm(y, residual, post.weight.data, post.variance_epsilon)
-        act = kernels.wstream_gemm(x, mlp.gate_up_proj.weight.data, epilogue="silu_and_mul", out_blocked=blocked_act)
-        y = kernels.wstream_gemm(act, mlp.down_proj.weight.data)
+        y = kernels.wstream_gemm(gate_up(x), mlp.down_proj.weight.data)
         return comm.all_reduce_add_rmsnorm(y, residual, next_norm.weight.data, next_norm.variance_epsilon)
     x = kernels.wstream_gemm(a, attn.o_proj.weight.data, epilogue="add_rmsnorm", residual=residual, norm_weight=post.weight.data,
-                             eps=post.variance_epsilon, out_blocked=True)
-    act = kernels.wstream_gemm(x, mlp.gate_up_proj.weight.data, epilogue="silu_and_mul", out_blocked=blocked_act)
-    return kernels.wstream_gemm(act, mlp.down_proj.weight.data, epilogue="add_rmsnorm", residual=residual,
+                             eps=post.variance_epsilon, out_blocked=stream_gu)
+    return kernels.wstream_gemm(gate_up(x), mlp.down_proj.weight.data, epilogue="add_rmsnorm", residual=residual,
                                 norm_weight=next_norm.weight.data, eps=next_norm.variance_epsilon, out_blocked=True)
 
 

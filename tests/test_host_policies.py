@@ -447,3 +447,28 @@ def test_rows_the_elementwise_kernels_can_walk():
     assert not rows_vectorisable(torch.zeros(6, 12, dtype=torch.bfloat16), 12)       # width outside the vector
     assert not rows_vectorisable(x.view(2, 3, 64)[:, :2], 64)     # 3-D view that is not contiguous: a reshape would copy
     assert not rows_vectorisable(x, 32) and not rows_vectorisable(torch.zeros((), dtype=torch.bfloat16), 1)
+
+
+def test_fused_layer_row_gates_at_llama3_8b_shapes():
+    """Which decode batches the fused layer owns at Llama-3-8B's projection shapes: up to 64 rows every projection streams; at
+    65..128 rows the narrow ones still do and the wide gate_up is the library's (the hybrid form of fused_decode.decode_layer);
+    beyond 128 rows nothing streams and the layer is the operator-by-operator one."""
+    import types
+    import unittest.mock as um
+
+    from sglang_amd import fused_decode, kernels
+
+    def lin(n, k):
+        return types.SimpleNamespace(weight=torch.empty((n, k), dtype=torch.bfloat16, device="meta"), quant_method=None, bias=None)
+
+    rope = type("RotaryEmbedding", (), {})()
+    rope.is_neox_style, rope.rotary_dim = True, 128
+    attn = _named("LlamaAttention", qkv_proj=lin(6144, 4096), o_proj=lin(4096, 4096), rotary_emb=rope, head_dim=128, num_heads=32, num_kv_heads=8, attn=None)
+    layer = _named("LlamaDecoderLayer", self_attn=attn, mlp=_named("LlamaMLP", gate_up_proj=lin(28672, 4096), down_proj=lin(4096, 14336)))
+    with um.patch.object(fused_decode, "_plain_linear", lambda l: True):          # (meta weights are not device weights)
+        for rows in (1, 64, 65, 96, 128):
+            assert fused_decode.layer_fusable(layer, rows), rows
+        assert not fused_decode.layer_fusable(layer, 129)
+        assert "qkv_proj" in fused_decode.layer_unfusable_reason(layer, 200)
+    assert kernels.wstream_preferred(64, 28672, 4096) and not kernels.wstream_preferred(65, 28672, 4096)      # the hybrid's switch
+    assert kernels.wstream_preferred(128, 6144, 4096) and kernels.wstream_preferred(128, 4096, 14336)

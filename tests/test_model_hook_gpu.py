@@ -38,8 +38,10 @@ class RefShapedLlamaModel:
 # (the third case: the 8B shapes with a qkv bias -- the layer form of Qwen2Model, the hook's second target)
 # (the last two: sparse-MoE layers -- the form of MixtralModel, the hook's third target: fused attention half, the block's own gate /
 # TopK / experts, add + norm in one launch)
+# (("llama-3-8b-2l", 128 / 80): the hybrid form -- from 65 rows the wide gate_up projection is the library's GEMM + silu_and_mul, the rest
+# of the layer keeps its weight streams and fused combines)
 @pytest.mark.parametrize("model_name,B", [("tiny-llama3-rope", 5), ("llama-3-8b-2l", 64), ("llama-3-8b-2l-qkvbias", 16),
-                                          ("tiny-mixtral", 5), ("mixtral-8x7b-2l", 32)])
+                                          ("tiny-mixtral", 5), ("mixtral-8x7b-2l", 32), ("llama-3-8b-2l", 128), ("llama-3-8b-2l", 80)])
 def test_hook_takes_the_fused_branch_and_matches_the_operator_loop(device, monkeypatch, model_name, B):
     import dataclasses
 
