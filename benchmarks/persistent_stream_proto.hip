@@ -44,7 +44,8 @@ constexpr int kThreads = 576;         // + 1 wave that runs the grid barrier
 constexpr int kGrid = 256;            // one workgroup per CU, all resident
 constexpr int kMaxSeg = 16;
 constexpr int kActBytes = 512 * 1024;          // [64, 4096] bf16
-constexpr int kSliceBytes = 128 * 1024;        // what one workgroup needs of it (a K quarter of all 64 rows)
+constexpr int kSliceBytes = 128 * 1024;
+constexpr int kPartBytes = 4 * 1024 * 1024;       // [4 splits, 64, 4096] fp32        // what one workgroup needs of it (a K quarter of all 64 rows)
 
 struct Seg {
   const uint4* w;
@@ -60,6 +61,10 @@ struct Params {
   unsigned* bar;       // flat: [0] arrivals, [1] generation, [2] timed out; hierarchical: 32-word lines, see grid_barrier_hier
   unsigned char* act;  // kActBytes
   unsigned* sink;      // [grid * threads]
+  int combine;         // 1: a matrix publishes split-K partials (16 KiB per workgroup, 4 MiB) and a COMBINE phase -- 64 workgroups, one row
+                       //    each: 64 KiB of partials in, 8 KiB of normed activations out -- sits between it and the next matrix
+  int phase;           // launches + combine: 1 = this launch is a matrix (+ its partials), 2 = this launch is the combine
+  unsigned char* part; // kPartBytes
 };
 
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
@@ -129,6 +134,40 @@ __global__ __launch_bounds__(kThreads) void stream_chain_kernel(Params p) {
   bool have = false;
   const __amdgpu_buffer_rsrc_t act = __builtin_amdgcn_make_buffer_rsrc(p.act, 0, kActBytes, 0x00020000);
   const bool in_launch = p.handoff == 2;
+  const __amdgpu_buffer_rsrc_t part = __builtin_amdgcn_make_buffer_rsrc(p.part, 0, kPartBytes, 0x00020000);
+
+  auto boundary = [&]() {        // in-launch only: stores of this workgroup have left the CU, then the grid barrier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == kStreamThreads) {
+      if (p.hier) grid_barrier_hier(p.bar);
+      else grid_barrier(p.bar);
+    }
+    __syncthreads();
+  };
+  auto combine_phase = [&]() {   // one row per workgroup: its four split-K partial rows in, the normed row out
+    if (blockIdx.x < 64 && streamer) {
+      u32x4_t pv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int off = blockIdx.x * 65536 + (i * kStreamThreads + t) * 16;
+        pv[i] = in_launch ? __builtin_amdgcn_raw_buffer_load_b128(part, off, 0, 16) : *reinterpret_cast<const u32x4_t*>(p.part + off);
+      }
+      unsigned c = 0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) c ^= pv[i].x ^ pv[i].y ^ pv[i].z ^ pv[i].w;
+      const u32x4_t v = {c, c + 1u, c + 2u, c + 3u};
+      const int off = blockIdx.x * 8192 + t * 16;
+      if (in_launch) __builtin_amdgcn_raw_buffer_store_b128(v, act, off, 0, 16);
+      else *reinterpret_cast<u32x4_t*>(p.act + off) = v;
+      acc ^= c;
+    }
+  };
+  if (p.combine && p.phase == 2) {            // a combine launch of the launches form
+    combine_phase();
+    p.sink[blockIdx.x * kThreads + t] = acc;
+    return;
+  }
 
   for (int s = 0; s < p.n_seg; ++s) {
     // ---- what this matrix's GEMM needs of the previous one's output ------------------------------------
@@ -171,6 +210,23 @@ __global__ __launch_bounds__(kThreads) void stream_chain_kernel(Params p) {
       have = false;
     }
     // ---- publish this matrix's output share; the boundary --------------------------------------------------
+    if (p.combine) {
+      if (streamer) {                          // split-K partials: 16 KiB per workgroup
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int off = blockIdx.x * 16384 + (i * kStreamThreads + t) * 16;
+          const u32x4_t v = {acc, acc + 1u, acc + 2u, acc + 3u + static_cast<unsigned>(i)};
+          if (in_launch) __builtin_amdgcn_raw_buffer_store_b128(v, part, off, 0, 16);
+          else *reinterpret_cast<u32x4_t*>(p.part + off) = v;
+        }
+      }
+      if (in_launch) {
+        boundary();
+        combine_phase();
+        if (s + 1 < p.n_seg) boundary();
+      }
+      continue;
+    }
     if (streamer && t < 128 && ((p.handoff == 1) || (in_launch && p.act_mode))) {
       const int off = blockIdx.x * (kActBytes / kGrid) + t * 16;
       const u32x4_t v = {acc, acc + 1u, acc + 2u, acc + 3u};
@@ -207,22 +263,29 @@ struct Timer {
 
 template <int U>
 double time_form(hipStream_t st, const std::vector<Seg>& chain, int layers_per_chain, const char* form, unsigned* bar, unsigned char* act,
-                 unsigned* sink, int reps) {
+                 unsigned char* part, unsigned* sink, int reps) {
   Params base{};
   base.bar = bar;
   base.act = act;
+  base.part = part;
   base.sink = sink;
   const std::string f = form;
   hipGraph_t graph;
   hipGraphExec_t exec;
   CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
-  if (f == "launches" || f == "launches_no_handoff") {
+  if (f == "launches" || f == "launches_no_handoff" || f == "launches_combine") {
     for (size_t s = 0; s < chain.size(); ++s) {
       Params p = base;
       p.n_seg = 1;
       p.seg[0] = chain[s];
-      p.handoff = f == "launches" ? 1 : 0;
+      p.handoff = f == "launches_no_handoff" ? 0 : 1;
+      p.combine = f == "launches_combine" ? 1 : 0;
+      p.phase = 1;
       hipLaunchKernelGGL(stream_chain_kernel<U>, dim3(kGrid), dim3(kThreads), 0, st, p);
+      if (p.combine) {                    // the combine launch: 64 workgroups, as today's combine kernels
+        p.phase = 2;
+        hipLaunchKernelGGL(stream_chain_kernel<U>, dim3(64), dim3(kThreads), 0, st, p);
+      }
     }
   } else {
     // in-launch forms: "floor", or a name built of barrier / prefetch + _act0|_act1|_act2 + optional _hier
@@ -233,6 +296,7 @@ double time_form(hipStream_t st, const std::vector<Seg>& chain, int layers_per_c
     p.prefetch = f.rfind("prefetch", 0) == 0 ? 1 : 0;
     p.act_mode = f.find("_act1") != std::string::npos ? 1 : f.find("_act2") != std::string::npos ? 2 : 0;
     p.hier = f.find("_hier") != std::string::npos ? 1 : 0;
+    p.combine = f.find("_combine") != std::string::npos ? 1 : 0;
     hipLaunchKernelGGL(stream_chain_kernel<U>, dim3(kGrid), dim3(kThreads), 0, st, p);
   }
   CHECK(hipStreamEndCapture(st, &graph));
@@ -280,24 +344,23 @@ int main(int argc, char** argv) {
   CHECK(hipMemsetAsync(bar, 0, 4096, st));
   CHECK(hipMalloc(&act, kActBytes));
   CHECK(hipMemsetAsync(act, 0, kActBytes, st));
+  unsigned char* part;
+  CHECK(hipMalloc(&part, kPartBytes));
+  CHECK(hipMemsetAsync(part, 0, kPartBytes, st));
   CHECK(hipMalloc(&sink, sizeof(unsigned) * kGrid * kThreads));
   CHECK(hipStreamSynchronize(st));
 
   const char* forms[] = {"launches_no_handoff", "launches", "floor", "barrier_act0", "barrier_act0_hier", "barrier_act1", "barrier_act1_hier",
-                         "barrier_act2_hier", "prefetch_act0_hier", "prefetch_act1_hier", "prefetch_act2_hier"};
+                         "barrier_act2_hier", "prefetch_act0_hier", "prefetch_act1_hier", "prefetch_act2_hier", "launches_combine", "barrier_act1_hier_combine"};
   const int n_forms = sizeof(forms) / sizeof(forms[0]);
   std::string out = "{\"what\": \"us per layer of four streamed weight matrices (Llama-3-8B shapes), 256 workgroups x 8 streaming waves\", ";
   out += "\"layer_bytes\": " + std::to_string(static_cast<long>(layer_bytes)) + ", \"forms\": {";
-  for (int pass = 0; pass < 2; ++pass) {
-    for (int f = 0; f < n_forms; ++f) {
-      const double us = pass == 0 ? time_form<8>(st, chain, layers, forms[f], bar, act, sink, 20)
-                                  : time_form<16>(st, chain, layers, forms[f], bar, act, sink, 20);
-      char buf[256];
-      std::snprintf(buf, sizeof buf, "%s\"%s_u%d\": {\"us_per_layer\": %.2f, \"TB_per_s\": %.3f}", (pass || f) ? ", " : "", forms[f], pass ? 16 : 8, us,
-                    layer_bytes / us * 1e-6);
-      out += buf;
-      std::fprintf(stderr, "%-22s U=%2d  %8.2f us / layer  %.3f TB/s\n", forms[f], pass ? 16 : 8, us, layer_bytes / us * 1e-6);
-    }
+  for (int f = 0; f < n_forms; ++f) {       // (U = 16 loads in flight per lane measured the same as 8 in every form: dropped)
+    const double us = time_form<8>(st, chain, layers, forms[f], bar, act, part, sink, 20);
+    char buf[256];
+    std::snprintf(buf, sizeof buf, "%s\"%s_u8\": {\"us_per_layer\": %.2f, \"TB_per_s\": %.3f}", f ? ", " : "", forms[f], us, layer_bytes / us * 1e-6);
+    out += buf;
+    std::fprintf(stderr, "%-28s %8.2f us / layer  %.3f TB/s\n", forms[f], us, layer_bytes / us * 1e-6);
   }
   unsigned flags[3] = {0, 0, 0};
   CHECK(hipMemcpy(flags, bar, sizeof flags, hipMemcpyDeviceToHost));
