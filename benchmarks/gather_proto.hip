@@ -160,6 +160,50 @@ int main(int argc, char** argv) {
       CHECK(hipGraphDestroy(graph));
     }
   }
+  // ---- the floor of a SHORT flat stream: what a launch that reads a weight matrix once can reach at best, by size --------------
+  out += "}, \"flat_stream_by_size\": {";
+  unsigned char* big;
+  const size_t big_bytes = size_t(2200) << 20;
+  CHECK(hipMalloc(&big, big_bytes));
+  CHECK(hipMemsetAsync(big, 0x5a, big_bytes, st));
+  CHECK(hipFree(sink));
+  CHECK(hipMalloc(&sink, sizeof(unsigned) * 17000 * kThreads));
+  const char* names[5] = {"o_proj_33.6MB", "qkv_proj_50.3MB", "down_proj_117.4MB", "gate_up_proj_234.9MB", "lm_head_1050.7MB"};
+  const long sizes[5] = {4096L * 4096 * 2, 6144L * 4096 * 2, 4096L * 14336 * 2, 28672L * 4096 * 2, 128256L * 4096 * 2};
+  for (int m = 0; m < 5; ++m) {
+    const long sz = sizes[m] / (2 * kWgBytes) * (2 * kWgBytes);
+    const int n_wg = static_cast<int>(sz / kWgBytes);
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+    const int launches = 8;
+    CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+    for (int l = 0; l < launches; ++l) {
+      const size_t off = (static_cast<size_t>(l) * 271 * (1 << 20)) % (big_bytes - sz) / 65536 * 65536;      // a different 271 MiB-stepped window per launch
+      Params p{big + off, big + off + sz / 2, nullptr, 0, sink};
+      hipLaunchKernelGGL(gather_kernel, dim3(n_wg), dim3(kThreads), 0, st, p);
+    }
+    CHECK(hipStreamEndCapture(st, &graph));
+    CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    for (int i = 0; i < 2; ++i) CHECK(hipGraphLaunch(exec, st));
+    CHECK(hipStreamSynchronize(st));
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a));
+    CHECK(hipEventCreate(&b));
+    const int reps = 10;
+    CHECK(hipEventRecord(a, st));
+    for (int i = 0; i < reps; ++i) CHECK(hipGraphLaunch(exec, st));
+    CHECK(hipEventRecord(b, st));
+    CHECK(hipStreamSynchronize(st));
+    float ms = 0.f;
+    CHECK(hipEventElapsedTime(&ms, a, b));
+    const double us = ms * 1e3 / (reps * launches);
+    char buf[256];
+    std::snprintf(buf, sizeof buf, "%s\"%s\": {\"us_per_launch\": %.2f, \"TB_per_s\": %.3f}", m ? ", " : "", names[m], us, sz / us * 1e-6);
+    out += buf;
+    std::fprintf(stderr, "flat %-22s %8.2f us  %.3f TB/s\n", names[m], us, sz / us * 1e-6);
+    CHECK(hipGraphExecDestroy(exec));
+    CHECK(hipGraphDestroy(graph));
+  }
   out += "}}";
   std::printf("%s\n", out.c_str());
   if (argc > 1) {
