@@ -465,6 +465,11 @@ int sgl_amd_debug_extend_attention_shape(int shape, int flags);
  * workgroup per (item, kv head) unit; above it a grid of loop_grid resident workgroups walks the device-built item list.
  * 0 restores a default (10240 / 1280).  Results are identical in both forms.  Not part of the reference surface. */
 int sgl_amd_debug_cascade_launch_form(int64_t single_shot_units, int64_t loop_grid);
+/* Test / tuning switch of the weight-streaming GEMM (process-wide; the library never reads the environment): bit 1 = the fp32
+ * split-K partials are stored with plain write-back stores instead of write-through ones (the default since round 6:
+ * profiles/r06_exp2_gemm_ab.json).  Results are identical.  flags < 0 only reads.  Returns the previous value.  Not part of the
+ * reference surface. */
+int sgl_amd_debug_wstream_flags(int flags);
 
 /* ---- row-tiled grouped GEMM for prefill-sized MoE batches (reference: fused_moe_triton_kernels.py:324,771 with
  *      BLOCK_SIZE_M >= 64; fused_experts, triton_utils/fused_moe.py:242-455) -------------------------------------

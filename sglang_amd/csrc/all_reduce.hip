@@ -86,7 +86,7 @@ __device__ __forceinline__ void st16_sys(__amdgpu_buffer_rsrc_t r, int64_t off, 
 __host__ __device__ __forceinline__ int two_stage_owner(int64_t block, int64_t k, int world) { return static_cast<int>((block + k) % world); }
 
 template <bool ACQUIRE = true>
-__device__ __forceinline__ void flag_barrier(const ArParams& p, uint32_t (Signal::*arr)[kMaxBlocks][kMaxWorld], uint32_t flag) {
+__device__ __forceinline__ void flag_barrier(const ArParams& p, uint32_t (Signal::*arr)[kMaxBlocks][kMaxWorld], uint32_t flag, bool release_fence) {
   // RELEASE.  What a peer reads from this rank lives in this rank's OWN workspace and was written with system-scope
   // (sc0 sc1) stores: they write through L2 to memory, so publishing them needs no cache write-back -- only their
   // completion.  Every wave waits for its own stores (s_waitcnt vmcnt(0): the wait the memory model prescribes ahead of a
@@ -94,7 +94,9 @@ __device__ __forceinline__ void flag_barrier(const ArParams& p, uint32_t (Signal
   // flag goes out.  (A system-scope release fence here also writes back every dirty L2 line of the device -- the
   // projection's output, the residual stream: 24 us of a 33 us two-stage launch at 256 rows, 1.5 ms of a TP 4 rank's
   // 5.8 ms decode step.  It stays available as the fallback: release_fence.)
-  if (reinterpret_cast<const Signal*>(p.peers.base[p.rank])->release_fence) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  // (`release_fence`: this rank's own setting, read ONCE per launch at kernel entry into a scalar register -- not by every thread
+  // ahead of every barrier)
+  if (release_fence) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const int t = threadIdx.x;
@@ -149,6 +151,7 @@ __global__ __launch_bounds__(kArThreads) void xgmi_one_shot_all_reduce_kernel(Ar
   __shared__ float scratch[16];
   Signal* self = reinterpret_cast<Signal*>(p.peers.base[p.rank]);
   const uint32_t flag = self->flag[blockIdx.x] + 1;
+  const bool rel = __builtin_amdgcn_readfirstlane(static_cast<int>(self->release_fence)) != 0;
   const int64_t nvec = p.numel / 8;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kArThreads;
   // phase 0: my copy
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(kArThreads) void xgmi_one_shot_all_reduce_kernel(Ar
       for (int c = threadIdx.x * 8; c < p.hidden; c += kArThreads * 8)
         st16_sys(mine, kDataOffset + (static_cast<int64_t>(r) * p.hidden + c) * 2, ld16(p.inp + static_cast<int64_t>(r) * p.hidden + c));
   }
-  flag_barrier(p, &Signal::start, flag);
+  flag_barrier(p, &Signal::start, flag, rel);
 
   if (p.epilogue == 0) {
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kArThreads + threadIdx.x; i < nvec; i += stride) {
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(kArThreads) void xgmi_one_shot_all_reduce_kernel(Ar
       }
     }
   }
-  flag_barrier<false>(p, &Signal::end, flag);
+  flag_barrier<false>(p, &Signal::end, flag, rel);
   if (threadIdx.x == 0) self->flag[blockIdx.x] = flag;
 }
 
@@ -244,6 +247,7 @@ __global__ __launch_bounds__(kArThreads) void xgmi_two_stage_all_reduce_kernel(A
   __shared__ float scratch[16];
   Signal* self = reinterpret_cast<Signal*>(p.peers.base[p.rank]);
   const uint32_t flag = self->flag[blockIdx.x] + 1;
+  const bool rel = __builtin_amdgcn_readfirstlane(static_cast<int>(self->release_fence)) != 0;
   const __amdgpu_buffer_rsrc_t mine = ws_rsrc(p.peers.base[p.rank], p.ws_bytes);   // copies at kDataOffset, sums at sums_offset
   if (p.epilogue == 0) {
     const int64_t nvec = p.numel / 8;
@@ -265,7 +269,7 @@ __global__ __launch_bounds__(kArThreads) void xgmi_two_stage_all_reduce_kernel(A
         if (c0 + u < nchunks && i < nvec) st16_sys(mine, kDataOffset + i * 16, v[u]);
       }
     }
-    flag_barrier(p, &Signal::start, flag);
+    flag_barrier(p, &Signal::start, flag, rel);
     int64_t k = 0;
     for (int64_t c0 = static_cast<int64_t>(blockIdx.x) * kUnroll; c0 < nchunks; c0 += step, ++k) {
       if (two_stage_owner(blockIdx.x, k, WORLD) != p.rank) continue;
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(kArThreads) void xgmi_two_stage_all_reduce_kernel(A
         }
       }
     }
-    flag_barrier(p, &Signal::mid, flag);
+    flag_barrier(p, &Signal::mid, flag, rel);
     k = 0;
     for (int64_t c0 = static_cast<int64_t>(blockIdx.x) * kUnroll; c0 < nchunks; c0 += step, ++k) {
       const __amdgpu_buffer_rsrc_t src = ws_rsrc(p.peers.base[two_stage_owner(blockIdx.x, k, WORLD)], p.ws_bytes);   // the chunks' owner
@@ -308,7 +312,7 @@ __global__ __launch_bounds__(kArThreads) void xgmi_two_stage_all_reduce_kernel(A
     for (int r = blockIdx.x; r < p.rows; r += gridDim.x)
       for (int c = threadIdx.x * 8; c < p.hidden; c += kArThreads * 8)
         st16_sys(mine, kDataOffset + (static_cast<int64_t>(r) * p.hidden + c) * 2, ld16(p.inp + static_cast<int64_t>(r) * p.hidden + c));
-    flag_barrier(p, &Signal::start, flag);
+    flag_barrier(p, &Signal::start, flag, rel);
     int j = 0;
     for (int r = blockIdx.x; r < p.rows; r += gridDim.x, ++j) {
       if (two_stage_owner(blockIdx.x, j, WORLD) != p.rank) continue;
@@ -326,7 +330,7 @@ __global__ __launch_bounds__(kArThreads) void xgmi_two_stage_all_reduce_kernel(A
         }
       }
     }
-    flag_barrier(p, &Signal::mid, flag);
+    flag_barrier(p, &Signal::mid, flag, rel);
     j = 0;
     for (int r = blockIdx.x; r < p.rows; r += gridDim.x, ++j) {
       const __amdgpu_buffer_rsrc_t src = ws_rsrc(p.peers.base[two_stage_owner(blockIdx.x, j, WORLD)], p.ws_bytes);   // the row's owner
@@ -372,7 +376,7 @@ __global__ __launch_bounds__(kArThreads) void xgmi_two_stage_all_reduce_kernel(A
       }
     }
   }
-  flag_barrier<false>(p, &Signal::end, flag);
+  flag_barrier<false>(p, &Signal::end, flag, rel);
   if (threadIdx.x == 0) self->flag[blockIdx.x] = flag;
 }
 
@@ -382,6 +386,7 @@ template <int WORLD>
 __global__ __launch_bounds__(kArThreads) void xgmi_all_gather_kernel(ArParams p) {
   Signal* self = reinterpret_cast<Signal*>(p.peers.base[p.rank]);
   const uint32_t flag = self->flag[blockIdx.x] + 1;
+  const bool rel = __builtin_amdgcn_readfirstlane(static_cast<int>(self->release_fence)) != 0;
   const int64_t nvec = p.numel / 8;                 // of one rank's shard [rows, hidden]
   const int64_t nchunks = (nvec + kArThreads - 1) / kArThreads;
   const int vpr = p.hidden / 8;                     // vectors per shard row
@@ -390,7 +395,7 @@ __global__ __launch_bounds__(kArThreads) void xgmi_all_gather_kernel(ArParams p)
     const int64_t i = c * kArThreads + threadIdx.x;
     if (i < nvec) st16_sys(mine, kDataOffset + i * 16, ld16(p.inp + i * 8));
   }
-  flag_barrier(p, &Signal::start, flag);
+  flag_barrier(p, &Signal::start, flag, rel);
   for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
     const int64_t i = c * kArThreads + threadIdx.x;
     if (i < nvec) {
@@ -403,7 +408,7 @@ __global__ __launch_bounds__(kArThreads) void xgmi_all_gather_kernel(ArParams p)
       for (int r = 0; r < WORLD; ++r) st16(p.out + row * (static_cast<int64_t>(p.hidden) * WORLD) + static_cast<int64_t>(r) * p.hidden + col, v[r]);
     }
   }
-  flag_barrier<false>(p, &Signal::end, flag);
+  flag_barrier<false>(p, &Signal::end, flag, rel);
   if (threadIdx.x == 0) self->flag[blockIdx.x] = flag;
 }
 

@@ -38,6 +38,7 @@ constexpr int kRowsPerItem = 64;  // (member, q head) rows per item: 4 waves x o
 constexpr float kNegBig = -1.0e30f;
 // launch-form policy of the chunk kernel (see cascade_chunk_kernel); process-wide tuning knobs behind
 // sgl_amd_debug_cascade_launch_form, like the extend kernel's shape switch
+constexpr int64_t kSingleShotHardCap = 16384;    // the largest value the switch below may take: what the plan clears for is decided against THIS, not the switch
 int64_t g_cascade_single_shot_units = 10240;   // worst-case workgroups up to which the one-workgroup-per-unit form is launched
 int64_t g_cascade_loop_grid = 256 * 5;         // grid of the looping form: 1280 beat 1024 (= what is resident at four per CU) and equalled 2048
 
@@ -491,7 +492,11 @@ int sgl_amd_cascade_plan(const int32_t* req_to_token, int64_t req_to_token_strid
   hipLaunchKernelGGL(cascade_plan_kernel, dim3(1), dim3(kPlanThreads), 0, as_stream(stream), req_to_token,
                      req_to_token_stride, req_pool_indices, seq_lens, static_cast<int>(batch), min_shared_len,
                      kChunk, members_per_item, 64, chunks * kChunk, plan, static_cast<int>(max_items),
-                     static_cast<int>(max_items < g_cascade_single_shot_units ? max_items : g_cascade_single_shot_units));
+                     // end-of-list markers for every item a one-workgroup-per-unit launch of THIS batch can reach (the attention entry's
+                     // own bound, batch x (chunks + 1)) whenever such a launch is possible at ANY setting of the launch-form switch --
+                     // the switch may change between the plan and the attention launches, or after graphs were captured
+                     static_cast<int>(batch * (chunks + 1) * num_kv_heads <= kSingleShotHardCap
+                                          ? (batch * (chunks + 1) < max_items ? batch * (chunks + 1) : max_items) : 0));
   SGL_CHECK_LAUNCH("cascade_plan");
   return 0;
 }
@@ -585,7 +590,8 @@ int sgl_amd_cascade_decode_attention_ex(const void* q, const void* k_cache, cons
 
 int sgl_amd_debug_cascade_launch_form(int64_t single_shot_units, int64_t loop_grid) {
   SGL_CLEAR_STALE_ERROR();
-  SGL_CHECK_ARG(single_shot_units >= 0 && loop_grid >= 0 && loop_grid <= (1 << 20), "debug_cascade_launch_form: bad arguments");
+  SGL_CHECK_ARG(single_shot_units >= 0 && single_shot_units <= kSingleShotHardCap && loop_grid >= 0 && loop_grid <= (1 << 20),
+                "debug_cascade_launch_form: single_shot_units must be 0..%lld, loop_grid 0..2^20", (long long)kSingleShotHardCap);
   g_cascade_single_shot_units = single_shot_units > 0 ? single_shot_units : 10240;
   g_cascade_loop_grid = loop_grid > 0 ? loop_grid : 256 * 5;
   return 0;

@@ -201,6 +201,8 @@ struct WsParams {
   int topk_div;                 // source row of pair id = id / topk_div
   int out_f32;                  // y is fp32 (the down projection ahead of moe_sum_reduce)
   int round_before_scale;       // round the accumulator to bf16 before the router weight (fused_moe_native.py:157-163)
+  int dbg;                      // sgl_amd_debug_wstream_flags(): bit 1 = plain (write-back) partial stores; forced for partial buffers of
+                                // 2 GiB and more (32-bit buffer offsets)
   int pair_silu;                // 1: two-tile waves, y[:, 16 t ..] = silu(tile t) * tile (t + ntiles/2) instead of two outputs;
                                 // 2: one-tile waves whose 16 weight rows are [8 gate rows | 8 up rows] of output columns 8 t .. 8 t + 7
 };
@@ -280,9 +282,10 @@ __global__ __launch_bounds__(64 * NW, 1) void wstream_gemm_kernel(WsParams p) {
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, g = lane >> 4;
   const int wtiles = p.ntiles / TPW;                    // tiles a wave index ranges over
-  const int tile = blockIdx.x * NW + wid;
+  const int bx = blockIdx.x, by = GROUPED ? 0 : blockIdx.y;
+  const int tile = bx * NW + wid;
   const bool active = tile < wtiles;
-  const int split = GROUPED ? 0 : blockIdx.y;
+  const int split = by;
   const int rb = GROUPED ? blockIdx.y : 0;              // row block (grouped form)
   const uint16_t* wbase = p.w;
   if constexpr (GROUPED) {
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(64 * NW, 1) void wstream_gemm_kernel(WsParams p) {
   // together they would otherwise all pull the same 256-byte column of their rows at the same moment, which the row
   // stride (a multiple of 8 KiB) maps onto a few memory channels (gate_up 46.5 -> 38.6 us).  Split-K launches already
   // start at `splits` different columns and measured 0.3-1 us slower staggered.
-  const int rot = p.splits == 1 && n > 1 ? static_cast<int>((static_cast<int64_t>(blockIdx.x) * n) / gridDim.x) : 0;
+  const int rot = p.splits == 1 && n > 1 ? static_cast<int>((static_cast<int64_t>(bx) * n) / gridDim.x) : 0;
   auto issue_w = [&](int c_rel, int slot) {
     if (c_rel < n) {
       const int cr = c_rel + rot < n ? c_rel + rot : c_rel + rot - n;
@@ -527,8 +530,14 @@ __global__ __launch_bounds__(64 * NW, 1) void wstream_gemm_kernel(WsParams p) {
     for (int t = 0; t < TPW; ++t) {                      // plain form: tile t of the wave is output tile `tile + t * wtiles`
       const int nn = n0 + t * wtiles * 16;
       if (!GROUPED && p.part) {
-        float* base = p.part + static_cast<int64_t>(split) * p.M * p.N;
-        *reinterpret_cast<f32x4_t*>(base + m * p.N + nn) = acc[t][mt];
+        const int64_t e = (static_cast<int64_t>(split) * p.M + m) * p.N + nn;
+        if (!(p.dbg & 2)) {   // write-through (sc1): the partials leave the L2 while the stream runs, not at the kernel boundary
+                              // (qkv 18.7 -> 17.0, o 15.2 -> 14.7, down 29.1 -> 28.6 us per GEMM + combine pair: profiles/r06_exp2_gemm_ab.json)
+          const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(p.part, 0, static_cast<int>(static_cast<int64_t>(p.splits) * p.M * p.N * 4), 0x00020000);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[t][mt]), r, static_cast<int>(e * 4), 0, 16);
+        } else {
+          *reinterpret_cast<f32x4_t*>(p.part + e) = acc[t][mt];
+        }
         continue;
       }
       float o[4];
@@ -715,7 +724,15 @@ int launch_nw(const WsParams& p, int nw, bool two_tiles, hipStream_t st, int row
 
 }  // namespace
 
+static int g_ws_debug_flags = 0;
+
 extern "C" {
+
+int sgl_amd_debug_wstream_flags(int flags) {
+  const int old = g_ws_debug_flags;
+  if (flags >= 0) g_ws_debug_flags = flags;
+  return old;
+}
 
 #ifdef WS_EXPERIMENT
 // benchmarks/r02_exp16_prefetch.py: read the bytes a following weight-streaming launch asks for first (the first `pd`
@@ -774,6 +791,8 @@ static int wstream_launch_main(const char* who, const void* x, const void* w, co
   p.M = static_cast<int>(M); p.N = static_cast<int>(N); p.K = static_cast<int>(K);
   p.splits = num_k_splits; p.ntiles = static_cast<int>(N / 16);
   p.pair_silu = fused_silu ? (two_tiles ? 1 : 2) : 0;
+  p.dbg = g_ws_debug_flags;
+  if (static_cast<int64_t>(num_k_splits) * M * N * 4 >= (int64_t{1} << 31)) p.dbg |= 2;
   int rc;
   switch (static_cast<int>((M + 15) / 16)) {
     case 1: rc = launch_nw<1>(p, waves_per_group, two_tiles, st); break;

@@ -4,7 +4,7 @@ Takes the place of `CustomAllreduce` (/root/reference/python/sglang/srt/distribu
 custom_all_reduce.py:40-340: buffer creation + IPC handle exchange :182-258, `should_custom_ar` :260-290, the
 dispatch :292-340) under `GroupCoordinator.all_reduce` (srt/distributed/parallel_state.py:648-758).
 
-One workspace per rank (32 KiB of flags + a data area for the largest message), allocated by the library as its own
+One workspace per communicator and rank (32 KiB of flags + a data area for the largest message), allocated by the library as its own
 uncached hipMalloc so that it can be exported; the 64-byte hipIpcMemHandles travel through the (CPU / gloo or RCCL)
 process group once, every rank maps every peer's workspace, and from then on a call is ONE kernel launch on the
 current stream with no host state -- it records into the decode hipGraph like any other kernel, no
@@ -33,6 +33,35 @@ def one_shot_limit(world: int, max_bytes: int) -> int:
     (world - 1) copies per rank where the two-stage one moves 2 (world - 1) / world, at the price of a third flag
     barrier (~2 us): 512 KiB at world 4, 256 KiB at world 8."""
     return max_bytes if world == 2 else min(max_bytes, 512 * 1024 if world == 4 else 256 * 1024)
+
+
+class _LaunchOrder:
+    def __init__(self, comm):
+        self.comm = comm
+
+    def __enter__(self):
+        c = self.comm
+        self.cur = torch.cuda.current_stream()
+        self.capturing = torch.cuda.is_current_stream_capturing()
+        last = c._last_stream
+        if last is not None and last != self.cur and c._last_captured == self.capturing:
+            if self.capturing:
+                # inside ONE capture the previous launch sits on another capturing stream: a fresh event recorded there is the edge
+                ev = torch.cuda.Event()
+                ev.record(last)
+                self.cur.wait_event(ev)
+            elif c._last_event is not None:
+                self.cur.wait_event(c._last_event)
+        return self
+
+    def __exit__(self, *exc):
+        c = self.comm
+        if not self.capturing:
+            if c._last_event is None:
+                c._last_event = torch.cuda.Event()
+            c._last_event.record(self.cur)
+        c._last_stream, c._last_captured = self.cur, self.capturing
+        return False
 
 
 class XgmiAllReduce:
@@ -95,6 +124,16 @@ class XgmiAllReduce:
             raise
         self._peers = peers                      # host array of device pointers (kept alive with the object)
         self.disabled = False
+        self._last_stream, self._last_event, self._last_captured = None, None, False
+
+    def _ordered(self):
+        """Stream ordering of THIS communicator's launches (every launch method runs under it, whoever the caller is: the
+        GroupCoordinator hooks, the fused decode layer, tests).  One data area and one set of monotonically increasing flag
+        counters: its launches are only correct one after the other.  On one stream that is program order; a launch arriving on
+        ANOTHER stream than the previous one first waits for an event recorded behind the previous launch -- eagerly, and inside a
+        stream capture too (alt-stream branches forked inside a captured forward: the event is recorded on the previous capturing
+        stream and becomes a graph edge).  An eager launch is never made to wait on a launch that was only captured."""
+        return _LaunchOrder(self)
 
     # custom_all_reduce.py:260-290 should_custom_ar
     def should_use(self, x: torch.Tensor) -> bool:
@@ -117,10 +156,11 @@ class XgmiAllReduce:
             if norm_weight is None or residual.shape != x.shape or not residual.is_contiguous():
                 raise ValueError("XgmiAllReduce.all_reduce: add_rmsnorm needs a contiguous residual of x's shape and norm_weight")
             epilogue = 1
-        native.call("sgl_amd_xgmi_one_shot_all_reduce", x.data_ptr(), out.data_ptr(), rows, hidden, self.rank, self.world,
-                    self._peers, self.ws_bytes, epilogue, residual.data_ptr() if residual is not None else None,
-                    norm_weight.data_ptr() if norm_weight is not None else None, float(eps), int(num_blocks),
-                    torch.cuda.current_stream().cuda_stream)
+        with self._ordered():
+            native.call("sgl_amd_xgmi_one_shot_all_reduce", x.data_ptr(), out.data_ptr(), rows, hidden, self.rank, self.world,
+                        self._peers, self.ws_bytes, epilogue, residual.data_ptr() if residual is not None else None,
+                        norm_weight.data_ptr() if norm_weight is not None else None, float(eps), int(num_blocks),
+                        torch.cuda.current_stream().cuda_stream)
         return out
 
     def should_use_two_stage(self, x: torch.Tensor) -> bool:
@@ -147,10 +187,11 @@ class XgmiAllReduce:
             if norm_weight is None or residual.shape != x.shape or not residual.is_contiguous() or hidden > 16384:
                 raise ValueError("XgmiAllReduce.two_stage_all_reduce: add_rmsnorm needs a contiguous residual of x's shape, norm_weight, hidden <= 16384")
             epilogue = 1
-        native.call("sgl_amd_xgmi_two_stage_all_reduce", x.data_ptr(), out.data_ptr(), x.numel() // hidden, hidden, self.rank, self.world,
-                    self._peers, self.ws_bytes, epilogue, residual.data_ptr() if residual is not None else None,
-                    norm_weight.data_ptr() if norm_weight is not None else None, float(eps), int(num_blocks),
-                    torch.cuda.current_stream().cuda_stream)
+        with self._ordered():
+            native.call("sgl_amd_xgmi_two_stage_all_reduce", x.data_ptr(), out.data_ptr(), x.numel() // hidden, hidden, self.rank, self.world,
+                        self._peers, self.ws_bytes, epilogue, residual.data_ptr() if residual is not None else None,
+                        norm_weight.data_ptr() if norm_weight is not None else None, float(eps), int(num_blocks),
+                        torch.cuda.current_stream().cuda_stream)
         return out
 
     def all_reduce_add_rmsnorm(self, x: torch.Tensor, residual: torch.Tensor, norm_weight: torch.Tensor, eps: float) -> torch.Tensor:
@@ -174,8 +215,9 @@ class XgmiAllReduce:
                 and self.fits_all_gather(x)):
             raise ValueError("XgmiAllReduce.all_gather: 2-D contiguous bf16 shard with cols % 8 == 0 that fits the workspace")
         out = torch.empty((x.shape[0], x.shape[1] * self.world), dtype=x.dtype, device=x.device)
-        native.call("sgl_amd_xgmi_all_gather", x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], self.rank, self.world, self._peers,
-                    self.ws_bytes, int(num_blocks), torch.cuda.current_stream().cuda_stream)
+        with self._ordered():
+            native.call("sgl_amd_xgmi_all_gather", x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], self.rank, self.world, self._peers,
+                        self.ws_bytes, int(num_blocks), torch.cuda.current_stream().cuda_stream)
         return out
 
     def arm(self, trap_on_timeout: bool = True) -> None:

@@ -157,6 +157,19 @@ def paged_allocator_class():
 
 
 # ------------------------------------------------------------------------------------------------ KV pool
+def _parameter_unbound(fn, name: str, args: tuple, kwargs: dict) -> bool:
+    """True when `fn(*args, **kwargs)` would leave the parameter `name` to its default (and `fn` has such a parameter)."""
+    import inspect
+
+    try:
+        sig = inspect.signature(fn)
+        if name not in sig.parameters:
+            return False
+        return name not in sig.bind_partial(*args, **kwargs).arguments
+    except (TypeError, ValueError):        # unbindable arguments: let the real call report them
+        return False
+
+
 def mha_kv_pool_class():
     """`current_platform.get_mha_kv_pool_cls()`: the reference's MHA pool (its buffers, layouts, accessors, PD / offload code
     untouched) whose `set_kv_buffer` is one launch of the gfx950 store kernel."""
@@ -176,7 +189,9 @@ def mha_kv_pool_class():
             # (kv_cache_configurator.py:1183-1199): no `enable_kv_cache_copy`, which its own pool gets as "a speculative algorithm is
             # configured" (:1660) -- without it `move_kv_cache` (the accepted-draft compaction of every verify step,
             # spec_utils.py:754) asserts.  Found by running NGRAM speculative decoding under the reference's scheduler (round 5).
-            if "enable_kv_cache_copy" not in kwargs and len(args) < 17:
+            # Injected only when the caller left the parameter UNBOUND -- decided against the base constructor's own signature, not an
+            # argument count (a caller passing it positionally must not get it a second time as a keyword).
+            if _parameter_unbound(base.__init__, "enable_kv_cache_copy", (self,) + args, kwargs):
                 try:
                     from sglang.srt.runtime_context import get_spec
 

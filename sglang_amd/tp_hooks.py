@@ -12,8 +12,9 @@ four methods -- and on `GroupCoordinator.__init__`, where the communicator is bu
                            it off) an XgmiAllReduce is attached -- IPC handles exchanged over the group's OWN gloo group
                            (`cpu_group`), proved against the group's OWN RCCL group (`device_group`) by the start-up
                            self-test and dropped on EVERY rank together if any rank fails (parallel_state.start_xgmi);
-                           groups over the same ranks (tp / attention_tp / moe_tp of a plain TP launch) share one
-                           (its launches are serialised across streams: `_one_stream_at_a_time`)
+                           every group gets its OWN communicator (workspace + flag counters), as the reference's `ca_comm`;
+                           launches of one communicator from two streams are ordered by the communicator itself
+                           (`XgmiAllReduce._ordered`, eagerly and inside captures)
   all_reduce               bf16 messages up to 64 MiB: one launch on the current stream (one-shot below the reference's
                            switch points, custom_all_reduce.py:260-307, two-stage above), graph-capturable; everything
                            else -- and every group without a communicator -- is the reference's method, untouched
@@ -36,7 +37,7 @@ import torch
 XGMI_ATTR = "_sgl_amd_xgmi"
 # group names of srt/distributed/parallel_state.py:2451-2672 whose all-reduces sit on the decode path
 GROUP_NAMES = ("tp", "attention_tp", "moe_tp", "moe_ep")
-_BY_RANKS = {}            # tuple(ranks) -> communicator: groups over the same ranks share one workspace
+_COMMS = []               # every communicator built here (close_all)
 
 _P = "sglang.srt.distributed.parallel_state.GroupCoordinator."
 HOOK_TARGETS = (_P + "__init__", _P + "all_reduce", _P + "fused_allreduce_rmsnorm", _P + "all_gather")
@@ -58,14 +59,15 @@ def attach(group):
                 or torch.device(dev).type != "cuda" or _group_base_name(group) not in GROUP_NAMES
                 or getattr(group, "cpu_group", None) is None or getattr(group, "device_group", None) is None):
             return None
-        key = tuple(getattr(group, "ranks", ()) or ())
-        comm = _BY_RANKS.get(key) if key else None
-        if comm is None:
-            from .distributed.parallel_state import start_xgmi
+        # ONE communicator per GroupCoordinator -- its own workspace and flag counters, as the reference gives every group its own
+        # `ca_comm` (parallel_state.py:405-470): groups over the same ranks (tp / attention_tp / moe_tp of a plain TP launch) may then
+        # run on different streams, or in different branches of one capture, without sharing a byte.  (Rounds 4-5 shared one
+        # communicator per rank set and serialised its launches; 128 MiB of workspace per group is the price of not doing that.)
+        from .distributed.parallel_state import start_xgmi
 
-            comm = start_xgmi(group.cpu_group, group.device_group, int(group.rank_in_group), world, torch.device(dev))
-            if key and comm is not None:
-                _BY_RANKS[key] = comm
+        comm = start_xgmi(group.cpu_group, group.device_group, int(group.rank_in_group), world, torch.device(dev))
+        if comm is not None:
+            _COMMS.append(comm)
         setattr(group, XGMI_ATTR, comm)
         return comm
     except Exception as e:                         # noqa: BLE001 -- the reference's own collectives remain
@@ -96,39 +98,6 @@ def _takes(comm, x: torch.Tensor) -> bool:
     return comm is not None and isinstance(x, torch.Tensor) and (comm.should_use(x) or comm.should_use_two_stage(x))
 
 
-class _one_stream_at_a_time:
-    """Groups over the same ranks share ONE communicator: one data area and one set of monotonically increasing flag counters.
-    Its launches are therefore only correct one after the other.  On one stream that is program order; a launch arriving on
-    ANOTHER stream than the previous one (an alt-stream shared-expert branch, two-batch overlap, two groups driven from two
-    streams) first waits for an event recorded behind the previous launch, so the two never overlap -- the reference gives every
-    GroupCoordinator its own `ca_comm` instead (parallel_state.py:405-470), this package trades that for one workspace per rank
-    set.  Inside a stream capture nothing is recorded or waited on: a captured decode step is a single-stream graph, and an event
-    recorded outside a capture must not be waited on inside one."""
-
-    def __init__(self, comm):
-        self.comm = comm
-
-    def __enter__(self):
-        self.capturing = (not torch.cuda.is_available()) or torch.cuda.is_current_stream_capturing()
-        if self.capturing:
-            return self
-        cur = torch.cuda.current_stream()
-        last = getattr(self.comm, "_sgl_last_stream", None)
-        if last is not None and last != cur:
-            cur.wait_event(self.comm._sgl_last_event)
-        self.cur = cur
-        return self
-
-    def __exit__(self, *exc):
-        if not self.capturing:
-            ev = getattr(self.comm, "_sgl_last_event", None)
-            if ev is None:
-                ev = self.comm._sgl_last_event = torch.cuda.Event()
-            ev.record(self.cur)
-            self.comm._sgl_last_stream = self.cur
-        return False
-
-
 # ---- the hooks: HookType.AROUND = hook(original_fn, *args, **kwargs) ------------------------------------------------
 def group_init_hook(original, self, *args, **kwargs):
     original(self, *args, **kwargs)
@@ -138,8 +107,7 @@ def group_init_hook(original, self, *args, **kwargs):
 def group_all_reduce_hook(original, self, input_):
     comm = communicator_of(self)
     if comm is not None and self.world_size > 1 and not torch.compiler.is_compiling() and _takes(comm, input_):
-        with _one_stream_at_a_time(comm):
-            return comm.all_reduce_any(input_)
+        return comm.all_reduce_any(input_)
     return original(self, input_)
 
 
@@ -152,8 +120,7 @@ def group_fused_allreduce_rmsnorm_hook(original, self, input_, residual_inp_, we
         # `residual_inp_` is updated IN PLACE and handed back as the residual output: the one caller
         # (layernorm.py:198-245 `_forward_with_allreduce_fusion`) returns the pair as its (hidden, residual) and never reads
         # its own `residual` again -- a caller that kept using the tensor it passed in would see it changed
-        with _one_stream_at_a_time(comm):
-            out = comm.all_reduce_add_rmsnorm(input_, residual_inp_, weight_, float(eps))
+        out = comm.all_reduce_add_rmsnorm(input_, residual_inp_, weight_, float(eps))
         return out, residual_inp_
     return original(self, input_, residual_inp_, weight_, eps)
 
@@ -164,8 +131,7 @@ def group_all_gather_hook(original, self, input_, dim=-1, output_tensor_list=Non
             and isinstance(input_, torch.Tensor) and input_.is_cuda and input_.dim() == 2 and dim in (-1, 1)
             and input_.dtype == torch.bfloat16 and input_.shape[1] % 8 == 0 and not comm.disabled
             and comm.fits_all_gather(input_)):
-        with _one_stream_at_a_time(comm):
-            return comm.all_gather(input_.contiguous())
+        return comm.all_gather(input_.contiguous())
     return original(self, input_, dim, output_tensor_list)
 
 
@@ -181,9 +147,9 @@ def install(registry, hook_type_around) -> None:
 
 def close_all() -> None:
     """Process shutdown / tests: unmap and free every communicator built here."""
-    for comm in list(_BY_RANKS.values()):
+    for comm in list(_COMMS):
         try:
             comm.close()
         except Exception:
             pass
-    _BY_RANKS.clear()
+    _COMMS.clear()

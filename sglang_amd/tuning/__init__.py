@@ -12,6 +12,7 @@ from pathlib import Path
 
 RESULTS = Path(__file__).resolve().parent / "tunableop_gfx950.csv"
 _loaded = False
+STATUS = "not asked"       # what happened, in words: the log and the reference-stack reports (`plugin_counts.gemm_selections`) carry it
 
 
 def load_gemm_selections() -> bool:
@@ -22,10 +23,12 @@ def load_gemm_selections() -> bool:
         return True
     import torch
 
-    if os.environ.get("SGLANG_AMD_TUNABLEOP", "1") == "0" or not torch.cuda.is_available() or not RESULTS.exists():
-        return False
+    if os.environ.get("SGLANG_AMD_TUNABLEOP", "1") == "0":
+        return _report("off (SGLANG_AMD_TUNABLEOP=0): library default selections")
+    if not torch.cuda.is_available() or not RESULTS.exists():
+        return _report("off (no GPU / no committed selections)")
     if os.environ.get("PYTORCH_TUNABLEOP_TUNING") == "1":
-        return False                      # a tuning run (benchmarks/tune_gemms.py) is in control
+        return _report("off (a TunableOp tuning run is in control)")      # benchmarks/tune_gemms.py
     try:
         import tempfile
 
@@ -39,6 +42,20 @@ def load_gemm_selections() -> bool:
         _loaded = bool(ok)
         if not ok:
             tun.enable(False)
-        return _loaded
-    except Exception:                     # an older / newer TunableOp API: keep the library defaults
-        return False
+            return _report(f"REJECTED by TunableOp's validators ({RESULTS.name} does not match this PyTorch / ROCm / GPU): library default selections")
+        n = sum(1 for line in RESULTS.read_text().splitlines() if line and not line.startswith("Validator"))
+        _report(f"loaded ({n} GEMM selections from {RESULTS.name}, lookup only; process-wide: every torch matmul of the listed shapes; "
+                "SGLANG_AMD_TUNABLEOP=0 turns it off)")
+        return True
+    except Exception as e:                # an older / newer TunableOp API: keep the library defaults    # noqa: BLE001
+        return _report(f"off ({type(e).__name__}: {e})")
+
+
+def _report(what: str) -> bool:
+    """One log line per process about the GEMM selections (a rejected file would otherwise be a silent slowdown)."""
+    global STATUS
+    STATUS = what
+    import logging
+
+    logging.getLogger("sglang_amd").info("library-GEMM selections: %s", what)
+    return False

@@ -1663,10 +1663,10 @@ def _install_spec_standins(ns) -> None:
 
 def _plugin_counts() -> dict:
     """What the plug-in's own counters saw in this process (whole process: warm-up + timed job + capture)."""
-    from sglang_amd import mem_hooks
+    from sglang_amd import mem_hooks, tuning
     from sglang_amd.layers import layernorm
 
-    return dict(mem_hooks=dict(mem_hooks.counts), rmsnorm=dict(layernorm.served))
+    return dict(mem_hooks=dict(mem_hooks.counts), rmsnorm=dict(layernorm.served), gemm_selections=tuning.STATUS)
 
 
 def _count_triton_launches() -> list:

@@ -100,9 +100,22 @@ def _worker(rank, world, port, q):
         grp = GC([list(range(world))], 0, "gloo", False, False, True, False, False, False, False, group_name="tp")
         comm = tp_hooks.communicator_of(grp)
         assert comm is not None, "no communicator was attached to a 2-rank GPU group built with use_custom_allreduce"
-        # a second group over the same ranks (attention_tp of a plain TP launch) shares the workspace
+        # a second group over the same ranks (attention_tp of a plain TP launch) gets a communicator of its OWN -- workspace and
+        # flag counters -- as the reference gives every group its own ca_comm (parallel_state.py:405-470); both work, interleaved
         grp2 = GC([list(range(world))], 0, "gloo", False, False, True, False, False, False, False, group_name="attention_tp")
-        assert tp_hooks.communicator_of(grp2) is comm
+        comm2 = tp_hooks.communicator_of(grp2)
+        assert comm2 is not None and comm2 is not comm and comm2._own != comm._own
+        for i in range(3):
+            xs = _inputs(world, 64, 4096, 40 + i)
+            want = torch.stack([x.float() for x in xs]).sum(0).to(torch.bfloat16)
+            s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+            torch.cuda.synchronize()
+            with torch.cuda.stream(s1):
+                got1 = grp.all_reduce(xs[rank].to(dev).clone())
+            with torch.cuda.stream(s2):
+                got2 = grp2.all_reduce(xs[rank].to(dev).clone())
+            torch.cuda.synchronize()
+            assert torch.equal(got1.cpu(), want) and torch.equal(got2.cpu(), want), i
         # a group built WITHOUT the hint keeps the reference's collectives
         plain = GC([list(range(world))], 0, "gloo", False, False, False, False, False, False, False, group_name="tp")
         assert tp_hooks.communicator_of(plain) is None
@@ -259,34 +272,72 @@ def test_hooked_group_coordinator_two_processes_one_gpu(device):
                 p.kill()
 
 
-def test_launches_of_a_shared_communicator_are_serialised_across_streams(device):
-    """groups over the same ranks share one communicator (one data area, one set of flag counters), so two of its
-    launches must never overlap.  The hooks wrap every launch in `_one_stream_at_a_time`: a launch that arrives on another stream
-    than the previous one waits for an event recorded behind that one.  Observed here with a stand-in communicator: stream B's
-    "launch" reads what stream A's "launch" writes behind a long sleep -- it sees the value only if it waited."""
+def test_launches_of_one_communicator_are_ordered_across_streams(device):
+    """a communicator has one data area and one set of flag counters, so two of its launches must
+    never overlap.  Since round 6 every GroupCoordinator has its OWN communicator and the ordering lives in the communicator itself
+    (`XgmiAllReduce._ordered`, around every launch whoever the caller is -- hooks, the fused decode layer): a launch that arrives on
+    another stream than the previous one waits for an event recorded behind that one.  Observed here with a stand-in communicator:
+    stream B's "launch" reads what stream A's "launch" writes behind a long sleep -- it sees the value only if it waited."""
     import types
 
     import torch
 
-    from sglang_amd import tp_hooks
+    from sglang_amd.distributed.xgmi_all_reduce import _LaunchOrder
 
-    comm = types.SimpleNamespace()
+    comm = types.SimpleNamespace(_last_stream=None, _last_event=None, _last_captured=False)
     x = torch.zeros(1, device=device)
     a, b = torch.cuda.Stream(device), torch.cuda.Stream(device)
     torch.cuda.synchronize()
     with torch.cuda.stream(a):
-        with tp_hooks._one_stream_at_a_time(comm):
+        with _LaunchOrder(comm):
             torch.cuda._sleep(200_000_000)            # ~0.1 s of spinning ahead of the write
             x.fill_(1.0)
     with torch.cuda.stream(b):
-        with tp_hooks._one_stream_at_a_time(comm):
+        with _LaunchOrder(comm):
             y = x.clone()
     torch.cuda.synchronize()
     assert float(y) == 1.0, "stream B's launch did not wait for stream A's"
-    assert comm._sgl_last_stream == b
+    assert comm._last_stream == b
     # same stream again: no wait is needed, the event just moves on
     with torch.cuda.stream(b):
-        with tp_hooks._one_stream_at_a_time(comm):
+        with _LaunchOrder(comm):
             x.add_(1.0)
     torch.cuda.synchronize()
     assert float(x) == 2.0
+
+
+def test_launches_of_one_communicator_are_ordered_inside_a_capture(device):
+    """The same inside ONE stream capture (the reference forks alt streams inside captured forwards for some models): a launch
+    on a forked capturing stream gets a graph edge from the previous launch's stream; an eager launch afterwards does not wait
+    on anything that was only captured."""
+    import types
+
+    import torch
+
+    from sglang_amd.distributed.xgmi_all_reduce import _LaunchOrder
+
+    comm = types.SimpleNamespace(_last_stream=None, _last_event=None, _last_captured=False)
+    x = torch.zeros(1, device=device)
+    y = torch.zeros(1, device=device)
+    side = torch.cuda.Stream(device)
+    g = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g):
+        main = torch.cuda.current_stream()
+        with _LaunchOrder(comm):
+            torch.cuda._sleep(100_000_000)
+            x.fill_(3.0)
+        side.wait_stream(main)                        # fork
+        with torch.cuda.stream(side):
+            with _LaunchOrder(comm):                  # previous launch was on `main`: an event edge, not a race
+                y.copy_(x)
+        main.wait_stream(side)                        # join
+    x.zero_(); y.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert float(y) == 3.0
+    assert comm._last_captured is True
+    with _LaunchOrder(comm):                          # eager, after a capture: nothing to wait for, must not raise
+        x.add_(1.0)
+    torch.cuda.synchronize()
+    assert float(x) == 4.0 and comm._last_captured is False
