@@ -1178,7 +1178,7 @@ def run_shared_prefix_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=1
 
 
 def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, unique=8, out=4, overlap=False, server_args=None,
-                      logprobs=False, spec_ngram=0, sampling=None) -> dict:
+                      logprobs=False, spec_ngram=0, sampling=None, spec_tree=False) -> dict:
     """The reference's `Scheduler` ITSELF (managers/scheduler.py: request intake, `PrefillAdder`, the real radix cache built by
     `kv_cache_builder`, running-batch merge, `TpModelWorker` -> `ModelRunner`, result processing, output streaming) with the body of
     its `event_loop_normal` (scheduler.py:1748-1780) executed here step by step instead of behind zmq sockets (zmq is not in this
@@ -1209,6 +1209,8 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
         # N draft tokens per request under a tree mask (ngram_worker.py:310-397), captured by the reference's graph runner in that mode
         assert real_weights, "the scripted drafter needs the oracle's greedy continuation: small real-weight models only"
         _install_spec_standins(ns)
+        SPEC_OPTS["tree"] = bool(spec_tree)
+        del SPEC_VERIFY[:]
         server_args = dict(server_args or {}, speculative_algorithm="NGRAM", speculative_num_draft_tokens=int(spec_ngram))
     if not gpu:
         from sglang.kernels import fused_op as FO
@@ -1321,6 +1323,12 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
             pend, capture["pending"] = capture["pending"], None
             lo = getattr(res, "logits_output", None)
             lg = getattr(lo, "next_token_logits", None)
+            if capture.get("spec") and nm == "TARGET_VERIFY" and lg is not None and SPEC_VERIFY and SPEC_VERIFY[-1]["logits"] is None:
+                # [requests x draft nodes, vocab]: row (b, j) scores the token after node j's path (logits_processor: every
+                # position of a verify forward is kept); joined with the host-side record of the draft it belongs to
+                nrow = sum(len(q_["draft"]) for q_ in SPEC_VERIFY[-1]["requests"])
+                if lg.shape[0] >= nrow:
+                    SPEC_VERIFY[-1]["logits"] = lg[:nrow].float().cpu()
             if capture["on"] and pend is not None and lg is not None and lg.shape[0] >= len(pend):
                 lg = lg[: len(pend)].float().cpu()
                 for i, (rid, t) in enumerate(pend):
@@ -1409,13 +1417,15 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
         before = dict(counts)
         del triton_launches[:]
         prof_path = os.environ.get("REF_SCHED_CPROFILE")
-        capture["on"] = real_weights and not spec_ngram           # (a verify forward scores N rows per request: filed differently, not compared here)
+        capture["on"] = real_weights and not spec_ngram           # (a verify forward scores N rows per request: filed through SPEC_VERIFY)
+        capture["spec"] = bool(real_weights and spec_ngram)
+        del SPEC_VERIFY[:]
         modes_seen.clear()
         if prof_path:
             timed = _profiled(lambda: job("timed"), prof_path)
         else:
             timed = job("timed")
-        capture["on"] = False
+        capture["on"] = capture["spec"] = False
     triton_in_timed = sorted(set(triton_launches))
     rep = dict(mode="scheduler-job", event_loop="overlap" if overlap else "normal", server_args=server_args or {}, page_size=int(sch.page_size),
                chunked_prefill_size=sa.chunked_prefill_size, dims=dims_name, device=str(runner.device), scheduler=type(sch).__name__, tree_cache=type(sch.tree_cache).__name__,
@@ -1499,6 +1509,8 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
                                 product_max_err=float(e_p.abs().max()), reference_max_err=float(e_r.abs().max()),
                                 clear_rows=int(clear.sum()), argmax_agree_on_clear_rows=int((G_.argmax(-1) == A_.argmax(-1))[clear].sum()))
                 rep["logit_band"] = band
+        if spec_ngram:
+            rep["spec"]["logit_band"] = spec_logit_band(dims_name, runner, gpu, moe=arch == "mixtral")
         if sampling and capture["rows"]:
             # sampled tokens are not the oracle's greedy tokens; what must hold: every token the scheduler delivered lies inside the
             # top-k set of the very logits row it was sampled from (captured from the forward that produced it)
@@ -1531,8 +1543,145 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
     return rep
 
 
+def spec_logit_band(dims_name, runner, gpu, moe=False) -> dict:
+    """Every TARGET_VERIFY forward's logits against the oracle under the tree mask (triton_backend.py:860-919,
+    ngram_worker.py:310-397).  Row (request b, draft node j) of a verify forward scores the token that follows
+    `tokens[:-1] + path(j)` -- the request's verified sequence (whose last token is draft node 0, not yet in the KV cache) extended by
+    node j's ancestors-and-self in tree order.  The oracle evaluates every such sequence from scratch (one prefill, last position), literally
+    in bf16 and accumulating in fp32; the bars are the scheduler tests' own: the plug-in's error against the fp32-accumulating oracle
+    inside the band of the reference's literal evaluation against the same oracle.  Rows of REJECTED branches are scored like any
+    other (their logits were computed under the mask too).  Sparse-MoE models: rows whose own draft path contains a token with a near-tie
+    (2 bf16 ulps) between the last chosen and the first unchosen expert in any layer, or on which the two oracles already route
+    differently, are `flip_prone`; the per-logit bar is taken over the other rows."""
+    from oracle.model import OracleLM
+
+    seqs, where = [], []
+    records = [v for v in SPEC_VERIFY]
+    expected = sum(len(q["draft"]) for v in records for q in v["requests"])
+    for vi, v in enumerate(records):
+        if v["logits"] is None:
+            continue
+        row = 0
+        for q in v["requests"]:
+            n = len(q["draft"])
+            assert q["draft"][0] == q["tokens"][-1], "draft node 0 must be the request's last verified token"
+            for j in range(n):
+                path = [q["draft"][i] for i in range(j + 1) if q["mask"][j][i]]
+                seqs.append(tuple(q["tokens"][:-1] + path))
+                where.append((vi, row + j, sum(q["mask"][j]) - 1, j))
+            row += n
+    if not seqs:
+        return dict(rows_compared=0, rows_expected=expected)
+    uniq = sorted(set(seqs))
+    index = {sq: i for i, sq in enumerate(uniq)}
+    dev = runner.device
+    max_len = max(len(sq) for sq in uniq)
+
+    def evaluate(**kw):
+        out_rows, traces = [], []
+        for c0 in range(0, len(uniq), 48):                                  # (request slots of one oracle instance)
+            chunk = [list(sq) for sq in uniq[c0: c0 + 48]]
+            o_ = OracleLM(oracle_config(dims_name, 8192), oracle_weights(runner.model), num_slots=sum(map(len, chunk)) + 64,
+                          max_ctx=max_len + 8, max_reqs=len(chunk), device=dev, **kw)
+            if moe:
+                o_.trace = []
+            out_rows.append(o_.generate(chunk, 1, return_logits=True)[1][0].float().cpu())
+            if moe:
+                lens = [len(c) for c in chunk]
+                traces.append((lens, [(l_["router_logits"].float().cpu(), l_["topk_ids"].cpu()) for l_ in o_.trace[0]["layers"]]))
+        return torch.cat(out_rows), traces
+
+    lit, tr_lit = evaluate()
+    acc, tr_acc = evaluate(compute_dtype=torch.float32) if gpu else (None, None)
+    G_ = torch.stack([records[vi]["logits"][r] for vi, r, _, _ in where])
+    L_ = torch.stack([lit[index[sq]] for sq in seqs])
+    band = dict(rows_compared=len(seqs), rows_expected=expected, distinct_sequences=len(uniq), verify_forwards=len(records),
+                rows_by_depth={str(d_): sum(1 for w_ in where if w_[2] == d_) for d_ in sorted(set(w_[2] for w_ in where))},
+                identical_to_the_literal_oracle=bool(torch.equal(G_, L_)), max_abs_vs_literal=float((G_ - L_).abs().max()),
+                logit_rms=float(L_.pow(2).mean().sqrt()))
+    if acc is not None:
+        A_ = torch.stack([acc[index[sq]] for sq in seqs])
+        e_p, e_r = G_ - A_, L_ - A_
+        top2 = A_.topk(2, dim=-1).values
+        clear = (top2[:, 0] - top2[:, 1]) > 16 * 2.0 ** -8 * top2[:, 0].abs().clamp_min(1.0)
+        band.update(product_rms_err=float(e_p.pow(2).mean().sqrt()), reference_rms_err=float(e_r.pow(2).mean().sqrt()),
+                    product_max_err=float(e_p.abs().max()), reference_max_err=float(e_r.abs().max()),
+                    clear_rows=int(clear.sum()), argmax_agree_on_clear_rows=int((G_.argmax(-1) == A_.argmax(-1))[clear].sum()))
+        row_rms = e_p.pow(2).mean(-1).sqrt()
+        worst = row_rms.argsort(descending=True)[:6].tolist()
+        band["worst_rows"] = [dict(verify_forward=where[i][0], row=where[i][1], depth=where[i][2], node=where[i][3], rms_err=float(row_rms[i]),
+                                   reference_rms_err=float(e_r[i].pow(2).mean().sqrt())) for i in worst]
+        per_fwd = []
+        for vi, v in enumerate(records):
+            if v["logits"] is None:
+                continue
+            rows_v = [i for i, w_ in enumerate(where) if w_[0] == vi]
+            n_ = len(v["requests"][0]["draft"])
+            per_fwd.append(dict(forward=vi, requests=[q["rid"] for q in v["requests"]], lens=[len(q["tokens"]) for q in v["requests"]],
+                                shapes=["chain" if all(all(q["mask"][a][b_] for b_ in range(a + 1)) for a in range(n_)) else "tree" for q in v["requests"]],
+                                rms_err_per_request=[round(float(e_p[rows_v[k * n_: (k + 1) * n_]].pow(2).mean().sqrt()), 4) for k in range(len(v["requests"]))]))
+        band["per_forward"] = per_fwd
+        if moe:
+            prone_u, c0 = set(), 0
+            k_top = int(tr_acc[0][1][0][1].shape[-1])
+            tail = {}
+            for sq, w_ in zip(seqs, where):
+                tail[index[sq]] = max(tail.get(index[sq], 0), w_[2] + 1)                            # the draft path: depth + 1 tokens
+            for (lens, la), (_, ll) in zip(tr_acc, tr_lit):
+                owner = torch.repeat_interleave(torch.arange(len(lens)), torch.tensor(lens))       # token row -> its sequence in the chunk
+                # only the tokens THIS forward evaluated (the node's own path) count: the shared prompt's tokens sit in every
+                # sequence and were routed by earlier forwards; their flips reach a verify row through the KV cache only
+                in_tail = torch.cat([torch.arange(n_) >= n_ - tail[c0 + i] for i, n_ in enumerate(lens)])
+                for (rl_a, ti_a), (_, ti_l) in zip(la, ll):
+                    # a near-tie between the last chosen and the first unchosen expert: within 2 bf16 ulps of the router logits' scale
+                    srt = rl_a.sort(dim=-1, descending=True).values
+                    tie = (srt[:, k_top - 1] - srt[:, k_top]) <= 2 * 2.0 ** -8 * srt[:, 0].abs().clamp_min(1e-3)
+                    differ = (ti_a.sort(-1).values != ti_l.sort(-1).values).any(-1)
+                    prone_u.update((owner[(tie | differ) & in_tail] + c0).tolist())
+                c0 += len(lens)
+            keep = torch.tensor([index[sq] not in prone_u for sq in seqs])
+            band.update(flip_prone_rows=int((~keep).sum()), rows_without_flip_risk=int(keep.sum()))
+            if keep.any():
+                band.update(product_max_err_no_flip=float(e_p[keep].abs().max()), reference_max_err_no_flip=float(e_r[keep].abs().max()),
+                            product_rms_err_no_flip=float(e_p[keep].pow(2).mean().sqrt()), reference_rms_err_no_flip=float(e_r[keep].pow(2).mean().sqrt()))
+    return band
+
+
 SPEC_TRUTH = []          # scripted drafter: whole token sequences (prompt + the oracle's greedy continuation) of the running job
-SPEC_STATS = dict(lookups=0, matched=0, drafted_true_tokens=0)
+SPEC_STATS = dict(lookups=0, matched=0, drafted_true_tokens=0, tree_drafts=0, chain_drafts=0)
+SPEC_OPTS = dict(tree=False)     # tree=True: the drafter also proposes WRONG branches (breadth 2) so that rejected siblings are walked
+SPEC_VERIFY = []         # one record per verify forward of the timed job: what was drafted (host side) -- the captured logits join it
+
+
+def spec_tree_patterns(n: int):
+    """Ancestor-or-self masks of the scripted drafter's draft shapes over n nodes (node 0 = the last verified token), as
+    (name, mask [n][n], true_depth [n], wrong [n]): node i carries the TRUE continuation token number true_depth[i] (1-based) of its
+    own path, or -- wrong[i] -- a corrupted token at that depth.  Nodes are in BFS order (siblings adjacent, parents first), the
+    order the n-gram corpus emits (ngram_corpus.py:94-110).
+      chain           0 - 1 - 2 - ... (one of them corrupted by the caller)
+      wrong-first     0 -> {1: WRONG t1, 2: t1}, 2 -> 3: t2, 3 -> 4 ...      the walk must step over a wrong FIRST sibling
+      wrong-second    0 -> {1: t1, 2: WRONG t1}, 1 -> 3: t2, 3 -> 4 ...      a rejected sibling beside the accepted one"""
+    import numpy as np
+
+    def build(parents):
+        m = np.zeros((n, n), dtype=np.int64)
+        for i in range(n):
+            j = i
+            while j >= 0:
+                m[i, j] = 1
+                j = parents[j]
+        return m
+
+    out = []
+    if n >= 3:
+        # wrong-first: parents 0:-1, 1:0, 2:0, 3:2, 4:3 ...
+        par = [-1, 0, 0] + [i - 1 if i > 3 else 2 for i in range(3, n)]
+        depth = [0, 1, 1] + [i - 1 for i in range(3, n)]
+        out.append(("wrong-first", build(par), depth, [False, True, False] + [False] * (n - 3)))
+        # wrong-second: parents 0:-1, 1:0, 2:0, 3:1, 4:3 ...
+        par = [-1, 0, 0] + [1 if i == 3 else i - 1 for i in range(3, n)]
+        out.append(("wrong-second", build(par), depth, [False, False, True] + [False] * (n - 3)))
+    return out
 
 
 def _install_spec_standins(ns) -> None:
@@ -1575,17 +1724,29 @@ def _install_spec_standins(ns) -> None:
                 tail, total = list(tail), int(total)
                 draft = [tail[-1]] + [7 + (total + 3 * i) % 5 for i in range(1, n)]            # no match: junk (all rejected)
                 SPEC_STATS["lookups"] += 1
+                mask[b] = np.tril(np.ones((n, n), dtype=np.int64))                             # a chain: node i's ancestors are 0..i
+                trees = spec_tree_patterns(n) if SPEC_OPTS["tree"] else []
                 for seq in SPEC_TRUTH:
                     if len(seq) >= total and seq[total - len(tail): total] == tail:
                         cont = seq[total: total + n - 1]
-                        wrong = 1 + total % n                                                  # 1..n: index n = nothing corrupted
-                        for i, t in enumerate(cont, start=1):
-                            draft[i] = t if i != wrong else (t + 1) % 1000 + 3
+                        shape = SPEC_STATS["matched"] % (len(trees) + 1)                       # chain, wrong-first, wrong-second in turn
+                        if shape == 0 or len(cont) < n - 2 or not trees:
+                            wrong = 1 + total % n                                              # 1..n: index n = nothing corrupted
+                            for i, t in enumerate(cont, start=1):
+                                draft[i] = t if i != wrong else (t + 1) % 1000 + 3
+                            SPEC_STATS["drafted_true_tokens"] += min(len(cont), wrong - 1)
+                            SPEC_STATS["chain_drafts"] += 1
+                        else:
+                            _, tm, depth, wrong_node = trees[shape - 1]
+                            for i in range(1, n):
+                                t = cont[depth[i] - 1]
+                                draft[i] = (t + 1) % 1000 + 3 if wrong_node[i] else t
+                            mask[b] = tm
+                            SPEC_STATS["drafted_true_tokens"] += max(depth)                    # the whole true path is on offer
+                            SPEC_STATS["tree_drafts"] += 1
                         SPEC_STATS["matched"] += 1
-                        SPEC_STATS["drafted_true_tokens"] += min(len(cont), wrong - 1)
                         break
                 ids[b * n: (b + 1) * n] = draft
-                mask[b] = np.tril(np.ones((n, n), dtype=np.int64))                             # a chain: node i's ancestors are 0..i
             return ids, mask.reshape(-1)
 
     for modname in ("sglang.kernels.ops.speculative.ngram_corpus", "sglang.srt.speculative.cpp_ngram.ngram_corpus"):
@@ -1627,6 +1788,33 @@ def _install_spec_standins(ns) -> None:
 
     NW = importlib.import_module("sglang.srt.speculative.ngram_worker")
     NW.reconstruct_indices_from_tree_mask = reconstruct_indices_from_tree_mask
+    if not getattr(NW.NGRAMWorker._prepare_draft_tokens, "_recording", False):
+        prepare = NW.NGRAMWorker._prepare_draft_tokens
+
+        def recording_prepare(self, batch):
+            # (ngram_worker.py:230-308) the sequence a draft continues = origin_input_ids + output_ids + the tokens accepted by the
+            # previous verify step that the overlap loop has not written back yet (`prev_token_ids`)
+            drafts, mask = prepare(self, batch)
+            n = int(self.draft_token_num)
+            stride = n if self.prev_token_ids else 0                        # (the worker's own stride, :243)
+            recs = []
+            kv_lens = [int(x) for x in batch.seq_lens.cpu().tolist()]       # tokens whose K/V rows are in the cache (device truth)
+            for i, r in enumerate(batch.reqs):
+                prev = self.prev_token_ids[i * stride: i * stride + self.prev_accept_lens[i]] if stride else []
+                # the verified sequence = the first kv_len tokens + draft node 0 (the last accepted token, scored by this forward).
+                # NOT simply origin + output + prev: when an EXTEND batch ran between two verify steps the result processor has already
+                # written the previous step's accepted tokens into output_ids and `prev` repeats them (the worker's `total_lens` is
+                # then too long by that much -- it only steers the n-gram lookup)
+                known = [int(t) for t in list(r.origin_input_ids) + list(r.output_ids) + list(prev)]
+                assert len(known) >= kv_lens[i], (len(known), kv_lens[i])
+                recs.append(dict(rid=r.rid, tokens=known[: kv_lens[i]] + [int(drafts[i * n])],
+                                 draft=[int(t) for t in drafts[i * n: (i + 1) * n]],
+                                 mask=np.asarray(mask).reshape(len(batch.reqs), n, n)[i].astype(bool).tolist()))
+            SPEC_VERIFY.append(dict(requests=recs, logits=None))
+            return drafts, mask
+
+        recording_prepare._recording = True
+        NW.NGRAMWorker._prepare_draft_tokens = recording_prepare
     EU = importlib.import_module("sglang.srt.speculative.eagle_utils")
 
     def verify_tree_greedy_func(predicts, accept_index, accept_token_num, candidates, retrieve_index, retrieve_next_token,
@@ -1986,6 +2174,7 @@ if __name__ == "__main__":
     ap.add_argument("--logprobs", action="store_true", help="scheduler run: return_logprob + top-2 logprobs on every request")
     ap.add_argument("--sampling", default=None, help='scheduler run: SamplingParams of every request as JSON, e.g. {"temperature": 0.8, "top_k": 20, "top_p": 0.9}')
     ap.add_argument("--spec-ngram", type=int, default=0, help="scheduler run: NGRAM speculative decoding with N draft tokens (scripted drafter): TARGET_VERIFY forwards")
+    ap.add_argument("--spec-tree", action="store_true", help="scheduler run with --spec-ngram: the scripted drafter also proposes wrong BRANCHES (breadth 2)")
     ap.add_argument("--overlap", action="store_true", help="scheduler run: the body of event_loop_overlap (the server default)")
     ap.add_argument("--radix", action="store_true", help="shared-prefix run: prefixes from the reference's real RadixCache")
     ap.add_argument("--tp", type=int, default=1, help="tensor-parallel ranks: this process launches itself N times (rank 0 reports)")
@@ -2022,7 +2211,8 @@ if __name__ == "__main__":
     rep = {"cpu-oracle": lambda: run_cpu_oracle(a.dims), "loader": run_loader, "gpu": lambda: run_gpu(a.dims), "mem-hooks": run_mem_hooks,
            "runner": lambda: run_runner(a.dims, _json_arg(a.server_args)), "latency": lambda: run_latency(a.dims, *[int(x) for x in a.shape.split(",")]),
            "scheduler": lambda: run_scheduler_job(a.dims if a.dims != "tiny" else "tiny_v16k", *[int(x) for x in a.job.split(",")],
-                                                  overlap=a.overlap, server_args=_json_arg(a.server_args), logprobs=a.logprobs, spec_ngram=a.spec_ngram, sampling=_json_arg(a.sampling)),
+                                                  overlap=a.overlap, server_args=_json_arg(a.server_args), logprobs=a.logprobs, spec_ngram=a.spec_ngram, sampling=_json_arg(a.sampling),
+                                                  spec_tree=a.spec_tree),
            "shared-prefix": lambda: run_shared_prefix_job(a.dims if a.dims != "tiny" else "tiny_v16k", *[int(x) for x in a.job.split(",")],
                                                           radix=a.radix)}[a.run]()
     rep["tp"] = tp_world()[0]

@@ -285,7 +285,7 @@ def test_target_verify_under_the_references_scheduler(device):
     out = ROOT / "gpurun_out" / "reference_model_scheduler_target_verify.json"
     n_out = 12
     p = subprocess.run([sys.executable, str(ROOT / "tests" / "golden" / "ref_model.py"), "--run", "scheduler", "--overlap", "--spec-ngram", "4",
-                        "--job", f"2,2,16,8,{n_out}", "--json", str(out)],
+                        "--spec-tree", "--job", f"2,2,16,8,{n_out}", "--json", str(out)],
                        cwd=ROOT, env=dict(os.environ, SGLANG_USE_AITER="0"), capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-6000:]
     rep = json.loads(out.read_text())
@@ -302,6 +302,30 @@ def test_target_verify_under_the_references_scheduler(device):
         assert job["cached_tokens_of_others"] == [16]
     assert rep["graph_replays_in_the_timed_job"] >= 3                              # the verify forwards are replays of TARGET_VERIFY graphs
     assert rep["oracle"]["token_agreement"] >= 0.75, rep["oracle"]
+    # the drafter proposed chains AND trees with wrong branches (a wrong first sibling, a rejected second sibling): both walked
+    assert sp["drafter"]["tree_drafts"] >= 2 and sp["drafter"]["chain_drafts"] >= 1, sp["drafter"]
+    _spec_logit_bars(sp, dense=True)
+
+
+def _spec_logit_bars(sp, dense: bool) -> None:
+    """every row of every TARGET_VERIFY forward -- accepted and rejected draft nodes alike -- against the oracle's
+    evaluation of that node's own token path (tests/golden/ref_model.py spec_logit_band), with the scheduler tests' bars: the plug-in's
+    error against the fp32-accumulating oracle inside 1.25 x (rms) / 2 x (worst logit) the band of the reference's literal bf16
+    evaluation; a wrong-but-close custom-mask kernel, a stale tree mask or a wrong position fails here, not at token agreement."""
+    lb = sp["logit_band"]
+    assert lb["rows_compared"] == lb["rows_expected"] > 0 and lb["verify_forwards"] >= 3, lb
+    assert len(lb["rows_by_depth"]) >= 3, lb                          # roots, children, grandchildren were all scored
+    if dense:
+        assert lb["product_rms_err"] <= 1.25 * lb["reference_rms_err"] + 1e-4, lb
+        assert lb["product_max_err"] <= 2.0 * lb["reference_max_err"] + 1e-3, lb
+        assert lb["argmax_agree_on_clear_rows"] == lb["clear_rows"], lb
+    else:
+        # sparse-MoE: a flipped expert choice moves a whole row; rows whose token path holds a near-tie of the router (or on which the
+        # two oracles themselves route differently) keep the 2 x rms bar only, the others get the per-logit bar as well
+        assert lb["product_rms_err"] <= 2.0 * lb["reference_rms_err"] + 1e-3, lb
+        assert lb["rows_without_flip_risk"] >= lb["rows_compared"] // 4, lb
+        assert lb["product_rms_err_no_flip"] <= 1.25 * lb["reference_rms_err_no_flip"] + 1e-4, lb
+        assert lb["product_max_err_no_flip"] <= 2.0 * lb["reference_max_err_no_flip"] + 1e-3, lb
 
 
 @pytest.mark.parametrize("config", ["eager", "small-graph", "fp8-kv", "qwen2", "no-radix", "tp2", "spec-mixtral", "spec-paged", "long-shared",
@@ -327,7 +351,7 @@ def test_plugin_under_the_references_scheduler_more_configurations(device, confi
              "qwen2": ["--dims", "tiny_qwen2"],
              "no-radix": ["--server-args", '{"disable_radix_cache": true}'],
              "tp2": ["--tp", "2"],
-             "spec-mixtral": ["--spec-ngram", "3", "--dims", "tiny_mixtral", "--job", "2,2,16,8,10"],
+             "spec-mixtral": ["--spec-ngram", "3", "--spec-tree", "--dims", "tiny_mixtral", "--job", "2,2,16,8,10"],
              "spec-paged": ["--spec-ngram", "4", "--job", "2,2,32,16,12", "--server-args", '{"page_size": 16, "speculative_ngram_max_bfs_breadth": 1}'],
              "long-shared": ["--job", "2,4,160,40,48"],
              "long-shared-paged": ["--job", "2,4,160,40,48", "--server-args", '{"page_size": 16}'],
@@ -356,6 +380,7 @@ def test_plugin_under_the_references_scheduler_more_configurations(device, confi
         assert sp["worker"] == "NGRAMWorker" and verify >= 3 and sp["drafter"]["drafted_true_tokens"] > 0, sp
         assert sp["drafter"]["lookups"] < n_req * (n_out - 1), ("no draft was ever accepted", sp["drafter"])
         assert rep["oracle"]["token_agreement"] >= 0.75, rep["oracle"]
+        _spec_logit_bars(sp, dense=config != "spec-mixtral")
         return
     # no Triton launch on the path; the logits of every forward inside the reference's own band
     assert rep["triton_launches_in_the_timed_job"] == 0, rep["triton_kernels_in_the_timed_job"]
