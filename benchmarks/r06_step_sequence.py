@@ -60,5 +60,53 @@ def main(prof_dir, out_path, start_sub="wstream_gemm_kernel<4, 5, 1", anchor="ar
     print(open(out_path).read())
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not (len(sys.argv) > 4 and sys.argv[4] == "prefill"):
     main(*sys.argv[1:4])
+
+
+def prefill_region(prof_dir, out_path):
+    """Busy vs wall of the LAST step's prefill (first extend-attention launch of the step .. first fused decode launch): kernels by
+    total time, idle gaps above 5 us with the kernels around them."""
+    rows = []
+    for t in glob.glob(f"{prof_dir}/**/*kernel_trace.csv", recursive=True):
+        for r in csv.DictReader(open(t)):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+    rows.sort()
+    ext = [i for i, r in enumerate(rows) if "extend_attention" in r[2]]
+    dec = [i for i, r in enumerate(rows) if "wstream_combine_rope_kernel" in r[2]]
+    # the last step's prefill (run bench.py with --no-kernel-roofline --no-parity --no-reference-scheduler: nothing after the job
+    # launches the extend kernel): its 2 x L extend launches, from the arg-max that closed the previous step's decode
+    nl = sum(1 for i in dec if i > ext[-1]) and len([i for i in ext if i > max([d for d in dec if d < ext[-1]], default=-1)])
+    first_ext = ext[-nl]
+    am = [i for i, r in enumerate(rows) if "argmax" in r[2] and i < first_ext]
+    start = (am[-1] + 1) if am else first_ext
+    end = next(i for i in dec if i > ext[-1])
+    seg = rows[start:end]
+    wall = seg[-1][1] - seg[0][0]
+    busy, cur_e = 0, seg[0][0]
+    gaps = []
+    agg = defaultdict(lambda: [0, 0])
+    for k, (s, e, n) in enumerate(seg):
+        if s > cur_e:
+            if s - cur_e > 5000:
+                gaps.append((s - cur_e, seg[k - 1][2][:60], n[:60]))
+            busy += e - s
+        elif e > cur_e:
+            busy += e - cur_e
+        cur_e = max(cur_e, e)
+        agg[n][0] += 1
+        agg[n][1] += e - s
+    with open(out_path, "w") as f:
+        f.write(f"# prefill region of the last step: {len(seg)} launches\nwall {wall / 1e3:.1f} us, GPU busy {busy / 1e3:.1f} us, idle {(wall - busy) / 1e3:.1f} us ({100 * (wall - busy) / wall:.1f} %)\n\n")
+        f.write("calls   total_us   avg_us  kernel\n")
+        for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
+            f.write(f"{c:5d}  {t / 1e3:9.1f}  {t / c / 1e3:7.1f}  {n[:130]}\n")
+        f.write("\nidle gaps > 5 us (us, kernel before, kernel after), largest first\n")
+        for g, a, b in sorted(gaps, reverse=True)[:25]:
+            f.write(f"{g / 1e3:8.1f}  {a}  ->  {b}\n")
+        f.write(f"gaps > 5 us: {len(gaps)}, total {sum(g for g, _, _ in gaps) / 1e3:.1f} us\n")
+    print(open(out_path).read())
+
+
+if __name__ == "__main__" and len(sys.argv) > 4 and sys.argv[4] == "prefill":
+    prefill_region(sys.argv[1], sys.argv[2])

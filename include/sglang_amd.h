@@ -216,6 +216,11 @@ int sgl_amd_softmax_temperature(float* logits, const float* temperatures, int64_
 int64_t sgl_amd_softmax_temperature_split_workspace_bytes(int64_t batch, int num_splits);
 int sgl_amd_softmax_temperature_split(float* logits, const float* temperatures, int64_t batch, int64_t vocab,
                                       int64_t row_stride, int num_splits, void* workspace, void* stream);
+/* The same from bf16 logits (the model dtype: sampler.py widens them first, `logits.float()`): probs fp32 [B, V] =
+ * softmax(float(logits) / T) -- the widening is exact, the arithmetic the fp32 kernel's, without the separate pass. */
+int sgl_amd_softmax_temperature_split_bf16(const void* logits_bf16, float* probs, const float* temperatures, int64_t batch, int64_t vocab,
+                                           int64_t logits_row_stride, int64_t probs_row_stride, int num_splits, void* workspace,
+                                           void* stream);
 
 /* Top-k / top-p / min-p sampling with the reference's deterministic gumbel mode
  * (sampler.py:567-612 top_k_top_p_min_p_sampling_from_probs_torch + :688-729
@@ -234,6 +239,17 @@ int sgl_amd_top_k_top_p_min_p_sample(const float* probs, int64_t row_stride, int
                                      const int64_t* positions, int32_t* out_ids, void* ws_keys,
                                      void* ws_toks, int32_t* out_n_keep, int filtered, void* stream);
 int sgl_amd_sampling_lds_keep(void);
+/* The filtered case (filtered = 1 above) for decode-sized batches of wide rows: the two full-row passes of the single-workgroup
+ * kernel -- the first radix level's histogram, the collection of the cut's candidates -- run as `num_ranges` column ranges per
+ * row over the whole chip, a third launch finishes every row from its candidate list (rows the shortcut does not cover run the
+ * whole routine there).  Same ids and kept counts as sgl_amd_top_k_top_p_min_p_sample.  ws_ranges: caller-owned,
+ * sgl_amd_sample_ranges_workspace_bytes(batch, num_ranges) bytes, 16-byte aligned, no initial state. */
+int64_t sgl_amd_sample_ranges_workspace_bytes(int64_t batch, int num_ranges);
+int sgl_amd_top_k_top_p_min_p_sample_ranges(const float* probs, int64_t row_stride, int64_t batch, int64_t vocab,
+                                            const int32_t* top_ks, const float* top_ps, const float* min_ps,
+                                            const int64_t* seeds, const int64_t* positions, int32_t* out_ids,
+                                            void* ws_keys, void* ws_toks, int32_t* out_n_keep, int num_ranges,
+                                            void* ws_ranges, void* stream);
 /* sgl_kernel.top_k_renorm_prob / top_p_renorm_prob (kernels/aot/python/sgl_kernel/sampling.py:28,79)
  * and sampler.py:753-762 top_p_normalize_probs_torch: zero everything outside the kept sorted
  * prefix and renormalise.  Per-row arrays override the scalar values when non-NULL;

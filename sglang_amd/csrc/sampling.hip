@@ -206,30 +206,50 @@ __device__ __forceinline__ void split_range(int64_t vocab, int splits, int64_t* 
   *begin = b; *end = e;
 }
 
-__global__ __launch_bounds__(kSplitThreads) void softmax_partials_kernel(const float* __restrict__ logits, const float* __restrict__ temperatures,
+// `IN` = float (in place: out == logits) or uint16_t (bf16 logits widened on the fly: what `logits.float()` + the fp32 kernel compute,
+// without the 16 MB read + 33 MB write of the separate widening pass and with half the bytes in both passes here)
+template <typename IN>
+__device__ __forceinline__ void ld4(const IN* p, float (&v)[4]);
+template <>
+__device__ __forceinline__ void ld4<float>(const float* p, float (&v)[4]) {
+  const float4 q = *reinterpret_cast<const float4*>(p);
+  v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+}
+template <>
+__device__ __forceinline__ void ld4<uint16_t>(const uint16_t* p, float (&v)[4]) {
+  const uint2 q = *reinterpret_cast<const uint2*>(p);
+  v[0] = bf_lo(q.x); v[1] = bf_hi(q.x); v[2] = bf_lo(q.y); v[3] = bf_hi(q.y);
+}
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const uint16_t* p) { return bf2f(*p); }
+
+template <typename IN>
+__global__ __launch_bounds__(kSplitThreads) void softmax_partials_kernel(const IN* __restrict__ logits, const float* __restrict__ temperatures,
                                                                          int64_t vocab, int64_t row_stride, int splits,
                                                                          float* __restrict__ partials) {
   __shared__ float scratch[16];
   const int64_t row = blockIdx.y;
-  const float* x = logits + row * row_stride;
+  const IN* x = logits + row * row_stride;
   const float t = temperatures[row];
   int64_t b, e;
   split_range(vocab, splits, &b, &e);
   const int64_t e4 = b + (e - b) / 4 * 4;
   float mx = -INFINITY;
   for (int64_t i = b + 4 * threadIdx.x; i < e4; i += 4 * kSplitThreads) {
-    const float4 v = *reinterpret_cast<const float4*>(x + i);
-    mx = fmaxf(fmaxf(mx, v.x / t), fmaxf(v.y / t, fmaxf(v.z / t, v.w / t)));
+    float v[4];
+    ld4<IN>(x + i, v);
+    mx = fmaxf(fmaxf(mx, v[0] / t), fmaxf(v[1] / t, fmaxf(v[2] / t, v[3] / t)));
   }
-  for (int64_t i = e4 + threadIdx.x; i < e; i += kSplitThreads) mx = fmaxf(mx, x[i] / t);
+  for (int64_t i = e4 + threadIdx.x; i < e; i += kSplitThreads) mx = fmaxf(mx, ld1(x + i) / t);
   mx = block_max(mx, scratch);
   float sum = 0.f;
   if (mx > -INFINITY) {
     for (int64_t i = b + 4 * threadIdx.x; i < e4; i += 4 * kSplitThreads) {
-      const float4 v = *reinterpret_cast<const float4*>(x + i);
-      sum += expf(v.x / t - mx) + expf(v.y / t - mx) + expf(v.z / t - mx) + expf(v.w / t - mx);
+      float v[4];
+      ld4<IN>(x + i, v);
+      sum += expf(v[0] / t - mx) + expf(v[1] / t - mx) + expf(v[2] / t - mx) + expf(v[3] / t - mx);
     }
-    for (int64_t i = e4 + threadIdx.x; i < e; i += kSplitThreads) sum += expf(x[i] / t - mx);
+    for (int64_t i = e4 + threadIdx.x; i < e; i += kSplitThreads) sum += expf(ld1(x + i) / t - mx);
   }
   sum = block_sum(sum, scratch);
   if (threadIdx.x == 0) {
@@ -238,11 +258,14 @@ __global__ __launch_bounds__(kSplitThreads) void softmax_partials_kernel(const f
   }
 }
 
-__global__ __launch_bounds__(kSplitThreads) void softmax_normalize_kernel(float* __restrict__ logits, const float* __restrict__ temperatures,
-                                                                          int64_t vocab, int64_t row_stride, int splits,
+template <typename IN>
+__global__ __launch_bounds__(kSplitThreads) void softmax_normalize_kernel(const IN* __restrict__ logits, float* __restrict__ out,
+                                                                          const float* __restrict__ temperatures, int64_t vocab,
+                                                                          int64_t row_stride, int64_t out_stride, int splits,
                                                                           const float* __restrict__ partials) {
   const int64_t row = blockIdx.y;
-  float* x = logits + row * row_stride;
+  const IN* x = logits + row * row_stride;
+  float* y = out + row * out_stride;
   const float t = temperatures[row];
   const float* pr = partials + row * splits * 2;
   float mx = -INFINITY;
@@ -256,11 +279,13 @@ __global__ __launch_bounds__(kSplitThreads) void softmax_normalize_kernel(float*
   split_range(vocab, splits, &b, &e);
   const int64_t e4 = b + (e - b) / 4 * 4;
   for (int64_t i = b + 4 * threadIdx.x; i < e4; i += 4 * kSplitThreads) {
-    float4 v = *reinterpret_cast<const float4*>(x + i);
-    v.x = expf(v.x / t - mx) / sum; v.y = expf(v.y / t - mx) / sum; v.z = expf(v.z / t - mx) / sum; v.w = expf(v.w / t - mx) / sum;
-    *reinterpret_cast<float4*>(x + i) = v;
+    float v[4];
+    ld4<IN>(x + i, v);
+    float4 o;
+    o.x = expf(v[0] / t - mx) / sum; o.y = expf(v[1] / t - mx) / sum; o.z = expf(v[2] / t - mx) / sum; o.w = expf(v[3] / t - mx) / sum;
+    *reinterpret_cast<float4*>(y + i) = o;
   }
-  for (int64_t i = e4 + threadIdx.x; i < e; i += kSplitThreads) x[i] = expf(x[i] / t - mx) / sum;
+  for (int64_t i = e4 + threadIdx.x; i < e; i += kSplitThreads) y[i] = expf(ld1(x + i) / t - mx) / sum;
 }
 
 }  // namespace
@@ -329,11 +354,30 @@ int sgl_amd_softmax_temperature_split(float* logits, const float* temperatures, 
   if (batch == 0) return 0;
   const dim3 grid(num_splits, static_cast<unsigned>(batch));
   float* partials = static_cast<float*>(workspace);
-  hipLaunchKernelGGL(softmax_partials_kernel, grid, dim3(kSplitThreads), 0, as_stream(stream), logits, temperatures, vocab, row_stride,
-                     num_splits, partials);
-  hipLaunchKernelGGL(softmax_normalize_kernel, grid, dim3(kSplitThreads), 0, as_stream(stream), logits, temperatures, vocab, row_stride,
-                     num_splits, partials);
+  hipLaunchKernelGGL(softmax_partials_kernel<float>, grid, dim3(kSplitThreads), 0, as_stream(stream), static_cast<const float*>(logits), temperatures,
+                     vocab, row_stride, num_splits, partials);
+  hipLaunchKernelGGL(softmax_normalize_kernel<float>, grid, dim3(kSplitThreads), 0, as_stream(stream), static_cast<const float*>(logits), logits,
+                     temperatures, vocab, row_stride, row_stride, num_splits, partials);
   SGL_CHECK_LAUNCH("softmax_temperature_split");
+  return 0;
+}
+
+int sgl_amd_softmax_temperature_split_bf16(const void* logits_bf16, float* probs, const float* temperatures, int64_t batch, int64_t vocab,
+                                           int64_t logits_row_stride, int64_t probs_row_stride, int num_splits, void* workspace, void* stream) {
+  SGL_CLEAR_STALE_ERROR();
+  SGL_CHECK_ARG(vocab > 0 && batch <= 65535 && num_splits >= 1 && num_splits <= 64, "softmax_temperature_split_bf16: batch <= 65535, 1..64 splits");
+  SGL_CHECK_ARG(workspace && logits_bf16 && probs && (reinterpret_cast<uintptr_t>(logits_bf16) & 7) == 0 && logits_row_stride % 4 == 0 &&
+                    (reinterpret_cast<uintptr_t>(probs) & 15) == 0 && probs_row_stride % 4 == 0,
+                "softmax_temperature_split_bf16: needs the workspace, 8-byte aligned bf16 rows and 16-byte aligned fp32 rows");
+  if (batch == 0) return 0;
+  const dim3 grid(num_splits, static_cast<unsigned>(batch));
+  float* partials = static_cast<float*>(workspace);
+  const uint16_t* x = static_cast<const uint16_t*>(logits_bf16);
+  hipLaunchKernelGGL(softmax_partials_kernel<uint16_t>, grid, dim3(kSplitThreads), 0, as_stream(stream), x, temperatures, vocab, logits_row_stride,
+                     num_splits, partials);
+  hipLaunchKernelGGL(softmax_normalize_kernel<uint16_t>, grid, dim3(kSplitThreads), 0, as_stream(stream), x, probs, temperatures, vocab,
+                     logits_row_stride, probs_row_stride, num_splits, partials);
+  SGL_CHECK_LAUNCH("softmax_temperature_split_bf16");
   return 0;
 }
 

@@ -128,6 +128,7 @@ struct Select {
 };
 
 constexpr int kCand = 4096;       // candidate list capacity (4 per thread: one tile)
+constexpr int kDirect = 2048;     // preloaded candidate lists up to this length (= kLdsKeep) are ranked whole (sample_row)
 constexpr int kHistCopies = 16;   // lane-group private copies of the select histograms
 constexpr int kHistStride = 257;  // ... one bank apart
 
@@ -219,8 +220,77 @@ __device__ __forceinline__ double block_scan_incl(double v, double* s_part /* kN
   return base + v;
 }
 
-__device__ __forceinline__ void select_begin(RowSmem& sm) {
+template <class SM>
+__device__ __forceinline__ void select_begin(SM& sm) {
   if (threadIdx.x == 0) { sm.prefix = 0; sm.c_above = 0; sm.s_above = 0; sm.done_all = 0; sm.n_eq_keep = 0; }
+}
+
+// The decision of one level, from the level's histogram in sm.hist_cnt / hist_sum (bins of the values that match `prefix`): walks
+// the bins from the top, finds the bin the cut falls into and updates the select state.  Wave 0 only; the caller's barrier follows.
+template <class SM>
+__device__ __forceinline__ void select_decide(int level, int shift, uint32_t prefix, int64_t top_k, unsigned long long p_fix, SM& sm) {
+  const int tid = threadIdx.x;
+  if (tid < 64) {
+    // lane l owns bins 255-4l .. 252-4l (descending); inclusive scan over lanes.
+    uint32_t c4[4];
+    unsigned long long s4[4];
+    uint32_t lc = 0;
+    unsigned long long ls = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      c4[j] = sm.hist_cnt[255 - 4 * tid - j];
+      s4[j] = sm.hist_sum[255 - 4 * tid - j];
+      lc += c4[j];
+      ls += s4[j];
+    }
+    uint32_t ic = lc;
+    unsigned long long is = ls;
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t oc = __shfl_up(ic, off, 64);
+      const unsigned long long os = __shfl_up(is, off, 64);
+      if (tid >= off) { ic += oc; is += os; }
+    }
+    long long c = static_cast<long long>(sm.c_above) + (ic - lc);
+    unsigned long long s = sm.s_above + (is - ls);
+    int fail = -1;
+    long long c_b = 0;
+    unsigned long long s_b = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (fail < 0) {
+        const bool whole = (c + c4[j] <= top_k) && (s + s4[j] <= p_fix);
+        if (whole || c4[j] == 0) { c += c4[j]; s += s4[j]; }
+        else { fail = 255 - 4 * tid - j; c_b = c; s_b = s; }
+      }
+    }
+    const unsigned long long bal = __ballot(fail >= 0);
+    if (bal == 0ull) {
+      if (tid == 0) sm.done_all = 1;   // everything at this prefix is kept (only possible at level 0)
+    } else {
+      const int first = __ffsll(static_cast<long long>(bal)) - 1;
+      if (tid == first) {
+        sm.found_bin = fail;
+        sm.c_above = static_cast<int>(c_b);
+        sm.s_above = s_b;
+        sm.prefix = prefix | (static_cast<uint32_t>(fail) << shift);
+        if (level == 3) {
+          // single value v, m copies: keep j = 0.. while c_b + j < top_k and s_b + j*v <= p_fix
+          const uint32_t m = sm.hist_cnt[fail];
+          const unsigned long long v = sm.hist_sum[fail] / (m ? m : 1);
+          long long nk = top_k - c_b;
+          if (nk < 0) nk = 0;
+          long long np;
+          if (s_b > p_fix) np = 0;
+          else if (v == 0) np = m;
+          else np = static_cast<long long>((p_fix - s_b) / v) + 1;
+          long long n = m;
+          if (nk < n) n = nk;
+          if (np < n) n = np;
+          sm.n_eq_keep = static_cast<int>(n);
+        }
+      }
+    }
+  }
 }
 
 // Levels [level_begin, level_end) of the select over the values x[0 .. V) (a row, or the candidate list in LDS); the
@@ -260,67 +330,7 @@ __device__ void select_levels(const float* __restrict__ x, int V, int level_begi
       sm.hist_sum[tid] = sfix;
     }
     __syncthreads();
-    if (tid < 64) {
-      // lane l owns bins 255-4l .. 252-4l (descending); inclusive scan over lanes.
-      uint32_t c4[4];
-      unsigned long long s4[4];
-      uint32_t lc = 0;
-      unsigned long long ls = 0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        c4[j] = sm.hist_cnt[255 - 4 * tid - j];
-        s4[j] = sm.hist_sum[255 - 4 * tid - j];
-        lc += c4[j];
-        ls += s4[j];
-      }
-      uint32_t ic = lc;
-      unsigned long long is = ls;
-      for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t oc = __shfl_up(ic, off, 64);
-        const unsigned long long os = __shfl_up(is, off, 64);
-        if (tid >= off) { ic += oc; is += os; }
-      }
-      long long c = static_cast<long long>(sm.c_above) + (ic - lc);
-      unsigned long long s = sm.s_above + (is - ls);
-      int fail = -1;
-      long long c_b = 0;
-      unsigned long long s_b = 0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (fail < 0) {
-          const bool whole = (c + c4[j] <= top_k) && (s + s4[j] <= p_fix);
-          if (whole || c4[j] == 0) { c += c4[j]; s += s4[j]; }
-          else { fail = 255 - 4 * tid - j; c_b = c; s_b = s; }
-        }
-      }
-      const unsigned long long bal = __ballot(fail >= 0);
-      if (bal == 0ull) {
-        if (tid == 0) sm.done_all = 1;   // everything at this prefix is kept (only possible at level 0)
-      } else {
-        const int first = __ffsll(static_cast<long long>(bal)) - 1;
-        if (tid == first) {
-          sm.found_bin = fail;
-          sm.c_above = static_cast<int>(c_b);
-          sm.s_above = s_b;
-          sm.prefix = prefix | (static_cast<uint32_t>(fail) << shift);
-          if (level == 3) {
-            // single value v, m copies: keep j = 0.. while c_b + j < top_k and s_b + j*v <= p_fix
-            const uint32_t m = sm.hist_cnt[fail];
-            const unsigned long long v = sm.hist_sum[fail] / (m ? m : 1);
-            long long nk = top_k - c_b;
-            if (nk < 0) nk = 0;
-            long long np;
-            if (s_b > p_fix) np = 0;
-            else if (v == 0) np = m;
-            else np = static_cast<long long>((p_fix - s_b) / v) + 1;
-            long long n = m;
-            if (nk < n) n = nk;
-            if (np < n) n = np;
-            sm.n_eq_keep = static_cast<int>(n);
-          }
-        }
-      }
-    }
+    select_decide(level, shift, prefix, top_k, p_fix, sm);
     __syncthreads();
     if (sm.done_all) break;
     mask |= 0xffu << shift;
@@ -571,9 +581,11 @@ struct SampleParams {
   int filtered;                // 0: sampling_from_probs (no filter, col = token id)
 };
 
-__global__ __launch_bounds__(kT) void sample_kernel(SampleParams p) {
-  __shared__ RowSmem sm;
-  const int row = blockIdx.x, tid = threadIdx.x;
+// One row of the sampler, by one 1024-thread workgroup.  n_preloaded < 0: from the row itself (the first radix level and the
+// candidate collection are two full-row passes).  n_preloaded >= 0 (the column-range launches below did those passes over the
+// whole chip): the select state behind level 0 is in `sm` and sm.cand_* hold the n_preloaded candidates in token order.
+__device__ void sample_row(const SampleParams& p, const int row, RowSmem& sm, const int n_preloaded) {
+  const int tid = threadIdx.x;
   const float* x = p.probs + static_cast<int64_t>(row) * p.row_stride;
   const int V = p.V;
   const uint64_t seed = static_cast<uint64_t>(p.seeds[row]);
@@ -605,12 +617,24 @@ __global__ __launch_bounds__(kT) void sample_kernel(SampleParams p) {
   // three levels, the min-p maximum and the compaction run on that list: two full-row passes instead of six.
   // (the select returns a SUPERSET prefix of the reference's kept set; the top-p rule itself is applied exactly below)
   const unsigned long long p_fix = top_p_fix_superset(top_p);
-  select_begin(sm);
-  select_levels(x, V, 0, 1, top_k, p_fix, sm);
   const float* src = x;                              // what the rest of the selection reads: the row, or the candidates
   int n_src = V;
   bool from_cand = false;
-  if (!sm.done_all) {
+  // A short preloaded candidate list is ranked WHOLE and the three rules of sampler.py:574-591 are applied to every ranked
+  // element (rank < top_k; the exact top-p test; p >= max * min_p): the candidates are everything from the cut's first-level bin
+  // upwards, i.e. a prefix of the sorted order that contains the kept set -- the radix levels 1-3 and the compaction only ever
+  // shortened that prefix (a dozen workgroup barriers; 20 -> 7 us for the finish launch at [64, 128256], top-k 50 / top-p 0.9).
+  const bool direct = n_preloaded >= 0 && n_preloaded <= kDirect;
+  if (n_preloaded >= 0) {
+    src = reinterpret_cast<const float*>(sm.cand_val);
+    n_src = n_preloaded;
+    from_cand = true;
+    if (!direct) select_levels(src, n_src, 1, 4, top_k, p_fix, sm);
+  } else {
+    select_begin(sm);
+    select_levels(x, V, 0, 1, top_k, p_fix, sm);
+  }
+  if (n_preloaded < 0 && !sm.done_all) {
     const int bin = sm.found_bin;
     const long long n_cand = static_cast<long long>(sm.c_above) + sm.hist_cnt[bin];
     __syncthreads();                                 // (hist_cnt is rewritten by the next level)
@@ -622,7 +646,8 @@ __global__ __launch_bounds__(kT) void sample_kernel(SampleParams p) {
     }
     select_levels(src, n_src, 1, 4, top_k, p_fix, sm);
   }
-  const Select sel = select_result(sm);
+  Select sel{0u, 0};
+  if (!direct) sel = select_result(sm);
 
   uint32_t min_key = 0;
   if (p.min_ps) {
@@ -641,11 +666,19 @@ __global__ __launch_bounds__(kT) void sample_kernel(SampleParams p) {
   // small nuclei are compacted into LDS, larger ones into the global workspace
   uint32_t* gk0 = p.ws_keys ? p.ws_keys + static_cast<int64_t>(row) * 2 * V : nullptr;
   int32_t* gt0 = p.ws_toks ? p.ws_toks + static_cast<int64_t>(row) * 2 * V : nullptr;
-  const int n_keep = compact_kept(src, n_src, sel, min_key, sm, [&](int posn, uint32_t key, int idx) {
-    const int tok = from_cand ? sm.cand_tok[idx] : idx;
-    if (posn < kLdsKeep) { sm.keys[posn] = key; sm.toks[posn] = tok; }
-    if (gk0) { gk0[posn] = key; gt0[posn] = tok; }
-  });
+  int n_keep;
+  if (direct) {
+    __syncthreads();
+    for (int i = tid; i < n_src; i += kT) { sm.keys[i] = key_of(src[i]); sm.toks[i] = sm.cand_tok[i]; }
+    n_keep = n_src;
+    __syncthreads();
+  } else {
+    n_keep = compact_kept(src, n_src, sel, min_key, sm, [&](int posn, uint32_t key, int idx) {
+      const int tok = from_cand ? sm.cand_tok[idx] : idx;
+      if (posn < kLdsKeep) { sm.keys[posn] = key; sm.toks[posn] = tok; }
+      if (gk0) { gk0[posn] = key; gt0[posn] = tok; }
+    });
+  }
   // The pairs are a prefix of the reference's sorted order (descending value, ties by token id) that contains its kept
   // set.  Rank them, then apply sampler.py:577-580 element by element on the sorted list: inclusive prefix sums in
   // double (what torch.cumsum computes on the CPU; a fixed tree here instead of its left-to-right loop: the two agree
@@ -694,7 +727,8 @@ __global__ __launch_bounds__(kT) void sample_kernel(SampleParams p) {
     for (int u = 0; u < kPer; ++u) {
       const int r = tid * kPer + u;
       run += static_cast<double>(pv[u]);
-      if (r < n_keep && exact_top_p_keep(run, pv[u], top_p)) {
+      const bool in_rules = !direct || (r < top_k && s_key[r < n_keep ? r : 0] >= min_key);     // (the select enforced both otherwise)
+      if (r < n_keep && in_rules && exact_top_p_keep(run, pv[u], top_p)) {
         ++kept;
         const double sc = log(static_cast<double>(pv[u])) + gumbel_from_hash(murmur_hash32(hpre, r));
         Best c{sc, r, s_tok2[r]};
@@ -740,6 +774,253 @@ __global__ __launch_bounds__(kT) void sample_kernel(SampleParams p) {
     }
     p.out_ids[row] = tok;
   }
+}
+
+// rank-0 token of an EMPTY nucleus (top_k == 0: the reference's all -inf row argmax-es to sorted rank 0) = the arg max of the row
+__device__ void fixup_empty_nucleus(const SampleParams& p, const int row, RowSmem& sm) {
+  if (!p.top_ks || p.top_ks[row] > 0) return;          // (workgroup-uniform)
+  const int tid = threadIdx.x;
+  const float* x = p.probs + static_cast<int64_t>(row) * p.row_stride;
+  Best best{0.0, -1, 0};
+  for (int i = tid; i < p.V; i += kT) {
+    Best c{static_cast<double>(x[i]), i, i};
+    if (best_better(best, c)) best = c;
+  }
+  __syncthreads();
+  best = block_best(best, sm.s_score, sm.s_rank, sm.s_tok);
+  if (tid == 0) p.out_ids[row] = best.token;
+}
+
+__global__ __launch_bounds__(kT) void sample_kernel(SampleParams p) {
+  __shared__ RowSmem sm;
+  sample_row(p, blockIdx.x, sm, -1);
+}
+
+// ---- the filtered case for decode-sized batches: the two full-row passes cut into column ranges over the whole chip -----
+// One workgroup per row keeps 64 of 256 CUs busy and reads its 0.5 MB row twice at one CU's rate (75 us for [64, 128256],
+// top-k 50 / top-p 0.9).  Three launches instead:
+//   hist     grid (ranges, rows): the first radix level's count + fixed-point sum histogram of every column range -> workspace
+//            (integer and 2^-40 fixed-point sums: the merged histogram is the single-workgroup one bit for bit);
+//   collect  grid (ranges, rows): every workgroup merges its row's range histograms, takes the level's decision (the same code,
+//            select_decide), and writes its range's candidates -- every element of the cut's bin and the bins above it -- into
+//            the row's candidate list at the offset the range histograms give it: the list is in token order;
+//   finish   grid (rows): the candidates (<= kCand) go to LDS and the row is finished as before: levels 1-3, min-p, compaction,
+//            ranking, the exact top-p rule, the gumbel arg-max.  Rows the shortcut does not cover (everything kept at level 0,
+//            more than kCand candidates) run the whole single-workgroup routine there.
+// Same ids and kept counts as sample_kernel by construction.
+struct RangeWs {
+  uint32_t* cnt;               // [B, S, 256]
+  unsigned long long* sum;     // [B, S, 256]
+  uint32_t* cand_val;          // [B, kCand]
+  int* cand_tok;               // [B, kCand]
+  int* state;                  // [B, 8]: 0 shortcut usable, 1 found bin, 2 c_above, 3 n_cand, 4/5 s_above lo / hi
+};
+
+__host__ __device__ inline int64_t range_ws_bytes(int64_t batch, int splits) {
+  return batch * splits * 256 * 12 + batch * kCand * 8 + batch * 32;
+}
+__host__ __device__ inline RangeWs range_ws_view(void* base, int64_t batch, int splits) {
+  RangeWs w;
+  unsigned char* b = static_cast<unsigned char*>(base);
+  w.sum = reinterpret_cast<unsigned long long*>(b);                 b += batch * splits * 256 * 8;
+  w.cnt = reinterpret_cast<uint32_t*>(b);                           b += batch * splits * 256 * 4;
+  w.cand_val = reinterpret_cast<uint32_t*>(b);                      b += batch * kCand * 4;
+  w.cand_tok = reinterpret_cast<int*>(b);                           b += batch * kCand * 4;
+  w.state = reinterpret_cast<int*>(b);
+  return w;
+}
+
+__device__ __forceinline__ void sample_range(int V, int splits, int* begin, int* end) {
+  const int per = ((V + splits - 1) / splits + 3) / 4 * 4;
+  int b = per * static_cast<int>(blockIdx.x), e = b + per;
+  if (b > V) b = V;
+  if (e > V) e = V;
+  *begin = b; *end = e;
+}
+
+__global__ __launch_bounds__(kT) void sample_hist_ranges_kernel(SampleParams p, int splits, RangeWs ws) {
+  __shared__ uint32_t part_cnt[kHistCopies * kHistStride];
+  __shared__ unsigned long long part_sum[kHistCopies * kHistStride];
+  const int row = blockIdx.y, tid = threadIdx.x;
+  const float* x = p.probs + static_cast<int64_t>(row) * p.row_stride;
+  int b, e;
+  sample_range(p.V, splits, &b, &e);
+  for (int z = tid; z < kHistCopies * kHistStride; z += kT) { part_cnt[z] = 0; part_sum[z] = 0; }
+  __syncthreads();
+  const int copy = (tid & (kHistCopies - 1)) * kHistStride;
+  auto tally = [&](float v) {
+    const int bin = copy + (key_of(v) >> 24);
+    atomicAdd(&part_cnt[bin], 1u);
+    atomicAdd(&part_sum[bin], static_cast<unsigned long long>(to_fix(v)));
+  };
+  const int e4 = vec4_len(x, p.V) ? b + (e - b) / 4 * 4 : b;       // (ranges start at multiples of four)
+  for (int i = b + 4 * tid; i < e4; i += 4 * kT) {
+    const float4 v = *reinterpret_cast<const float4*>(x + i);
+    tally(v.x); tally(v.y); tally(v.z); tally(v.w);
+  }
+  for (int i = e4 + tid; i < e; i += kT) tally(x[i]);
+  __syncthreads();
+  if (tid < 256) {
+    uint32_t c = 0;
+    unsigned long long sfix = 0;
+#pragma unroll
+    for (int k = 0; k < kHistCopies; ++k) { c += part_cnt[k * kHistStride + tid]; sfix += part_sum[k * kHistStride + tid]; }
+    const int64_t o = (static_cast<int64_t>(row) * splits + blockIdx.x) * 256 + tid;
+    ws.cnt[o] = c;
+    ws.sum[o] = sfix;
+  }
+}
+
+// what the collect launch needs of RowSmem: the level's histogram, the select state, two scratch rows (3 KiB instead of 87: two
+// workgroups per CU)
+struct CollectSmem {
+  uint32_t hist_cnt[256];
+  unsigned long long hist_sum[256];
+  int wave_a[kNW];
+  float red[16];
+  uint32_t prefix;
+  int c_above;
+  unsigned long long s_above;
+  int found_bin;
+  int n_eq_keep;
+  int done_all;
+};
+
+__global__ __launch_bounds__(kT) void sample_collect_ranges_kernel(SampleParams p, int splits, RangeWs ws) {
+  __shared__ CollectSmem sm;
+  const int row = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const float* x = p.probs + static_cast<int64_t>(row) * p.row_stride;
+  const int V = p.V;
+  int64_t top_k = p.top_ks ? p.top_ks[row] : V;
+  if (top_k > V) top_k = V;
+  if (top_k < 0) top_k = 0;
+  const float top_p = p.top_ps ? p.top_ps[row] : 1.0f;
+  const unsigned long long p_fix = top_p_fix_superset(top_p);
+  const int64_t hrow = static_cast<int64_t>(row) * splits * 256;
+  select_begin(sm);
+  uint32_t mine_before = 0;           // (tid < 256) elements of bin `tid` in the ranges ahead of this one
+  if (tid < 256) {
+    uint32_t c = 0;
+    unsigned long long sfix = 0;
+    for (int s = 0; s < splits; ++s) {
+      const uint32_t cs = ws.cnt[hrow + s * 256 + tid];
+      if (s < static_cast<int>(blockIdx.x)) mine_before += cs;
+      c += cs;
+      sfix += ws.sum[hrow + s * 256 + tid];
+    }
+    sm.hist_cnt[tid] = c;
+    sm.hist_sum[tid] = sfix;
+  }
+  __syncthreads();
+  select_decide(0, 24, 0u, top_k, p_fix, sm);
+  __syncthreads();
+  const int bin = sm.found_bin;
+  const long long n_cand = sm.done_all ? 0 : static_cast<long long>(sm.c_above) + sm.hist_cnt[bin];
+  const bool usable = !sm.done_all && n_cand <= kCand;
+  if (blockIdx.x == 0 && tid == 0) {
+    int* st = ws.state + static_cast<int64_t>(row) * 8;
+    st[0] = usable ? 1 : 0;
+    st[1] = bin;
+    st[2] = sm.c_above;
+    st[3] = static_cast<int>(n_cand);
+    st[4] = static_cast<int>(sm.s_above & 0xffffffffull);
+    st[5] = static_cast<int>(sm.s_above >> 32);
+  }
+  if (!usable) return;
+  // where this range's candidates start in the row's list: the candidates of the ranges ahead of it
+  float before_f = (tid < 256 && tid >= bin) ? static_cast<float>(mine_before) : 0.f;       // (<= kCand: exact in fp32)
+  int base = static_cast<int>(block_sum(before_f, sm.red) + 0.5f);
+  uint32_t* out_val = ws.cand_val + static_cast<int64_t>(row) * kCand;
+  int* out_tok = ws.cand_tok + static_cast<int64_t>(row) * kCand;
+  int b, e;
+  sample_range(V, splits, &b, &e);
+  const uint32_t lo = static_cast<uint32_t>(bin) << 24;
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const int e4 = vec4_len(x, V) ? b + (e - b) / 4 * 4 : b;
+  for (int i0 = b; i0 < e4; i0 += 4 * kT) {
+    const int i = i0 + 4 * tid;
+    float val[4] = {0.f, 0.f, 0.f, 0.f};
+    if (i < e4) {
+      const float4 v = *reinterpret_cast<const float4*>(x + i);
+      val[0] = v.x; val[1] = v.y; val[2] = v.z; val[3] = v.w;
+    }
+    bool in[4];
+    int before = 0, wave = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      in[j] = i < e4 && key_of(val[j]) >= lo;
+      const unsigned long long bb = __ballot(in[j]);
+      before += __popcll(bb & lt_mask);
+      wave += __popcll(bb);
+    }
+    __syncthreads();
+    if (lane == 0) sm.wave_a[wid] = wave;
+    __syncthreads();
+    int o = 0, t = 0;
+    for (int w = 0; w < kNW; ++w) {
+      const int a = sm.wave_a[w];
+      if (w < wid) o += a;
+      t += a;
+    }
+    int pos = base + o + before;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (in[j]) { out_val[pos] = __float_as_uint(val[j]); out_tok[pos] = i + j; ++pos; }
+    base += t;
+  }
+  for (int i0 = e4; i0 < e; i0 += kT) {
+    const int i = i0 + tid;
+    const float v = i < e ? x[i] : 0.f;
+    const bool in = i < e && key_of(v) >= lo;
+    const unsigned long long bb = __ballot(in);
+    __syncthreads();
+    if (lane == 0) sm.wave_a[wid] = __popcll(bb);
+    __syncthreads();
+    int o = 0, t = 0;
+    for (int w = 0; w < kNW; ++w) {
+      const int a = sm.wave_a[w];
+      if (w < wid) o += a;
+      t += a;
+    }
+    if (in) { const int pos = base + o + __popcll(bb & lt_mask); out_val[pos] = __float_as_uint(v); out_tok[pos] = i; }
+    base += t;
+  }
+}
+
+__global__ __launch_bounds__(kT) void sample_finish_ranges_kernel(SampleParams p, RangeWs ws) {
+  __shared__ RowSmem sm;
+  const int row = blockIdx.x, tid = threadIdx.x;
+  // ONE round trip: the row's state record and this thread's share of the candidate list (whatever its length: entries behind
+  // the list's end are never looked at) travel together
+  const int4 st0 = *reinterpret_cast<const int4*>(ws.state + static_cast<int64_t>(row) * 8);          // usable, bin, c_above, n_cand
+  const int2 st1 = *reinterpret_cast<const int2*>(ws.state + static_cast<int64_t>(row) * 8 + 4);      // s_above lo, hi
+  uint32_t cv[kCand / kT];
+  int ct[kCand / kT];
+#pragma unroll
+  for (int u = 0; u < kCand / kT; ++u) {
+    cv[u] = ws.cand_val[static_cast<int64_t>(row) * kCand + tid + u * kT];
+    ct[u] = ws.cand_tok[static_cast<int64_t>(row) * kCand + tid + u * kT];
+  }
+  if (!st0.x) {               // (workgroup-uniform) the whole routine, from the row
+    sample_row(p, row, sm, -1);
+    fixup_empty_nucleus(p, row, sm);
+    return;
+  }
+  const int n_cand = st0.w;
+#pragma unroll
+  for (int u = 0; u < kCand / kT; ++u)
+    if (tid + u * kT < n_cand) { sm.cand_val[tid + u * kT] = cv[u]; sm.cand_tok[tid + u * kT] = ct[u]; }
+  if (tid == 0) {
+    sm.prefix = static_cast<uint32_t>(st0.y) << 24;
+    sm.found_bin = st0.y;
+    sm.c_above = st0.z;
+    sm.s_above = (static_cast<unsigned long long>(static_cast<uint32_t>(st1.y)) << 32) | static_cast<uint32_t>(st1.x);
+    sm.done_all = 0;
+    sm.n_eq_keep = 0;
+  }
+  __syncthreads();
+  sample_row(p, row, sm, n_cand);
+  fixup_empty_nucleus(p, row, sm);
 }
 
 // ---- the unfiltered case for decode-sized batches: a row cut into column ranges over the whole chip -------------
@@ -805,17 +1086,7 @@ __global__ __launch_bounds__(64) void sample_unfiltered_merge_kernel(SampleParam
 // kernel so that the common path stays branch-free.
 __global__ __launch_bounds__(kT) void empty_nucleus_fixup_kernel(SampleParams p) {
   __shared__ RowSmem sm;
-  const int row = blockIdx.x, tid = threadIdx.x;
-  int64_t top_k = p.top_ks ? p.top_ks[row] : p.V;
-  if (top_k > 0) return;
-  const float* x = p.probs + static_cast<int64_t>(row) * p.row_stride;
-  Best best{0.0, -1, 0};
-  for (int i = tid; i < p.V; i += kT) {
-    Best c{static_cast<double>(x[i]), i, i};
-    if (best_better(best, c)) best = c;
-  }
-  best = block_best(best, sm.s_score, sm.s_rank, sm.s_tok);
-  if (tid == 0) p.out_ids[row] = best.token;
+  fixup_empty_nucleus(p, blockIdx.x, sm);
 }
 
 // ---- renormalisation (sgl_kernel.top_k_renorm_prob / top_p_renorm_prob,
@@ -898,6 +1169,35 @@ int sgl_amd_top_k_top_p_min_p_sample(const float* probs, int64_t row_stride, int
 }
 
 int sgl_amd_sampling_lds_keep(void) { return kLdsKeep; }
+
+int64_t sgl_amd_sample_ranges_workspace_bytes(int64_t batch, int num_ranges) { return range_ws_bytes(batch, num_ranges); }
+
+int sgl_amd_top_k_top_p_min_p_sample_ranges(const float* probs, int64_t row_stride, int64_t batch, int64_t vocab,
+                                            const int32_t* top_ks, const float* top_ps, const float* min_ps,
+                                            const int64_t* seeds, const int64_t* positions, int32_t* out_ids,
+                                            void* ws_keys, void* ws_toks, int32_t* out_n_keep, int num_ranges,
+                                            void* ws_ranges, void* stream) {
+  SGL_CLEAR_STALE_ERROR();
+  SGL_CHECK_ARG(vocab > 0 && vocab <= 0x7fffffffLL, "top_k_top_p_min_p_sample_ranges: bad vocab");
+  SGL_CHECK_ARG(batch <= 65535, "top_k_top_p_min_p_sample_ranges: batch <= 65535");
+  SGL_CHECK_ARG(seeds != nullptr, "top_k_top_p_min_p_sample_ranges: seeds are required");
+  SGL_CHECK_ARG((ws_keys == nullptr) == (ws_toks == nullptr), "top_k_top_p_min_p_sample_ranges: pass both ranking workspaces or neither");
+  SGL_CHECK_ARG(num_ranges >= 2 && num_ranges <= 64 && ws_ranges, "top_k_top_p_min_p_sample_ranges: 2..64 column ranges and their workspace");
+  SGL_CHECK_ARG((reinterpret_cast<uintptr_t>(ws_ranges) & 15) == 0, "top_k_top_p_min_p_sample_ranges: the range workspace must be 16-byte aligned");
+  if (batch == 0) return 0;
+  SampleParams p;
+  p.probs = probs; p.row_stride = row_stride; p.V = static_cast<int>(vocab);
+  p.top_ks = top_ks; p.top_ps = top_ps; p.min_ps = min_ps; p.seeds = seeds; p.positions = positions;
+  p.out_ids = out_ids; p.ws_keys = static_cast<uint32_t*>(ws_keys); p.ws_toks = static_cast<int32_t*>(ws_toks);
+  p.out_n_keep = out_n_keep; p.filtered = 1;
+  const RangeWs ws = range_ws_view(ws_ranges, batch, num_ranges);
+  const dim3 grid(num_ranges, static_cast<unsigned>(batch));
+  hipLaunchKernelGGL(sample_hist_ranges_kernel, grid, dim3(kT), 0, as_stream(stream), p, num_ranges, ws);
+  hipLaunchKernelGGL(sample_collect_ranges_kernel, grid, dim3(kT), 0, as_stream(stream), p, num_ranges, ws);
+  hipLaunchKernelGGL(sample_finish_ranges_kernel, dim3(batch), dim3(kT), 0, as_stream(stream), p, ws);
+  SGL_CHECK_LAUNCH("top_k_top_p_min_p_sample_ranges");        // (the empty-nucleus fix-up is part of the finish launch)
+  return 0;
+}
 
 int sgl_amd_top_k_top_p_renorm_probs(const float* probs, float* out, int64_t in_row_stride,
                                      int64_t out_row_stride, int64_t batch, int64_t vocab,

@@ -197,6 +197,23 @@ class Engine:
                     self.logits_by_req.setdefault(q.rid, []).append(rows[i])
 
     # ---- KV slot allocation with eviction (allocation.py:150-279 alloc_token_slots) ----
+    @staticmethod
+    def _extend_ids(reqs: Sequence[Req], prefix_lens: Sequence[int]) -> torch.Tensor:
+        """int64 [sum of extend lengths]: every request's prompt behind its cached prefix, concatenated (host tensor).  Buffer copies of
+        the requests' `array('q')` prompts instead of a Python loop over the tokens (0.4 ms at 7680 tokens)."""
+        import numpy as np
+
+        parts = []
+        for q, p in zip(reqs, prefix_lens):
+            arr = getattr(q, "origin_array", None)
+            if arr is not None and len(arr) == len(q.origin_input_ids):
+                parts.append(np.frombuffer(arr, dtype=np.int64)[p:])
+            else:
+                parts.append(np.asarray(q.origin_input_ids[p:], dtype=np.int64))
+        if not parts:
+            return torch.empty(0, dtype=torch.int64)
+        return torch.from_numpy(np.concatenate(parts))
+
     def _alloc_token_slots(self, n: int) -> torch.Tensor:
         alloc, tree = self.r.token_to_kv_pool_allocator, self.r.tree_cache
         if alloc.available_size() < n:
@@ -250,8 +267,7 @@ class Engine:
                                    dtype=torch.int64).to(dev, non_blocking=True)
         kernels.write_req_to_token(r.req_to_token_pool.req_to_token, req_pool_dev, prefix_ptrs, prefix_dev, seq_dev,
                                    ext_dev, out_cache_loc)
-        input_ids = torch.tensor([t for q, p in zip(reqs, prefix_lens) for t in q.origin_input_ids[p:]],
-                                 dtype=torch.int64).to(dev, non_blocking=True)
+        input_ids = self._extend_ids(reqs, prefix_lens).to(dev, non_blocking=True)
         fb = ForwardBatch.init_new(forward_mode=ForwardMode.EXTEND, input_ids=input_ids, req_pool_indices=req_pool_dev,
                                    seq_lens=seq_dev.to(torch.int32), out_cache_loc=out_cache_loc, seq_lens_cpu=seq_cpu,
                                    req_to_token_pool=r.req_to_token_pool, token_to_kv_pool=r.token_to_kv_pool,
@@ -261,16 +277,20 @@ class Engine:
         logits = r.forward(fb)
         self._record_logits(logits, reqs)
         next_ids = r.sample(logits, fb)
+        # process_batch_result_prefill -> cache_unfinished_req (batch_result_processor.py:240).  The insert takes the PROMPT only (the new
+        # token has no KV yet), so it does not wait for the sampled ids: it runs on the host while the GPU is still inside the forward
+        # launched above (its few device ops queue up behind it) -- the way the reference's overlap loop processes a batch's
+        # bookkeeping under the next launch.  Round 6: 1.6 ms of a 89 ms warm pass at 60 requests used to sit behind the sync.
+        for q in reqs:
+            saved = q.output_ids
+            q.output_ids = []                        # fill_ids = prompt only
+            tree.cache_unfinished_req(q)
+            q.output_ids = saved
         ids_cpu = next_ids.tolist()                  # the scheduler's one sync per step
         now = time.perf_counter()
         for q, t in zip(reqs, ids_cpu):
             q.output_ids.append(int(t))
             q.t_first_token = now
-            # process_batch_result_prefill -> cache_unfinished_req (batch_result_processor.py:240)
-            saved = q.output_ids
-            q.output_ids = []                        # fill_ids = prompt only: the new token has no KV yet
-            tree.cache_unfinished_req(q)
-            q.output_ids = saved
         self.running.extend(reqs)
         return next_ids
 

@@ -447,6 +447,25 @@ def argmax(logits: torch.Tensor) -> torch.Tensor:
     return ids
 
 
+def softmax_temperature_from_bf16(logits: torch.Tensor, temperatures: torch.Tensor) -> Optional[torch.Tensor]:
+    """fp32 probs = softmax(logits.float() / T) straight from bf16 logits for decode-sized batches of wide rows (the widening is
+    exact, the arithmetic the fp32 kernel's); None when the shape is not that case (the caller widens and uses softmax_temperature_)."""
+    _dev(logits, temperatures)
+    if logits.dtype != _BF16 or logits.dim() != 2 or logits.stride(1) != 1:
+        return None
+    B, V = logits.shape
+    t = temperatures.reshape(-1)
+    splits = min(64, 2048 // max(1, B))
+    if not (B and splits >= 2 and V >= 4096 * splits // 8 and logits.data_ptr() % 8 == 0 and logits.stride(0) % 4 == 0 and B <= 65535
+            and t.dtype == torch.float32 and t.numel() == B and t.is_contiguous()):
+        return None
+    probs = torch.empty((B, V + (-V) % 4), dtype=torch.float32, device=logits.device)[:, :V]     # 16-byte aligned rows
+    ws = torch.empty((B * splits * 2,), dtype=torch.float32, device=logits.device)
+    native.call("sgl_amd_softmax_temperature_split_bf16", logits.data_ptr(), probs.data_ptr(), t.data_ptr(), B, V, logits.stride(0),
+                probs.stride(0), splits, ws.data_ptr(), _stream())
+    return probs
+
+
 def softmax_temperature_(logits: torch.Tensor, temperatures: torch.Tensor) -> torch.Tensor:
     _dev(logits, temperatures)
     _need(logits.dtype == torch.float32 and logits.dim() == 2 and logits.stride(1) == 1, "softmax: fp32 [B, V]")
@@ -472,6 +491,15 @@ def sampling_lds_keep() -> int:
     return native.lib().sgl_amd_sampling_lds_keep()
 
 
+def sample_ranges(batch: int, vocab: int) -> int:
+    """Column ranges per row for the filtered sampler: about 512 workgroups over the chip (0 = one workgroup per row: batches that
+    fill the chip on their own, or rows too short to be worth three launches)."""
+    if batch <= 0 or batch > 256 or vocab < 16384:
+        return 0
+    r = min(16, 512 // batch)
+    return r if r >= 2 else 0
+
+
 def _sample_workspace(batch: int, vocab: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
     """Caller-owned ranking workspace for nuclei larger than the LDS capacity (B*2*V words each)."""
     key = (batch, vocab, str(device))
@@ -486,7 +514,7 @@ def _sample_workspace(batch: int, vocab: int, device) -> Tuple[torch.Tensor, tor
 def top_k_top_p_min_p_sample(probs: torch.Tensor, top_ks: Optional[torch.Tensor], top_ps: Optional[torch.Tensor],
                              min_ps: Optional[torch.Tensor], sampling_seed: Optional[torch.Tensor],
                              positions: Optional[torch.Tensor], filtered: bool = True, use_workspace: bool = True,
-                             return_n_keep: bool = False):
+                             return_n_keep: bool = False, ranges: Optional[int] = None):
     """sampler.py:567-612 / :732-750 on the gfx950 sampler.  probs fp32 [B, V] (after softmax).
     Without sampling_seed fresh per-row seeds are drawn from torch's device generator."""
     _dev(probs)
@@ -510,6 +538,19 @@ def top_k_top_p_min_p_sample(probs: torch.Tensor, top_ks: Optional[torch.Tensor]
     n_keep = torch.empty(B, dtype=torch.int32, device=dev) if return_n_keep else None
     if filtered:
         ws = _sample_workspace(B, V, dev) if use_workspace else (None, None)
+        # decode-sized batches of wide rows: the two full-row passes as column ranges over the whole chip, then one workgroup
+        # per row on the candidate list (sampling_topk.hip: hist / collect / finish; same ids and kept counts)
+        ranges = sample_ranges(B, V) if (ranges is None and use_workspace) else int(ranges or 0)
+        if ranges >= 2 and probs.data_ptr() % 16 == 0 and probs.stride(0) % 4 == 0:
+            key = ("ranges", B, ranges, str(dev))
+            wr = _SAMPLE_WS.get(key)
+            if wr is None:
+                wr = _SAMPLE_WS[key] = torch.empty(native.lib().sgl_amd_sample_ranges_workspace_bytes(B, ranges) // 8 + 1,
+                                                   dtype=torch.int64, device=dev)
+            native.call("sgl_amd_top_k_top_p_min_p_sample_ranges", probs.data_ptr(), probs.stride(0), B, V, _ptr(top_ks), _ptr(top_ps),
+                        _ptr(min_ps), seeds.data_ptr(), _ptr(positions), ids.data_ptr(), _ptr(ws[0]), _ptr(ws[1]), _ptr(n_keep),
+                        ranges, wr.data_ptr(), _stream())
+            return (ids, n_keep) if return_n_keep else ids
     else:           # unfiltered: 256 bytes per row of range partials (the kernel spreads decode-sized batches over the chip)
         small = torch.empty((B, 64), dtype=torch.int32, device=dev) if use_workspace else None
         ws = (small, small)

@@ -81,9 +81,14 @@ class Sampler(nn.Module):
             # sampler.py:148-152, 211-260: div_ temperature, softmax in place, then sample from probs
             simple_sampling_case = not (sampling_info.need_top_p_sampling or sampling_info.need_top_k_sampling
                                         or sampling_info.need_min_p_sampling)
-            if logits.dtype != torch.float32:
-                logits = logits.float()                                     # exact widening of the bf16 logits
-            probs = kernels.softmax_temperature_(logits, sampling_info.temperatures)
+            probs = None
+            if logits.dtype == torch.bfloat16 and not return_logprob:
+                # bf16 logits of a decode-sized batch: widened inside the softmax launches (exact; no separate pass)
+                probs = kernels.softmax_temperature_from_bf16(logits, sampling_info.temperatures)
+            if probs is None:
+                if logits.dtype != torch.float32:
+                    logits = logits.float()                                 # exact widening of the bf16 logits
+                probs = kernels.softmax_temperature_(logits, sampling_info.temperatures)
             if simple_sampling_case:
                 ids = kernels.top_k_top_p_min_p_sample(probs, None, None, None, sampling_info.sampling_seed, positions,
                                                        filtered=False)

@@ -168,6 +168,36 @@ def test_unfiltered_sampling_over_column_ranges_equals_the_row_kernel(device):
     assert split.cpu()[ok].tolist() == ref.tolist()
 
 
+@pytest.mark.parametrize("V,B", [(128256, 64), (32000, 7), (151936, 3), (16388, 20)])
+def test_filtered_sampling_over_column_ranges_equals_the_row_kernel(device, V, B):
+    """Round 6: the filtered sampler for decode-sized batches -- the first radix level's histogram and the collection of the cut's
+    candidates as column ranges over the whole chip, a third launch finishing each row from its candidate list.  Ids AND kept counts
+    must equal the one-workgroup-per-row kernel's (and through it the oracle's) at every range count: peaked rows (few candidates),
+    flat rows (more candidates than the list holds: those rows run the whole routine in the finish launch), top-k only / top-p only /
+    both / min-p, a tie that straddles a range boundary, top_k = 0."""
+    K = _k()
+    g = torch.Generator().manual_seed(V + B)
+    scale = torch.tensor([4.0, 1.0, 8.0, 0.3, 2.0, 6.0, 3.0][:B] + [3.0] * max(0, B - 7)).unsqueeze(1)
+    probs = torch.softmax(torch.randn((B, V), generator=g) * scale, dim=-1)
+    if B >= 3:
+        per = ((V + 7) // 8 + 3) // 4 * 4                  # a 4-way tie around the first boundary of the 8-range split, cut by top_k = 2
+        probs[2] *= 0.2
+        probs[2, [per - 2, per - 1, per, per + 1]] = 0.2
+    top_ks = torch.tensor(([50, 1, 2, TOP_K_ALL, 1000, 0, 20] * (B // 7 + 1))[:B], dtype=torch.int32)
+    top_ps = torch.tensor(([0.9, 1.0, 1.0, 0.95, 0.8, 0.5, 0.999] * (B // 7 + 1))[:B])
+    min_ps = torch.tensor(([0.0, 0.0, 0.0, 0.01, 0.0, 0.0, 0.2] * (B // 7 + 1))[:B])
+    seeds = torch.randint(0, 2 ** 62, (B,), generator=g)
+    pos = torch.randint(0, 4096, (B,), generator=g)
+    args = (probs.to(device), top_ks.to(device), top_ps.to(device))
+    for mp in (None, min_ps.to(device)):
+        want, want_n = K.top_k_top_p_min_p_sample(*args, mp, seeds.to(device), pos.to(device), return_n_keep=True, ranges=0)
+        for ranges in (2, 5, 8, 16):
+            got, got_n = K.top_k_top_p_min_p_sample(*args, mp, seeds.to(device), pos.to(device), return_n_keep=True, ranges=ranges)
+            assert got_n.cpu().tolist() == want_n.cpu().tolist(), (ranges, mp is not None)
+            assert got.cpu().tolist() == want.cpu().tolist(), (ranges, mp is not None)
+    assert K.sample_ranges(64, 128256) == 8 and K.sample_ranges(512, 128256) == 0 and K.sample_ranges(64, 4096) == 0
+
+
 def test_ties_and_degenerate_rows(device):
     K = _k()
     V = 4096
@@ -267,3 +297,31 @@ def test_sampler_module_flow(device):
                               torch.zeros(B, device=device), is_all_greedy=False, sampling_seed=seeds.to(device))
     got2 = smp(LogitsProcessorOutput(logits.to(device).clone()), info2, positions=pos.to(device))
     assert got2.cpu().tolist() == oh.sampling_from_probs(gp, seeds, pos).tolist()
+
+
+def test_softmax_from_bf16_logits_equals_widen_then_softmax(device):
+    """Round 6: the model-dtype logits of a decode-sized batch are widened INSIDE the two softmax launches: bit-identical to
+    `logits.float()` followed by the fp32 kernel (the widening is exact, the arithmetic and the range order the same), and the
+    Sampler module takes that route for bf16 logits (same ids as with pre-widened logits)."""
+    from sglang_amd.layers.sampler import LogitsProcessorOutput, Sampler, SamplingBatchInfo
+
+    K = _k()
+    g = torch.Generator().manual_seed(5)
+    assert K.softmax_temperature_from_bf16(torch.zeros((3, 32000), dtype=torch.bfloat16, device=device), torch.ones((3, 1), device=device)) is None
+    for B, V in ((64, 128256), (3, 40000), (17, 151936)):
+        lg = (torch.randn((B, V), generator=g) * 3).to(torch.bfloat16).to(device)
+        temps = (torch.rand((B, 1), generator=g) + 0.5).to(device)
+        want = K.softmax_temperature_(lg.float(), temps)
+        got = K.softmax_temperature_from_bf16(lg, temps)
+        assert got is not None and torch.equal(got, want), (B, V)
+    B, V = 16, 128256
+    lg = (torch.randn((B, V), generator=g) * 2).to(torch.bfloat16).to(device)
+    info = SamplingBatchInfo(torch.ones((B, 1), device=device), torch.full((B,), 0.9, device=device),
+                             torch.full((B,), 50, dtype=torch.int32, device=device), torch.zeros(B, device=device), False,
+                             need_top_p_sampling=True, need_top_k_sampling=True,
+                             sampling_seed=torch.arange(B, device=device, dtype=torch.int64) + 7)
+    pos = torch.arange(B, device=device, dtype=torch.int64)
+    smp = Sampler()
+    a = smp(LogitsProcessorOutput(next_token_logits=lg), info, positions=pos)
+    b = smp(LogitsProcessorOutput(next_token_logits=lg.float()), info, positions=pos)
+    assert a.cpu().tolist() == b.cpu().tolist()
