@@ -228,7 +228,14 @@ def worker(args):
 
     if args.operator_surface:
         models.OPERATOR_SURFACE_ONLY = True
-    ps.init_distributed_environment()
+    # SGLANG_AMD_BENCH_SHARE_GPU=1: the ranks of an N > 1 launch all use GPU 0 (gloo process groups, the xGMI kernels over hipIpc
+    # between the processes) -- a DRY RUN of the driver's multi-GPU command on a one-GPU box (tests/test_engine_gpu.py): the launch
+    # path, the rank checks and the JSON line are the real ones, the number is not a multi-GPU measurement and the line says so
+    share_gpu = os.environ.get("SGLANG_AMD_BENCH_SHARE_GPU", "") not in ("", "0") and int(os.environ.get("WORLD_SIZE", "1")) > 1
+    if share_gpu:
+        ps.init_distributed_environment(backend="gloo", device_index=0)
+    else:
+        ps.init_distributed_environment()
     world = ps.get_tensor_model_parallel_world_size()
     rank = int(os.environ.get("RANK", "0"))
     if args.rank_of:
@@ -321,7 +328,7 @@ def worker(args):
     sync(); barrier()
     elapsed = time.perf_counter() - t_start
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if share_gpu else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -381,7 +388,8 @@ def worker(args):
                                + (" [fp8_e4m3 KV pool -- not the baseline configuration]" if kv_fp8 else "")
                                + (f" [REDUCED: {args.layers} layers -- not a valid bench line]" if reduced else ""),
                    "model": cfg.name, "global_batch": B, "seq_len": in_len,
-                   "parallelism": f"tp{world}" if not args.rank_of else
+                   "parallelism": (f"tp{world}" + (f" as {world} processes time-slicing ONE GPU (gloo groups, xGMI kernels over hipIpc): a dry run "
+                                                      "of the launch path -- NOT a multi-GPU measurement" if share_gpu else "")) if not args.rank_of else
                    f"RANK SHAPES of tp{tp} on 1 GPU: rank 0's weight shards, the tp{tp} job's batch, collectives = world-of-1 "
                    f"loopback launches of the xGMI kernels (no wire time) -- not a multi-GPU measurement",
                    "decode": decode_mode},

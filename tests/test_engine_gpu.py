@@ -1,11 +1,15 @@
 """End-to-end GPU parity: the product engine (radix cache + paged pools + HIP kernels +
 hipGraph decode) against the CPU oracle model that shares nothing between requests."""
+import os
 import random
+from pathlib import Path
 
 import pytest
 import torch
 
 from oracle.model import OracleLM, weights_from_product_model
+
+ROOT = Path(__file__).resolve().parent.parent
 
 pytestmark = pytest.mark.gpu
 
@@ -365,3 +369,40 @@ def test_target_verify_scores_a_draft_tree_like_its_linearised_paths(device):
         # the engine goes on decoding afterwards (the verify step left no state behind)
         eng.decode_step(); eng.flush_decode_outputs()
         eng.finish(list(eng.running))
+
+
+def test_the_drivers_multi_gpu_bench_command_starts_on_one_gpu(device, tmp_path):
+    """the SCALE driver's command -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N --steps K --warmup W` -- is known to start, run TP = N and print ONE JSON line with `n_gpus` = N
+    before a multi-GPU box ever runs it: here with N = 2 ranks time-slicing GPU 0 (SGLANG_AMD_BENCH_SHARE_GPU=1: gloo groups, the xGMI
+    kernels over hipIpc; the line says it is a dry run).  And a job whose world size is not --gpus is refused, not reported."""
+    import json
+    import socket
+    import subprocess
+    import sys
+
+    def port():
+        s_ = socket.socket()
+        s_.bind(("127.0.0.1", 0))
+        p_ = s_.getsockname()[1]
+        s_.close()
+        return p_
+
+    small = ["--model", "qwen2.5-0.5b", "--groups", "1", "--per-group", "4", "--prefix", "32", "--unique", "16", "--out", "4",
+             "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-parity", "--no-kernel-roofline", "--no-reference-scheduler"]
+    env = dict(os.environ, SGLANG_AMD_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", SGLANG_USE_AITER="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port()), str(ROOT / "bench.py"), "--gpus", "2"] + small
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]                        # rank 0 alone prints
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["scaling"] == "weak" and rec["steps"] == 1, rec
+    assert rec["config"]["parallelism"].startswith("tp2") and "NOT a multi-GPU measurement" in rec["config"]["parallelism"], rec["config"]
+    assert rec["config"]["global_batch"] == 8                       # weak scaling: 1 group x 4 prompts per GPU
+    # one rank under a --gpus 2 command line: refused
+    cmd[cmd.index("--nproc-per-node") + 1] = "1"
+    cmd[cmd.index("--master-port") + 1] = str(port())
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0 and "refusing to report" in (p.stderr + p.stdout), (p.returncode, p.stderr[-1500:])

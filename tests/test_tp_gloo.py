@@ -49,6 +49,40 @@ def _worker(rank: int, world: int, port: int, name: str, q):
         plain = ps.tensor_model_parallel_all_reduce(torch.nn.functional.linear(xk, wk))
         piecewise = ps.row_parallel_linear(xk, wk, min_rows_per_chunk=64, max_chunks=4)
         assert torch.equal(plain, piecewise) and piecewise.shape == (300, 24)
+        # ... and its SCHEDULE is the overlapped one: every chunk's collective is issued asynchronously (on RCCL's own stream on a
+        # GPU node) right behind that chunk's matmul, the next chunk's matmul is launched without waiting, and the first wait comes
+        # after the last collective was issued ("overlap asserted by a trace" -- the trace a one-GPU lease allows)
+        import torch.distributed as _dist
+
+        trace = []
+        real_ar, real_mm = _dist.all_reduce, torch.matmul
+
+        class _Work:
+            def __init__(self, w, i):
+                self.w, self.i = w, i
+
+            def wait(self):
+                trace.append(("wait", self.i))
+                return self.w.wait()
+
+        def traced_ar(t, *a, **k):
+            i = sum(1 for e in trace if e[0] == "all_reduce")
+            trace.append(("all_reduce", i, bool(k.get("async_op"))))
+            w = real_ar(t, *a, **k)
+            return _Work(w, i) if k.get("async_op") else w
+
+        def traced_mm(a_, b_, **k):
+            trace.append(("matmul", tuple(a_.shape)))
+            return real_mm(a_, b_, **k)
+
+        _dist.all_reduce, torch.matmul = traced_ar, traced_mm
+        try:
+            ps.row_parallel_linear(xk, wk, min_rows_per_chunk=64, max_chunks=4)
+        finally:
+            _dist.all_reduce, torch.matmul = real_ar, real_mm
+        kinds = [e[0] for e in trace]
+        assert kinds == ["matmul", "all_reduce"] * 4 + ["wait"] * 4, trace
+        assert all(e[2] for e in trace if e[0] == "all_reduce") and [e[1] for e in trace if e[0] == "matmul"] == [(75, 32)] * 4, trace
         # the fused form falls back to all-reduce + the norm kernel's arithmetic when no one-shot communicator exists
         assert ps.get_xgmi_all_reduce() is None
 
