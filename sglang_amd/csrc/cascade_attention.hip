@@ -99,19 +99,23 @@ struct ChunkParams {
 template <int D, bool FP8, bool HND>
 __global__ __launch_bounds__(kThreads, 5) void cascade_chunk_kernel(ChunkParams p) {
   __shared__ U4 sm[(kChunk / (D > 64 ? D / 64 : 1)) * (D / 8)];   // K: [token of the part][piece ^ swz];  V^T: [d of the part][8-token chunk ^ swz]
+  __shared__ float ml_s[64];                                      // token-split units: (max, sum) of [wave][row < 8]
+  __shared__ U4 side_s[D > 64 ? 4 * 8 * (D - 64) / 4 : 1];        // ... and their O^T partials of every V^T part but the last
   const int unit = blockIdx.x;
   const int tid = threadIdx.x;
 #include "cascade_chunk_body.inc"
 }
 
 template <int D, bool FP8, bool HND>
-__device__ __forceinline__ void cascade_chunk_unit(const ChunkParams& p, U4* sm, const int unit, const int tid) {
+__device__ __forceinline__ void cascade_chunk_unit(const ChunkParams& p, U4* sm, float* ml_s, U4* side_s, const int unit, const int tid) {
 #include "cascade_chunk_body.inc"
 }
 
 template <int D, bool FP8, bool HND>
 __global__ __launch_bounds__(kThreads, 4) void cascade_chunk_loop_kernel(ChunkParams p) {
   __shared__ U4 sm[(kChunk / (D > 64 ? D / 64 : 1)) * (D / 8)];
+  __shared__ float ml_s[64];
+  __shared__ U4 side_s[D > 64 ? 4 * 8 * (D - 64) / 4 : 1];
   int n_items = __builtin_amdgcn_readfirstlane(p.plan[0]);                   // header[0]: the list's length
   if (n_items > p.max_items) n_items = p.max_items;
   const int n_units = n_items * p.num_kv_heads;
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(kThreads, 4) void cascade_chunk_loop_kernel(ChunkPa
       const ChunkParams pl = __builtin_bit_cast(ChunkParams, raw);
       int tid = threadIdx.x;
       asm volatile("" : "+v"(tid));
-      cascade_chunk_unit<D, FP8, HND>(pl, sm, unit, tid);
+      cascade_chunk_unit<D, FP8, HND>(pl, sm, ml_s, side_s, unit, tid);
       __syncthreads();                                                        // the image is reused by the next unit
     }
   }

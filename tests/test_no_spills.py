@@ -43,15 +43,19 @@ def test_cascade_chunk_kernel_fits_five_workgroups_per_cu(tmp_path):
         # barrier, read back after the softmax) in scratch in some instances: tolerated; anything more lands inside the
         # load burst (a reload waits for every row in flight) and must fail here
         assert u["vgpr_spill_count"] <= 3 and u["sgpr_spill_count"] == 0, (name, u)
+        if "ILi128ELb0E" in name:                               # the bf16 D = 128 instances (the benchmarked ones): none at all
+            assert u["vgpr_spill_count"] == 0, (name, u)
         assert u["vgpr_count"] <= 96, (name, u)                 # 512 / 5 waves per SIMD, 8-register granules
-        assert u["group_segment_fixed_size"] <= 16384, (name, u)  # five 16 KiB images of the 160 KiB (LDS granule 1280 B)
+        # five workgroups per CU: LDS is handed out in 1280-byte granules -- the 16 KiB image + the token-split units' side buffer
+        # (8 KiB at D = 128) + 256 B of (max, sum) = 20 granules, five of them 128 000 of the 163 840 bytes
+        assert u["group_segment_fixed_size"] <= 25600, (name, u)
     # the looping form (large request tables: a bounded grid walks the item list) runs four workgroups per CU and must not spill at all
     # (a five-per-CU instance parks ~29 registers in scratch and measured 34 against 26.7 us per layer: profiles/r05_exp1b_cascade_forms.json)
     loop = {k: v for k, v in usage.items() if "cascade_chunk_loop_kernel" in k}
     assert len(loop) == 8, sorted(usage)
     for name, u in loop.items():
         assert u["vgpr_spill_count"] == 0 and u["sgpr_spill_count"] == 0, (name, u)
-        assert u["vgpr_count"] <= 128 and u["group_segment_fixed_size"] <= 16384, (name, u)
+        assert u["vgpr_count"] <= 128 and u["group_segment_fixed_size"] <= 25600, (name, u)
 
 
 @pytest.mark.skipif(not Path(HIPCC).exists(), reason="hipcc not installed")
