@@ -528,7 +528,7 @@ def kernel_rooflines(args, cfg, runner, result, B, G, P, in_len, ctx, t_decode_s
         """Average duration of one launch: `fn` (which enqueues `launches` kernels) captured into a
         hipGraph, replayed `reps` times between two HIP events on the current stream.  `warm` untimed replays run
         first, back to back with the timed ones: the first replays after host-side work measure 8-10 % slower
-        (benchmarks/r02_exp19_model_weights.py: 45.5 us, then 41.8 us for the same launches)."""
+        (benchmarks/archive/r02_exp19_model_weights.py: 45.5 us, then 41.8 us for the same launches)."""
         fn()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
