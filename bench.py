@@ -59,7 +59,7 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_PEAK_TFLOPS = 2500.0     # bf16 dense
-PMC_FILE = ROOT / "profiles" / "r05_pmc.json"
+PMC_FILE = ROOT / "profiles" / "r06_pmc.json"
 PMC_NAME = "profiles/" + PMC_FILE.name
 
 
