@@ -684,6 +684,12 @@ def kernel_rooflines(args, cfg, runner, result, B, G, P, in_len, ctx, t_decode_s
         # to a 20 us launch pair)
         t_c = graph_time(lambda: [K.cascade_decode_attention(cws, q, kc, vc, o, r2t, pool_idx, seq, D ** -0.5) for _ in range(NREP)],
                          NREP, reps=10)
+        # ... and the same launches over EIGHT layers' pools in turn: every row then comes from HBM, as inside the step (one layer's
+        # 65 MB stay in the 256 MiB memory-side cache from replay to replay: the figure above is a cache-warm one)
+        nl = min(NREP, len(runner.model.layers))
+        pools = [(runner.token_to_kv_pool.get_key_buffer(i), runner.token_to_kv_pool.get_value_buffer(i)) for i in range(nl)]
+        t_cc = graph_time(lambda: [K.cascade_decode_attention(cws, q, kc_, vc_, o, r2t, pool_idx, seq, D ** -0.5) for kc_, vc_ in pools],
+                          nl, reps=10) if nl >= 4 else None
         uniq = (G * args.prefix + B * (len_k - args.prefix)) * row_bytes
         tr = None
         casc_src = ("cascade_attention.hip", "cascade_plan.hpp")
@@ -692,7 +698,9 @@ def kernel_rooflines(args, cfg, runner, result, B, G, P, in_len, ctx, t_decode_s
             tr = hbm_bytes(rc) + hbm_bytes(rm)
         att["cascade"] = {"kernel": "cascade_chunk_kernel + cascade_merge2_kernel", "us_per_layer": t_c * 1e6,
                           "bytes_unique": uniq, "achieved": uniq / t_c / 1e9, "frac": uniq / t_c / 1e9 / HBM_PEAK_GBPS,
-                          "traffic": tr}
+                          "traffic": tr,
+                          "us_per_layer_cold_pools": t_cc * 1e6 if t_cc else None,
+                          "frac_cold_pools": uniq / t_cc / 1e9 / HBM_PEAK_GBPS if t_cc else None}
     splits = choose_num_splits(B, Hkv_r, Hq_r // Hkv_r, len_k)
     ws = K.decode_workspace(B, Hq_r, D, splits, dev) if splits > 1 else (None, None)
     t_k = graph_time(lambda: [K.decode_attention(q, kc, vc, o, r2t, pool_idx, seq, D ** -0.5, splits, ws[0], ws[1]) for _ in range(NREP)],

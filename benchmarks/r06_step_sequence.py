@@ -57,6 +57,16 @@ def main(prof_dir, out_path, start_sub="wstream_gemm_kernel<4, 5, 1", anchor="ar
             td += d
             f.write(f"{p:3d}  {g:7.2f}  {d:7.2f}   {pos_name[p][:140]}\n")
         f.write(f"sum  {tg:7.2f}  {td:7.2f}\n")
+        # what a step runs OUTSIDE its layers, in launch order (one representative step): the tail of the last layer's launches
+        # (final norm / lm_head / arg-max) and everything between the arg-max and the first layer of the next step
+        i = good[len(good) // 2]
+        seg = rows[marks[i]:marks[i + 1] + 1]
+        starts = [j for j, r in enumerate(seg) if start_sub in r[2]]
+        f.write("\noutside the layers (one step, launch order): gap_us  dur_us  kernel\n")
+        per = starts[1] - starts[0] if len(starts) > 1 else 9
+        for k in list(range(0, starts[0])) + list(range(starts[-1] + per, len(seg))):
+            g = (seg[k][0] - seg[k - 1][1]) / 1e3 if k else 0.0
+            f.write(f"  {g:7.2f} {(seg[k][1] - seg[k][0]) / 1e3:7.2f}   {seg[k][2][:120]}\n")
     print(open(out_path).read())
 
 

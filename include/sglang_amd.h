@@ -48,6 +48,12 @@ const char* sgl_amd_target_arch(void);
 /* out[r,:] = bf16((x[r,:] * rsqrt(mean(x^2)+eps)) * weight), fp32 math. */
 int sgl_amd_rmsnorm(const void* x, const void* weight, void* out, int64_t num_rows, int hidden,
                     int64_t x_row_stride, int64_t out_row_stride, float eps, void* stream);
+/* hidden_out[r,:] = table[ids[r],:] (the embedding lookup of a decode step: models/llama.py:433-437 `embed_tokens(input_ids)`, the
+ * output becomes the residual stream) and out[r,:] = RMSNorm(hidden_out[r,:]) * weight (the first layer's input_layernorm,
+ * :349-353) in one launch.  bf16; ids int64 in [0, vocab). */
+int sgl_amd_embedding_rmsnorm(const int64_t* ids, const void* table, const void* weight, void* hidden_out, void* out,
+                              int64_t num_rows, int hidden, int64_t vocab, int64_t table_row_stride, int64_t hidden_row_stride,
+                              int64_t out_row_stride, float eps, void* stream);
 /* in place: residual <- bf16(x + residual); x <- rmsnorm(fp32(x + residual)). */
 int sgl_amd_fused_add_rmsnorm(void* x, void* residual, const void* weight, int64_t num_rows,
                               int hidden, int64_t x_row_stride, int64_t res_row_stride, float eps,
@@ -200,9 +206,10 @@ int sgl_amd_cascade_decode_attention_ex(const void* q, const void* k_cache, cons
 int sgl_amd_argmax(const void* logits, int logits_is_bf16, int64_t* ids, int64_t batch,
                    int64_t vocab, int64_t row_stride, void* stream);
 /* The same ids with every row cut into num_splits column ranges (one workgroup each; a decode batch on one workgroup
- * per row leaves most CUs idle): range winners meet in a per-row 64-bit key by atomicMax, the last arriver writes the id.
- * workspace: sgl_amd_argmax_split_workspace_bytes(batch) bytes, ZERO before the first call, private to one stream at a
- * time (the kernel re-arms it); rows 16-byte aligned; vocab < 2^32. */
+ * per row leaves most CUs idle): every range's winner is a 64-bit key (order-preserving value bits, then the smaller
+ * index) in the workspace, a second launch takes the row maxima (round 6: two plain launches instead of atomics + fences
+ * behind the lm_head stream).  workspace: sgl_amd_argmax_split_workspace_bytes(batch) bytes, caller-owned, no initial
+ * state, private to one stream at a time; rows 16-byte aligned; vocab < 2^32. */
 int64_t sgl_amd_argmax_split_workspace_bytes(int64_t batch);
 int sgl_amd_argmax_split(const void* logits, int logits_is_bf16, int64_t* ids, int64_t batch, int64_t vocab,
                          int64_t row_stride, int num_splits, void* workspace, void* stream);

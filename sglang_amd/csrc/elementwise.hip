@@ -86,6 +86,49 @@ __global__ void rmsnorm_kernel(const uint16_t* __restrict__ x, uint16_t* __restr
   }
 }
 
+// hidden[row] = table[ids[row]] (the embedding lookup of the decode step, llama.py:433-437) and out[row] = RMSNorm(hidden[row])
+// (the first layer's input_layernorm, llama.py:349-353) in ONE launch: the rows are in registers anyway.  ids outside
+// [0, vocab) read row 0 (the reference's F.embedding would fault: the caller never passes them).
+__global__ void embedding_rmsnorm_kernel(const int64_t* __restrict__ ids, const uint16_t* __restrict__ table,
+                                         const uint16_t* __restrict__ w, uint16_t* __restrict__ hidden_out,
+                                         uint16_t* __restrict__ out, int hidden, int64_t vocab, int64_t table_stride,
+                                         int64_t hid_stride, int64_t out_stride, float eps) {
+  __shared__ float scratch[16];
+  const int64_t row = blockIdx.x;
+  const int nvec = hidden >> 3;
+  int64_t id = ids[row];
+  if (id < 0 || id >= vocab) id = 0;
+  const uint16_t* xr = table + id * table_stride;
+  uint16_t* hr = hidden_out + row * hid_stride;
+  uint16_t* orow = out + row * out_stride;
+  float xs[kMaxVecPerThread][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < kMaxVecPerThread; ++i) {
+    const int v = i * blockDim.x + threadIdx.x;
+    if (v < nvec) {
+      const U4 raw = ld16(xr + (v << 3));
+      st16(hr + (v << 3), raw);
+      unpack8(raw, xs[i]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ss += xs[i][j] * xs[i][j];
+    }
+  }
+  ss = block_sum(ss, scratch);
+  const float rs = 1.0f / sqrtf(ss / static_cast<float>(hidden) + eps);
+#pragma unroll
+  for (int i = 0; i < kMaxVecPerThread; ++i) {
+    const int v = i * blockDim.x + threadIdx.x;
+    if (v < nvec) {
+      float ws[8], o[8];
+      unpack8(ld16(w + (v << 3)), ws);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (xs[i][j] * rs) * ws[j];
+      st16(orow + (v << 3), pack8(o));
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // SiLU-and-mul.  in [T, 2d] -> out [T, d].  torch-native rounding
 // (activation.py:141-143): s = bf16(silu(g)); out = bf16(s * u).
@@ -316,6 +359,25 @@ int sgl_amd_rmsnorm(const void* x, const void* weight, void* out, int64_t num_ro
                      static_cast<const uint16_t*>(x), nullptr, static_cast<const uint16_t*>(weight),
                      static_cast<uint16_t*>(out), hidden, x_row_stride, 0, out_row_stride, eps);
   SGL_CHECK_LAUNCH("rmsnorm");
+  return 0;
+}
+
+int sgl_amd_embedding_rmsnorm(const int64_t* ids, const void* table, const void* weight, void* hidden_out, void* out,
+                              int64_t num_rows, int hidden, int64_t vocab, int64_t table_row_stride, int64_t hidden_row_stride,
+                              int64_t out_row_stride, float eps, void* stream) {
+  SGL_CLEAR_STALE_ERROR();
+  SGL_CHECK_ARG(hidden > 0 && hidden % 8 == 0 && vocab > 0, "embedding_rmsnorm: hidden=%d must be a positive multiple of 8", hidden);
+  SGL_CHECK_ARG(table_row_stride % 8 == 0 && hidden_row_stride % 8 == 0 && out_row_stride % 8 == 0,
+                "embedding_rmsnorm: row strides must be multiples of 8 elements");
+  SGL_CHECK_ARG(ids && aligned16(table) && aligned16(weight) && aligned16(hidden_out) && aligned16(out),
+                "embedding_rmsnorm: pointers must be 16-byte aligned");
+  if (num_rows == 0) return 0;
+  const int threads = norm_threads(hidden);
+  SGL_CHECK_ARG((hidden >> 3) <= threads * kMaxVecPerThread, "embedding_rmsnorm: hidden=%d too large", hidden);
+  hipLaunchKernelGGL(embedding_rmsnorm_kernel, dim3(num_rows), dim3(threads), 0, as_stream(stream), ids,
+                     static_cast<const uint16_t*>(table), static_cast<const uint16_t*>(weight), static_cast<uint16_t*>(hidden_out),
+                     static_cast<uint16_t*>(out), hidden, vocab, table_row_stride, hidden_row_stride, out_row_stride, eps);
+  SGL_CHECK_LAUNCH("embedding_rmsnorm");
   return 0;
 }
 

@@ -145,15 +145,18 @@ __global__ __launch_bounds__(kRowThreads) void argmax_split_kernel(const void* _
       any = true;
     }
   };
+  const int nthr = blockDim.x;                           // 1024 (one-launch form) or 256 (two-launch form: eight vectors per thread)
   int64_t j = v0 + threadIdx.x;
-  for (; j + kRowThreads < v1; j += 2 * kRowThreads) {     // two loads in flight
-    const U4 a = vbase[j], b2 = vbase[j + kRowThreads];
+  for (; j + 3 * nthr < v1; j += 4 * nthr) {             // four loads in flight
+    const U4 a = vbase[j], b2 = vbase[j + nthr], c2 = vbase[j + 2 * nthr], d2 = vbase[j + 3 * nthr];
     take_vec(a, j * EPV);
-    take_vec(b2, (j + kRowThreads) * EPV);
+    take_vec(b2, (j + nthr) * EPV);
+    take_vec(c2, (j + 2 * nthr) * EPV);
+    take_vec(d2, (j + 3 * nthr) * EPV);
   }
-  if (j < v1) take_vec(vbase[j], j * EPV);
+  for (; j < v1; j += nthr) take_vec(vbase[j], j * EPV);
   if (blockIdx.x == splits - 1)
-    for (int64_t i = nvec * EPV + threadIdx.x; i < vocab; i += kRowThreads) take(load_logit<BF16>(base, i), i);
+    for (int64_t i = nvec * EPV + threadIdx.x; i < vocab; i += nthr) take(load_logit<BF16>(base, i), i);
   for (int off = 32; off > 0; off >>= 1) {
     const unsigned long long o = __shfl_xor(best, off, 64);
     best = o > best ? o : best;
@@ -162,7 +165,14 @@ __global__ __launch_bounds__(kRowThreads) void argmax_split_kernel(const void* _
   if (lane == 0) s_key[wid] = best;
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int w = 1; w < kRowThreads / 64; ++w) best = s_key[w] > best ? s_key[w] : best;
+    for (int w = 1; w < nthr / 64; ++w) best = s_key[w] > best ? s_key[w] : best;
+    if (tickets == nullptr) {
+      // two-launch form (round 6): the range's key goes to its own word, a second launch takes the row maxima.  Inside the decode
+      // step the one-launch form below measured 15.9 us for 16 MB: its two fences (agent-scope: an L2 write-back each) and the
+      // returning atomics sit behind a stream of 1 GB of lm_head weights; two plain launches are ~9 us
+      keys[row * splits + blockIdx.x] = best;
+      return;
+    }
     atomicMax(&keys[row], best);
     __threadfence();
     if (atomicAdd(&tickets[row], 1u) == static_cast<unsigned>(splits - 1)) {
@@ -173,6 +183,18 @@ __global__ __launch_bounds__(kRowThreads) void argmax_split_kernel(const void* _
       atomicExch(&tickets[row], 0u);
     }
   }
+}
+
+__global__ __launch_bounds__(256) void argmax_merge_kernel(const unsigned long long* __restrict__ keys, int64_t* __restrict__ ids,
+                                                           int64_t batch, int splits) {
+  const int64_t row = blockIdx.x * 256ll + threadIdx.x;
+  if (row >= batch) return;
+  unsigned long long k = 0ull;
+  for (int s = 0; s < splits; ++s) {
+    const unsigned long long o = keys[row * splits + s];
+    k = o > k ? o : k;
+  }
+  ids[row] = k ? static_cast<int64_t>(0xffffffffu - static_cast<uint32_t>(k & 0xffffffffu)) : 0;
 }
 
 // logits <- softmax(logits / T), fp32, in place (sampler.py:211-216).
@@ -308,7 +330,7 @@ int sgl_amd_argmax(const void* logits, int logits_is_bf16, int64_t* ids, int64_t
   return 0;
 }
 
-int64_t sgl_amd_argmax_split_workspace_bytes(int64_t batch) { return batch * 16; }
+int64_t sgl_amd_argmax_split_workspace_bytes(int64_t batch) { return batch * 64 * 8; }   /* a key per (row, range <= 64) */
 
 int sgl_amd_argmax_split(const void* logits, int logits_is_bf16, int64_t* ids, int64_t batch, int64_t vocab,
                          int64_t row_stride, int num_splits, void* workspace, void* stream) {
@@ -319,14 +341,15 @@ int sgl_amd_argmax_split(const void* logits, int logits_is_bf16, int64_t* ids, i
                 "argmax_split: needs the workspace and 16-byte aligned rows");
   if (batch == 0) return 0;
   unsigned long long* keys = static_cast<unsigned long long*>(workspace);
-  unsigned int* tickets = reinterpret_cast<unsigned int*>(keys + batch);
   const dim3 grid(num_splits, static_cast<unsigned>(batch));
   if (logits_is_bf16)
-    hipLaunchKernelGGL(argmax_split_kernel<true>, grid, dim3(kRowThreads), 0, as_stream(stream), logits, ids, vocab, row_stride,
-                       num_splits, keys, tickets);
+    hipLaunchKernelGGL(argmax_split_kernel<true>, grid, dim3(256), 0, as_stream(stream), logits, ids, vocab, row_stride,
+                       num_splits, keys, static_cast<unsigned int*>(nullptr));
   else
-    hipLaunchKernelGGL(argmax_split_kernel<false>, grid, dim3(kRowThreads), 0, as_stream(stream), logits, ids, vocab, row_stride,
-                       num_splits, keys, tickets);
+    hipLaunchKernelGGL(argmax_split_kernel<false>, grid, dim3(256), 0, as_stream(stream), logits, ids, vocab, row_stride,
+                       num_splits, keys, static_cast<unsigned int*>(nullptr));
+  hipLaunchKernelGGL(argmax_merge_kernel, dim3(static_cast<unsigned>((batch + 255) / 256)), dim3(256), 0, as_stream(stream), keys, ids,
+                     batch, num_splits);
   SGL_CHECK_LAUNCH("argmax_split");
   return 0;
 }

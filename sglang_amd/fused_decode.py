@@ -218,14 +218,45 @@ def decode_layer_moe(layer, positions: torch.Tensor, normed: torch.Tensor, forwa
     return h
 
 
-def decode_model(model, hidden_states: torch.Tensor, positions: torch.Tensor, forward_batch, comm=None) -> torch.Tensor:
+def plain_embedding_weight(emb) -> Optional[torch.Tensor]:
+    """The table of an embedding module whose forward at TP = 1 is exactly `F.embedding(ids, weight)` (vocab_parallel_embedding.py:
+    527-540, 566-579: an unsharded VocabParallelEmbedding with the unquantised method), else None: sharded tables (masking + the
+    all-reduce), quantised or LoRA-wrapped embeddings keep the module's own forward."""
+    if type(emb).__name__ != "VocabParallelEmbedding" or hasattr(emb, "base_layer") or hasattr(emb, "set_lora"):
+        return None
+    if int(getattr(emb, "tp_size", 1) or 1) != 1:
+        return None
+    qm = getattr(emb, "quant_method", None)
+    if qm is not None and type(qm).__name__ != "UnquantizedEmbeddingMethod":
+        return None
+    w = getattr(emb, "weight", None)
+    if not isinstance(w, torch.Tensor) or w.dtype != _BF16 or w.dim() != 2 or w.stride(1) != 1 or not w.is_cuda or w.data_ptr() % 16 or w.stride(0) % 8:
+        return None
+    return w.data
+
+
+def embed_and_norm(model, input_ids: torch.Tensor):
+    """(embed_tokens(input_ids), input_layernorm of layer 0 of it) -- one launch when the embedding is a plain table and the ids are the
+    int64 vector a decode batch carries; the module's own forward + the norm kernel otherwise."""
+    n0 = model.layers[0].input_layernorm
+    w = plain_embedding_weight(model.embed_tokens)
+    if (w is not None and isinstance(input_ids, torch.Tensor) and input_ids.is_cuda and input_ids.dtype == torch.int64 and input_ids.dim() == 1
+            and input_ids.is_contiguous() and n0.weight.dtype == _BF16 and n0.weight.shape[-1] == w.shape[1]
+            and int(getattr(model.embed_tokens, "num_embeddings", w.shape[0])) <= w.shape[0]):
+        return kernels.embedding_rmsnorm(input_ids, w, n0.weight.data, n0.variance_epsilon)
+    hidden_states = model.embed_tokens(input_ids)
+    return hidden_states, None
+
+
+def decode_model(model, hidden_states: torch.Tensor, positions: torch.Tensor, forward_batch, comm=None, first_normed=None) -> torch.Tensor:
     """The layer loop + final norm of LlamaModel.forward for a decode batch: returns norm(...) [M, hidden] (chunk-major at
-    TP = 1: kernels.unblock)."""
+    TP = 1: kernels.unblock).  `first_normed`: layer 0's input_layernorm of `hidden_states` when embed_and_norm() already made it."""
     layers = model.layers
     residual = hidden_states                     # the embedding output becomes the residual stream (llama.py:349-353)
     if comm is not None and not residual.is_contiguous():
         residual = residual.contiguous()
-    x = kernels.rmsnorm(hidden_states, layers[0].input_layernorm.weight.data, layers[0].input_layernorm.variance_epsilon)
+    x = first_normed if first_normed is not None else kernels.rmsnorm(hidden_states, layers[0].input_layernorm.weight.data,
+                                                                        layers[0].input_layernorm.variance_epsilon)
     for i, layer in enumerate(layers):
         nxt = layers[i + 1].input_layernorm if i + 1 < len(layers) else model.norm
         step = decode_layer_moe if moe_block_of(layer) is not None else decode_layer
@@ -328,9 +359,9 @@ def llama_model_forward_hook(original, self, input_ids, positions, forward_batch
         known = rows > 0 and isinstance(emb_w, torch.Tensor) and emb_w.dim() == 2
         if known:
             if emb_w.is_cuda and emb_w.dtype == _BF16 and rows_fusable(self, rows, int(emb_w.shape[1]), forward_batch, comm):
-                hidden_states = self.embed_tokens(input_ids)
+                hidden_states, normed0 = embed_and_norm(self, input_ids) if comm is None else (self.embed_tokens(input_ids), None)
                 if model_fusable(self, hidden_states, forward_batch, comm):      # (what the embedding returned is what was assumed)
-                    return kernels.unblock(decode_model(self, hidden_states, positions, forward_batch, comm))
+                    return kernels.unblock(decode_model(self, hidden_states, positions, forward_batch, comm, normed0))
                 _say_once_why_not(self, forward_batch, hidden_states)
                 return _finish_unfused(original, self, hidden_states, positions, forward_batch)
         else:

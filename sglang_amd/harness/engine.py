@@ -445,13 +445,21 @@ class Engine:
                           attn_backend=r.attn_backend, sampling_info=sampling_info)
         if r.graph_runner is None or not r.graph_runner.can_run(bs):
             fb.positions = kernels.clamp_position(fb.seq_lens)
+        replayed = r.graph_runner is not None and r.graph_runner.can_run(bs)
         logits = r.forward(fb)
         self._record_logits(logits, st["reqs"])
-        next_ids = r.sample(logits, fb)
-        if fused:
-            st["last_ids"].copy_(next_ids)              # straight into the graph's input buffer
+        info = sampling_info
+        if (fused and replayed and getattr(r.graph_runner, "greedy_ids_in_graph", False) and (info is None or info.is_all_greedy)
+                and st["last_ids"].data_ptr() == r.graph_runner.input_ids.data_ptr()):
+            # the replayed graph has already put the greedy pick of every row into its own input buffer (= this state's last_ids):
+            # nothing to launch, nothing to copy.  (The returned tensor IS that buffer: valid until the next step.)
+            next_ids = st["last_ids"]
         else:
-            st["last_ids"] = next_ids.to(torch.int64)
+            next_ids = r.sample(logits, fb)
+            if fused:
+                st["last_ids"].copy_(next_ids)          # straight into the graph's input buffer
+            else:
+                st["last_ids"] = next_ids.to(torch.int64)
         # token hand-off to the host: an async copy into pinned memory + an event, so that the scheduler can
         # launch step N+1 before it looks at step N's tokens (overlap scheduling, scheduler.py:1783)
         on_gpu = next_ids.is_cuda                       # (host-logic tests drive this class with CPU tensors)

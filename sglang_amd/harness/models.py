@@ -362,10 +362,19 @@ class CausalLM(nn.Module):
 
     def forward_hidden(self, input_ids: torch.Tensor, positions: torch.Tensor, forward_batch) -> torch.Tensor:
         embeds = getattr(forward_batch, "input_embeds", None)
-        hidden_states = embeds if embeds is not None else F.embedding(input_ids, self.embed_tokens)
+        x = None
+        if (embeds is None and forward_batch.forward_mode.is_decode() and input_ids.is_cuda and input_ids.dtype == torch.int64
+                and input_ids.dim() == 1 and self.embed_tokens.dtype == BF and not OPERATOR_SURFACE_ONLY):
+            # decode step: the embedding lookup and the first layer's input norm in one launch (fused_decode.embed_and_norm does the
+            # same on a reference model)
+            n0 = self.layers[0].input_layernorm
+            hidden_states, x = kernels.embedding_rmsnorm(input_ids, self.embed_tokens.data, n0.weight.data, n0.variance_epsilon)
+        else:
+            hidden_states = embeds if embeds is not None else F.embedding(input_ids, self.embed_tokens)
         if all(layer.fusable(hidden_states, self.tp_size) for layer in self.layers):
             residual = hidden_states                     # the embedding output becomes the residual stream
-            x = self.layers[0].input_layernorm(hidden_states)
+            if x is None:
+                x = self.layers[0].input_layernorm(hidden_states)
             for i, layer in enumerate(self.layers):
                 nxt = self.layers[i + 1].input_layernorm if i + 1 < len(self.layers) else self.norm
                 x = layer.forward_decode_fused(positions, x, forward_batch, residual, nxt)

@@ -62,6 +62,21 @@ def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float, out: Optional[tor
     return out.view(x.shape) if out.shape != x.shape else out
 
 
+def embedding_rmsnorm(ids: torch.Tensor, table: torch.Tensor, weight: torch.Tensor, eps: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(table[ids], RMSNorm(table[ids]) * weight): the decode step's embedding lookup and the first layer's input norm in one
+    launch (bf16 table [V, H], int64 ids [M])."""
+    _dev(ids, table, weight)
+    _need(ids.dtype == torch.int64 and ids.dim() == 1 and ids.is_contiguous(), "embedding_rmsnorm: int64 ids [M]")
+    _need(table.dtype == _BF16 and table.dim() == 2 and table.stride(1) == 1 and weight.dtype == _BF16 and weight.numel() == table.shape[1],
+          "embedding_rmsnorm: bf16 table [V, H] and weight [H]")
+    M, H = ids.shape[0], table.shape[1]
+    hidden = torch.empty((M, H), dtype=_BF16, device=table.device)
+    out = torch.empty((M, H), dtype=_BF16, device=table.device)
+    native.call("sgl_amd_embedding_rmsnorm", ids.data_ptr(), table.data_ptr(), weight.data_ptr(), hidden.data_ptr(), out.data_ptr(),
+                M, H, table.shape[0], table.stride(0), hidden.stride(0), out.stride(0), float(eps), _stream())
+    return hidden, out
+
+
 def fused_add_rmsnorm(x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float) -> None:
     """sgl_kernel.fused_add_rmsnorm(input, residual, weight, eps): both updated in place."""
     _dev(x, residual, weight)
@@ -420,14 +435,17 @@ def cascade_plan_summary(ws: CascadeWorkspace, batch: int) -> dict:
 _ARGMAX_WS: dict = {}
 
 
-def argmax(logits: torch.Tensor) -> torch.Tensor:
+def argmax(logits: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """torch.argmax(logits, -1) (first maximum, NaN maximal).  Decode-sized batches of wide rows are cut into column
-    ranges so that the whole chip reads them (64 x 128256 bf16: 21 -> 7 us)."""
+    ranges so that the whole chip reads them (64 x 128256 bf16: 21 -> 7 us).  `out`: a contiguous int64 [B] tensor to write the
+    ids into (the decode graph's own input buffer: harness/graph_runner)."""
     _dev(logits)
     _need(logits.dim() == 2 and logits.stride(1) == 1, "argmax: [B, V] row-major")
     _need(logits.dtype in (torch.float32, _BF16), "argmax: fp32 or bf16 logits")
     B, V = logits.shape
-    ids = torch.empty(B, dtype=torch.int64, device=logits.device)
+    if out is not None:
+        _need(out.dtype == torch.int64 and out.shape == (B,) and out.is_contiguous() and out.device == logits.device, "argmax: out int64 [B]")
+    ids = out if out is not None else torch.empty(B, dtype=torch.int64, device=logits.device)
     es = logits.element_size()
     splits = min(16, max(1, 512 // max(B, 1)))
     if (splits > 1 and V >= 16384 and B <= 65535 and V < 2 ** 32 and logits.data_ptr() % 16 == 0

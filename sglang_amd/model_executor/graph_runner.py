@@ -59,10 +59,19 @@ class DecodeGraphRunner:
                             positions=self.positions[:bs], req_to_token_pool=mr.req_to_token_pool,
                             token_to_kv_pool=mr.token_to_kv_pool, attn_backend=mr.attn_backend)
 
+    # The captured step ends with the GREEDY pick of every row written straight into the graph's own input-id buffer: a caller whose
+    # batch is all-greedy (harness/engine.py) has nothing to launch between two replays but its slot bookkeeping -- the eager
+    # arg-max behind a replay cost the launch plus ~9 us of graph-to-eager hand-over per step, and a copy of the ids into this
+    # buffer.  A sampling batch ignores the pick (the caller writes its sampled ids over it); the logits are returned either way.
+    greedy_ids_in_graph = True
+
     def _run(self, fb: ForwardBatch) -> torch.Tensor:
         kernels.clamp_position(fb.seq_lens, out=fb.positions)      # in-graph: positions = seq_lens - 1
         self.mr.attn_backend.init_forward_metadata_in_graph(fb)    # in-graph: shared-prefix plan of this step
-        return self.mr.model.forward(fb.input_ids, fb.positions, fb).next_token_logits
+        logits = self.mr.model.forward(fb.input_ids, fb.positions, fb).next_token_logits
+        if self.greedy_ids_in_graph and logits.dtype in (torch.float32, torch.bfloat16) and logits.stride(-1) == 1:
+            kernels.argmax(logits, out=fb.input_ids)               # sampler.py:133-141 on the step's own logits
+        return logits
 
     def capture(self) -> None:
         # A Python GC pass that frees device tensors / graphs of an earlier runner while a capture

@@ -428,6 +428,23 @@ def test_argmax_and_softmax(device):
         torch.testing.assert_close(p, ref, atol=1e-6, rtol=1e-4)
 
 
+@pytest.mark.parametrize("M,V,H", [(64, 128256, 4096), (1, 1000, 896), (17, 32000, 8192)])
+def test_embedding_rmsnorm_equals_lookup_then_norm(device, M, V, H):
+    """Round 6: the decode step's embedding lookup and the first layer's input norm in one launch (models/llama.py:433-437 then
+    :349-353): the gathered rows bit-identical to F.embedding, the normed rows bit-identical to the RMSNorm kernel on them (the same
+    arithmetic) and within the norm's bar of the oracle."""
+    g = torch.Generator().manual_seed(M + H)
+    table = (torch.randn((V, H), generator=g) * 0.05).to(BF).to(device)
+    w = (1.0 + 0.1 * torch.randn(H, generator=g)).to(BF).to(device)
+    ids = torch.randint(0, V, (M,), generator=g).to(device)
+    hidden, normed = _k().embedding_rmsnorm(ids, table, w, 1e-5)
+    want_h = torch.nn.functional.embedding(ids, table)
+    assert torch.equal(hidden, want_h)
+    assert torch.equal(normed, _k().rmsnorm(want_h, w, 1e-5))
+    ref = oo.rmsnorm(want_h.cpu(), w.cpu(), 1e-5)
+    assert float((normed.cpu().float() - ref.float()).abs().max()) <= 2.0 ** -7 * float(ref.float().abs().max())
+
+
 @pytest.mark.parametrize("B,V", [(64, 128256), (3, 151936), (17, 32003), (200, 50257)])
 def test_argmax_split_rows_semantics(device, B, V):
     """The column-range form (decode-sized batches of wide rows): first maximum on ties across ranges, NaN maximal,
