@@ -219,6 +219,15 @@ def main():
     worker(args)
 
 
+def _trace(msg: str) -> None:
+    """SGLANG_AMD_BENCH_TRACE=1: one stderr line per phase and rank (where a multi-rank launch stops, if it stops)."""
+    if os.environ.get("SGLANG_AMD_BENCH_TRACE", "") not in ("", "0"):
+        print(f"[bench rank {os.environ.get('RANK', '0')} +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
 def worker(args):
     from sglang_amd.distributed import parallel_state as ps
     from sglang_amd.harness import models
@@ -233,11 +242,17 @@ def worker(args):
     # path, the rank checks and the JSON line are the real ones, the number is not a multi-GPU measurement and the line says so
     share_gpu = os.environ.get("SGLANG_AMD_BENCH_SHARE_GPU", "") not in ("", "0") and int(os.environ.get("WORLD_SIZE", "1")) > 1
     if share_gpu:
+        # ranks that SHARE a GPU must leave each other CUs: a rank's all-reduce workgroups spin on flags that the peer's workgroups
+        # write, and the peer's launches (its GEMMs first) need CUs to get there -- on a node every rank owns a GPU
+        from sglang_amd import native
+
+        native.call("sgl_amd_xgmi_debug_auto_blocks_cap", max(8, 128 // int(os.environ.get("WORLD_SIZE", "2"))))
         ps.init_distributed_environment(backend="gloo", device_index=0)
     else:
         ps.init_distributed_environment()
     world = ps.get_tensor_model_parallel_world_size()
     rank = int(os.environ.get("RANK", "0"))
+    _trace(f"process groups up (world {world}), xGMI communicator {'on' if ps.get_xgmi_all_reduce() is not None else 'off'}")
     if args.rank_of:
         if world != 1 or args.gpus != 1:
             raise SystemExit("--rank-of runs on one GPU (--gpus 1)")
@@ -267,6 +282,7 @@ def worker(args):
     runner = ModelRunner(cfg, max_total_tokens=B * (in_len + args.out) + 4096, max_running_requests=B,
                          max_context_len=ctx, page_size=args.page_size, device=dev, use_graph=not args.no_graph,
                          graph_max_bs=B, strict_graph=True, kv_cache_dtype=args.kv_cache_dtype)
+    _trace("model built, decode graphs captured")
     if not args.no_graph and runner.graph_runner is None:
         raise SystemExit("hipGraph decode was requested but no graph runner exists")
     if runner.model.config.name != cfg.name:
@@ -300,13 +316,16 @@ def worker(args):
                 rid += 1
         eng.prefill(leaders)
         sync(); t1 = time.perf_counter()
+        _trace("cold prefill done")
         if rest:
             eng.prefill(rest)
         sync(); t2 = time.perf_counter()
+        _trace("warm prefill done")
         for _ in range(args.out - 1):
             eng.decode_step()
             eng.flush_decode_outputs(lag=1)   # per-step token hand-off, one step behind the launch (overlap scheduling)
         sync(); t3 = time.perf_counter()
+        _trace("decode done")
         reqs = list(eng.running)
         hit = sum(q.cached_tokens for q in reqs)
         eng.finish(reqs)

@@ -193,6 +193,12 @@ def tensor_model_parallel_all_reduce_add_rmsnorm(x: torch.Tensor, residual: torc
     return x
 
 
+# rows from which a row-parallel projection takes the piecewise form below (SGLANG_AMD_PIECEWISE_MIN_ROWS overrides: a dry run whose
+# ranks share one GPU over gloo groups keeps everything on the xGMI kernels -- gloo's staged device all-reduce and a spinning
+# xGMI launch of the other rank time-slicing the same GPU wait for each other)
+PIECEWISE_MIN_ROWS = int(os.environ.get("SGLANG_AMD_PIECEWISE_MIN_ROWS", "2048"))
+
+
 def row_parallel_linear(x: torch.Tensor, weight: torch.Tensor, min_rows_per_chunk: int = 1024, max_chunks: int = 4
                         ) -> torch.Tensor:
     """all_reduce(x @ weight^T) for a prefill-sized row-parallel projection with the collective OVERLAPPED with the

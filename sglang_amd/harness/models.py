@@ -120,7 +120,7 @@ class Linear(nn.Module):
     def forward_all_reduce(self, x: torch.Tensor) -> torch.Tensor:
         """RowParallelLinear.forward (linear.py): all_reduce(self(x)); prefill-sized inputs overlap the collective with
         the matmul piecewise (parallel_state.row_parallel_linear)."""
-        if (ps.get_tensor_model_parallel_world_size() > 1 and self.bias is None and x.dim() == 2 and x.shape[0] >= 2048
+        if (ps.get_tensor_model_parallel_world_size() > 1 and self.bias is None and x.dim() == 2 and x.shape[0] >= ps.PIECEWISE_MIN_ROWS
                 and not self.streams(x)):
             return ps.row_parallel_linear(x, self.weight)
         return ps.tensor_model_parallel_all_reduce(self.forward(x))

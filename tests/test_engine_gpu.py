@@ -401,6 +401,18 @@ def test_the_drivers_multi_gpu_bench_command_starts_on_one_gpu(device, tmp_path)
     assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["scaling"] == "weak" and rec["steps"] == 1, rec
     assert rec["config"]["parallelism"].startswith("tp2") and "NOT a multi-GPU measurement" in rec["config"]["parallelism"], rec["config"]
     assert rec["config"]["global_batch"] == 8                       # weak scaling: 1 group x 4 prompts per GPU
+    # the same at Llama-3-8B's own dimensions (two layers): 2 x 1024-token cold prefill rows take the two-stage xGMI all-reduce and the
+    # piecewise row-parallel projection, 32 decode rows the one-shot kernel with the add + RMSNorm epilogue inside captured graphs
+    # (round 6: this shape hung until the shared-GPU run capped the all-reduce grids -- two ranks' spinning workgroups and the
+    # peer's GEMMs time-slice ONE GPU here; on a node every rank owns its GPU)
+    big = ["--model", "llama-3-8b", "--layers", "2", "--groups", "1", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-parity",
+           "--no-kernel-roofline", "--no-reference-scheduler"]
+    cmd_big = cmd[:cmd.index("--gpus") + 2] + big
+    cmd_big[cmd_big.index("--master-port") + 1] = str(port())
+    p = subprocess.run(cmd_big, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-4000:]
+    rec = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 32 and "REDUCED: 2 layers" in rec["config"]["workload"], rec["config"]
     # one rank under a --gpus 2 command line: refused
     cmd[cmd.index("--nproc-per-node") + 1] = "1"
     cmd[cmd.index("--master-port") + 1] = str(port())
