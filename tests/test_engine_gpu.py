@@ -140,6 +140,34 @@ def test_greedy_sampler_and_graph_padding(device):
         torch.testing.assert_close(a, b, atol=2e-2, rtol=2e-2)
 
 
+def test_deferred_prefill_ids_reach_the_requests_unchanged(device):
+    """prefill(defer_ids=True): the second pass is prepared and queued while the first one's ids are still on the device;
+    tokens, radix hits and first-token stamps are those of the synchronous hand-off, and nothing is delivered twice."""
+    from sglang_amd.harness.engine import Req
+
+    cfg, _, e_sync = _build("tiny-llama", device, True)
+    _, _, e_defer = _build("tiny-llama", device, True)
+    prompts = _shared_prefix_prompts(cfg, groups=2, per_group=3, shared=40, unique=6, seed=4)
+    outs = []
+    for eng, defer in ((e_sync, False), (e_defer, True)):
+        reqs = [Req(i, p, 4) for i, p in enumerate(prompts)]
+        leaders, rest = reqs[0::3], [q for i, q in enumerate(reqs) if i % 3]
+        eng.prefill(leaders, defer_ids=defer)
+        if defer:
+            assert all(q.output_ids == [] for q in leaders) and len(eng._deferred_prefill) == 1
+        eng.prefill(rest)                                   # delivers the leaders' ids after queueing its own forward
+        assert all(len(q.output_ids) == 1 and q.t_first_token > 0 for q in reqs)
+        assert [q.cached_tokens for q in rest] == [40] * 4
+        eng.prefill([Req(100, prompts[0][:30] + [7, 8, 9], 4)], defer_ids=True)
+        for _ in range(3):
+            eng.decode_step()                               # the first one resolves the late joiner
+        eng.flush_decode_outputs()
+        assert not eng._deferred_prefill
+        outs.append([list(q.output_ids) for q in eng.running])
+        assert all(len(o) == 4 for o in outs[-1][:6]) and len(outs[-1][6]) == 4
+    assert outs[0] == outs[1]
+
+
 def test_decode_batch_beyond_64_rows_matches_oracle(device):
     """80 running requests: the decode projections take the 65..128-row forms of the weight-streaming
     GEMM (narrow N) or the library GEMM (wide N), with the fused qkv-rope / add-norm combines."""
