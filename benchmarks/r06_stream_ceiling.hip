@@ -139,6 +139,40 @@ __global__ __launch_bounds__(64 * NW, 1) void stream_kernel(Params p) {
   if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u) p.sink[0] = acc.x;
 }
 
+// Round 6, experiment 6 ("mall" mode): is a weight matrix that a PREVIOUS kernel pulled through the 256 MiB infinity cache
+// streamed faster than one that comes from HBM, and can a small side kernel do that pulling while the chip runs a launch that
+// leaves HBM idle (the decode layer's four finish launches, ~20 us per layer)?
+template <int POLICY>   // 0 default, 1 nt, 2 sc1
+__global__ __launch_bounds__(256) void prefetch_kernel(const unsigned char* w, long bytes, unsigned* sink) {
+  const long n16 = bytes / 16;
+  u32x4_t acc = {0u, 0u, 0u, 0u};
+  const long stride = static_cast<long>(gridDim.x) * 256;
+  long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
+  for (; i + 3 * stride < n16; i += 4 * stride) {
+    u32x4_t v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned char* a = w + (i + j * stride) * 16;
+      if constexpr (POLICY == 1) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(v[j]) : "v"(a) : "memory");
+      else if constexpr (POLICY == 2) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[j]) : "v"(a) : "memory");
+      else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[j]) : "v"(a) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { asm volatile("" : "+v"(v[j])); acc ^= v[j]; }
+  }
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u) sink[1] = acc.x;
+}
+
+// a launch that keeps the chip "busy" without touching HBM for `ticks` of the 100 MHz counter (a finish launch's shadow)
+__global__ __launch_bounds__(256) void idle_kernel(long ticks, unsigned* sink) {
+  const uint64_t t0 = __builtin_readcyclecounter();
+  (void)t0;
+  const uint64_t s0 = wall_clock64();
+  while (static_cast<long>(wall_clock64() - s0) < ticks) __builtin_amdgcn_s_sleep(8);
+  if (ticks < 0) sink[2] = 1;
+}
+
 struct Config {
   const char* label;
   int G, S, pattern, stagger, gdiv;
@@ -234,6 +268,106 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
+
+  if (argc > 2 && std::string(argv[2]) == "mall") {
+    auto time_graph = [&](auto&& body, int launches) {
+      hipGraph_t graph;
+      hipGraphExec_t exec;
+      CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+      body();
+      CHECK(hipStreamEndCapture(st, &graph));
+      CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+      for (int i = 0; i < 2; ++i) CHECK(hipGraphLaunch(exec, st));
+      CHECK(hipStreamSynchronize(st));
+      float sum = 0.f;
+      const int reps = 6;
+      for (int i = 0; i < reps; ++i) {
+        CHECK(hipEventRecord(e0, st));
+        CHECK(hipGraphLaunch(exec, st));
+        CHECK(hipEventRecord(e1, st));
+        CHECK(hipStreamSynchronize(st));
+        float ms;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        sum += ms;
+      }
+      CHECK(hipGraphExecDestroy(exec));
+      CHECK(hipGraphDestroy(graph));
+      return sum / reps * 1e3 / launches;
+    };
+    hipStream_t side;
+    CHECK(hipStreamCreate(&side));
+    hipEvent_t fork, join;
+    CHECK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+    CHECK(hipEventCreateWithFlags(&join, hipEventDisableTiming));
+    std::string js = "{\"what\": \"weight stream from HBM vs after a prefetch through the infinity cache; us per launch\", \"rows\": [";
+    bool jf = true;
+    const Config mc[] = {{"o_33MB", 256, 4, 0, 0, 1, 0, 8, 4, 0, 4, 1}, {"o_33MB_default", 256, 4, 0, 0, 1, 0, 8, 4, 0, 4, 0},
+                         {"down_117MB", 256, 14, 0, 0, 1, 0, 8, 4, 0, 4, 1}, {"down_117MB_default", 256, 14, 0, 0, 1, 0, 8, 4, 0, 4, 0},
+                         {"gateup_235MB", 256, 56, 0, 0, 1, 0, 4, 4, 0, 8, 1}, {"gateup_235MB_default", 256, 56, 0, 0, 1, 0, 4, 4, 0, 8, 0}};
+    for (const Config& c : mc) {
+      kernel_t k = pick(c);
+      const long bytes = static_cast<long>(c.G) * c.nw * c.S * c.wp * 1024;
+      int copies = static_cast<int>(pool_bytes / bytes);
+      if (copies > 24) copies = 24;
+      Params p{};
+      p.act = act; p.sink = sink; p.S = c.S; p.pattern = 0; p.act_chunks = 32;
+      auto launch = [&](int r) { p.w = pool + static_cast<long>(r) * bytes; hipLaunchKernelGGL(k, dim3(c.G), dim3(64 * c.nw), 0, st, p); };
+      const double t_hbm = time_graph([&] { for (int r = 0; r < copies; ++r) launch(r); }, copies);
+      const double t_res = time_graph([&] { for (int r = 0; r < copies; ++r) launch(0); }, copies);
+      std::printf("%-22s %6.1f MB  from HBM %7.2f us   same copy again %7.2f us\n", c.label, bytes / 1e6, t_hbm, t_res);
+      char buf[640];
+      std::snprintf(buf, sizeof buf, "%s{\"stream\": \"%s\", \"MB\": %.1f, \"hbm_us\": %.2f, \"resident_us\": %.2f", jf ? "" : ", ", c.label, bytes / 1e6, t_hbm, t_res);
+      js += buf;
+      jf = false;
+      // a prefetch launch in front of every stream launch (serial): pf alone, pf + stream
+      for (int pol = 0; pol < 3; ++pol) {
+        for (int pg : {64, 256, 1024}) {
+          auto pf = [&](int r, hipStream_t s) {
+            const unsigned char* w = pool + static_cast<long>(r) * bytes;
+            if (pol == 0) hipLaunchKernelGGL(prefetch_kernel<0>, dim3(pg), dim3(256), 0, s, w, bytes, sink);
+            else if (pol == 1) hipLaunchKernelGGL(prefetch_kernel<1>, dim3(pg), dim3(256), 0, s, w, bytes, sink);
+            else hipLaunchKernelGGL(prefetch_kernel<2>, dim3(pg), dim3(256), 0, s, w, bytes, sink);
+          };
+          const double t_pf = time_graph([&] { for (int r = 0; r < copies; ++r) pf(r, st); }, copies);
+          const double t_both = time_graph([&] { for (int r = 0; r < copies; ++r) { pf(r, st); launch(r); } }, copies);
+          std::printf("    prefetch policy %d, %4d workgroups: alone %7.2f us, prefetch + stream %7.2f us -> stream after prefetch %7.2f us\n", pol, pg, t_pf,
+                      t_both, t_both - t_pf);
+          std::snprintf(buf, sizeof buf, ", \"pf_pol%d_wg%d\": {\"prefetch_us\": %.2f, \"both_us\": %.2f}", pol, pg, t_pf, t_both);
+          js += buf;
+        }
+      }
+      // concurrency: main = [idle launch of T us, stream(r)], side = prefetch(r) forked before the idle launch, joined after the stream
+      for (long idle_us : {5L, 20L}) {
+        for (int pg : {32, 64, 128}) {
+          auto body = [&](bool with_pf) {
+            for (int r = 0; r < copies; ++r) {
+              if (with_pf) {
+                CHECK(hipEventRecord(fork, st));
+                CHECK(hipStreamWaitEvent(side, fork, 0));
+                hipLaunchKernelGGL(prefetch_kernel<0>, dim3(pg), dim3(256), 0, side, pool + static_cast<long>(r) * bytes, bytes, sink);
+                CHECK(hipEventRecord(join, side));
+              }
+              hipLaunchKernelGGL(idle_kernel, dim3(256), dim3(256), 0, st, idle_us * 100, sink);
+              launch(r);
+              if (with_pf) CHECK(hipStreamWaitEvent(st, join, 0));
+            }
+          };
+          const double t0_ = time_graph([&] { body(false); }, copies);
+          const double t1_ = time_graph([&] { body(true); }, copies);
+          std::printf("    idle %2ld us + stream: %7.2f us; with a %3d-workgroup prefetch running beside it: %7.2f us\n", idle_us, t0_, pg, t1_);
+          std::snprintf(buf, sizeof buf, ", \"idle%ld_pfwg%d\": {\"plain_us\": %.2f, \"with_prefetch_us\": %.2f}", idle_us, pg, t0_, t1_);
+          js += buf;
+        }
+      }
+      js += "}";
+    }
+    js += "]}";
+    if (!out_path.empty()) {
+      FILE* f = std::fopen(out_path.c_str(), "w");
+      if (f) { std::fputs(js.c_str(), f); std::fputc('\n', f); std::fclose(f); }
+    }
+    return 0;
+  }
 
   std::string json = "{\"what\": \"LDS-DMA weight stream: us per launch (hipGraph of rotated copies, boundary included), TB/s of weight bytes\", \"configs\": {";
   bool first = true;
