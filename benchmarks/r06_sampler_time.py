@@ -45,6 +45,14 @@ out["softmax_us"] = graph_time(lambda: K.softmax_temperature_(f32.clone(), info.
 probs = K.softmax_temperature_(lg.float(), info.temperatures)
 for r in (0, 2, 4, 8, 16):
     out[f"sample_ranges_{r}_us"] = graph_time(lambda: K.top_k_top_p_min_p_sample(probs, info.top_ks, info.top_ps, None, info.sampling_seed, pos, ranges=r))
+out["softmax_from_bf16_us"] = graph_time(lambda: K.softmax_temperature_from_bf16(lg, info.temperatures))
+out["sample_from_bf16_logits_us"] = graph_time(lambda: K.sample_from_bf16_logits(lg, info.temperatures, info.top_ks, info.top_ps, None, info.sampling_seed, pos))
+# top-p only (no top-k): every range emits its 64 largest, 1024 candidates are ranked
+allk = torch.full((B,), 1 << 30, dtype=torch.int32, device=dev)
+_, fb = K.sample_from_bf16_logits(lg, info.temperatures, allk, info.top_ps, None, info.sampling_seed, pos, return_fallback=True)
+out["top_p_only_rows_redone_the_long_way"] = int(fb.sum())
+out["sample_from_bf16_logits_top_p_only_us"] = graph_time(lambda: K.sample_from_bf16_logits(lg, info.temperatures, allk, info.top_ps, None, info.sampling_seed, pos))
+out["two_calls_top_p_only_us"] = graph_time(lambda: K.top_k_top_p_min_p_sample(K.softmax_temperature_from_bf16(lg, info.temperatures), allk, info.top_ps, None, info.sampling_seed, pos))
 out["algorithmic_bytes"] = B * V * 4
 out["frac_of_hbm_8TBps"] = B * V * 4 / out["sampler_forward_us"] / 1e6 / 8.0
 print(json.dumps(out, indent=1))

@@ -12,6 +12,7 @@
 // L2 between the passes, so the passes cost L2 bandwidth, not HBM.
 #include "common.hpp"
 #include "sglang_amd.h"
+#include "softmax_ranges.hpp"
 
 using namespace sgl_amd;
 
@@ -218,33 +219,9 @@ __global__ __launch_bounds__(kRowThreads) void softmax_temperature_kernel(
 // works on 64 rows (one 1024-thread workgroup per row reads its 0.5 MB three times at one CU's bandwidth: 141 us for
 // [64, 128256]).  Pass 1: every range's maximum and sum of exp(x / t - that maximum); pass 2: every workgroup merges the
 // row's partials in range order (deterministic) and normalises its range.  16-byte loads; ranges are multiples of four.
-constexpr int kSplitThreads = 256;
-
-__device__ __forceinline__ void split_range(int64_t vocab, int splits, int64_t* begin, int64_t* end) {
-  const int64_t per = ((vocab + splits - 1) / splits + 3) / 4 * 4;
-  int64_t b = per * blockIdx.x, e = b + per;
-  if (b > vocab) b = vocab;
-  if (e > vocab) e = vocab;
-  *begin = b; *end = e;
-}
-
 // `IN` = float (in place: out == logits) or uint16_t (bf16 logits widened on the fly: what `logits.float()` + the fp32 kernel compute,
-// without the 16 MB read + 33 MB write of the separate widening pass and with half the bytes in both passes here)
-template <typename IN>
-__device__ __forceinline__ void ld4(const IN* p, float (&v)[4]);
-template <>
-__device__ __forceinline__ void ld4<float>(const float* p, float (&v)[4]) {
-  const float4 q = *reinterpret_cast<const float4*>(p);
-  v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-}
-template <>
-__device__ __forceinline__ void ld4<uint16_t>(const uint16_t* p, float (&v)[4]) {
-  const uint2 q = *reinterpret_cast<const uint2*>(p);
-  v[0] = bf_lo(q.x); v[1] = bf_hi(q.x); v[2] = bf_lo(q.y); v[3] = bf_hi(q.y);
-}
-__device__ __forceinline__ float ld1(const float* p) { return *p; }
-__device__ __forceinline__ float ld1(const uint16_t* p) { return bf2f(*p); }
-
+// without the 16 MB read + 33 MB write of the separate widening pass and with half the bytes in both passes here).
+// The pieces live in softmax_ranges.hpp (shared with the sampler that evaluates the probabilities of its candidates only).
 template <typename IN>
 __global__ __launch_bounds__(kSplitThreads) void softmax_partials_kernel(const IN* __restrict__ logits, const float* __restrict__ temperatures,
                                                                          int64_t vocab, int64_t row_stride, int splits,
@@ -254,26 +231,9 @@ __global__ __launch_bounds__(kSplitThreads) void softmax_partials_kernel(const I
   const IN* x = logits + row * row_stride;
   const float t = temperatures[row];
   int64_t b, e;
-  split_range(vocab, splits, &b, &e);
-  const int64_t e4 = b + (e - b) / 4 * 4;
-  float mx = -INFINITY;
-  for (int64_t i = b + 4 * threadIdx.x; i < e4; i += 4 * kSplitThreads) {
-    float v[4];
-    ld4<IN>(x + i, v);
-    mx = fmaxf(fmaxf(mx, v[0] / t), fmaxf(v[1] / t, fmaxf(v[2] / t, v[3] / t)));
-  }
-  for (int64_t i = e4 + threadIdx.x; i < e; i += kSplitThreads) mx = fmaxf(mx, ld1(x + i) / t);
-  mx = block_max(mx, scratch);
-  float sum = 0.f;
-  if (mx > -INFINITY) {
-    for (int64_t i = b + 4 * threadIdx.x; i < e4; i += 4 * kSplitThreads) {
-      float v[4];
-      ld4<IN>(x + i, v);
-      sum += expf(v[0] / t - mx) + expf(v[1] / t - mx) + expf(v[2] / t - mx) + expf(v[3] / t - mx);
-    }
-    for (int64_t i = e4 + threadIdx.x; i < e; i += kSplitThreads) sum += expf(ld1(x + i) / t - mx);
-  }
-  sum = block_sum(sum, scratch);
+  split_range_of(vocab, splits, blockIdx.x, &b, &e);
+  float mx, sum;
+  range_partial<IN>(x, t, b, e, scratch, &mx, &sum);
   if (threadIdx.x == 0) {
     partials[(row * splits + blockIdx.x) * 2 + 0] = mx;
     partials[(row * splits + blockIdx.x) * 2 + 1] = sum;
@@ -289,25 +249,19 @@ __global__ __launch_bounds__(kSplitThreads) void softmax_normalize_kernel(const 
   const IN* x = logits + row * row_stride;
   float* y = out + row * out_stride;
   const float t = temperatures[row];
-  const float* pr = partials + row * splits * 2;
-  float mx = -INFINITY;
-  for (int s = 0; s < splits; ++s) mx = fmaxf(mx, pr[2 * s]);
-  float sum = 0.f;
-  for (int s = 0; s < splits; ++s) {
-    const float ms = pr[2 * s];
-    if (ms > -INFINITY) sum += pr[2 * s + 1] * expf(ms - mx);      // range order: the same bits in every workgroup
-  }
+  float mx, sum;
+  merge_partials(partials + row * splits * 2, splits, &mx, &sum);
   int64_t b, e;
-  split_range(vocab, splits, &b, &e);
+  split_range_of(vocab, splits, blockIdx.x, &b, &e);
   const int64_t e4 = b + (e - b) / 4 * 4;
   for (int64_t i = b + 4 * threadIdx.x; i < e4; i += 4 * kSplitThreads) {
     float v[4];
     ld4<IN>(x + i, v);
     float4 o;
-    o.x = expf(v[0] / t - mx) / sum; o.y = expf(v[1] / t - mx) / sum; o.z = expf(v[2] / t - mx) / sum; o.w = expf(v[3] / t - mx) / sum;
+    o.x = softmax_prob(v[0], t, mx, sum); o.y = softmax_prob(v[1], t, mx, sum); o.z = softmax_prob(v[2], t, mx, sum); o.w = softmax_prob(v[3], t, mx, sum);
     *reinterpret_cast<float4*>(y + i) = o;
   }
-  for (int64_t i = e4 + threadIdx.x; i < e; i += kSplitThreads) y[i] = expf(ld1(x + i) / t - mx) / sum;
+  for (int64_t i = e4 + threadIdx.x; i < e; i += kSplitThreads) y[i] = softmax_prob(ld1(x + i), t, mx, sum);
 }
 
 }  // namespace

@@ -26,6 +26,7 @@
 // The row (V x 4 B, ~0.5 MB) is read 5-6 times but stays in L2.
 #include "common.hpp"
 #include "sglang_amd.h"
+#include "softmax_ranges.hpp"
 
 using namespace sgl_amd;
 
@@ -584,7 +585,18 @@ struct SampleParams {
 // One row of the sampler, by one 1024-thread workgroup.  n_preloaded < 0: from the row itself (the first radix level and the
 // candidate collection are two full-row passes).  n_preloaded >= 0 (the column-range launches below did those passes over the
 // whole chip): the select state behind level 0 is in `sm` and sm.cand_* hold the n_preloaded candidates in token order.
-__device__ void sample_row(const SampleParams& p, const int row, RowSmem& sm, const int n_preloaded) {
+// The candidate list of sample_from_logits (below) is exact only above a FRONTIER: the largest probability among the elements
+// its column ranges did not emit.  Ranks and prefix sums of list elements above it are the reference's; the element the reference
+// has at the first rank at or below it has exactly that probability.  If the three rules would keep THAT element the list is
+// not enough (`*unusable` is set: the row is redone from the full row); if they do not, nothing at or behind it is kept
+// (rank >= top_k, value < the min-p threshold and exclusive prefix sum > top_p are all monotone along the sorted order).
+struct Frontier {
+  uint32_t key;        // key_of(frontier probability)
+  float prob;
+  int* unusable;       // LDS flag, cleared by the caller
+};
+
+__device__ void sample_row(const SampleParams& p, const int row, RowSmem& sm, const int n_preloaded, const Frontier* fr = nullptr) {
   const int tid = threadIdx.x;
   const float* x = p.probs + static_cast<int64_t>(row) * p.row_stride;
   const int V = p.V;
@@ -726,6 +738,15 @@ __device__ void sample_row(const SampleParams& p, const int row, RowSmem& sm, co
 #pragma unroll
     for (int u = 0; u < kPer; ++u) {
       const int r = tid * kPer + u;
+      if (fr) {
+        // (workgroup-uniform branch) is r the first rank at or below the frontier?  ranks 0 .. n_keep all have an owner (n_keep < kLdsKeep)
+        const bool below = r >= n_keep || s_key[r] <= fr->key;
+        const bool prev_above = r == 0 || (r - 1 < n_keep && s_key[r - 1] > fr->key);
+        if (r <= n_keep && below && prev_above) {
+          const bool keep_h = r < top_k && fr->key >= min_key && exact_top_p_keep(run + static_cast<double>(fr->prob), fr->prob, top_p);
+          if (keep_h) *fr->unusable = 1;
+        }
+      }
       run += static_cast<double>(pv[u]);
       const bool in_rules = !direct || (r < top_k && s_key[r < n_keep ? r : 0] >= min_key);     // (the select enforced both otherwise)
       if (r < n_keep && in_rules && exact_top_p_keep(run, pv[u], top_p)) {
@@ -1023,6 +1044,524 @@ __global__ __launch_bounds__(kT) void sample_finish_ranges_kernel(SampleParams p
   fixup_empty_nucleus(p, row, sm);
 }
 
+// ---- the filtered case straight from bf16 logits: the probabilities of a row are never written -------------------------------
+// Sampler.forward on a decode batch used to be five launches over the [B, V] fp32 probabilities (softmax partials, normalise:
+// 33 MB written; histogram + collect: 33 MB read each; finish).  The kept set of sampler.py:574-591 is a prefix of the row's
+// descending order, and p(x) = expf(x / t - max) / sum is monotone in the bf16 logit x, so the prefix can be found on the LOGITS:
+//   candidates  grid (16 column ranges, rows), 256 threads: the softmax partials of the range (the bits of the two-launch softmax:
+//               softmax_ranges.hpp) and an exact two-level radix select on the 16-bit order keys of the range's logits: every
+//               element >= the range's K-th largest (K = min(top_k, 64)) goes to the range's candidate list in token order
+//               (<= 127 of them: ties at the cut included), with the largest key NOT emitted -- the range's frontier;
+//   finish      grid (rows), 1024 threads: merges the partials, turns the <= 16 x 127 candidates into probabilities (the same
+//               function of the same inputs as the normalise launch: the same bits), and runs the row routine's direct form on
+//               them (rank all, the three rules element by element, fp64 gumbel arg-max) with the frontier test of sample_row;
+//   a row the candidates cannot decide (the rules reach the frontier: flat rows, top-p without top-k over a wide nucleus;
+//   more than 127 ties; top_k == 0; a non-finite softmax) is redone the long way by the same workgroup: it writes the row's
+//   probabilities into a scratch matrix and runs the single-workgroup routine on them (no launch for rows that do not need it).
+// [64, 128256], top-k 50 / top-p 0.9: 16 MB read once from HBM instead of ~130 MB of traffic.  Same ids and kept counts as the
+// long way by construction (tests/test_sampler_gpu.py compares them on every row).
+constexpr int kFastRangesMax = 16;
+constexpr int kFastCap = 127;
+constexpr int kFastK = 64;
+static_assert(kFastRangesMax * kFastCap < kDirect, "the finish launch ranks the whole list in LDS, with one spare rank");
+
+struct FastWs {
+  float* partials;      // [B, S, 2]
+  uint32_t* cand_val;   // [B, R, kFastCap]: the logit as fp32 bits
+  int* cand_tok;        // [B, R, kFastCap]
+  int* meta;            // [B, R, 2]: candidates (-1: more than kFastCap), frontier order key (-1: everything emitted)
+  int* fallback;        // [B]: 1 = redo the row from its probabilities
+};
+__host__ __device__ inline int64_t fast_ws_bytes(int64_t batch, int splits) {
+  return batch * splits * 8 + batch * kFastRangesMax * kFastCap * 8 + batch * kFastRangesMax * 8 + batch * 4;
+}
+__host__ __device__ inline FastWs fast_ws_view(void* base, int64_t batch, int splits) {
+  FastWs w;
+  unsigned char* b = static_cast<unsigned char*>(base);
+  w.partials = reinterpret_cast<float*>(b);         b += batch * splits * 8;
+  w.cand_val = reinterpret_cast<uint32_t*>(b);      b += batch * kFastRangesMax * kFastCap * 4;
+  w.cand_tok = reinterpret_cast<int*>(b);           b += batch * kFastRangesMax * kFastCap * 4;
+  w.meta = reinterpret_cast<int*>(b);               b += batch * kFastRangesMax * 8;
+  w.fallback = reinterpret_cast<int*>(b);
+  return w;
+}
+
+// bf16 bit pattern -> 16-bit key that orders like the value (-0 < +0; NaN rows never get here: their softmax is not finite)
+__device__ __forceinline__ uint32_t order16(uint32_t bits) { return bits ^ ((bits & 0x8000u) ? 0xffffu : 0x8000u); }
+__device__ __forceinline__ uint32_t unorder16(uint32_t key) { return key ^ ((key & 0x8000u) ? 0x8000u : 0xffffu); }
+
+// which of 256 bins holds the K-th largest element: `c` = this thread's (tid = bin) count.  Returns through LDS `sel`:
+// [0] bin, [1] elements in the bins above it, [2] elements in it.  Needs K >= 1 and K <= the total.  256 threads.
+__device__ __forceinline__ void select_bin_256(uint32_t c, uint32_t K, uint32_t* wave_tot, int* sel) {
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  uint32_t v = c;                                   // inclusive suffix sum over the wave's 64 bins
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t o = __shfl_down(v, off, 64);
+    if (lane + off < 64) v += o;
+  }
+  if (lane == 0) wave_tot[wid] = v;
+  __syncthreads();
+  uint32_t above = 0;
+  for (int w = wid + 1; w < 4; ++w) above += wave_tot[w];
+  const uint32_t incl = v + above, excl = incl - c;
+  if (incl >= K && excl < K) { sel[0] = tid; sel[1] = static_cast<int>(excl); sel[2] = static_cast<int>(c); }
+  __syncthreads();
+}
+
+constexpr int kFastSlots = 16;     // 1024-column steps of a workgroup's columns (4 per thread and step): <= 16384 columns
+
+// A workgroup's columns live in REGISTERS (one round trip to L2 / HBM for the whole range: a pass over them from memory cost
+// ~3 us each, and the first version made seven).  Slot s = (softmax range g = s / J of the workgroup's G, step j = s % J): the 4
+// columns b_g + 1024 j + 4 tid ..; the row's last range may end in <= 3 more columns (thread tid < 3 holds one).  NS = slots
+// compiled in (8 covers [*, 128256] at 16 candidate ranges).
+template <int NS>
+__global__ __launch_bounds__(kSplitThreads) void sample_logit_candidates_kernel(const uint16_t* __restrict__ logits, int64_t row_stride,
+                                                                                const float* __restrict__ temperatures, int V, int S, int G, int J,
+                                                                                const int32_t* __restrict__ top_ks, FastWs ws) {
+  __shared__ float red[4][4];
+  __shared__ int redi[4];
+  __shared__ int slot_cnt[NS + 1][4];
+  __shared__ alignas(16) uint32_t hist[4][257];
+  __shared__ uint32_t wave_tot[4];
+  __shared__ int sel[4];
+  const int row = blockIdx.y, c = blockIdx.x, R = gridDim.x;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const uint16_t* x = logits + static_cast<int64_t>(row) * row_stride;
+  const float t = temperatures[row];
+  const int per = ((V + S - 1) / S + 3) / 4 * 4;    // (split_range_of's geometry)
+  // ---- one burst: every column of the workgroup ----
+  uint2 q[NS];
+  uint32_t on_mask = 0;                              // slot s holds four columns of this thread
+  auto slot_g = [&](int s) { return s / J; };        // (uniform)
+  auto slot_col = [&](int s) {
+    const int g = s / J, j = s - g * J;
+    int64_t b = static_cast<int64_t>(per) * (c * G + g);
+    if (b > V) b = V;
+    return static_cast<int>(b) + 1024 * j + 4 * tid;
+  };
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int g = s / J;
+    int64_t b = static_cast<int64_t>(per) * (c * G + g), e = b + per;
+    if (b > V) b = V;
+    if (e > V) e = V;
+    const int64_t e4 = b + (e - b) / 4 * 4;
+    const int i = slot_col(s);
+    const bool on = g < G && i < e4;
+    on_mask |= on ? (1u << s) : 0u;
+    q[s] = on ? *reinterpret_cast<const uint2*>(x + i) : uint2{0u, 0u};
+  }
+  // (the <= 3 columns behind the last multiple of four: in the row's last range only, which is this workgroup's last if any)
+  const int tail_g = G - 1;
+  int tail_i = -1;
+  uint32_t tail_bits = 0;
+  {
+    int64_t b = static_cast<int64_t>(per) * (c * G + tail_g), e = b + per;
+    if (b > V) b = V;
+    if (e > V) e = V;
+    const int64_t e4 = b + (e - b) / 4 * 4;
+    if (e4 + tid < e) { tail_i = static_cast<int>(e4 + tid); tail_bits = x[tail_i]; }
+  }
+  auto bits_of = [&](int s, int k) -> uint32_t { return k == 0 ? (q[s].x & 0xffffu) : k == 1 ? (q[s].x >> 16) : k == 2 ? (q[s].y & 0xffffu) : (q[s].y >> 16); };
+  auto val_of = [&](int s, int k) -> float { return __uint_as_float(bits_of(s, k) << 16); };
+  auto is_on = [&](int s) { return (on_mask >> s) & 1u; };
+
+  // ---- the softmax partials of the G ranges: range_partial's arithmetic in range_partial's order (softmax_ranges.hpp), every
+  // range's two workgroup reductions done side by side.  The maximum of x / t is (the maximum of x) / t for t > 0 -- a correctly
+  // rounded division is monotone -- so the first pass divides once per range, not once per column. ----
+  const bool t_pos = t > 0.f;                        // (uniform; other temperatures: column by column, and the row goes the long way)
+  float mxg[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    float m;
+    if (t_pos) m = fmaxf(fmaxf(val_of(s, 0), val_of(s, 1)), fmaxf(val_of(s, 2), val_of(s, 3)));
+    else m = fmaxf(fmaxf(val_of(s, 0) / t, val_of(s, 1) / t), fmaxf(val_of(s, 2) / t, val_of(s, 3) / t));
+    const int g = is_on(s) ? slot_g(s) : -1;
+#pragma unroll
+    for (int gg = 0; gg < 4; ++gg) mxg[gg] = g == gg ? fmaxf(mxg[gg], m) : mxg[gg];
+  }
+  if (tail_i >= 0) {
+    const float m = t_pos ? __uint_as_float(tail_bits << 16) : __uint_as_float(tail_bits << 16) / t;
+#pragma unroll
+    for (int gg = 0; gg < 4; ++gg) mxg[gg] = tail_g == gg ? fmaxf(mxg[gg], m) : mxg[gg];
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float w = wave_max(mxg[g]);
+    if (lane == 0) red[g][wid] = w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float m = fmaxf(fmaxf(red[g][0], red[g][1]), fmaxf(red[g][2], red[g][3]));
+    mxg[g] = t_pos ? m / t : m;
+  }
+  __syncthreads();
+  float smg[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    if (is_on(s)) {
+      const int g = slot_g(s);
+      const float mx = g == 0 ? mxg[0] : g == 1 ? mxg[1] : g == 2 ? mxg[2] : mxg[3];
+      if (mx > -INFINITY) {
+        const float add = expf(val_of(s, 0) / t - mx) + expf(val_of(s, 1) / t - mx) + expf(val_of(s, 2) / t - mx) + expf(val_of(s, 3) / t - mx);
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) smg[gg] = g == gg ? smg[gg] + add : smg[gg];
+      }
+    }
+  }
+  if (tail_i >= 0) {
+    const float mx = tail_g == 0 ? mxg[0] : tail_g == 1 ? mxg[1] : tail_g == 2 ? mxg[2] : mxg[3];
+    if (mx > -INFINITY) {
+      const float add = expf(__uint_as_float(tail_bits << 16) / t - mx);
+#pragma unroll
+      for (int gg = 0; gg < 4; ++gg) smg[gg] = tail_g == gg ? smg[gg] + add : smg[gg];
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float w = wave_sum(smg[g]);
+    if (lane == 0) red[g][wid] = w;
+  }
+  __syncthreads();
+  if (tid < G) {
+    // block_sum's association over the four wave sums: (w0 + w2) + (w1 + w3)
+    const float tot = (red[tid][0] + red[tid][2]) + (red[tid][1] + red[tid][3]);
+    const float mx = tid == 0 ? mxg[0] : tid == 1 ? mxg[1] : tid == 2 ? mxg[2] : mxg[3];
+    ws.partials[(static_cast<int64_t>(row) * S + c * G + tid) * 2 + 0] = mx;
+    ws.partials[(static_cast<int64_t>(row) * S + c * G + tid) * 2 + 1] = tot;
+  }
+
+  // ---- candidates ----
+  int* meta = ws.meta + (static_cast<int64_t>(row) * R + c) * 2;
+  int64_t top_k = top_ks ? top_ks[row] : V;
+  if (top_k > V) top_k = V;
+  int n;
+  {
+    int64_t cb = static_cast<int64_t>(per) * (c * G), ce = static_cast<int64_t>(per) * (c * G + G);
+    if (cb > V) cb = V;
+    if (ce > V) ce = V;
+    n = static_cast<int>(ce - cb);
+  }
+  if (n <= 0 || top_k <= 0) {                       // (top_k <= 0: the finish launch sends the row the long way)
+    if (tid == 0) { meta[0] = 0; meta[1] = -1; }
+    return;
+  }
+  const int Kc = static_cast<int>(top_k < kFastK ? top_k : kFastK);
+  const uint32_t K = static_cast<uint32_t>(Kc < n ? Kc : n);
+  auto for_each = [&](auto&& f) {                   // every column this thread holds (registers)
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+      if (is_on(s)) { f(bits_of(s, 0)); f(bits_of(s, 1)); f(bits_of(s, 2)); f(bits_of(s, 3)); }
+    if (tail_i >= 0) f(tail_bits);
+  };
+  // A lower bound of the K-th largest key without a histogram: every wave takes the ceil(K / 4)-th largest of its 64 per-lane
+  // maxima, the bound is the smallest of the four (K distinct columns are >= it).  For rows in any order but an adversarial one
+  // ~K .. 2 K columns pass it: they ARE the candidates, a superset of everything >= the K-th largest.  (Histogramming the range
+  // cost 13 us of LDS atomics on the handful of hot bins of a softmax row.)
+  int my_max = -1;
+  for_each([&](uint32_t bits) { const int k = static_cast<int>(order16(bits)); my_max = k > my_max ? k : my_max; });
+  {
+    const int kw = (static_cast<int>(K) + 3) / 4;
+    int rank = 0;                                   // lanes ahead of mine in (value desc, lane asc) order
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+      const int o = __builtin_amdgcn_readlane(my_max, j);
+      rank += (o > my_max) || (o == my_max && j < lane);
+    }
+    if (rank == kw - 1) redi[wid] = my_max;
+  }
+  __syncthreads();
+  int bound = redi[0];
+#pragma unroll
+  for (int w = 1; w < 4; ++w) bound = redi[w] < bound ? redi[w] : bound;
+  uint32_t kth = bound < 0 ? 0u : static_cast<uint32_t>(bound);
+  __syncthreads();
+  {
+    int cnt = 0;
+    for_each([&](uint32_t bits) { cnt += order16(bits) >= kth; });
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+    if (lane == 0) redi[wid] = cnt;
+    __syncthreads();
+    const int tot = redi[0] + redi[1] + redi[2] + redi[3];
+    __syncthreads();
+    if (tot > kFastCap) {                             // (workgroup-uniform) too many pass the bound: the exact two-level select
+      for (int z = tid; z < 4 * 257; z += kSplitThreads) (&hist[0][0])[z] = 0;
+      __syncthreads();
+      for_each([&](uint32_t bits) { atomicAdd(&hist[wid][order16(bits) >> 8], 1u); });
+      __syncthreads();
+      select_bin_256(hist[0][tid] + hist[1][tid] + hist[2][tid] + hist[3][tid], K, wave_tot, sel);
+      const uint32_t b1 = static_cast<uint32_t>(sel[0]), above1 = static_cast<uint32_t>(sel[1]);
+      __syncthreads();
+      for (int z = tid; z < 4 * 257; z += kSplitThreads) (&hist[0][0])[z] = 0;
+      __syncthreads();
+      for_each([&](uint32_t bits) {
+        const uint32_t k = order16(bits);
+        if ((k >> 8) == b1) atomicAdd(&hist[wid][k & 255u], 1u);
+      });
+      __syncthreads();
+      select_bin_256(hist[0][tid] + hist[1][tid] + hist[2][tid] + hist[3][tid], K - above1, wave_tot, sel);
+      kth = (b1 << 8) | static_cast<uint32_t>(sel[0]);
+      const int n_ge = static_cast<int>(above1) + sel[1] + sel[2];
+      if (n_ge > kFastCap) {                          // (workgroup-uniform) a tie wider than the list
+        if (tid == 0) { meta[0] = -1; meta[1] = -1; }
+        return;
+      }
+    }
+  }
+  // ---- emit in token order = (slot, thread, column): per (slot, wave) counts first, positions from their table ----
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  int front = -1;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    int total = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t key = order16(bits_of(s, k));
+      const bool in = is_on(s) && key >= kth;
+      if (is_on(s) && key < kth && static_cast<int>(key) > front) front = static_cast<int>(key);
+      total += __popcll(__ballot(in));
+    }
+    if (lane == 0) slot_cnt[s][wid] = total;
+  }
+  {
+    const uint32_t key = order16(tail_bits);
+    const bool in = tail_i >= 0 && key >= kth;
+    if (tail_i >= 0 && key < kth && static_cast<int>(key) > front) front = static_cast<int>(key);
+    const int total = __popcll(__ballot(in));
+    if (lane == 0) slot_cnt[NS][wid] = total;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const int o = __shfl_xor(front, off, 64);
+    front = o > front ? o : front;
+  }
+  if (lane == 0) redi[wid] = front;
+  __syncthreads();
+  uint32_t* out_val = ws.cand_val + (static_cast<int64_t>(row) * R + c) * kFastCap;
+  int* out_tok = ws.cand_tok + (static_cast<int64_t>(row) * R + c) * kFastCap;
+  int acc = 0;                                        // candidates of the slots before this one
+#pragma unroll
+  for (int s = 0; s <= NS; ++s) {
+    const int c0 = slot_cnt[s][0], c1 = slot_cnt[s][1], c2 = slot_cnt[s][2], c3 = slot_cnt[s][3];
+    const int mine = wid == 0 ? c0 : wid == 1 ? c1 : wid == 2 ? c2 : c3;
+    if (mine > 0) {                                   // (wave-uniform)
+      int pos = acc + (wid > 0 ? c0 : 0) + (wid > 1 ? c1 : 0) + (wid > 2 ? c2 : 0);
+      if (s < NS) {
+        const int ss = s < NS ? s : 0;
+        bool in[4];
+        int before = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          in[k] = is_on(ss) && order16(bits_of(ss, k)) >= kth;
+          before += __popcll(__ballot(in[k]) & lt_mask);
+        }
+        pos += before;
+        const int col = slot_col(ss);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (in[k]) { out_val[pos] = bits_of(ss, k) << 16; out_tok[pos] = col + k; ++pos; }
+      } else {
+        const bool in = tail_i >= 0 && order16(tail_bits) >= kth;
+        pos += __popcll(__ballot(in) & lt_mask);
+        if (in) { out_val[pos] = tail_bits << 16; out_tok[pos] = tail_i; }
+      }
+    }
+    acc += c0 + c1 + c2 + c3;
+  }
+  if (tid == 0) {
+    int f = redi[0];
+    for (int w = 1; w < 4; ++w) f = redi[w] > f ? redi[w] : f;
+    meta[0] = acc;
+    meta[1] = f;
+  }
+}
+
+__global__ __launch_bounds__(kT) void sample_finish_fast_kernel(SampleParams p, const uint16_t* __restrict__ logits, int64_t logits_row_stride,
+                                                                 const float* __restrict__ temperatures, int S, int R, FastWs ws) {
+  __shared__ RowSmem sm;
+  __shared__ int pre[kFastRangesMax + 1];
+  __shared__ int m_cnt[kFastRangesMax], m_front[kFastRangesMax];
+  __shared__ int s_front, s_bad, s_unusable;
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const float t = temperatures[row];
+  if (tid < R) {                                        // (one round trip for the row's R records, not R of them)
+    const int2 m = *reinterpret_cast<const int2*>(ws.meta + (static_cast<int64_t>(row) * R + tid) * 2);
+    m_cnt[tid] = m.x; m_front[tid] = m.y;
+  }
+  float mx, sum;
+  merge_partials(ws.partials + static_cast<int64_t>(row) * S * 2, S, &mx, &sum);
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0, front = -1, bad = 0;
+    for (int c = 0; c < R; ++c) {
+      pre[c] = acc;
+      if (m_cnt[c] < 0) bad = 1; else acc += m_cnt[c];
+      front = m_front[c] > front ? m_front[c] : front;
+    }
+    pre[R] = acc;
+    const int64_t tk = p.top_ks ? p.top_ks[row] : p.V;
+    if (tk <= 0 || acc == 0 || acc >= kDirect) bad = 1;
+    if (!(t > 0.f) || !(sum > 0.f) || !(sum < INFINITY) || !(mx > -INFINITY) || !(mx < INFINITY)) bad = 1;
+    s_front = front; s_bad = bad; s_unusable = 0;
+  }
+  __syncthreads();
+  if (!s_bad) {                                         // (workgroup-uniform)
+    // ---- this thread's <= 2 candidates (list order = token order = (range, position) order) ----
+    const int lane = tid & 63, wid = tid >> 6;
+    int64_t top_k = p.top_ks ? p.top_ks[row] : p.V;
+    if (top_k > p.V) top_k = p.V;
+    const float top_p = p.top_ps ? p.top_ps[row] : 1.0f;
+    const unsigned long long p_fix = top_p_fix_superset(top_p);
+    bool have[2];
+    uint32_t key16[2], pbits[2];
+    int tok[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int idx = tid + u * kT;
+      const int c = idx / kFastCap, j = idx - c * kFastCap;
+      have[u] = c < R && j < m_cnt[c < R ? c : 0];
+      key16[u] = 0; pbits[u] = 0; tok[u] = 0;
+      if (have[u]) {
+        const int64_t o = (static_cast<int64_t>(row) * R + c) * kFastCap + j;
+        const uint32_t lb = ws.cand_val[o];
+        key16[u] = order16(lb >> 16);
+        pbits[u] = __float_as_uint(softmax_prob(__uint_as_float(lb), t, mx, sum));
+        tok[u] = ws.cand_tok[o];
+      }
+    }
+    // ---- prune to a prefix of the descending order that holds top_k elements or top_p (+ 2^-22) of the mass, whichever comes
+    // first: a two-level select on the 16-bit logit keys with count and fixed-point mass histograms (order-independent).  The
+    // candidates dropped here join the elements the ranges left out: the frontier rises to the largest of them. ----
+    uint32_t cutkey = 0;
+    bool found_any = true;
+    {
+      uint32_t base_c = 0;
+      unsigned long long base_s = 0;
+#pragma unroll
+      for (int level = 0; level < 2; ++level) {
+        if (tid < 256) { sm.hist_cnt[tid] = 0; sm.hist_sum[tid] = 0; }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const bool in = have[u] && (level == 0 || (key16[u] >> 8) == (cutkey >> 8));
+          if (in) {
+            const int bin = level == 0 ? (key16[u] >> 8) : (key16[u] & 255u);
+            atomicAdd(&sm.hist_cnt[bin], 1u);
+            atomicAdd(&sm.hist_sum[bin], static_cast<unsigned long long>(to_fix(__uint_as_float(pbits[u]))));
+          }
+        }
+        __syncthreads();
+        uint32_t vc = 0;
+        unsigned long long vs = 0;
+        uint32_t my_c = 0;
+        unsigned long long my_s = 0;
+        if (tid < 256) {                                // (waves 0 .. 3 whole) inclusive suffix sums over the wave's 64 bins
+          my_c = vc = sm.hist_cnt[tid];
+          my_s = vs = sm.hist_sum[tid];
+#pragma unroll
+          for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t oc = __shfl_down(vc, off, 64);
+            const unsigned long long os = __shfl_down(vs, off, 64);
+            if (lane + off < 64) { vc += oc; vs += os; }
+          }
+          if (lane == 0) { sm.wave_a[wid] = static_cast<int>(vc); sm.part_sum[wid] = vs; }
+        }
+        if (tid == 0) sm.found_bin = -1;
+        __syncthreads();
+        if (tid < 256) {
+          uint32_t ac = base_c;
+          unsigned long long as = base_s;
+          for (int w = wid + 1; w < 4; ++w) { ac += static_cast<uint32_t>(sm.wave_a[w]); as += sm.part_sum[w]; }
+          const uint32_t incl_c = vc + ac, excl_c = incl_c - my_c;
+          const unsigned long long incl_s = vs + as, excl_s = incl_s - my_s;
+          const bool cond_incl = static_cast<int64_t>(incl_c) >= top_k || incl_s >= p_fix;
+          const bool cond_excl = static_cast<int64_t>(excl_c) >= top_k || excl_s >= p_fix;
+          if (cond_incl && !cond_excl) { sm.found_bin = tid; sm.c_above = static_cast<int>(excl_c); sm.s_above = excl_s; }
+        }
+        __syncthreads();
+        const int fb = sm.found_bin;
+        if (fb < 0) { found_any = false; break; }       // (uniform) level 0 only: the whole list is inside both limits
+        cutkey = level == 0 ? (static_cast<uint32_t>(fb) << 8) : (cutkey | static_cast<uint32_t>(fb));
+        base_c = static_cast<uint32_t>(sm.c_above);
+        base_s = sm.s_above;
+        __syncthreads();
+      }
+      if (!found_any) cutkey = 0;
+    }
+    // ---- compact the survivors, in list order, into the row routine's candidate arrays ----
+    bool keep[2];
+    int dropped = s_front;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      keep[u] = have[u] && key16[u] >= cutkey;
+      if (have[u] && !keep[u] && static_cast<int>(key16[u]) > dropped) dropped = static_cast<int>(key16[u]);
+    }
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const unsigned long long b0 = __ballot(keep[0]), b1 = __ballot(keep[1]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const int o = __shfl_xor(dropped, off, 64);
+      dropped = o > dropped ? o : dropped;
+    }
+    __syncthreads();
+    if (lane == 0) { sm.wave_a[wid] = __popcll(b0); sm.wave_b[wid] = __popcll(b1); sm.s_rank[wid] = dropped; }
+    __syncthreads();
+    int off0 = 0, tot0 = 0, off1 = 0, n = 0, front = -1;
+    for (int w = 0; w < kNW; ++w) {
+      if (w < wid) { off0 += sm.wave_a[w]; off1 += sm.wave_b[w]; }
+      tot0 += sm.wave_a[w];
+      n += sm.wave_b[w];
+      front = sm.s_rank[w] > front ? sm.s_rank[w] : front;
+    }
+    n += tot0;
+    if (keep[0]) { const int pos = off0 + __popcll(b0 & lt_mask); sm.cand_val[pos] = pbits[0]; sm.cand_tok[pos] = tok[0]; }
+    if (keep[1]) { const int pos = tot0 + off1 + __popcll(b1 & lt_mask); sm.cand_val[pos] = pbits[1]; sm.cand_tok[pos] = tok[1]; }
+    Frontier fr;
+    fr.unusable = &s_unusable;
+    fr.prob = 0.f;
+    fr.key = 0u;
+    const bool has_front = front >= 0;
+    if (has_front) {
+      fr.prob = softmax_prob(__uint_as_float(unorder16(static_cast<uint32_t>(front)) << 16), t, mx, sum);
+      fr.key = key_of(fr.prob);
+    }
+    __syncthreads();
+    // A long list that reaches neither limit (top-p over a wide nucleus without top-k) and has elements behind it: the frontier
+    // test below would send the row the long way after an O(n^2) ranking of the whole list -- go there at once.
+    if (!found_any && has_front && n > 256 && !p.min_ps) {
+      if (tid == 0) s_unusable = 1;
+    } else {
+      sample_row(p, row, sm, n, has_front ? &fr : nullptr);
+    }
+    __syncthreads();
+  }
+  const bool redo = s_bad || s_unusable;
+  if (tid == 0) ws.fallback[row] = redo ? 1 : 0;
+  if (!redo) return;
+  // ---- the long way, for this row only: its probabilities into the scratch matrix (this workgroup writes the whole row and is the
+  // only one to read it), then the row routine on them ----
+  {
+    const uint16_t* x = logits + static_cast<int64_t>(row) * logits_row_stride;
+    float* y = const_cast<float*>(p.probs) + static_cast<int64_t>(row) * p.row_stride;
+    const int V4 = p.V & ~3;
+    for (int i = 4 * tid; i < V4; i += 4 * kT) {
+      float v[4];
+      ld4<uint16_t>(x + i, v);
+      float4 o;
+      o.x = softmax_prob(v[0], t, mx, sum); o.y = softmax_prob(v[1], t, mx, sum); o.z = softmax_prob(v[2], t, mx, sum); o.w = softmax_prob(v[3], t, mx, sum);
+      *reinterpret_cast<float4*>(y + i) = o;
+    }
+    for (int i = V4 + tid; i < p.V; i += kT) y[i] = softmax_prob(ld1(x + i), t, mx, sum);
+    __threadfence_block();
+    __syncthreads();
+  }
+  sample_row(p, row, sm, -1);
+  fixup_empty_nucleus(p, row, sm);
+}
+
 // ---- the unfiltered case for decode-sized batches: a row cut into column ranges over the whole chip -------------
 // sampling_from_probs scores EVERY token (fp32 log + an fp64 gumbel each): one workgroup per row keeps 64 of 256 CUs busy
 // (209 us for [64, 128256]).  Pass 1: grid (ranges, rows), every workgroup's best (score, token) of its range goes to the
@@ -1196,6 +1735,50 @@ int sgl_amd_top_k_top_p_min_p_sample_ranges(const float* probs, int64_t row_stri
   hipLaunchKernelGGL(sample_collect_ranges_kernel, grid, dim3(kT), 0, as_stream(stream), p, num_ranges, ws);
   hipLaunchKernelGGL(sample_finish_ranges_kernel, dim3(batch), dim3(kT), 0, as_stream(stream), p, ws);
   SGL_CHECK_LAUNCH("top_k_top_p_min_p_sample_ranges");        // (the empty-nucleus fix-up is part of the finish launch)
+  return 0;
+}
+
+int64_t sgl_amd_sample_from_logits_workspace_bytes(int64_t batch, int num_splits) { return fast_ws_bytes(batch, num_splits); }
+
+int sgl_amd_top_k_top_p_min_p_sample_from_logits(const void* logits_bf16, int64_t logits_row_stride, const float* temperatures,
+                                                 float* probs_scratch, int64_t probs_row_stride, int64_t batch, int64_t vocab,
+                                                 const int32_t* top_ks, const float* top_ps, const float* min_ps,
+                                                 const int64_t* seeds, const int64_t* positions, int32_t* out_ids,
+                                                 void* ws_keys, void* ws_toks, int32_t* out_n_keep, int num_splits,
+                                                 void* ws_fast, void* stream) {
+  SGL_CLEAR_STALE_ERROR();
+  SGL_CHECK_ARG(vocab > 0 && vocab <= 0x7fffffffLL, "sample_from_logits: bad vocab");
+  SGL_CHECK_ARG(batch <= 65535, "sample_from_logits: batch <= 65535");
+  SGL_CHECK_ARG(seeds != nullptr && temperatures != nullptr, "sample_from_logits: seeds and temperatures are required");
+  SGL_CHECK_ARG((ws_keys == nullptr) == (ws_toks == nullptr), "sample_from_logits: pass both ranking workspaces or neither");
+  SGL_CHECK_ARG(num_splits >= 2 && num_splits <= 64 && ws_fast && (reinterpret_cast<uintptr_t>(ws_fast) & 15) == 0,
+                "sample_from_logits: 2..64 softmax ranges and a 16-byte aligned workspace");
+  SGL_CHECK_ARG(logits_bf16 && (reinterpret_cast<uintptr_t>(logits_bf16) & 7) == 0 && logits_row_stride % 4 == 0 && probs_scratch &&
+                    (reinterpret_cast<uintptr_t>(probs_scratch) & 15) == 0 && probs_row_stride % 4 == 0,
+                "sample_from_logits: needs 8-byte aligned bf16 rows and a 16-byte aligned fp32 scratch matrix for the rows redone the long way");
+  if (batch == 0) return 0;
+  SampleParams p;
+  p.probs = probs_scratch; p.row_stride = probs_row_stride; p.V = static_cast<int>(vocab);
+  p.top_ks = top_ks; p.top_ps = top_ps; p.min_ps = min_ps; p.seeds = seeds; p.positions = positions;
+  p.out_ids = out_ids; p.ws_keys = static_cast<uint32_t*>(ws_keys); p.ws_toks = static_cast<int32_t*>(ws_toks);
+  p.out_n_keep = out_n_keep; p.filtered = 1;
+  const FastWs ws = fast_ws_view(ws_fast, batch, num_splits);
+  const int G = (num_splits >= kFastRangesMax && num_splits % kFastRangesMax == 0) ? num_splits / kFastRangesMax : 1;
+  const int R = num_splits / G;
+  SGL_CHECK_ARG(R <= kFastRangesMax, "sample_from_logits: num_splits must be <= 16 or a multiple of 16");
+  const int64_t per = ((vocab + num_splits - 1) / num_splits + 3) / 4 * 4;
+  const int J = static_cast<int>((per + 1023) / 1024);
+  SGL_CHECK_ARG(G <= 4 && G * J <= kFastSlots, "sample_from_logits: a workgroup holds at most 16384 columns of a row (vocab / ranges too large)");
+  const uint16_t* x = static_cast<const uint16_t*>(logits_bf16);
+  if (G * J <= 8)
+    hipLaunchKernelGGL(sample_logit_candidates_kernel<8>, dim3(R, static_cast<unsigned>(batch)), dim3(kSplitThreads), 0, as_stream(stream), x,
+                       logits_row_stride, temperatures, static_cast<int>(vocab), num_splits, G, J, top_ks, ws);
+  else
+    hipLaunchKernelGGL(sample_logit_candidates_kernel<kFastSlots>, dim3(R, static_cast<unsigned>(batch)), dim3(kSplitThreads), 0, as_stream(stream),
+                       x, logits_row_stride, temperatures, static_cast<int>(vocab), num_splits, G, J, top_ks, ws);
+  hipLaunchKernelGGL(sample_finish_fast_kernel, dim3(batch), dim3(kT), 0, as_stream(stream), p, x, logits_row_stride, temperatures, num_splits, R,
+                     ws);
+  SGL_CHECK_LAUNCH("top_k_top_p_min_p_sample_from_logits");
   return 0;
 }
 

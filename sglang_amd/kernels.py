@@ -578,6 +578,56 @@ def top_k_top_p_min_p_sample(probs: torch.Tensor, top_ks: Optional[torch.Tensor]
     return (ids, n_keep) if return_n_keep else ids
 
 
+def sample_from_bf16_logits(logits: torch.Tensor, temperatures: torch.Tensor, top_ks: Optional[torch.Tensor],
+                            top_ps: Optional[torch.Tensor], min_ps: Optional[torch.Tensor], sampling_seed: Optional[torch.Tensor],
+                            positions: Optional[torch.Tensor], return_n_keep: bool = False, return_fallback: bool = False):
+    """sampler.py:211-260 for the bf16 logits of a decode-sized batch in one native call: softmax(logits / T) + the filtered
+    sampler, the probabilities never written (sampling_topk.hip: candidates / finish, + two launches that redo flagged rows the
+    long way).  Same ids and kept counts as softmax_temperature_from_bf16 + top_k_top_p_min_p_sample.  None when the shape is not
+    that case (the caller takes the two calls)."""
+    _dev(logits, temperatures)
+    if logits.dtype != _BF16 or logits.dim() != 2 or logits.stride(1) != 1:
+        return None
+    B, V = logits.shape
+    t = temperatures.reshape(-1)
+    splits = min(64, 2048 // max(1, B))            # the softmax's own range count: the partials are its partials
+    if not (B and splits >= 2 and (splits <= 16 or splits % 16 == 0) and V >= 4096 * splits // 8 and logits.data_ptr() % 8 == 0
+            and logits.stride(0) % 4 == 0 and B <= 65535 and t.dtype == torch.float32 and t.numel() == B and t.is_contiguous()):
+        return None
+    dev = logits.device
+    if sampling_seed is None:
+        sampling_seed = torch.randint(0, 2 ** 62, (B,), dtype=torch.int64, device=dev)
+    seeds = sampling_seed.to(torch.int64) if sampling_seed.dtype != torch.int64 else sampling_seed
+    _need(seeds.numel() == B and seeds.is_contiguous(), "sample: seeds [B]")
+    if positions is not None:
+        positions = positions.to(torch.int64).contiguous()
+        _need(positions.numel() == B, "sample: positions [B]")
+    top_ks = top_ks.to(torch.int32).contiguous() if top_ks is not None else None
+    top_ps = top_ps.to(torch.float32).contiguous() if top_ps is not None else None
+    min_ps = min_ps.to(torch.float32).contiguous() if min_ps is not None else None
+    ids = torch.empty(B, dtype=torch.int32, device=dev)
+    n_keep = torch.empty(B, dtype=torch.int32, device=dev) if return_n_keep else None
+    ws = _sample_workspace(B, V, dev)
+    key = ("from_logits", B, V, splits, str(dev))
+    fast = _SAMPLE_WS.get(key)
+    if fast is None:
+        nbytes = native.lib().sgl_amd_sample_from_logits_workspace_bytes(B, splits)
+        # (the probability scratch is only touched for rows redone the long way; kept with the workspace, not allocated per call)
+        fast = _SAMPLE_WS[key] = (torch.empty(nbytes // 8 + 2, dtype=torch.int64, device=dev),
+                                  torch.empty((B, V + (-V) % 4), dtype=torch.float32, device=dev))
+    wf, scratch = fast
+    native.call("sgl_amd_top_k_top_p_min_p_sample_from_logits", logits.data_ptr(), logits.stride(0), t.data_ptr(), scratch.data_ptr(),
+                scratch.stride(0), B, V, _ptr(top_ks), _ptr(top_ps), _ptr(min_ps), seeds.data_ptr(), _ptr(positions), ids.data_ptr(),
+                _ptr(ws[0]), _ptr(ws[1]), _ptr(n_keep), splits, wf.data_ptr(), _stream())
+    out = (ids,)
+    if return_n_keep:
+        out += (n_keep,)
+    if return_fallback:
+        nbytes = native.lib().sgl_amd_sample_from_logits_workspace_bytes(B, splits)
+        out += (wf.view(torch.int32)[nbytes // 4 - B: nbytes // 4].clone(),)
+    return out[0] if len(out) == 1 else out
+
+
 def _renorm(probs: torch.Tensor, top_k, top_p) -> torch.Tensor:
     _dev(probs)
     probs = probs.float()

@@ -81,22 +81,27 @@ class Sampler(nn.Module):
             # sampler.py:148-152, 211-260: div_ temperature, softmax in place, then sample from probs
             simple_sampling_case = not (sampling_info.need_top_p_sampling or sampling_info.need_top_k_sampling
                                         or sampling_info.need_min_p_sampling)
-            probs = None
+            probs = ids = None
+            min_ps = sampling_info.min_ps if sampling_info.need_min_p_sampling else None
             if logits.dtype == torch.bfloat16 and not return_logprob:
-                # bf16 logits of a decode-sized batch: widened inside the softmax launches (exact; no separate pass)
-                probs = kernels.softmax_temperature_from_bf16(logits, sampling_info.temperatures)
-            if probs is None:
-                if logits.dtype != torch.float32:
-                    logits = logits.float()                                 # exact widening of the bf16 logits
-                probs = kernels.softmax_temperature_(logits, sampling_info.temperatures)
-            if simple_sampling_case:
-                ids = kernels.top_k_top_p_min_p_sample(probs, None, None, None, sampling_info.sampling_seed, positions,
-                                                       filtered=False)
-            else:
-                ids = kernels.top_k_top_p_min_p_sample(
-                    probs, sampling_info.top_ks, sampling_info.top_ps,
-                    sampling_info.min_ps if sampling_info.need_min_p_sampling else None,
-                    sampling_info.sampling_seed, positions)
+                # bf16 logits of a decode-sized batch.  Filtered sampling: ONE native call, the probabilities are never written;
+                # otherwise the logits are widened inside the softmax launches (exact; no separate pass)
+                if not simple_sampling_case:
+                    ids = kernels.sample_from_bf16_logits(logits, sampling_info.temperatures, sampling_info.top_ks,
+                                                          sampling_info.top_ps, min_ps, sampling_info.sampling_seed, positions)
+                if ids is None:
+                    probs = kernels.softmax_temperature_from_bf16(logits, sampling_info.temperatures)
+            if ids is None:
+                if probs is None:
+                    if logits.dtype != torch.float32:
+                        logits = logits.float()                             # exact widening of the bf16 logits
+                    probs = kernels.softmax_temperature_(logits, sampling_info.temperatures)
+                if simple_sampling_case:
+                    ids = kernels.top_k_top_p_min_p_sample(probs, None, None, None, sampling_info.sampling_seed, positions,
+                                                           filtered=False)
+                else:
+                    ids = kernels.top_k_top_p_min_p_sample(probs, sampling_info.top_ks, sampling_info.top_ps, min_ps,
+                                                           sampling_info.sampling_seed, positions)
             if return_logprob:
                 logprobs = torch.log(probs)                                 # :252-257
         if return_logprob:

@@ -198,6 +198,67 @@ def test_filtered_sampling_over_column_ranges_equals_the_row_kernel(device, V, B
     assert K.sample_ranges(64, 128256) == 8 and K.sample_ranges(512, 128256) == 0 and K.sample_ranges(64, 4096) == 0
 
 
+@pytest.mark.parametrize("V,B", [(128256, 64), (128256, 16), (40000, 3), (65536, 130), (151936, 1)])
+def test_sampling_straight_from_bf16_logits_equals_softmax_then_sample(device, V, B):
+    """Round 6: Sampler.forward's filtered case for the bf16 logits of a decode-sized batch in ONE native call that never writes the
+    probabilities: every column range selects its largest logits exactly, only those become probabilities (the softmax launches' own
+    partials / merge / formula: the same bits) and are ranked, filtered and sampled; rows the candidates cannot decide are redone from
+    their full probability row inside the call.  Ids AND kept counts must equal softmax_temperature_from_bf16 +
+    top_k_top_p_min_p_sample on every row: peaked and flat rows, top-k only / top-p only / both / min-p, top_k in {0, 1, 64, 65, all},
+    ties wider than a range's list, rows of near-zero logits under one large one (distinct logits, equal probabilities), hot and
+    cold temperatures.  Rows with top_k <= 64 over gaussian logits must take the short way."""
+    K = _k()
+    g = torch.Generator().manual_seed(3 * V + B)
+    scale = torch.tensor(([4.0, 1.0, 8.0, 0.3, 2.0, 6.0, 3.0, 0.05] * (B // 8 + 1))[:B]).unsqueeze(1)
+    lg = torch.randn((B, V), generator=g) * scale
+    temps = (torch.rand((B, 1), generator=g) + 0.5)
+    top_ks = torch.tensor(([50, 1, 64, TOP_K_ALL, 65, 0, 20, 1000] * (B // 8 + 1))[:B], dtype=torch.int32)
+    top_ps = torch.tensor(([0.9, 1.0, 1.0, 0.95, 0.8, 0.5, 0.999, 0.9] * (B // 8 + 1))[:B])
+    min_ps = torch.tensor(([0.0, 0.0, 0.0, 0.01, 0.0, 0.0, 0.2, 0.0] * (B // 8 + 1))[:B])
+    special = {}
+    if B >= 16:
+        lg[8] = 0.0                                            # every logit equal: a tie wider than any list (top_k 50)
+        lg[9] = (torch.randn(V, generator=g) * 1e-6)           # near-zero logits under one large one: x / t - max collapses,
+        lg[9, 77] = 12.0                                       # distinct logits with equal probabilities (top_k 1 / top_p 1)
+        lg[10] = (torch.randint(0, 3, (V,), generator=g).float() - 1.0) * 4      # three values only: huge ties at the cut (top_k 64)
+        lg[11, :] = -30.0
+        lg[11, 5:9] = torch.tensor([2.0, 2.0, 1.0, 2.0])       # a tiny support (top_k all, top_p 0.95, min_p 0.01)
+        temps[12] = 40.0                                       # hot: flat row, top_k 65 / top_p 0.8
+        temps[14] = 0.05                                       # cold
+        special = {8, 9, 10, 12}
+    lg = lg.to(torch.bfloat16)
+    seeds = torch.randint(0, 2 ** 62, (B,), generator=g)
+    pos = torch.randint(0, 4096, (B,), generator=g)
+    d = lambda x: x.to(device)
+    if K.softmax_temperature_from_bf16(d(lg), d(temps)) is None:
+        assert K.sample_from_bf16_logits(d(lg), d(temps), d(top_ks), d(top_ps), None, d(seeds), d(pos)) is None
+        return
+    for mp in (None, d(min_ps)):
+        probs = K.softmax_temperature_from_bf16(d(lg), d(temps))
+        want, want_n = K.top_k_top_p_min_p_sample(probs, d(top_ks), d(top_ps), mp, d(seeds), d(pos), return_n_keep=True)
+        got, got_n, fb = K.sample_from_bf16_logits(d(lg), d(temps), d(top_ks), d(top_ps), mp, d(seeds), d(pos), return_n_keep=True,
+                                                   return_fallback=True)
+        fb = fb.cpu().tolist()
+        assert got_n.cpu().tolist() == want_n.cpu().tolist(), (mp is not None, fb)
+        assert got.cpu().tolist() == want.cpu().tolist(), (mp is not None, fb)
+        for r in range(B):
+            if r not in special and 1 <= int(top_ks[r]) <= 64 and float(scale[r]) >= 1.0:
+                assert fb[r] == 0, (r, fb)
+        assert all(fb[r] == 1 for r in range(B) if int(top_ks[r]) == 0)
+    # the split rule of the softmax it shares its partials with; other range counts have no short way
+    assert K.sample_from_bf16_logits(d(lg[:1, :4096].contiguous()), d(temps[:1]), d(top_ks[:1]), d(top_ps[:1]), None, d(seeds[:1]),
+                                     d(pos[:1])) is None or V < 4096 * 8
+
+
+def test_sampling_from_bf16_logits_unsupported_range_counts_fall_back(device):
+    """B = 40 -> 51 softmax ranges (neither <= 16 nor a multiple of 16): no short way, the Sampler module takes the two calls."""
+    K = _k()
+    lg = torch.randn((40, 128256)).to(torch.bfloat16).to(device)
+    t = torch.ones((40, 1), device=device)
+    assert K.sample_from_bf16_logits(lg, t, None, torch.full((40,), 0.9, device=device), None, torch.arange(40, device=device), None) is None
+    assert K.softmax_temperature_from_bf16(lg, t) is not None
+
+
 def test_ties_and_degenerate_rows(device):
     K = _k()
     V = 4096
