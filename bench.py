@@ -783,13 +783,16 @@ def kernel_rooflines(args, cfg, runner, result, B, G, P, in_len, ctx, t_decode_s
     t_s = graph_time(lambda: smp(LogitsProcessorOutput(next_token_logits=lg), info, positions=pos_s), 1, reps=20)
     t_a = graph_time(lambda: K.argmax(lg), 1, reps=20)
     alg_s = Bs * V * 4
-    result["sampler"] = {"bound": "hbm", "kernel": "Sampler.forward: widen + softmax_temperature_kernel + sample_kernel (4-level radix "
-                                                    "select, ballot compaction, fp64 gumbel arg-max with the reference's murmur hash)",
+    result["sampler"] = {"bound": "hbm", "kernel": "Sampler.forward on bf16 logits: sample_logit_candidates_kernel (softmax partials + every column "
+                                                    "range's largest logits, from registers) + sample_finish_fast_kernel (probabilities of the candidates only, "
+                                                    "pruned list ranked in LDS, the three rules, fp64 gumbel arg-max with the reference's murmur hash; rows the "
+                                                    "candidates cannot decide are redone from their full probability row there)",
                          "config": {"temperature": 1.0, "top_k": 50, "top_p": 0.9, "seeded": True, "batch": Bs, "vocab": V},
                          "us_per_call": t_s * 1e6, "algorithmic_bytes": alg_s, "achieved": alg_s / t_s / 1e9, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": alg_s / t_s / 1e9 / HBM_PEAK_GBPS,
-                         "note": "B x V x 4 B = the fp32 probabilities read once; the kernels make 5-6 passes over a row "
-                                 "(0.5 MB, L2-resident after the first), so the figure is a floor on L2 traffic, not HBM traffic",
+                         "note": "algorithmic bytes stay SURVEY 8(d)'s B x V x 4 B (the fp32 probabilities read once) so that rounds compare; "
+                                 "since round 6 the path reads the B x V x 2 B bf16 logits once and never writes the probabilities -- "
+                                 "what bounds it is the vector ALU (one fp32 division and one expf per logit for the softmax sum), not memory",
                          "greedy_argmax_us": t_a * 1e6, "share_of_decode_step_if_sampling": t_s / t_decode_step}
 
 

@@ -19,3 +19,4 @@ for _ in range(20):
     ids, fb = K.sample_from_bf16_logits(lg, t, tk, tp, None, seed, pos, return_fallback=True)
 torch.cuda.synchronize()
 print("rows redone the long way:", int(fb.sum()))
+

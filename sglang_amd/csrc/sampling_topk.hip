@@ -710,10 +710,12 @@ __device__ void sample_row(const SampleParams& p, const int row, RowSmem& sm, co
       my_rank[u] = -1;
       if (e < n_keep) {
         const uint32_t ke = sm.keys[e];
+        const int te = sm.toks[e];
         int rank = 0;
         for (int j = 0; j < n_keep; ++j) {
           const uint32_t kj = sm.keys[j];
-          rank += (kj > ke) || (kj == ke && j < e);
+          // ties by token id (for lists in token order that is `j < e`; sample_from_logits' lists are in no particular order)
+          rank += (kj > ke) || (kj == ke && sm.toks[j] < te);
         }
         my_key[u] = ke; my_tok[u] = sm.toks[e]; my_rank[u] = rank;
       }
@@ -1121,7 +1123,6 @@ __global__ __launch_bounds__(kSplitThreads) void sample_logit_candidates_kernel(
                                                                                 const int32_t* __restrict__ top_ks, FastWs ws) {
   __shared__ float red[4][4];
   __shared__ int redi[4];
-  __shared__ int slot_cnt[NS + 1][4];
   __shared__ alignas(16) uint32_t hist[4][257];
   __shared__ uint32_t wave_tot[4];
   __shared__ int sel[4];
@@ -1171,6 +1172,7 @@ __global__ __launch_bounds__(kSplitThreads) void sample_logit_candidates_kernel(
   // range's two workgroup reductions done side by side.  The maximum of x / t is (the maximum of x) / t for t > 0 -- a correctly
   // rounded division is monotone -- so the first pass divides once per range, not once per column. ----
   const bool t_pos = t > 0.f;                        // (uniform; other temperatures: column by column, and the row goes the long way)
+  const bool t_one = t == 1.0f;                      // (uniform) x / 1 is x: the exponent pass skips 32 divisions
   float mxg[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
@@ -1205,7 +1207,9 @@ __global__ __launch_bounds__(kSplitThreads) void sample_logit_candidates_kernel(
       const int g = slot_g(s);
       const float mx = g == 0 ? mxg[0] : g == 1 ? mxg[1] : g == 2 ? mxg[2] : mxg[3];
       if (mx > -INFINITY) {
-        const float add = expf(val_of(s, 0) / t - mx) + expf(val_of(s, 1) / t - mx) + expf(val_of(s, 2) / t - mx) + expf(val_of(s, 3) / t - mx);
+        float add;
+        if (t_one) add = expf(val_of(s, 0) - mx) + expf(val_of(s, 1) - mx) + expf(val_of(s, 2) - mx) + expf(val_of(s, 3) - mx);
+        else add = expf(val_of(s, 0) / t - mx) + expf(val_of(s, 1) / t - mx) + expf(val_of(s, 2) / t - mx) + expf(val_of(s, 3) / t - mx);
 #pragma unroll
         for (int gg = 0; gg < 4; ++gg) smg[gg] = g == gg ? smg[gg] + add : smg[gg];
       }
@@ -1250,89 +1254,121 @@ __global__ __launch_bounds__(kSplitThreads) void sample_logit_candidates_kernel(
   }
   const int Kc = static_cast<int>(top_k < kFastK ? top_k : kFastK);
   const uint32_t K = static_cast<uint32_t>(Kc < n ? Kc : n);
-  auto for_each = [&](auto&& f) {                   // every column this thread holds (registers)
+  auto for_each = [&](auto&& f) {                   // every column this thread holds (registers): f(bf16 bits, column)
 #pragma unroll
     for (int s = 0; s < NS; ++s)
-      if (is_on(s)) { f(bits_of(s, 0)); f(bits_of(s, 1)); f(bits_of(s, 2)); f(bits_of(s, 3)); }
-    if (tail_i >= 0) f(tail_bits);
+      if (is_on(s)) {
+        const int col = slot_col(s);
+        f(bits_of(s, 0), col); f(bits_of(s, 1), col + 1); f(bits_of(s, 2), col + 2); f(bits_of(s, 3), col + 3);
+      }
+    if (tail_i >= 0) f(tail_bits, tail_i);
   };
-  // A lower bound of the K-th largest key without a histogram: every wave takes the ceil(K / 4)-th largest of its 64 per-lane
-  // maxima, the bound is the smallest of the four (K distinct columns are >= it).  For rows in any order but an adversarial one
-  // ~K .. 2 K columns pass it: they ARE the candidates, a superset of everything >= the K-th largest.  (Histogramming the range
-  // cost 13 us of LDS atomics on the handful of hot bins of a softmax row.)
-  int my_max = -1;
-  for_each([&](uint32_t bits) { const int k = static_cast<int>(order16(bits)); my_max = k > my_max ? k : my_max; });
+  auto for_each_val = [&](auto&& f) {               // the same, as the fp32 value of the logit (one shift or mask per column)
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+      if (is_on(s)) {
+        const int col = slot_col(s);
+        f(__uint_as_float(q[s].x << 16), col); f(__uint_as_float(q[s].x & 0xffff0000u), col + 1);
+        f(__uint_as_float(q[s].y << 16), col + 2); f(__uint_as_float(q[s].y & 0xffff0000u), col + 3);
+      }
+    if (tail_i >= 0) f(__uint_as_float(tail_bits << 16), tail_i);
+  };
+  const int n_mine = 4 * __popc(on_mask) + (tail_i >= 0 ? 1 : 0);
+  // A lower bound of the K-th largest logit without a histogram: every wave takes the ceil(K / 4)-th largest of its 64 per-lane
+  // maxima (a 16-step bit search on the 16-bit order keys with ballots), the bound is the smallest of the four: K distinct columns
+  // are >= it.  For rows in any order but an adversarial one ~K .. 2 K columns pass it: they ARE the candidates, a superset of
+  // everything >= the K-th largest.  (Histogramming the range cost 13 us of LDS atomics on the handful of hot bins of a softmax
+  // row.)  Columns are compared as fp32 values (-0 == +0 there: a superset still; a NaN passes no test -- its row's softmax is
+  // not finite and the finish launch sends it the long way).
+  float my_maxf = -INFINITY;
+  for_each_val([&](float v, int) { my_maxf = fmaxf(my_maxf, v); });
+  const int my_max = n_mine > 0 ? static_cast<int>(order16(__float_as_uint(my_maxf) >> 16)) : -1;
   {
     const int kw = (static_cast<int>(K) + 3) / 4;
-    int rank = 0;                                   // lanes ahead of mine in (value desc, lane asc) order
+    uint32_t pre = 0;                               // largest v with #(lane maxima >= v) >= kw  (0 if fewer than kw lanes hold columns)
 #pragma unroll
-    for (int j = 0; j < 64; ++j) {
-      const int o = __builtin_amdgcn_readlane(my_max, j);
-      rank += (o > my_max) || (o == my_max && j < lane);
+    for (int bit = 15; bit >= 0; --bit) {
+      const uint32_t cand = pre | (1u << bit);
+      const int cnt = __popcll(__ballot(my_max >= static_cast<int>(cand)));
+      pre = cnt >= kw ? cand : pre;
     }
-    if (rank == kw - 1) redi[wid] = my_max;
+    if (lane == 0) redi[wid] = static_cast<int>(pre);
   }
+  if (tid == 0) sel[3] = 0;                          // the emit counter
   __syncthreads();
   int bound = redi[0];
 #pragma unroll
   for (int w = 1; w < 4; ++w) bound = redi[w] < bound ? redi[w] : bound;
-  uint32_t kth = bound < 0 ? 0u : static_cast<uint32_t>(bound);
-  __syncthreads();
-  {
-    int cnt = 0;
-    for_each([&](uint32_t bits) { cnt += order16(bits) >= kth; });
+  uint32_t kth = static_cast<uint32_t>(bound);
+  uint32_t* out_val = ws.cand_val + (static_cast<int64_t>(row) * R + c) * kFastCap;
+  int* out_tok = ws.cand_tok + (static_cast<int64_t>(row) * R + c) * kFastCap;
+  // ---- emit (in no particular order: the finish launch ranks by (value, token)); the largest value left out is the frontier.
+  // Positions: hits per lane, an exclusive scan over the wave, ONE LDS atomic per wave ----
+  float front_f = -INFINITY;
+  bool any_left = false;
+  auto emit = [&]() {
+    const float L = kth == 0u ? -INFINITY : __uint_as_float(unorder16(kth) << 16);
+    front_f = -INFINITY;
+    int hits = 0;
+    for_each_val([&](float v, int) {
+      hits += v >= L;
+      front_f = fmaxf(front_f, v < L ? v : -INFINITY);
+    });
+    any_left = hits < n_mine;
+    int incl = hits;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
-    if (lane == 0) redi[wid] = cnt;
-    __syncthreads();
-    const int tot = redi[0] + redi[1] + redi[2] + redi[3];
-    __syncthreads();
-    if (tot > kFastCap) {                             // (workgroup-uniform) too many pass the bound: the exact two-level select
-      for (int z = tid; z < 4 * 257; z += kSplitThreads) (&hist[0][0])[z] = 0;
-      __syncthreads();
-      for_each([&](uint32_t bits) { atomicAdd(&hist[wid][order16(bits) >> 8], 1u); });
-      __syncthreads();
-      select_bin_256(hist[0][tid] + hist[1][tid] + hist[2][tid] + hist[3][tid], K, wave_tot, sel);
-      const uint32_t b1 = static_cast<uint32_t>(sel[0]), above1 = static_cast<uint32_t>(sel[1]);
-      __syncthreads();
-      for (int z = tid; z < 4 * 257; z += kSplitThreads) (&hist[0][0])[z] = 0;
-      __syncthreads();
-      for_each([&](uint32_t bits) {
-        const uint32_t k = order16(bits);
-        if ((k >> 8) == b1) atomicAdd(&hist[wid][k & 255u], 1u);
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += o;
+    }
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    int base = 0;
+    if (total > 0) {                                  // (wave-uniform)
+      if (lane == 0) base = atomicAdd(&sel[3], total);
+      base = __builtin_amdgcn_readfirstlane(base);
+    }
+    int pos = base + incl - hits;
+    if (hits > 0) {
+      for_each_val([&](float v, int col) {
+        if (v >= L) {
+          if (pos < kFastCap) { out_val[pos] = __float_as_uint(v); out_tok[pos] = col; }
+          ++pos;
+        }
       });
-      __syncthreads();
-      select_bin_256(hist[0][tid] + hist[1][tid] + hist[2][tid] + hist[3][tid], K - above1, wave_tot, sel);
-      kth = (b1 << 8) | static_cast<uint32_t>(sel[0]);
-      const int n_ge = static_cast<int>(above1) + sel[1] + sel[2];
-      if (n_ge > kFastCap) {                          // (workgroup-uniform) a tie wider than the list
-        if (tid == 0) { meta[0] = -1; meta[1] = -1; }
-        return;
-      }
     }
-  }
-  // ---- emit in token order = (slot, thread, column): per (slot, wave) counts first, positions from their table ----
-  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  int front = -1;
-#pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    int total = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const uint32_t key = order16(bits_of(s, k));
-      const bool in = is_on(s) && key >= kth;
-      if (is_on(s) && key < kth && static_cast<int>(key) > front) front = static_cast<int>(key);
-      total += __popcll(__ballot(in));
+  };
+  emit();
+  __syncthreads();
+  if (sel[3] > kFastCap) {                          // (workgroup-uniform) too many pass the bound: the exact two-level select
+    __syncthreads();
+    for (int z = tid; z < 4 * 257; z += kSplitThreads) (&hist[0][0])[z] = 0;
+    __syncthreads();
+    for_each([&](uint32_t bits, int) { atomicAdd(&hist[wid][order16(bits) >> 8], 1u); });
+    __syncthreads();
+    select_bin_256(hist[0][tid] + hist[1][tid] + hist[2][tid] + hist[3][tid], K, wave_tot, sel);
+    const uint32_t b1 = static_cast<uint32_t>(sel[0]), above1 = static_cast<uint32_t>(sel[1]);
+    __syncthreads();
+    for (int z = tid; z < 4 * 257; z += kSplitThreads) (&hist[0][0])[z] = 0;
+    __syncthreads();
+    for_each([&](uint32_t bits, int) {
+      const uint32_t k = order16(bits);
+      if ((k >> 8) == b1) atomicAdd(&hist[wid][k & 255u], 1u);
+    });
+    __syncthreads();
+    select_bin_256(hist[0][tid] + hist[1][tid] + hist[2][tid] + hist[3][tid], K - above1, wave_tot, sel);
+    kth = (b1 << 8) | static_cast<uint32_t>(sel[0]);
+    const int n_ge = static_cast<int>(above1) + sel[1] + sel[2];
+    __syncthreads();
+    if (n_ge > kFastCap) {                            // (workgroup-uniform) a tie wider than the list
+      if (tid == 0) { meta[0] = -1; meta[1] = -1; }
+      return;
     }
-    if (lane == 0) slot_cnt[s][wid] = total;
+    if (tid == 0) sel[3] = 0;
+    __syncthreads();
+    emit();
+    __syncthreads();
   }
-  {
-    const uint32_t key = order16(tail_bits);
-    const bool in = tail_i >= 0 && key >= kth;
-    if (tail_i >= 0 && key < kth && static_cast<int>(key) > front) front = static_cast<int>(key);
-    const int total = __popcll(__ballot(in));
-    if (lane == 0) slot_cnt[NS][wid] = total;
-  }
+  int front = any_left ? static_cast<int>(order16(__float_as_uint(front_f) >> 16)) : -1;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     const int o = __shfl_xor(front, off, 64);
@@ -1340,42 +1376,78 @@ __global__ __launch_bounds__(kSplitThreads) void sample_logit_candidates_kernel(
   }
   if (lane == 0) redi[wid] = front;
   __syncthreads();
-  uint32_t* out_val = ws.cand_val + (static_cast<int64_t>(row) * R + c) * kFastCap;
-  int* out_tok = ws.cand_tok + (static_cast<int64_t>(row) * R + c) * kFastCap;
-  int acc = 0;                                        // candidates of the slots before this one
-#pragma unroll
-  for (int s = 0; s <= NS; ++s) {
-    const int c0 = slot_cnt[s][0], c1 = slot_cnt[s][1], c2 = slot_cnt[s][2], c3 = slot_cnt[s][3];
-    const int mine = wid == 0 ? c0 : wid == 1 ? c1 : wid == 2 ? c2 : c3;
-    if (mine > 0) {                                   // (wave-uniform)
-      int pos = acc + (wid > 0 ? c0 : 0) + (wid > 1 ? c1 : 0) + (wid > 2 ? c2 : 0);
-      if (s < NS) {
-        const int ss = s < NS ? s : 0;
-        bool in[4];
-        int before = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          in[k] = is_on(ss) && order16(bits_of(ss, k)) >= kth;
-          before += __popcll(__ballot(in[k]) & lt_mask);
-        }
-        pos += before;
-        const int col = slot_col(ss);
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (in[k]) { out_val[pos] = bits_of(ss, k) << 16; out_tok[pos] = col + k; ++pos; }
-      } else {
-        const bool in = tail_i >= 0 && order16(tail_bits) >= kth;
-        pos += __popcll(__ballot(in) & lt_mask);
-        if (in) { out_val[pos] = tail_bits << 16; out_tok[pos] = tail_i; }
-      }
-    }
-    acc += c0 + c1 + c2 + c3;
-  }
   if (tid == 0) {
     int f = redi[0];
     for (int w = 1; w < 4; ++w) f = redi[w] > f ? redi[w] : f;
-    meta[0] = acc;
+    meta[0] = sel[3] > kFastCap ? -1 : sel[3];        // (fp32 compares emit -0 with +0: the exact select's count is a key count)
     meta[1] = f;
+  }
+}
+
+// The row routine's direct form for a list of <= 64 survivors, by ONE wave (lane = list element): the same rules, the same
+// arithmetic (exact_top_p_keep on fp64 inclusive prefix sums, fp64 gumbel scores, best_better) without a workgroup barrier --
+// sample_row spends ~15 us on its dozen barriers and serial LDS loops for the ~50 elements a pruned list holds.
+__device__ void finish_small_list(const SampleParams& p, const int row, const uint32_t* cand_val, const int* cand_tok, uint32_t* s_key, int* s_tok,
+                                  const int n, int64_t top_k, const float top_p, const bool has_min_p, const float min_p, const uint64_t seed,
+                                  const uint32_t pos, const Frontier* fr) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t key = lane < n ? key_of(__uint_as_float(cand_val[lane])) : 0u;
+  const int tok = lane < n ? cand_tok[lane] : 0x7fffffff;
+  uint32_t min_key = 0;
+  if (has_min_p) {
+    float mxp = lane < n ? __uint_as_float(cand_val[lane]) : 0.f;
+    mxp = wave_max(fmaxf(mxp, 0.f));
+    min_key = key_of(mxp * min_p);
+  }
+  int rank = 0;                                       // descending value, ties by token id
+#pragma unroll 8
+  for (int j = 0; j < 64; ++j) {
+    const uint32_t kj = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(key), j));
+    const int tj = __builtin_amdgcn_readlane(tok, j);
+    rank += (j < n) && ((kj > key) || (kj == key && tj < tok));
+  }
+  if (lane < n) { s_key[rank] = key; s_tok[rank] = tok; }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  const int r = lane;                                 // lane r owns sorted rank r
+  const uint32_t kr = r < n ? s_key[r] : 0u;
+  const int tr = r < n ? s_tok[r] : 0;
+  const float pv = r < n ? __uint_as_float(kr) : 0.f;
+  double run = static_cast<double>(pv);               // inclusive prefix sums in lane order
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const double o = __shfl_up(run, off, 64);
+    if (lane >= off) run += o;
+  }
+  if (fr) {
+    // the first rank at or below the frontier: the elements above it are a prefix of the sorted order
+    const int r0 = __popcll(__ballot(r < n && kr > fr->key));
+    const double incl_prev = __shfl(run, r0 > 0 ? r0 - 1 : 0, 64);
+    const double excl = r0 > 0 ? incl_prev : 0.0;
+    const bool keep_h = r0 < top_k && fr->key >= min_key && exact_top_p_keep(excl + static_cast<double>(fr->prob), fr->prob, top_p);
+    if (keep_h && lane == 0) *fr->unusable = 1;
+  }
+  const uint32_t hpre = murmur_prefix(seed, pos);
+  Best best{0.0, -1, 0};
+  const bool keep = r < n && r < top_k && kr >= min_key && exact_top_p_keep(run, pv, top_p);
+  if (keep) {
+    best.score = log(static_cast<double>(pv)) + gumbel_from_hash(murmur_hash32(hpre, r));
+    best.rank = r;
+    best.token = tr;
+  }
+  const int kept = __popcll(__ballot(keep));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    Best o;
+    o.score = __shfl_xor(best.score, off, 64);
+    o.rank = __shfl_xor(best.rank, off, 64);
+    o.token = __shfl_xor(best.token, off, 64);
+    if (best_better(best, o)) best = o;
+  }
+  if (lane == 0) {
+    p.out_ids[row] = best.rank < 0 ? 0 : best.token;   // (empty nucleus: the reference's all -inf row argmax-es to sorted rank 0)
+    if (p.out_n_keep) p.out_n_keep[row] = kept;
   }
 }
 
@@ -1385,15 +1457,51 @@ __global__ __launch_bounds__(kT) void sample_finish_fast_kernel(SampleParams p, 
   __shared__ int pre[kFastRangesMax + 1];
   __shared__ int m_cnt[kFastRangesMax], m_front[kFastRangesMax];
   __shared__ int s_front, s_bad, s_unusable;
+  __shared__ float s_mx, s_sum;
   const int row = blockIdx.x, tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  // ---- ONE round trip to memory for everything the row needs: its parameters, the R range records, the 2 S softmax partials and
+  // this thread's <= 2 slots of the candidate lists (read whether filled or not: validity comes from the records) ----
   const float t = temperatures[row];
-  if (tid < R) {                                        // (one round trip for the row's R records, not R of them)
-    const int2 m = *reinterpret_cast<const int2*>(ws.meta + (static_cast<int64_t>(row) * R + tid) * 2);
-    m_cnt[tid] = m.x; m_front[tid] = m.y;
+  int64_t top_k = p.top_ks ? p.top_ks[row] : p.V;
+  const float top_p = p.top_ps ? p.top_ps[row] : 1.0f;
+  const float min_p = p.min_ps ? p.min_ps[row] : 0.f;
+  const uint64_t seed = static_cast<uint64_t>(p.seeds[row]);
+  const uint32_t spos = p.positions ? static_cast<uint32_t>(p.positions[row] & 0xffffffffll) : 0u;
+  uint32_t lb[2] = {0u, 0u};
+  int tok[2] = {0, 0};
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int idx = tid + u * kT;
+    if (idx < R * kFastCap) {
+      lb[u] = ws.cand_val[static_cast<int64_t>(row) * R * kFastCap + idx];
+      tok[u] = ws.cand_tok[static_cast<int64_t>(row) * R * kFastCap + idx];
+    }
   }
-  float mx, sum;
-  merge_partials(ws.partials + static_cast<int64_t>(row) * S * 2, S, &mx, &sum);
+  if (tid >= 256 && tid < 512) { sm.hist_cnt[tid - 256] = 0; sm.hist_sum[tid - 256] = 0; sm.part_cnt[tid - 256] = 0; sm.part_sum[16 + tid - 256] = 0; }
+  if (tid == 512) { sm.found_bin = -1; sm.n_eq_keep = -1; }
+  if (tid >= 64 && tid < 64 + R) {
+    const int2 m = *reinterpret_cast<const int2*>(ws.meta + (static_cast<int64_t>(row) * R + tid - 64) * 2);
+    m_cnt[tid - 64] = m.x; m_front[tid - 64] = m.y;
+  }
+  if (wid == 0) {
+    // the row's maximum and sum from its S partials: merge_partials' arithmetic (softmax_ranges.hpp) with the S exponentials
+    // side by side; the sum itself stays a left-to-right chain over the ranges (the bits of the normalise launch)
+    const float pm = lane < S ? ws.partials[(static_cast<int64_t>(row) * S + lane) * 2] : -INFINITY;
+    const float ps = lane < S ? ws.partials[(static_cast<int64_t>(row) * S + lane) * 2 + 1] : 0.f;
+    const float mx = wave_max(pm);
+    const float ex = pm > -INFINITY ? expf(pm - mx) : 0.f;
+    float sum = 0.f;
+    for (int s2 = 0; s2 < S; ++s2) {
+      const float es = __uint_as_float(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(__float_as_uint(ex)), s2)));
+      const float ss = __uint_as_float(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(__float_as_uint(ps)), s2)));
+      const float ms = __uint_as_float(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(__float_as_uint(pm)), s2)));
+      if (ms > -INFINITY) sum = __fmaf_rn(ss, es, sum);
+    }
+    if (lane == 0) { s_mx = mx; s_sum = sum; }
+  }
   __syncthreads();
+  const float mx = s_mx, sum = s_sum;
   if (tid == 0) {
     int acc = 0, front = -1, bad = 0;
     for (int c = 0; c < R; ++c) {
@@ -1402,35 +1510,23 @@ __global__ __launch_bounds__(kT) void sample_finish_fast_kernel(SampleParams p, 
       front = m_front[c] > front ? m_front[c] : front;
     }
     pre[R] = acc;
-    const int64_t tk = p.top_ks ? p.top_ks[row] : p.V;
-    if (tk <= 0 || acc == 0 || acc >= kDirect) bad = 1;
+    if (top_k <= 0 || acc == 0 || acc >= kDirect) bad = 1;
     if (!(t > 0.f) || !(sum > 0.f) || !(sum < INFINITY) || !(mx > -INFINITY) || !(mx < INFINITY)) bad = 1;
     s_front = front; s_bad = bad; s_unusable = 0;
   }
   __syncthreads();
   if (!s_bad) {                                         // (workgroup-uniform)
-    // ---- this thread's <= 2 candidates (list order = token order = (range, position) order) ----
-    const int lane = tid & 63, wid = tid >> 6;
-    int64_t top_k = p.top_ks ? p.top_ks[row] : p.V;
     if (top_k > p.V) top_k = p.V;
-    const float top_p = p.top_ps ? p.top_ps[row] : 1.0f;
     const unsigned long long p_fix = top_p_fix_superset(top_p);
     bool have[2];
     uint32_t key16[2], pbits[2];
-    int tok[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int idx = tid + u * kT;
       const int c = idx / kFastCap, j = idx - c * kFastCap;
       have[u] = c < R && j < m_cnt[c < R ? c : 0];
-      key16[u] = 0; pbits[u] = 0; tok[u] = 0;
-      if (have[u]) {
-        const int64_t o = (static_cast<int64_t>(row) * R + c) * kFastCap + j;
-        const uint32_t lb = ws.cand_val[o];
-        key16[u] = order16(lb >> 16);
-        pbits[u] = __float_as_uint(softmax_prob(__uint_as_float(lb), t, mx, sum));
-        tok[u] = ws.cand_tok[o];
-      }
+      key16[u] = have[u] ? order16(lb[u] >> 16) : 0u;
+      pbits[u] = have[u] ? __float_as_uint(softmax_prob(__uint_as_float(lb[u]), t, mx, sum)) : 0u;
     }
     // ---- prune to a prefix of the descending order that holds top_k elements or top_p (+ 2^-22) of the mass, whichever comes
     // first: a two-level select on the 16-bit logit keys with count and fixed-point mass histograms (order-independent).  The
@@ -1438,19 +1534,21 @@ __global__ __launch_bounds__(kT) void sample_finish_fast_kernel(SampleParams p, 
     uint32_t cutkey = 0;
     bool found_any = true;
     {
+      // (both levels' histograms were cleared before the kernel's first barrier: level 0 in hist_cnt / hist_sum, level 1 in
+      // part_cnt[0..255] / part_sum[16..271]; three barriers per level)
       uint32_t base_c = 0;
       unsigned long long base_s = 0;
 #pragma unroll
       for (int level = 0; level < 2; ++level) {
-        if (tid < 256) { sm.hist_cnt[tid] = 0; sm.hist_sum[tid] = 0; }
-        __syncthreads();
+        uint32_t* h_cnt = level == 0 ? sm.hist_cnt : sm.part_cnt;
+        unsigned long long* h_sum = level == 0 ? sm.hist_sum : sm.part_sum + 16;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const bool in = have[u] && (level == 0 || (key16[u] >> 8) == (cutkey >> 8));
           if (in) {
             const int bin = level == 0 ? (key16[u] >> 8) : (key16[u] & 255u);
-            atomicAdd(&sm.hist_cnt[bin], 1u);
-            atomicAdd(&sm.hist_sum[bin], static_cast<unsigned long long>(to_fix(__uint_as_float(pbits[u]))));
+            atomicAdd(&h_cnt[bin], 1u);
+            atomicAdd(&h_sum[bin], static_cast<unsigned long long>(to_fix(__uint_as_float(pbits[u]))));
           }
         }
         __syncthreads();
@@ -1459,8 +1557,8 @@ __global__ __launch_bounds__(kT) void sample_finish_fast_kernel(SampleParams p, 
         uint32_t my_c = 0;
         unsigned long long my_s = 0;
         if (tid < 256) {                                // (waves 0 .. 3 whole) inclusive suffix sums over the wave's 64 bins
-          my_c = vc = sm.hist_cnt[tid];
-          my_s = vs = sm.hist_sum[tid];
+          my_c = vc = h_cnt[tid];
+          my_s = vs = h_sum[tid];
 #pragma unroll
           for (int off = 1; off < 64; off <<= 1) {
             const uint32_t oc = __shfl_down(vc, off, 64);
@@ -1469,7 +1567,6 @@ __global__ __launch_bounds__(kT) void sample_finish_fast_kernel(SampleParams p, 
           }
           if (lane == 0) { sm.wave_a[wid] = static_cast<int>(vc); sm.part_sum[wid] = vs; }
         }
-        if (tid == 0) sm.found_bin = -1;
         __syncthreads();
         if (tid < 256) {
           uint32_t ac = base_c;
@@ -1479,15 +1576,17 @@ __global__ __launch_bounds__(kT) void sample_finish_fast_kernel(SampleParams p, 
           const unsigned long long incl_s = vs + as, excl_s = incl_s - my_s;
           const bool cond_incl = static_cast<int64_t>(incl_c) >= top_k || incl_s >= p_fix;
           const bool cond_excl = static_cast<int64_t>(excl_c) >= top_k || excl_s >= p_fix;
-          if (cond_incl && !cond_excl) { sm.found_bin = tid; sm.c_above = static_cast<int>(excl_c); sm.s_above = excl_s; }
+          if (cond_incl && !cond_excl) {
+            if (level == 0) { sm.found_bin = tid; sm.c_above = static_cast<int>(excl_c); sm.s_above = excl_s; }
+            else { sm.n_eq_keep = tid; }
+          }
         }
         __syncthreads();
-        const int fb = sm.found_bin;
+        const int fb = level == 0 ? sm.found_bin : sm.n_eq_keep;
         if (fb < 0) { found_any = false; break; }       // (uniform) level 0 only: the whole list is inside both limits
         cutkey = level == 0 ? (static_cast<uint32_t>(fb) << 8) : (cutkey | static_cast<uint32_t>(fb));
         base_c = static_cast<uint32_t>(sm.c_above);
         base_s = sm.s_above;
-        __syncthreads();
       }
       if (!found_any) cutkey = 0;
     }
@@ -1533,6 +1632,10 @@ __global__ __launch_bounds__(kT) void sample_finish_fast_kernel(SampleParams p, 
     // test below would send the row the long way after an O(n^2) ranking of the whole list -- go there at once.
     if (!found_any && has_front && n > 256 && !p.min_ps) {
       if (tid == 0) s_unusable = 1;
+    } else if (n <= 64) {                               // (workgroup-uniform) what a pruned list almost always is
+      if (wid == 0)
+        finish_small_list(p, row, sm.cand_val, sm.cand_tok, sm.keys, sm.toks, n, top_k, top_p, p.min_ps != nullptr, min_p, seed, spos,
+                          has_front ? &fr : nullptr);
     } else {
       sample_row(p, row, sm, n, has_front ? &fr : nullptr);
     }

@@ -68,7 +68,7 @@ __device__ __forceinline__ void merge_partials(const float* pr, int splits, floa
   float sum = 0.f;
   for (int s = 0; s < splits; ++s) {
     const float ms = pr[2 * s];
-    if (ms > -INFINITY) sum += pr[2 * s + 1] * expf(ms - mx);
+    if (ms > -INFINITY) sum = __fmaf_rn(pr[2 * s + 1], expf(ms - mx), sum);   // (an explicit fma: the same bits wherever this chain is evaluated)
   }
   *out_max = mx;
   *out_sum = sum;
