@@ -53,6 +53,10 @@ _, fb = K.sample_from_bf16_logits(lg, info.temperatures, allk, info.top_ps, None
 out["top_p_only_rows_redone_the_long_way"] = int(fb.sum())
 out["sample_from_bf16_logits_top_p_only_us"] = graph_time(lambda: K.sample_from_bf16_logits(lg, info.temperatures, allk, info.top_ps, None, info.sampling_seed, pos))
 out["two_calls_top_p_only_us"] = graph_time(lambda: K.top_k_top_p_min_p_sample(K.softmax_temperature_from_bf16(lg, info.temperatures), allk, info.top_ps, None, info.sampling_seed, pos))
+# fp32 logits (what the reference's LogitsProcessor hands its Sampler): the same one-call path
+lf = lg.float()
+out["sampler_forward_fp32_logits_us"] = graph_time(lambda: smp(LogitsProcessorOutput(next_token_logits=lf), info, positions=pos))
+out["softmax_then_sample_fp32_logits_us"] = graph_time(lambda: K.top_k_top_p_min_p_sample(K.softmax_temperature_(lf.clone(), info.temperatures), info.top_ks, info.top_ps, None, info.sampling_seed, pos)) - graph_time(lambda: lf.clone())
 out["algorithmic_bytes"] = B * V * 4
 out["frac_of_hbm_8TBps"] = B * V * 4 / out["sampler_forward_us"] / 1e6 / 8.0
 print(json.dumps(out, indent=1))

@@ -257,10 +257,11 @@ int sgl_amd_top_k_top_p_min_p_sample_ranges(const float* probs, int64_t row_stri
                                             const int64_t* seeds, const int64_t* positions, int32_t* out_ids,
                                             void* ws_keys, void* ws_toks, int32_t* out_n_keep, int num_ranges,
                                             void* ws_ranges, void* stream);
-/* sampler.py:211-260 in one call for the MODEL-DTYPE logits of a decode-sized batch: softmax(logits / T) followed by the filtered
- * sampler above, without ever writing the [batch, vocab] probabilities.  p(x) is monotone in the logit, so every column range
+/* sampler.py:211-260 in one call for the logits of a decode-sized batch -- bf16 (the model's dtype) or fp32 (what the reference's
+ * LogitsProcessor hands its Sampler: logits_processor.py `.float()`) --: softmax(logits / T) followed by the filtered
+ * sampler above, without ever writing the [batch, vocab] probabilities (the fp32 logits are NOT overwritten with them).  p(x) is monotone in the logit, so every column range
  * selects its largest bf16 logits exactly (two-level radix select on 16-bit order keys) and only those candidates are turned into
- * probabilities -- with the range partials, the merge and the formula of sgl_amd_softmax_temperature_split_bf16 (num_splits
+ * probabilities -- with the range partials, the merge and the formula of sgl_amd_softmax_temperature_split{,_bf16} (num_splits
  * ranges: the same bits) -- ranked, filtered by the three rules and sampled.  A row whose candidates cannot decide the rules
  * (they reach the largest value a range left out: flat rows, top-p over a wide nucleus without top-k, > 127 ties, top_k <= 0, a
  * non-finite softmax) is redone inside the same call from its full probability row, written into probs_scratch for that row only.
@@ -268,7 +269,7 @@ int sgl_amd_top_k_top_p_min_p_sample_ranges(const float* probs, int64_t row_stri
  * sgl_amd_sample_from_logits_workspace_bytes(batch, num_splits) bytes, 16-byte aligned, no initial state (its last `batch`
  * int32 words hold, after the call, which rows went the long way: tests / telemetry). */
 int64_t sgl_amd_sample_from_logits_workspace_bytes(int64_t batch, int num_splits);
-int sgl_amd_top_k_top_p_min_p_sample_from_logits(const void* logits_bf16, int64_t logits_row_stride, const float* temperatures,
+int sgl_amd_top_k_top_p_min_p_sample_from_logits(const void* logits, int logits_is_bf16, int64_t logits_row_stride, const float* temperatures,
                                                  float* probs_scratch, int64_t probs_row_stride, int64_t batch, int64_t vocab,
                                                  const int32_t* top_ks, const float* top_ps, const float* min_ps,
                                                  const int64_t* seeds, const int64_t* positions, int32_t* out_ids,

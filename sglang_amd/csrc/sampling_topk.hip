@@ -1071,11 +1071,11 @@ struct FastWs {
   float* partials;      // [B, S, 2]
   uint32_t* cand_val;   // [B, R, kFastCap]: the logit as fp32 bits
   int* cand_tok;        // [B, R, kFastCap]
-  int* meta;            // [B, R, 2]: candidates (-1: more than kFastCap), frontier order key (-1: everything emitted)
+  int* meta;            // [B, R, 4]: candidates (-1: more than kFastCap), 1 if columns were left out, the largest of them (fp32 bits), 0
   int* fallback;        // [B]: 1 = redo the row from its probabilities
 };
 __host__ __device__ inline int64_t fast_ws_bytes(int64_t batch, int splits) {
-  return batch * splits * 8 + batch * kFastRangesMax * kFastCap * 8 + batch * kFastRangesMax * 8 + batch * 4;
+  return batch * splits * 8 + batch * kFastRangesMax * kFastCap * 8 + batch * kFastRangesMax * 16 + batch * 4;
 }
 __host__ __device__ inline FastWs fast_ws_view(void* base, int64_t batch, int splits) {
   FastWs w;
@@ -1083,14 +1083,40 @@ __host__ __device__ inline FastWs fast_ws_view(void* base, int64_t batch, int sp
   w.partials = reinterpret_cast<float*>(b);         b += batch * splits * 8;
   w.cand_val = reinterpret_cast<uint32_t*>(b);      b += batch * kFastRangesMax * kFastCap * 4;
   w.cand_tok = reinterpret_cast<int*>(b);           b += batch * kFastRangesMax * kFastCap * 4;
-  w.meta = reinterpret_cast<int*>(b);               b += batch * kFastRangesMax * 8;
+  w.meta = reinterpret_cast<int*>(b);               b += batch * kFastRangesMax * 16;
   w.fallback = reinterpret_cast<int*>(b);
   return w;
 }
 
-// bf16 bit pattern -> 16-bit key that orders like the value (-0 < +0; NaN rows never get here: their softmax is not finite)
-__device__ __forceinline__ uint32_t order16(uint32_t bits) { return bits ^ ((bits & 0x8000u) ? 0xffffu : 0x8000u); }
-__device__ __forceinline__ uint32_t unorder16(uint32_t key) { return key ^ ((key & 0x8000u) ? 0x8000u : 0xffffu); }
+// fp32 bit pattern -> the top 16 bits of a key that orders like the value (-0 < +0; NaN rows never get here: their softmax is
+// not finite).  bf16 logits are their fp32 widening: the 16 bits ARE the whole key; for genuine fp32 logits columns that agree in
+// them are selected together (a superset still).
+__device__ __forceinline__ uint32_t order_hi16(uint32_t fbits) { return (fbits ^ ((fbits & 0x80000000u) ? 0xffffffffu : 0x80000000u)) >> 16; }
+// the smallest fp32 value whose key is `key16` (every column with a key >= key16 compares >= it)
+__device__ __forceinline__ float floor_of_key16(uint32_t key16) {
+  const uint32_t k = key16 << 16;
+  return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
+}
+
+// four consecutive columns of a row of logits in registers
+template <typename IN>
+struct Cols4;
+template <>
+struct Cols4<uint16_t> {
+  uint2 q;
+  __device__ __forceinline__ void load(const uint16_t* p) { q = *reinterpret_cast<const uint2*>(p); }
+  __device__ __forceinline__ void zero() { q = uint2{0u, 0u}; }
+  __device__ __forceinline__ float v(int k) const {
+    return __uint_as_float(k == 0 ? (q.x << 16) : k == 1 ? (q.x & 0xffff0000u) : k == 2 ? (q.y << 16) : (q.y & 0xffff0000u));
+  }
+};
+template <>
+struct Cols4<float> {
+  float4 q;
+  __device__ __forceinline__ void load(const float* p) { q = *reinterpret_cast<const float4*>(p); }
+  __device__ __forceinline__ void zero() { q = float4{0.f, 0.f, 0.f, 0.f}; }
+  __device__ __forceinline__ float v(int k) const { return k == 0 ? q.x : k == 1 ? q.y : k == 2 ? q.z : q.w; }
+};
 
 // which of 256 bins holds the K-th largest element: `c` = this thread's (tid = bin) count.  Returns through LDS `sel`:
 // [0] bin, [1] elements in the bins above it, [2] elements in it.  Needs K >= 1 and K <= the total.  256 threads.
@@ -1117,8 +1143,8 @@ constexpr int kFastSlots = 16;     // 1024-column steps of a workgroup's columns
 // ~3 us each, and the first version made seven).  Slot s = (softmax range g = s / J of the workgroup's G, step j = s % J): the 4
 // columns b_g + 1024 j + 4 tid ..; the row's last range may end in <= 3 more columns (thread tid < 3 holds one).  NS = slots
 // compiled in (8 covers [*, 128256] at 16 candidate ranges).
-template <int NS>
-__global__ __launch_bounds__(kSplitThreads) void sample_logit_candidates_kernel(const uint16_t* __restrict__ logits, int64_t row_stride,
+template <typename IN, int NS>
+__global__ __launch_bounds__(kSplitThreads) void sample_logit_candidates_kernel(const IN* __restrict__ logits, int64_t row_stride,
                                                                                 const float* __restrict__ temperatures, int V, int S, int G, int J,
                                                                                 const int32_t* __restrict__ top_ks, FastWs ws) {
   __shared__ float red[4][4];
@@ -1128,11 +1154,11 @@ __global__ __launch_bounds__(kSplitThreads) void sample_logit_candidates_kernel(
   __shared__ int sel[4];
   const int row = blockIdx.y, c = blockIdx.x, R = gridDim.x;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const uint16_t* x = logits + static_cast<int64_t>(row) * row_stride;
+  const IN* x = logits + static_cast<int64_t>(row) * row_stride;
   const float t = temperatures[row];
   const int per = ((V + S - 1) / S + 3) / 4 * 4;    // (split_range_of's geometry)
   // ---- one burst: every column of the workgroup ----
-  uint2 q[NS];
+  Cols4<IN> q[NS];
   uint32_t on_mask = 0;                              // slot s holds four columns of this thread
   auto slot_g = [&](int s) { return s / J; };        // (uniform)
   auto slot_col = [&](int s) {
@@ -1151,21 +1177,21 @@ __global__ __launch_bounds__(kSplitThreads) void sample_logit_candidates_kernel(
     const int i = slot_col(s);
     const bool on = g < G && i < e4;
     on_mask |= on ? (1u << s) : 0u;
-    q[s] = on ? *reinterpret_cast<const uint2*>(x + i) : uint2{0u, 0u};
+    if (on) q[s].load(x + i);
+    else q[s].zero();
   }
   // (the <= 3 columns behind the last multiple of four: in the row's last range only, which is this workgroup's last if any)
   const int tail_g = G - 1;
   int tail_i = -1;
-  uint32_t tail_bits = 0;
+  float tail_v = 0.f;
   {
     int64_t b = static_cast<int64_t>(per) * (c * G + tail_g), e = b + per;
     if (b > V) b = V;
     if (e > V) e = V;
     const int64_t e4 = b + (e - b) / 4 * 4;
-    if (e4 + tid < e) { tail_i = static_cast<int>(e4 + tid); tail_bits = x[tail_i]; }
+    if (e4 + tid < e) { tail_i = static_cast<int>(e4 + tid); tail_v = ld1(x + tail_i); }
   }
-  auto bits_of = [&](int s, int k) -> uint32_t { return k == 0 ? (q[s].x & 0xffffu) : k == 1 ? (q[s].x >> 16) : k == 2 ? (q[s].y & 0xffffu) : (q[s].y >> 16); };
-  auto val_of = [&](int s, int k) -> float { return __uint_as_float(bits_of(s, k) << 16); };
+  auto val_of = [&](int s, int k) -> float { return q[s].v(k); };
   auto is_on = [&](int s) { return (on_mask >> s) & 1u; };
 
   // ---- the softmax partials of the G ranges: range_partial's arithmetic in range_partial's order (softmax_ranges.hpp), every
@@ -1184,7 +1210,7 @@ __global__ __launch_bounds__(kSplitThreads) void sample_logit_candidates_kernel(
     for (int gg = 0; gg < 4; ++gg) mxg[gg] = g == gg ? fmaxf(mxg[gg], m) : mxg[gg];
   }
   if (tail_i >= 0) {
-    const float m = t_pos ? __uint_as_float(tail_bits << 16) : __uint_as_float(tail_bits << 16) / t;
+    const float m = t_pos ? tail_v : tail_v / t;
 #pragma unroll
     for (int gg = 0; gg < 4; ++gg) mxg[gg] = tail_g == gg ? fmaxf(mxg[gg], m) : mxg[gg];
   }
@@ -1218,7 +1244,7 @@ __global__ __launch_bounds__(kSplitThreads) void sample_logit_candidates_kernel(
   if (tail_i >= 0) {
     const float mx = tail_g == 0 ? mxg[0] : tail_g == 1 ? mxg[1] : tail_g == 2 ? mxg[2] : mxg[3];
     if (mx > -INFINITY) {
-      const float add = expf(__uint_as_float(tail_bits << 16) / t - mx);
+      const float add = expf(tail_v / t - mx);
 #pragma unroll
       for (int gg = 0; gg < 4; ++gg) smg[gg] = tail_g == gg ? smg[gg] + add : smg[gg];
     }
@@ -1238,7 +1264,7 @@ __global__ __launch_bounds__(kSplitThreads) void sample_logit_candidates_kernel(
   }
 
   // ---- candidates ----
-  int* meta = ws.meta + (static_cast<int64_t>(row) * R + c) * 2;
+  int* meta = ws.meta + (static_cast<int64_t>(row) * R + c) * 4;
   int64_t top_k = top_ks ? top_ks[row] : V;
   if (top_k > V) top_k = V;
   int n;
@@ -1249,29 +1275,22 @@ __global__ __launch_bounds__(kSplitThreads) void sample_logit_candidates_kernel(
     n = static_cast<int>(ce - cb);
   }
   if (n <= 0 || top_k <= 0) {                       // (top_k <= 0: the finish launch sends the row the long way)
-    if (tid == 0) { meta[0] = 0; meta[1] = -1; }
+    if (tid == 0) { meta[0] = 0; meta[1] = 0; meta[2] = 0; }
     return;
   }
   const int Kc = static_cast<int>(top_k < kFastK ? top_k : kFastK);
   const uint32_t K = static_cast<uint32_t>(Kc < n ? Kc : n);
-  auto for_each = [&](auto&& f) {                   // every column this thread holds (registers): f(bf16 bits, column)
+  auto for_each_val = [&](auto&& f) {               // every column this thread holds (registers): f(fp32 value of the logit, column)
 #pragma unroll
     for (int s = 0; s < NS; ++s)
       if (is_on(s)) {
         const int col = slot_col(s);
-        f(bits_of(s, 0), col); f(bits_of(s, 1), col + 1); f(bits_of(s, 2), col + 2); f(bits_of(s, 3), col + 3);
+        f(q[s].v(0), col); f(q[s].v(1), col + 1); f(q[s].v(2), col + 2); f(q[s].v(3), col + 3);
       }
-    if (tail_i >= 0) f(tail_bits, tail_i);
+    if (tail_i >= 0) f(tail_v, tail_i);
   };
-  auto for_each_val = [&](auto&& f) {               // the same, as the fp32 value of the logit (one shift or mask per column)
-#pragma unroll
-    for (int s = 0; s < NS; ++s)
-      if (is_on(s)) {
-        const int col = slot_col(s);
-        f(__uint_as_float(q[s].x << 16), col); f(__uint_as_float(q[s].x & 0xffff0000u), col + 1);
-        f(__uint_as_float(q[s].y << 16), col + 2); f(__uint_as_float(q[s].y & 0xffff0000u), col + 3);
-      }
-    if (tail_i >= 0) f(__uint_as_float(tail_bits << 16), tail_i);
+  auto for_each = [&](auto&& f) {                   // the same as (16-bit order key, column)
+    for_each_val([&](float v, int col) { f(order_hi16(__float_as_uint(v)), col); });
   };
   const int n_mine = 4 * __popc(on_mask) + (tail_i >= 0 ? 1 : 0);
   // A lower bound of the K-th largest logit without a histogram: every wave takes the ceil(K / 4)-th largest of its 64 per-lane
@@ -1282,7 +1301,7 @@ __global__ __launch_bounds__(kSplitThreads) void sample_logit_candidates_kernel(
   // not finite and the finish launch sends it the long way).
   float my_maxf = -INFINITY;
   for_each_val([&](float v, int) { my_maxf = fmaxf(my_maxf, v); });
-  const int my_max = n_mine > 0 ? static_cast<int>(order16(__float_as_uint(my_maxf) >> 16)) : -1;
+  const int my_max = n_mine > 0 ? static_cast<int>(order_hi16(__float_as_uint(my_maxf))) : -1;
   {
     const int kw = (static_cast<int>(K) + 3) / 4;
     uint32_t pre = 0;                               // largest v with #(lane maxima >= v) >= kw  (0 if fewer than kw lanes hold columns)
@@ -1307,7 +1326,7 @@ __global__ __launch_bounds__(kSplitThreads) void sample_logit_candidates_kernel(
   float front_f = -INFINITY;
   bool any_left = false;
   auto emit = [&]() {
-    const float L = kth == 0u ? -INFINITY : __uint_as_float(unorder16(kth) << 16);
+    const float L = kth == 0u ? -INFINITY : floor_of_key16(kth);
     front_f = -INFINITY;
     int hits = 0;
     for_each_val([&](float v, int) {
@@ -1343,16 +1362,15 @@ __global__ __launch_bounds__(kSplitThreads) void sample_logit_candidates_kernel(
     __syncthreads();
     for (int z = tid; z < 4 * 257; z += kSplitThreads) (&hist[0][0])[z] = 0;
     __syncthreads();
-    for_each([&](uint32_t bits, int) { atomicAdd(&hist[wid][order16(bits) >> 8], 1u); });
+    for_each([&](uint32_t k16, int) { atomicAdd(&hist[wid][k16 >> 8], 1u); });
     __syncthreads();
     select_bin_256(hist[0][tid] + hist[1][tid] + hist[2][tid] + hist[3][tid], K, wave_tot, sel);
     const uint32_t b1 = static_cast<uint32_t>(sel[0]), above1 = static_cast<uint32_t>(sel[1]);
     __syncthreads();
     for (int z = tid; z < 4 * 257; z += kSplitThreads) (&hist[0][0])[z] = 0;
     __syncthreads();
-    for_each([&](uint32_t bits, int) {
-      const uint32_t k = order16(bits);
-      if ((k >> 8) == b1) atomicAdd(&hist[wid][k & 255u], 1u);
+    for_each([&](uint32_t k16, int) {
+      if ((k16 >> 8) == b1) atomicAdd(&hist[wid][k16 & 255u], 1u);
     });
     __syncthreads();
     select_bin_256(hist[0][tid] + hist[1][tid] + hist[2][tid] + hist[3][tid], K - above1, wave_tot, sel);
@@ -1360,7 +1378,7 @@ __global__ __launch_bounds__(kSplitThreads) void sample_logit_candidates_kernel(
     const int n_ge = static_cast<int>(above1) + sel[1] + sel[2];
     __syncthreads();
     if (n_ge > kFastCap) {                            // (workgroup-uniform) a tie wider than the list
-      if (tid == 0) { meta[0] = -1; meta[1] = -1; }
+      if (tid == 0) { meta[0] = -1; meta[1] = 0; meta[2] = 0; }
       return;
     }
     if (tid == 0) sel[3] = 0;
@@ -1368,19 +1386,24 @@ __global__ __launch_bounds__(kSplitThreads) void sample_logit_candidates_kernel(
     emit();
     __syncthreads();
   }
-  int front = any_left ? static_cast<int>(order16(__float_as_uint(front_f) >> 16)) : -1;
+  // the largest value left out, over the workgroup (any_left: this thread left something out)
+  float fr_w = any_left ? front_f : -INFINITY;
+  int left_w = any_left ? 1 : 0;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
-    const int o = __shfl_xor(front, off, 64);
-    front = o > front ? o : front;
+    fr_w = fmaxf(fr_w, __shfl_xor(fr_w, off, 64));
+    left_w |= __shfl_xor(left_w, off, 64);
   }
-  if (lane == 0) redi[wid] = front;
+  if (lane == 0) { red[0][wid] = fr_w; redi[wid] = left_w; }
   __syncthreads();
   if (tid == 0) {
-    int f = redi[0];
-    for (int w = 1; w < 4; ++w) f = redi[w] > f ? redi[w] : f;
-    meta[0] = sel[3] > kFastCap ? -1 : sel[3];        // (fp32 compares emit -0 with +0: the exact select's count is a key count)
-    meta[1] = f;
+    const float f = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+    int4 m;
+    m.x = sel[3] > kFastCap ? -1 : sel[3];            // (fp32 compares emit -0 with +0: the exact select's count is a key count)
+    m.y = redi[0] | redi[1] | redi[2] | redi[3];
+    m.z = static_cast<int>(__float_as_uint(f));
+    m.w = 0;
+    *reinterpret_cast<int4*>(meta) = m;
   }
 }
 
@@ -1451,12 +1474,15 @@ __device__ void finish_small_list(const SampleParams& p, const int row, const ui
   }
 }
 
-__global__ __launch_bounds__(kT) void sample_finish_fast_kernel(SampleParams p, const uint16_t* __restrict__ logits, int64_t logits_row_stride,
+template <typename IN>
+__global__ __launch_bounds__(kT) void sample_finish_fast_kernel(SampleParams p, const IN* __restrict__ logits, int64_t logits_row_stride,
                                                                  const float* __restrict__ temperatures, int S, int R, FastWs ws) {
   __shared__ RowSmem sm;
   __shared__ int pre[kFastRangesMax + 1];
-  __shared__ int m_cnt[kFastRangesMax], m_front[kFastRangesMax];
-  __shared__ int s_front, s_bad, s_unusable;
+  __shared__ int m_cnt[kFastRangesMax], m_left[kFastRangesMax];
+  __shared__ float m_front[kFastRangesMax];
+  __shared__ int s_has_front, s_bad, s_unusable;
+  __shared__ float s_front;
   __shared__ float s_mx, s_sum;
   const int row = blockIdx.x, tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
@@ -1481,8 +1507,8 @@ __global__ __launch_bounds__(kT) void sample_finish_fast_kernel(SampleParams p, 
   if (tid >= 256 && tid < 512) { sm.hist_cnt[tid - 256] = 0; sm.hist_sum[tid - 256] = 0; sm.part_cnt[tid - 256] = 0; sm.part_sum[16 + tid - 256] = 0; }
   if (tid == 512) { sm.found_bin = -1; sm.n_eq_keep = -1; }
   if (tid >= 64 && tid < 64 + R) {
-    const int2 m = *reinterpret_cast<const int2*>(ws.meta + (static_cast<int64_t>(row) * R + tid - 64) * 2);
-    m_cnt[tid - 64] = m.x; m_front[tid - 64] = m.y;
+    const int4 m = *reinterpret_cast<const int4*>(ws.meta + (static_cast<int64_t>(row) * R + tid - 64) * 4);
+    m_cnt[tid - 64] = m.x; m_left[tid - 64] = m.y; m_front[tid - 64] = __uint_as_float(static_cast<uint32_t>(m.z));
   }
   if (wid == 0) {
     // the row's maximum and sum from its S partials: merge_partials' arithmetic (softmax_ranges.hpp) with the S exponentials
@@ -1503,16 +1529,17 @@ __global__ __launch_bounds__(kT) void sample_finish_fast_kernel(SampleParams p, 
   __syncthreads();
   const float mx = s_mx, sum = s_sum;
   if (tid == 0) {
-    int acc = 0, front = -1, bad = 0;
+    int acc = 0, has = 0, bad = 0;
+    float front = -INFINITY;
     for (int c = 0; c < R; ++c) {
       pre[c] = acc;
       if (m_cnt[c] < 0) bad = 1; else acc += m_cnt[c];
-      front = m_front[c] > front ? m_front[c] : front;
+      if (m_left[c]) { has = 1; front = fmaxf(front, m_front[c]); }
     }
     pre[R] = acc;
     if (top_k <= 0 || acc == 0 || acc >= kDirect) bad = 1;
     if (!(t > 0.f) || !(sum > 0.f) || !(sum < INFINITY) || !(mx > -INFINITY) || !(mx < INFINITY)) bad = 1;
-    s_front = front; s_bad = bad; s_unusable = 0;
+    s_front = front; s_has_front = has; s_bad = bad; s_unusable = 0;
   }
   __syncthreads();
   if (!s_bad) {                                         // (workgroup-uniform)
@@ -1525,7 +1552,7 @@ __global__ __launch_bounds__(kT) void sample_finish_fast_kernel(SampleParams p, 
       const int idx = tid + u * kT;
       const int c = idx / kFastCap, j = idx - c * kFastCap;
       have[u] = c < R && j < m_cnt[c < R ? c : 0];
-      key16[u] = have[u] ? order16(lb[u] >> 16) : 0u;
+      key16[u] = have[u] ? order_hi16(lb[u]) : 0u;
       pbits[u] = have[u] ? __float_as_uint(softmax_prob(__uint_as_float(lb[u]), t, mx, sum)) : 0u;
     }
     // ---- prune to a prefix of the descending order that holds top_k elements or top_p (+ 2^-22) of the mass, whichever comes
@@ -1592,28 +1619,31 @@ __global__ __launch_bounds__(kT) void sample_finish_fast_kernel(SampleParams p, 
     }
     // ---- compact the survivors, in list order, into the row routine's candidate arrays ----
     bool keep[2];
-    int dropped = s_front;
+    float dropped = s_has_front ? s_front : -INFINITY;   // the largest logit NOT in the list handed on: left out by a range, or dropped here
+    int any_out = s_has_front;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       keep[u] = have[u] && key16[u] >= cutkey;
-      if (have[u] && !keep[u] && static_cast<int>(key16[u]) > dropped) dropped = static_cast<int>(key16[u]);
+      if (have[u] && !keep[u]) { dropped = fmaxf(dropped, __uint_as_float(lb[u])); any_out = 1; }
     }
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const unsigned long long b0 = __ballot(keep[0]), b1 = __ballot(keep[1]);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-      const int o = __shfl_xor(dropped, off, 64);
-      dropped = o > dropped ? o : dropped;
+      dropped = fmaxf(dropped, __shfl_xor(dropped, off, 64));
+      any_out |= __shfl_xor(any_out, off, 64);
     }
     __syncthreads();
-    if (lane == 0) { sm.wave_a[wid] = __popcll(b0); sm.wave_b[wid] = __popcll(b1); sm.s_rank[wid] = dropped; }
+    if (lane == 0) { sm.wave_a[wid] = __popcll(b0); sm.wave_b[wid] = __popcll(b1); sm.red[wid] = dropped; sm.s_rank[wid] = any_out; }
     __syncthreads();
-    int off0 = 0, tot0 = 0, off1 = 0, n = 0, front = -1;
+    int off0 = 0, tot0 = 0, off1 = 0, n = 0, has_front_i = 0;
+    float front = -INFINITY;
     for (int w = 0; w < kNW; ++w) {
       if (w < wid) { off0 += sm.wave_a[w]; off1 += sm.wave_b[w]; }
       tot0 += sm.wave_a[w];
       n += sm.wave_b[w];
-      front = sm.s_rank[w] > front ? sm.s_rank[w] : front;
+      front = fmaxf(front, sm.red[w]);
+      has_front_i |= sm.s_rank[w];
     }
     n += tot0;
     if (keep[0]) { const int pos = off0 + __popcll(b0 & lt_mask); sm.cand_val[pos] = pbits[0]; sm.cand_tok[pos] = tok[0]; }
@@ -1622,9 +1652,9 @@ __global__ __launch_bounds__(kT) void sample_finish_fast_kernel(SampleParams p, 
     fr.unusable = &s_unusable;
     fr.prob = 0.f;
     fr.key = 0u;
-    const bool has_front = front >= 0;
+    const bool has_front = has_front_i != 0;
     if (has_front) {
-      fr.prob = softmax_prob(__uint_as_float(unorder16(static_cast<uint32_t>(front)) << 16), t, mx, sum);
+      fr.prob = softmax_prob(front, t, mx, sum);
       fr.key = key_of(fr.prob);
     }
     __syncthreads();
@@ -1647,12 +1677,12 @@ __global__ __launch_bounds__(kT) void sample_finish_fast_kernel(SampleParams p, 
   // ---- the long way, for this row only: its probabilities into the scratch matrix (this workgroup writes the whole row and is the
   // only one to read it), then the row routine on them ----
   {
-    const uint16_t* x = logits + static_cast<int64_t>(row) * logits_row_stride;
+    const IN* x = logits + static_cast<int64_t>(row) * logits_row_stride;
     float* y = const_cast<float*>(p.probs) + static_cast<int64_t>(row) * p.row_stride;
     const int V4 = p.V & ~3;
     for (int i = 4 * tid; i < V4; i += 4 * kT) {
       float v[4];
-      ld4<uint16_t>(x + i, v);
+      ld4<IN>(x + i, v);
       float4 o;
       o.x = softmax_prob(v[0], t, mx, sum); o.y = softmax_prob(v[1], t, mx, sum); o.z = softmax_prob(v[2], t, mx, sum); o.w = softmax_prob(v[3], t, mx, sum);
       *reinterpret_cast<float4*>(y + i) = o;
@@ -1843,7 +1873,7 @@ int sgl_amd_top_k_top_p_min_p_sample_ranges(const float* probs, int64_t row_stri
 
 int64_t sgl_amd_sample_from_logits_workspace_bytes(int64_t batch, int num_splits) { return fast_ws_bytes(batch, num_splits); }
 
-int sgl_amd_top_k_top_p_min_p_sample_from_logits(const void* logits_bf16, int64_t logits_row_stride, const float* temperatures,
+int sgl_amd_top_k_top_p_min_p_sample_from_logits(const void* logits, int logits_is_bf16, int64_t logits_row_stride, const float* temperatures,
                                                  float* probs_scratch, int64_t probs_row_stride, int64_t batch, int64_t vocab,
                                                  const int32_t* top_ks, const float* top_ps, const float* min_ps,
                                                  const int64_t* seeds, const int64_t* positions, int32_t* out_ids,
@@ -1856,9 +1886,10 @@ int sgl_amd_top_k_top_p_min_p_sample_from_logits(const void* logits_bf16, int64_
   SGL_CHECK_ARG((ws_keys == nullptr) == (ws_toks == nullptr), "sample_from_logits: pass both ranking workspaces or neither");
   SGL_CHECK_ARG(num_splits >= 2 && num_splits <= 64 && ws_fast && (reinterpret_cast<uintptr_t>(ws_fast) & 15) == 0,
                 "sample_from_logits: 2..64 softmax ranges and a 16-byte aligned workspace");
-  SGL_CHECK_ARG(logits_bf16 && (reinterpret_cast<uintptr_t>(logits_bf16) & 7) == 0 && logits_row_stride % 4 == 0 && probs_scratch &&
+  SGL_CHECK_ARG(logits && (reinterpret_cast<uintptr_t>(logits) & (logits_is_bf16 ? 7 : 15)) == 0 && logits_row_stride % 4 == 0 && probs_scratch &&
                     (reinterpret_cast<uintptr_t>(probs_scratch) & 15) == 0 && probs_row_stride % 4 == 0,
-                "sample_from_logits: needs 8-byte aligned bf16 rows and a 16-byte aligned fp32 scratch matrix for the rows redone the long way");
+                "sample_from_logits: needs 8-byte aligned bf16 (16-byte aligned fp32) rows and a 16-byte aligned fp32 scratch matrix for the rows "
+                "redone the long way");
   if (batch == 0) return 0;
   SampleParams p;
   p.probs = probs_scratch; p.row_stride = probs_row_stride; p.V = static_cast<int>(vocab);
@@ -1872,15 +1903,22 @@ int sgl_amd_top_k_top_p_min_p_sample_from_logits(const void* logits_bf16, int64_
   const int64_t per = ((vocab + num_splits - 1) / num_splits + 3) / 4 * 4;
   const int J = static_cast<int>((per + 1023) / 1024);
   SGL_CHECK_ARG(G <= 4 && G * J <= kFastSlots, "sample_from_logits: a workgroup holds at most 16384 columns of a row (vocab / ranges too large)");
-  const uint16_t* x = static_cast<const uint16_t*>(logits_bf16);
-  if (G * J <= 8)
-    hipLaunchKernelGGL(sample_logit_candidates_kernel<8>, dim3(R, static_cast<unsigned>(batch)), dim3(kSplitThreads), 0, as_stream(stream), x,
-                       logits_row_stride, temperatures, static_cast<int>(vocab), num_splits, G, J, top_ks, ws);
-  else
-    hipLaunchKernelGGL(sample_logit_candidates_kernel<kFastSlots>, dim3(R, static_cast<unsigned>(batch)), dim3(kSplitThreads), 0, as_stream(stream),
-                       x, logits_row_stride, temperatures, static_cast<int>(vocab), num_splits, G, J, top_ks, ws);
-  hipLaunchKernelGGL(sample_finish_fast_kernel, dim3(batch), dim3(kT), 0, as_stream(stream), p, x, logits_row_stride, temperatures, num_splits, R,
-                     ws);
+  const dim3 cgrid(R, static_cast<unsigned>(batch));
+#define SGL_LAUNCH_FAST(IN_)                                                                                                               \
+  do {                                                                                                                                     \
+    const IN_* x = static_cast<const IN_*>(logits);                                                                                        \
+    if (G * J <= 8)                                                                                                                        \
+      hipLaunchKernelGGL((sample_logit_candidates_kernel<IN_, 8>), cgrid, dim3(kSplitThreads), 0, as_stream(stream), x, logits_row_stride, \
+                         temperatures, static_cast<int>(vocab), num_splits, G, J, top_ks, ws);                                             \
+    else                                                                                                                                   \
+      hipLaunchKernelGGL((sample_logit_candidates_kernel<IN_, kFastSlots>), cgrid, dim3(kSplitThreads), 0, as_stream(stream), x,           \
+                         logits_row_stride, temperatures, static_cast<int>(vocab), num_splits, G, J, top_ks, ws);                          \
+    hipLaunchKernelGGL(sample_finish_fast_kernel<IN_>, dim3(batch), dim3(kT), 0, as_stream(stream), p, x, logits_row_stride, temperatures,  \
+                       num_splits, R, ws);                                                                                                 \
+  } while (0)
+  if (logits_is_bf16) SGL_LAUNCH_FAST(uint16_t);
+  else SGL_LAUNCH_FAST(float);
+#undef SGL_LAUNCH_FAST
   SGL_CHECK_LAUNCH("top_k_top_p_min_p_sample_from_logits");
   return 0;
 }

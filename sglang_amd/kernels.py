@@ -578,21 +578,26 @@ def top_k_top_p_min_p_sample(probs: torch.Tensor, top_ks: Optional[torch.Tensor]
     return (ids, n_keep) if return_n_keep else ids
 
 
-def sample_from_bf16_logits(logits: torch.Tensor, temperatures: torch.Tensor, top_ks: Optional[torch.Tensor],
-                            top_ps: Optional[torch.Tensor], min_ps: Optional[torch.Tensor], sampling_seed: Optional[torch.Tensor],
-                            positions: Optional[torch.Tensor], return_n_keep: bool = False, return_fallback: bool = False):
-    """sampler.py:211-260 for the bf16 logits of a decode-sized batch in one native call: softmax(logits / T) + the filtered
-    sampler, the probabilities never written (sampling_topk.hip: candidates / finish, + two launches that redo flagged rows the
-    long way).  Same ids and kept counts as softmax_temperature_from_bf16 + top_k_top_p_min_p_sample.  None when the shape is not
-    that case (the caller takes the two calls)."""
+def sample_from_logits(logits: torch.Tensor, temperatures: torch.Tensor, top_ks: Optional[torch.Tensor],
+                       top_ps: Optional[torch.Tensor], min_ps: Optional[torch.Tensor], sampling_seed: Optional[torch.Tensor],
+                       positions: Optional[torch.Tensor], return_n_keep: bool = False, return_fallback: bool = False):
+    """sampler.py:211-260 for the logits of a decode-sized batch -- bf16 (the model's dtype) or fp32 (what the reference's
+    LogitsProcessor hands its Sampler) -- in one native call: softmax(logits / T) + the filtered sampler, the probabilities never
+    written and the logits left as they are (sampling_topk.hip: candidates / finish; rows the candidates cannot decide are redone
+    from their full probability row inside the finish launch).  Same ids and kept counts as softmax_temperature_{,from_bf16} +
+    top_k_top_p_min_p_sample.  None when the shape is not that case (the caller takes the two calls)."""
     _dev(logits, temperatures)
-    if logits.dtype != _BF16 or logits.dim() != 2 or logits.stride(1) != 1:
+    if logits.dtype not in (_BF16, torch.float32) or logits.dim() != 2 or logits.stride(1) != 1:
         return None
     B, V = logits.shape
     t = temperatures.reshape(-1)
+    bf = logits.dtype == _BF16
     splits = min(64, 2048 // max(1, B))            # the softmax's own range count: the partials are its partials
-    if not (B and splits >= 2 and (splits <= 16 or splits % 16 == 0) and V >= 4096 * splits // 8 and logits.data_ptr() % 8 == 0
-            and logits.stride(0) % 4 == 0 and B <= 65535 and t.dtype == torch.float32 and t.numel() == B and t.is_contiguous()):
+    per = ((V + splits - 1) // max(1, splits) + 3) // 4 * 4
+    groups = splits // 16 if (splits >= 16 and splits % 16 == 0) else 1
+    if not (B and splits >= 2 and (splits <= 16 or splits % 16 == 0) and V >= 4096 * splits // 8 and groups * ((per + 1023) // 1024) <= 16
+            and logits.data_ptr() % (8 if bf else 16) == 0 and logits.stride(0) % 4 == 0 and B <= 65535
+            and t.dtype == torch.float32 and t.numel() == B and t.is_contiguous()):
         return None
     dev = logits.device
     if sampling_seed is None:
@@ -610,22 +615,26 @@ def sample_from_bf16_logits(logits: torch.Tensor, temperatures: torch.Tensor, to
     ws = _sample_workspace(B, V, dev)
     key = ("from_logits", B, V, splits, str(dev))
     fast = _SAMPLE_WS.get(key)
+    nbytes = native.lib().sgl_amd_sample_from_logits_workspace_bytes(B, splits)
     if fast is None:
-        nbytes = native.lib().sgl_amd_sample_from_logits_workspace_bytes(B, splits)
         # (the probability scratch is only touched for rows redone the long way; kept with the workspace, not allocated per call)
         fast = _SAMPLE_WS[key] = (torch.empty(nbytes // 8 + 2, dtype=torch.int64, device=dev),
                                   torch.empty((B, V + (-V) % 4), dtype=torch.float32, device=dev))
     wf, scratch = fast
-    native.call("sgl_amd_top_k_top_p_min_p_sample_from_logits", logits.data_ptr(), logits.stride(0), t.data_ptr(), scratch.data_ptr(),
-                scratch.stride(0), B, V, _ptr(top_ks), _ptr(top_ps), _ptr(min_ps), seeds.data_ptr(), _ptr(positions), ids.data_ptr(),
-                _ptr(ws[0]), _ptr(ws[1]), _ptr(n_keep), splits, wf.data_ptr(), _stream())
+    native.call("sgl_amd_top_k_top_p_min_p_sample_from_logits", logits.data_ptr(), 1 if bf else 0, logits.stride(0), t.data_ptr(),
+                scratch.data_ptr(), scratch.stride(0), B, V, _ptr(top_ks), _ptr(top_ps), _ptr(min_ps), seeds.data_ptr(), _ptr(positions),
+                ids.data_ptr(), _ptr(ws[0]), _ptr(ws[1]), _ptr(n_keep), splits, wf.data_ptr(), _stream())
     out = (ids,)
     if return_n_keep:
         out += (n_keep,)
     if return_fallback:
-        nbytes = native.lib().sgl_amd_sample_from_logits_workspace_bytes(B, splits)
         out += (wf.view(torch.int32)[nbytes // 4 - B: nbytes // 4].clone(),)
     return out[0] if len(out) == 1 else out
+
+
+def sample_from_bf16_logits(logits: torch.Tensor, *args, **kwargs):
+    """sample_from_logits for bf16 logits only (None otherwise)."""
+    return sample_from_logits(logits, *args, **kwargs) if logits.dtype == _BF16 else None
 
 
 def _renorm(probs: torch.Tensor, top_k, top_p) -> torch.Tensor:

@@ -83,13 +83,15 @@ class Sampler(nn.Module):
                                         or sampling_info.need_min_p_sampling)
             probs = ids = None
             min_ps = sampling_info.min_ps if sampling_info.need_min_p_sampling else None
-            if logits.dtype == torch.bfloat16 and not return_logprob:
-                # bf16 logits of a decode-sized batch.  Filtered sampling: ONE native call, the probabilities are never written;
-                # otherwise the logits are widened inside the softmax launches (exact; no separate pass)
+            if not return_logprob:
+                # The logits of a decode-sized batch (bf16, or the fp32 the reference's LogitsProcessor hands over), no logprobs asked
+                # for.  Filtered sampling: ONE native call, the probabilities are never written (and the logits not overwritten with
+                # them: sampler.py:216 does that in place, nothing downstream reads them without return_logprob); otherwise bf16
+                # logits are widened inside the softmax launches (exact; no separate pass)
                 if not simple_sampling_case:
-                    ids = kernels.sample_from_bf16_logits(logits, sampling_info.temperatures, sampling_info.top_ks,
-                                                          sampling_info.top_ps, min_ps, sampling_info.sampling_seed, positions)
-                if ids is None:
+                    ids = kernels.sample_from_logits(logits, sampling_info.temperatures, sampling_info.top_ks, sampling_info.top_ps,
+                                                     min_ps, sampling_info.sampling_seed, positions)
+                if ids is None and logits.dtype == torch.bfloat16:
                     probs = kernels.softmax_temperature_from_bf16(logits, sampling_info.temperatures)
             if ids is None:
                 if probs is None:

@@ -231,20 +231,29 @@ def test_sampling_straight_from_bf16_logits_equals_softmax_then_sample(device, V
     pos = torch.randint(0, 4096, (B,), generator=g)
     d = lambda x: x.to(device)
     if K.softmax_temperature_from_bf16(d(lg), d(temps)) is None:
-        assert K.sample_from_bf16_logits(d(lg), d(temps), d(top_ks), d(top_ps), None, d(seeds), d(pos)) is None
+        assert K.sample_from_logits(d(lg), d(temps), d(top_ks), d(top_ps), None, d(seeds), d(pos)) is None
         return
     for mp in (None, d(min_ps)):
         probs = K.softmax_temperature_from_bf16(d(lg), d(temps))
         want, want_n = K.top_k_top_p_min_p_sample(probs, d(top_ks), d(top_ps), mp, d(seeds), d(pos), return_n_keep=True)
-        got, got_n, fb = K.sample_from_bf16_logits(d(lg), d(temps), d(top_ks), d(top_ps), mp, d(seeds), d(pos), return_n_keep=True,
-                                                   return_fallback=True)
-        fb = fb.cpu().tolist()
-        assert got_n.cpu().tolist() == want_n.cpu().tolist(), (mp is not None, fb)
-        assert got.cpu().tolist() == want.cpu().tolist(), (mp is not None, fb)
-        for r in range(B):
-            if r not in special and 1 <= int(top_ks[r]) <= 64 and float(scale[r]) >= 1.0:
-                assert fb[r] == 0, (r, fb)
-        assert all(fb[r] == 1 for r in range(B) if int(top_ks[r]) == 0)
+        for src in (d(lg), d(lg).float()):               # bf16 logits; the same values as fp32 (the reference's LogitsProcessor widens them)
+            before = src.clone()
+            got, got_n, fb = K.sample_from_logits(src, d(temps), d(top_ks), d(top_ps), mp, d(seeds), d(pos), return_n_keep=True,
+                                                  return_fallback=True)
+            fb = fb.cpu().tolist()
+            assert torch.equal(src, before)                 # the logits are read, never overwritten
+            assert got_n.cpu().tolist() == want_n.cpu().tolist(), (mp is not None, str(src.dtype), fb)
+            assert got.cpu().tolist() == want.cpu().tolist(), (mp is not None, str(src.dtype), fb)
+            for r in range(B):
+                if r not in special and 1 <= int(top_ks[r]) <= 64 and float(scale[r]) >= 1.0:
+                    assert fb[r] == 0, (r, fb)
+            assert all(fb[r] == 1 for r in range(B) if int(top_ks[r]) == 0)
+    # genuine fp32 logits (low mantissa bits in use): against the fp32 softmax + sample
+    lf = (d(lg).float() + d(torch.randn((B, V), generator=g)) * 1e-3).contiguous()
+    probs = K.softmax_temperature_(lf.clone(), d(temps))
+    want, want_n = K.top_k_top_p_min_p_sample(probs, d(top_ks), d(top_ps), None, d(seeds), d(pos), return_n_keep=True)
+    got, got_n = K.sample_from_logits(lf, d(temps), d(top_ks), d(top_ps), None, d(seeds), d(pos), return_n_keep=True)
+    assert got_n.cpu().tolist() == want_n.cpu().tolist() and got.cpu().tolist() == want.cpu().tolist()
     # the split rule of the softmax it shares its partials with; other range counts have no short way
     assert K.sample_from_bf16_logits(d(lg[:1, :4096].contiguous()), d(temps[:1]), d(top_ks[:1]), d(top_ps[:1]), None, d(seeds[:1]),
                                      d(pos[:1])) is None or V < 4096 * 8
