@@ -54,6 +54,10 @@ class LogitsProcessorOutput:
     next_token_token_ids_logprobs_idx: Optional[List] = None
 
 
+# which route the non-greedy batches of this process took (tests / telemetry: tests/golden/ref_model.py reports it)
+served = {"one_call_from_logits": 0, "softmax_then_sample": 0}
+
+
 class Sampler(nn.Module):
     """sampler.py:71-300.  Dtypes follow the reference: greedy ids are int64 (torch.argmax, :139), sampled ids
     int32 (sampling_from_probs_torch / the torch top-k/top-p path).  Unseeded sampling draws one fresh 62-bit seed
@@ -91,6 +95,7 @@ class Sampler(nn.Module):
                 if not simple_sampling_case:
                     ids = kernels.sample_from_logits(logits, sampling_info.temperatures, sampling_info.top_ks, sampling_info.top_ps,
                                                      min_ps, sampling_info.sampling_seed, positions)
+                    served["one_call_from_logits" if ids is not None else "softmax_then_sample"] += 1
                 if ids is None and logits.dtype == torch.bfloat16:
                     probs = kernels.softmax_temperature_from_bf16(logits, sampling_info.temperatures)
             if ids is None:

@@ -1522,7 +1522,9 @@ def run_scheduler_job(dims_name="tiny_v16k", groups=2, per_group=2, prefix=16, u
                     if row is None:
                         continue
                     total += 1
-                    inside += int(int(tok) in set(row.topk(min(k_, V)).indices.tolist()))
+                    # (a token TIED with the k-th largest logit is inside: at a 128 K vocabulary bf16 logits tie at rank k often, and
+                    # which of the tied tokens a descending sort puts first is the sort's business -- the reference's torch.sort is not stable)
+                    inside += int(float(row[int(tok)]) >= float(row.topk(min(k_, V)).values[-1]))
             rep["sampling"] = dict(params=sampling, tokens_checked=total, tokens_inside_their_rows_top_k=inside,
                                    distinct_first_tokens=len(set(tuple(v[:2]) for v in timed["generated"].values())))
         if logprobs:
@@ -1852,9 +1854,9 @@ def _install_spec_standins(ns) -> None:
 def _plugin_counts() -> dict:
     """What the plug-in's own counters saw in this process (whole process: warm-up + timed job + capture)."""
     from sglang_amd import mem_hooks, tuning
-    from sglang_amd.layers import layernorm
+    from sglang_amd.layers import layernorm, sampler
 
-    return dict(mem_hooks=dict(mem_hooks.counts), rmsnorm=dict(layernorm.served), gemm_selections=tuning.STATUS)
+    return dict(mem_hooks=dict(mem_hooks.counts), rmsnorm=dict(layernorm.served), gemm_selections=tuning.STATUS, sampler=dict(sampler.served))
 
 
 def _count_triton_launches() -> list:

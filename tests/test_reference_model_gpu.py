@@ -329,7 +329,7 @@ def _spec_logit_bars(sp, dense: bool) -> None:
 
 
 @pytest.mark.parametrize("config", ["eager", "small-graph", "fp8-kv", "qwen2", "no-radix", "tp2", "spec-mixtral", "spec-paged", "long-shared",
-                                    "long-shared-paged", "sampling"])
+                                    "long-shared-paged", "sampling", "sampling-wide-vocab"])
 def test_plugin_under_the_references_scheduler_more_configurations(device, config):
     """Configurations of the reference's scheduler (overlap loop) beyond the seven of test_plugin_under_the_references_scheduler, added
     in round 5 after two of them exposed defects: no decode graphs at all; graphs for 2 requests with 6 running (replays and eager
@@ -340,7 +340,9 @@ def test_plugin_under_the_references_scheduler_more_configurations(device, confi
     sharing 160 tokens over 48 decode steps at page sizes 1 and 16 (the shared-prefix decode plan finds a >= 128-token group under
     the reference's tables, contexts cross chunk boundaries; 384 logit rows in the band); every request SAMPLING (temperature 0.8,
     top-k 20, top-p 0.9 through the scheduler's SamplingBatchInfo: each delivered token lies in the top-k set of the logits row it was
-    sampled from, the rows -- teacher-forced with the sampled tokens -- in the band)."""
+    sampled from, the rows -- teacher-forced with the sampled tokens -- in the band); the same at Llama-3-8B's width and vocabulary
+    (two layers), where the scheduler's fp32 [4, 128256] logits take the one-call sampler that never writes the probabilities
+    (round 6)."""
     import ref_model
 
     if ref_model.ref_root() is None:
@@ -355,7 +357,9 @@ def test_plugin_under_the_references_scheduler_more_configurations(device, confi
              "spec-paged": ["--spec-ngram", "4", "--job", "2,2,32,16,12", "--server-args", '{"page_size": 16, "speculative_ngram_max_bfs_breadth": 1}'],
              "long-shared": ["--job", "2,4,160,40,48"],
              "long-shared-paged": ["--job", "2,4,160,40,48", "--server-args", '{"page_size": 16}'],
-             "sampling": ["--job", "2,2,16,8,8", "--sampling", '{"temperature": 0.8, "top_k": 20, "top_p": 0.9}']}[config]
+             "sampling": ["--job", "2,2,16,8,8", "--sampling", '{"temperature": 0.8, "top_k": 20, "top_p": 0.9}'],
+             "sampling-wide-vocab": ["--dims", "llama3_8b_2layers", "--job", "2,2,16,8,8", "--sampling",
+                                     '{"temperature": 0.8, "top_k": 20, "top_p": 0.9}']}[config]
     out = ROOT / "gpurun_out" / f"reference_model_scheduler_more_{config}.json"
     p = subprocess.run([sys.executable, str(ROOT / "tests" / "golden" / "ref_model.py"), "--run", "scheduler", "--overlap", "--json", str(out)] + extra,
                        cwd=ROOT, env=dict(os.environ, SGLANG_USE_AITER="0"), capture_output=True, text=True, timeout=600)
@@ -364,7 +368,7 @@ def test_plugin_under_the_references_scheduler_more_configurations(device, confi
     spec = config.startswith("spec")
     assert rep["attn_backend_class"] == "HipAttnBackend" and rep["kv_pool_class"] == "Mi355xMHATokenToKVPool"
     n_req, n_out = {"small-graph": (6, 6), "spec-mixtral": (4, 10), "spec-paged": (4, 12), "long-shared": (8, 48), "long-shared-paged": (8, 48),
-                    "sampling": (4, 8)}.get(config, (4, 4))
+                    "sampling": (4, 8), "sampling-wide-vocab": (4, 8)}.get(config, (4, 4))
     for job in (rep["warm_up"], rep["timed"]):
         assert job["finished_requests"] == n_req and job["tokens_per_request"] == [n_out], job
     if config == "eager":
@@ -389,9 +393,12 @@ def test_plugin_under_the_references_scheduler_more_configurations(device, confi
     assert lb["product_rms_err"] <= 1.25 * lb["reference_rms_err"] + 1e-4, lb
     assert lb["product_max_err"] <= 2.0 * lb["reference_max_err"] + 1e-3, lb
     assert lb["argmax_agree_on_clear_rows"] == lb["clear_rows"], lb
-    if config == "sampling":
+    if config.startswith("sampling"):
         sm = rep["sampling"]
         assert sm["tokens_checked"] == sm["tokens_inside_their_rows_top_k"] == n_req * n_out and sm["distinct_first_tokens"] >= 2, sm
+        routes = rep["plugin_counts"]["sampler"]
+        if config == "sampling-wide-vocab":
+            assert routes["one_call_from_logits"] >= n_out - 1 and routes["softmax_then_sample"] == 0, routes
         return
     if config.startswith("long-shared"):
         assert rep["timed"]["cached_tokens_of_others"] == [160]
